@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the RNN-T hot path on MI355X.
+
+Workload `rnnt_loss_M1` (BASELINE.json metric): RNN-T loss fwd+bwd through
+the drop-in `warp_rnnt.RNNTLoss.apply(...).sum().backward()` on a (B=32, T=1000, U=50, V=5000)
+fp32 log-prob lattice, inputs resident in HBM, dense gradient produced.  One "step" = one batch
+of B utterances per GPU.  N>1: one process per GPU (torch.distributed, RCCL), utterances are
+independent so ranks shard them with no data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_inputs(B, T, U, V, dev, seed):
+    """SURVEY 8d M1 inputs: log_softmax(randn) built utterance by utterance (no 2x temp)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lp = torch.empty((B, T, U + 1, V), dtype=torch.float32, device=dev)
+    for n in range(B):
+        lp[n].normal_(generator=g)
+        lp[n] = torch.log_softmax(lp[n], dim=-1)
+    gl = torch.Generator(device=dev)
+    gl.manual_seed(seed + 1)
+    labels = torch.randint(1, V, (B, U), generator=gl, device=dev, dtype=torch.int32)
+    tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ul = torch.full((B,), U, dtype=torch.int32, device=dev)
+    return lp, labels, tl, ul
+
+
+def cpu_baseline(lp, labels, tl, ul, n_utts, min_seconds=10.0):
+    """Reference-side CPU leg: the oracle's fp32 OpenMP port on a bounded sample of the SAME
+    workload (first n_utts utterances), timed on this box's host cores.  Checker only."""
+    from oracle import rnnt as O
+    O.build()
+    x = lp[:n_utts].cpu().numpy()
+    y = labels[:n_utts].cpu().numpy()
+    t_ = tl[:n_utts].cpu().numpy()
+    u_ = ul[:n_utts].cpu().numpy()
+    O.rnnt_loss(x[:1], y[:1], t_[:1], u_[:1], dtype=np.float32)  # page in
+    done, t0 = 0, time.perf_counter()
+    while True:
+        costs, grads = O.rnnt_loss(x, y, t_, u_, dtype=np.float32)
+        done += n_utts
+        el = time.perf_counter() - t0
+        if el >= min_seconds or done >= 8 * n_utts:
+            break
+    return {"value": done / el, "unit": "utterances/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "%d utterances of the same (T=%d,U=%d,V=%d) batch, oracle fp32 C/OpenMP port "
+                      "(costs + dense grads), %.1f s" % (done, x.shape[1], x.shape[2] - 1,
+                                                       x.shape[3], el)}, costs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--labels", type=int, default=50)
+    ap.add_argument("--vocab", type=int, default=5000)
+    ap.add_argument("--cpu-utts", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from warp_rnnt import RNNTLoss  # the drop-in import the reference scripts use
+    from pika_amd import rnnt as R
+
+    B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    lp, labels, tl, ul = make_inputs(B, T, U, V, dev, 1234 + 100 * rank)
+    lp.requires_grad_(True)
+    loss_fn = RNNTLoss(blank=0, reduction="sum").apply
+
+    def step():
+        lp.grad = None
+        costs = loss_fn(lp, labels, tl, ul)
+        costs.sum().backward()
+        return costs
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    R.KERNEL_EVENTS = {"fwd": [], "bwd": []}  # HIP events on the launch stream, per C-ABI call
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        costs = step()
+    barrier()
+    el = time.perf_counter() - t0
+    ev = R.KERNEL_EVENTS
+    R.KERNEL_EVENTS = None
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        ms_step = el / args.steps * 1e3
+        value = B * world / (el / args.steps)
+        bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]]))
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
+        cells = T * (U + 1)
+        bytes_per_utt = cells * V * 4 + 2 * cells * 4 + 4 * cells * 4
+        achieved = bytes_per_utt * B / (bwd_ms * 1e-3) / 1e9
+        # measured ceiling for a pure write stream of the same size (hipMemsetAsync)
+        gbuf = lp.grad
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            gbuf.zero_()
+        e1.record()
+        torch.cuda.synchronize()
+        fill_gbps = gbuf.numel() * 4 * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "rnnt_grad_pmc.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "utterances/sec RNNT fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
+            "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rnnt_loss_M1: warp_rnnt.RNNTLoss.apply(...).sum().backward() on "
+                                   "log_softmax(randn) (B,T,U+1,V) fp32, dense grad out",
+                       "batch_per_gpu": B, "T": T, "U": U, "V": V, "global_batch": B * world,
+                       "parallelism": "utterance-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "rnnt_grad_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "bytes_per_launch": bytes_per_utt * B,
+                         "kernel_ms": bwd_ms, "forward_ms": fwd_ms,
+                         "measured_fill_GBps": fill_gbps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, c_cpu = cpu_baseline(lp.detach(), labels, tl, ul, min(args.cpu_utts, B))
+            out["cpu_baseline"] = cb
+            c_gpu = costs.detach()[:len(c_cpu)].cpu().numpy()
+            out["cpu_baseline"]["max_rel_cost_diff_vs_gpu"] = float(
+                np.max(np.abs(c_gpu - c_cpu) / np.abs(c_cpu)))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+/*
+ * include/pika_rnnt.h -- C ABI of the MI355X-native RNN-T loss (libpika_amd.so).
+ *
+ * Replaces, for PIKA's RNN-T training path, the third-party `warp_rnnt` CUDA
+ * extension that the reference binds at
+ *   /root/reference/trainer/train_transducer_bmuf_otfaug.py:25,58,97-99
+ *   /root/reference/trainer/train_transducer_mbr_bmuf_otfaug.py:23,64,157-159
+ * (`RNNTLoss(blank=0, reduction='sum').apply(log_probs, labels, frames_lengths,
+ *   labels_lengths)` -> per-utterance costs, differentiable w.r.t. log_probs).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory
+ *     owned by the caller; the library never allocates or frees device memory;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and is stream-ordered: nothing synchronises the host;
+ *   - thread-safe per stream (no global mutable state);
+ *   - return value: 0 on success, a negative PIKA_E* code for bad arguments,
+ *     a positive hipError_t value if a launch failed.
+ *
+ * Tensor contract:
+ *   log_probs      f32 (B,T,U1,V) contiguous, already log-softmaxed
+ *   labels         i32 (B,U1-1)   entries >= labels_lengths[n] are padding and never read
+ *   frames_lengths i32 (B,)       T_n, clamped on device to [1,T]
+ *   labels_lengths i32 (B,)       U_n, clamped on device to [0,U1-1]
+ *   costs          f32 (B,)       -log P(y_n | x_n)
+ *   grads          f32 (B,T,U1,V) d(sum_n grad_costs[n]*cost_n)/d log_probs, DENSE:
+ *                                 every element is written (zeros included), so the
+ *                                 caller may hand over uninitialised memory.
+ */
+#ifndef PIKA_RNNT_H
+#define PIKA_RNNT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIKA_OK 0
+#define PIKA_EINVAL (-1)   /* null pointer / non-positive dimension / blank out of range */
+#define PIKA_ETOOBIG (-2)  /* U1 > 1024 (one workgroup spans the label axis) */
+
+/* Library/ABI version, bumped on any signature change. */
+int pika_amd_abi_version(void);
+
+/* Bytes of device scratch `workspace` needed by the calls below for a (B,T,U1)
+ * lattice batch.  Layout (DESIGN.md "RNNT loss / HBM layout"): four skewed
+ * f32 planes [B][T+U1-1][W] (W = workgroup width covering U1, a multiple of 64) (blank log-prob, emit log-prob, alpha,
+ * beta) + per-utterance log-likelihoods. */
+size_t pika_rnnt_workspace_bytes(int B, int T, int U1);
+
+/* Forward: gathers the two log-probs each lattice cell needs, runs the alpha and
+ * beta anti-diagonal recurrences (one wavefront per direction per utterance),
+ * writes costs[B] and leaves the lattice in `workspace` for the backward call. */
+int pika_rnnt_loss_forward(const float *log_probs, const int *labels,
+                           const int *frames_lengths, const int *labels_lengths,
+                           int B, int T, int U1, int V, int blank,
+                           float *costs, void *workspace, void *stream);
+
+/* Backward: one streaming pass that writes the dense gradient tensor.
+ * `grad_costs` (B,) f32 scales utterance n's gradient (autograd's grad_output);
+ * NULL means all ones.  `workspace` must be the buffer filled by the matching
+ * forward call (same B,T,U1 and lengths). */
+int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths,
+                            const int *labels_lengths,
+                            int B, int T, int U1, int V, int blank,
+                            const float *grad_costs, const void *workspace,
+                            float *grads, void *stream);
+
+/* warp_rnnt-shaped one-shot: forward + backward with unit grad_costs. */
+int pika_rnnt_loss_fwd_bwd(const float *log_probs, const int *labels,
+                           const int *frames_lengths, const int *labels_lengths,
+                           int B, int T, int U1, int V, int blank,
+                           float *costs, float *grads, void *workspace, void *stream);
+
+/* Test/diagnostic hook: un-skews the lattice held in `workspace` into dense
+ * (B,T,U1) f32 planes (invalid cells = -1e30).  Either output may be NULL. */
+int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
+                             const int *labels_lengths, int B, int T, int U1,
+                             float *alphas, float *betas, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_RNNT_H */

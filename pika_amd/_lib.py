@@ -1,0 +1,51 @@
+"""ctypes binding of the C ABI declared in include/*.h (libpika_amd.so).
+
+Fails loudly: a missing library is an ImportError-grade RuntimeError, never a fallback.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
+ABI_VERSION = 1
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pika_rnnt.h one to one
+SIGNATURES = {
+    "pika_amd_abi_version": (_i, []),
+    "pika_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pika_rnnt_loss_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pika_rnnt_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pika_rnnt_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pika_rnnt_export_lattice": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpika_amd.so once (torch must be imported first so that both share one HIP runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "pika_amd: %s is missing -- run `python -m pika_amd.build` (or "
+                "__graft_entry__.build()); there is no CPU/PyTorch fallback." % LIB_PATH)
+        import torch  # noqa: F401  (loads libamdhip64 with the SONAME our library links to)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        got = handle.pika_amd_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError("pika_amd: ABI version %d != expected %d; rebuild" % (got, ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "bad argument" if rc < 0 else "hipError_t"
+        raise RuntimeError("pika_amd: %s failed (%s %d)" % (what, kind, rc))

@@ -1,0 +1,55 @@
+"""In-tree build of libpika_amd.so: ``hipcc --offload-arch=gfx950`` on every csrc/*.hip.
+
+No cmake, no JIT cache: the .so sits next to the package so it travels with the repo
+snapshot to the GPU box (``*.so`` is git-ignored, not gpurun-ignored).
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(PKG, "libpika_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile each .hip to an object (cached by mtime) and link the shared library."""
+    objdir = os.path.join(PKG, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = glob.glob(os.path.join(INCLUDE, "*.h")) + glob.glob(os.path.join(CSRC, "*.h")) \
+        + glob.glob(os.path.join(CSRC, "*.hpp"))
+    objs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if force or _stale(obj, [src] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

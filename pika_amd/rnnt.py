@@ -1,0 +1,156 @@
+"""Host side of the RNN-T loss: mirrors the `warp_rnnt` surface PIKA imports.
+
+Reference call site (trainer/train_transducer_bmuf_otfaug.py:58,97-99):
+
+    transducer_loss = RNNTLoss(blank=0, reduction='sum').apply
+    loss = transducer_loss(outputs, target_batch.int(), len_batch, ali_lens)
+    loss = loss.sum()
+
+so `RNNTLoss(...)` must be constructible with keyword arguments and expose `.apply(log_probs,
+labels, frames_lengths, labels_lengths)` returning per-utterance costs (B,) that the caller
+sums (and in the MBR script pre-multiplies by a float, train_transducer_mbr_bmuf_otfaug.py:157).
+
+MI355X-first split: forward runs only gather + alpha/beta (~0.1 ms) and keeps the lattice in a
+34 MB workspace; the dense (B,T,U1,V) gradient is written ONCE, in backward, already scaled
+by autograd's grad_output -- warp_rnnt instead materialises it in forward and multiplies it
+again in backward (3 extra passes over 32 GB at the benchmark shape).
+"""
+import torch
+
+from . import _lib
+
+
+# bench.py hook: when set to {"fwd": [], "bwd": []}, every C-ABI call is bracketed by HIP events
+# recorded on the launch stream (torch's current stream) so kernel time is measured live.
+KERNEL_EVENTS = None
+
+
+class _timed(object):
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.e1.record()
+            KERNEL_EVENTS[self.key].append((self.e0, self.e1))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_inputs(log_probs, labels, frames_lengths, labels_lengths, blank):
+    # same argument checks, same exception types as the reference binding's Python wrapper
+    if not log_probs.is_cuda:
+        raise RuntimeError("pika_amd RNNTLoss: log_probs must live on a HIP device "
+                           "(there is no CPU path; the CPU checker lives in oracle/ for tests only)")
+    if log_probs.dtype != torch.float32:
+        raise TypeError("log_probs must be float32, got %s" % log_probs.dtype)
+    for name, t in (("labels", labels), ("frames_lengths", frames_lengths),
+                    ("labels_lengths", labels_lengths)):
+        if t.dtype != torch.int32:
+            raise TypeError("%s must be int32, got %s" % (name, t.dtype))
+        if t.device != log_probs.device:
+            raise RuntimeError("%s is on %s but log_probs is on %s" % (name, t.device, log_probs.device))
+    if log_probs.dim() != 4:
+        raise ValueError("log_probs must be (B,T,U+1,V), got %s" % (tuple(log_probs.shape),))
+    B, T, U1, V = log_probs.shape
+    if labels.dim() != 2 or labels.shape[0] != B or labels.shape[1] != U1 - 1:
+        raise ValueError("labels must be (B,U)=(%d,%d), got %s" % (B, U1 - 1, tuple(labels.shape)))
+    if frames_lengths.shape != (B,) or labels_lengths.shape != (B,):
+        raise ValueError("frames_lengths / labels_lengths must be (B,)")
+    if not 0 <= blank < V:
+        raise ValueError("blank=%d outside [0,%d)" % (blank, V))
+    if U1 > 1024:
+        raise ValueError("U+1=%d > 1024 not supported" % U1)
+
+
+class _RNNTLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0):
+        _check_inputs(log_probs, labels, frames_lengths, labels_lengths, blank)
+        lib = _lib.lib()
+        lp = log_probs.contiguous()
+        labels = labels.contiguous()
+        frames_lengths = frames_lengths.contiguous()
+        labels_lengths = labels_lengths.contiguous()
+        B, T, U1, V = lp.shape
+        with torch.cuda.device(lp.device):
+            costs = torch.empty(B, dtype=torch.float32, device=lp.device)
+            ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8,
+                             device=lp.device)
+            with _timed("fwd"):
+                _lib.check(lib.pika_rnnt_loss_forward(
+                    _ptr(lp), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths),
+                    B, T, U1, V, blank, _ptr(costs), _ptr(ws), _stream()), "pika_rnnt_loss_forward")
+        ctx.save_for_backward(labels, frames_lengths, labels_lengths, ws)
+        ctx.dims = (B, T, U1, V, blank)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        labels, frames_lengths, labels_lengths, ws = ctx.saved_tensors
+        B, T, U1, V, blank = ctx.dims
+        lib = _lib.lib()
+        gc = grad_costs.to(torch.float32).contiguous()
+        with torch.cuda.device(ws.device):
+            grads = torch.empty((B, T, U1, V), dtype=torch.float32, device=ws.device)
+            with _timed("bwd"):
+                _lib.check(lib.pika_rnnt_loss_backward(
+                    _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
+                    _ptr(gc), _ptr(ws), _ptr(grads), _stream()), "pika_rnnt_loss_backward")
+        return grads, None, None, None, None
+
+
+def rnnt_loss(log_probs, labels, frames_lengths, labels_lengths, average_frames=False,
+              reduction=None, blank=0):
+    """Functional form (same keyword surface as warp_rnnt.rnnt_loss)."""
+    costs = _RNNTLossFn.apply(log_probs, labels, frames_lengths, labels_lengths, blank)
+    if average_frames:
+        costs = costs / frames_lengths.to(costs)
+    if reduction == "sum":
+        return costs.sum()
+    if reduction == "mean":
+        return costs.mean()
+    if reduction in (None, "none"):
+        return costs
+    raise ValueError("Unknown reduction: %r" % (reduction,))
+
+
+class RNNTLoss(object):
+    """`RNNTLoss(blank=0, reduction='sum').apply(...)` exactly as the reference scripts use it.
+
+    As with the binding the reference imports, constructor keywords other than `blank` do not
+    change what `.apply` returns: per-utterance costs (B,), which the caller reduces itself
+    (train_transducer_bmuf_otfaug.py:99 `loss = loss.sum()`).
+    """
+
+    def __init__(self, blank=0, reduction="sum", **unused):
+        self.blank = int(blank)
+        self.reduction = reduction
+
+    def apply(self, log_probs, labels, frames_lengths, labels_lengths):
+        return _RNNTLossFn.apply(log_probs, labels, frames_lengths, labels_lengths, self.blank)
+
+    __call__ = apply
+
+
+def export_lattice(ctx_ws, frames_lengths, labels_lengths, B, T, U1):
+    """Diagnostic: dense (B,T,U1) alpha/beta from a workspace tensor (tests only)."""
+    lib = _lib.lib()
+    a = torch.empty((B, T, U1), dtype=torch.float32, device=ctx_ws.device)
+    b = torch.empty_like(a)
+    _lib.check(lib.pika_rnnt_export_lattice(_ptr(ctx_ws), _ptr(frames_lengths), _ptr(labels_lengths),
+                                            B, T, U1, _ptr(a), _ptr(b), _stream()),
+               "pika_rnnt_export_lattice")
+    return a, b

@@ -1,0 +1,177 @@
+"""GPU parity tests of the HIP RNN-T loss against the CPU oracle, through the C ABI
+(pika_amd.rnnt -> ctypes -> libpika_amd.so).  Tolerances: costs 1e-5 rel vs the fp64 oracle
+(north_star budget: 1e-3 rel fp32); gradients abs 2e-5 on small lattices (values are
+probabilities in [0,1]); on the full-size lattice the fp32 log-space budget is that of the
+fp32 oracle itself (alpha magnitudes ~1e4 -> ulp 1e-3), stated in the test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnnt as O
+from helpers import make_case
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnt_loss_small.npz")
+
+
+def run_hip(dev, lp, y, tl, ul, blank=0, grad_out=None, want_lattice=False):
+    from pika_amd import rnnt as R
+    x = torch.from_numpy(lp).to(dev).requires_grad_(True)
+    args = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (y, tl, ul)]
+    costs = R.RNNTLoss(blank=blank, reduction="sum").apply(x, *args)
+    lattice = None
+    if want_lattice:
+        ws = costs.grad_fn.saved_tensors[3]
+        a, b = R.export_lattice(ws, args[1], args[2], *lp.shape[:3])
+        lattice = (a.cpu().numpy(), b.cpu().numpy())
+    if grad_out is None:
+        costs.sum().backward()
+    else:
+        costs.backward(torch.from_numpy(grad_out).to(dev))
+    torch.cuda.synchronize()
+    out = (costs.detach().cpu().numpy(), x.grad.cpu().numpy())
+    return out + (lattice,) if want_lattice else out
+
+
+def test_native_library_is_loaded(hip_device):
+    from pika_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libpika_amd.so" in maps
+
+
+def test_golden_fixture(hip_device):
+    z = np.load(GOLD)
+    c, g, (a, b) = run_hip(hip_device, z["log_probs"], z["labels"], z["frames_lengths"],
+                           z["labels_lengths"], want_lattice=True)
+    assert np.allclose(c, z["costs"], rtol=1e-5)
+    assert np.allclose(c, z["brute_force_costs"], rtol=1e-5)
+    assert np.abs(g - z["grads"]).max() < 2e-5
+    valid = np.isfinite(z["alphas"])
+    assert np.abs(a[valid] - z["alphas"][valid]).max() < 1e-4
+    assert np.abs(b[valid] - z["betas"][valid]).max() < 1e-4
+    assert np.all(a[~valid] <= -1e29) and np.all(b[~valid] <= -1e29)
+
+
+@pytest.mark.parametrize("B,T,U,V,ragged,seed", [
+    (1, 1, 0, 4, False, 0),        # single cell: cost = -lp[0,0,blank]
+    (2, 1, 3, 8, False, 1),        # one frame
+    (2, 5, 0, 8, False, 2),        # no labels (U1 = 1)
+    (3, 7, 5, 12, True, 3),
+    (4, 33, 17, 40, True, 4),
+    (2, 50, 63, 16, True, 5),      # U1 = 64: exactly one full wavefront
+    (2, 40, 64, 16, True, 6),      # U1 = 65: two-wave workgroup path (LDS edge exchange)
+    (2, 30, 130, 12, True, 7),     # U1 = 131: three waves
+    (1, 20, 300, 8, True, 8),      # U1 = 301: six-wave variant (width 384)
+    (3, 25, 9, 13, True, 9),       # V % 4 != 0: scalar-store gradient path
+    (3, 25, 9, 6, True, 10),       # V % 4 != 0, rows not 16-byte aligned
+    (5, 64, 20, 100, True, 11),    # BASELINE.json configs[0] vocabulary
+])
+def test_matches_fp64_oracle(hip_device, B, T, U, V, ragged, seed):
+    lp, y, tl, ul = make_case(B, T, U, V, seed, ragged=ragged)
+    c64, g64, a64, b64 = O.rnnt_loss(lp, y, tl, ul, want_lattice=True)
+    c, g, (a, b) = run_hip(hip_device, lp, y, tl, ul, want_lattice=True)
+    assert np.allclose(c, c64, rtol=1e-5, atol=1e-5), (c, c64)
+    assert np.abs(g - g64).max() < 2e-5
+    valid = np.isfinite(a64)
+    assert np.abs(a[valid] - a64[valid]).max() < 1e-3 * max(1.0, np.abs(a64[valid]).max() * 1e-2)
+    assert np.abs(b[valid] - b64[valid]).max() < 1e-3 * max(1.0, np.abs(b64[valid]).max() * 1e-2)
+    # structure: exact zeros everywhere except blank / next-label entries of valid cells
+    nz = g != 0
+    assert nz.sum() <= int(((tl.astype(np.int64)) * (ul + 1) * 2).sum())
+    for n in range(B):
+        assert not nz[n, tl[n]:].any() and not nz[n, :, ul[n] + 1:].any()
+
+
+def test_nonzero_blank_index(hip_device):
+    lp, y, tl, ul = make_case(3, 12, 6, 10, 21, ragged=True, blank=7)
+    c64, g64 = O.rnnt_loss(lp, y, tl, ul, blank=7)
+    c, g = run_hip(hip_device, lp, y, tl, ul, blank=7)
+    assert np.allclose(c, c64, rtol=1e-5) and np.abs(g - g64).max() < 2e-5
+
+
+def test_label_equal_to_blank_follows_oracle_order(hip_device):
+    lp, y, tl, ul = make_case(2, 6, 4, 8, 22)
+    y[0, 1] = 0  # a label that collides with blank: the emit term overwrites the blank term
+    c64, g64 = O.rnnt_loss(lp, y, tl, ul)
+    c, g = run_hip(hip_device, lp, y, tl, ul)
+    assert np.allclose(c, c64, rtol=1e-5) and np.abs(g - g64).max() < 2e-5
+
+
+def test_grad_output_scaling_and_mbr_style_prescale(hip_device):
+    lp, y, tl, ul = make_case(4, 10, 5, 16, 23, ragged=True)
+    w = np.array([0.5, -2.0, 0.0, 3.25], np.float32)
+    _, g64 = O.rnnt_loss(lp, y, tl, ul)
+    _, g = run_hip(hip_device, lp, y, tl, ul, grad_out=w)
+    assert np.abs(g - g64 * w[:, None, None, None]).max() < 1e-4
+    assert np.all(g[2] == 0)
+    # train_transducer_mbr_bmuf_otfaug.py:157 style: python float * loss, then .sum().backward()
+    from pika_amd.rnnt import RNNTLoss
+    x = torch.from_numpy(lp).to(hip_device).requires_grad_(True)
+    loss = 0.1 * RNNTLoss(blank=0, reduction="sum").apply(
+        x, *[torch.from_numpy(a).to(hip_device) for a in (y, tl, ul)])
+    loss.sum().backward()
+    assert np.abs(x.grad.cpu().numpy() - 0.1 * g64).max() < 2e-5
+
+
+def test_padding_labels_never_read_and_noncontiguous_input(hip_device):
+    lp, y, tl, ul = make_case(3, 9, 6, 12, 24, ragged=True)
+    y2 = y.copy()
+    for n in range(3):
+        y2[n, ul[n]:] = 2 ** 30
+    c1, g1 = run_hip(hip_device, lp, y, tl, ul)
+    c2, g2 = run_hip(hip_device, lp, y2, tl, ul)
+    assert np.array_equal(c1, c2) and np.array_equal(g1, g2)
+    # expanded / permuted views are made contiguous by the op, like the reference binding
+    from pika_amd.rnnt import RNNTLoss
+    x = torch.from_numpy(lp).to(hip_device).permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    assert not x.is_contiguous()
+    c3 = RNNTLoss().apply(x, *[torch.from_numpy(a).to(hip_device) for a in (y, tl, ul)])
+    assert np.array_equal(c3.cpu().numpy(), c1)
+
+
+def test_minus_inf_log_probs_do_not_poison(hip_device):
+    lp, y, tl, ul = make_case(2, 6, 3, 8, 25)
+    lp[0, 2, 1, 5] = -np.inf        # an entry no path uses
+    lp[1, 1, 1, 0] = -np.inf        # a blank transition some paths use
+    c64, g64 = O.rnnt_loss(lp, y, tl, ul)
+    c, g = run_hip(hip_device, lp, y, tl, ul)
+    assert np.all(np.isfinite(c)) and np.allclose(c, c64, rtol=1e-5)
+    assert np.abs(g - g64).max() < 2e-5
+
+
+def test_argument_errors_mirror_binding(hip_device):
+    from pika_amd.rnnt import RNNTLoss
+    lp, y, tl, ul = make_case(2, 4, 2, 5, 26)
+    d = hip_device
+    t = lambda a: torch.from_numpy(a).to(d)
+    with pytest.raises(TypeError):
+        RNNTLoss().apply(t(lp).double(), t(y), t(tl), t(ul))
+    with pytest.raises(TypeError):
+        RNNTLoss().apply(t(lp), t(y).long(), t(tl), t(ul))
+    with pytest.raises(ValueError):
+        RNNTLoss().apply(t(lp), t(y)[:, :1], t(tl), t(ul))
+    with pytest.raises(RuntimeError):
+        RNNTLoss().apply(t(lp), torch.from_numpy(y), t(tl), t(ul))
+
+
+def test_full_size_lattice_properties_and_sampled_parity(hip_device):
+    """BASELINE.json shape (T=1000,U=50,V=5000) at B=2: fp64 oracle on the same inputs plus
+    size-independent properties (diagonal occupancy = 1, total mass = T+U, alpha/beta ll agree)."""
+    B, T, U, V = 2, 1000, 50, 5000
+    lp, y, tl, ul = make_case(B, T, U, V, 1234)
+    tl[1], ul[1] = 777, 31
+    y[1, 31:] = V
+    c64, g64 = O.rnnt_loss(lp, y, tl, ul)
+    c, g = run_hip(hip_device, lp, y, tl, ul)
+    assert np.allclose(c, c64, rtol=1e-5), (c, c64)
+    # fp32 log-space budget: |alpha| ~ 9e3 -> ulp 1e-3; exponent error ~ few 1e-2 worst case
+    c32, g32 = O.rnnt_loss(lp, y, tl, ul, dtype=np.float32)
+    budget = max(3 * np.abs(g32 - g64).max(), 5e-3)
+    assert np.abs(g - g64).max() < budget, (np.abs(g - g64).max(), budget)
+    for n in range(B):
+        assert abs(-g[n].astype(np.float64).sum() - (tl[n] + ul[n])) < 0.02 * (tl[n] + ul[n])
+        assert not (g[n, tl[n]:] != 0).any() and not (g[n, :, ul[n] + 1:] != 0).any()
+    assert (g != 0).sum() <= int((tl.astype(np.int64) * (ul + 1) * 2).sum())
