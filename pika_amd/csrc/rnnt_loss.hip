@@ -2,26 +2,32 @@
 //
 // Replaces the third-party `warp_rnnt` CUDA loss the reference calls at
 //   /root/reference/trainer/train_transducer_bmuf_otfaug.py:58,97-99
-// (SURVEY.md 8a row 10).  This is a from-scratch CDNA4 design, not a hipify:
+// (SURVEY.md 8a row 10).  From-scratch CDNA4 design, not a hipify:
 //
-//   gather   : one thread per lattice cell pulls the TWO log-probs the cell needs
-//              (blank, next label) out of the (B,T,U1,V) tensor into two compact
-//              planes stored SKEWED: element (t,u) lives at [t+u][u], so every
-//              anti-diagonal of the lattice is one contiguous 256-byte row.
-//   alpha/beta: one 64-lane wavefront per utterance and direction walks the
-//              anti-diagonals; lane = u, the neighbour term moves one lane with a
-//              single DPP wave-shift (no LDS, no barrier), log-probs for the next
-//              8 diagonals are prefetched into registers while the current 8 are
-//              consumed (the recurrence is latency-bound, T+U-1 dependent steps).
-//              U1 > 64 falls back to one workgroup of pad64(U1) threads with an
-//              LDS exchange per diagonal.
-//   grad     : the HBM-bound part -- one streaming pass that writes the dense
-//              (B,T,U1,V) gradient exactly once: a wave owns whole V-rows, 16-byte
-//              stores, the two non-zeros of a row are blended into the zero
-//              stream in registers (no memset + scatter, no read of log_probs).
+//   gather    : one thread per lattice cell pulls the TWO log-probs the cell needs (blank, next
+//               label) out of the (B,T,U1,V) tensor into two compact planes stored SKEWED:
+//               cell (t,u) lives at [t+u][u], so every anti-diagonal is one contiguous row.
+//   alpha/beta: one 64-lane wavefront per utterance and direction walks the anti-diagonals;
+//               lane = u, the neighbour term moves one lane with a single DPP wave-shift (no
+//               LDS, no barrier); log-probs of the next 8 diagonals are prefetched into
+//               registers while the current 8 are consumed (the recurrence is latency-bound).
+//               Every 16 diagonals the wave subtracts its running maximum and accumulates it
+//               in fp64 ("offsets"), so the fp32 lattice values stay O(100) however long the
+//               utterance is -- the absolute error of a plain fp32 log-space lattice grows
+//               with |alpha| ~ T (ulp(9000) = 1e-3 at the benchmark shape).
+//               U1 > 64: one workgroup of up to 16 waves, LDS hand-off at the wave edges.
+//   rowmeta   : per lattice cell, the two non-zero gradient values (fp64 offset arithmetic,
+//               scaled by autograd's grad_output) + the label index, 16 bytes per cell.
+//   grad      : THE HBM-bound kernel -- one flat, address-ordered streaming pass that writes the
+//               dense (B,T,U1,V) gradient exactly once with 16-byte stores in 1 KiB-aligned
+//               wave transactions; each 16-byte group looks up its row's rowmeta and blends
+//               the non-zeros in registers (no memset + scatter, log_probs is not re-read).
+//               Measured on MI355X: row-structured writers (a wave or a workgroup per 20 kB
+//               V-row) reach only 3.5-4.7 TB/s because rows start on non-128-byte boundaries;
+//               the flat form runs at the hipMemsetAsync rate (5.7-5.9 TB/s).
 //
-// Algorithmic HBM bytes per utterance (T=1000,U1=51,V=5000): 1.020 GB gradient
-// write + ~1.2 MB lattice traffic; see DESIGN.md.
+// Algorithmic HBM bytes per utterance (T=1000,U1=51,V=5000): 1.020 GB gradient write + ~1.2 MB
+// lattice traffic; see DESIGN.md.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,15 +37,17 @@
 
 namespace {
 
-constexpr float NEG = -1.0e30f;  // "log zero": finite so NEG+NEG and NEG-NEG never make NaN
-constexpr int WAVE = 64;
+constexpr float NEG = -1.0e30f;  // "log zero": finite, so NEG+NEG / NEG-NEG never make NaN
+constexpr float NEG_HALF = -0.5e30f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr int UNR = 8;     // diagonals prefetched per register batch
+constexpr int RENORM = 16; // diagonals between renormalisations (multiple of UNR)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Width (in lanes) of one skewed lattice row = threads of the alpha/beta workgroup:
-// the smallest instantiated wave count that covers U1 label columns.
+// Width (in lanes) of one skewed lattice row = threads of the alpha/beta workgroup: the
+// smallest instantiated wave count that covers U1 label columns.
 inline int lattice_width(int U1) {
     static const int kWaves[] = {1, 2, 3, 4, 6, 8, 12, 16};
     for (int nw : kWaves)
@@ -47,13 +55,23 @@ inline int lattice_width(int U1) {
     return 0;
 }
 
+struct RowMeta {  // 16 bytes per lattice cell
+    float gb;     // gradient at [.., blank]
+    float ge;     // gradient at [.., ye]
+    int ye;       // next label, -1 if the cell emits none
+    int pad;
+};
+
 struct Lattice {
     float *lpb;    // [B][D][Wp] blank log-prob of cell (t,u) at row t+u, col u
     float *lpe;    // [B][D][Wp] log-prob of emitting y_{u+1} from cell (t,u)
-    float *alpha;  // [B][D][Wp]
-    float *beta;   // [B][D][Wp]
-    float *ll;     // [B] log-likelihood from beta[0,0]
-    float *ll_a;   // [B] log-likelihood from the alpha side (diagnostic)
+    float *alpha;  // [B][D][Wp] alpha minus off_a[b][row]
+    float *beta;   // [B][D][Wp] beta  minus off_b[b][row]
+    double *off_a; // [B][D]
+    double *off_b; // [B][D]
+    double *ll;    // [B] log-likelihood, beta side
+    double *ll_a;  // [B] log-likelihood, alpha side (diagnostic)
+    RowMeta *meta; // [B*T*U1]
     int Wp, D;
 };
 
@@ -64,16 +82,27 @@ inline size_t plane_elems(int B, int T, int U1) {
 inline Lattice carve(void *ws, int B, int T, int U1) {
     Lattice L;
     const size_t n = plane_elems(B, T, U1);
+    L.Wp = lattice_width(U1);
+    L.D = T + U1 - 1;
     float *p = static_cast<float *>(ws);
     L.lpb = p;
     L.lpe = p + n;
     L.alpha = p + 2 * n;
     L.beta = p + 3 * n;
-    L.ll = p + 4 * n;
+    double *q = reinterpret_cast<double *>(p + 4 * n);  // n is a multiple of 64: 8-byte aligned
+    L.off_a = q;
+    L.off_b = q + (size_t)B * L.D;
+    L.ll = q + 2 * (size_t)B * L.D;
     L.ll_a = L.ll + B;
-    L.Wp = lattice_width(U1);
-    L.D = T + U1 - 1;
+    L.meta = reinterpret_cast<RowMeta *>(L.ll_a + B);  // 2BD+2B doubles: 16-byte aligned
     return L;
+}
+
+inline size_t workspace_bytes(int B, int T, int U1) {
+    const size_t D = (size_t)(T + U1 - 1);
+    return 4 * plane_elems(B, T, U1) * sizeof(float) +
+           (2 * (size_t)B * D + 2 * (size_t)B) * sizeof(double) +
+           (size_t)B * T * U1 * sizeof(RowMeta);
 }
 
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -85,15 +114,25 @@ __device__ inline float lae(float x, float y) {
     return m + LN2 * __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(d * LOG2E));
 }
 
-// lane i <- lane i-1 across the whole 64-lane wave (DPP wave_shr:1); lane 0 <- fill.
-__device__ inline float wave_shr1(float v, float fill) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v),
-                                                      0x138, 0xf, 0xf, false));
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ inline float dpp(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL,
+                                                      ROW_MASK, 0xf, false));
 }
+// lane i <- lane i-1 across the whole 64-lane wave (DPP wave_shr:1); lane 0 <- fill.
+__device__ inline float wave_shr1(float v, float fill) { return dpp<0x138>(v, fill); }
 // lane i <- lane i+1 (DPP wave_shl:1); lane 63 <- fill.
-__device__ inline float wave_shl1(float v, float fill) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v),
-                                                      0x130, 0xf, 0xf, false));
+__device__ inline float wave_shl1(float v, float fill) { return dpp<0x130>(v, fill); }
+
+// max over the 64 lanes, broadcast (row_shr 1/2/4/8 + row_bcast 15/31, then readlane 63).
+__device__ inline float wave_max(float v) {
+    v = fmaxf(v, dpp<0x111>(v, NEG));
+    v = fmaxf(v, dpp<0x112>(v, NEG));
+    v = fmaxf(v, dpp<0x114>(v, NEG));
+    v = fmaxf(v, dpp<0x118>(v, NEG));
+    v = fmaxf(v, dpp<0x142, 0xa>(v, NEG));
+    v = fmaxf(v, dpp<0x143, 0xc>(v, NEG));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -125,21 +164,22 @@ __global__ __launch_bounds__(256) void rnnt_gather_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // alpha / beta recurrences.  grid = (2, B): blockIdx.x 0 = alpha, 1 = beta.
-// block = NW*64 threads = pad64(U1); thread u owns lattice column u.
+// block = NW*64 threads = lattice_width(U1); thread u owns lattice column u.
 // ---------------------------------------------------------------------------------------------
 template <int NW>
-struct Shift {
+struct Xchg {
     // NW == 1: pure DPP.  NW > 1: DPP inside a wave + LDS hand-off at wave edges.
-    float *edge;  // [2][NW+1]
+    float *edge;  // [2][NW+1], edge[.][0] and edge[.][NW] stay NEG
+    float *red;   // [2][NW]
     __device__ inline float up(float v, int step) const {  // thread u <- thread u-1
         if constexpr (NW == 1) {
             return wave_shr1(v, NEG);
         } else {
             const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
             float *e = edge + (step & 1) * (NW + 1);
-            if (l == 63) e[w + 1] = v;
+            if (l == 63 && w + 1 < NW) e[w + 1] = v;
             __syncthreads();
-            return wave_shr1(v, e[w]);  // e[0] preset to NEG
+            return wave_shr1(v, e[w]);
         }
     }
     __device__ inline float down(float v, int step) const {  // thread u <- thread u+1
@@ -148,25 +188,34 @@ struct Shift {
         } else {
             const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
             float *e = edge + (step & 1) * (NW + 1);
-            if (l == 0) e[w] = v;
+            if (l == 0 && w > 0) e[w] = v;
             __syncthreads();
-            return wave_shl1(v, e[w + 1]);  // e[NW] preset to NEG
+            return wave_shl1(v, e[w + 1]);
         }
     }
+    __device__ inline float max_all(float v, int step) const {  // workgroup-wide max
+        float m = wave_max(v);
+        if constexpr (NW > 1) {
+            float *r = red + ((step / RENORM) & 1) * NW;
+            if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = m;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) m = fmaxf(m, r[w]);
+        }
+        return m;
+    }
 };
-
-constexpr int UNR = 8;  // diagonals prefetched per register batch
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void rnnt_alpha_beta_kernel(
     const float *__restrict__ lpb_, const float *__restrict__ lpe_, float *__restrict__ alpha_,
-    float *__restrict__ beta_, const int *__restrict__ Tn_, const int *__restrict__ Un_,
-    float *__restrict__ ll_, float *__restrict__ ll_a_, float *__restrict__ costs, int T, int U1,
-    int Wp, int D) {
-    __shared__ float edge_buf[2 * (NW + 1)];
-    Shift<NW> sh{edge_buf};
+    float *__restrict__ beta_, double *__restrict__ off_a_, double *__restrict__ off_b_,
+    const int *__restrict__ Tn_, const int *__restrict__ Un_, double *__restrict__ ll_,
+    double *__restrict__ ll_a_, float *__restrict__ costs, int T, int U1, int Wp, int D) {
+    __shared__ float lds[2 * (NW + 1) + 2 * NW];
+    Xchg<NW> xc{lds, lds + 2 * (NW + 1)};
     if constexpr (NW > 1) {
-        if (threadIdx.x < 2 * (NW + 1)) edge_buf[threadIdx.x] = NEG;
+        if (threadIdx.x < 2 * (NW + 1) + 2 * NW) lds[threadIdx.x] = NEG;
         __syncthreads();
     }
     const int b = blockIdx.y;
@@ -181,12 +230,15 @@ __global__ __launch_bounds__(NW * 64) void rnnt_alpha_beta_kernel(
     auto inside = [&](int d) { const int t = d - u; return t >= 0 && t < Tn && u <= Un; };
 
     float pbv[2][UNR], pev[2][UNR];
+    double off = 0.0;  // sum of subtracted maxima (identical in every thread)
 
     if (blockIdx.x == 0) {
         // ----- alpha: A_d[u] = lae(A_{d-1}[u] + lpb_{d-1}[u], A_{d-1}[u-1] + lpe_{d-1}[u-1]) -----
         float *alpha = alpha_ + base;
+        double *offs = off_a_ + (size_t)b * D;
         float a = (u == 0) ? 0.0f : NEG;
         alpha[0] = a;
+        if (u == 0) offs[0] = 0.0;
         auto load = [&](int buf, int d0) {  // rows d0-1 .. d0+UNR-2
 #pragma unroll
             for (int i = 0; i < UNR; ++i) {
@@ -203,9 +255,15 @@ __global__ __launch_bounds__(NW * 64) void rnnt_alpha_beta_kernel(
                 const int d = d0 + i;
                 if (d <= dend) {  // workgroup-uniform
                     const float x = a + pbv[buf][i];
-                    const float y = sh.up(a + pev[buf][i], d);
+                    const float y = xc.up(a + pev[buf][i], d);
                     a = inside(d) ? lae(x, y) : NEG;
+                    if ((d0 + i) % RENORM == 0) {  // d0 = 1 (mod UNR): compile-time per i
+                        const float m = xc.max_all(a, d);
+                        a = a > NEG_HALF ? a - m : NEG;
+                        off += (double)m;
+                    }
                     alpha[(size_t)d * Wp] = a;
+                    if (u == 0) offs[d] = off;
                 }
             }
         };
@@ -216,10 +274,11 @@ __global__ __launch_bounds__(NW * 64) void rnnt_alpha_beta_kernel(
             load(0, d0 + 2 * UNR);
             steps(1, d0 + UNR);
         }
-        if (u == Un) ll_a_[b] = a + fmaxf(lpb[(size_t)dend * Wp], NEG);
+        if (u == Un) ll_a_[b] = (double)a + off + (double)fmaxf(lpb[(size_t)dend * Wp], NEG);
     } else {
         // ----- beta: B_d[u] = lae(B_{d+1}[u] + lpb_d[u], B_{d+1}[u+1] + lpe_d[u]) -----
         float *beta = beta_ + base;
+        double *offs = off_b_ + (size_t)b * D;
         float bt = NEG;
         auto load = [&](int buf, int d0) {  // rows d0, d0-1, ..., d0-UNR+1
 #pragma unroll
@@ -231,21 +290,29 @@ __global__ __launch_bounds__(NW * 64) void rnnt_alpha_beta_kernel(
                 pev[buf][i] = ok ? ve : 0.0f;
             }
         };
+        int k = 0;  // steps taken, for the renormalisation cadence
         auto steps = [&](int buf, int d0) {
 #pragma unroll
             for (int i = 0; i < UNR; ++i) {
                 const int d = d0 - i;
                 if (d >= 0) {
                     const int t = d - u;
-                    const float dn = sh.down(bt, d);
+                    const float dn = xc.down(bt, d);
                     const float x = bt + pbv[buf][i];
                     const float y = dn + pev[buf][i];
                     float nb = lae(x, y);
                     if (t == Tn - 1 && u == Un) nb = pbv[buf][i];  // terminal blank
                     bt = inside(d) ? nb : NEG;
+                    if (i == UNR - 1 && (k & (RENORM / UNR - 1)) == RENORM / UNR - 1) {
+                        const float m = xc.max_all(bt, k * UNR);
+                        bt = bt > NEG_HALF ? bt - m : NEG;
+                        off += (double)m;
+                    }
                     beta[(size_t)d * Wp] = bt;
+                    if (u == 0) offs[d] = off;
                 }
             }
+            ++k;
         };
         load(0, dend);
         for (int d0 = dend; d0 >= 0; d0 -= 2 * UNR) {
@@ -255,105 +322,144 @@ __global__ __launch_bounds__(NW * 64) void rnnt_alpha_beta_kernel(
             steps(1, d0 - UNR);
         }
         if (u == 0) {
-            ll_[b] = bt;
-            costs[b] = -bt;
+            const double ll = (double)bt + off;
+            ll_[b] = ll;
+            costs[b] = (float)(-ll);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// grad: dense (B,T,U1,V) gradient, written once.  A wave takes RPT consecutive V-rows per task:
-// lanes 0..RPT-1 compute the two non-zeros of "their" row with vector ops, then the wave streams
-// each row with 16-byte stores, the row's scalars broadcast by v_readlane.
+// rowmeta: the two non-zeros of every V-row of the gradient
 // ---------------------------------------------------------------------------------------------
-constexpr int RPT = 16;
-
-template <bool VEC4, bool NT>
-__global__ __launch_bounds__(256) void rnnt_grad_kernel(
+__global__ __launch_bounds__(256) void rnnt_rowmeta_kernel(
     const int *__restrict__ labels, const int *__restrict__ Tn_, const int *__restrict__ Un_,
-    int B, int T, int U1, int V, int blank, const float *__restrict__ grad_costs,
+    int B, int T, int U1, int V, const float *__restrict__ grad_costs,
     const float *__restrict__ lpb, const float *__restrict__ lpe, const float *__restrict__ alpha,
-    const float *__restrict__ beta, const float *__restrict__ ll, int Wp, int D,
-    float *__restrict__ grads) {
-    const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const float *__restrict__ beta, const double *__restrict__ off_a,
+    const double *__restrict__ off_b, const double *__restrict__ ll, int Wp, int D,
+    RowMeta *__restrict__ meta) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nrows = (long)B * T * U1;
-    const long ntasks = (nrows + RPT - 1) / RPT;
+    if (row >= nrows) return;
+    float gb = 0.f, ge = 0.f;
+    int ye = -1;
+    const int u = (int)(row % U1);
+    const int t = (int)((row / U1) % T);
+    const int b = (int)(row / ((long)U1 * T));
+    const int Tn = clampi(Tn_[b], 1, T), Un = clampi(Un_[b], 0, U1 - 1);
+    if (t < Tn && u <= Un) {
+        const int d = t + u;
+        const size_t o = ((size_t)b * D + d) * Wp + u;
+        const float a = alpha[o];
+        const float sc = grad_costs ? grad_costs[b] : 1.0f;
+        const double base = off_a[(size_t)b * D + d] - ll[b];
+        // exponent = alpha + beta' + lp - ll, with the large parts cancelled in fp64
+        const float k1 = (d + 1 < D) ? (float)(base + off_b[(size_t)b * D + d + 1]) : 0.0f;
+        if (t < Tn - 1)
+            gb = -sc * __expf(k1 + (a + beta[o + Wp] + lpb[o]));
+        else if (u == Un)
+            gb = -sc * __expf((float)base + (a + lpb[o]));
+        if (u < Un) {
+            const int y = labels[(size_t)b * (U1 - 1) + u];
+            if (y >= 0 && y < V) {
+                ye = y;
+                ge = -sc * __expf(k1 + (a + beta[o + Wp + 1] + lpe[o]));
+            }
+        }
+    }
+    meta[row] = RowMeta{gb, ge, ye, 0};
+}
 
-    for (long task = wave; task < ntasks; task += nwaves) {
-        const long row0 = task * RPT;
-        float gb = 0.0f, ge = 0.0f;
-        int ye = -1;
-        const long row = row0 + lane;
-        if (lane < RPT && row < nrows) {
-            const int u = (int)(row % U1);
-            const int t = (int)((row / U1) % T);
-            const int b = (int)(row / ((long)U1 * T));
-            const int Tn = clampi(Tn_[b], 1, T), Un = clampi(Un_[b], 0, U1 - 1);
-            if (t < Tn && u <= Un) {
-                const size_t o = ((size_t)b * D + (t + u)) * Wp + u;
-                const float a = alpha[o], l = ll[b];
-                const float sc = grad_costs ? grad_costs[b] : 1.0f;
-                if (t < Tn - 1)
-                    gb = -sc * __expf(a + beta[o + Wp] + lpb[o] - l);
-                else if (u == Un)
-                    gb = -sc * __expf(a + lpb[o] - l);
-                if (u < Un) {
-                    const int y = labels[(size_t)b * (U1 - 1) + u];
-                    if (y >= 0 && y < V) {
-                        ye = y;
-                        ge = -sc * __expf(a + beta[o + Wp + 1] + lpe[o] - l);
-                    }
-                }
-            }
+// ---------------------------------------------------------------------------------------------
+// grad: flat streaming writer.  Thread -> PT 16-byte groups, 256 groups apart, so each wave
+// instruction stores one 1 KiB-aligned contiguous KiB and workgroups are dispatched in address
+// order.  A wave instruction (64 groups) spans at most two V-rows when V/4 >= 64, so both rows'
+// metadata arrive through the scalar cache (s_load) and the per-lane work is two compares.
+// Hardware A/B (tools/grad_sweep.hip, MI355X, 32.64 GB tensor): PT=2 + scalar metadata 4.65 ms
+// (7.0 TB/s) vs per-lane metadata PT=4 5.3 ms, hipMemsetAsync 5.1-5.5 ms, row-structured
+// writers 7-9 ms.
+// ---------------------------------------------------------------------------------------------
+__device__ inline v4f blend_row(int q, int qb, int cb, float gb, float ge, int ye) {
+    const int qe = ye >> 2, ce = ye & 3;  // ye = -1 -> qe = -1: never matches
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (q == qb) {
+        v.x = cb == 0 ? gb : 0.f; v.y = cb == 1 ? gb : 0.f;
+        v.z = cb == 2 ? gb : 0.f; v.w = cb == 3 ? gb : 0.f;
+    }
+    if (q == qe) {  // label wins if it equals blank (oracle order)
+        v.x = ce == 0 ? ge : v.x; v.y = ce == 1 ? ge : v.y;
+        v.z = ce == 2 ? ge : v.z; v.w = ce == 3 ? ge : v.w;
+    }
+    return v;
+}
+
+template <bool SCALAR_META, int PT>
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(const RowMeta *__restrict__ meta,
+                                                        size_t n4, size_t nrows, int V4, int blank,
+                                                        v4f *__restrict__ grads) {
+    const int qb = blank >> 2, cb = blank & 3;
+    if constexpr (SCALAR_META) {  // requires V4 >= 64
+        const int lane = threadIdx.x & 63;
+        // first group of this wave's first store (wave-uniform, made provably so)
+        size_t i0 = (size_t)blockIdx.x * (256 * PT) + (threadIdx.x & ~63);
+        i0 = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(i0 >> 32)) << 32) |
+             (unsigned)__builtin_amdgcn_readfirstlane((int)i0);
+        size_t row0 = i0 / (unsigned)V4;
+        int q0 = (int)(i0 - row0 * V4);
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const size_t i = i0 + lane;
+            const size_t r0 = row0 < nrows ? row0 : nrows - 1;
+            const size_t r1 = row0 + 1 < nrows ? row0 + 1 : nrows - 1;
+            const RowMeta m0 = meta[r0], m1 = meta[r1];  // scalar loads
+            int q = q0 + lane;
+            const bool second = q >= V4;
+            q = second ? q - V4 : q;
+            const v4f v = blend_row(q, qb, cb, second ? m1.gb : m0.gb, second ? m1.ge : m0.ge,
+                                    second ? m1.ye : m0.ye);
+            if (i < n4) grads[i] = v;
+            i0 += 256;
+            q0 += 256;
+            while (q0 >= V4) { q0 -= V4; ++row0; }
         }
-        const int nr = (int)min((long)RPT, nrows - row0);
-        for (int r = 0; r < nr; ++r) {
-            const float sgb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gb), r));
-            const float sge = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ge), r));
-            const int sye = __builtin_amdgcn_readlane(ye, r);
-            float *rowp = grads + (size_t)(row0 + r) * V;
-            if constexpr (VEC4) {
-                const int V4 = V >> 2;
-                const int qb = blank >> 2, cb = blank & 3;
-                const int qe = sye >> 2, ce = sye & 3;  // sye = -1 -> qe = -1: never matches
-                v4f *p = reinterpret_cast<v4f *>(rowp);
-                // the row's two non-zeros as whole 16-byte groups (scalar work, once per row)
-                v4f vb4 = {cb == 0 ? sgb : 0.f, cb == 1 ? sgb : 0.f, cb == 2 ? sgb : 0.f,
-                           cb == 3 ? sgb : 0.f};
-                v4f ve4 = {ce == 0 ? sge : 0.f, ce == 1 ? sge : 0.f, ce == 2 ? sge : 0.f,
-                           ce == 3 ? sge : 0.f};
-                if (qe == qb) {  // same group: label wins on a clash (oracle order)
-                    ve4.x = ce == 0 ? sge : vb4.x; ve4.y = ce == 1 ? sge : vb4.y;
-                    ve4.z = ce == 2 ? sge : vb4.z; ve4.w = ce == 3 ? sge : vb4.w;
-                }
-#pragma unroll 4
-                for (int q = lane; q < V4; q += WAVE) {
-                    v4f v = {0.f, 0.f, 0.f, 0.f};
-                    if (q == qb) v = vb4;
-                    if (q == qe) v = ve4;
-                    if constexpr (NT)
-                        __builtin_nontemporal_store(v, p + q);
-                    else
-                        p[q] = v;
-                }
-            } else {
-                for (int j = lane; j < V; j += WAVE) {
-                    float v = 0.0f;
-                    if (j == blank) v = sgb;
-                    if (j == sye) v = sge;
-                    rowp[j] = v;
-                }
+    } else {
+        size_t i = (size_t)blockIdx.x * (256 * PT) + threadIdx.x;
+        size_t row = i / (unsigned)V4;
+        int q = (int)(i - row * V4);
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            if (i < n4) {
+                const RowMeta m = meta[row];
+                grads[i] = blend_row(q, qb, cb, m.gb, m.ge, m.ye);
             }
+            i += 256;
+            q += 256;
+            while (q >= V4) { q -= V4; ++row; }
         }
+    }
+}
+
+// generic path (V % 4 != 0 or unaligned base): one float per thread-iteration
+__global__ __launch_bounds__(256) void rnnt_grad_scalar_kernel(const RowMeta *__restrict__ meta,
+                                                               size_t n, int V, int blank,
+                                                               float *__restrict__ grads) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t row = i / (unsigned)V;
+        const int j = (int)(i - row * V);
+        float v = 0.f;
+        const RowMeta m = meta[row];
+        if (j == blank) v = m.gb;
+        if (j == m.ye) v = m.ge;
+        grads[i] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void rnnt_export_kernel(
-    const float *__restrict__ alpha, const float *__restrict__ beta, const int *__restrict__ Tn_,
-    const int *__restrict__ Un_, int B, int T, int U1, int Wp, int D, float *__restrict__ out_a,
-    float *__restrict__ out_b) {
+    const float *__restrict__ alpha, const float *__restrict__ beta, const double *__restrict__ off_a,
+    const double *__restrict__ off_b, const int *__restrict__ Tn_, const int *__restrict__ Un_,
+    int B, int T, int U1, int Wp, int D, float *__restrict__ out_a, float *__restrict__ out_b) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * T * U1) return;
     const int u = (int)(idx % U1);
@@ -362,8 +468,8 @@ __global__ __launch_bounds__(256) void rnnt_export_kernel(
     const size_t o = ((size_t)b * D + (t + u)) * Wp + u;
     const int Tn = clampi(Tn_[b], 1, T), Un = clampi(Un_[b], 0, U1 - 1);
     const bool ok = t < Tn && u <= Un;
-    if (out_a) out_a[idx] = ok ? alpha[o] : NEG;
-    if (out_b) out_b[idx] = ok ? beta[o] : NEG;
+    if (out_a) out_a[idx] = ok ? (float)((double)alpha[o] + off_a[(size_t)b * D + t + u]) : NEG;
+    if (out_b) out_b[idx] = ok ? (float)((double)beta[o] + off_b[(size_t)b * D + t + u]) : NEG;
 }
 
 int check_dims(int B, int T, int U1, int V, int blank) {
@@ -376,23 +482,8 @@ template <int NW>
 void launch_ab(const Lattice &L, const int *Tn, const int *Un, float *costs, int B, int T, int U1,
                hipStream_t s) {
     hipLaunchKernelGGL((rnnt_alpha_beta_kernel<NW>), dim3(2, B), dim3(NW * 64), 0, s, L.lpb, L.lpe,
-                       L.alpha, L.beta, Tn, Un, L.ll, L.ll_a, costs, T, U1, L.Wp, L.D);
-}
-
-int grad_variant() {  // tuning hook (A/B on hardware): PIKA_RNNT_GRAD_NT=0 disables nontemporal stores
-    static const int v = [] {
-        const char *e = getenv("PIKA_RNNT_GRAD_NT");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
-}
-
-int grad_blocks() {
-    static const int v = [] {
-        const char *e = getenv("PIKA_RNNT_GRAD_BLOCKS");
-        return e ? atoi(e) : 2048;  // 256 CUs x 8 workgroups of 4 waves
-    }();
-    return v;
+                       L.alpha, L.beta, L.off_a, L.off_b, Tn, Un, L.ll, L.ll_a, costs, T, U1, L.Wp,
+                       L.D);
 }
 
 }  // namespace
@@ -403,7 +494,7 @@ int pika_amd_abi_version(void) { return 1; }
 
 size_t pika_rnnt_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024) return 0;
-    return (4 * plane_elems(B, T, U1) + 2 * (size_t)B) * sizeof(float);
+    return workspace_bytes(B, T, U1);
 }
 
 int pika_rnnt_loss_forward(const float *log_probs, const int *labels, const int *frames_lengths,
@@ -440,19 +531,31 @@ int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths, const 
     if (U1 > 1 && !labels) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+    const size_t nrows = (size_t)B * T * U1;
+    hipLaunchKernelGGL(rnnt_rowmeta_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s,
+                       labels, frames_lengths, labels_lengths, B, T, U1, V, grad_costs, L.lpb, L.lpe,
+                       L.alpha, L.beta, L.off_a, L.off_b, L.ll, L.Wp, L.D, L.meta);
+    const size_t n = nrows * (size_t)V;
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(grads) & 15) == 0);
-    const long ntasks = ((long)B * T * U1 + RPT - 1) / RPT;
-    const int blocks = (int)min((long)grad_blocks(), (ntasks + 3) / 4);
-#define PIKA_GRAD(VEC, NT)                                                                        \
-    hipLaunchKernelGGL((rnnt_grad_kernel<VEC, NT>), dim3(blocks), dim3(256), 0, s, labels,       \
-                       frames_lengths, labels_lengths, B, T, U1, V, blank, grad_costs, L.lpb,     \
-                       L.lpe, L.alpha, L.beta, L.ll, L.Wp, L.D, grads)
     if (vec4) {
-        if (grad_variant()) PIKA_GRAD(true, true); else PIKA_GRAD(true, false);
+        const size_t n4 = n / 4;
+        const int V4 = V / 4;
+        if (V4 >= 64) {
+            const size_t blocks = (n4 + 511) / 512;
+            if (blocks > 0x7fffffffu) return PIKA_ETOOBIG;
+            hipLaunchKernelGGL((rnnt_grad_kernel<true, 2>), dim3((unsigned)blocks), dim3(256), 0, s,
+                               L.meta, n4, nrows, V4, blank, reinterpret_cast<v4f *>(grads));
+        } else {
+            const size_t blocks = (n4 + 1023) / 1024;
+            if (blocks > 0x7fffffffu) return PIKA_ETOOBIG;
+            hipLaunchKernelGGL((rnnt_grad_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, s,
+                               L.meta, n4, nrows, V4, blank, reinterpret_cast<v4f *>(grads));
+        }
     } else {
-        PIKA_GRAD(false, false);
+        const size_t want = (n + 255) / 256;
+        hipLaunchKernelGGL(rnnt_grad_scalar_kernel, dim3((unsigned)(want < 65536 ? want : 65536)),
+                           dim3(256), 0, s, L.meta, n, V, blank, grads);
     }
-#undef PIKA_GRAD
     return (int)hipGetLastError();
 }
 
@@ -474,8 +577,8 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
     const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
     const size_t cells = (size_t)B * T * U1;
     hipLaunchKernelGGL(rnnt_export_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), L.alpha, L.beta, frames_lengths,
-                       labels_lengths, B, T, U1, L.Wp, L.D, alphas, betas);
+                       static_cast<hipStream_t>(stream), L.alpha, L.beta, L.off_a, L.off_b,
+                       frames_lengths, labels_lengths, B, T, U1, L.Wp, L.D, alphas, betas);
     return (int)hipGetLastError();
 }
 

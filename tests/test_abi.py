@@ -41,9 +41,14 @@ def test_ctypes_table_matches_headers():
 def test_workspace_size_formula():
     from pika_amd import _lib
     lib = _lib.lib()
-    # four skewed planes [B][T+U1-1][W] + 2*B floats; W = 64 for U1 <= 64
-    assert lib.pika_rnnt_workspace_bytes(32, 1000, 51) == (4 * 32 * 1050 * 64 + 64) * 4
-    assert lib.pika_rnnt_workspace_bytes(1, 10, 65) == (4 * 1 * 74 * 128 + 2) * 4
+    # four skewed f32 planes [B][D][W] (D = T+U1-1, W = 64 for U1 <= 64) + fp64 offsets
+    # [2][B][D] + ll [2][B] + 16 bytes of row metadata per lattice cell
+    def expect(B, T, U1, W):
+        D = T + U1 - 1
+        return 4 * B * D * W * 4 + (2 * B * D + 2 * B) * 8 + B * T * U1 * 16
+    assert lib.pika_rnnt_workspace_bytes(32, 1000, 51) == expect(32, 1000, 51, 64)
+    assert lib.pika_rnnt_workspace_bytes(1, 10, 65) == expect(1, 10, 65, 128)
+    assert lib.pika_rnnt_workspace_bytes(3, 7, 200) == expect(3, 7, 200, 256)
     assert lib.pika_rnnt_workspace_bytes(0, 10, 5) == 0
     assert lib.pika_rnnt_workspace_bytes(1, 10, 1025) == 0
 

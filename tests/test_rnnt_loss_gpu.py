@@ -1,8 +1,9 @@
 """GPU parity tests of the HIP RNN-T loss against the CPU oracle, through the C ABI
 (pika_amd.rnnt -> ctypes -> libpika_amd.so).  Tolerances: costs 1e-5 rel vs the fp64 oracle
-(north_star budget: 1e-3 rel fp32); gradients abs 2e-5 on small lattices (values are
-probabilities in [0,1]); on the full-size lattice the fp32 log-space budget is that of the
-fp32 oracle itself (alpha magnitudes ~1e4 -> ulp 1e-3), stated in the test."""
+(north_star budget: 1e-3 rel fp32); gradients |err| <= 1e-4*|g| + 1e-5 on small lattices (ten
+times tighter than the north_star budget; the residual is fp32 rounding of the three O(100)
+renormalised log terms in the exponent) and 1e-3 rel + 2e-5 abs on the full-size lattice."""
+
 import os
 
 import numpy as np
@@ -14,6 +15,13 @@ from helpers import make_case
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnt_loss_small.npz")
+
+
+def grads_close(g, g64, rel=1e-4, abs_=1e-5):
+    err = np.abs(g - g64)
+    bad = err > rel * np.abs(g64) + abs_
+    assert not bad.any(), "max excess %g (max abs err %g)" % (
+        float((err - rel * np.abs(g64)).max()), float(err.max()))
 
 
 def run_hip(dev, lp, y, tl, ul, blank=0, grad_out=None, want_lattice=False):
@@ -48,7 +56,7 @@ def test_golden_fixture(hip_device):
                            z["labels_lengths"], want_lattice=True)
     assert np.allclose(c, z["costs"], rtol=1e-5)
     assert np.allclose(c, z["brute_force_costs"], rtol=1e-5)
-    assert np.abs(g - z["grads"]).max() < 2e-5
+    grads_close(g, z["grads"])
     valid = np.isfinite(z["alphas"])
     assert np.abs(a[valid] - z["alphas"][valid]).max() < 1e-4
     assert np.abs(b[valid] - z["betas"][valid]).max() < 1e-4
@@ -68,13 +76,17 @@ def test_golden_fixture(hip_device):
     (3, 25, 9, 13, True, 9),       # V % 4 != 0: scalar-store gradient path
     (3, 25, 9, 6, True, 10),       # V % 4 != 0, rows not 16-byte aligned
     (5, 64, 20, 100, True, 11),    # BASELINE.json configs[0] vocabulary
+    (3, 9, 4, 256, True, 12),      # V/4 = 64: smallest vocabulary on the scalar-metadata writer
+    (2, 11, 6, 300, True, 13),     # V/4 = 75: wave stores straddle row boundaries
+    (2, 5, 3, 1024, False, 14),    # V/4 = 256: one row per workgroup store
+    (3, 7, 2, 5000, True, 15),     # benchmark vocabulary, tiny lattice
 ])
 def test_matches_fp64_oracle(hip_device, B, T, U, V, ragged, seed):
     lp, y, tl, ul = make_case(B, T, U, V, seed, ragged=ragged)
     c64, g64, a64, b64 = O.rnnt_loss(lp, y, tl, ul, want_lattice=True)
     c, g, (a, b) = run_hip(hip_device, lp, y, tl, ul, want_lattice=True)
     assert np.allclose(c, c64, rtol=1e-5, atol=1e-5), (c, c64)
-    assert np.abs(g - g64).max() < 2e-5
+    grads_close(g, g64)
     valid = np.isfinite(a64)
     assert np.abs(a[valid] - a64[valid]).max() < 1e-3 * max(1.0, np.abs(a64[valid]).max() * 1e-2)
     assert np.abs(b[valid] - b64[valid]).max() < 1e-3 * max(1.0, np.abs(b64[valid]).max() * 1e-2)
@@ -89,7 +101,8 @@ def test_nonzero_blank_index(hip_device):
     lp, y, tl, ul = make_case(3, 12, 6, 10, 21, ragged=True, blank=7)
     c64, g64 = O.rnnt_loss(lp, y, tl, ul, blank=7)
     c, g = run_hip(hip_device, lp, y, tl, ul, blank=7)
-    assert np.allclose(c, c64, rtol=1e-5) and np.abs(g - g64).max() < 2e-5
+    assert np.allclose(c, c64, rtol=1e-5)
+    grads_close(g, g64)
 
 
 def test_label_equal_to_blank_follows_oracle_order(hip_device):
@@ -97,7 +110,8 @@ def test_label_equal_to_blank_follows_oracle_order(hip_device):
     y[0, 1] = 0  # a label that collides with blank: the emit term overwrites the blank term
     c64, g64 = O.rnnt_loss(lp, y, tl, ul)
     c, g = run_hip(hip_device, lp, y, tl, ul)
-    assert np.allclose(c, c64, rtol=1e-5) and np.abs(g - g64).max() < 2e-5
+    assert np.allclose(c, c64, rtol=1e-5)
+    grads_close(g, g64)
 
 
 def test_grad_output_scaling_and_mbr_style_prescale(hip_device):
@@ -105,7 +119,7 @@ def test_grad_output_scaling_and_mbr_style_prescale(hip_device):
     w = np.array([0.5, -2.0, 0.0, 3.25], np.float32)
     _, g64 = O.rnnt_loss(lp, y, tl, ul)
     _, g = run_hip(hip_device, lp, y, tl, ul, grad_out=w)
-    assert np.abs(g - g64 * w[:, None, None, None]).max() < 1e-4
+    grads_close(g, g64 * w[:, None, None, None], abs_=4e-5)
     assert np.all(g[2] == 0)
     # train_transducer_mbr_bmuf_otfaug.py:157 style: python float * loss, then .sum().backward()
     from pika_amd.rnnt import RNNTLoss
@@ -113,7 +127,7 @@ def test_grad_output_scaling_and_mbr_style_prescale(hip_device):
     loss = 0.1 * RNNTLoss(blank=0, reduction="sum").apply(
         x, *[torch.from_numpy(a).to(hip_device) for a in (y, tl, ul)])
     loss.sum().backward()
-    assert np.abs(x.grad.cpu().numpy() - 0.1 * g64).max() < 2e-5
+    grads_close(x.grad.cpu().numpy(), 0.1 * g64)
 
 
 def test_padding_labels_never_read_and_noncontiguous_input(hip_device):
@@ -139,7 +153,7 @@ def test_minus_inf_log_probs_do_not_poison(hip_device):
     c64, g64 = O.rnnt_loss(lp, y, tl, ul)
     c, g = run_hip(hip_device, lp, y, tl, ul)
     assert np.all(np.isfinite(c)) and np.allclose(c, c64, rtol=1e-5)
-    assert np.abs(g - g64).max() < 2e-5
+    grads_close(g, g64)
 
 
 def test_argument_errors_mirror_binding(hip_device):
@@ -167,10 +181,11 @@ def test_full_size_lattice_properties_and_sampled_parity(hip_device):
     c64, g64 = O.rnnt_loss(lp, y, tl, ul)
     c, g = run_hip(hip_device, lp, y, tl, ul)
     assert np.allclose(c, c64, rtol=1e-5), (c, c64)
-    # fp32 log-space budget: |alpha| ~ 9e3 -> ulp 1e-3; exponent error ~ few 1e-2 worst case
-    c32, g32 = O.rnnt_loss(lp, y, tl, ul, dtype=np.float32)
-    budget = max(3 * np.abs(g32 - g64).max(), 5e-3)
-    assert np.abs(g - g64).max() < budget, (np.abs(g - g64).max(), budget)
+    # north_star tolerance: 1e-3 rel fp32 (+2e-5 abs floor).  A plain fp32 log-space lattice cannot
+    # meet it here (|alpha| ~ 9e3 -> ulp 1e-3 in the exponent; the fp32 oracle misses it); the HIP
+    # kernel renormalises every 16 diagonals with fp64 offsets and does.
+    err = np.abs(g - g64)
+    assert np.all(err <= 1e-3 * np.abs(g64) + 2e-5), float((err - 1e-3 * np.abs(g64)).max())
     for n in range(B):
         assert abs(-g[n].astype(np.float64).sum() - (tl[n] + ul[n])) < 0.02 * (tl[n] + ul[n])
         assert not (g[n, tl[n]:] != 0).any() and not (g[n, :, ul[n] + 1:] != 0).any()
