@@ -1,0 +1,42 @@
+/*
+ * include/pika_bmuf.h -- C ABI of the fused BMUF (block-momentum model averaging) kernels.
+ *
+ * Replaces the chain of PyTorch ops in the reference's
+ *   /root/reference/trainer/bmuf.py:76-100  (BmufTrainer.update_and_sync)
+ * and the per-parameter copy loop /root/reference/trainer/bmuf.py:14-35 (_copy_vec_to_param).
+ *
+ * MI355X formulation (DESIGN.md "BMUF"): parameters live as views of ONE flat fp32 vector
+ * `local` (no flatten/unflatten copies); every rank keeps `global` and `delta_prev`; the
+ * exchange is ONE all-reduce(SUM) of `delta` over RCCL/xGMI (host side, torch.distributed),
+ * bracketed by the two single-pass kernels below.
+ *
+ * Same conventions as pika_rnnt.h: device pointers owned by the caller, stream-ordered on
+ * `stream` (hipStream_t as void*), no allocation, return 0 / negative PIKA_E* / hipError_t.
+ */
+#ifndef PIKA_BMUF_H
+#define PIKA_BMUF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* delta[i] = global[i] - local[i]                                   (bmuf.py:83-84) */
+int pika_bmuf_delta(const float *global, const float *local, float *delta, size_t n, void *stream);
+
+/* *flag (device int, caller zeroes it) is set to 1 if any delta[i] is NaN   (bmuf.py:89) */
+int pika_bmuf_nan_flag(const float *delta, size_t n, int *flag, void *stream);
+
+/* One pass over four vectors (bmuf.py:93-98, executed identically on every rank):
+ *   d          = delta[i] * inv_world
+ *   delta_prev = block_momentum * delta_prev + block_lr * (1 - block_momentum) * d
+ *   global    -= (1 + block_momentum) * delta_prev
+ *   local      = global                      (replaces broadcast + _copy_vec_to_param) */
+int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float *local, size_t n,
+                     float inv_world, float block_momentum, float block_lr, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_BMUF_H */

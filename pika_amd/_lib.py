@@ -11,7 +11,7 @@ ABI_VERSION = 1
 
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
-# name -> (restype, argtypes); mirrors include/pika_rnnt.h one to one
+# name -> (restype, argtypes); mirrors include/*.h one to one
 SIGNATURES = {
     "pika_amd_abi_version": (_i, []),
     "pika_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -19,6 +19,11 @@ SIGNATURES = {
     "pika_rnnt_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_export_lattice": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    # include/pika_bmuf.h
+    "pika_bmuf_delta": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "pika_bmuf_nan_flag": (_i, [_vp, _sz, _vp, _vp]),
+    "pika_bmuf_update": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float,
+                              ctypes.c_float, _vp]),
 }
 
 _lib = None

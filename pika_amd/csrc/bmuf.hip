@@ -1,0 +1,124 @@
+// pika_amd/csrc/bmuf.hip -- fused BMUF vector kernels for gfx950.
+// Reference math: /root/reference/trainer/bmuf.py:83-98.  HBM-bound streaming kernels over
+// the ~90 M-float flat parameter vector (361 MB): 16-byte accesses, grid-stride, 2048 blocks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pika_bmuf.h"
+#include "pika_rnnt.h"  // PIKA_EINVAL
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int BLOCKS = 2048;  // 256 CUs x 8
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bmuf_delta_kernel(const float *__restrict__ g,
+                                                         const float *__restrict__ l,
+                                                         float *__restrict__ d, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const size_t n4 = n >> 2;
+        for (size_t k = i; k < n4; k += stride)
+            reinterpret_cast<v4f *>(d)[k] =
+                reinterpret_cast<const v4f *>(g)[k] - reinterpret_cast<const v4f *>(l)[k];
+        for (size_t k = (n4 << 2) + i; k < n; k += stride) d[k] = g[k] - l[k];
+    } else {
+        for (; i < n; i += stride) d[i] = g[i] - l[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void bmuf_nan_kernel(const float *__restrict__ d, size_t n,
+                                                       int *__restrict__ flag) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        bad |= (d[i] != d[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// Same operation order and roundings as bmuf.py:93-96 run as separate PyTorch ops: FMA
+// contraction is switched off so every product is rounded before it is added.
+template <typename V>
+__device__ inline void upd(V d, V &dp, V &g, V &l, float inv_world, float bm, float blr) {
+#pragma clang fp contract(off)
+    const V avg = d * inv_world;
+    const V t1 = dp * bm;
+    const V t2 = avg * (blr * (1.0f - bm));
+    dp = t1 + t2;
+    const V t3 = dp * (1.0f + bm);
+    g = g - t3;
+    l = g;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bmuf_update_kernel(const float *__restrict__ delta,
+                                                          float *__restrict__ dprev,
+                                                          float *__restrict__ g,
+                                                          float *__restrict__ l, size_t n,
+                                                          float inv_world, float bm, float blr) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (VEC) {
+        const size_t n4 = n >> 2;
+        for (size_t k = i; k < n4; k += stride) {
+            const v4f d = reinterpret_cast<const v4f *>(delta)[k];
+            v4f p = reinterpret_cast<v4f *>(dprev)[k], gg = reinterpret_cast<v4f *>(g)[k], ll;
+            upd(d, p, gg, ll, inv_world, bm, blr);
+            reinterpret_cast<v4f *>(dprev)[k] = p;
+            reinterpret_cast<v4f *>(g)[k] = gg;
+            reinterpret_cast<v4f *>(l)[k] = ll;
+        }
+        for (size_t k = (n4 << 2) + i; k < n; k += stride)
+            upd(delta[k], dprev[k], g[k], l[k], inv_world, bm, blr);
+    } else {
+        for (size_t k = i; k < n; k += stride) upd(delta[k], dprev[k], g[k], l[k], inv_world, bm, blr);
+    }
+}
+
+inline int grid_for(size_t n) {
+    const size_t want = (n + 1023) / 1024;
+    return (int)(want < 1 ? 1 : (want > BLOCKS ? BLOCKS : want));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pika_bmuf_delta(const float *global, const float *local, float *delta, size_t n, void *stream) {
+    if (!global || !local || !delta) return PIKA_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (aligned16(global) && aligned16(local) && aligned16(delta))
+        hipLaunchKernelGGL(bmuf_delta_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, global, local, delta, n);
+    else
+        hipLaunchKernelGGL(bmuf_delta_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, global, local, delta, n);
+    return (int)hipGetLastError();
+}
+
+int pika_bmuf_nan_flag(const float *delta, size_t n, int *flag, void *stream) {
+    if (!delta || !flag) return PIKA_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bmuf_nan_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), delta, n, flag);
+    return (int)hipGetLastError();
+}
+
+int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float *local, size_t n,
+                     float inv_world, float block_momentum, float block_lr, void *stream) {
+    if (!delta || !delta_prev || !global || !local) return PIKA_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (aligned16(delta) && aligned16(delta_prev) && aligned16(global) && aligned16(local))
+        hipLaunchKernelGGL(bmuf_update_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, delta,
+                           delta_prev, global, local, n, inv_world, block_momentum, block_lr);
+    else
+        hipLaunchKernelGGL(bmuf_update_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, delta,
+                           delta_prev, global, local, n, inv_world, block_momentum, block_lr);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+"""BMUF: our all-reduce formulation vs (a) golden vectors produced by the REFERENCE BmufTrainer
+run under gloo (tests/golden/make_bmuf_golden.py) and (b) a single-process restatement of
+bmuf.py:76-98.  world_size 2, gloo, CPU -- covers the N>1 path without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bmuf_common as C  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bmuf_ws2.npz")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out, inject_nan):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from trainer.bmuf import BmufTrainer  # drop-in import path used by the reference script
+    model = C.make_model(rank)
+    init = C.flat(model)
+    tr = BmufTrainer(0, rank, world, model, C.BM, C.BLR)
+    after_init = C.flat(model)
+    rounds, status = [], []
+    for rnd in range(C.ROUNDS):
+        C.local_step(model, rank, rnd)
+        if inject_nan and rnd == 1 and rank == 1:
+            with torch.no_grad():
+                next(model.parameters()).view(-1)[0] = float("nan")
+        status.append(tr.update_and_sync())
+        rounds.append(C.flat(model))
+        if status[-1] == 0:
+            break
+    # parameters must still be views of the flat vector (optimizer re-creation keeps working)
+    p0 = next(model.parameters())
+    assert p0.data_ptr() == tr.local.data_ptr()
+    t = torch.tensor([1.5 + rank, 10.0 * (rank + 1)])
+    tr.sum_reduce(t)
+    tr.broadcast(t)
+    np.savez(out % rank, init=init, after_init=after_init, rounds=np.stack(rounds),
+             loss=t.numpy(), status=np.array(status))
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, inject_nan=False, world=2):
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(world, C.free_port(), out, inject_nan), nprocs=world, join=True)
+    return [np.load(out % r) for r in range(world)]
+
+
+def test_matches_reference_golden_and_restatement(tmp_path):
+    z = _run(tmp_path)
+    gold = np.load(GOLD)
+    assert np.array_equal(z[0]["init"], gold["init0"]) and np.array_equal(z[1]["init"], gold["init1"])
+    for r in (0, 1):
+        assert np.array_equal(z[r]["after_init"], gold["after_init"])  # broadcast of rank 0's weights
+        assert np.all(z[r]["status"] == 1)
+        # all-reduce sums in a different order than reduce-to-root: allow 2 ulp of fp32
+        assert np.allclose(z[r]["rounds"], gold["rounds"], rtol=3e-7, atol=3e-8)
+        assert np.allclose(z[r]["loss"], gold["loss"])
+    assert np.array_equal(z[0]["rounds"], z[1]["rounds"]), "replicas must stay bitwise identical"
+    sim = C.simulate_reference_math(2)
+    assert np.allclose(z[0]["rounds"], sim, rtol=3e-7, atol=3e-8)
+
+
+def test_nan_guard_stops_every_rank_consistently(tmp_path):
+    z = _run(tmp_path, inject_nan=True)
+    for r in (0, 1):
+        assert list(z[r]["status"]) == [1, 0]  # STOP on the same block on every rank
+
+
+@pytest.mark.gpu
+def test_fused_kernels_match_reference_math(hip_device):
+    from pika_amd import _lib
+    lib = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (1, 7, 1024, 4099, 1 << 20):
+        g = torch.Generator(device="cpu").manual_seed(n)
+        G = torch.randn(n, generator=g)
+        Lc = G + 0.01 * torch.randn(n, generator=g)
+        dp = 0.1 * torch.randn(n, generator=g)
+        Gd, Ld, dpd = G.to(hip_device), Lc.to(hip_device), dp.to(hip_device)
+        delta = torch.empty_like(Gd)
+        _lib.check(lib.pika_bmuf_delta(Gd.data_ptr(), Ld.data_ptr(), delta.data_ptr(), n, st), "delta")
+        assert torch.equal(delta.cpu(), G - Lc)
+        world, bm, blr = 8, 0.9, 1.0
+        summed = delta * 3.0  # stand-in for the all-reduced sum
+        ref_d = summed.cpu() / float(world)
+        ref_dp = bm * dp + (blr * (1 - bm) * ref_d)
+        ref_G = G - (1 + bm) * ref_dp
+        _lib.check(lib.pika_bmuf_update(summed.data_ptr(), dpd.data_ptr(), Gd.data_ptr(), Ld.data_ptr(),
+                                        n, 1.0 / world, bm, blr, st), "update")
+        torch.cuda.synchronize()
+        assert torch.allclose(dpd.cpu(), ref_dp, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(Gd.cpu(), ref_G, rtol=1e-6, atol=1e-7)
+        assert torch.equal(Ld, Gd)
+        flag = torch.zeros(1, dtype=torch.int32, device=hip_device)
+        _lib.check(lib.pika_bmuf_nan_flag(delta.data_ptr(), n, flag.data_ptr(), st), "nan")
+        assert flag.item() == 0
+        delta[n // 2] = float("nan")
+        _lib.check(lib.pika_bmuf_nan_flag(delta.data_ptr(), n, flag.data_ptr(), st), "nan")
+        assert flag.item() == 1
+    # unaligned views take the scalar path
+    base = torch.randn(4100, device=hip_device)
+    a, b = base[1:4098], base[2:4099].clone()
+    out = torch.empty(4100, device=hip_device)[1:4098]
+    _lib.check(lib.pika_bmuf_delta(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), st), "delta")
+    assert torch.equal(out, a - b)
+
+
+@pytest.mark.gpu
+def test_trainer_on_hip_single_rank(hip_device, tmp_path):
+    """world_size 1 on the GPU: BmufTrainer end to end through the fused kernels (RCCL backend)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(C.free_port()), RANK="0", WORLD_SIZE="1")
+    from pika_amd.bmuf import BmufTrainer
+    model = C.make_model(0).to(hip_device)
+    tr = BmufTrainer(0, 0, 1, model, C.BM, C.BLR)
+    cpu_model = C.make_model(0)
+    G = torch.from_numpy(C.flat(cpu_model))
+    dprev = torch.zeros_like(G)
+    for rnd in range(C.ROUNDS):
+        C.local_step(cpu_model, 0, rnd)
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), cpu_model.parameters()):
+                p.copy_(q)
+        assert tr.update_and_sync() == 1
+        delta = (G - torch.from_numpy(C.flat(cpu_model))) / 1.0
+        dprev = C.BM * dprev + (C.BLR * (1 - C.BM) * delta)
+        G = G - (1 + C.BM) * dprev
+        torch.nn.utils.vector_to_parameters(G.clone(), cpu_model.parameters())
+        assert np.allclose(C.flat(model), G.numpy(), rtol=1e-6, atol=1e-7)
+    dist.destroy_process_group()
