@@ -1,0 +1,48 @@
+"""TDNN-Transformer encoder (reference: trainer/model/rnnt_tdnn_transformer.py:27-89)."""
+import torch.nn as nn
+
+from . import ops
+from .modules import TransformerEncoderLayer
+
+
+class Net(nn.Module):
+    """fc_in+ReLU+BN, `tdnn_layers` time-delay layers (3 taps; dilation 1 for the first three,
+    3 afterwards; the last one also strides by 4) each followed by ReLU+BN, a transformer layer
+    after every third TDNN layer (heads 16/16/8, d_ff = 4*nhid, dropout 0.2, no mask, no
+    positional encoding), then BN + fc_out."""
+
+    HEADS = (16, 16, 8)
+
+    def __init__(self, input_dim, input_ctx, output_dim, tdnn_nhid, tdnn_layers, bn_dim=0):
+        super().__init__()
+        assert tdnn_layers > 4
+        self.input_dim, self.output_dim, self.tdnn_nhid = input_dim, output_dim, tdnn_nhid
+        self.filter_size = 3
+        self.fc_in = nn.Linear(input_dim, tdnn_nhid)
+        self.bn_in = nn.BatchNorm1d(tdnn_nhid)
+
+        def td(dil, stride=1):  # parameters kept in the reference's Conv2d container/shape
+            return nn.Conv2d(1, tdnn_nhid, kernel_size=(self.filter_size, tdnn_nhid),
+                             stride=(stride, 1), dilation=(dil, 1))
+        layers = [td(1) for _ in range(3)] + [td(3) for _ in range(tdnn_layers - 4)] + [td(3, 4)]
+        self.hidden_conv = nn.ModuleList(layers)
+        self.hidden_bn = nn.ModuleList([nn.BatchNorm1d(tdnn_nhid) for _ in range(tdnn_layers)])
+        self.transformer = nn.ModuleList(
+            [TransformerEncoderLayer(tdnn_nhid, h, tdnn_nhid * 4, 0.2, max_relative_positions=0)
+             for h in self.HEADS])
+        self.bn_final = nn.BatchNorm1d(tdnn_nhid)
+        self.fc_out = nn.Linear(tdnn_nhid, output_dim)
+
+    def forward(self, x, frame_offset=0):
+        B = x.size(0)
+        C = self.tdnn_nhid
+        h = ops.relu(ops.linear(x, self.fc_in.weight, self.fc_in.bias))
+        h = ops.batch_norm(h.reshape(-1, C), self.bn_in).view(B, -1, C)
+        for i, (conv, bn) in enumerate(zip(self.hidden_conv, self.hidden_bn)):
+            h = ops.relu(ops.tdnn(h, conv.weight, conv.bias, conv.dilation[0], conv.stride[0]))
+            h = ops.batch_norm(h.reshape(-1, C), bn).view(B, -1, C)
+            if (i + 1) % 3 == 0:
+                h = self.transformer[i // 3](h, mask=None)
+        h = ops.batch_norm(h.reshape(-1, C), self.bn_final)
+        h = ops.linear(h, self.fc_out.weight, self.fc_out.bias).view(B, -1, self.output_dim)
+        return h[:, frame_offset:, :]

@@ -1,0 +1,72 @@
+"""Transformer building blocks with the reference's parameter layout
+(trainer/model/modules/{transformer,multi_headed_attn,position_ffn}.py)."""
+import torch.nn as nn
+
+from . import ops
+
+
+class PositionwiseFeedForward(nn.Module):
+    """x + drop(w_2(drop(relu(w_1(LN(x))))))   (position_ffn.py:27-39)"""
+
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+        self.dropout_1 = nn.Dropout(dropout)
+        self.relu = nn.ReLU()
+        self.dropout_2 = nn.Dropout(dropout)
+
+    def forward(self, x):
+        h = ops.relu(ops.linear(ops.layer_norm(x, self.layer_norm), self.w_1.weight, self.w_1.bias))
+        h = ops.dropout(h, self.dropout_1.p, self.training)
+        y = ops.linear(h, self.w_2.weight, self.w_2.bias)
+        return ops.dropout(y, self.dropout_2.p, self.training) + x
+
+
+class MultiHeadedAttention(nn.Module):
+    """Self-attention as the RNN-T path uses it: no layer cache, no relative positions
+    (multi_headed_attn.py:179-184,199-241 is the only branch the hot path reaches)."""
+
+    def __init__(self, head_count, model_dim, dropout=0.1, max_relative_positions=0):
+        assert model_dim % head_count == 0
+        super().__init__()
+        self.dim_per_head = model_dim // head_count
+        self.model_dim = model_dim
+        self.head_count = head_count
+        self.linear_keys = nn.Linear(model_dim, head_count * self.dim_per_head)
+        self.linear_values = nn.Linear(model_dim, head_count * self.dim_per_head)
+        self.linear_query = nn.Linear(model_dim, head_count * self.dim_per_head)
+        self.softmax = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.final_linear = nn.Linear(model_dim, model_dim)
+        self.max_relative_positions = max_relative_positions
+        if max_relative_positions > 0:
+            raise NotImplementedError("relative positions are off the RNN-T hot path (SURVEY 8a row 7)")
+
+    def forward(self, key, value, query, mask=None, layer_cache=None, type=None):
+        if layer_cache is not None:
+            raise NotImplementedError("layer_cache is off the RNN-T hot path (SURVEY 8a row 7)")
+        k = ops.linear(key, self.linear_keys.weight, self.linear_keys.bias)
+        v = ops.linear(value, self.linear_values.weight, self.linear_values.bias)
+        q = ops.linear(query, self.linear_query.weight, self.linear_query.bias)
+        ctx = ops.attention(q, k, v, self.head_count, mask, self.dropout.p, self.training)
+        out = ops.linear(ctx, self.final_linear.weight, self.final_linear.bias)
+        return out, None  # the reference also returns head-0 attention, unused on this path
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Pre-LN layer: out = drop(MHA(LN(x))) + x; return FFN(out)   (transformer.py:85-100)"""
+
+    def __init__(self, d_model, heads, d_ff, dropout, max_relative_positions=0):
+        super().__init__()
+        self.self_attn = MultiHeadedAttention(heads, d_model, dropout=dropout,
+                                              max_relative_positions=max_relative_positions)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dropout)
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, inputs, mask):
+        n = ops.layer_norm(inputs, self.layer_norm)
+        ctx, _ = self.self_attn(n, n, n, mask=mask, type="self")
+        return self.feed_forward(ops.dropout(ctx, self.dropout.p, self.training) + inputs)

@@ -1,0 +1,110 @@
+"""Functional ops used by the model forward passes.
+
+Dispatch rule: GPU tensors -> HIP kernels of libpika_amd.so where one exists (listed in
+DESIGN.md "kernel inventory"); plain library GEMMs go to hipBLASLt through torch.matmul.
+CPU tensors (module-structure tests, gloo plumbing) use the equivalent torch ops.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def linear(x, weight, bias=None):
+    return F.linear(x, weight, bias)
+
+
+def relu(x):
+    return F.relu(x)
+
+
+def batch_norm(x2d, bn):
+    """BatchNorm1d over rows of a (M,C) matrix with the module's buffers (train: batch stats)."""
+    return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                        bn.training or not bn.track_running_stats,
+                        _bn_momentum(bn), bn.eps)
+
+
+def _bn_momentum(bn):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            return 1.0 / float(bn.num_batches_tracked)
+    return 0.0 if bn.momentum is None else bn.momentum
+
+
+def layer_norm(x, ln):
+    return F.layer_norm(x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+
+
+def dropout(x, p, training):
+    return F.dropout(x, p, training) if (training and p > 0.0) else x
+
+
+def tdnn(x, weight, bias, dilation, stride):
+    """Time-delay layer: y[b,t,n] = sum_j sum_c W[n,0,j,c] * x[b, t*stride + j*dilation, c] + bias[n].
+
+    x (B,T,C); weight is the reference's Conv2d weight (N,1,taps,C)
+    (rnnt_tdnn_transformer.py:44-57 builds it as a (taps x C) 2-d convolution).  Computed as ONE
+    GEMM with K = taps*C over time-shifted views -- never as a convolution."""
+    N, _, taps, C = weight.shape
+    B, T, _ = x.shape
+    span = T - dilation * (taps - 1)
+    t_out = (span - 1) // stride + 1
+    cols = [x[:, j * dilation: j * dilation + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
+    a = torch.cat(cols, dim=-1)  # (B, t_out, taps*C)
+    return F.linear(a, weight.reshape(N, taps * C), bias)
+
+
+def causal_conv1d(x, weight, bias):
+    """y[b,t,n] = sum_j sum_c W[n,c,j] * x[b, t - (k-1) + j, c] + bias (zeros left of t=0).
+
+    x (B,T,C), weight (N,C,k): the reference pads k-1 both sides and trims the right
+    (rnnt_conv_transformer_lm.py:36-45,73)."""
+    N, C, k = weight.shape
+    B, T, _ = x.shape
+    xp = F.pad(x, (0, 0, k - 1, 0))
+    a = torch.cat([xp[:, j: j + T, :] for j in range(k)], dim=-1)  # (B,T,k*C), tap-major
+    w = weight.permute(0, 2, 1).reshape(N, k * C)
+    return F.linear(a, w, bias)
+
+
+def attention(q, k, v, heads, mask, p_drop, training):
+    """Multi-head scaled dot-product attention on (B,T,H*D) projections; returns (B,Tq,H*D).
+
+    Matches multi_headed_attn.py:199-231: q scaled by 1/sqrt(D) BEFORE q.k^T, scores in fp32,
+    masked_fill(mask, -1e18), softmax, dropout on the probabilities."""
+    B, Tq, HD = q.shape
+    Tk = k.shape[1]
+    D = HD // heads
+    qh = (q / math.sqrt(D)).view(B, Tq, heads, D).transpose(1, 2)
+    kh = k.view(B, Tk, heads, D).transpose(1, 2)
+    vh = v.view(B, Tk, heads, D).transpose(1, 2)
+    scores = torch.matmul(qh, kh.transpose(2, 3)).float()
+    if mask is not None:
+        scores = scores.masked_fill(mask.unsqueeze(1), -1e18)
+    attn = torch.softmax(scores, dim=-1).to(q.dtype)
+    ctx = torch.matmul(dropout(attn, p_drop, training), vh)
+    return ctx.transpose(1, 2).contiguous().view(B, Tq, HD)
+
+
+def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
+    """Gated joint network over the full (T,U) lattice.
+
+    enc (B,T,H), pred (B,U,H) -> (B,T,U,V).  Reference (transducer.py:98-111) concatenates the
+    expanded tensors into (B,T,U,2H) and runs fc1/fc_gate on it (103 GFLOP/utt at config 2);
+    here the 2H-wide weights are split into their encoder and prediction halves, applied to
+    (B,T,H) and (B,U,H) separately and broadcast-added (1.2 GFLOP/utt), which is the same
+    affine map."""
+    H = enc.shape[-1]
+    w1e, w1p = fc1.weight[:, :H], fc1.weight[:, H:]
+    wge, wgp = fc_gate.weight[:, :H], fc_gate.weight[:, H:]
+    e1 = F.linear(enc, w1e, fc1.bias)
+    p1 = F.linear(pred, w1p)
+    eg = F.linear(enc, wge, fc_gate.bias)
+    pg = F.linear(pred, wgp)
+    h = torch.tanh(e1.unsqueeze(2) + p1.unsqueeze(1)) * torch.sigmoid(eg.unsqueeze(2) + pg.unsqueeze(1))
+    out = F.linear(h, fc2.weight, fc2.bias)
+    if log_softmax:
+        out = F.log_softmax(out if scale == 1.0 else scale * out, dim=-1)
+    return out

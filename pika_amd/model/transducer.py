@@ -1,0 +1,70 @@
+"""Generic transducer (reference: trainer/model/transducer.py:27-112): encoder + embedding +
+prediction network + gated joint + optional log-softmax."""
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+from . import ops
+from .encoder import Net as TdnnTransformerEncoder
+from .prednet import Net as ConvTransformerPredNet
+
+
+class Net(nn.Module):
+    """`opt` supplies rnn_size, local_rank, decoder_type, brnn, encoder_type, dropout,
+    enc_layers, dec_layers, embd_dim, padding_idx (transducer.py:27-68)."""
+
+    def __init__(self, opt, input_dim, output_dim):
+        super().__init__()
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.hid_dim = opt.rnn_size
+        self.local_rank = opt.local_rank
+        self.pack_seq = True
+        self.decoder_type = opt.decoder_type
+        if opt.encoder_type == 'rnn':
+            dirs = 2 if opt.brnn else 1
+            self.encoder = nn.LSTM(input_size=input_dim, hidden_size=self.hid_dim // dirs,
+                                   dropout=opt.dropout, num_layers=opt.enc_layers,
+                                   bidirectional=opt.brnn, batch_first=True)
+        else:
+            # widths are hard-coded in the reference (transducer.py:46-50), not flag-controlled
+            self.encoder = TdnnTransformerEncoder(input_dim=input_dim, input_ctx=0,
+                                                  output_dim=self.hid_dim, tdnn_nhid=1024,
+                                                  tdnn_layers=9)
+            self.pack_seq = False
+        self.embed = nn.Embedding(output_dim + 1, opt.embd_dim, padding_idx=opt.padding_idx)
+        if opt.decoder_type == 'rnn':
+            self.decoder = nn.LSTM(input_size=opt.embd_dim, hidden_size=self.hid_dim,
+                                   dropout=opt.dropout, num_layers=opt.dec_layers,
+                                   bidirectional=False, batch_first=True)
+        else:
+            self.decoder = ConvTransformerPredNet(embeddings=self.embed, output_dim=self.hid_dim,
+                                                  d_model=512, num_layers=opt.dec_layers, heads=8,
+                                                  d_ff=2048, dropout=opt.dropout)
+        self.fc1 = nn.Linear(2 * self.hid_dim, self.hid_dim)
+        self.fc_gate = nn.Linear(2 * self.hid_dim, self.hid_dim)
+        self.fc2 = nn.Linear(self.hid_dim, output_dim)
+
+    def encode(self, x, x_len=None):
+        if self.pack_seq and x_len is not None:
+            packed = pack_padded_sequence(x, x_len, batch_first=True, enforce_sorted=True)
+            packed, _ = self.encoder(packed)
+            return pad_packed_sequence(packed, batch_first=True)[0]
+        return self.encoder(x)
+
+    def predict(self, y):
+        """Prediction network on label sequences that already start with SOS (= blank = 0)."""
+        if self.decoder_type == 'rnn':
+            return self.decoder(self.embed(y))[0]
+        return self.decoder(y)
+
+    def forward(self, x, y, x_len=None, softmax=True):
+        enc = self.encode(x, x_len)
+        sos = torch.zeros(y.shape[0], 1, dtype=torch.long, device=y.device)  # SOS = blank = 0
+        pred = self.predict(torch.cat((sos, y), dim=1))
+        return ops.joint(enc, pred, self.fc1, self.fc_gate, self.fc2, log_softmax=softmax)
+
+    def clean_hidden(self):
+        """interface kept for the training scripts"""
+
+    def reset_hidden(self, h, reset_idx):
+        """interface kept for the training scripts"""

@@ -1,0 +1,93 @@
+"""Model parity: our encoder / prediction net / joint against golden
+activations and gradients recorded from the REFERENCE model code (tests/golden/
+make_model_golden.py, PyTorch-CPU fp32).  Identical weights on both sides come from
+oracle.pika_ref.seeded_state_dict (same keys and shapes => same tensors).
+Tolerance: 1e-3 rel fp32 per north_star; measured error is ~1e-6 (fp32 reassociation only)."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import model_common as C  # noqa: E402
+from oracle.pika_ref import seeded_state_dict  # noqa: E402  (deterministic weights only)
+
+
+def ours(dec, device="cpu"):
+    from pika_amd.model import transducer, encoder
+    net = C.build(transducer, encoder, dec)
+    net.load_state_dict(seeded_state_dict(net, C.SEED))
+    return net.to(device)
+
+
+def close(a, b, rtol=1e-3, atol=1e-5):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    scale = np.abs(b).max()
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale + atol, "max err %g vs scale %g" % (err, scale)
+
+
+def run_parity(dec, device):
+    z = np.load(os.path.join(HERE, "golden", "model_tiny_%s.npz" % dec))
+    net = ours(dec, device)
+    x, y, y_len, w = [t.to(device) for t in C.inputs()]
+    net.eval()
+    with torch.no_grad():
+        close(net.encoder(x), z["enc_eval"])
+        sos = torch.zeros(C.B, 1, dtype=torch.long, device=device)
+        close(net.predict(torch.cat((sos, y), 1)), z["pred_eval"])
+        close(net(x, y, None, True), z["joint_eval"])
+        close(net(x, y, None, False), z["joint_eval_nosm"])
+    net.train()
+    lp = net(x, y, None, True)
+    close(lp, z["joint_train"])
+    (lp * w).sum().backward()
+    params = dict(net.named_parameters())
+    for k in z["grad_keys"]:
+        close(params[str(k)].grad, z["grad:" + str(k)], rtol=1e-3, atol=1e-5)
+    close(net.encoder.bn_in.running_mean, z["bn_in_running_mean_after"])
+    close(net.encoder.bn_final.running_var, z["bn_final_running_var_after"])
+
+
+@pytest.mark.parametrize("dec", ["transformer", "rnn"])
+def test_module_tree_matches_reference_layout(dec):
+    """state_dict keys/shapes are the checkpoint + BMUF-vector contract."""
+    net = ours(dec)
+    z = np.load(os.path.join(HERE, "golden", "model_tiny_%s.npz" % dec))
+    names = [k for k, _ in net.named_parameters()]
+    for k in z["grad_keys"]:
+        assert str(k) in names
+    for attr in ("encoder", "decoder", "embed", "fc1", "fc_gate", "fc2", "pack_seq", "decoder_type",
+                 "hid_dim", "output_dim"):
+        assert hasattr(net, attr)
+    assert net.embed.padding_idx == C.V and net.fc1.in_features == 2 * C.H
+
+
+@pytest.mark.parametrize("dec", ["transformer", "rnn"])
+def test_cpu_plumbing_matches_reference_golden(dec):
+    run_parity(dec, "cpu")
+
+
+def test_full_size_parameter_count_and_pickle_roundtrip(tmp_path):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    import importlib
+    mod = importlib.import_module("model.transducer")  # how the training script finds it
+    opt = C.make_opt("transformer")
+    opt.rnn_size, opt.embd_dim, opt.padding_idx = 1024, 100, 5000
+    net = mod.Net(opt, 240, 5000)
+    assert sum(p.numel() for p in net.parameters()) == 85648652  # SURVEY 2.3 [probe]: 85.6 M
+    small = ours("transformer")
+    f = tmp_path / "model.epoch.0.0"
+    torch.save(small, f)  # whole-module pickle, as train_transducer_bmuf_otfaug.py:363-366
+    back = torch.load(f, weights_only=False)
+    assert all(torch.equal(a, b) for a, b in zip(small.state_dict().values(), back.state_dict().values()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dec", ["transformer", "rnn"])
+def test_gpu_matches_reference_golden(hip_device, dec):
+    run_parity(dec, hip_device)
