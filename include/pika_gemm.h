@@ -1,0 +1,55 @@
+/*
+ * include/pika_gemm.h -- C ABI of the MFMA GEMM used by the RNN-T model kernels.
+ *
+ * C[z][m][n] (+)= act( sum_k A[z](m,k) * B[z](n,k) + bias[n] )        ("NT": both operands are
+ * indexed (output-row, reduction) with the reduction index contiguous)
+ *
+ * Replaces the cuBLAS/cuDNN calls the reference reaches through nn.Linear, the TDNN
+ * Conv2d(1,C,(3,C),dilation) (rnnt_tdnn_transformer.py:44-57), the causal Conv1d(k=5)
+ * (rnnt_conv_transformer_lm.py:36-45), torch.matmul in attention (multi_headed_attn.py:207,223)
+ * and the joint's fc2 (transducer.py:108).  An operand may be a VIRTUAL time-delay matrix:
+ * row r = (b,t), reduction k = (tap,c) reads x[b, t*stride + tap*dil - pad, c] (zero outside
+ * [0,t_in)), so convolutions run as ONE GEMM without materialising im2col.
+ *
+ * Arithmetic: operands are rounded to bf16 (RNE) on their way into LDS, products accumulate in
+ * fp32 on v_mfma_f32_16x16x32_bf16.  PIKA_GEMM_FP32SPLIT splits each fp32 operand exactly into
+ * three bf16 parts (8+8+8 mantissa bits) and issues the 6 MFMAs whose products exceed 2^-24 of
+ * the leading one: fp32-class accuracy (~1e-7 relative) at 1/6 of the bf16 rate, used for the
+ * parity runs against the reference's fp32 arithmetic.
+ */
+#ifndef PIKA_GEMM_H
+#define PIKA_GEMM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIKA_F32 0
+#define PIKA_BF16 1
+
+typedef struct {
+    const void *ptr;
+    int dtype;           /* PIKA_F32 | PIKA_BF16 */
+    int rows_per_batch;  /* row r -> b = r / rows_per_batch, t = r % rows_per_batch */
+    int t_in;            /* source time extent: rows with ti outside [0,t_in) read as zero */
+    long long batch_stride; /* elements between consecutive b */
+    long long ld;        /* elements between consecutive source time rows */
+    int C;               /* channels per tap: k -> tap = k / C, c = k % C */
+    int stride, dil, pad;/* ti = t*stride + tap*dil - pad */
+    long long z_outer, z_inner; /* element offsets per batched-GEMM index z: (z / z_div, z % z_div) */
+} pika_operand_t;
+
+#define PIKA_GEMM_RELU 1
+#define PIKA_GEMM_ACCUMULATE 2
+#define PIKA_GEMM_FP32SPLIT 4
+
+/* Requirements: K % 4 == 0, operand C % 4 == 0, every addressed row 16-byte (f32) / 8-byte (bf16)
+ * aligned.  Returns PIKA_EINVAL otherwise (the caller decides; nothing falls back silently). */
+int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+                 long long c_z_outer, long long c_z_inner, int M, int N, int K, int batch,
+                 int z_div, const float *bias, int flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_GEMM_H */

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
 ABI_VERSION = 1
 
-_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
 # name -> (restype, argtypes); mirrors include/*.h one to one
 SIGNATURES = {
@@ -27,6 +27,12 @@ SIGNATURES = {
     # include/pika_feat.h
     "pika_cmvn_apply": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "pika_specaug_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    # include/pika_gemm.h
+    "pika_gemm_nt": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    # include/pika_ops.h
+    "pika_transpose_cast": (_i, [_vp, _i, _i, _vp, _ll, _i, _vp]),
+    "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
+    "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

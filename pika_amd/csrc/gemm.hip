@@ -1,0 +1,275 @@
+// pika_amd/csrc/gemm.hip -- bf16-MFMA GEMM for gfx950 (see include/pika_gemm.h).
+//
+// 128x128x32 tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 MFMA 16x16x32 tiles
+// (64 fp32 accumulators per lane).  fp32 (or bf16) operands are loaded with 16-byte (8-byte)
+// global loads into registers, rounded to bf16 (v_cvt_pk_bf16_f32) and staged into LDS rows of
+// 32 bf16 padded to 80 bytes: ds_read_b128 of the MFMA fragments (row = lane&15, k-group =
+// lane>>4) is then bank-conflict-free (16 rows x 20 dwords cover all 64 banks exactly once).
+// Global loads of step k+1 are issued before the MFMAs of step k and written to the other LDS
+// buffer after them: one barrier per K-step.  MFMA is issued as D^T = B_frag x A_frag so each
+// lane ends up with 4 CONSECUTIVE columns of one row of C -> 16-byte epilogue stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pika_gemm.h"
+#include "pika_rnnt.h"  // PIKA_EINVAL
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PITCH = 40;                  // bf16 per LDS row (32 + 8 pad) = 80 bytes
+constexpr int TILE_ELEMS = 128 * PITCH;    // one operand tile in bf16 elements
+
+struct Op {  // device-side copy of pika_operand_t
+    const char *ptr;
+    int rows_per_batch, t_in;
+    long long batch_stride, ld;
+    int C, stride, dil, pad;
+};
+
+// Per-thread loader of one operand: rows r_i = r0 + tid/8 + 32 i (i<4), k quad = (tid%8)*4.
+template <typename T>
+struct Loader {
+    const T *base;
+    long long rowoff[4];  // b * batch_stride
+    int tbase[4];         // t*stride - pad, or a huge negative for out-of-range rows
+    long long ld;
+    int t_in, C, dil;
+    int tap, c;           // decomposition of this thread's current k
+    int k, K;
+
+    __device__ inline void init(const Op &o, long long zoff, int r0, int nrows, int K_) {
+        const int tid = threadIdx.x;
+        base = reinterpret_cast<const T *>(o.ptr) + zoff;
+        ld = o.ld; t_in = o.t_in; C = o.C; dil = o.dil; K = K_;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + (tid >> 3) + 32 * i;
+            if (r < nrows) {
+                const int b = r / o.rows_per_batch, t = r - b * o.rows_per_batch;
+                rowoff[i] = (long long)b * o.batch_stride;
+                tbase[i] = t * o.stride - o.pad;
+            } else {
+                rowoff[i] = 0;
+                tbase[i] = -(1 << 29);
+            }
+        }
+        k = (tid & 7) * 4;
+        tap = k / C;
+        c = k - tap * C;
+    }
+    __device__ inline void advance() {
+        k += BK;
+        c += BK;
+        while (c >= C) { c -= C; ++tap; }
+    }
+    __device__ inline void load(f32x4 v[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ti = tbase[i] + tap * dil;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (k < K && ti >= 0 && ti < t_in) {
+                const T *p = base + rowoff[i] + (long long)ti * ld + c;
+                if constexpr (sizeof(T) == 4) {
+                    x = *reinterpret_cast<const f32x4 *>(p);
+                } else {
+                    const bf16x4 h = *reinterpret_cast<const bf16x4 *>(p);
+                    x = __builtin_convertvector(h, f32x4);
+                }
+            }
+            v[i] = x;
+        }
+    }
+};
+
+// Stage one operand tile: NS = 1 rounds to bf16; NS = 3 writes the exact 3-way bf16 split
+// x = h + m + l (8+8+8 mantissa bits) into three consecutive tiles (stride `part`).
+template <int NS>
+__device__ inline void stage(__bf16 *dst, int part, const f32x4 v[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int off = ((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 4;
+        f32x4 r = v[i];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bf16x4 h = __builtin_convertvector(r, bf16x4);
+            *reinterpret_cast<bf16x4 *>(dst + s * part + off) = h;
+            if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
+        }
+    }
+}
+
+template <typename TA, typename TB, int NS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo, long long a_zi,
+                                                      long long b_zo, long long b_zi,
+                                                      float *__restrict__ Cp, long long ldc,
+                                                      long long c_zo, long long c_zi, int M, int N,
+                                                      int K, int z_div,
+                                                      const float *__restrict__ bias, int flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: [buf][A parts 0..NS-1 | B parts 0..NS-1]
+    constexpr int PER_BUF = 2 * NS * TILE_ELEMS;
+    constexpr int BOFF = NS * TILE_ELEMS;
+    __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
+
+    const int z = blockIdx.z, zo = z / z_div, zi = z - zo * z_div;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    Loader<TA> la;
+    Loader<TB> lb;
+    la.init(A, zo * a_zo + zi * a_zi, m0, M, K);
+    lb.init(B, zo * b_zo + zi * b_zi, n0, N, K);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[4], rb[4];
+    const int nk = (K + BK - 1) / BK;
+    la.load(ra);
+    lb.load(rb);
+    stage<NS>(lds, TILE_ELEMS, ra);
+    stage<NS>(lds + BOFF, TILE_ELEMS, rb);
+    __syncthreads();
+
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    for (int kb = 0; kb < nk; ++kb) {
+        const __bf16 *cur = lds + (kb & 1) * PER_BUF;
+        __bf16 *nxt = lds + ((kb + 1) & 1) * PER_BUF;
+        const bool more = kb + 1 < nk;
+        if (more) {
+            la.advance();
+            lb.advance();
+            la.load(ra);
+            lb.load(rb);
+        }
+        // split products kept: (0,0) [NS=1]; + (0,1),(1,0),(1,1),(0,2),(2,0) [NS=3]: every term
+        // above 2^-24 of the leading one
+        constexpr int NPAIR = NS == 1 ? 1 : 6;
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+        for (int p = NPAIR - 1; p >= 0; --p) {  // small terms first
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8 *>(cur + PA[p] * TILE_ELEMS + (wm * 64 + i * 16 + frow) * PITCH + fk);
+                fb[i] = *reinterpret_cast<const bf16x8 *>(cur + BOFF + PB[p] * TILE_ELEMS + (wn * 64 + i * 16 + frow) * PITCH + fk);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            stage<NS>(nxt, TILE_ELEMS, ra);
+            stage<NS>(nxt + BOFF, TILE_ELEMS, rb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = (lane>>4)*4
+    float *Cz = Cp + zo * c_zo + zi * c_zi;
+    const bool relu = flags & PIKA_GEMM_RELU, accum = flags & PIKA_GEMM_ACCUMULATE;
+    const bool vec_ok = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cz) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            f32x4 v = acc[i][j];
+            float *dst = Cz + (long long)m * ldc + n;
+            if (n + 3 < N && vec_ok) {
+                if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);  // bias + n: n%4==0
+                if (accum) v += *reinterpret_cast<const f32x4 *>(dst);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<f32x4 *>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < N) {
+                        float s = v[e] + (bias ? bias[n + e] : 0.f);
+                        if (accum) s += dst[e];
+                        if (relu) s = fmaxf(s, 0.f);
+                        dst[e] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+Op to_op(const pika_operand_t &o) {
+    Op r;
+    r.ptr = static_cast<const char *>(o.ptr);
+    r.rows_per_batch = o.rows_per_batch; r.t_in = o.t_in;
+    r.batch_stride = o.batch_stride; r.ld = o.ld;
+    r.C = o.C; r.stride = o.stride; r.dil = o.dil; r.pad = o.pad;
+    return r;
+}
+
+bool operand_ok(const pika_operand_t &o, int K) {
+    if (!o.ptr || o.rows_per_batch <= 0 || o.t_in <= 0 || o.C <= 0 || o.stride <= 0) return false;
+    if (o.dtype != PIKA_F32 && o.dtype != PIKA_BF16) return false;
+    if ((o.C & 3) || (K & 3) || (o.ld & 3) || (o.batch_stride & 3) || (o.z_outer & 3) || (o.z_inner & 3))
+        return false;
+    const uintptr_t align = o.dtype == PIKA_F32 ? 15 : 7;
+    return (reinterpret_cast<uintptr_t>(o.ptr) & align) == 0;
+}
+
+template <typename TA, typename TB, int NS>
+int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+           long long c_zo, long long c_zi, int M, int N, int K, int batch, int z_div,
+           const float *bias, int flags, hipStream_t s) {
+    constexpr size_t smem = (size_t)2 * 2 * NS * TILE_ELEMS * sizeof(__bf16);
+    static bool attr_set = false;  // idempotent; racing threads set the same value
+    auto kern = gemm_nt_kernel<TA, TB, NS>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, to_op(*A), to_op(*B), A->z_outer, A->z_inner,
+                       B->z_outer, B->z_inner, C, ldc, c_zo, c_zi, M, N, K, z_div, bias, flags);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C,
+                            long long ldc, long long c_z_outer, long long c_z_inner, int M, int N,
+                            int K, int batch, int z_div, const float *bias, int flags,
+                            void *stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || z_div <= 0) return PIKA_EINVAL;
+    if (!operand_ok(*A, K) || !operand_ok(*B, K)) return PIKA_EINVAL;
+    if (batch > 65535 || (M + BM - 1) / BM > 65535) return PIKA_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool x3 = flags & PIKA_GEMM_FP32SPLIT;
+    const int key = (A->dtype == PIKA_BF16 ? 2 : 0) | (B->dtype == PIKA_BF16 ? 1 : 0);
+#define GO(TA, TB)                                                                               \
+    return x3 ? launch<TA, TB, 3>(A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div,  \
+                                     bias, flags, s)                                             \
+              : launch<TA, TB, 1>(A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, \
+                                      bias, flags, s)
+    switch (key) {
+        case 0: GO(float, float);
+        case 1: GO(float, __bf16);
+        case 2: GO(__bf16, float);
+        default: GO(__bf16, __bf16);
+    }
+#undef GO
+}

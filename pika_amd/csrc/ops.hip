@@ -1,0 +1,131 @@
+// pika_amd/csrc/ops.hip -- transposes, column sums and col2im around the MFMA GEMM (gfx950).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pika_ops.h"
+#include "pika_rnnt.h"
+
+namespace {
+
+struct Op {
+    const char *ptr;
+    int dtype, rows_per_batch, t_in;
+    long long batch_stride, ld;
+    int C, stride, dil, pad;
+};
+
+__device__ inline float load_elem(const Op &o, int r, int k) {
+    const int b = r / o.rows_per_batch, t = r - b * o.rows_per_batch;
+    const int tap = k / o.C, c = k - tap * o.C;
+    const int ti = t * o.stride + tap * o.dil - o.pad;
+    if (ti < 0 || ti >= o.t_in) return 0.f;
+    const long long off = (long long)b * o.batch_stride + (long long)ti * o.ld + c;
+    if (o.dtype == PIKA_F32) return reinterpret_cast<const float *>(o.ptr)[off];
+    return (float)reinterpret_cast<const __bf16 *>(o.ptr)[off];
+}
+
+// 64x64 tile through LDS (pitch 65: conflict-free column reads); reads coalesced along k,
+// writes coalesced along r.
+template <typename TOUT>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(Op X, int rows, int K,
+                                                             TOUT *__restrict__ out,
+                                                             long long ld_out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, k = k0 + tx;
+        tile[i][tx] = (r < rows && k < K) ? load_elem(X, r, k) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int k = k0 + i, r = r0 + tx;
+        if (k < K && r < ld_out) out[(long long)k * ld_out + r] = (TOUT)tile[tx][i];
+    }
+}
+
+// grid (ceil(cols/64), chunks): each block sums a slab of rows for 64 columns, 4 row-groups,
+// then one atomicAdd per column per block (out pre-zeroed by the host wrapper).
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long long ld,
+                                                     int rows, int cols, int rows_per_block,
+                                                     float *__restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int rbeg = blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = rbeg + g; r < rend; r += 4) s += x[(long long)r * ld + c];
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] +
+                                                   part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ dcol,
+                                                     float *__restrict__ dx, int B, int t_out,
+                                                     int t_in, int C, int taps, int stride, int dil,
+                                                     int pad) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * t_in * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int ti = (int)((idx / C) % t_in);
+    const int b = (int)(idx / ((long long)C * t_in));
+    float s = 0.f;
+    for (int tap = 0; tap < taps; ++tap) {
+        const int num = ti + pad - tap * dil;
+        if (num < 0 || num % stride) continue;
+        const int t = num / stride;
+        if (t >= t_out) continue;
+        s += dcol[((long long)b * t_out + t) * ((long long)taps * C) + (long long)tap * C + c];
+    }
+    dx[idx] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, long long ld_out,
+                        int out_dtype, void *stream) {
+    if (!X || !X->ptr || !out || rows <= 0 || K <= 0 || ld_out < rows) return PIKA_EINVAL;
+    if (X->rows_per_batch <= 0 || X->C <= 0 || X->stride <= 0) return PIKA_EINVAL;
+    Op o{static_cast<const char *>(X->ptr), X->dtype, X->rows_per_batch, X->t_in, X->batch_stride,
+         X->ld, X->C, X->stride, X->dil, X->pad};
+    dim3 grid((K + 63) / 64, (unsigned)((ld_out + 63) / 64));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == PIKA_F32)
+        hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, s, o, rows, K,
+                           static_cast<float *>(out), ld_out);
+    else if (out_dtype == PIKA_BF16)
+        hipLaunchKernelGGL(transpose_cast_kernel<__bf16>, grid, dim3(256), 0, s, o, rows, K,
+                           static_cast<__bf16 *>(out), ld_out);
+    else
+        return PIKA_EINVAL;
+    return (int)hipGetLastError();
+}
+
+int pika_colsum(const float *x, long long ld, int rows, int cols, float *out, void *stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    const int chunks = max(1, min(256, rows / 256));
+    const int rpb = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, x, ld, rows,
+                       cols, rpb, out);
+    return (int)hipGetLastError();
+}
+
+int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C, int taps,
+                int stride, int dil, int pad, void *stream) {
+    if (!dcol || !dx || B <= 0 || t_out <= 0 || t_in <= 0 || C <= 0 || taps <= 0 || stride <= 0)
+        return PIKA_EINVAL;
+    const long long total = (long long)B * t_in * C;
+    hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dcol, dx, B, t_out, t_in, C, taps, stride,
+                       dil, pad);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""autograd Functions backed by libpika_amd.so (GPU tensors only).
+
+Forward AND backward GEMMs run on the hand-written MFMA kernel (pika_gemm_nt): the backward
+operands that the NT form needs with the other index contiguous (W^T, dY^T, X^T) are produced
+by pika_transpose_cast (fp32 -> bf16, or fp32 in fp32-split mode, written once), bias gradients by
+pika_colsum, the time-delay adjoint by pika_col2im.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .. import gemm as G
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pad4(n):
+    return (n + 3) & ~3
+
+
+def _tdtype():
+    # transposed operands: bf16 halves their traffic; the fp32-split mode needs the fp32 bits
+    return torch.float32 if G.PRECISION == "fp32" else torch.bfloat16
+
+
+def transpose_cast(op, rows, K, device):
+    """(K, pad4(rows)) transposed copy of a (virtual) operand, zero-padded columns."""
+    ld = _pad4(rows)
+    dt = _tdtype()
+    out = torch.empty((K, ld), dtype=dt, device=device)
+    rc = _lib.lib().pika_transpose_cast(ctypes.byref(op), rows, K, out.data_ptr(), ld,
+                                        G.PIKA_F32 if dt == torch.float32 else G.PIKA_BF16, _stream())
+    _lib.check(rc, "pika_transpose_cast")
+    return out
+
+
+def colsum(x2d):
+    out = torch.empty(x2d.shape[1], dtype=torch.float32, device=x2d.device)
+    _lib.check(_lib.lib().pika_colsum(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1],
+                                      out.data_ptr(), _stream()), "pika_colsum")
+    return out
+
+
+def _weight_t(w2d):
+    """W^T (K,N) for dX = dY @ W.  Weights are small next to activations; one pass per call."""
+    op, rows, K = G.matrix(w2d)
+    return transpose_cast(op, rows, K, w2d.device)
+
+
+def _grad_weight(dy2, a_op, M, Ka, N):
+    """dW[N,Ka] = dY^T[N,M] @ A[M,Ka] as an NT GEMM over the padded row index."""
+    dyt = transpose_cast(G.matrix(dy2)[0], M, N, dy2.device)       # (N, Mp)
+    at = transpose_cast(a_op, M, Ka, dy2.device)                    # (Ka, Mp)
+    return G.gemm_nt(dyt, at)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) over the last dim (nn.Linear semantics), optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or (x2.stride(0) & 3):
+            x2 = x2.contiguous()
+        with torch.cuda.device(x.device):
+            y = G.gemm_nt(x2, weight, bias=bias, relu=relu)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = dy.reshape(-1, N)
+        if ctx.relu:
+            dy2 = dy2 * (y > 0)
+        dy2 = dy2.contiguous()
+        M = dy2.shape[0]
+        dx = dw = db = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[0]:
+                if N % 4 == 0:
+                    dx = G.gemm_nt(dy2, _weight_t(weight)).view(*dy.shape[:-1], K)
+                else:  # reduction length not a multiple of 4: pad the (small) N axis
+                    Np = _pad4(N)
+                    dyp = torch.zeros((M, Np), device=dy.device)
+                    dyp[:, :N] = dy2
+                    wt = torch.zeros((K, Np), device=dy.device)
+                    wt[:, :N] = weight.t()
+                    dx = G.gemm_nt(dyp, wt).view(*dy.shape[:-1], K)
+            if ctx.needs_input_grad[1]:
+                dw = _grad_weight(dy2, G.matrix(x2)[0], M, K, N)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy2)
+        return dx, dw, db, None
+
+
+class TimeDelayFn(torch.autograd.Function):
+    """y[b,t,n] = act(sum_{tap,c} W[n,tap*C+c] * x[b, t*stride + tap*dil - pad, c] + bias[n]).
+
+    TDNN layers (pad 0) and the causal Conv1d of the prediction net (taps 5, pad 4) as ONE GEMM
+    over a virtual operand: im2col is never materialised in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, x, w2d, bias, taps, dil, stride, pad, relu):
+        x = x.contiguous()
+        Bn, T, C = x.shape
+        N = w2d.shape[0]
+        with torch.cuda.device(x.device):
+            a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
+            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            G.launch(a_op, G.matrix(w2d)[0], y, N, M, N, K, bias=bias, relu=relu)
+        ctx.cfg = (taps, dil, stride, pad, relu, t_out)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w2d, y if relu else None)
+        return y.view(Bn, t_out, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2d, y = ctx.saved_tensors
+        taps, dil, stride, pad, relu, t_out = ctx.cfg
+        Bn, T, C = x.shape
+        N, K = w2d.shape
+        dy2 = dy.reshape(-1, N)
+        if relu:
+            dy2 = dy2 * (y > 0)
+        dy2 = dy2.contiguous()
+        M = dy2.shape[0]
+        dx = dw = db = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[0]:
+                dcol = G.gemm_nt(dy2, _weight_t(w2d))  # (M, taps*C)
+                dx = torch.empty_like(x)
+                _lib.check(_lib.lib().pika_col2im(dcol.data_ptr(), dx.data_ptr(), Bn, t_out, T, C,
+                                                  taps, stride, dil, pad, _stream()), "pika_col2im")
+            if ctx.needs_input_grad[1]:
+                a_op = G.time_delay(x, taps, dil, stride, pad)[0]
+                dw = _grad_weight(dy2, a_op, M, K, N)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy2)
+        return dx, dw, db, None, None, None, None, None

@@ -10,8 +10,21 @@ import torch
 import torch.nn.functional as F
 
 
-def linear(x, weight, bias=None):
-    return F.linear(x, weight, bias)
+def _hip(x):
+    return x.is_cuda
+
+
+def _gemm_ok(*dims):
+    return all(d % 4 == 0 for d in dims)
+
+
+def linear(x, weight, bias=None, relu=False):
+    """nn.Linear semantics (+ optional fused ReLU epilogue); MFMA GEMM kernel on the GPU."""
+    if _hip(x) and _gemm_ok(weight.shape[1]):
+        from .hipops import LinearFn
+        return LinearFn.apply(x, weight, bias, relu)
+    y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y
 
 
 def relu(x):
@@ -49,6 +62,9 @@ def tdnn(x, weight, bias, dilation, stride):
     GEMM with K = taps*C over time-shifted views -- never as a convolution."""
     N, _, taps, C = weight.shape
     B, T, _ = x.shape
+    if _hip(x) and _gemm_ok(C):
+        from .hipops import TimeDelayFn
+        return TimeDelayFn.apply(x, weight.reshape(N, taps * C), bias, taps, dilation, stride, 0, False)
     span = T - dilation * (taps - 1)
     t_out = (span - 1) // stride + 1
     cols = [x[:, j * dilation: j * dilation + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
@@ -63,6 +79,10 @@ def causal_conv1d(x, weight, bias):
     (rnnt_conv_transformer_lm.py:36-45,73)."""
     N, C, k = weight.shape
     B, T, _ = x.shape
+    if _hip(x) and _gemm_ok(C):
+        from .hipops import TimeDelayFn
+        w2 = weight.permute(0, 2, 1).reshape(N, k * C)  # tap-major columns
+        return TimeDelayFn.apply(x, w2, bias, k, 1, 1, k - 1, False)
     xp = F.pad(x, (0, 0, k - 1, 0))
     a = torch.cat([xp[:, j: j + T, :] for j in range(k)], dim=-1)  # (B,T,k*C), tap-major
     w = weight.permute(0, 2, 1).reshape(N, k * C)

@@ -1,0 +1,119 @@
+"""MFMA GEMM (include/pika_gemm.h) vs fp64 matmul of the same operands.
+bf16 mode: products of bf16-rounded operands, fp32 accumulate -> compared against the fp64
+product OF THE ROUNDED operands (tight) and of the raw operands (loose, 2^-8 relative per
+element).  fp32 mode (3-way bf16 split, 6 MFMAs): fp32-class accuracy -> 1e-6 of the row scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref(a, b, bias=None, relu=False):
+    c = a.double() @ b.double().t()
+    if bias is not None:
+        c = c + bias.double()
+    return torch.relu(c) if relu else c
+
+
+def err_scale(a, b):
+    return (a.double().abs() @ b.double().abs().t()).clamp_min(1e-30)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (16, 16, 32), (1, 4, 4), (300, 200, 64),
+                                   (257, 130, 100), (1000, 5000, 1024), (2048, 1024, 240),
+                                   (333, 100, 3072)])
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_plain_nt(hip_device, M, N, K, precision):
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    # asymmetric, non-square data: a transposed or row/col-swapped kernel cannot pass
+    a = (torch.randn(M, K, generator=g) + 0.3 * torch.arange(K) / K).to(hip_device)
+    b = (torch.randn(N, K, generator=g) * (1 + torch.arange(N).unsqueeze(1) / N)).to(hip_device)
+    bias = torch.randn(N, generator=g).to(hip_device)
+    out = G.gemm_nt(a, b, bias=bias, relu=False, precision=precision)
+    torch.cuda.synchronize()
+    if precision == "bf16":
+        ar, br = a.bfloat16().float(), b.bfloat16().float()
+        e = (out.double() - ref(ar, br, bias)).abs() / err_scale(ar, br)
+        assert e.max().item() < 2e-6 * max(1.0, K ** 0.5 / 8), e.max().item()  # fp32 accumulation only
+        e2 = (out.double() - ref(a, b, bias)).abs() / err_scale(a, b)
+        assert e2.max().item() < 2 ** -7
+    else:
+        e = (out.double() - ref(a, b, bias)).abs() / err_scale(a, b)
+        assert e.max().item() < 1e-6 * max(1.0, K ** 0.5 / 8), e.max().item()
+
+
+def test_epilogues_and_strided_output(hip_device):
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(200, 96, generator=g).to(hip_device)
+    b = torch.randn(72, 96, generator=g).to(hip_device)
+    bias = torch.randn(72, generator=g).to(hip_device)
+    big = torch.full((200, 160), 7.0, device=hip_device)
+    out = big[:, 40:112]  # ldc = 160, column offset: 16-byte aligned
+    G.gemm_nt(a, b, bias=bias, relu=True, out=out, precision="fp32")
+    want = ref(a, b, bias, relu=True)
+    assert ((out.double() - want).abs() / err_scale(a, b).clamp_min(1)).max() < 2e-6
+    assert torch.all(big[:, :40] == 7.0) and torch.all(big[:, 112:] == 7.0)
+    prev = out.clone()
+    G.gemm_nt(a, b, out=out, accumulate=True, precision="fp32")
+    assert ((out.double() - (prev.double() + ref(a, b))).abs() / err_scale(a, b).clamp_min(1)).max() < 2e-6
+    # unaligned output rows (ldc % 4 != 0) take the scalar epilogue
+    odd = torch.zeros(200, 73, device=hip_device)
+    G.gemm_nt(a, b, bias=bias, out=odd[:, :72], precision="fp32")
+    assert ((odd[:, :72].double() - ref(a, b, bias)).abs() / err_scale(a, b).clamp_min(1)).max() < 2e-6
+
+
+def test_bf16_operands_and_errors(hip_device):
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(130, 64, generator=g).to(hip_device)
+    b = torch.randn(90, 64, generator=g).to(hip_device)
+    o1 = G.gemm_nt(a.bfloat16(), b.bfloat16(), precision="bf16")
+    o2 = G.gemm_nt(a, b, precision="bf16")
+    assert torch.equal(o1, o2)  # rounding on the fly == pre-rounded operands
+    o3 = G.gemm_nt(a.bfloat16(), b, precision="bf16")
+    assert torch.equal(o1, o3)
+    with pytest.raises(RuntimeError):  # K % 4 != 0 is refused, not silently mis-computed
+        G.gemm_nt(a[:, :63].contiguous(), b[:, :63].contiguous())
+
+
+@pytest.mark.parametrize("taps,dil,stride,pad,T,C,N", [(3, 1, 1, 0, 50, 64, 96), (3, 3, 1, 0, 77, 32, 40),
+                                                     (3, 3, 4, 0, 90, 64, 64), (5, 1, 1, 4, 23, 16, 48)])
+def test_time_delay_operand(hip_device, taps, dil, stride, pad, T, C, N):
+    """Virtual im2col operand == explicit shifted-view concatenation (model/ops.py tdnn /
+    causal_conv1d, which mirror rnnt_tdnn_transformer.py:44-57 and rnnt_conv_transformer_lm.py:73)."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(taps * 100 + dil * 10 + stride)
+    Bn = 3
+    x = torch.randn(Bn, T, C, generator=g).to(hip_device)
+    w = torch.randn(N, taps * C, generator=g).to(hip_device)
+    a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
+    b_op, _, _ = G.matrix(w)
+    out = torch.empty(M, N, device=hip_device)
+    G.launch(a_op, b_op, out, N, M, N, K, precision="fp32")
+    xp = torch.nn.functional.pad(x, (0, 0, pad, 0))
+    cols = [xp[:, j * dil: j * dil + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
+    a = torch.cat(cols, -1).reshape(M, K)
+    want = ref(a, w)
+    assert ((out.double() - want).abs() / err_scale(a, w)).max() < 2e-6
+
+
+def test_batched_strided_attention_shapes(hip_device):
+    """scores[b,h] = q[b,:,h,:] @ k[b,:,h,:]^T on (B,T,H*D) tensors: z = b*H + h."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(9)
+    Bn, T, H, D = 2, 70, 4, 16
+    q = torch.randn(Bn, T, H * D, generator=g).to(hip_device)
+    k = torch.randn(Bn, T, H * D, generator=g).to(hip_device)
+    a_op = G.Operand(q.data_ptr(), 0, T, T, 0, H * D, D, 1, 0, 0, T * H * D, D)
+    b_op = G.Operand(k.data_ptr(), 0, T, T, 0, H * D, D, 1, 0, 0, T * H * D, D)
+    out = torch.empty(Bn, H, T, T, device=hip_device)
+    G.launch(a_op, b_op, out, T, T, T, D, precision="fp32", batch=Bn * H, z_div=H,
+             c_z_outer=H * T * T, c_z_inner=T * T)
+    qh = q.view(Bn, T, H, D).transpose(1, 2).double()
+    kh = k.view(Bn, T, H, D).transpose(1, 2).double()
+    want = qh @ kh.transpose(2, 3)
+    scale = qh.abs() @ kh.abs().transpose(2, 3)
+    assert ((out.double() - want).abs() / scale).max() < 2e-6

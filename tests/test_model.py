@@ -90,4 +90,30 @@ def test_full_size_parameter_count_and_pickle_roundtrip(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dec", ["transformer", "rnn"])
 def test_gpu_matches_reference_golden(hip_device, dec):
-    run_parity(dec, hip_device)
+    """fp32-parity arithmetic (fp32-split split MFMA): 1e-3 rel, the north_star tolerance."""
+    from pika_amd import gemm as G
+    old = G.PRECISION
+    G.PRECISION = "fp32"
+    try:
+        run_parity(dec, hip_device)
+    finally:
+        G.PRECISION = old
+
+
+@pytest.mark.gpu
+def test_gpu_bf16_arithmetic_stays_close(hip_device):
+    """Config-2 arithmetic (bf16 operands, fp32 accumulate): activations within 3e-2 of the fp32
+    reference relative to the tensor scale (documented tolerance of the bf16 mode)."""
+    from pika_amd import gemm as G
+    old = G.PRECISION
+    G.PRECISION = "bf16"
+    try:
+        z = np.load(os.path.join(HERE, "golden", "model_tiny_transformer.npz"))
+        net = ours("transformer", hip_device)
+        x, y, y_len, w = [t.to(hip_device) for t in C.inputs()]
+        net.eval()
+        with torch.no_grad():
+            close(net.encoder(x), z["enc_eval"], rtol=3e-2)
+            close(net(x, y, None, True), z["joint_eval"], rtol=3e-2)
+    finally:
+        G.PRECISION = old
