@@ -65,8 +65,57 @@ def cpu_baseline(lp, labels, tl, ul, n_utts, min_seconds=10.0):
                                                        x.shape[3], el)}, costs
 
 
+def train_step_workload(args, dev, rank, world):
+    """one full training step of the config-2 model (TDNN-Transformer encoder,
+    conv-transformer prediction net, gated joint, RNN-T loss, backward, inf-norm clip, Nesterov
+    SGD) on synthetic 80-d fbank spliced to 240, resident in HBM.  Lattice T' = 240."""
+    from types import SimpleNamespace
+    from model.transducer import Net  # drop-in import path of the training script
+    from warp_rnnt import RNNTLoss
+    from pika_amd.features import SpecAugment, cmvn_apply_
+    B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
+                          encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
+                          embd_dim=100, padding_idx=V)
+    torch.manual_seed(777 + rank)
+    np.random.seed(777 + rank)
+    model = Net(opt, 240, V).to(dev)
+    model.train()
+    g = torch.Generator(device=dev)
+    g.manual_seed(2000 + rank)
+    feats = torch.randn(B, T, 80, generator=g, device=dev) * 4 + 8
+    data0 = torch.cat((torch.cat((feats[:, :1], feats[:, :-1]), 1), feats,
+                       torch.cat((feats[:, 1:], feats[:, -1:]), 1)), -1).contiguous()
+    labels = torch.randint(1, V, (B, U), generator=g, device=dev)
+    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ali = torch.full((B,), U, dtype=torch.int32, device=dev)
+    offset = torch.full((240,), -8.0, device=dev)
+    scale = torch.full((240,), 0.25, device=dev)
+    loss_fn = RNNTLoss(blank=0, reduction="sum").apply
+    aug = SpecAugment(15, 35)
+    optim = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
+
+    def step():
+        optim.zero_grad(set_to_none=True)
+        len_b = lens - 42                       # train_transducer_bmuf_otfaug.py:80-82
+        len_b = len_b // 4 + (len_b % 4 != 0).int()
+        data = data0.clone()
+        cmvn_apply_(data, offset, scale, cmn=True)
+        aug.apply(data)
+        out = model(data, labels, len_b, True)
+        loss = loss_fn(out, labels.int(), len_b, ali).sum()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+        optim.step()
+        return loss
+
+    flops_per_utt = 730e9  # SURVEY 8d M2: ~243 GF fwd, x3 fwd+bwd (split fc1/fc_gate)
+    return step, flops_per_utt
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "train_step"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -93,6 +142,44 @@ def main():
     from pika_amd import rnnt as R
 
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    if args.workload == "train_step":
+        step, flops_per_utt = train_step_workload(args, dev, rank, world)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        if rank == 0:
+            from pika_amd import gemm as G
+            tf = flops_per_utt * B / (el / args.steps) / 1e12
+            print(json.dumps({
+                "metric": "utterances/sec RNNT train step (T_in=%d,U=%d,V=%d)" % (T, U, V),
+                "value": B * world / (el / args.steps), "unit": "utterances/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16" if G.PRECISION == "bf16" else "f32-split", "data": "synthetic",
+                "config": {"workload": "train_step: full PIKA TDNN-Transformer RNN-T, CMVN+SpecAugment, "
+                                       "fwd, RNN-T loss, bwd, clip, SGD", "batch_per_gpu": B,
+                           "T_in": T, "T_enc": 240, "U": U, "V": V, "loss": float(loss.item())},
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
+                             "frac": tf / 2500.0, "traffic": None}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     lp, labels, tl, ul = make_inputs(B, T, U, V, dev, 1234 + 100 * rank)
     lp.requires_grad_(True)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply

@@ -1,0 +1,42 @@
+/*
+ * include/pika_joint.h -- C ABI of the joint-network kernels around the fc2 GEMM.
+ *
+ * Reference: /root/reference/trainer/model/transducer.py:98-111
+ *   out = fc2(tanh(fc1(z)) * sigmoid(fc_gate(z))),  z = cat(enc[b,t], pred[b,u]);  log_softmax
+ * and its decode-time twin /root/reference/decoder/transducer_decoder.py:173-177.
+ * With fc1/fc_gate split into encoder/prediction halves:
+ *   h[b,t,u,:] = tanh(e1[b,t,:] + p1[b,u,:]) * sigmoid(eg[b,t,:] + pg[b,u,:])
+ * Conventions as in pika_rnnt.h.
+ */
+#ifndef PIKA_JOINT_H
+#define PIKA_JOINT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* h (B,T,U,H) = tanh(e1+p1)*sigmoid(eg+pg); e* (B,T,H), p* (B,U,H) f32 contiguous; H % 4 == 0.
+ * out_dtype PIKA_F32 | PIKA_BF16 (pika_gemm.h). */
+int pika_joint_gate_fwd(const float *e1, const float *p1, const float *eg, const float *pg,
+                        void *h, int out_dtype, int B, int T, int U, int H, void *stream);
+
+/* Backward of the gate given dh (B,T,U,H) f32: de1/deg (B,T,H) = sum over u, dp1/dpg (B,U,H) =
+ * sum over t of  dz1 = dh*sig(zg)*(1-tanh(z1)^2),  dzg = dh*tanh(z1)*sig(zg)*(1-sig(zg)).
+ * tanh/sigmoid are recomputed from e*,p* (nothing of size B*T*U*H is kept from the forward). */
+int pika_joint_gate_bwd(const float *dh, const float *e1, const float *p1, const float *eg,
+                        const float *pg, float *de1, float *dp1, float *deg, float *dpg,
+                        int B, int T, int U, int H, void *stream);
+
+/* In place on x (rows, cols) f32 with pitch ld: x = log_softmax(scale * x) per row. */
+int pika_log_softmax_rows(float *x, long long rows, int cols, long long ld, float scale,
+                          void *stream);
+
+/* In place on g: g = scale * (g - exp(lp) * rowsum(g))  (log-softmax backward; lp = the
+ * forward output, same shape/pitch). */
+int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int cols, long long ld,
+                              float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_JOINT_H */

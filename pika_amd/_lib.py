@@ -33,6 +33,11 @@ SIGNATURES = {
     "pika_transpose_cast": (_i, [_vp, _i, _i, _vp, _ll, _i, _vp]),
     "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    # include/pika_joint.h
+    "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pika_joint_gate_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),
+    "pika_log_softmax_rows": (_i, [_vp, _ll, _i, _ll, ctypes.c_float, _vp]),
+    "pika_log_softmax_bwd_rows": (_i, [_vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
 }
 
 _lib = None

@@ -42,7 +42,7 @@ struct Loader {
     int tap, c;           // decomposition of this thread's current k
     int k, K;
 
-    __device__ inline void init(const Op &o, long long zoff, int r0, int nrows, int K_) {
+    __device__ inline void init(const Op &o, long long zoff, int r0, int nrows, int K_, int k0) {
         const int tid = threadIdx.x;
         base = reinterpret_cast<const T *>(o.ptr) + zoff;
         ld = o.ld; t_in = o.t_in; C = o.C; dil = o.dil; K = K_;
@@ -58,7 +58,7 @@ struct Loader {
                 tbase[i] = -(1 << 29);
             }
         }
-        k = (tid & 7) * 4;
+        k = k0 + (tid & 7) * 4;
         tap = k / C;
         c = k - tap * C;
     }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo
                                                       long long b_zo, long long b_zi,
                                                       float *__restrict__ Cp, long long ldc,
                                                       long long c_zo, long long c_zi, int M, int N,
-                                                      int K, int z_div,
+                                                      int K, int z_div, int splitk,
                                                       const float *__restrict__ bias, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: [buf][A parts 0..NS-1 | B parts 0..NS-1]
@@ -117,15 +117,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo
     constexpr int BOFF = NS * TILE_ELEMS;
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
 
-    const int z = blockIdx.z, zo = z / z_div, zi = z - zo * z_div;
+    // split-K (only with batch == 1): blockIdx.z indexes a K range and the epilogue accumulates
+    // with atomics into a zeroed C
+    const int split = splitk > 1 ? blockIdx.z : 0;
+    const int z = splitk > 1 ? 0 : blockIdx.z, zo = z / z_div, zi = z - zo * z_div;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     Loader<TA> la;
     Loader<TB> lb;
-    la.init(A, zo * a_zo + zi * a_zi, m0, M, K);
-    lb.init(B, zo * b_zo + zi * b_zi, n0, N, K);
+    const int nk_all = (K + BK - 1) / BK;
+    const int nk_per = (nk_all + splitk - 1) / splitk;
+    const int kb0 = split * nk_per;
+    const int nk = min(nk_all, kb0 + nk_per) - kb0;
+    if (nk <= 0) return;
+    la.init(A, zo * a_zo + zi * a_zi, m0, M, K, kb0 * BK);
+    lb.init(B, zo * b_zo + zi * b_zi, n0, N, K, kb0 * BK);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -134,7 +142,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[4], rb[4];
-    const int nk = (K + BK - 1) / BK;
     la.load(ra);
     lb.load(rb);
     stage<NS>(lds, TILE_ELEMS, ra);
@@ -191,6 +198,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo
             if (n >= N) continue;
             f32x4 v = acc[i][j];
             float *dst = Cz + (long long)m * ldc + n;
+            if (splitk > 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) atomicAdd(dst + e, v[e] + ((bias && split == 0) ? bias[n + e] : 0.f));
+                continue;
+            }
             if (n + 3 < N && vec_ok) {
                 if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);  // bias + n: n%4==0
                 if (accum) v += *reinterpret_cast<const f32x4 *>(dst);
@@ -242,9 +255,24 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    // split-K when the output grid cannot fill 256 CUs and the reduction is long (weight
+    // gradients: M,N ~ 1e3, K = rows ~ 3e4).  Not combinable with ReLU / accumulate.
+    const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
+    const int nk = (K + BK - 1) / BK;
+    int splitk = 1;
+    if (batch == 1 && tiles < 256 && nk >= 32 && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
+        splitk = (512 + tiles - 1) / tiles;
+        if (splitk > nk / 8) splitk = nk / 8;
+        if (splitk > 64) splitk = 64;
+        if (splitk < 1) splitk = 1;
+    }
+    if (splitk > 1) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splitk > 1 ? splitk : batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, to_op(*A), to_op(*B), A->z_outer, A->z_inner,
-                       B->z_outer, B->z_inner, C, ldc, c_zo, c_zi, M, N, K, z_div, bias, flags);
+                       B->z_outer, B->z_inner, C, ldc, c_zo, c_zi, M, N, K, z_div, splitk, bias, flags);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,252 @@
+// pika_amd/csrc/joint.hip -- joint-network elementwise / row kernels for gfx950
+// (include/pika_joint.h; reference trainer/model/transducer.py:98-111).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pika_gemm.h"
+#include "pika_joint.h"
+#include "pika_rnnt.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float fast_tanh(float x) {
+    // 1 - 2/(e^{2x}+1): exact limits at +-inf, abs error ~1e-7
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ inline float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ inline f32x4 gate4(f32x4 z1, f32x4 zg) {
+    f32x4 r;
+    r.x = fast_tanh(z1.x) * fast_sigmoid(zg.x);
+    r.y = fast_tanh(z1.y) * fast_sigmoid(zg.y);
+    r.z = fast_tanh(z1.z) * fast_sigmoid(zg.z);
+    r.w = fast_tanh(z1.w) * fast_sigmoid(zg.w);
+    return r;
+}
+
+// grid (T, B), block H/4 threads (<= 1024): thread owns 4 channels, loops over u.
+template <typename TOUT>
+__global__ void gate_fwd_kernel(const float *__restrict__ e1, const float *__restrict__ p1,
+                                const float *__restrict__ eg, const float *__restrict__ pg,
+                                TOUT *__restrict__ h, int T, int U, int H) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    const int H4 = H >> 2;
+    for (int c = threadIdx.x; c < H4; c += blockDim.x) {
+        const f32x4 a1 = reinterpret_cast<const f32x4 *>(e1 + ((size_t)b * T + t) * H)[c];
+        const f32x4 ag = reinterpret_cast<const f32x4 *>(eg + ((size_t)b * T + t) * H)[c];
+        for (int u = 0; u < U; ++u) {
+            const f32x4 b1 = reinterpret_cast<const f32x4 *>(p1 + ((size_t)b * U + u) * H)[c];
+            const f32x4 bg = reinterpret_cast<const f32x4 *>(pg + ((size_t)b * U + u) * H)[c];
+            const f32x4 r = gate4(a1 + b1, ag + bg);
+            TOUT *dst = h + (((size_t)b * T + t) * U + u) * H + 4 * c;
+            if constexpr (sizeof(TOUT) == 4)
+                *reinterpret_cast<f32x4 *>(dst) = r;
+            else
+                *reinterpret_cast<bf16x4 *>(dst) = __builtin_convertvector(r, bf16x4);
+        }
+    }
+}
+
+__device__ inline void gate_grads(float z1, float zg, float dh, float &d1, float &dg) {
+    const float th = fast_tanh(z1), sg = fast_sigmoid(zg);
+    d1 = dh * sg * (1.0f - th * th);
+    dg = dh * th * sg * (1.0f - sg);
+}
+
+// REDUCE_U: grid (T,B): sums over u -> de1/deg[b,t,:].  else grid (U,B): sums over t -> dp1/dpg.
+template <bool REDUCE_U>
+__global__ void gate_bwd_kernel(const float *__restrict__ dh, const float *__restrict__ e1,
+                                const float *__restrict__ p1, const float *__restrict__ eg,
+                                const float *__restrict__ pg, float *__restrict__ o1,
+                                float *__restrict__ og, int T, int U, int H) {
+    const int b = blockIdx.y, fixed = blockIdx.x;
+    const int H4 = H >> 2;
+    const int n = REDUCE_U ? U : T;
+    for (int c = threadIdx.x; c < H4; c += blockDim.x) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, sg = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < n; ++i) {
+            const int t = REDUCE_U ? fixed : i, u = REDUCE_U ? i : fixed;
+            const f32x4 z1 = reinterpret_cast<const f32x4 *>(e1 + ((size_t)b * T + t) * H)[c] +
+                             reinterpret_cast<const f32x4 *>(p1 + ((size_t)b * U + u) * H)[c];
+            const f32x4 zg = reinterpret_cast<const f32x4 *>(eg + ((size_t)b * T + t) * H)[c] +
+                             reinterpret_cast<const f32x4 *>(pg + ((size_t)b * U + u) * H)[c];
+            const f32x4 d = reinterpret_cast<const f32x4 *>(dh + (((size_t)b * T + t) * U + u) * H)[c];
+            float a, g;
+            gate_grads(z1.x, zg.x, d.x, a, g); s1.x += a; sg.x += g;
+            gate_grads(z1.y, zg.y, d.y, a, g); s1.y += a; sg.y += g;
+            gate_grads(z1.z, zg.z, d.z, a, g); s1.z += a; sg.z += g;
+            gate_grads(z1.w, zg.w, d.w, a, g); s1.w += a; sg.w += g;
+        }
+        const size_t o = ((size_t)b * (REDUCE_U ? T : U) + fixed) * H;
+        reinterpret_cast<f32x4 *>(o1 + o)[c] = s1;
+        reinterpret_cast<f32x4 *>(og + o)[c] = sg;
+    }
+}
+
+// ---- row kernels: one 256-thread workgroup per row, row held in registers (cols <= 8192) ----
+constexpr int ROW_THREADS = 256;
+constexpr int MAXQ = 8;  // float4 per thread
+
+__device__ inline float block_reduce(float v, bool is_max, float *lds) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    v = lds[0];
+#pragma unroll
+    for (int w = 1; w < ROW_THREADS / 64; ++w) v = is_max ? fmaxf(v, lds[w]) : v + lds[w];
+    __syncthreads();
+    return v;
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void log_softmax_kernel(float *__restrict__ x, int cols,
+                                                                  long long ld, float scale) {
+    __shared__ float lds[ROW_THREADS / 64];
+    float *row = x + (long long)blockIdx.x * ld;
+    const bool vec = ((cols & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec && cols <= ROW_THREADS * 4 * MAXQ) {
+        const int c4 = cols >> 2;
+        f32x4 v[MAXQ];
+        float m = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int i = threadIdx.x + q * ROW_THREADS;
+            if (i < c4) {
+                v[q] = reinterpret_cast<const f32x4 *>(row)[i] * scale;
+                m = fmaxf(m, fmaxf(fmaxf(v[q].x, v[q].y), fmaxf(v[q].z, v[q].w)));
+            }
+        }
+        m = block_reduce(m, true, lds);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int i = threadIdx.x + q * ROW_THREADS;
+            if (i < c4) s += __expf(v[q].x - m) + __expf(v[q].y - m) + __expf(v[q].z - m) + __expf(v[q].w - m);
+        }
+        s = block_reduce(s, false, lds);
+        const float lse = m + __logf(s);
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int i = threadIdx.x + q * ROW_THREADS;
+            if (i < c4) reinterpret_cast<f32x4 *>(row)[i] = v[q] - lse;
+        }
+    } else {
+        float m = -INFINITY;
+        for (int i = threadIdx.x; i < cols; i += ROW_THREADS) m = fmaxf(m, row[i] * scale);
+        m = block_reduce(m, true, lds);
+        float s = 0.f;
+        for (int i = threadIdx.x; i < cols; i += ROW_THREADS) s += __expf(row[i] * scale - m);
+        s = block_reduce(s, false, lds);
+        const float lse = m + __logf(s);
+        for (int i = threadIdx.x; i < cols; i += ROW_THREADS) row[i] = row[i] * scale - lse;
+    }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void log_softmax_bwd_kernel(const float *__restrict__ lp,
+                                                                      float *__restrict__ g, int cols,
+                                                                      long long ld, float scale) {
+    __shared__ float lds[ROW_THREADS / 64];
+    const float *lrow = lp + (long long)blockIdx.x * ld;
+    float *grow = g + (long long)blockIdx.x * ld;
+    const bool vec = ((cols & 3) == 0) && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(lp) & 15) == 0);
+    if (vec && cols <= ROW_THREADS * 4 * MAXQ) {
+        const int c4 = cols >> 2;
+        f32x4 v[MAXQ];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int i = threadIdx.x + q * ROW_THREADS;
+            if (i < c4) {
+                v[q] = reinterpret_cast<const f32x4 *>(grow)[i];
+                s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+            }
+        }
+        s = block_reduce(s, false, lds);
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int i = threadIdx.x + q * ROW_THREADS;
+            if (i < c4) {
+                const f32x4 l = reinterpret_cast<const f32x4 *>(lrow)[i];
+                f32x4 r;
+                r.x = scale * (v[q].x - __expf(l.x) * s);
+                r.y = scale * (v[q].y - __expf(l.y) * s);
+                r.z = scale * (v[q].z - __expf(l.z) * s);
+                r.w = scale * (v[q].w - __expf(l.w) * s);
+                reinterpret_cast<f32x4 *>(grow)[i] = r;
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < cols; i += ROW_THREADS) s += grow[i];
+        s = block_reduce(s, false, lds);
+        for (int i = threadIdx.x; i < cols; i += ROW_THREADS)
+            grow[i] = scale * (grow[i] - __expf(lrow[i]) * s);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pika_joint_gate_fwd(const float *e1, const float *p1, const float *eg, const float *pg, void *h,
+                        int out_dtype, int B, int T, int U, int H, void *stream) {
+    if (!e1 || !p1 || !eg || !pg || !h || B <= 0 || T <= 0 || U <= 0 || H <= 0 || (H & 3))
+        return PIKA_EINVAL;
+    if (B > 65535) return PIKA_ETOOBIG;
+    const int threads = min(1024, ((H / 4 + 63) / 64) * 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == PIKA_F32)
+        hipLaunchKernelGGL(gate_fwd_kernel<float>, dim3(T, B), dim3(threads), 0, s, e1, p1, eg, pg,
+                           static_cast<float *>(h), T, U, H);
+    else if (out_dtype == PIKA_BF16)
+        hipLaunchKernelGGL(gate_fwd_kernel<__bf16>, dim3(T, B), dim3(threads), 0, s, e1, p1, eg, pg,
+                           static_cast<__bf16 *>(h), T, U, H);
+    else
+        return PIKA_EINVAL;
+    return (int)hipGetLastError();
+}
+
+int pika_joint_gate_bwd(const float *dh, const float *e1, const float *p1, const float *eg,
+                        const float *pg, float *de1, float *dp1, float *deg, float *dpg, int B, int T,
+                        int U, int H, void *stream) {
+    if (!dh || !e1 || !p1 || !eg || !pg || !de1 || !dp1 || !deg || !dpg || B <= 0 || T <= 0 ||
+        U <= 0 || H <= 0 || (H & 3))
+        return PIKA_EINVAL;
+    if (B > 65535) return PIKA_ETOOBIG;
+    const int threads = min(1024, ((H / 4 + 63) / 64) * 64);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3(T, B), dim3(threads), 0, s, dh, e1, p1, eg, pg,
+                       de1, deg, T, U, H);
+    hipLaunchKernelGGL(gate_bwd_kernel<false>, dim3(U, B), dim3(threads), 0, s, dh, e1, p1, eg, pg,
+                       dp1, dpg, T, U, H);
+    return (int)hipGetLastError();
+}
+
+int pika_log_softmax_rows(float *x, long long rows, int cols, long long ld, float scale,
+                          void *stream) {
+    if (!x || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), x, cols, ld, scale);
+    return (int)hipGetLastError();
+}
+
+int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int cols, long long ld,
+                              float scale, void *stream) {
+    if (!lp || !g || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), lp, g, cols, ld, scale);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

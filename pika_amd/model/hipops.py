@@ -66,12 +66,14 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or (x2.stride(0) & 3):
             x2 = x2.contiguous()
-        with torch.cuda.device(x.device):
-            y = G.gemm_nt(x2, weight, bias=bias, relu=relu)
+        N = weight.shape[0]
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)  # not a view:
+        with torch.cuda.device(x.device):                 # downstream ops may overwrite it in place
+            G.gemm_nt(x2, weight, bias=bias, relu=relu, out=out.view(-1, N))
         ctx.relu = relu
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x2, weight, y if relu else None)
-        return y.view(*x.shape[:-1], weight.shape[0])
+        ctx.save_for_backward(x2, weight, out if relu else None)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -79,7 +81,7 @@ class LinearFn(torch.autograd.Function):
         N, K = weight.shape
         dy2 = dy.reshape(-1, N)
         if ctx.relu:
-            dy2 = dy2 * (y > 0)
+            dy2 = dy2 * (y.view(-1, N) > 0)
         dy2 = dy2.contiguous()
         M = dy2.shape[0]
         dx = dw = db = None
@@ -114,12 +116,12 @@ class TimeDelayFn(torch.autograd.Function):
         N = w2d.shape[0]
         with torch.cuda.device(x.device):
             a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
-            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            y = torch.empty((Bn, t_out, N), dtype=torch.float32, device=x.device)
             G.launch(a_op, G.matrix(w2d)[0], y, N, M, N, K, bias=bias, relu=relu)
         ctx.cfg = (taps, dil, stride, pad, relu, t_out)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w2d, y if relu else None)
-        return y.view(Bn, t_out, N)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -129,7 +131,7 @@ class TimeDelayFn(torch.autograd.Function):
         N, K = w2d.shape
         dy2 = dy.reshape(-1, N)
         if relu:
-            dy2 = dy2 * (y > 0)
+            dy2 = dy2 * (y.view(-1, N) > 0)
         dy2 = dy2.contiguous()
         M = dy2.shape[0]
         dx = dw = db = None
@@ -145,3 +147,72 @@ class TimeDelayFn(torch.autograd.Function):
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy2)
         return dx, dw, db, None, None, None, None, None
+
+
+class GateFn(torch.autograd.Function):
+    """h[b,t,u,:] = tanh(e1[b,t]+p1[b,u]) * sigmoid(eg[b,t]+pg[b,u])  (include/pika_joint.h).
+
+    Output is bf16 in the bf16 arithmetic mode (it only feeds the fc2 MFMA GEMM, which would
+    round it anyway) and fp32 in the parity mode.  Nothing of size B*T*U*H is saved: the backward
+    recomputes tanh/sigmoid from the four small inputs."""
+
+    @staticmethod
+    def forward(ctx, e1, p1, eg, pg):
+        e1, p1, eg, pg = [t.contiguous() for t in (e1, p1, eg, pg)]
+        Bn, T, H = e1.shape
+        U = p1.shape[1]
+        dt = torch.float32 if G.PRECISION == "fp32" else torch.bfloat16
+        h = torch.empty((Bn, T, U, H), dtype=dt, device=e1.device)
+        with torch.cuda.device(e1.device):
+            _lib.check(_lib.lib().pika_joint_gate_fwd(
+                e1.data_ptr(), p1.data_ptr(), eg.data_ptr(), pg.data_ptr(), h.data_ptr(),
+                G.PIKA_F32 if dt == torch.float32 else G.PIKA_BF16, Bn, T, U, H, _stream()),
+                "pika_joint_gate_fwd")
+        ctx.save_for_backward(e1, p1, eg, pg)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        e1, p1, eg, pg = ctx.saved_tensors
+        Bn, T, H = e1.shape
+        U = p1.shape[1]
+        dh = dh.float().contiguous()
+        de1, deg = torch.empty_like(e1), torch.empty_like(eg)
+        dp1, dpg = torch.empty_like(p1), torch.empty_like(pg)
+        with torch.cuda.device(dh.device):
+            _lib.check(_lib.lib().pika_joint_gate_bwd(
+                dh.data_ptr(), e1.data_ptr(), p1.data_ptr(), eg.data_ptr(), pg.data_ptr(),
+                de1.data_ptr(), dp1.data_ptr(), deg.data_ptr(), dpg.data_ptr(), Bn, T, U, H,
+                _stream()), "pika_joint_gate_bwd")
+        return de1, dp1, deg, dpg
+
+
+class LogSoftmaxFn(torch.autograd.Function):
+    """log_softmax(scale * x) over the last dim, IN PLACE on x (the (B,T,U,V) logits buffer is
+    7.8 GB at config 2); backward rewrites the incoming dense gradient in place as well."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        assert x.is_contiguous()
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().pika_log_softmax_rows(x.data_ptr(), rows, cols, cols, float(scale),
+                                                        _stream()), "pika_log_softmax_rows")
+        ctx.mark_dirty(x)
+        ctx.scale = float(scale)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (lp,) = ctx.saved_tensors
+        cols = lp.shape[-1]
+        rows = lp.numel() // cols
+        if not g.is_contiguous():
+            g = g.contiguous()
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().pika_log_softmax_bwd_rows(lp.data_ptr(), g.data_ptr(), rows, cols,
+                                                            cols, ctx.scale, _stream()),
+                       "pika_log_softmax_bwd_rows")
+        return g, None

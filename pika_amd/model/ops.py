@@ -119,6 +119,16 @@ def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
     H = enc.shape[-1]
     w1e, w1p = fc1.weight[:, :H], fc1.weight[:, H:]
     wge, wgp = fc_gate.weight[:, :H], fc_gate.weight[:, H:]
+    if _hip(enc) and _gemm_ok(H, fc2.weight.shape[1]):
+        from .hipops import GateFn, LogSoftmaxFn
+        e1 = linear(enc, w1e.contiguous(), fc1.bias)
+        p1 = linear(pred, w1p.contiguous())
+        eg = linear(enc, wge.contiguous(), fc_gate.bias)
+        pg = linear(pred, wgp.contiguous())
+        out = linear(GateFn.apply(e1, p1, eg, pg), fc2.weight, fc2.bias)
+        if log_softmax:
+            out = LogSoftmaxFn.apply(out, scale)
+        return out
     e1 = F.linear(enc, w1e, fc1.bias)
     p1 = F.linear(pred, w1p)
     eg = F.linear(enc, wge, fc_gate.bias)

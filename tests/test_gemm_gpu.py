@@ -22,7 +22,7 @@ def err_scale(a, b):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (16, 16, 32), (1, 4, 4), (300, 200, 64),
                                    (257, 130, 100), (1000, 5000, 1024), (2048, 1024, 240),
-                                   (333, 100, 3072)])
+                                   (333, 100, 3072), (200, 300, 8192), (1024, 1024, 32000)])  # last two: split-K path
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_plain_nt(hip_device, M, N, K, precision):
     from pika_amd import gemm as G
