@@ -43,8 +43,9 @@ typedef struct {
 #define PIKA_GEMM_ACCUMULATE 2
 #define PIKA_GEMM_FP32SPLIT 4
 
-/* Requirements: K % 4 == 0, operand C % 4 == 0, every addressed row 16-byte (f32) / 8-byte (bf16)
- * aligned.  Returns PIKA_EINVAL otherwise (the caller decides; nothing falls back silently). */
+/* Requirements (16-byte operand loads): K % 4 == 0; with g = 4 for f32 / 8 for bf16 operands, C,
+ * ld and the batch strides must be multiples of g and the base pointer 16-byte aligned; the rows
+ * of a bf16 operand must be readable and ZERO up to the next multiple of 8 past K.  Returns PIKA_EINVAL otherwise (the caller decides; nothing falls back silently). */
 int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
                  long long c_z_outer, long long c_z_inner, int M, int N, int K, int batch,
                  int z_div, const float *bias, int flags, void *stream);

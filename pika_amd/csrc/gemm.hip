@@ -10,6 +10,7 @@
 // lane ends up with 4 CONSECUTIVE columns of one row of C -> 16-byte epilogue stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pika_gemm.h"
 #include "pika_rnnt.h"  // PIKA_EINVAL
@@ -20,9 +21,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PITCH = 40;                  // bf16 per LDS row (32 + 8 pad) = 80 bytes
-constexpr int TILE_ELEMS = 128 * PITCH;    // one operand tile in bf16 elements
+template <int WM_, int WN_, int BK_>
+struct Cfg {
+    static constexpr int WM = WM_, WN = WN_, BK = BK_;
+    static constexpr int BM = WM * 64, BN = WN * 64, THREADS = WM * WN * 64;
+    static constexpr int PITCH = BK + 8;  // bf16 per LDS row; (PITCH/2) dwords = 20 or 36: the 16
+                                          // rows of a fragment read land on 16 distinct 4-bank groups
+};
 
 struct Op {  // device-side copy of pika_operand_t
     const char *ptr;
@@ -31,15 +36,21 @@ struct Op {  // device-side copy of pika_operand_t
     int C, stride, dil, pad;
 };
 
-// Per-thread loader of one operand: rows r_i = r0 + tid/8 + 32 i (i<4), k quad = (tid%8)*4.
-template <typename T>
+// Per-thread loader of one operand tile (ROWS x BK): 16-byte loads (4 f32 or 8 bf16), TPR threads
+// per row, NP passes of RPP rows.
+template <typename T, int ROWS, typename CF>
 struct Loader {
+    static constexpr int EPL = 16 / sizeof(T);
+    static constexpr int TPR = CF::BK / EPL;
+    static constexpr int RPP = CF::THREADS / TPR;
+    static constexpr int NP = ROWS / RPP;
+    static_assert(ROWS % RPP == 0, "tile rows must be a multiple of rows per pass");
     const T *base;
-    long long rowoff[4];  // b * batch_stride
-    int tbase[4];         // t*stride - pad, or a huge negative for out-of-range rows
+    long long rowoff[NP];  // b * batch_stride
+    int tbase[NP];         // t*stride - pad, or a huge negative for out-of-range rows
     long long ld;
     int t_in, C, dil;
-    int tap, c;           // decomposition of this thread's current k
+    int tap, c;            // decomposition of this thread's current k
     int k, K;
 
     __device__ inline void init(const Op &o, long long zoff, int r0, int nrows, int K_, int k0) {
@@ -47,8 +58,8 @@ struct Loader {
         base = reinterpret_cast<const T *>(o.ptr) + zoff;
         ld = o.ld; t_in = o.t_in; C = o.C; dil = o.dil; K = K_;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + (tid >> 3) + 32 * i;
+        for (int i = 0; i < NP; ++i) {
+            const int r = r0 + tid / TPR + RPP * i;
             if (r < nrows) {
                 const int b = r / o.rows_per_batch, t = r - b * o.rows_per_batch;
                 rowoff[i] = (long long)b * o.batch_stride;
@@ -58,82 +69,95 @@ struct Loader {
                 tbase[i] = -(1 << 29);
             }
         }
-        k = k0 + (tid & 7) * 4;
+        k = k0 + (tid % TPR) * EPL;
         tap = k / C;
         c = k - tap * C;
     }
     __device__ inline void advance() {
-        k += BK;
-        c += BK;
+        k += CF::BK;
+        c += CF::BK;
         while (c >= C) { c -= C; ++tap; }
     }
-    __device__ inline void load(f32x4 v[4]) const {
+    // A 16-byte load never straddles a tap for f32 (C % 4 == 0); for bf16 it needs C % 8 == 0,
+    // which the host checks (bf16 operands are our own transposed copies / plain matrices).
+    __device__ inline void load(f32x4 raw[NP]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int ti = tbase[i] + tap * dil;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (k < K && ti >= 0 && ti < t_in) {
-                const T *p = base + rowoff[i] + (long long)ti * ld + c;
-                if constexpr (sizeof(T) == 4) {
-                    x = *reinterpret_cast<const f32x4 *>(p);
-                } else {
-                    const bf16x4 h = *reinterpret_cast<const bf16x4 *>(p);
-                    x = __builtin_convertvector(h, f32x4);
+            if (k < K && ti >= 0 && ti < t_in)
+                x = *reinterpret_cast<const f32x4 *>(base + rowoff[i] + (long long)ti * ld + c);
+            raw[i] = x;
+        }
+    }
+    // Stage into LDS: NS = 1 rounds to bf16; NS = 3 writes the exact 3-way bf16 split
+    // x = h + m + l (8+8+8 mantissa bits) into three consecutive tiles (stride `part`).
+    template <int NS>
+    __device__ inline void stage(__bf16 *dst, int part, const f32x4 raw[NP]) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int off = (tid / TPR + RPP * i) * CF::PITCH + (tid % TPR) * EPL;
+            if constexpr (sizeof(T) == 4) {
+                f32x4 r = raw[i];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bf16x4 h = __builtin_convertvector(r, bf16x4);
+                    *reinterpret_cast<bf16x4 *>(dst + s * part + off) = h;
+                    if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
+                }
+            } else {
+                *reinterpret_cast<f32x4 *>(dst + off) = raw[i];  // already bf16: parts 1,2 are zero
+                if constexpr (NS > 1) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 1; s < NS; ++s) *reinterpret_cast<f32x4 *>(dst + s * part + off) = z;
                 }
             }
-            v[i] = x;
         }
     }
 };
 
-// Stage one operand tile: NS = 1 rounds to bf16; NS = 3 writes the exact 3-way bf16 split
-// x = h + m + l (8+8+8 mantissa bits) into three consecutive tiles (stride `part`).
-template <int NS>
-__device__ inline void stage(__bf16 *dst, int part, const f32x4 v[4]) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int off = ((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 4;
-        f32x4 r = v[i];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const bf16x4 h = __builtin_convertvector(r, bf16x4);
-            *reinterpret_cast<bf16x4 *>(dst + s * part + off) = h;
-            if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
-        }
-    }
-}
-
-template <typename TA, typename TB, int NS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo, long long a_zi,
-                                                      long long b_zo, long long b_zi,
-                                                      float *__restrict__ Cp, long long ldc,
-                                                      long long c_zo, long long c_zi, int M, int N,
-                                                      int K, int z_div, int splitk,
-                                                      const float *__restrict__ bias, int flags) {
+template <typename TA, typename TB, int NS, typename CF>
+__global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
+    Op A, Op B, long long a_zo, long long a_zi, long long b_zo, long long b_zi,
+    float *__restrict__ Cp, long long ldc, long long c_zo, long long c_zi, int M, int N, int K,
+    int z_div, int splitk, const float *__restrict__ bias, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = CF::BM, BN = CF::BN, BK = CF::BK, PITCH = CF::PITCH;
+    constexpr int TA_ELEMS = BM * PITCH, TB_ELEMS = BN * PITCH;
     // layout: [buf][A parts 0..NS-1 | B parts 0..NS-1]
-    constexpr int PER_BUF = 2 * NS * TILE_ELEMS;
-    constexpr int BOFF = NS * TILE_ELEMS;
+    constexpr int BOFF = NS * TA_ELEMS;
+    constexpr int PER_BUF = NS * (TA_ELEMS + TB_ELEMS);
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
 
     // split-K (only with batch == 1): blockIdx.z indexes a K range and the epilogue accumulates
     // with atomics into a zeroed C
     const int split = splitk > 1 ? blockIdx.z : 0;
     const int z = splitk > 1 ? 0 : blockIdx.z, zo = z / z_div, zi = z - zo * z_div;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give every XCD a contiguous run of
+    // tiles (n fastest) so the tiles that share an A row-panel meet in one L2.
+    const int nx = gridDim.x, ntiles = nx * gridDim.y;
+    int tile = blockIdx.y * nx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / nx) * BM, n0 = (tile % nx) * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / CF::WN, wn = wave % CF::WN;
 
-    Loader<TA> la;
-    Loader<TB> lb;
+    Loader<TA, BM, CF> la;
+    Loader<TB, BN, CF> lb;
     const int nk_all = (K + BK - 1) / BK;
     const int nk_per = (nk_all + splitk - 1) / splitk;
     const int kb0 = split * nk_per;
     const int nk = min(nk_all, kb0 + nk_per) - kb0;
     if (nk <= 0) return;
-    la.init(A, zo * a_zo + zi * a_zi, m0, M, K, kb0 * BK);
-    lb.init(B, zo * b_zo + zi * b_zi, n0, N, K, kb0 * BK);
+    // a bf16 operand is read in 8-element groups: its rows are zero-padded to a multiple of 8
+    // by contract, so its bound is K rounded up (the other operand supplies the zeros)
+    la.init(A, zo * a_zo + zi * a_zi, m0, M, sizeof(TA) == 2 ? (K + 7) & ~7 : K, kb0 * BK);
+    lb.init(B, zo * b_zo + zi * b_zi, n0, N, sizeof(TB) == 2 ? (K + 7) & ~7 : K, kb0 * BK);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -141,11 +165,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[Loader<TA, BM, CF>::NP], rb[Loader<TB, BN, CF>::NP];
     la.load(ra);
     lb.load(rb);
-    stage<NS>(lds, TILE_ELEMS, ra);
-    stage<NS>(lds + BOFF, TILE_ELEMS, rb);
+    la.template stage<NS>(lds, TA_ELEMS, ra);
+    lb.template stage<NS>(lds + BOFF, TB_ELEMS, rb);
     __syncthreads();
 
     const int frow = lane & 15, fk = (lane >> 4) * 8;
@@ -165,21 +189,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(Op A, Op B, long long a_zo
         constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
         for (int p = NPAIR - 1; p >= 0; --p) {  // small terms first
-            bf16x8 fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8 *>(cur + PA[p] * TILE_ELEMS + (wm * 64 + i * 16 + frow) * PITCH + fk);
-                fb[i] = *reinterpret_cast<const bf16x8 *>(cur + BOFF + PB[p] * TILE_ELEMS + (wn * 64 + i * 16 + frow) * PITCH + fk);
+            for (int kk = 0; kk < BK; kk += 32) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = *reinterpret_cast<const bf16x8 *>(cur + PA[p] * TA_ELEMS + (wm * 64 + i * 16 + frow) * PITCH + kk + fk);
+                    fb[i] = *reinterpret_cast<const bf16x8 *>(cur + BOFF + PB[p] * TB_ELEMS + (wn * 64 + i * 16 + frow) * PITCH + kk + fk);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            stage<NS>(nxt, TILE_ELEMS, ra);
-            stage<NS>(nxt + BOFF, TILE_ELEMS, rb);
+            la.template stage<NS>(nxt, TA_ELEMS, ra);
+            lb.template stage<NS>(nxt + BOFF, TB_ELEMS, rb);
         }
         __syncthreads();
     }
@@ -236,19 +263,20 @@ Op to_op(const pika_operand_t &o) {
 bool operand_ok(const pika_operand_t &o, int K) {
     if (!o.ptr || o.rows_per_batch <= 0 || o.t_in <= 0 || o.C <= 0 || o.stride <= 0) return false;
     if (o.dtype != PIKA_F32 && o.dtype != PIKA_BF16) return false;
-    if ((o.C & 3) || (K & 3) || (o.ld & 3) || (o.batch_stride & 3) || (o.z_outer & 3) || (o.z_inner & 3))
+    const int g = o.dtype == PIKA_F32 ? 3 : 7;  // elements per 16-byte load - 1
+    if ((o.C & g) || (K & 3) || (o.ld & g) || (o.batch_stride & g) || (o.z_outer & g) || (o.z_inner & g))
         return false;
-    const uintptr_t align = o.dtype == PIKA_F32 ? 15 : 7;
-    return (reinterpret_cast<uintptr_t>(o.ptr) & align) == 0;
+    return (reinterpret_cast<uintptr_t>(o.ptr) & 15) == 0;
 }
 
-template <typename TA, typename TB, int NS>
+template <typename TA, typename TB, int NS, typename CF>
 int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
            long long c_zo, long long c_zi, int M, int N, int K, int batch, int z_div,
            const float *bias, int flags, hipStream_t s) {
-    constexpr size_t smem = (size_t)2 * 2 * NS * TILE_ELEMS * sizeof(__bf16);
+    constexpr size_t smem = (size_t)2 * NS * (CF::BM + CF::BN) * CF::PITCH * sizeof(__bf16);
+    static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;  // idempotent; racing threads set the same value
-    auto kern = gemm_nt_kernel<TA, TB, NS>;
+    auto kern = gemm_nt_kernel<TA, TB, NS, CF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -257,8 +285,8 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     }
     // split-K when the output grid cannot fill 256 CUs and the reduction is long (weight
     // gradients: M,N ~ 1e3, K = rows ~ 3e4).  Not combinable with ReLU / accumulate.
-    const int tiles = ((N + BN - 1) / BN) * ((M + BM - 1) / BM);
-    const int nk = (K + BK - 1) / BK;
+    const int tiles = ((N + CF::BN - 1) / CF::BN) * ((M + CF::BM - 1) / CF::BM);
+    const int nk = (K + CF::BK - 1) / CF::BK;
     int splitk = 1;
     if (batch == 1 && tiles < 256 && nk >= 32 && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
         splitk = (512 + tiles - 1) / tiles;
@@ -270,10 +298,38 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splitk > 1 ? splitk : batch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, to_op(*A), to_op(*B), A->z_outer, A->z_inner,
-                       B->z_outer, B->z_inner, C, ldc, c_zo, c_zi, M, N, K, z_div, splitk, bias, flags);
+    if ((M + CF::BM - 1) / CF::BM > 65535) return PIKA_ETOOBIG;
+    dim3 grid((N + CF::BN - 1) / CF::BN, (M + CF::BM - 1) / CF::BM, splitk > 1 ? splitk : batch);
+    hipLaunchKernelGGL(kern, grid, dim3(CF::THREADS), smem, s, to_op(*A), to_op(*B), A->z_outer,
+                       A->z_inner, B->z_outer, B->z_inner, C, ldc, c_zo, c_zi, M, N, K, z_div,
+                       splitk, bias, flags);
     return (int)hipGetLastError();
+}
+
+// Tile configuration: PIKA_GEMM_CFG=0..3 overrides (hardware A/B only).
+//   0: 128x128x32 / 4 waves   1: 128x128x64 / 4 waves   2: 256x128x64 / 8 waves   3: 256x128x32
+int cfg_override() {
+    static const int v = [] { const char *e = getenv("PIKA_GEMM_CFG"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
+template <typename TA, typename TB>
+int dispatch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+             long long c_zo, long long c_zi, int M, int N, int K, int batch, int z_div,
+             const float *bias, int flags, hipStream_t s) {
+#define ARGS A, B, C, ldc, c_zo, c_zi, M, N, K, batch, z_div, bias, flags, s
+    if (flags & PIKA_GEMM_FP32SPLIT) return launch<TA, TB, 3, Cfg<2, 2, 32>>(ARGS);
+    // measured on MI355X (tools/gemm_bench.py, profiles/r1_gemm_cfg_sweep.txt): 256x128x64 / 8 waves
+    // wins except for f32 x bf16 operands, where 128x128x64 does
+    int cfg = cfg_override();
+    if (cfg < 0) cfg = (sizeof(TA) == 4 && sizeof(TB) == 2) ? 1 : 2;
+    switch (cfg) {
+        case 0: return launch<TA, TB, 1, Cfg<2, 2, 32>>(ARGS);
+        case 2: return launch<TA, TB, 1, Cfg<4, 2, 64>>(ARGS);
+        case 3: return launch<TA, TB, 1, Cfg<4, 2, 32>>(ARGS);
+        default: return launch<TA, TB, 1, Cfg<2, 2, 64>>(ARGS);
+    }
+#undef ARGS
 }
 
 }  // namespace
@@ -284,20 +340,15 @@ extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, fl
                             void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || z_div <= 0) return PIKA_EINVAL;
     if (!operand_ok(*A, K) || !operand_ok(*B, K)) return PIKA_EINVAL;
-    if (batch > 65535 || (M + BM - 1) / BM > 65535) return PIKA_ETOOBIG;
+    if (batch > 65535) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool x3 = flags & PIKA_GEMM_FP32SPLIT;
     const int key = (A->dtype == PIKA_BF16 ? 2 : 0) | (B->dtype == PIKA_BF16 ? 1 : 0);
-#define GO(TA, TB)                                                                               \
-    return x3 ? launch<TA, TB, 3>(A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div,  \
-                                     bias, flags, s)                                             \
-              : launch<TA, TB, 1>(A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, \
-                                      bias, flags, s)
+#define ARGS A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, bias, flags, s
     switch (key) {
-        case 0: GO(float, float);
-        case 1: GO(float, __bf16);
-        case 2: GO(__bf16, float);
-        default: GO(__bf16, __bf16);
+        case 0: return dispatch<float, float>(ARGS);
+        case 1: return dispatch<float, __bf16>(ARGS);
+        case 2: return dispatch<__bf16, float>(ARGS);
+        default: return dispatch<__bf16, __bf16>(ARGS);
     }
-#undef GO
+#undef ARGS
 }

@@ -21,6 +21,10 @@ def _pad4(n):
     return (n + 3) & ~3
 
 
+def _pad8(n):
+    return (n + 7) & ~7
+
+
 def _tdtype():
     # transposed operands: bf16 halves their traffic; the fp32-split mode needs the fp32 bits
     return torch.float32 if G.PRECISION == "fp32" else torch.bfloat16
@@ -28,7 +32,7 @@ def _tdtype():
 
 def transpose_cast(op, rows, K, device):
     """(K, pad4(rows)) transposed copy of a (virtual) operand, zero-padded columns."""
-    ld = _pad4(rows)
+    ld = _pad8(rows)  # a multiple of 8 so the copy can be a bf16 GEMM operand (16-byte loads)
     dt = _tdtype()
     out = torch.empty((K, ld), dtype=dt, device=device)
     rc = _lib.lib().pika_transpose_cast(ctypes.byref(op), rows, K, out.data_ptr(), ld,

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 900 python bench.py --workload train_step --steps 3 --warmup 1 --batch ${1:-32} > gpurun_out/train_step.log 2>&1; echo "rc=$?" >> gpurun_out/train_step.log
 tail -5 gpurun_out/train_step.log
 export TMPDIR=/tmp; cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ts -- python $GRAFT_REPO_ROOT/bench.py --workload train_step --steps 2 --warmup 1 --batch ${1:-32} > $GRAFT_REPO_ROOT/gpurun_out/prof_ts.log 2>&1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_ts; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ts -- python $GRAFT_REPO_ROOT/bench.py --workload train_step --steps 2 --warmup 1 --batch ${1:-32} > $GRAFT_REPO_ROOT/gpurun_out/prof_ts.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv,glob
