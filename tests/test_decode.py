@@ -1,0 +1,68 @@
+"""Beam-search parity: our vectorised decoder vs golden n-best lists
+recorded from the REFERENCE decoder on the same tiny model (tests/golden/make_decode_golden.py).
+Hypotheses (blanks included, as the reference returns them) must be IDENTICAL; scores within
+1e-4 (fp32 reassociation of the split joint)."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import model_common as C  # noqa: E402
+import decode_common as D  # noqa: E402
+from oracle.pika_ref import seeded_state_dict  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "decode_tiny.npz")
+
+
+def build(dec, device):
+    from pika_amd.model import transducer, encoder
+    net = C.build(transducer, encoder, dec)
+    net.load_state_dict(seeded_state_dict(net, C.SEED))
+    D.tweak(net)
+    return net.eval().to(device)
+
+
+def run_all(dec, device):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from decoder.transducer_decoder import TransducerDecoder   # the scripts' import path
+    from decoder.beam_transducer import GlobalScorer
+    z = np.load(GOLD)
+    net = build(dec, device)
+    x, x_len = D.inputs()
+    x, x_len_d = x.to(device), x_len.to(device)
+    for name, cfg in D.SCENARIOS.items():
+        args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None,
+                               nonblk_reward=0.0)
+        d = TransducerDecoder(net, batch_size=x.shape[0], beam_size=cfg["beam"], n_best=cfg["n_best"],
+                              blk=0, global_scorer=GlobalScorer(), sm_scale=cfg["sm_scale"],
+                              cuda=(device != "cpu"), beam_prune=True, args=args)
+        ret, enc = d.decode_batch(x, x_len_d, D.max_len(cfg, x_len))
+        got = D.pack(ret["predictions"], ret["scores"])
+        pre = "%s/%s/" % (dec, name)
+        assert np.array_equal(got["lens"], z[pre + "lens"]), (dec, name, got["lens"], z[pre + "lens"])
+        assert np.array_equal(got["hyps"], z[pre + "hyps"]), (dec, name)
+        assert np.allclose(got["scores"], z[pre + "scores"], rtol=1e-5, atol=1e-4), (dec, name)
+        # return types the decode script relies on (decode_transducer.py:139,166): 0-dim tensors
+        e = ret["predictions"][0][0][0] if len(ret["predictions"][0][0]) else torch.tensor(0)
+        assert hasattr(e, "item")
+
+
+@pytest.mark.parametrize("dec", ["transformer", "rnn"])
+def test_cpu_decoder_matches_reference_nbest(dec):
+    run_all(dec, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dec", ["transformer", "rnn"])
+def test_gpu_decoder_matches_reference_nbest(hip_device, dec):
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"   # fp32-class joint: identical arg-max decisions
+    try:
+        run_all(dec, hip_device)
+    finally:
+        G.PRECISION = old
