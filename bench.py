@@ -113,9 +113,58 @@ def train_step_workload(args, dev, rank, world):
     return step, flops_per_utt
 
 
+def decode_workload(args, dev, rank):
+    """batch beam decode, B utterances x beam 16, 10 s of synthetic fbank each,
+    full-size model with random weights.  Random weights never emit blank, so fc2 is sharpened
+    and the blank bias calibrated (greedy, 8 utterances) until an utterance emits ~U=50 labels
+    over its T'=240 frames -- the step count (T'+U) of a trained model."""
+    from types import SimpleNamespace
+    from model.transducer import Net
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    B, T, V = args.batch, args.frames, args.vocab
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type=args.pred_net, brnn=False,
+                          encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
+                          embd_dim=100, padding_idx=V)
+    torch.manual_seed(777 + rank)
+    model = Net(opt, 240, V).to(dev).eval()
+    g = torch.Generator(device=dev)
+    g.manual_seed(3000 + rank)
+    feats = (torch.randn(B, T, 240, generator=g, device=dev)).contiguous()
+    x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long, device=dev)
+    dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+
+    def decoder(beam, nbest):
+        return TransducerDecoder(model, batch_size=B, beam_size=beam, n_best=nbest, blk=0,
+                                 global_scorer=GlobalScorer(), sm_scale=0.8, cuda=True,
+                                 beam_prune=True, args=dargs)
+
+    with torch.no_grad():
+        model.fc2.weight *= 8.0
+        lo, hi = 0.0, 40.0
+        for _ in range(8):  # bisection on the blank bias
+            mid = 0.5 * (lo + hi)
+            model.fc2.bias[0] = mid
+            ret, _ = decoder(1, 1).decode_batch(feats[:8], x_len[:8], [int(v) + 100 for v in x_len[:8]])
+            labels = np.mean([sum(1 for e in h[0] if int(e) != 0) for h in ret["predictions"]])
+            if labels > args.labels:
+                lo = mid
+            else:
+                hi = mid
+        model.fc2.bias[0] = 0.5 * (lo + hi)
+    dec = decoder(args.beam, args.beam)
+
+    def step():
+        return dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
+    step.decoder = dec
+    return step, float(labels)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "train_step"])
+    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "train_step", "decode"])
+    ap.add_argument("--beam", type=int, default=16)
+    ap.add_argument("--pred-net", default="transformer", choices=["transformer", "rnn"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -142,6 +191,32 @@ def main():
     from pika_amd import rnnt as R
 
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    if args.workload == "decode":
+        step, cal_labels = decode_workload(args, dev, rank)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ret, _ = step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        audio_s = B * T / 100.0
+        hyps = ret["predictions"]
+        nlab = float(np.mean([sum(1 for e in h[0] if int(e) != 0) for h in hyps]))
+        nsteps = float(np.mean([len(h[0]) + 1 for h in hyps]))
+        if rank == 0:
+            print(json.dumps({
+                "metric": "decode RTF (wall / audio seconds), batch beam search", "value": el / audio_s,
+                "unit": "RTF", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "decode: B=%d beam=%d n_best=%d, %d-frame utterances, full model "
+                                       "(%s prediction net), sm_scale 0.8" % (B, args.beam, args.beam, T, args.pred_net),
+                           "audio_seconds": audio_s, "utterances_per_s": B / el,
+                           "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
+                           "calibration_labels": cal_labels, "timing": step.decoder.timing}}), flush=True)
+        return
     if args.workload == "train_step":
         step, flops_per_utt = train_step_workload(args, dev, rank, world)
         for _ in range(args.warmup):

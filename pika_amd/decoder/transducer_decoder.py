@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from ..model import ops
 from .beam_search import BeamState, EOS
+from .prednet_cache import IncrementalPredNet
 
 
 class GlobalScorer(object):
@@ -44,42 +45,42 @@ class TransducerDecoder(object):
         self.args = args
         self.t_idx = None
         self.dec_states = None
+        self.use_graph = True   # capture the steady-state step in a hipGraph on the GPU
+        self.incremental = True  # transformer prediction net: one new position per step (cached)
 
-    # ---- prediction network stepping --------------------------------------------------------
+    # ---- prediction network stepping (fixed shapes: every row is recomputed, rows whose last
+    # symbol is not a label keep their state; transducer_decoder.py:139-171) ---------------------
     def _pred_init(self, n, device):
         sos = torch.full((n, 1), self.blk, dtype=torch.long, device=device)
         if self.model.decoder_type == 'rnn':
             _, st = self.model.decoder(self.model.embed(sos))                 # :116-117
-            return st[0].contiguous(), st[1].contiguous()
-        return self.model.decoder(sos)[:, -1, :]                              # :121
+            return [st[0].contiguous(), st[1].contiguous()]
+        return [self.model.decoder(sos)[:, -1, :].contiguous()]               # :121
 
-    def _pred_step(self, state, inp, beam):
-        """Advance the rows whose last symbol is a label (> blank); transducer_decoder.py:139-171."""
-        nonblk = inp.gt(self.blk)
-        if not bool(nonblk.any()):
-            return state
+    def _pred_step(self, state, inp, beam, L):
+        nonblk = inp.gt(self.blk)                                             # labels only (eos = -1)
         if self.model.decoder_type == 'rnn':
             h, c = state
-            idx = nonblk.nonzero(as_tuple=False).squeeze(1)
-            dec_in = self.model.embed(inp[idx].unsqueeze(1))
-            _, (h2, c2) = self.model.decoder(dec_in, (h[:, idx].contiguous(), c[:, idx].contiguous()))
-            h = h.index_copy(1, idx, h2)
-            c = c.index_copy(1, idx, c2)
-            return h, c
-        # transformer prediction net: re-run on [blank] + partial hypothesis (:153-171)
-        idx = nonblk.nonzero(as_tuple=False).squeeze(1)
-        hyp = beam.hyp.view(-1, beam.hyp.shape[2])[idx]
-        ln = beam.hyp_len.view(-1)[idx]
-        L = int(ln.max()) + 1
+            dec_in = self.model.embed(inp.clamp(min=0).unsqueeze(1))
+            _, (h2, c2) = self.model.decoder(dec_in, (h, c))
+            m = nonblk.view(1, -1, 1)
+            h.copy_(torch.where(m, h2, h))
+            c.copy_(torch.where(m, c2, c))
+            return
+        if self._inc is not None:
+            self._inc.step(state[0], inp, beam.hyp_len.view(-1), beam.step_t, L)
+            return
+        # transformer prediction net: re-run on [blank] + partial hypothesis, padded to the
+        # current bucket length L (:153-171); position len(hyp) holds the new state
+        hyp = beam.hyp.view(-1, beam.hyp.shape[2])[:, :L - 1]
+        ln = beam.hyp_len.view(-1).clamp(max=L - 1)
         pad = self.model.embed.padding_idx
-        seq = torch.full((idx.numel(), L), pad, dtype=torch.long, device=inp.device)
-        seq[:, 0] = self.blk
         pos = torch.arange(1, L, device=inp.device).unsqueeze(0)
-        body = torch.where(pos <= ln.unsqueeze(1), hyp[:, :L - 1], torch.full_like(hyp[:, :L - 1], pad))
-        seq[:, 1:] = body
+        body = torch.where(pos <= ln.unsqueeze(1), hyp, torch.full_like(hyp, pad))
+        seq = torch.cat((torch.full_like(body[:, :1], self.blk), body), dim=1)
         out = self.model.decoder(seq)
-        last = out[torch.arange(idx.numel(), device=inp.device), ln]          # position len(cur_hyp)-1
-        return state.index_copy(0, idx, last)
+        last = out.gather(1, ln.view(-1, 1, 1).expand(-1, 1, out.shape[2])).squeeze(1)
+        state[0].copy_(torch.where(nonblk.unsqueeze(1), last, state[0]))
 
     # ---- the search ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -97,6 +98,7 @@ class TransducerDecoder(object):
         mlen = [int(m) if (m is not None and int(m)) else 10000 for m in max_len]   # :83
         beam = BeamState(B, K, self.blk, self.n_best, mlen, V, dev, beam_prune=self.beam_prune)
         num_frames = torch.as_tensor(x_len, device=dev).long()
+        rnn = model.decoder_type == 'rnn'
 
         # encoder halves of the joint, once
         w1, wg = model.fc1, model.fc_gate
@@ -105,29 +107,68 @@ class TransducerDecoder(object):
         w1p, wgp = w1.weight[:, H:].contiguous(), wg.weight[:, H:].contiguous()
 
         t_idx = torch.full((B, K), -1, dtype=torch.long, device=dev)          # :107
-        state = self._pred_init(B * K, dev)
+        self._inc = None
+        if not rnn and self.incremental:
+            self._inc = IncrementalPredNet(model.decoder, B * K, beam.s_cap, beam.hyp.shape[2] + 1,
+                                           dev, self.blk)
+            state = [self._inc.state0.clone()]
+        else:
+            state = self._pred_init(B * K, dev)
         bidx = torch.arange(B, device=dev).unsqueeze(1).expand(B, K)
+        flags = torch.zeros(2, dtype=torch.long, device=dev)                  # [all done, max hyp len]
 
-        while not bool(beam.done().all()):                                    # :123
+        def step(first, L):
             inp = beam.y                                                      # (B,K)  :127
-            t_idx = t_idx + inp.eq(self.blk).long()                           # :129
+            t_idx.add_(inp.eq(self.blk).long())                               # :129
             tg = t_idx.clamp(0, T - 1)
-            state = self._pred_step(state, inp.reshape(-1), beam)
-            dec_hid = state[0][-1] if model.decoder_type == 'rnn' else state  # (B*K,H)
+            if not first:
+                self._pred_step(state, inp.reshape(-1), beam, L)
+            dec_hid = state[0][-1] if rnn else state[0]                       # (B*K,H)
             z1 = e1_all[bidx, tg] + ops.linear(dec_hid, w1p).view(B, K, H)
             zg = eg_all[bidx, tg] + ops.linear(dec_hid, wgp).view(B, K, H)
             h = torch.tanh(z1) * torch.sigmoid(zg)
             logits = ops.linear(h, model.fc2.weight, model.fc2.bias)
             logp = F.log_softmax(self.sm_scale * logits, dim=-1)              # :177
-            prev_k = beam.advance(logp, t_idx, num_frames, self.lm_scorer_scale)   # :182
+            prev_k = beam._advance(logp, t_idx, num_frames, self.lm_scorer_scale, first)   # :182
             # _beam_update :188-202: re-order prediction-net state and frame indices by parent
             flat = (bidx * K + prev_k).reshape(-1)
-            if model.decoder_type == 'rnn':
-                state = (state[0].index_select(1, flat), state[1].index_select(1, flat))
+            for s_ in state:
+                s_.copy_(s_.index_select(1 if rnn else 0, flat))
+            if self._inc is not None:
+                self._inc.reorder(flat)
+            t_idx.copy_(t_idx.gather(1, prev_k))
+            flags[0] = beam.done().all().long()
+            flags[1] = beam.hyp_len.max()
+
+        def bucket(max_hyp):  # prefix length (SOS + labels) the prediction net attends over
+            return 2 if rnn else min(beam.hyp.shape[2] + 1, ((max_hyp + 1 + 1 + 15) // 16) * 16)
+
+        import time as _time
+        _t0 = _time.perf_counter()
+        use_graph = enc_out.is_cuda and self.use_graph
+        graphs = {}
+        n_eager = 0
+        step(True, 2)
+        beam.steps += 1
+        f = flags.tolist()
+        while not f[0]:                                                       # :123
+            L = bucket(f[1])
+            if use_graph and n_eager >= 2:
+                if L not in graphs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        step(False, L)
+                    graphs[L] = g
+                graphs[L].replay()
             else:
-                state = state.index_select(0, flat)
-            t_idx = t_idx.gather(1, prev_k)
+                step(False, L)
+                n_eager += 1
+            beam.steps += 1
+            f = flags.tolist()
         self.t_idx = t_idx
-        self.dec_states = state
+        self.dec_states = tuple(state) if rnn else state[0]
+        _t1 = _time.perf_counter()
         preds, scores = beam.results()
+        self.timing = {"search_s": _t1 - _t0, "results_s": _time.perf_counter() - _t1,
+                       "steps": beam.steps, "graphs": len(graphs)}
         return {"predictions": preds, "scores": scores}, enc_out

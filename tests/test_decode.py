@@ -66,3 +66,24 @@ def test_gpu_decoder_matches_reference_nbest(hip_device, dec):
         run_all(dec, hip_device)
     finally:
         G.PRECISION = old
+
+
+def test_incremental_prediction_net_equals_prefix_recompute():
+    """The ancestry-cached one-position-per-step prediction net (decoder/prednet_cache.py) and the
+    reference-style re-run over the whole prefix produce the same n-best lists and scores."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    net = build("transformer", "cpu")
+    x, x_len = D.inputs()
+    outs = []
+    for inc in (True, False):
+        args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+        d = TransducerDecoder(net, batch_size=4, beam_size=5, n_best=5, blk=0, global_scorer=GlobalScorer(),
+                              sm_scale=0.9, cuda=False, beam_prune=True, args=args)
+        d.incremental = inc
+        ret, _ = d.decode_batch(x, x_len, [40] * 4)
+        outs.append(D.pack(ret["predictions"], ret["scores"]))
+        assert (d._inc is not None) == inc
+    assert np.array_equal(outs[0]["hyps"], outs[1]["hyps"])
+    assert np.allclose(outs[0]["scores"], outs[1]["scores"], atol=1e-4)
