@@ -1,0 +1,135 @@
+"""Readers for the on-disk formats that feed the hot path, without PyKaldi:
+
+* `.mrk` / `.seq` audio containers (utils/wav_to_seq.py:28-39): `.mrk` line = `uttid byte_offset
+  num_bytes`, `.seq` = concatenated raw int16 PCM;
+* Kaldi int-vector archives (labels): text `uttid i1 i2 ...` or binary (`uttid \\0B` + int32 count
+  with 1-byte size markers), read specifiers `ark:path`, `ark,t:path` or a plain path;
+* Kaldi float-matrix archives / scp (offline features for loader/utt_loader.py);
+* Kaldi text matrices (the CMVN statistics file, train_transducer_bmuf_otfaug.py:341-346).
+"""
+import struct
+
+import numpy as np
+
+
+def _rspec_path(rspec):
+    if ":" in rspec and rspec.split(":", 1)[0].replace(",", "").isalpha():
+        kind, path = rspec.split(":", 1)
+        return kind, path
+    return "ark", rspec
+
+
+def read_mrk(path):
+    """[(uttid, byte_offset, num_bytes)]"""
+    out = []
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f:
+            p = line.split()
+            if p:
+                out.append((p[0], int(p[1]), int(p[2])))
+    return out
+
+
+def read_pcm(seq_file, offset, num_bytes):
+    num_bytes -= num_bytes % 2                      # otf_utt_loader.py:215
+    seq_file.seek(offset)
+    return np.frombuffer(seq_file.read(num_bytes), dtype="int16")
+
+
+def _read_token(f):
+    tok = b""
+    while True:
+        c = f.read(1)
+        if not c:
+            return None
+        if c in b" \n\t":
+            if tok:
+                return tok.decode("utf-8")
+            continue
+        tok += c
+
+
+def read_int_vectors(rspec):
+    """Yield (uttid, np.int32 array) from a Kaldi int-vector archive (text or binary)."""
+    kind, path = _rspec_path(rspec)
+    if kind.startswith("scp"):
+        raise NotImplementedError("scp int-vector tables are not used by the recipes")
+    with open(path, "rb") as f:
+        while True:
+            pos = f.tell()
+            key = _read_token(f)
+            if key is None:
+                return
+            head = f.read(2)
+            if head == b"\0B":                       # binary: \0B <4> <int32 n> then n x (<4> <int32>)
+                assert f.read(1) == b"\x04"
+                n = struct.unpack("<i", f.read(4))[0]
+                raw = np.frombuffer(f.read(5 * n), dtype=np.uint8).reshape(n, 5)
+                yield key, raw[:, 1:].copy().view("<i4").reshape(n).astype(np.int32)
+            else:                                    # text line
+                f.seek(pos)
+                parts = f.readline().decode("utf-8").split()
+                yield parts[0], np.array([int(v) for v in parts[1:]], np.int32)
+
+
+def _read_binary_matrix(f):
+    head = f.read(2)
+    assert head == b"\0B", "expected a binary Kaldi matrix"
+    tok = _read_token(f)
+    if tok not in ("FM", "DM"):
+        raise NotImplementedError("Kaldi matrix type %r (compressed matrices unsupported)" % tok)
+    assert f.read(1) == b"\x04"
+    rows = struct.unpack("<i", f.read(4))[0]
+    assert f.read(1) == b"\x04"
+    cols = struct.unpack("<i", f.read(4))[0]
+    dt = "<f4" if tok == "FM" else "<f8"
+    data = np.frombuffer(f.read(rows * cols * int(dt[-1])), dtype=dt).reshape(rows, cols)
+    return data.astype(np.float32)
+
+
+def read_matrices(rspec):
+    """Yield (uttid, float32 matrix) from `ark:file` (binary) or `scp:file` (path:offset lines)."""
+    kind, path = _rspec_path(rspec)
+    if kind.startswith("scp"):
+        with open(path, "r", encoding="utf-8") as s:
+            for line in s:
+                key, loc = line.split(None, 1)
+                fn, off = loc.strip().rsplit(":", 1) if ":" in loc else (loc.strip(), "0")
+                with open(fn, "rb") as f:
+                    f.seek(int(off))
+                    yield key, _read_binary_matrix(f)
+        return
+    with open(path, "rb") as f:
+        while True:
+            key = _read_token(f)
+            if key is None:
+                return
+            yield key, _read_binary_matrix(f)
+
+
+def write_matrix_ark(path, items):
+    """Binary float-matrix archive writer (tests and data prep)."""
+    with open(path, "wb") as f:
+        for key, m in items:
+            m = np.ascontiguousarray(m, dtype="<f4")
+            f.write(key.encode("utf-8") + b" \0BFM \x04" + struct.pack("<i", m.shape[0]) + b"\x04" +
+                    struct.pack("<i", m.shape[1]) + m.tobytes())
+
+
+def read_text_matrix(path):
+    """Kaldi text matrix ` [ a b c\\n d e f ]` -> float64 array (CMVN statistics: 2 x (D+1))."""
+    with open(path, "r") as f:
+        txt = f.read()
+    body = txt[txt.index("[") + 1: txt.rindex("]")]
+    rows = [[float(v) for v in line.split()] for line in body.strip().split("\n") if line.strip()]
+    return np.array(rows, np.float64)
+
+
+def cmvn_offset_scale(stats, repeat=1, floor=1.0e-20):
+    """mean/var from accumulated stats -> (offset, scale), each repeated over the splice window
+    (train_transducer_bmuf_otfaug.py:345-355)."""
+    mean = stats[0][:-1] / stats[0][-1]
+    var = stats[1][:-1] / stats[0][-1] - mean * mean
+    if np.min(np.abs(var)) < floor:
+        raise ValueError("problematic cmvn_stats, variance too small")
+    return np.tile(-mean, repeat), np.tile(1.0 / np.sqrt(var), repeat)

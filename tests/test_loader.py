@@ -1,0 +1,138 @@
+"""Loader host logic (file formats, batching protocol, RNG order) without a GPU, and the full
+on-the-fly pipeline against the oracle on the GPU."""
+import os
+import random
+import struct
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+from oracle import fbank_ref as F  # noqa: E402
+
+
+def make_corpus(tmp, n_utts=7, seed=3):
+    rng = np.random.default_rng(seed)
+    mrk, seq, lab = tmp / "a.mrk.0", tmp / "a.seq.0", tmp / "a.label.0"
+    off, pcms, labels = 0, [], []
+    with open(mrk, "w") as fm, open(seq, "wb") as fs, open(lab, "w") as fl:
+        for i in range(n_utts):
+            n = int(rng.integers(3000, 9000))
+            pcm = np.clip(rng.standard_normal(n) * 2000, -32768, 32767).astype(np.int16)
+            pcm.tofile(fs)
+            fm.write("utt%d %d %d\n" % (i, off, 2 * n))       # utils/wav_to_seq.py:37
+            off += 2 * n
+            y = rng.integers(1, 50, int(rng.integers(2, 9)))
+            fl.write("utt%d %s\n" % (i, " ".join(str(v) for v in y)))
+            pcms.append(pcm)
+            labels.append(y.astype(np.int32))
+    lst = tmp / "data.lst"
+    lst.write_text("%s %s ark:%s\n" % (mrk, seq, lab))
+    conf = tmp / "fbank.conf"
+    conf.write_text("--window-type=hamming\n--sample-frequency=16000\n--dither=0\n--low-freq=40\n"
+                    "--high-freq=-200\n--num-mel-bins=80\n")
+    return str(lst), str(conf), pcms, labels
+
+
+def loader_args(conf, batch_size=3, **kw):
+    a = SimpleNamespace(lctx=1, rctx=1, max_len=1600, num_workers=1, sample_rate=16000, batch_first=True,
+                        reverse_labels=False, feat_config=conf, stride=1, batch_size=batch_size, SOS=-1,
+                        EOS=-1, queue_size=8, TU_limit=15000, padding_tgt=99, feats_dim=80,
+                        gain_range="50,10", speed_rate="0.9,1.0,1.1", local_rank=0)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_kaldi_io_formats(tmp_path):
+    from pika_amd.loader import kaldi_io as K
+    # binary int-vector archive
+    p = tmp_path / "ali.ark"
+    with open(p, "wb") as f:
+        for key, v in (("a", [3, 1, 4]), ("bb", []), ("c", [70000])):
+            f.write(key.encode() + b" \0B\x04" + struct.pack("<i", len(v)))
+            for x in v:
+                f.write(b"\x04" + struct.pack("<i", x))
+    got = list(K.read_int_vectors("ark:%s" % p))
+    assert [k for k, _ in got] == ["a", "bb", "c"] and got[0][1].tolist() == [3, 1, 4] and got[2][1].tolist() == [70000]
+    # float matrix ark round trip + scp with offsets
+    mats = [("u1", np.arange(6, dtype=np.float32).reshape(2, 3)), ("u2", np.ones((4, 3), np.float32))]
+    ark = tmp_path / "f.ark"
+    K.write_matrix_ark(str(ark), mats)
+    back = list(K.read_matrices("ark:%s" % ark))
+    assert all(k == k2 and np.array_equal(m, m2) for (k, m), (k2, m2) in zip(mats, back))
+    scp = tmp_path / "f.scp"
+    scp.write_text("u2 %s:%d\n" % (ark, len(b"u1 ") + 2 + 3 + 10 + 24 + len(b"u2 ")))
+    (k, m), = list(K.read_matrices("scp:%s" % scp))
+    assert k == "u2" and np.array_equal(m, mats[1][1])
+    # CMVN text matrix
+    c = tmp_path / "cmvn"
+    c.write_text(" [\n  10 20 5\n  30 90 0 ]\n")
+    st = K.read_text_matrix(str(c))
+    off, sc = K.cmvn_offset_scale(st, repeat=3)
+    assert np.allclose(off, np.tile([-2, -4], 3)) and np.allclose(sc, np.tile(1 / np.sqrt([2.0, 2.0]), 3))
+
+
+def test_host_batching_protocol_and_rng_order(tmp_path):
+    """Same draws, in the same order, as loader/otf_utt_loader.py:221-223; T*U filter :247;
+    empty-batch sentinel :288; label padding :270."""
+    from pika_amd.loader import otf_utt_loader as L
+    from pika_amd.loader.frontend import FbankConfig
+    lst, conf, pcms, labels = make_corpus(tmp_path)
+    args = loader_args(conf, batch_size=3)
+    random.seed(5); np.random.seed(5)
+    exp = []
+    for pcm in pcms:
+        spr = [0.9, 1.0, 1.1][random.randint(0, 2)]
+        exp.append((spr, np.random.uniform(-50.0, -10.0)))
+    random.seed(5); np.random.seed(5)
+    cfg = FbankConfig.from_file(conf)
+    trip = [tuple(open(lst).read().split())]
+    batches = list(L.host_batches(trip, cfg, args))
+    assert batches[-1] is None and len(batches) == 3          # 7 utts, batch 3: 2 full batches + None
+    flat = [u for b in batches[:-1] for u in b]
+    for (pcm, spr, db, ali, ulen), (espr, edb), p0, y0 in zip(flat, exp, pcms, labels):
+        assert spr == espr and db == edb and np.array_equal(pcm, p0) and np.array_equal(ali, y0)
+        n_out = len(p0) if spr == 1.0 else int(len(p0) / spr)
+        assert ulen == 1 + (n_out - 400) // 160
+    # T*U filter drops everything -> the reference's empty-batch tuple
+    args2 = loader_args(conf, batch_size=3, TU_limit=0)
+    b2 = list(L.host_batches(trip, cfg, args2))
+    assert b2[0] == [] and L.assemble(b2[0], None, args2)[0] is None
+    # assemble with a fake front end: padding value and shapes
+    fake = lambda pc, r, d: (torch.zeros(len(pc), 5, 240), [u[4] for u in batches[0]])
+    data, tgt, lens, alens = L.assemble(batches[0], fake, args)
+    assert tgt.dtype == torch.int32 and tgt.shape == (3, max(len(l) for l in labels[:3]))
+    assert all(tgt[i, len(labels[i]):].eq(99).all() for i in range(3))
+    assert lens.dtype == torch.int32 and alens.tolist() == [len(l) for l in labels[:3]]
+
+
+@pytest.mark.gpu
+def test_otf_loader_end_to_end_matches_oracle(hip_device, tmp_path):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from loader import otf_utt_loader as L      # the script's import path
+    lst, conf, pcms, labels = make_corpus(tmp_path)
+    args = loader_args(conf, batch_size=3)
+    random.seed(9); np.random.seed(9)
+    draws = []
+    for _ in pcms:
+        spr = [0.9, 1.0, 1.1][random.randint(0, 2)]
+        draws.append((spr, np.random.uniform(-50.0, -10.0)))
+    random.seed(9); np.random.seed(9)
+    got = list(L.dataloader(lst, None, None, args))
+    assert len(got) == 2
+    i = 0
+    for data, tgt, lens, alens in got:
+        assert data.is_cuda and data.shape[2] == L.get_inputdim(args) == 240
+        d = data.cpu().numpy()
+        for b in range(3):
+            spr, db = draws[i]
+            wav = F.perturb(pcms[i], spr, db).astype(np.float64)
+            ref = F.splice(F.kaldi_fbank(wav).astype(np.float32), 1, 1)
+            assert lens[b] == ref.shape[0]
+            # int16 quantisation can differ by one LSB on a few samples: log-mel moves < 5e-3
+            assert np.abs(d[b, :lens[b]] - ref).max() < 5e-3
+            assert np.array_equal(tgt[b, :alens[b]].numpy(), labels[i])
+            i += 1
