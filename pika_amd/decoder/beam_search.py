@@ -17,8 +17,13 @@ DEAD = -1e20      # beam_transducer.py:104,113
 
 
 class BeamState(object):
-    def __init__(self, batch, beam, blk, n_best, max_len, vocab, device, beam_prune=True):
+    def __init__(self, batch, beam, blk, n_best, max_len, vocab, device, beam_prune=True,
+                 lm_scorer=None, nonblk_reward=0.0, global_scorer=True):
         B, K = batch, beam
+        self.lm_scorer, self.nonblk_reward, self.global_scorer = lm_scorer, nonblk_reward, global_scorer
+        # FST shallow fusion keeps, per slot, the set of active LM states with their costs (:64-70);
+        # sets are ragged, so this path runs on the host (one device read per step)
+        self.state_sets = [[{0: 0.0} for _ in range(K)] for _ in range(B)] if lm_scorer else None
         self.B, self.K, self.V = B, K, vocab
         self.blk, self.n_best, self.beam_prune = blk, n_best, beam_prune
         self.device = device
@@ -89,6 +94,8 @@ class BeamState(object):
         self.ks_hist.index_copy_(0, self.step_t, prev_k.unsqueeze(0))
         new_scores = best - lm_scale * self.lm_scores.gather(1, prev_k)       # :131-132
         self.scores.copy_(new_scores)
+        if self.lm_scorer is not None:
+            self._fst_update(prev_k, y)                                       # :135-159
         self.step_t += 1
         n_ys = self.step_t + 1                                                # len(self.next_ys), (1,)
 
@@ -114,7 +121,14 @@ class BeamState(object):
         pos = (self.fin_n.unsqueeze(1) + rank).clamp(max=self.fin_cap - 2)
         pos = torch.where(fin, pos, torch.full_like(pos, self.fin_cap - 1))
         idx = (self._brow + pos).reshape(-1)
-        self.fin_score.view(-1).scatter_(0, idx, new_scores.reshape(-1))
+        fin_value = new_scores
+        if self.lm_scorer is not None:
+            # :165-180: `s = self.scores[i]` is a VIEW, so `s += scale * final_lm_score` also lands
+            # in self.scores, and the global scorer (which returns self.scores) hands it back: the
+            # final LM cost is part of the finished score with or without a global scorer
+            fin_value = new_scores + lm_scale * self._fst_final(fin)
+            self.scores.copy_(fin_value)
+        self.fin_score.view(-1).scatter_(0, idx, fin_value.reshape(-1))
         self.fin_step.view(-1).scatter_(0, idx, (n_ys - 1).expand(B * K))
         self.fin_k.view(-1).scatter_(0, idx, self._kidx.reshape(-1))
         self.fin_n += fin.sum(1)
@@ -124,6 +138,47 @@ class BeamState(object):
         self.ys_hist.index_copy_(0, self.step_t, y.unsqueeze(0))
         self.eos_top |= y[:, 0].eq(EOS)                                       # :183-186
         return prev_k
+
+    def _fst_update(self, prev_k, y):
+        """On-the-fly FST scoring of the surviving candidates (beam_transducer.py:135-159)."""
+        pk, ys = prev_k.cpu().tolist(), y.cpu().tolist()
+        lm = torch.zeros(self.B, self.K)
+        for b in range(self.B):
+            old, new = self.state_sets[b], []
+            for i in range(self.K):
+                parent = old[pk[b][i]]
+                nxt = {}
+                if ys[b][i] != self.blk:
+                    ilabel = ys[b][i] + 1                                     # :139
+                    for state in list(parent.keys()):
+                        scores, states = self.lm_scorer.get_scores(state, ilabel)
+                        for ns, cost in zip(states, scores):
+                            next_cost = parent[state] + cost
+                            if next_cost < nxt.get(ns, float("inf")):         # :147-149 (sic: the
+                                nxt[ns] = next_cost - self.nonblk_reward      # reward is not in the test)
+                else:
+                    nxt = dict(parent)                                        # :151-152
+                lm[b, i] = -min(nxt.values()) if nxt else -1e20               # :153-157
+                new.append(nxt)
+            self.state_sets[b] = new
+        self.lm_scores.copy_(lm.to(self.device))
+
+    def _fst_final(self, fin):
+        """-min over active states of (cost + final cost) for finishing slots (:167-177), zero for
+        the others."""
+        out = torch.zeros(self.B, self.K)
+        f = fin.cpu()
+        for b in range(self.B):
+            for i in range(self.K):
+                if bool(f[b, i]):
+                    best = {}
+                    for state, c in self.state_sets[b][i].items():
+                        fs, st = self.lm_scorer.final_score(state)
+                        for s_, cost in zip(st, fs):
+                            if c + cost < best.get(s_, float("inf")):
+                                best[s_] = c + cost
+                    out[b, i] = -min(best.values())
+        return out.to(self.device)
 
     def done(self):
         return self.eos_top & (self.fin_n >= self.n_best)                     # :189-194

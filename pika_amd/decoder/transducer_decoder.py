@@ -96,7 +96,10 @@ class TransducerDecoder(object):
         if max_len is None:
             max_len = [None] * B
         mlen = [int(m) if (m is not None and int(m)) else 10000 for m in max_len]   # :83
-        beam = BeamState(B, K, self.blk, self.n_best, mlen, V, dev, beam_prune=self.beam_prune)
+        beam = BeamState(B, K, self.blk, self.n_best, mlen, V, dev, beam_prune=self.beam_prune,
+                         lm_scorer=self.lm_scorer,
+                         nonblk_reward=getattr(self.args, "nonblk_reward", 0.0),
+                         global_scorer=self.global_scorer is not None)
         num_frames = torch.as_tensor(x_len, device=dev).long()
         rnn = model.decoder_type == 'rnn'
 
@@ -145,7 +148,7 @@ class TransducerDecoder(object):
 
         import time as _time
         _t0 = _time.perf_counter()
-        use_graph = enc_out.is_cuda and self.use_graph
+        use_graph = enc_out.is_cuda and self.use_graph and self.lm_scorer is None
         graphs = {}
         n_eager = 0
         step(True, 2)
