@@ -1,0 +1,29 @@
+"""`from kaldi.matrix import _matrix_ext, DoubleMatrix`
+(trainer/train_transducer_bmuf_otfaug.py:22, used at :342-344)."""
+import numpy as np
+
+from pika_amd.loader import kaldi_io
+
+
+class DoubleMatrix(object):
+    def __init__(self):
+        self.data = np.zeros((0, 0))
+
+    def read_(self, stream, binary):
+        if binary:
+            raise NotImplementedError("binary CMVN statistics: write them in text mode (the recipes do)")
+        self.data = kaldi_io.read_text_matrix(stream.name)
+        return self
+
+
+class _MatrixExt(object):
+    @staticmethod
+    def double_matrix_to_numpy(m):
+        return m.data
+
+    @staticmethod
+    def matrix_to_numpy(m):
+        return np.asarray(getattr(m, "data", m))
+
+
+_matrix_ext = _MatrixExt()

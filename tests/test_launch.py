@@ -1,0 +1,71 @@
+"""The UNCHANGED reference training script run through `pika_amd.launch` (BASELINE.json configs[0],
+CPU plumbing, world_size 1): argument plumbing, drop-in import surface, kaldi/torch._six shims,
+loader file formats, model, BMUF (gloo), Logger, whole-module checkpoint.  The two GPU-only ops are
+replaced by the oracles through a test-only preload (tests/cpu_plumbing.py).  Needs /root/reference,
+which exists in the build container only."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SCRIPT = "/root/reference/trainer/train_transducer_bmuf_otfaug.py"
+sys.path.insert(0, HERE)
+from test_loader import make_corpus  # noqa: E402
+from bmuf_common import free_port  # noqa: E402
+
+
+def test_argv_and_shims():
+    from pika_amd import launch
+    assert launch.fix_argv(["--local-rank=3", "x"]) == ["--local_rank", "3", "x"]
+    os.environ["LOCAL_RANK"] = "5"
+    try:
+        assert launch.fix_argv(["a"]) == ["a", "--local_rank", "5"]
+        assert launch.fix_argv(["--local_rank", "1"]) == ["--local_rank", "1"]
+    finally:
+        del os.environ["LOCAL_RANK"]
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    import editdistance
+    assert editdistance.eval([1, 2, 3], [1, 3]) == 1 and editdistance.eval([], [4, 4]) == 2
+    assert editdistance.eval("kitten", "sitting") == 3
+
+
+@pytest.mark.skipif(not os.path.exists(SCRIPT), reason="reference tree not present on this box")
+def test_unchanged_training_script_runs_one_epoch(tmp_path):
+    lst, conf, pcms, labels = make_corpus(tmp_path, n_utts=4, seed=8, lo=14000, hi=20000)
+    cmvn = tmp_path / "cmvn.stats"
+    D = 80
+    rng = np.random.default_rng(0)
+    n, mean = 1000.0, rng.normal(8, 1, D)
+    s1 = np.concatenate((mean * n, [n]))
+    s2 = np.concatenate(((mean ** 2 + 4.0) * n, [0.0]))
+    cmvn.write_text(" [\n  " + " ".join("%.10g" % v for v in s1) + "\n  " + " ".join("%.10g" % v for v in s2) + " ]\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               PYTHONPATH=os.pathsep.join([ROOT, HERE]), OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "pika_amd.launch", "--preload", "cpu_plumbing", SCRIPT,
+           "--verbose", "--optim", "sgd", "--initial_lr", "0.003", "--final_lr", "0.0001", "--grad_clip", "3.0",
+           "--num_batches_per_epoch", "2", "--num_epochs", "1", "--momentum", "0.9", "--block_momentum", "0.9",
+           "--sync_period", "1", "--feats_dim", "80", "--cuda", "--batch_size", "2", "--encoder_type", "transformer",
+           "--enc_layers", "2", "--decoder_type", "transformer", "--dec_layers", "1", "--rnn_type", "LSTM",
+           "--rnn_size", "64", "--embd_dim", "16", "--dropout", "0.0", "--padding_idx", "50", "--padding_tgt", "50",
+           "--stride", "1", "--queue_size", "4", "--loader", "otf_utt", "--batch_first", "--cmn",
+           "--cmvn_stats", str(cmvn), "--output_dim", "50", "--num_workers", "1", "--sample_rate", "16000",
+           "--feat_config", conf, "--TU_limit", "15000", "--gain_range", "50,10", "--speed_rate", "0.9,1.0,1.1",
+           "--log_per_n_frames", "1", "--max_len", "1600", "--lctx", "1", "--rctx", "1", "--model_lctx", "21",
+           "--model_rctx", "21", "--model_stride", "4", "--local-rank=0",
+           "transducer", lst, str(tmp_path / "train.WORKER-ID.log"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = (tmp_path / "train.0.log").read_text()
+    assert "Training Finished" in log and "model proto: transducer" in log and "Loss:" in log
+    losses = [float(l.split("Loss:")[1].split()[0]) for l in log.splitlines() if l.startswith("Loss:")]
+    assert losses and all(np.isfinite(losses))
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    model = torch.load(out / "model.epoch.0.0", weights_only=False)   # whole-module pickle (:363-366)
+    assert type(model).__module__ == "pika_amd.model.transducer" and model.fc2.out_features == 50

@@ -14,13 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 from oracle import fbank_ref as F  # noqa: E402
 
 
-def make_corpus(tmp, n_utts=7, seed=3):
+def make_corpus(tmp, n_utts=7, seed=3, lo=3000, hi=9000):
     rng = np.random.default_rng(seed)
     mrk, seq, lab = tmp / "a.mrk.0", tmp / "a.seq.0", tmp / "a.label.0"
     off, pcms, labels = 0, [], []
     with open(mrk, "w") as fm, open(seq, "wb") as fs, open(lab, "w") as fl:
         for i in range(n_utts):
-            n = int(rng.integers(3000, 9000))
+            n = int(rng.integers(lo, hi))
             pcm = np.clip(rng.standard_normal(n) * 2000, -32768, 32767).astype(np.int16)
             pcm.tofile(fs)
             fm.write("utt%d %d %d\n" % (i, off, 2 * n))       # utils/wav_to_seq.py:37
