@@ -175,3 +175,27 @@ class TransducerDecoder(object):
         self.timing = {"search_s": _t1 - _t0, "results_s": _time.perf_counter() - _t1,
                        "steps": beam.steps, "graphs": len(graphs)}
         return {"predictions": preds, "scores": scores}, enc_out
+
+
+def _las_scores(rescorer, x, tgt, scale=1.0):
+    """Shared body of las_rescore / bilas_rescore (decoder/transducer_decoder.py:219-253)."""
+    lens = torch.IntTensor([x.size(0)])
+    outputs, _, _, _ = rescorer(x, tgt, lens)
+    logp = F.log_softmax(scale * rescorer.dec_proj(outputs), dim=-1).squeeze(1)
+    idx = tgt[1:].squeeze(-1).squeeze(-1)
+    return logp[torch.arange(idx.size(0)), idx].tolist()
+
+
+def las_rescore(self, x, tgt, bw=False):
+    """x (T,1,C) encoder output of one utterance, tgt (L,1,1) = [SOS] + hyp + [EOS]."""
+    with torch.no_grad():
+        return _las_scores(self.las_rescorer_bw if bw else self.las_rescorer, x, tgt)
+
+
+def bilas_rescore(self, x, tgt):
+    with torch.no_grad():
+        return _las_scores(self.bilas_rescorer, x, tgt, scale=0.5)
+
+
+TransducerDecoder.las_rescore = las_rescore
+TransducerDecoder.bilas_rescore = bilas_rescore

@@ -1,0 +1,56 @@
+"""LAS rescoring: per-token log-probs vs golden recorded from the REFERENCE
+las.Net + TransducerDecoder.las_rescore (tests/golden/make_las_golden.py).  `bilas_rescore`
+cannot be pinned: the reference calls its model with 7 positional arguments
+(transducer_decoder.py:247-248) and no class in the reference tree accepts them."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import las_common as LC  # noqa: E402
+from oracle.pika_ref import seeded_state_dict  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "las_rescore.npz")
+
+
+def run(device):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from trainer.model import las                       # pickle/import path of a trained rescorer
+    from decoder.transducer_decoder import TransducerDecoder
+    z = np.load(GOLD)
+    for attn in ("mlp", "general"):
+        net = las.Net(LC.opt(attn), LC.C_IN, LC.V, LC.PAD)
+        net.load_state_dict(seeded_state_dict(net, 31, scale=0.3))   # same keys/shapes as the reference
+        net = net.eval().to(device)
+        args = SimpleNamespace(las_rescorer=net, las_rescorer_bw=net, bilas_rescorer=None)
+        d = TransducerDecoder(None, 1, 1, args=args)
+        x, hyps = LC.inputs()
+        x = x.to(device)
+        for i, h in enumerate(hyps):
+            tgt = torch.LongTensor([LC.SOS] + h + [LC.EOS]).to(device).unsqueeze(-1).unsqueeze(-1)
+            got = d.las_rescore(x, tgt)
+            assert np.allclose(got, z["%s/las/%d" % (attn, i)], rtol=1e-4, atol=1e-4), (attn, i)
+            assert np.allclose(d.las_rescore(x, tgt, bw=True), got)
+        # batched n-best scoring == one-by-one scoring
+        batched = net.score_nbest(x, hyps, LC.SOS, LC.EOS)
+        for i in range(len(hyps)):
+            assert np.allclose(batched[i], z["%s/las/%d" % (attn, i)], rtol=1e-4, atol=1e-4)
+
+
+def test_cpu_las_rescore_matches_reference():
+    run("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_las_rescore_matches_reference(hip_device):
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        run(hip_device)
+    finally:
+        G.PRECISION = old
