@@ -36,6 +36,14 @@ int pika_log_softmax_rows(float *x, long long rows, int cols, long long ld, floa
 int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int cols, long long ld,
                               float scale, void *stream);
 
+/* MBR risk gradient (reference: trainer/train_transducer_mbr_bmuf_otfaug.py:225-235, where a
+ * dense (rows, V) tensor holding ONE non-zero per row is pushed through log_softmax backward).
+ * In place on lp (rows, V) = log_softmax(scale * logits):
+ *   lp[r, v] <- scale * val[r] * ((v == sym[r]) - exp(lp[r, v]))      (rows with val == 0 -> zeros)
+ * i.e. d/dlogits of sum_r val[r] * lp[r, sym[r]].  sym i32, val f32. */
+int pika_mbr_risk_grad_rows(float *lp, const int *sym, const float *val, long long rows, int cols,
+                            long long ld, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pika_joint_gate_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),
     "pika_log_softmax_rows": (_i, [_vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_log_softmax_bwd_rows": (_i, [_vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
+    "pika_mbr_risk_grad_rows": (_i, [_vp, _vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     # include/pika_audio.h
     "pika_audio_perturb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp, _vp, _vp]),
     "pika_fbank": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, ctypes.c_float, ctypes.c_float,

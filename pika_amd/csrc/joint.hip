@@ -193,6 +193,17 @@ __global__ __launch_bounds__(ROW_THREADS) void log_softmax_bwd_kernel(const floa
     }
 }
 
+__global__ __launch_bounds__(ROW_THREADS) void mbr_risk_grad_kernel(float *__restrict__ lp,
+                                                                    const int *__restrict__ sym,
+                                                                    const float *__restrict__ val,
+                                                                    int cols, long long ld, float scale) {
+    float *row = lp + (long long)blockIdx.x * ld;
+    const float v = val[blockIdx.x] * scale;
+    const int s = sym[blockIdx.x];
+    for (int i = threadIdx.x; i < cols; i += ROW_THREADS)
+        row[i] = v == 0.f ? 0.f : v * ((i == s ? 1.f : 0.f) - __expf(row[i]));
+}
+
 }  // namespace
 
 extern "C" {
@@ -246,6 +257,15 @@ int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int col
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
     hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
                        static_cast<hipStream_t>(stream), lp, g, cols, ld, scale);
+    return (int)hipGetLastError();
+}
+
+int pika_mbr_risk_grad_rows(float *lp, const int *sym, const float *val, long long rows, int cols,
+                            long long ld, float scale, void *stream) {
+    if (!lp || !sym || !val || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(mbr_risk_grad_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
+                       static_cast<hipStream_t>(stream), lp, sym, val, cols, ld, scale);
     return (int)hipGetLastError();
 }
 
