@@ -43,8 +43,7 @@ class RiskFn(torch.autograd.Function):
                 _lib.check(_lib.lib().pika_log_softmax_rows(logits.data_ptr(), rows, V, V, float(scale),
                                                             torch.cuda.current_stream().cuda_stream),
                            "pika_log_softmax_rows")
-            lp = logits
-            ctx.mark_dirty(logits)
+            lp = logits  # overwritten in place by the kernel; its producer (fc2 GEMM) keeps no copy
         else:
             lp = F.log_softmax(scale * logits, dim=-1)
         ctx.scale = float(scale)
