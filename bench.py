@@ -66,51 +66,105 @@ def cpu_baseline(lp, labels, tl, ul, n_utts, min_seconds=10.0):
 
 
 def train_step_workload(args, dev, rank, world):
-    """one full training step of the config-2 model (TDNN-Transformer encoder,
-    conv-transformer prediction net, gated joint, RNN-T loss, backward, inf-norm clip, Nesterov
-    SGD) on synthetic 80-d fbank spliced to 240, resident in HBM.  Lattice T' = 240."""
+    """BASELINE.json configs[1] / SURVEY 8d M2: one full training step of the config-2 model fed by
+    the HIP loader: pinned int16 audio (10.0 s / utterance, synthetic) -> speed/volume perturbation
+    -> fbank (dither 1, as egs/fbank.conf) -> splice -> CMVN -> SpecAugment -> TDNN-Transformer encoder,
+    conv-transformer prediction net, gated joint -> RNN-T loss -> backward -> inf-norm clip ->
+    Nesterov SGD; with world > 1 a BMUF block sync (RCCL all-reduce of the flat parameter vector)
+    every 5 steps, as in the recipe.  Lattice T' = 240."""
     from types import SimpleNamespace
     from model.transducer import Net  # drop-in import path of the training script
     from warp_rnnt import RNNTLoss
     from pika_amd.features import SpecAugment, cmvn_apply_
+    from pika_amd.loader.frontend import FbankConfig, GpuFrontEnd
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
                           embd_dim=100, padding_idx=V)
-    torch.manual_seed(777 + rank)
+    torch.manual_seed(777)      # identical initial replicas; BMUF broadcasts rank 0's anyway
     np.random.seed(777 + rank)
     model = Net(opt, 240, V).to(dev)
     model.train()
+    cfg = FbankConfig(num_mel_bins=80, low_freq=40, high_freq=-200, dither=1.0, window_type="hamming")
+    fe = GpuFrontEnd(cfg, dev, lctx=1, rctx=1, stride=1)
+    n_samples = 400 + (T - 1) * 160      # T fbank frames at unchanged speed
+    rng = np.random.default_rng(2000 + rank)
+    pcms = [np.clip(rng.standard_normal(n_samples) * 3000, -32768, 32767).astype(np.int16) for _ in range(B)]
     g = torch.Generator(device=dev)
     g.manual_seed(2000 + rank)
-    feats = torch.randn(B, T, 80, generator=g, device=dev) * 4 + 8
-    data0 = torch.cat((torch.cat((feats[:, :1], feats[:, :-1]), 1), feats,
-                       torch.cat((feats[:, 1:], feats[:, -1:]), 1)), -1).contiguous()
     labels = torch.randint(1, V, (B, U), generator=g, device=dev)
-    lens = torch.full((B,), T, dtype=torch.int32, device=dev)
     ali = torch.full((B,), U, dtype=torch.int32, device=dev)
     offset = torch.full((240,), -8.0, device=dev)
     scale = torch.full((240,), 0.25, device=dev)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
     aug = SpecAugment(15, 35)
-    optim = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
+    state = {"optim": torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True), "n": 0}
+    bmuf = None
+    if world > 1:
+        from trainer.bmuf import BmufTrainer
+        bmuf = BmufTrainer(0, rank, world, model, 0.9, 1.0)
 
     def step():
-        optim.zero_grad(set_to_none=True)
+        state["optim"].zero_grad(set_to_none=True)
+        # speed 1.0 keeps the benchmark shape fixed (T frames); the level perturbation is drawn
+        dbs = np.random.uniform(-50.0, -10.0, B)
+        data, flens = fe(pcms, [1.0] * B, list(dbs))
+        lens = torch.tensor(flens, dtype=torch.int32, device=dev)
         len_b = lens - 42                       # train_transducer_bmuf_otfaug.py:80-82
         len_b = len_b // 4 + (len_b % 4 != 0).int()
-        data = data0.clone()
         cmvn_apply_(data, offset, scale, cmn=True)
         aug.apply(data)
         out = model(data, labels, len_b, True)
         loss = loss_fn(out, labels.int(), len_b, ali).sum()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
-        optim.step()
+        state["optim"].step()
+        state["n"] += 1
+        if bmuf is not None and state["n"] % 5 == 0:      # sync_period 5 (:112-123)
+            assert bmuf.update_and_sync()
+            state["optim"] = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
         return loss
 
     flops_per_utt = 730e9  # SURVEY 8d M2: ~243 GF fwd, x3 fwd+bwd (split fc1/fc_gate)
     return step, flops_per_utt
+
+
+def run_train_step(args, dev, rank, world, steps, warmup):
+    from pika_amd import gemm as G
+    B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    step, flops_per_utt = train_step_workload(args, dev, rank, world)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    tf = flops_per_utt * B / (el / steps) / 1e12
+    return {"metric": "utterances/sec RNNT train step (T_in=%d,U=%d,V=%d)" % (T, U, V),
+            "value": B * world / (el / steps), "unit": "utterances/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if G.PRECISION == "bf16" else "f32-split", "data": "synthetic",
+            "config": {"workload": "train_step (BASELINE configs[1]): full PIKA TDNN-Transformer RNN-T, HIP "
+                                   "loader from pinned int16 audio (fbank+splice), CMVN, SpecAugment, fwd, "
+                                   "RNN-T loss, bwd, clip, SGD%s" % (", BMUF all-reduce every 5 steps" if world > 1 else ""),
+                       "batch_per_gpu": B, "T_in": T, "T_enc": 240, "U": U, "V": V,
+                       "global_batch": B * world, "parallelism": "bmuf-dp%d" % world,
+                       "loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": tf / 2500.0, "traffic": None}}
 
 
 def decode_workload(args, dev, rank):
@@ -174,6 +228,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--cpu-utts", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the secondary full-train-step measurement of the default run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,39 +274,9 @@ def main():
                            "calibration_labels": cal_labels, "timing": step.decoder.timing}}), flush=True)
         return
     if args.workload == "train_step":
-        step, flops_per_utt = train_step_workload(args, dev, rank, world)
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        out = run_train_step(args, dev, rank, world, args.steps, args.warmup)
         if rank == 0:
-            from pika_amd import gemm as G
-            tf = flops_per_utt * B / (el / args.steps) / 1e12
-            print(json.dumps({
-                "metric": "utterances/sec RNNT train step (T_in=%d,U=%d,V=%d)" % (T, U, V),
-                "value": B * world / (el / args.steps), "unit": "utterances/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16" if G.PRECISION == "bf16" else "f32-split", "data": "synthetic",
-                "config": {"workload": "train_step: full PIKA TDNN-Transformer RNN-T, CMVN+SpecAugment, "
-                                       "fwd, RNN-T loss, bwd, clip, SGD", "batch_per_gpu": B,
-                           "T_in": T, "T_enc": 240, "U": U, "V": V, "loss": float(loss.item())},
-                "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
-                             "frac": tf / 2500.0, "traffic": None}}), flush=True)
+            print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -330,6 +356,16 @@ def main():
             c_gpu = costs.detach()[:len(c_cpu)].cpu().numpy()
             out["cpu_baseline"]["max_rel_cost_diff_vs_gpu"] = float(
                 np.max(np.abs(c_gpu - c_cpu) / np.abs(c_cpu)))
+    if not args.no_train_step:
+        # secondary measurement in the same run: the full configs[1] training step
+        lp.grad = None
+        gbuf = costs = None  # noqa: F841  (drop the 2 x 32 GB of the loss workload)
+        del lp, labels, tl, ul
+        torch.cuda.empty_cache()
+        ts = run_train_step(args, dev, rank, world, max(5, min(args.steps, 10)), 2)
+        if rank == 0:
+            out["train_step"] = {k: ts[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

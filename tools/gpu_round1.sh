@@ -1,13 +1,12 @@
 #!/bin/bash
-# GPU pass: parity tests, smoke, bench, kernel-trace profile, gradient-writer sweep
+# GPU pass: full GPU test suite, smoke, default bench (M1 + train step), kernel-trace profile
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest.log
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
-timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
-timeout 300 ./tools/grad_sweep > gpurun_out/sweep.log 2>&1
+timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
 export TMPDIR=/tmp; cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train-step > $GRAFT_REPO_ROOT/gpurun_out/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
-tail -15 gpurun_out/pytest.log; tail -3 gpurun_out/smoke.log; tail -3 gpurun_out/bench.log; cat gpurun_out/sweep.log
-find gpurun_out/prof -type f | head
+tail -4 gpurun_out/pytest.log; tail -2 gpurun_out/smoke.log; tail -2 gpurun_out/bench.log
