@@ -1,0 +1,38 @@
+/*
+ * include/pika_decode.h -- C ABI of the fused beam-search step.
+ *
+ * One launch performs, for every utterance of the batch, what the reference does per utterance in
+ * Python with per-element host reads (/root/reference/decoder/beam_transducer.py:82-187
+ * `BeamMergeTransducer.advance`, plus the frame-index part of `_beam_update`,
+ * /root/reference/decoder/transducer_decoder.py:188-202):
+ *   log-softmax(sm_scale * logits) per beam row, + running scores (+ lm_scale * lm_scores), rows
+ *   whose last symbol is eos and duplicate partial hypotheses disabled (-1e20), sorted top-K over
+ *   the K*V candidates, parent / symbol split, score update, finish rule
+ *   ((y == blank and t_idx[parent] == frames-1) or len > max_len), partial-hypothesis update,
+ *   `finished` list append, back-pointer / symbol history, eos_top, frame-index re-ordering.
+ * All state is int64 / f32 device memory laid out as pika_amd/decoder/beam_search.py keeps it.
+ * Two launches: one wavefront per beam row (row top-K), then one workgroup per utterance (merge +
+ * bookkeeping).  `cand_ws`: B*K*K*8 bytes of device scratch.
+ * Requirements: K <= 64, V <= 5120, K*L*4 bytes <= 64 KiB; otherwise PIKA_ETOOBIG.
+ * `first` != 0 selects the reference's first-step branch (only row 0 competes, no score added).
+ */
+#ifndef PIKA_DECODE_H
+#define PIKA_DECODE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int pika_beam_advance(const float *logits, float sm_scale, int first, float *scores,
+                      const float *lm_scores, float lm_scale, long long *y, long long *t_idx,
+                      const long long *num_frames, const long long *max_len, long long *hyp,
+                      long long *hyp_len, int L, long long *ks_hist, long long *ys_hist,
+                      const long long *step_t, unsigned char *eos_top, float *fin_score,
+                      long long *fin_step, long long *fin_k, long long *fin_n, int fin_cap,
+                      long long *prev_k_out, void *cand_ws, int B, int K, int V, int blk,
+                      int beam_prune, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_DECODE_H */

@@ -39,6 +39,10 @@ SIGNATURES = {
     "pika_log_softmax_rows": (_i, [_vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_log_softmax_bwd_rows": (_i, [_vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_mbr_risk_grad_rows": (_i, [_vp, _vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
+    # include/pika_decode.h
+    "pika_beam_advance": (_i, [_vp, ctypes.c_float, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
+                               _i, _vp]),
     # include/pika_audio.h
     "pika_audio_perturb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp, _vp, _vp]),
     "pika_fbank": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, ctypes.c_float, ctypes.c_float,

@@ -1,0 +1,238 @@
+// pika_amd/csrc/decode.hip -- fused beam-search step for gfx950 (include/pika_decode.h).
+//
+// One 256-thread workgroup per utterance.  Each of the 4 waves stages beam rows (V scaled logits)
+// in a wave-private 20 KiB LDS slab: row max / log-sum-exp by wave reductions, then the row's K
+// best entries by K rounds of "lane-local arg-max over the slab + wave arg-max" (ties -> lowest
+// index).  The K*K row winners are merged by a rank sort; the bookkeeping of the reference's
+// `advance` (finish rule, hypotheses, finished list, history) runs on K lanes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pika_decode.h"
+#include "pika_rnnt.h"
+
+namespace {
+
+constexpr float DEAD = -1e20f;
+constexpr long long EOS = -1;
+constexpr int MAXV = 5120, MAXK = 64, WAVES = 4;
+
+struct Cand { float v; int idx; };
+
+__device__ inline bool better(float va, int ia, float vb, int ib) {
+    return va > vb || (va == vb && ia < ib);
+}
+
+// ---- kernel A: one wavefront per beam row -> the row's K best candidates -----------------------
+__global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
+    const float *__restrict__ logits, float sm_scale, int first, const float *__restrict__ scores,
+    const float *__restrict__ lm_scores, float lm_scale, const long long *__restrict__ y,
+    const long long *__restrict__ hyp, const long long *__restrict__ hyp_len, int L, int B, int K,
+    int V, int beam_prune, Cand *__restrict__ cand) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowid = blockIdx.x * WAVES + wave;
+    if (rowid >= B * K) return;
+    float *x = reinterpret_cast<float *>(smem) + wave * MAXV;
+    const int b = rowid / K, k = rowid - b * K;
+    const long long bk = (long long)b * K;
+    Cand *out = cand + (long long)rowid * K;
+
+    // disabled row: eos, or a duplicate of an earlier live slot's partial hypothesis (:100-114)
+    bool d;
+    if (first) {
+        d = k != 0;
+    } else {
+        d = y[bk + k] == EOS;
+        const long long len = hyp_len[bk + k];
+        if (!d && beam_prune && len > 0) {
+            for (int j = 0; j < k && !d; ++j) {
+                if (y[bk + j] == EOS || hyp_len[bk + j] != len) continue;
+                bool same = true;
+                for (long long p = lane; p < len; p += 64)
+                    same &= hyp[(bk + j) * L + p] == hyp[(bk + k) * L + p];
+                d = __all(same);
+            }
+        }
+    }
+    if (d) {  // the whole row is -1e20: its K lowest indices stand in (ties -> index order)
+        if (lane < K) out[lane] = Cand{first ? -3.0e38f : DEAD, k * V + lane};
+        return;
+    }
+    const float *row = logits + (bk + k) * (long long)V;
+    float m = -INFINITY;
+    for (int v0 = lane; v0 < V; v0 += 64 * 8) {   // 8 independent loads in flight per lane
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = v0 + 64 * j < V ? row[v0 + 64 * j] : -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (v0 + 64 * j < V) { x[v0 + 64 * j] = sm_scale * t[j]; m = fmaxf(m, sm_scale * t[j]); }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += __expf(x[v] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float logsum = __logf(s);
+    const float add_s = scores[bk + k], add_l = lm_scale * lm_scores[bk + k];
+    // Lane-local two best entries cached in registers; a lane re-scans its slice only when both
+    // were consumed, so a round costs one wave arg-max instead of a V/64-element scan.
+    float a1 = -INFINITY, a2 = -INFINITY;
+    int i1 = 0x7fffffff, i2 = 0x7fffffff;
+    auto rescan = [&]() {
+        a1 = a2 = -INFINITY; i1 = i2 = 0x7fffffff;
+        for (int v = lane; v < V; v += 64) {
+            const float t = x[v];
+            if (t > a1) { a2 = a1; i2 = i1; a1 = t; i1 = v; }
+            else if (t > a2) { a2 = t; i2 = v; }
+        }
+    };
+    rescan();
+    for (int r = 0; r < K; ++r) {
+        if (__any(i1 == 0x7fffffff)) {
+            if (i1 == 0x7fffffff) rescan();   // consumed entries are -inf in the slab
+        }
+        float bv = a1;
+        int bi = i1;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (bi == i1 && bi != 0x7fffffff) {   // the owning lane pops its cache
+            x[bi] = -INFINITY;
+            a1 = a2; i1 = i2;
+            a2 = -INFINITY; i2 = 0x7fffffff;
+        }
+        if (lane == 0) {
+            float val = (bv - m) - logsum;                 // log_softmax, torch's operation order
+            if (!first) val = (val + add_s) + add_l;       // (:94-97)
+            out[r] = Cand{val, k * V + (bi == 0x7fffffff ? 0 : bi)};
+        }
+    }
+}
+
+// ---- kernel B: one workgroup per utterance: merge + the bookkeeping of `advance` -------------
+__global__ __launch_bounds__(256) void beam_merge_kernel(
+    const Cand *__restrict__ cand_g, int first, float *__restrict__ scores,
+    const float *__restrict__ lm_scores, float lm_scale, long long *__restrict__ y,
+    long long *__restrict__ t_idx, const long long *__restrict__ num_frames,
+    const long long *__restrict__ max_len, long long *__restrict__ hyp,
+    long long *__restrict__ hyp_len, int L, long long *__restrict__ ks_hist,
+    long long *__restrict__ ys_hist, const long long *__restrict__ step_t,
+    unsigned char *__restrict__ eos_top, float *__restrict__ fin_score,
+    long long *__restrict__ fin_step, long long *__restrict__ fin_k, long long *__restrict__ fin_n,
+    int fin_cap, long long *__restrict__ prev_k_out, int B, int K, int V, int blk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
+    Cand *cand = reinterpret_cast<Cand *>(hyp_l + K * L);                // [K][K]
+    __shared__ float lm_old[MAXK], best_v[MAXK];
+    __shared__ long long t_old[MAXK], len_old[MAXK];
+    __shared__ int best_i[MAXK], fin_flag[MAXK];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long bk = (long long)b * K;
+    if (tid < K) {
+        lm_old[tid] = lm_scores[bk + tid];
+        t_old[tid] = t_idx[bk + tid];
+        len_old[tid] = hyp_len[bk + tid];
+    }
+    for (int i = tid; i < K * L; i += blockDim.x) hyp_l[i] = (int)hyp[bk * L + i];
+    const int nc = K * K;
+    for (int c = tid; c < nc; c += blockDim.x) cand[c] = cand_g[bk * K + c];
+    __syncthreads();
+
+    // rank sort of the K*K row winners, value desc / flat index asc (:119-121)
+    for (int c = tid; c < nc; c += blockDim.x) {
+        const Cand me = cand[c];
+        int rank = 0;
+        for (int j = 0; j < nc; ++j) rank += better(cand[j].v, cand[j].idx, me.v, me.idx) ? 1 : 0;
+        if (rank < K) { best_v[rank] = me.v; best_i[rank] = me.idx; }
+    }
+    __syncthreads();
+
+    // ---- bookkeeping on K lanes (:125-187) ---------------------------------------------------
+    const long long s = step_t[0];                  // steps taken before this one
+    const long long n_ys = s + 2;                   // len(next_ys) after the append
+    if (tid < K) {
+        const int id = best_i[tid];
+        const int pk = id / V, ysym = id - pk * V;
+        const float ns = best_v[tid] - lm_scale * lm_old[pk];
+        const bool fin = (ysym == blk && t_old[pk] == num_frames[b] - 1) || (n_ys > max_len[b]);
+        fin_flag[tid] = fin ? 1 : 0;
+        scores[bk + tid] = ns;
+        prev_k_out[bk + tid] = pk;
+        ks_hist[(s * B + b) * K + tid] = pk;
+        const long long yn = fin ? EOS : (long long)ysym;
+        y[bk + tid] = yn;
+        ys_hist[((s + 1) * B + b) * K + tid] = yn;
+        t_idx[bk + tid] = t_old[pk];                // transducer_decoder.py:201-202
+        if (tid == 0 && yn == EOS) eos_top[b] = 1;
+        if (!fin) hyp_len[bk + tid] = len_old[pk] + ((ysym != blk) ? 1 : 0);
+    }
+    __syncthreads();
+    if (tid == 0) {                                  // finished list, slot order (:165-181)
+        long long n = fin_n[b];
+        for (int i = 0; i < K; ++i) {
+            if (!fin_flag[i]) continue;
+            const long long pos = n < fin_cap - 2 ? n : fin_cap - 2;
+            fin_score[(long long)b * fin_cap + pos] = scores[bk + i];
+            fin_step[(long long)b * fin_cap + pos] = n_ys - 1;
+            fin_k[(long long)b * fin_cap + pos] = i;
+            ++n;
+        }
+        fin_n[b] = n;
+    }
+    // partial hypotheses: slot i <- parent's labels (+ y), finished slots keep their own (:217-226)
+    for (int i = 0; i < K; ++i) {
+        if (fin_flag[i]) continue;
+        const int p = best_i[i] / V, ys_ = best_i[i] - p * V;
+        const int plen = (int)len_old[p];
+        long long *dst = hyp + (bk + i) * L;
+        for (int q = tid; q < L; q += blockDim.x) {
+            long long v = hyp_l[p * L + q];
+            if (q == plen && ys_ != blk) v = ys_;
+            dst[q] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first, float *scores,
+                                 const float *lm_scores, float lm_scale, long long *y,
+                                 long long *t_idx, const long long *num_frames,
+                                 const long long *max_len, long long *hyp, long long *hyp_len, int L,
+                                 long long *ks_hist, long long *ys_hist, const long long *step_t,
+                                 unsigned char *eos_top, float *fin_score, long long *fin_step,
+                                 long long *fin_k, long long *fin_n, int fin_cap,
+                                 long long *prev_k_out, void *cand_ws, int B, int K, int V, int blk,
+                                 int beam_prune, void *stream) {
+    if (!logits || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
+        !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step ||
+        !fin_k || !fin_n || !prev_k_out || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3)
+        return PIKA_EINVAL;
+    if (K > MAXK || V > MAXV || V < K || (size_t)K * L * 4 > 64 * 1024) return PIKA_ETOOBIG;
+    if (!cand_ws) return PIKA_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_row_topk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * MAXV * 4);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_merge_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    Cand *cand = static_cast<Cand *>(cand_ws);
+    hipLaunchKernelGGL(beam_row_topk_kernel, dim3((B * K + WAVES - 1) / WAVES), dim3(WAVES * 64),
+                       (size_t)WAVES * MAXV * 4, st, logits, sm_scale, first, scores, lm_scores, lm_scale,
+                       y, hyp, hyp_len, L, B, K, V, beam_prune, cand);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256),
+                       (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand), st, cand, first, scores,
+                       lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist,
+                       ys_hist, step_t, eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out,
+                       B, K, V, blk);
+    return (int)hipGetLastError();
+}

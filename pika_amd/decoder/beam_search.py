@@ -180,6 +180,34 @@ class BeamState(object):
                     out[b, i] = -min(best.values())
         return out.to(self.device)
 
+    def fused_ok(self):
+        return (self.device.type == "cuda" and self.lm_scorer is None and self.K <= 64 and
+                self.K <= self.V <= 5120 and self.K * self.hyp.shape[2] * 4 <= 64 * 1024)
+
+    def advance_fused(self, logits, t_idx, num_frames, sm_scale, lm_scale, first):
+        """The whole of `_advance` + the frame-index re-ordering in ONE HIP launch
+        (include/pika_decode.h).  `logits` are the raw fc2 outputs (B,K,V); `t_idx` is updated in
+        place.  Returns prev_k (a persistent buffer)."""
+        from .. import _lib
+        if not hasattr(self, "_prev_k"):
+            self._prev_k = torch.zeros(self.B, self.K, dtype=torch.long, device=self.device)
+            self._eos_u8 = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
+            self._cand = torch.empty(self.B * self.K * self.K * 8, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().pika_beam_advance(
+                logits.data_ptr(), float(sm_scale), int(bool(first)), self.scores.data_ptr(),
+                self.lm_scores.data_ptr(), float(lm_scale), self.y.data_ptr(), t_idx.data_ptr(),
+                num_frames.data_ptr(), self.max_len.data_ptr(), self.hyp.data_ptr(),
+                self.hyp_len.data_ptr(), self.hyp.shape[2], self.ks_hist.data_ptr(),
+                self.ys_hist.data_ptr(), self.step_t.data_ptr(), self._eos_u8.data_ptr(),
+                self.fin_score.data_ptr(), self.fin_step.data_ptr(), self.fin_k.data_ptr(),
+                self.fin_n.data_ptr(), self.fin_cap, self._prev_k.data_ptr(), self._cand.data_ptr(), self.B, self.K, self.V,
+                self.blk, int(self.beam_prune), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pika_beam_advance")
+        self.step_t += 1
+        self.eos_top.copy_(self._eos_u8.bool())
+        return self._prev_k
+
     def done(self):
         return self.eos_top & (self.fin_n >= self.n_best)                     # :189-194
 

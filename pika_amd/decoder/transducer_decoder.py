@@ -46,6 +46,7 @@ class TransducerDecoder(object):
         self.t_idx = None
         self.dec_states = None
         self.use_graph = True   # capture the steady-state step in a hipGraph on the GPU
+        self.fused_step = True   # fused HIP advance kernel on the GPU (include/pika_decode.h)
         self.incremental = True  # transformer prediction net: one new position per step (cached)
 
     # ---- prediction network stepping (fixed shapes: every row is recomputed, rows whose last
@@ -131,17 +132,24 @@ class TransducerDecoder(object):
             zg = eg_all[bidx, tg] + ops.linear(dec_hid, wgp).view(B, K, H)
             h = torch.tanh(z1) * torch.sigmoid(zg)
             logits = ops.linear(h, model.fc2.weight, model.fc2.bias)
-            logp = F.log_softmax(self.sm_scale * logits, dim=-1)              # :177
-            prev_k = beam._advance(logp, t_idx, num_frames, self.lm_scorer_scale, first)   # :182
+            if fused:
+                prev_k = beam.advance_fused(logits.contiguous(), t_idx, num_frames, self.sm_scale,
+                                            self.lm_scorer_scale, first)
+            else:
+                logp = F.log_softmax(self.sm_scale * logits, dim=-1)          # :177
+                prev_k = beam._advance(logp, t_idx, num_frames, self.lm_scorer_scale, first)   # :182
             # _beam_update :188-202: re-order prediction-net state and frame indices by parent
             flat = (bidx * K + prev_k).reshape(-1)
             for s_ in state:
                 s_.copy_(s_.index_select(1 if rnn else 0, flat))
             if self._inc is not None:
                 self._inc.reorder(flat)
-            t_idx.copy_(t_idx.gather(1, prev_k))
+            if not fused:
+                t_idx.copy_(t_idx.gather(1, prev_k))
             flags[0] = beam.done().all().long()
             flags[1] = beam.hyp_len.max()
+
+        fused = self.fused_step and beam.fused_ok()
 
         def bucket(max_hyp):  # prefix length (SOS + labels) the prediction net attends over
             return 2 if rnn else min(beam.hyp.shape[2] + 1, ((max_hyp + 1 + 1 + 15) // 16) * 16)

@@ -87,3 +87,32 @@ def test_incremental_prediction_net_equals_prefix_recompute():
         assert (d._inc is not None) == inc
     assert np.array_equal(outs[0]["hyps"], outs[1]["hyps"])
     assert np.allclose(outs[0]["scores"], outs[1]["scores"], atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_advance_kernel_equals_tensor_op_path(hip_device):
+    """include/pika_decode.h vs the torch-op `_advance`, both on the GPU, several beam widths."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        for dec in ("rnn", "transformer"):
+            net = build(dec, hip_device)
+            x, x_len = D.inputs()
+            x, xl = x.to(hip_device), x_len.to(hip_device)
+            for beam, nb, ml in ((1, 1, None), (5, 3, None), (16, 16, None), (7, 7, 9)):
+                outs = []
+                for fused in (True, False):
+                    args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+                    d = TransducerDecoder(net, 4, beam, n_best=nb, blk=0, global_scorer=GlobalScorer(), sm_scale=0.85,
+                                          cuda=True, beam_prune=True, args=args)
+                    d.fused_step = fused
+                    mlen = [int(v) + 100 for v in x_len] if ml is None else [ml] * 4
+                    ret, _ = d.decode_batch(x, xl, mlen)
+                    outs.append(D.pack(ret["predictions"], ret["scores"]))
+                assert np.array_equal(outs[0]["hyps"], outs[1]["hyps"]), (dec, beam)
+                assert np.allclose(outs[0]["scores"], outs[1]["scores"], atol=2e-4), (dec, beam)
+    finally:
+        G.PRECISION = old
