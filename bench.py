@@ -336,7 +336,9 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "rnnt_grad_pmc.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            # measured at (B=32,T=1000,U=50,V=5000); bytes scale with the batch, valid for that lattice only
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch") * B / 32.0 \
+                if (T, U, V) == (1000, 50, 5000) else None
         out = {
             "metric": "utterances/sec RNNT fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
             "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,

@@ -1,0 +1,35 @@
+/*
+ * include/pika_norm.h -- C ABI of the BatchNorm kernels of the TDNN encoder.
+ *
+ * Replaces nn.BatchNorm1d over the (B*T, C) activation matrix in training mode
+ * (/root/reference/trainer/model/rnnt_tdnn_transformer.py:76-78,80-82,85: `bn(relu(conv(x)))`,
+ * batch statistics over ALL B*T rows, padded frames included).  Conventions as in pika_rnnt.h.
+ */
+#ifndef PIKA_NORM_H
+#define PIKA_NORM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-channel sums: stats[0..C) = sum_r x[r][c], stats[C..2C) = sum_r x[r][c]^2 (fp64, zeroed by
+ * the call).  x (rows, C) f32 contiguous. */
+int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *stream);
+
+/* y = (x - mean) * rstd * gamma + beta with mean/var from `stats` (biased variance, eps inside the
+ * sqrt); writes save_mean / save_rstd (C each, for the backward) and, when running_mean != NULL,
+ * running = (1-momentum)*running + momentum*{mean, unbiased var}. */
+int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
+                  const float *beta, float eps, float momentum, float *running_mean,
+                  float *running_var, float *save_mean, float *save_rstd, float *y, void *stream);
+
+/* Backward, two launches: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (fp64); then
+ * dx = gamma*rstd*(dy - sum_dy/rows - xhat*sum_dy_xhat/rows), dgamma = sum dy*xhat, dbeta = sum dy. */
+int pika_bn_backward(const float *dy, const float *x, long long rows, int C, const float *gamma,
+                     const float *save_mean, const float *save_rstd, double *sums, float *dx,
+                     float *dgamma, float *dbeta, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_NORM_H */

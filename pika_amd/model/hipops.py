@@ -220,3 +220,43 @@ class LogSoftmaxFn(torch.autograd.Function):
                                                             cols, ctx.scale, _stream()),
                        "pika_log_softmax_bwd_rows")
         return g, None
+
+
+class BatchNormFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over the rows of a (M,C) matrix (include/pika_norm.h); running
+    statistics updated in place exactly as nn.BatchNorm1d does (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        x = x.contiguous()
+        M, C = x.shape
+        lib = _lib.lib()
+        with torch.cuda.device(x.device):
+            stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            rstd = torch.empty_like(mean)
+            y = torch.empty_like(x)
+            _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), _stream()), "pika_bn_stats")
+            _lib.check(lib.pika_bn_apply(
+                x.data_ptr(), M, C, stats.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps),
+                float(momentum), None if running_mean is None else running_mean.data_ptr(),
+                None if running_var is None else running_var.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                y.data_ptr(), _stream()), "pika_bn_apply")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        M, C = x.shape
+        dy = dy.contiguous()
+        with torch.cuda.device(x.device):
+            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            dx = torch.empty_like(x)
+            dg = torch.empty(C, dtype=torch.float32, device=x.device)
+            db = torch.empty_like(dg)
+            _lib.check(_lib.lib().pika_bn_backward(dy.data_ptr(), x.data_ptr(), M, C, weight.data_ptr(),
+                                                   mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
+                                                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(), _stream()),
+                       "pika_bn_backward")
+        return dx, dg, db, None, None, None, None

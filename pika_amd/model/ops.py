@@ -33,6 +33,12 @@ def relu(x):
 
 def batch_norm(x2d, bn):
     """BatchNorm1d over rows of a (M,C) matrix with the module's buffers (train: batch stats)."""
+    train_stats = bn.training or not bn.track_running_stats
+    if _hip(x2d) and train_stats and bn.affine and x2d.shape[1] % 4 == 0 and x2d.dtype == torch.float32:
+        from .hipops import BatchNormFn
+        mom = _bn_momentum(bn)
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        return BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom)
     return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                         bn.training or not bn.track_running_stats,
                         _bn_momentum(bn), bn.eps)
