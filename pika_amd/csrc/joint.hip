@@ -193,6 +193,84 @@ __global__ __launch_bounds__(ROW_THREADS) void log_softmax_bwd_kernel(const floa
     }
 }
 
+
+// ---- wave-per-row variants: no workgroup barriers, 4 rows in flight per workgroup; row held in
+// registers (cols <= 64 lanes * 4 * WQ floats) -------------------------------------------------
+constexpr int WQ = 20;  // float4 per lane -> up to 5120 columns
+
+__device__ inline float wave_red(float v, bool is_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void log_softmax_wave_kernel(float *__restrict__ x, long long rows,
+                                                               int cols, long long ld, float scale) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = cols >> 2;
+    f32x4 *row = reinterpret_cast<f32x4 *>(x + r * ld);
+    f32x4 v[WQ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) {
+            v[q] = row[i] * scale;
+            m = fmaxf(m, fmaxf(fmaxf(v[q].x, v[q].y), fmaxf(v[q].z, v[q].w)));
+        }
+    }
+    m = wave_red(m, true);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+        if (lane + q * 64 < c4)
+            s += __expf(v[q].x - m) + __expf(v[q].y - m) + __expf(v[q].z - m) + __expf(v[q].w - m);
+    s = wave_red(s, false);
+    const float lse = m + __logf(s);
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+        if (lane + q * 64 < c4) row[lane + q * 64] = v[q] - lse;
+}
+
+__global__ __launch_bounds__(256) void log_softmax_bwd_wave_kernel(const float *__restrict__ lp,
+                                                                   float *__restrict__ g, long long rows,
+                                                                   int cols, long long ld, float scale) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = cols >> 2;
+    const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * ld);
+    f32x4 *grow = reinterpret_cast<f32x4 *>(g + r * ld);
+    f32x4 v[WQ];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+        if (lane + q * 64 < c4) {
+            v[q] = grow[lane + q * 64];
+            s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        }
+    s = wave_red(s, false);
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+        if (lane + q * 64 < c4) {
+            const f32x4 l = lrow[lane + q * 64];
+            f32x4 o;
+            o.x = scale * (v[q].x - __expf(l.x) * s);
+            o.y = scale * (v[q].y - __expf(l.y) * s);
+            o.z = scale * (v[q].z - __expf(l.z) * s);
+            o.w = scale * (v[q].w - __expf(l.w) * s);
+            grow[lane + q * 64] = o;
+        }
+}
+
+inline bool wave_row_ok(const void *a, const void *b, int cols, long long ld) {
+    return (cols & 3) == 0 && (ld & 3) == 0 && cols <= 64 * 4 * WQ &&
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+
 __global__ __launch_bounds__(ROW_THREADS) void mbr_risk_grad_kernel(float *__restrict__ lp,
                                                                     const int *__restrict__ sym,
                                                                     const float *__restrict__ val,
@@ -246,8 +324,12 @@ int pika_log_softmax_rows(float *x, long long rows, int cols, long long ld, floa
                           void *stream) {
     if (!x || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
-    hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
-                       static_cast<hipStream_t>(stream), x, cols, ld, scale);
+    if (wave_row_ok(x, x, cols, ld))
+        hipLaunchKernelGGL(log_softmax_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), x, rows, cols, ld, scale);
+    else
+        hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
+                           static_cast<hipStream_t>(stream), x, cols, ld, scale);
     return (int)hipGetLastError();
 }
 
@@ -255,8 +337,12 @@ int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int col
                               float scale, void *stream) {
     if (!lp || !g || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
-    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
-                       static_cast<hipStream_t>(stream), lp, g, cols, ld, scale);
+    if (wave_row_ok(lp, g, cols, ld))
+        hipLaunchKernelGGL(log_softmax_bwd_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), lp, g, rows, cols, ld, scale);
+    else
+        hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
+                           static_cast<hipStream_t>(stream), lp, g, cols, ld, scale);
     return (int)hipGetLastError();
 }
 
