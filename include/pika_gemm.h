@@ -37,13 +37,19 @@ typedef struct {
     int C;               /* channels per tap: k -> tap = k / C, c = k % C */
     int stride, dil, pad;/* ti = t*stride + tap*dil - pad */
     long long z_outer, z_inner; /* element offsets per batched-GEMM index z: (z / z_div, z % z_div) */
+    int trans;           /* 0: (row, k) = (time-like (b,t), channel-like (tap,c)): reduction contiguous.
+                          * 1: roles swapped -- the REDUCTION runs over the time-like index and the output
+                          *    row over the channel-like one (matrix stored [k][row], output index
+                          *    contiguous): dY and X in dW = dY^T X, W in dX = dY W.  No transposed copy
+                          *    is made: the kernel uses the gfx950 LDS transpose read. */
 } pika_operand_t;
 
 #define PIKA_GEMM_RELU 1
 #define PIKA_GEMM_ACCUMULATE 2
 #define PIKA_GEMM_FP32SPLIT 4
 
-/* Requirements (16-byte operand loads): K % 4 == 0; with g = 4 for f32 / 8 for bf16 operands, C,
+/* Requirements (16-byte operand loads): K % 4 == 0 unless both operands are `trans` (then the output
+ * extents M / N must be multiples of g instead); with g = 4 for f32 / 8 for bf16 operands, C,
  * ld and the batch strides must be multiples of g and the base pointer 16-byte aligned; the rows
  * of a bf16 operand must be readable and ZERO up to the next multiple of 8 past K.  Returns PIKA_EINVAL otherwise (the caller decides; nothing falls back silently). */
 int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,

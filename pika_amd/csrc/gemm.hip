@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pika_gemm.h"
 #include "pika_rnnt.h"  // PIKA_EINVAL
 
@@ -29,12 +31,114 @@ struct Cfg {
                                           // rows of a fragment read land on 16 distinct 4-bank groups
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
 struct Op {  // device-side copy of pika_operand_t
     const char *ptr;
     int rows_per_batch, t_in;
     long long batch_stride, ld;
     int C, stride, dil, pad;
 };
+
+// Transposed operand: the matrix is stored with the OUTPUT index contiguous, X[k][r] (k = reduction
+// = the time-like index (b,t), r = the channel-like index (tap,c)) -- dY and X in dW = dY^T X, W in
+// dX = dY W.  The tile goes into LDS as it lies in memory, [BK][COLS(+8)], with coalesced 16-byte
+// loads along r, and the MFMA fragments (8 consecutive k per lane) come out of the gfx950
+// transpose read ds_read_b64_tr_b16: within a 16-lane group, lanes 4j..4j+3 supply row j (16
+// consecutive r) and lane i receives column i of the 4 rows (measured: tools/tr_probe.hip).
+template <typename T, int COLS, typename CF>
+struct LoaderT {
+    static constexpr int EPL = 16 / sizeof(T);
+    static constexpr int TPR = COLS / EPL;              // threads per k-row
+    static constexpr int RPP = CF::THREADS / TPR;       // k-rows per pass
+    static constexpr int NP = CF::BK / RPP;
+    static constexpr int PITCHT = COLS + 8;
+    static_assert(CF::THREADS % TPR == 0 && CF::BK % RPP == 0 && NP >= 1, "tile shape");
+    const T *base;
+    long long ld, bstride;
+    int t_in, rpb, stride_;
+    int tapoff;            // tap*dil - pad of this thread's output quad (fixed)
+    int c;                 // channel of this thread's output quad (fixed)
+    bool out_ok;
+    int kb[NP], kt[NP];    // (b,t) of this thread's reduction rows
+    int k[NP], K;
+
+    __device__ inline void init(const Op &o, long long zoff, int o0, int nout, int K_, int k0) {
+        const int tid = threadIdx.x;
+        base = reinterpret_cast<const T *>(o.ptr) + zoff;
+        ld = o.ld; bstride = o.batch_stride; t_in = o.t_in; rpb = o.rows_per_batch; stride_ = o.stride; K = K_;
+        const int oq = o0 + (tid % TPR) * EPL;
+        out_ok = oq < nout;
+        const int tap = oq / o.C;
+        c = oq - tap * o.C;
+        tapoff = tap * o.dil - o.pad;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            k[i] = k0 + tid / TPR + RPP * i;
+            kb[i] = k[i] / rpb;
+            kt[i] = k[i] - kb[i] * rpb;
+        }
+    }
+    __device__ inline void advance() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            k[i] += CF::BK;
+            kt[i] += CF::BK;
+            while (kt[i] >= rpb) { kt[i] -= rpb; ++kb[i]; }
+        }
+    }
+    __device__ inline void load(f32x4 raw[NP]) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int ti = kt[i] * stride_ + tapoff;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (out_ok && k[i] < K && ti >= 0 && ti < t_in)
+                x = *reinterpret_cast<const f32x4 *>(base + (long long)kb[i] * bstride + (long long)ti * ld + c);
+            raw[i] = x;
+        }
+    }
+    template <int NS>
+    __device__ inline void stage(__bf16 *dst, int part, const f32x4 raw[NP]) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int off = (tid / TPR + RPP * i) * PITCHT + (tid % TPR) * EPL;
+            if constexpr (sizeof(T) == 4) {
+                f32x4 r = raw[i];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bf16x4 h = __builtin_convertvector(r, bf16x4);
+                    *reinterpret_cast<bf16x4 *>(dst + s * part + off) = h;
+                    if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
+                }
+            } else {
+                *reinterpret_cast<f32x4 *>(dst + off) = raw[i];
+                if constexpr (NS > 1) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 1; s < NS; ++s) *reinterpret_cast<f32x4 *>(dst + s * part + off) = z;
+                }
+            }
+        }
+    }
+};
+
+// MFMA fragment (8 consecutive k of output row/col `r0 + (lane&15)`) from either tile layout.
+template <bool TR, int PITCH, int PITCHT>
+__device__ inline bf16x8 fragment(const __bf16 *tile, int r0, int kk, int lane) {
+    if constexpr (!TR) {
+        return *reinterpret_cast<const bf16x8 *>(tile + (r0 + (lane & 15)) * PITCH + kk + (lane >> 4) * 8);
+    } else {
+        const int i = lane & 15, j = i >> 2, q = i & 3, k0 = kk + (lane >> 4) * 8;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const __bf16 *p0 = tile + (k0 + j) * PITCHT + r0 + 4 * q;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 4 * PITCHT));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
 
 // Per-thread loader of one operand tile (ROWS x BK): 16-byte loads (4 f32 or 8 bf16), TPR threads
 // per row, NP passes of RPP rows.
@@ -118,14 +222,17 @@ struct Loader {
     }
 };
 
-template <typename TA, typename TB, int NS, typename CF>
+template <typename TA, typename TB, int NS, typename CF, bool TRA, bool TRB>
 __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
     Op A, Op B, long long a_zo, long long a_zi, long long b_zo, long long b_zi,
     float *__restrict__ Cp, long long ldc, long long c_zo, long long c_zi, int M, int N, int K,
     int z_div, int splitk, const float *__restrict__ bias, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = CF::BM, BN = CF::BN, BK = CF::BK, PITCH = CF::PITCH;
-    constexpr int TA_ELEMS = BM * PITCH, TB_ELEMS = BN * PITCH;
+    using LA = typename std::conditional<TRA, LoaderT<TA, BM, CF>, Loader<TA, BM, CF>>::type;
+    using LB = typename std::conditional<TRB, LoaderT<TB, BN, CF>, Loader<TB, BN, CF>>::type;
+    constexpr int PTA = BM + 8, PTB = BN + 8;
+    constexpr int TA_ELEMS = TRA ? BK * PTA : BM * PITCH, TB_ELEMS = TRB ? BK * PTB : BN * PITCH;
     // layout: [buf][A parts 0..NS-1 | B parts 0..NS-1]
     constexpr int BOFF = NS * TA_ELEMS;
     constexpr int PER_BUF = NS * (TA_ELEMS + TB_ELEMS);
@@ -147,8 +254,8 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / CF::WN, wn = wave % CF::WN;
 
-    Loader<TA, BM, CF> la;
-    Loader<TB, BN, CF> lb;
+    LA la;
+    LB lb;
     const int nk_all = (K + BK - 1) / BK;
     const int nk_per = (nk_all + splitk - 1) / splitk;
     const int kb0 = split * nk_per;
@@ -156,8 +263,8 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
     if (nk <= 0) return;
     // a bf16 operand is read in 8-element groups: its rows are zero-padded to a multiple of 8
     // by contract, so its bound is K rounded up (the other operand supplies the zeros)
-    la.init(A, zo * a_zo + zi * a_zi, m0, M, sizeof(TA) == 2 ? (K + 7) & ~7 : K, kb0 * BK);
-    lb.init(B, zo * b_zo + zi * b_zi, n0, N, sizeof(TB) == 2 ? (K + 7) & ~7 : K, kb0 * BK);
+    la.init(A, zo * a_zo + zi * a_zi, m0, M, (sizeof(TA) == 2 && !TRA) ? (K + 7) & ~7 : K, kb0 * BK);
+    lb.init(B, zo * b_zo + zi * b_zi, n0, N, (sizeof(TB) == 2 && !TRB) ? (K + 7) & ~7 : K, kb0 * BK);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -165,14 +272,13 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[Loader<TA, BM, CF>::NP], rb[Loader<TB, BN, CF>::NP];
+    f32x4 ra[LA::NP], rb[LB::NP];
     la.load(ra);
     lb.load(rb);
     la.template stage<NS>(lds, TA_ELEMS, ra);
     lb.template stage<NS>(lds + BOFF, TB_ELEMS, rb);
     __syncthreads();
 
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
     for (int kb = 0; kb < nk; ++kb) {
         const __bf16 *cur = lds + (kb & 1) * PER_BUF;
         __bf16 *nxt = lds + ((kb + 1) & 1) * PER_BUF;
@@ -194,8 +300,8 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    fa[i] = *reinterpret_cast<const bf16x8 *>(cur + PA[p] * TA_ELEMS + (wm * 64 + i * 16 + frow) * PITCH + kk + fk);
-                    fb[i] = *reinterpret_cast<const bf16x8 *>(cur + BOFF + PB[p] * TB_ELEMS + (wn * 64 + i * 16 + frow) * PITCH + kk + fk);
+                    fa[i] = fragment<TRA, PITCH, PTA>(cur + PA[p] * TA_ELEMS, wm * 64 + i * 16, kk, lane);
+                    fb[i] = fragment<TRB, PITCH, PTB>(cur + BOFF + PB[p] * TB_ELEMS, wn * 64 + i * 16, kk, lane);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -260,23 +366,26 @@ Op to_op(const pika_operand_t &o) {
     return r;
 }
 
-bool operand_ok(const pika_operand_t &o, int K) {
+bool operand_ok(const pika_operand_t &o, int K, int nout) {
     if (!o.ptr || o.rows_per_batch <= 0 || o.t_in <= 0 || o.C <= 0 || o.stride <= 0) return false;
     if (o.dtype != PIKA_F32 && o.dtype != PIKA_BF16) return false;
     const int g = o.dtype == PIKA_F32 ? 3 : 7;  // elements per 16-byte load - 1
-    if ((o.C & g) || (K & 3) || (o.ld & g) || (o.batch_stride & g) || (o.z_outer & g) || (o.z_inner & g))
+    if ((o.C & g) || (o.ld & g) || (o.batch_stride & g) || (o.z_outer & g) || (o.z_inner & g))
         return false;
+    if (o.trans ? (nout & g) : (K & 3)) return false;   // the 16-byte loads run along this extent
     return (reinterpret_cast<uintptr_t>(o.ptr) & 15) == 0;
 }
 
-template <typename TA, typename TB, int NS, typename CF>
+template <typename TA, typename TB, int NS, typename CF, bool TRA, bool TRB>
 int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
            long long c_zo, long long c_zi, int M, int N, int K, int batch, int z_div,
            const float *bias, int flags, hipStream_t s) {
-    constexpr size_t smem = (size_t)2 * NS * (CF::BM + CF::BN) * CF::PITCH * sizeof(__bf16);
+    constexpr size_t ta = TRA ? CF::BK * (CF::BM + 8) : CF::BM * CF::PITCH;
+    constexpr size_t tb = TRB ? CF::BK * (CF::BN + 8) : CF::BN * CF::PITCH;
+    constexpr size_t smem = (size_t)2 * NS * (ta + tb) * sizeof(__bf16);
     static_assert(smem <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     static bool attr_set = false;  // idempotent; racing threads set the same value
-    auto kern = gemm_nt_kernel<TA, TB, NS, CF>;
+    auto kern = gemm_nt_kernel<TA, TB, NS, CF, TRA, TRB>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -306,28 +415,52 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     return (int)hipGetLastError();
 }
 
-// Tile configuration: PIKA_GEMM_CFG=0..3 overrides (hardware A/B only).
+// Tile configuration: PIKA_GEMM_CFG=0..3 overrides (hardware A/B only; NT operands).
 //   0: 128x128x32 / 4 waves   1: 128x128x64 / 4 waves   2: 256x128x64 / 8 waves   3: 256x128x32
 int cfg_override() {
     static const int v = [] { const char *e = getenv("PIKA_GEMM_CFG"); return e ? atoi(e) : -1; }();
     return v;
 }
 
-template <typename TA, typename TB>
+template <typename TA, typename TB, bool TRA, bool TRB>
 int dispatch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
              long long c_zo, long long c_zi, int M, int N, int K, int batch, int z_div,
              const float *bias, int flags, hipStream_t s) {
 #define ARGS A, B, C, ldc, c_zo, c_zi, M, N, K, batch, z_div, bias, flags, s
-    if (flags & PIKA_GEMM_FP32SPLIT) return launch<TA, TB, 3, Cfg<2, 2, 32>>(ARGS);
-    // measured on MI355X (tools/gemm_bench.py, profiles/r1_gemm_cfg_sweep.txt): 256x128x64 / 8 waves
-    // wins except for f32 x bf16 operands, where 128x128x64 does
-    int cfg = cfg_override();
-    if (cfg < 0) cfg = (sizeof(TA) == 4 && sizeof(TB) == 2) ? 1 : 2;
-    switch (cfg) {
-        case 0: return launch<TA, TB, 1, Cfg<2, 2, 32>>(ARGS);
-        case 2: return launch<TA, TB, 1, Cfg<4, 2, 64>>(ARGS);
-        case 3: return launch<TA, TB, 1, Cfg<4, 2, 32>>(ARGS);
-        default: return launch<TA, TB, 1, Cfg<2, 2, 64>>(ARGS);
+    if (flags & PIKA_GEMM_FP32SPLIT) {
+        // parity mode keeps every tensor fp32 (bf16 operands still work through the NT path)
+        if constexpr (!(TRA || TRB) || (sizeof(TA) == 4 && sizeof(TB) == 4))
+            return launch<TA, TB, 3, Cfg<2, 2, 32>, TRA, TRB>(ARGS);
+        else
+            return PIKA_EINVAL;
+    }
+    if constexpr (TRA || TRB) {
+        return launch<TA, TB, 1, Cfg<4, 2, 64>, TRA, TRB>(ARGS);
+    } else {
+        // measured on MI355X (tools/gemm_bench.py, profiles/r1_gemm_cfg_sweep.txt): 256x128x64 / 8
+        // waves wins except for f32 x bf16 operands, where 128x128x64 does
+        int cfg = cfg_override();
+        if (cfg < 0) cfg = (sizeof(TA) == 4 && sizeof(TB) == 2) ? 1 : 2;
+        switch (cfg) {
+            case 0: return launch<TA, TB, 1, Cfg<2, 2, 32>, false, false>(ARGS);
+            case 2: return launch<TA, TB, 1, Cfg<4, 2, 64>, false, false>(ARGS);
+            case 3: return launch<TA, TB, 1, Cfg<4, 2, 32>, false, false>(ARGS);
+            default: return launch<TA, TB, 1, Cfg<2, 2, 64>, false, false>(ARGS);
+        }
+    }
+#undef ARGS
+}
+
+template <typename TA, typename TB>
+int dispatch_trans(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+                   long long c_zo, long long c_zi, int M, int N, int K, int batch, int z_div,
+                   const float *bias, int flags, hipStream_t s) {
+#define ARGS A, B, C, ldc, c_zo, c_zi, M, N, K, batch, z_div, bias, flags, s
+    switch ((A->trans ? 2 : 0) | (B->trans ? 1 : 0)) {
+        case 0: return dispatch<TA, TB, false, false>(ARGS);
+        case 1: return dispatch<TA, TB, false, true>(ARGS);
+        case 2: return dispatch<TA, TB, true, false>(ARGS);
+        default: return dispatch<TA, TB, true, true>(ARGS);
     }
 #undef ARGS
 }
@@ -339,16 +472,16 @@ extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, fl
                             int K, int batch, int z_div, const float *bias, int flags,
                             void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || z_div <= 0) return PIKA_EINVAL;
-    if (!operand_ok(*A, K) || !operand_ok(*B, K)) return PIKA_EINVAL;
+    if (!operand_ok(*A, K, M) || !operand_ok(*B, K, N)) return PIKA_EINVAL;
     if (batch > 65535) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int key = (A->dtype == PIKA_BF16 ? 2 : 0) | (B->dtype == PIKA_BF16 ? 1 : 0);
 #define ARGS A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, bias, flags, s
     switch (key) {
-        case 0: return dispatch<float, float>(ARGS);
-        case 1: return dispatch<float, __bf16>(ARGS);
-        case 2: return dispatch<__bf16, float>(ARGS);
-        default: return dispatch<__bf16, __bf16>(ARGS);
+        case 0: return dispatch_trans<float, float>(ARGS);
+        case 1: return dispatch_trans<float, __bf16>(ARGS);
+        case 2: return dispatch_trans<__bf16, float>(ARGS);
+        default: return dispatch_trans<__bf16, __bf16>(ARGS);
     }
 #undef ARGS
 }

@@ -490,7 +490,7 @@ void launch_ab(const Lattice &L, const int *Tn, const int *Un, float *costs, int
 
 extern "C" {
 
-int pika_amd_abi_version(void) { return 1; }
+int pika_amd_abi_version(void) { return 2; }
 
 size_t pika_rnnt_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024) return 0;

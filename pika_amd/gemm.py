@@ -19,7 +19,8 @@ class Operand(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("dtype", ctypes.c_int), ("rows_per_batch", ctypes.c_int),
                 ("t_in", ctypes.c_int), ("batch_stride", ctypes.c_longlong), ("ld", ctypes.c_longlong),
                 ("C", ctypes.c_int), ("stride", ctypes.c_int), ("dil", ctypes.c_int),
-                ("pad", ctypes.c_int), ("z_outer", ctypes.c_longlong), ("z_inner", ctypes.c_longlong)]
+                ("pad", ctypes.c_int), ("z_outer", ctypes.c_longlong), ("z_inner", ctypes.c_longlong),
+                ("trans", ctypes.c_int)]
 
 
 def _dtype(t):
@@ -36,6 +37,14 @@ def matrix(t, z_outer=0, z_inner=0):
     rows, K = t.shape
     return Operand(t.data_ptr(), _dtype(t), max(rows, 1), max(rows, 1), 0, t.stride(0), K, 1, 0, 0,
                    z_outer, z_inner), rows, K
+
+
+def matrix_t(t):
+    """The (rows,K) matrix `t` used TRANSPOSED: output index = its columns, reduction = its rows.
+    Returns (operand, n_out, n_red)."""
+    op, rows, K = matrix(t)
+    op.trans = 1
+    return op, K, rows
 
 
 def time_delay(x, taps, dil=1, stride=1, pad=0):

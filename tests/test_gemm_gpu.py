@@ -117,3 +117,54 @@ def test_batched_strided_attention_shapes(hip_device):
     want = qh @ kh.transpose(2, 3)
     scale = qh.abs() @ kh.abs().transpose(2, 3)
     assert ((out.double() - want).abs() / scale).max() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 40), (300, 256, 1000), (1024, 3072, 5000), (100, 36, 77)])
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_transposed_operands_tn(hip_device, M, N, K, precision):
+    """C[M,N] = At^T @ Bt with At (K,M), Bt (K,N) read in place through `trans` operands
+    (weight-gradient form dW = dY^T X), and the mixed form A (M,K) normal x Bt (K,N) trans
+    (input-gradient form dX = dY W)."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    at = (torch.randn(K, M, generator=g) + 0.2 * torch.arange(M) / M).to(hip_device)
+    bt = (torch.randn(K, N, generator=g) * (1 + torch.arange(K).unsqueeze(1) / K)).to(hip_device)
+    a_op, m_, k_ = G.matrix_t(at)
+    b_op, n_, _ = G.matrix_t(bt)
+    assert (m_, n_, k_) == (M, N, K)
+    out = torch.empty(M, N, device=hip_device)
+    G.launch(a_op, b_op, out, N, M, N, K, precision=precision)
+    want = at.double().t() @ bt.double()
+    scale = at.double().abs().t() @ bt.double().abs()
+    tol = 1e-6 * max(1.0, K ** 0.5 / 8) if precision == "fp32" else 2 ** -7
+    assert ((out.double() - want).abs() / scale).max().item() < tol
+    if K % 4 == 0:
+        a = at.t().contiguous()                      # (M,K) normal operand
+        out2 = torch.empty(M, N, device=hip_device)
+        G.launch(G.matrix(a)[0], G.matrix_t(bt)[0], out2, N, M, N, K, precision=precision)
+        assert ((out2.double() - want).abs() / scale).max().item() < tol
+        if precision == "bf16":   # bf16 storage of the transposed operand (joint hidden h)
+            out3 = torch.empty(M, N, device=hip_device)
+            if N % 8 == 0:
+                G.launch(G.matrix(a)[0], G.matrix_t(bt.bfloat16())[0], out3, N, M, N, K, precision=precision)
+                assert torch.allclose(out3, out2, rtol=1e-4, atol=1e-2)  # split-K sums in any order
+
+
+def test_time_delay_weight_gradient_in_place(hip_device):
+    """dW[n,(tap,c)] = sum_(b,t) dY[(b,t),n] * x[b, t*stride + tap*dil - pad, c] with both operands
+    `trans` (one of them virtual) vs the explicit im2col product."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(77)
+    Bn, T, C, N, taps, dil, stride, pad = 3, 61, 32, 48, 3, 3, 4, 0
+    x = torch.randn(Bn, T, C, generator=g).to(hip_device)
+    a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
+    dy = torch.randn(M, N, generator=g).to(hip_device)
+    a_op.trans = 1
+    dy_op = G.matrix(dy)[0]
+    dy_op.trans = 1
+    out = torch.empty(N, K, device=hip_device)
+    G.launch(dy_op, a_op, out, K, N, K, M, precision="fp32")
+    cols = [x[:, j * dil: j * dil + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
+    a = torch.cat(cols, -1).reshape(M, K)
+    want = dy.double().t() @ a.double()
+    assert ((out.double() - want).abs() / (dy.double().abs().t() @ a.double().abs())).max() < 2e-6
