@@ -398,7 +398,8 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     const int nk = (K + CF::BK - 1) / CF::BK;
     int splitk = 1;
     if (batch == 1 && tiles < 256 && nk >= 32 && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
-        splitk = (512 + tiles - 1) / tiles;
+        static const int target = [] { const char *e = getenv("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 384; }();
+        splitk = (target + tiles - 1) / tiles;
         if (splitk > nk / 8) splitk = nk / 8;
         if (splitk > 64) splitk = 64;
         if (splitk < 1) splitk = 1;
