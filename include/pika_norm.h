@@ -24,10 +24,12 @@ int pika_bn_apply(const float *x, long long rows, int C, const double *stats, co
                   float *running_var, float *save_mean, float *save_rstd, float *y, void *stream);
 
 /* Backward, two launches: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (fp64); then
- * dx = gamma*rstd*(dy - sum_dy/rows - xhat*sum_dy_xhat/rows), dgamma = sum dy*xhat, dbeta = sum dy. */
+ * dx = gamma*rstd*(dy - sum_dy/rows - xhat*sum_dy_xhat/rows), dgamma = sum dy*xhat, dbeta = sum dy.
+ * relu_mask != 0: x is the output of a ReLU (the reference computes bn(relu(conv(.)))) and dx is
+ * additionally multiplied by (x > 0), i.e. the ReLU backward is folded into this pass. */
 int pika_bn_backward(const float *dy, const float *x, long long rows, int C, const float *gamma,
                      const float *save_mean, const float *save_rstd, double *sums, float *dx,
-                     float *dgamma, float *dbeta, void *stream);
+                     float *dgamma, float *dbeta, int relu_mask, void *stream);
 
 #ifdef __cplusplus
 }

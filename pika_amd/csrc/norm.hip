@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
                                                            const float *__restrict__ rstd,
                                                            const float *__restrict__ gamma,
                                                            const double *__restrict__ sums,
-                                                           float *__restrict__ dx) {
+                                                           float *__restrict__ dx, int relu_mask) {
     const long long stride = (long long)gridDim.x * 256;
     const float inv = 1.0f / (float)rows;
     const int C = C4 * 4;
@@ -100,7 +100,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sd[e] = (float)sums[4 * c + e]; sx[e] = (float)sums[C + 4 * c + e]; }
         const f32x4 xhat = (v - m) * r;
-        reinterpret_cast<f32x4 *>(dx)[i] = g * r * (d - sd * inv - xhat * (sx * inv));
+        f32x4 o = g * r * (d - sd * inv - xhat * (sx * inv));
+        if (relu_mask) {
+            o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f;
+            o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
+        }
+        reinterpret_cast<f32x4 *>(dx)[i] = o;
     }
 }
 
@@ -148,7 +153,7 @@ int pika_bn_apply(const float *x, long long rows, int C, const double *stats, co
 
 int pika_bn_backward(const float *dy, const float *x, long long rows, int C, const float *gamma,
                      const float *save_mean, const float *save_rstd, double *sums, float *dx,
-                     float *dgamma, float *dbeta, void *stream) {
+                     float *dgamma, float *dbeta, int relu_mask, void *stream) {
     if (!dy || !x || !gamma || !save_mean || !save_rstd || !sums || !dx || !dgamma || !dbeta ||
         rows <= 0 || C <= 0 || (C & 3))
         return PIKA_EINVAL;
@@ -159,7 +164,7 @@ int pika_bn_backward(const float *dy, const float *x, long long rows, int C, con
                        save_rstd, rows, C, sums);
     const long long n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, n4, C / 4, rows,
-                       save_mean, save_rstd, gamma, sums, dx);
+                       save_mean, save_rstd, gamma, sums, dx, relu_mask);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma,
                        dbeta);
     return (int)hipGetLastError();

@@ -36,11 +36,13 @@ class Net(nn.Module):
     def forward(self, x, frame_offset=0):
         B = x.size(0)
         C = self.tdnn_nhid
-        h = ops.relu(ops.linear(x, self.fc_in.weight, self.fc_in.bias))
-        h = ops.batch_norm(h.reshape(-1, C), self.bn_in).view(B, -1, C)
+        fuse = ops.fused_relu_bn_ok(x, self.bn_in)   # ReLU fwd in the GEMM epilogue, bwd in the BN backward
+        h = ops.linear(x, self.fc_in.weight, self.fc_in.bias, relu=2 if fuse else 1)
+        h = ops.batch_norm(h.reshape(-1, C), self.bn_in, relu_input=fuse).view(B, -1, C)
         for i, (conv, bn) in enumerate(zip(self.hidden_conv, self.hidden_bn)):
-            h = ops.relu(ops.tdnn(h, conv.weight, conv.bias, conv.dilation[0], conv.stride[0]))
-            h = ops.batch_norm(h.reshape(-1, C), bn).view(B, -1, C)
+            fuse = ops.fused_relu_bn_ok(h, bn)
+            h = ops.tdnn(h, conv.weight, conv.bias, conv.dilation[0], conv.stride[0], relu=2 if fuse else 1)
+            h = ops.batch_norm(h.reshape(-1, C), bn, relu_input=fuse).view(B, -1, C)
             if (i + 1) % 3 == 0:
                 h = self.transformer[i // 3](h, mask=None)
         h = ops.batch_norm(h.reshape(-1, C), self.bn_final)

@@ -105,7 +105,7 @@ class LinearFn(torch.autograd.Function):
             G.gemm_nt(x2, weight, bias=bias, relu=relu, out=out.view(-1, N))
         ctx.relu = relu
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x2, weight, out if relu else None)
+        ctx.save_for_backward(x2, weight, out if relu == 1 else None)
         return out
 
     @staticmethod
@@ -113,7 +113,7 @@ class LinearFn(torch.autograd.Function):
         x2, weight, y = ctx.saved_tensors
         N, K = weight.shape
         dy2 = dy.reshape(-1, N)
-        if ctx.relu:
+        if ctx.relu == 1:   # relu == 2: the mask was already applied by the consumer's backward
             dy2 = dy2 * (y.view(-1, N) > 0)
         dy2 = dy2.contiguous()
         M = dy2.shape[0]
@@ -145,7 +145,7 @@ class TimeDelayFn(torch.autograd.Function):
             G.launch(a_op, G.matrix(w2d)[0], y, N, M, N, K, bias=bias, relu=relu)
         ctx.cfg = (taps, dil, stride, pad, relu, t_out)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w2d, y if relu else None)
+        ctx.save_for_backward(x, w2d, y if relu == 1 else None)
         return y
 
     @staticmethod
@@ -155,7 +155,7 @@ class TimeDelayFn(torch.autograd.Function):
         Bn, T, C = x.shape
         N, K = w2d.shape
         dy2 = dy.reshape(-1, N)
-        if relu:
+        if relu == 1:
             dy2 = dy2 * (y.view(-1, N) > 0)
         dy2 = dy2.contiguous()
         M = dy2.shape[0]
@@ -248,8 +248,9 @@ class BatchNormFn(torch.autograd.Function):
     statistics updated in place exactly as nn.BatchNorm1d does (momentum, unbiased variance)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu_input=False):
         x = x.contiguous()
+        ctx.relu_input = bool(relu_input)
         M, C = x.shape
         lib = _lib.lib()
         with torch.cuda.device(x.device):
@@ -278,6 +279,7 @@ class BatchNormFn(torch.autograd.Function):
             db = torch.empty_like(dg)
             _lib.check(_lib.lib().pika_bn_backward(dy.data_ptr(), x.data_ptr(), M, C, weight.data_ptr(),
                                                    mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
-                                                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(), _stream()),
+                                                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                   int(ctx.relu_input), _stream()),
                        "pika_bn_backward")
-        return dx, dg, db, None, None, None, None
+        return dx, dg, db, None, None, None, None, None

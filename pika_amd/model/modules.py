@@ -18,7 +18,7 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout_2 = nn.Dropout(dropout)
 
     def forward(self, x):
-        h = ops.relu(ops.linear(ops.layer_norm(x, self.layer_norm), self.w_1.weight, self.w_1.bias))
+        h = ops.linear(ops.layer_norm(x, self.layer_norm), self.w_1.weight, self.w_1.bias, relu=1)
         h = ops.dropout(h, self.dropout_1.p, self.training)
         y = ops.linear(h, self.w_2.weight, self.w_2.bias)
         return ops.dropout(y, self.dropout_2.p, self.training) + x

@@ -14,6 +14,11 @@ def _hip(x):
     return x.is_cuda
 
 
+def _bf16_mode():
+    from .. import gemm as G
+    return G.PRECISION == "bf16"
+
+
 def _gemm_ok(*dims):
     return all(d % 4 == 0 for d in dims)
 
@@ -31,14 +36,22 @@ def relu(x):
     return F.relu(x)
 
 
-def batch_norm(x2d, bn):
-    """BatchNorm1d over rows of a (M,C) matrix with the module's buffers (train: batch stats)."""
+def fused_relu_bn_ok(x, bn):
+    """True when `bn(relu(gemm(x)))` can run as GEMM(+ReLU epilogue) -> BatchNorm kernels whose
+    backward also applies the ReLU mask (no separate ReLU passes)."""
+    return _hip(x) and (bn.training or not bn.track_running_stats) and bn.affine and \
+        torch.is_grad_enabled()
+
+
+def batch_norm(x2d, bn, relu_input=False):
+    """BatchNorm1d over rows of a (M,C) matrix with the module's buffers (train: batch stats).
+    relu_input: x2d is a ReLU output whose backward mask this op's backward must apply."""
     train_stats = bn.training or not bn.track_running_stats
     if _hip(x2d) and train_stats and bn.affine and x2d.shape[1] % 4 == 0 and x2d.dtype == torch.float32:
         from .hipops import BatchNormFn
         mom = _bn_momentum(bn)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        return BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom)
+        return BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom, relu_input)
     return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                         bn.training or not bn.track_running_stats,
                         _bn_momentum(bn), bn.eps)
@@ -60,7 +73,7 @@ def dropout(x, p, training):
     return F.dropout(x, p, training) if (training and p > 0.0) else x
 
 
-def tdnn(x, weight, bias, dilation, stride):
+def tdnn(x, weight, bias, dilation, stride, relu=0):
     """Time-delay layer: y[b,t,n] = sum_j sum_c W[n,0,j,c] * x[b, t*stride + j*dilation, c] + bias[n].
 
     x (B,T,C); weight is the reference's Conv2d weight (N,1,taps,C)
@@ -70,12 +83,13 @@ def tdnn(x, weight, bias, dilation, stride):
     B, T, _ = x.shape
     if _hip(x) and _gemm_ok(C):
         from .hipops import TimeDelayFn
-        return TimeDelayFn.apply(x, weight.reshape(N, taps * C), bias, taps, dilation, stride, 0, False)
+        return TimeDelayFn.apply(x, weight.reshape(N, taps * C), bias, taps, dilation, stride, 0, relu)
     span = T - dilation * (taps - 1)
     t_out = (span - 1) // stride + 1
     cols = [x[:, j * dilation: j * dilation + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
     a = torch.cat(cols, dim=-1)  # (B, t_out, taps*C)
-    return F.linear(a, weight.reshape(N, taps * C), bias)
+    y = F.linear(a, weight.reshape(N, taps * C), bias)
+    return F.relu(y) if relu else y
 
 
 def causal_conv1d(x, weight, bias):
