@@ -56,6 +56,12 @@ int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
                  long long c_z_outer, long long c_z_inner, int M, int N, int K, int batch,
                  int z_div, const float *bias, int flags, void *stream);
 
+/* C[M,N] f32 = A[M,K] bf16 * B[N,K]^T bf16 + bias[n] with direct global->LDS operand loads
+ * (gemm_glds.hip).  Requirements: K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned
+ * bases.  Rows beyond M / N are never stored. */
+int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, long long ldb, float *C,
+                      long long ldc, int M, int N, int K, const float *bias, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

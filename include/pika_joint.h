@@ -36,6 +36,12 @@ int pika_log_softmax_rows(float *x, long long rows, int cols, long long ld, floa
 int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int cols, long long ld,
                               float scale, void *stream);
 
+/* Same, written as bf16 into `out` (rows, ld_out) instead of in place; columns [cols, ld_out) are
+ * zero-filled so `out` can feed pika_gemm_bf16_nt with K = ld_out (a multiple of 64). */
+int pika_log_softmax_bwd_rows_bf16(const float *lp, const float *g, void *out, long long rows,
+                                   int cols, long long ld, long long ld_out, float scale,
+                                   void *stream);
+
 /* MBR risk gradient (reference: trainer/train_transducer_mbr_bmuf_otfaug.py:225-235, where a
  * dense (rows, V) tensor holding ONE non-zero per row is pushed through log_softmax backward).
  * In place on lp (rows, V) = log_softmax(scale * logits):

@@ -21,6 +21,8 @@ int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, lon
 
 /* out[c] = sum_r x[r][c]  (bias gradients).  x (rows, cols) f32 with pitch ld. */
 int pika_colsum(const float *x, long long ld, int rows, int cols, float *out, void *stream);
+/* the same over a bf16 matrix (fp32 accumulation) */
+int pika_colsum_bf16(const void *x, long long ld, int rows, int cols, float *out, void *stream);
 
 /* Adjoint of the virtual time-delay operand: dx[b,ti,c] = sum over (t,tap) with
  * t*stride + tap*dil - pad == ti of dcol[(b,t)][tap*C + c].  dx (B,t_in,C) contiguous f32 is

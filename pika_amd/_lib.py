@@ -29,15 +29,18 @@ SIGNATURES = {
     "pika_specaug_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     # include/pika_gemm.h
     "pika_gemm_nt": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "pika_gemm_bf16_nt": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp]),
     # include/pika_ops.h
     "pika_transpose_cast": (_i, [_vp, _i, _i, _vp, _ll, _i, _vp]),
     "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
+    "pika_colsum_bf16": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     # include/pika_joint.h
     "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pika_joint_gate_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),
     "pika_log_softmax_rows": (_i, [_vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_log_softmax_bwd_rows": (_i, [_vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
+    "pika_log_softmax_bwd_rows_bf16": (_i, [_vp, _vp, _vp, _ll, _i, _ll, _ll, ctypes.c_float, _vp]),
     "pika_mbr_risk_grad_rows": (_i, [_vp, _vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     # include/pika_norm.h
     "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp]),

@@ -266,6 +266,43 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_wave_kernel(const float *
         }
 }
 
+__global__ __launch_bounds__(256) void log_softmax_bwd_bf16_kernel(const float *__restrict__ lp,
+                                                                   const float *__restrict__ g,
+                                                                   __bf16 *__restrict__ out, long long rows,
+                                                                   int cols, long long ld, long long ld_out,
+                                                                   float scale) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = cols >> 2, o4 = (int)(ld_out >> 2);
+    const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * ld);
+    const f32x4 *grow = reinterpret_cast<const f32x4 *>(g + r * ld);
+    bf16x4 *orow = reinterpret_cast<bf16x4 *>(out + r * ld_out);
+    f32x4 v[WQ];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q)
+        if (lane + q * 64 < c4) {
+            v[q] = grow[lane + q * 64];
+            s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        }
+    s = wave_red(s, false);
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) {
+            const f32x4 l = lrow[i];
+            f32x4 o;
+            o.x = scale * (v[q].x - __expf(l.x) * s);
+            o.y = scale * (v[q].y - __expf(l.y) * s);
+            o.z = scale * (v[q].z - __expf(l.z) * s);
+            o.w = scale * (v[q].w - __expf(l.w) * s);
+            orow[i] = __builtin_convertvector(o, bf16x4);
+        } else if (i < o4) {
+            orow[i] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        }
+    }
+}
+
 inline bool wave_row_ok(const void *a, const void *b, int cols, long long ld) {
     return (cols & 3) == 0 && (ld & 3) == 0 && cols <= 64 * 4 * WQ &&
            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
@@ -352,6 +389,20 @@ int pika_mbr_risk_grad_rows(float *lp, const int *sym, const float *val, long lo
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
     hipLaunchKernelGGL(mbr_risk_grad_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
                        static_cast<hipStream_t>(stream), lp, sym, val, cols, ld, scale);
+    return (int)hipGetLastError();
+}
+
+int pika_log_softmax_bwd_rows_bf16(const float *lp, const float *g, void *out, long long rows,
+                                   int cols, long long ld, long long ld_out, float scale,
+                                   void *stream) {
+    if (!lp || !g || !out || rows <= 0 || cols <= 0 || ld < cols || ld_out < cols) return PIKA_EINVAL;
+    if (!wave_row_ok(lp, g, cols, ld) || (ld_out & 3) || ld_out > 64 * 4 * WQ ||
+        (reinterpret_cast<uintptr_t>(out) & 7))
+        return PIKA_EINVAL;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(log_softmax_bwd_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), lp, g, static_cast<__bf16 *>(out), rows, cols,
+                       ld, ld_out, scale);
     return (int)hipGetLastError();
 }
 

@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(Op X, int rows, int
 }
 
 // grid (ceil(cols/64), chunks): each block sums a slab of rows for 64 columns, 4 row-groups,
-// then one atomicAdd per column per block (out pre-zeroed by the host wrapper).
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, long long ld,
+// then one atomicAdd per column per block (out pre-zeroed by the host wrapper).  Fallback for
+// unaligned matrices.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ x, long long ld,
                                                      int rows, int cols, int rows_per_block,
                                                      float *__restrict__ out) {
     __shared__ float part[4][64];
@@ -54,11 +56,74 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
     const int rbeg = blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
     float s = 0.f;
     if (c < cols)
-        for (int r = rbeg + g; r < rend; r += 4) s += x[(long long)r * ld + c];
+        for (int r = rbeg + g; r < rend; r += 4) s += (float)x[(long long)r * ld + c];
     part[g][threadIdx.x & 63] = s;
     __syncthreads();
     if (g == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] +
                                                    part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// Vector variant: every lane owns one 16-byte granule (VEC = 4 f32 / 8 bf16 columns), a wave covers
+// 64*VEC contiguous columns of a row, the 4 waves of a block take rows r, r+1, r+2, r+3 and four
+// row-steps are kept in flight.  Requires ld % VEC == 0, cols % VEC == 0 and a 16-byte aligned base.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ x, long long ld,
+                                                         int rows, int cols, int rows_per_block,
+                                                         float *__restrict__ out) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ float part[4][64 * VEC];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * VEC;
+    const int rbeg = blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (c < cols) {
+        const T *col = x + c;
+        int r = rbeg + g;
+        for (; r + 12 < rend; r += 16) {
+            vec_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[q] = *reinterpret_cast<const vec_t *>(col + (long long)(r + 4 * q) * ld);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += (float)v[q][i];
+        }
+        for (; r < rend; r += 4) {
+            const vec_t v = *reinterpret_cast<const vec_t *>(col + (long long)r * ld);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += (float)v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) part[g][i * 64 + lane] = acc[i];
+    __syncthreads();
+    if (g == 0 && c < cols) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            atomicAdd(out + c + i, part[0][i * 64 + lane] + part[1][i * 64 + lane] +
+                                       part[2][i * 64 + lane] + part[3][i * 64 + lane]);
+    }
+}
+
+template <typename T>
+int colsum_impl(const T *x, long long ld, int rows, int cols, float *out, void *stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int chunks = max(1, min(256, rows / 256));
+    const int rpb = (rows + chunks - 1) / chunks;
+    if (ld % VEC == 0 && cols % VEC == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL((colsum_vec_kernel<T, VEC>), dim3((cols + 64 * VEC - 1) / (64 * VEC), chunks),
+                           dim3(256), 0, s, x, ld, rows, cols, rpb, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, x, ld,
+                           rows, cols, rpb, out);
+    return (int)hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ dcol,
@@ -106,15 +171,11 @@ int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, lon
 }
 
 int pika_colsum(const float *x, long long ld, int rows, int cols, float *out, void *stream) {
-    if (!x || !out || rows <= 0 || cols <= 0) return PIKA_EINVAL;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    const int chunks = max(1, min(256, rows / 256));
-    const int rpb = (rows + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, x, ld, rows,
-                       cols, rpb, out);
-    return (int)hipGetLastError();
+    return colsum_impl<float>(x, ld, rows, cols, out, stream);
+}
+
+int pika_colsum_bf16(const void *x, long long ld, int rows, int cols, float *out, void *stream) {
+    return colsum_impl<__bf16>(static_cast<const __bf16 *>(x), ld, rows, cols, out, stream);
 }
 
 int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C, int taps,

@@ -89,3 +89,25 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, accumulate=False, precision=N
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     assert out.stride(1) == 1
     return launch(a_op, b_op, out, out.stride(0), M, N, K, bias, relu, accumulate, precision)
+
+
+def gemm_bf16_nt(a, b, bias=None, out=None):
+    """out[M,N] f32 = a[M,K] bf16 @ b[N,K]^T bf16 + bias through the direct-to-LDS kernel
+    (include/pika_gemm.h: pika_gemm_bf16_nt).  K must be a multiple of 64."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    if not a.is_cuda:
+        raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.stride(1) == 1 and out.dtype == torch.float32
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().pika_gemm_bf16_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                          out.data_ptr(), out.stride(0), M, N, K,
+                                          None if bias is None else bias.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pika_gemm_bf16_nt(M=%d,N=%d,K=%d)" % (M, N, K))
+    return out

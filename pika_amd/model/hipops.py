@@ -62,7 +62,7 @@ def _grad_weight(dy2, a_op, a_g, M, Ka, N):
     """dW[N,Ka] = dY^T[N,M] @ A[M,Ka].  Both operands are read as they lie in memory (reduction =
     the row index): `trans` operands + the LDS transpose read, no transposed copies.  Falls back
     to explicit transposes when an output extent is not a multiple of the 16-byte load width."""
-    if N % 4 == 0 and Ka % a_g == 0:
+    if N % _g(dy2) == 0 and Ka % a_g == 0:
         dy_op = G.matrix(dy2)[0]
         dy_op.trans = 1
         a_op.trans = 1
@@ -241,6 +241,67 @@ class LogSoftmaxFn(torch.autograd.Function):
                                                             cols, ctx.scale, _stream()),
                        "pika_log_softmax_bwd_rows")
         return g, None
+
+
+def joint_out_ok(h, weight):
+    """JointOutFn preconditions: bf16 hidden, reduction a multiple of 64, vocabulary a multiple of
+    8 (16-byte bf16 granules of the d(logits) copy) that one wave covers (log-softmax row kernels)."""
+    N, K = weight.shape
+    return (G.PRECISION == "bf16" and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
+            and N <= 8192)
+
+
+class JointOutFn(torch.autograd.Function):
+    """log_softmax(scale * (h @ W2^T + b2)) over the (B,T,U,V) lattice: the 8 GFLOP-per-utterance
+    tail of the joint network (reference trainer/model/transducer.py:107-111), bf16 arithmetic mode.
+
+    forward : pika_gemm_bf16_nt (h bf16, bf16 copy of W2) -> logits f32, log-softmax in place.
+    backward: the dense RNN-T gradient g and the saved log-probs are folded into ONE bf16 matrix
+              d(logits) (M, pad64(V)) -- 2 bytes/element written instead of 4 rewritten in place,
+              and every consumer reads half the bytes: dh = d(logits) @ W2 (direct-to-LDS GEMM,
+              zero-padded reduction), dW2 = d(logits)^T @ h (both read in place as `trans`
+              operands), db2 = column sums."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, scale):
+        N, K = weight.shape
+        h2 = h.reshape(-1, K)
+        out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
+        G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().pika_log_softmax_rows(out.data_ptr(), h2.shape[0], N, N, float(scale),
+                                                        _stream()), "pika_log_softmax_rows")
+        ctx.scale = float(scale)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(h2, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h2, weight, lp = ctx.saved_tensors
+        N, K = weight.shape
+        M = h2.shape[0]
+        Np = (N + 63) & ~63
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dh = dw = db = None
+        with torch.cuda.device(g.device):
+            dl = torch.empty((M, Np), dtype=torch.bfloat16, device=g.device)
+            _lib.check(_lib.lib().pika_log_softmax_bwd_rows_bf16(
+                lp.data_ptr(), g.data_ptr(), dl.data_ptr(), M, N, N, Np, ctx.scale, _stream()),
+                "pika_log_softmax_bwd_rows_bf16")
+            del g
+            if ctx.needs_input_grad[0]:
+                wt = torch.zeros((K, Np), dtype=torch.bfloat16, device=dl.device)
+                wt[:, :N] = weight.detach().t()
+                dh = G.gemm_bf16_nt(dl, wt).view(*lp.shape[:-1], K)
+            if ctx.needs_input_grad[1]:
+                dw = _grad_weight(dl[:, :N], G.matrix(h2)[0], 8, M, K, N)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(N, dtype=torch.float32, device=dl.device)
+                _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
+                           "pika_colsum_bf16")
+        return dh, dw, db, None
 
 
 class BatchNormFn(torch.autograd.Function):

@@ -140,12 +140,15 @@ def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
     w1e, w1p = fc1.weight[:, :H], fc1.weight[:, H:]
     wge, wgp = fc_gate.weight[:, :H], fc_gate.weight[:, H:]
     if _hip(enc) and _gemm_ok(H, fc2.weight.shape[1]):
-        from .hipops import GateFn, LogSoftmaxFn
+        from .hipops import GateFn, JointOutFn, LogSoftmaxFn, joint_out_ok
         e1 = linear(enc, w1e.contiguous(), fc1.bias)
         p1 = linear(pred, w1p.contiguous())
         eg = linear(enc, wge.contiguous(), fc_gate.bias)
         pg = linear(pred, wgp.contiguous())
-        out = linear(GateFn.apply(e1, p1, eg, pg), fc2.weight, fc2.bias)
+        h = GateFn.apply(e1, p1, eg, pg)
+        if log_softmax and joint_out_ok(h, fc2.weight):
+            return JointOutFn.apply(h, fc2.weight, fc2.bias, scale)
+        out = linear(h, fc2.weight, fc2.bias)
         if log_softmax:
             out = LogSoftmaxFn.apply(out, scale)
         return out

@@ -168,3 +168,29 @@ def test_time_delay_weight_gradient_in_place(hip_device):
     a = torch.cat(cols, -1).reshape(M, K)
     want = dy.double().t() @ a.double()
     assert ((out.double() - want).abs() / (dy.double().abs().t() @ a.double().abs())).max() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1, 8, 64), (257, 129, 64), (1000, 5000, 1024),
+                                   (777, 1024, 5056)])
+def test_direct_to_lds_bf16_nt(hip_device, M, N, K):
+    """pika_gemm_bf16_nt (gemm_glds.hip): operands are exactly representable bf16, so the only error
+    against the fp64 product is fp32 accumulation."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = torch.randn(N, K, generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    want = a.double() @ b.double().t() + bias.double()
+    got = G.gemm_bf16_nt(a.to(hip_device), b.to(hip_device), bias=bias.to(hip_device))
+    tol = 4e-6 * (a.double().abs() @ b.double().abs().t()).max().item() + 1e-6
+    assert (got.double().cpu() - want).abs().max() < tol
+    # padded leading dimensions + no bias, output into a strided view
+    ap = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=hip_device)
+    ap[:, :K] = a.to(hip_device)
+    Np = (N + 3) & ~3
+    out = torch.full((M, Np + 4), -7.0, device=hip_device)
+    G.gemm_bf16_nt(ap[:, :K], b.to(hip_device), out=out[:, :N])
+    assert (out[:, :N].double().cpu() - (want - bias.double())).abs().max() < tol
+    assert bool((out[:, N:] == -7.0).all())
+    with pytest.raises(RuntimeError):
+        G.gemm_bf16_nt(a.to(hip_device)[:, :K - 32], b.to(hip_device)[:, :K - 32])

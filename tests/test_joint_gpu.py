@@ -52,3 +52,36 @@ def test_log_softmax_rows_forward_backward(hip_device, rows, cols, scale):
     assert (out.double().cpu() - ref.detach()).abs().max() < 1e-5
     (out * w.float().to(hip_device)).sum().backward()
     assert (xd.grad.double().cpu() - xr.grad).abs().max() < 1e-5 * max(1.0, w.abs().sum(-1).max().item())
+
+
+@pytest.mark.parametrize("M,V,H,scale", [(37, 104, 64, 1.0), (300, 5000, 128, 0.7), (5, 8, 64, 1.0)])
+def test_joint_output_fn(hip_device, M, V, H, scale):
+    """JointOutFn (fc2 + log-softmax, bf16 mode) vs the fp64 formula of transducer.py:107-111 on
+    bf16-representable inputs.  Error sources left: fp32 accumulation/exp and the bf16 rounding of
+    d(logits) in the backward (2^-9 relative per element)."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn, joint_out_ok
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(M + V)
+        h = (torch.randn(M, H, generator=g) * 0.5).bfloat16()
+        w = (torch.randn(V, H, generator=g) * 0.2).bfloat16()
+        b = torch.randn(V, generator=g) * 0.1
+        gy = torch.randn(M, V, generator=g) * (torch.rand(M, V, generator=g) < 0.05)  # sparse like RNN-T
+        h64, w64, b64 = [t.double().requires_grad_(True) for t in (h, w, b)]
+        ref = torch.log_softmax(scale * (h64 @ w64.t() + b64), dim=-1)
+        (ref * gy.double()).sum().backward()
+        hd = h.to(hip_device).requires_grad_(True)
+        wd = w.float().to(hip_device).requires_grad_(True)
+        bd = b.to(hip_device).requires_grad_(True)
+        assert joint_out_ok(hd, wd)
+        out = JointOutFn.apply(hd, wd, bd, scale)
+        assert (out.double().cpu() - ref.detach()).abs().max() < 2e-5
+        (out * gy.to(hip_device)).sum().backward()
+        for got, want in ((hd.grad, h64.grad), (wd.grad, w64.grad), (bd.grad, b64.grad)):
+            s = want.abs().max().item()
+            assert (got.double().cpu() - want).abs().max() < 1e-2 * s, (got.shape, s)
+            # unbiased rounding: the mean error is far below the per-element bound
+            assert abs((got.double().cpu() - want).mean().item()) < 1e-3 * s
+    finally:
+        G.PRECISION = old
