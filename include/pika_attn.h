@@ -1,0 +1,45 @@
+/*
+ * include/pika_attn.h -- C ABI of the fused multi-head self-attention core (libpika_amd.so).
+ *
+ * Replaces, for the encoder's transformer layers (no mask, no layer cache, no relative positions:
+ * the only branch the RNN-T training path reaches), the chain
+ *   /root/reference/trainer/model/multi_headed_attn.py:199-231
+ *     query = query / sqrt(D); scores = query @ key^T; attn = softmax(scores);
+ *     drop_attn = dropout(attn); context = drop_attn @ value
+ * whose (B,H,T,T) score/probability tensors (2 GB per layer at config 2) are never written here.
+ *
+ * Tensors: q, k, v, out, dout, dq, dk, dv are f32 (B,T,H*D) with row pitch `ld` floats (head h owns
+ * columns [h*D, (h+1)*D)); D is 64 or 128; ld % 4 == 0 and 16-byte aligned bases.
+ * lse (B*H*T,) f32 = log2-domain log-sum-exp of the scaled scores, written by the forward and read
+ * by the backward.  Arithmetic: operands rounded to bf16 for the MFMAs, fp32 softmax/accumulation.
+ *
+ * Dropout (p_drop in [0,1), 0 = none) is a counter-based hash of (seed, b, h, query, key), so the
+ * backward regenerates the forward's mask from `seed`; kept probabilities are scaled by
+ * 1/(1-p) where p = round(p_drop*65536)/65536.  pika_attention_keep_mask materialises the mask
+ * (tests only).  Conventions as in pika_rnnt.h.
+ */
+#ifndef PIKA_ATTN_H
+#define PIKA_ATTN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
+                       int B, int T, int H, int D, long long ld, float p_drop, unsigned seed,
+                       void *stream);
+
+/* delta (B*H*T,) f32 is scratch (sum_d out*dout per query row). */
+int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
+                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                       float *dv, int B, int T, int H, int D, long long ld, float p_drop,
+                       unsigned seed, void *stream);
+
+/* mask (B*H, T, T) u8: 1 where the probability of (query row, key column) is kept. */
+int pika_attention_keep_mask(unsigned char *mask, int BH, int T, float p_drop, unsigned seed,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_ATTN_H */

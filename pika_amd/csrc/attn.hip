@@ -1,0 +1,405 @@
+// pika_amd/csrc/attn.hip -- fused multi-head self-attention (forward, dQ, dK/dV) for gfx950.
+//
+// One workgroup = 4 waves = 64 query rows (forward, dQ) or 64 key rows (dK/dV) of one (batch, head);
+// the other axis streams through LDS in 64-row bf16 tiles.  All products are
+// v_mfma_f32_16x16x32_bf16 issued in the TRANSPOSED sense, S^T = K.Q^T, so that a lane's
+// accumulator registers hold reduction-axis neighbours of ONE output column (lane & 15): the
+// probabilities / score gradients can then be re-used directly as the B operand of the next MFMA
+// (O^T = V^T.P^T, dQ^T = K^T.dS^T, dV^T = dO^T.P, dK^T = Q^T.dS) with no trip through LDS.  The
+// 32-deep reduction of that second MFMA takes its 8 k-slots per lane from two 16-row accumulator
+// tiles (rows g*4..g*4+3 of each); the matching A operand comes out of the LDS tile with two
+// ds_read_b64_tr_b16 whose row addresses follow the same permutation.
+// Softmax is online (running max / partial sums in the log2 domain, log2(e)/sqrt(D) folded into
+// the bf16 rounding of Q); per-row statistics are lane-uniform per output column, so only the row
+// maximum needs a cross-lane exchange (two xor-shuffles per 64 keys).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pika_attn.h"
+#include "pika_rnnt.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TILE = 64;     // rows per LDS tile and per workgroup
+constexpr int THREADS = 256;
+
+__device__ inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// dropout decision for probability (row = (b*H+h)*T + query, key)
+__device__ inline uint32_t row_hash(uint32_t seed, uint32_t row) { return mix32(seed + row * 0x9E3779B9u); }
+__device__ inline bool keep(uint32_t rowh, uint32_t key, uint32_t thr) {
+    return (mix32(rowh ^ (key * 0x85ebca6bu)) & 0xffffu) >= thr;
+}
+
+__device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// 64 x D fp32 rows (pitch ld) -> bf16 LDS tile with pitch D+8; rows >= nvalid are zero-filled.
+template <int D>
+__device__ inline void load_tile(__bf16 *lds, const float *g, long long ld, int nvalid, float scale) {
+    constexpr int P = D + 8, F4 = D / 4, RPP = THREADS / F4;
+    const int c = threadIdx.x % F4, r0 = threadIdx.x / F4;
+    f32x4 v[TILE / RPP];
+#pragma unroll
+    for (int p = 0; p < TILE / RPP; ++p) {
+        const int r = r0 + p * RPP;
+        v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < nvalid) v[p] = *reinterpret_cast<const f32x4 *>(g + (long long)r * ld + c * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < TILE / RPP; ++p)
+        *reinterpret_cast<bf16x4 *>(lds + (r0 + p * RPP) * P + c * 4) = __builtin_convertvector(v[p] * scale, bf16x4);
+}
+
+// one row of a (.,D) fp32 matrix as D/32 MFMA operand fragments (8 consecutive d per lane)
+template <int D>
+__device__ inline void row_frags(bf16x8 *f, const float *row, int g, float scale) {
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(row + ks * 32 + g * 8) * scale;
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(row + ks * 32 + g * 8 + 4) * scale;
+        f[ks] = bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w,
+                       (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    }
+}
+
+// operand fragment with tile rows as the MFMA row/column index: row r0 + (lane&15), k = kk + g*8..+7
+template <int P>
+__device__ inline bf16x8 frag_n(const __bf16 *tile, int r0, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(tile + (r0 + (lane & 15)) * P + kk + (lane >> 4) * 8);
+}
+// operand fragment with tile COLUMNS as the MFMA row index (c0 + (lane&15)) and tile rows as the
+// reduction: k-slots 0..3 = rows k0 + g*4 + {0..3}, slots 4..7 = rows k0 + 16 + g*4 + {0..3}.
+template <int P>
+__device__ inline bf16x8 frag_t(const __bf16 *tile, int c0, int k0, int lane) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int i = lane & 15, j = i >> 2, c = i & 3, g = lane >> 4;
+    const __bf16 *p0 = tile + (k0 + g * 4 + j) * P + c0 + 4 * c;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p0 + 16 * P));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ inline f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+struct Args {
+    const float *q, *k, *v, *out, *dout, *lse, *delta;
+    float *o, *lse_w, *dq, *dk, *dv;
+    int T, H;
+    long long ld;
+    float qscale;     // log2(e) / sqrt(D)
+    float inv_keep;   // 1 / (1 - p)
+    uint32_t seed, thr;
+};
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
+    constexpr int P = D + 8, KS = D / 32, DT = D / 16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[TILE * P];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[TILE * P];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int T = A.T, h = blockIdx.y, b = blockIdx.z;
+    const int qrow = blockIdx.x * TILE + wave * 16 + (lane & 15);
+    const long long boff = (long long)b * T * A.ld + (long long)h * D;
+    const uint32_t bh = (uint32_t)(b * A.H + h);
+    bf16x8 qf[KS];
+    row_frags<D>(qf, A.q + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
+    const uint32_t rowh = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qrow);
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lpart = 0.f;
+    for (int kb = 0; kb < T; kb += TILE) {
+        __syncthreads();
+        load_tile<D>(Ks, A.k + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vs, A.v + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[kt] = mfma(frag_n<P>(Ks, kt * 16, ks * 32, lane), qf[ks], s[kt]);
+        }
+        if (kb + TILE > T) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb + kt * 16 + g * 4 + r >= T) s[kt][r] = -INFINITY;
+        }
+        float mb = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) mb = fmaxf(mb, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        mb = fmaxf(mb, __shfl_xor(mb, 16));
+        mb = fmaxf(mb, __shfl_xor(mb, 32));
+        const float mn = fmaxf(m, mb), alpha = ex2(m - mn);
+        m = mn;
+        lpart *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = ex2(s[kt][r] - mn);
+                lpart += p;
+                if (A.thr && !keep(rowh, (uint32_t)(kb + kt * 16 + g * 4 + r), A.thr)) p = 0.f;
+                pf[kt >> 1][(kt & 1) * 4 + r] = (__bf16)p;
+            }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) oacc[dt] = mfma(frag_t<P>(Vs, dt * 16, s2 * 32, lane), pf[s2], oacc[dt]);
+    }
+    float l = lpart;
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qrow < T) {
+        const float sc = A.inv_keep / l;
+        float *o = A.o + boff + (long long)qrow * A.ld + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(o + dt * 16) = oacc[dt] * sc;
+        if (g == 0) A.lse_w[(long long)bh * T + qrow] = m + __log2f(l);
+    }
+}
+
+// delta[bh*T + q] = sum_d out[b,q,h,d] * dout[b,q,h,d]; one workgroup per (b,q) row.
+template <int D>
+__global__ __launch_bounds__(THREADS) void attn_delta_kernel(Args A, float *delta) {
+    const int T = A.T, HD = A.H * D;
+    const long long row = blockIdx.x;  // b*T + q
+    const int b = (int)(row / T), qi = (int)(row - (long long)b * T);
+    for (int c = threadIdx.x * 4; c < HD; c += THREADS * 4) {
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(A.out + row * A.ld + c);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dout + row * A.ld + c);
+        float s = o.x * d.x + o.y * d.y + o.z * d.z + o.w * d.w;
+#pragma unroll
+        for (int w = 1; w < D / 4; w <<= 1) s += __shfl_xor(s, w);
+        if ((threadIdx.x & (D / 4 - 1)) == 0) delta[((long long)b * A.H + c / D) * T + qi] = s;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
+    constexpr int P = D + 8, KS = D / 32, DT = D / 16;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[TILE * P];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[TILE * P];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int T = A.T, h = blockIdx.y, b = blockIdx.z;
+    const int qrow = blockIdx.x * TILE + wave * 16 + (lane & 15);
+    const long long boff = (long long)b * T * A.ld + (long long)h * D;
+    const uint32_t bh = (uint32_t)(b * A.H + h);
+    bf16x8 qf[KS], dof[KS];
+    row_frags<D>(qf, A.q + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
+    row_frags<D>(dof, A.dout + boff + (long long)min(qrow, T - 1) * A.ld, g, 1.f);
+    const float lse = qrow < T ? A.lse[(long long)bh * T + qrow] : INFINITY;
+    const float delta = qrow < T ? A.delta[(long long)bh * T + qrow] : 0.f;
+    const uint32_t rowh = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qrow);
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < T; kb += TILE) {
+        __syncthreads();
+        load_tile<D>(Ks, A.k + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vs, A.v + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 dsf;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int kt = 2 * s2 + half;
+                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    sa = mfma(frag_n<P>(Ks, kt * 16, ks * 32, lane), qf[ks], sa);
+                    dp = mfma(frag_n<P>(Vs, kt * 16, ks * 32, lane), dof[ks], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + kt * 16 + g * 4 + r;
+                    const float p = key < T ? ex2(sa[r] - lse) : 0.f;
+                    float d = dp[r] * A.inv_keep;
+                    if (A.thr && !keep(rowh, (uint32_t)key, A.thr)) d = 0.f;
+                    dsf[half * 4 + r] = (__bf16)(p * (d - delta));
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma(frag_t<P>(Ks, dt * 16, s2 * 32, lane), dsf, acc[dt]);
+        }
+    }
+    if (qrow < T) {
+        const float sc = rsqrtf((float)D);
+        float *o = A.dq + boff + (long long)qrow * A.ld + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(o + dt * 16) = acc[dt] * sc;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
+    constexpr int P = D + 8, KS = D / 32, DT = D / 16;
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[TILE * P];
+    __shared__ __attribute__((aligned(16))) __bf16 Os[TILE * P];
+    __shared__ float lse_s[TILE], delta_s[TILE];
+    __shared__ uint32_t rowh_s[TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int T = A.T, h = blockIdx.y, b = blockIdx.z;
+    const int krow = blockIdx.x * TILE + wave * 16 + (lane & 15);
+    const long long boff = (long long)b * T * A.ld + (long long)h * D;
+    const uint32_t bh = (uint32_t)(b * A.H + h);
+    bf16x8 kf[KS], vf[KS];
+    row_frags<D>(kf, A.k + boff + (long long)min(krow, T - 1) * A.ld, g, 1.f);
+    row_frags<D>(vf, A.v + boff + (long long)min(krow, T - 1) * A.ld, g, 1.f);
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < T; qb += TILE) {
+        __syncthreads();
+        load_tile<D>(Qs, A.q + boff + (long long)qb * A.ld, A.ld, T - qb, A.qscale);
+        load_tile<D>(Os, A.dout + boff + (long long)qb * A.ld, A.ld, T - qb, 1.f);
+        if (threadIdx.x < TILE) {
+            const int qi = qb + threadIdx.x;
+            lse_s[threadIdx.x] = qi < T ? A.lse[(long long)bh * T + qi] : INFINITY;
+            delta_s[threadIdx.x] = qi < T ? A.delta[(long long)bh * T + qi] : 0.f;
+            rowh_s[threadIdx.x] = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qi);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pdf, dsf;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int qt = 2 * s2 + half;
+                f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    sa = mfma(frag_n<P>(Qs, qt * 16, ks * 32, lane), kf[ks], sa);
+                    dp = mfma(frag_n<P>(Os, qt * 16, ks * 32, lane), vf[ks], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = qt * 16 + g * 4 + r;
+                    const float p = ex2(sa[r] - lse_s[qi]);
+                    float pd = p * A.inv_keep, d = dp[r] * A.inv_keep;
+                    if (A.thr && !keep(rowh_s[qi], (uint32_t)krow, A.thr)) pd = d = 0.f;
+                    pdf[half * 4 + r] = (__bf16)pd;
+                    dsf[half * 4 + r] = (__bf16)(p * (d - delta_s[qi]));
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = mfma(frag_t<P>(Os, dt * 16, s2 * 32, lane), pdf, dv[dt]);
+                dk[dt] = mfma(frag_t<P>(Qs, dt * 16, s2 * 32, lane), dsf, dk[dt]);
+            }
+        }
+    }
+    if (krow < T) {
+        const float ln2 = 0.6931471805599453f;  // Qs carries log2(e)/sqrt(D)
+        float *ok = A.dk + boff + (long long)krow * A.ld + g * 4;
+        float *ov = A.dv + boff + (long long)krow * A.ld + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            *reinterpret_cast<f32x4 *>(ok + dt * 16) = dk[dt] * ln2;
+            *reinterpret_cast<f32x4 *>(ov + dt * 16) = dv[dt];
+        }
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void keep_mask_kernel(unsigned char *mask, long long rows, int T,
+                                                            uint32_t seed, uint32_t thr) {
+    const long long row = blockIdx.x;  // bh*T + q
+    const uint32_t rowh = row_hash(seed, (uint32_t)row);
+    for (int key = threadIdx.x; key < T; key += THREADS)
+        mask[row * T + key] = (!thr || keep(rowh, (uint32_t)key, thr)) ? 1 : 0;
+}
+
+inline bool args_ok(const void *a, const void *b, const void *c, const void *d, int B, int T, int H, int D,
+                    long long ld, float p) {
+    if (!a || !b || !c || !d || B <= 0 || T <= 0 || H <= 0) return false;
+    if ((D != 64 && D != 128) || ld < (long long)H * D || (ld & 3)) return false;
+    if (!(p >= 0.f && p < 1.f)) return false;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+         reinterpret_cast<uintptr_t>(d)) & 15)
+        return false;
+    return true;
+}
+
+inline void dropout_consts(Args &A, float p, unsigned seed) {
+    A.thr = (uint32_t)lrintf(p * 65536.f);
+    A.inv_keep = 65536.f / (float)(65536u - A.thr);
+    A.seed = seed;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
+                       int B, int T, int H, int D, long long ld, float p_drop, unsigned seed,
+                       void *stream) {
+    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !lse) return PIKA_EINVAL;
+    if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
+    Args A{};
+    A.q = q; A.k = k; A.v = v; A.o = out; A.lse_w = lse; A.T = T; A.H = H; A.ld = ld;
+    A.qscale = 1.4426950408889634f / sqrtf((float)D);
+    dropout_consts(A, p_drop, seed);
+    const dim3 grid((T + TILE - 1) / TILE, H, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(THREADS), 0, s, A);
+    else hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(THREADS), 0, s, A);
+    return (int)hipGetLastError();
+}
+
+int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
+                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                       float *dv, int B, int T, int H, int D, long long ld, float p_drop,
+                       unsigned seed, void *stream) {
+    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !args_ok(dout, dq, dk, dv, B, T, H, D, ld, p_drop) ||
+        !lse || !delta)
+        return PIKA_EINVAL;
+    if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
+    Args A{};
+    A.q = q; A.k = k; A.v = v; A.out = out; A.dout = dout; A.lse = lse; A.delta = delta;
+    A.dq = dq; A.dk = dk; A.dv = dv; A.T = T; A.H = H; A.ld = ld;
+    A.qscale = 1.4426950408889634f / sqrtf((float)D);
+    dropout_consts(A, p_drop, seed);
+    const dim3 grid((T + TILE - 1) / TILE, H, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (D == 64) {
+        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)(B * T)), dim3(THREADS), 0, s, A, delta);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, grid, dim3(THREADS), 0, s, A);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<64>, grid, dim3(THREADS), 0, s, A);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)(B * T)), dim3(THREADS), 0, s, A, delta);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<128>, grid, dim3(THREADS), 0, s, A);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<128>, grid, dim3(THREADS), 0, s, A);
+    }
+    return (int)hipGetLastError();
+}
+
+int pika_attention_keep_mask(unsigned char *mask, int BH, int T, float p_drop, unsigned seed,
+                             void *stream) {
+    if (!mask || BH <= 0 || T <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) return PIKA_EINVAL;
+    if ((long long)BH * T > 0x7fffffffLL) return PIKA_ETOOBIG;
+    Args A{};
+    dropout_consts(A, p_drop, seed);
+    hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)(BH * T)), dim3(THREADS), 0,
+                       static_cast<hipStream_t>(stream), mask, (long long)BH * T, T, A.seed, A.thr);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

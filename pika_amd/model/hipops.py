@@ -304,6 +304,58 @@ class JointOutFn(torch.autograd.Function):
         return dh, dw, db, None
 
 
+def attention_ok(q, k, v, heads, mask):
+    """AttentionFn preconditions: the encoder's self-attention (no mask, Tq == Tk), head width 64
+    or 128, bf16 arithmetic mode."""
+    D = q.shape[-1] // heads
+    return (G.PRECISION == "bf16" and mask is None and q.is_cuda and q.dtype == torch.float32
+            and q.shape == k.shape == v.shape and D in (64, 128) and D * heads == q.shape[-1])
+
+
+def attention_keep_mask(BH, T, p_drop, seed, device):
+    """(BH,T,T) bool keep-mask the fused kernels use for (p_drop, seed) -- for tests."""
+    m = torch.empty((BH, T, T), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().pika_attention_keep_mask(m.data_ptr(), BH, T, float(p_drop), int(seed), _stream()),
+                   "pika_attention_keep_mask")
+    return m.bool()
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(D)) [dropout] v per head on (B,T,H*D) projections
+    (multi_headed_attn.py:199-231) without materialising the (B,H,T,T) tensors: include/pika_attn.h."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, p_drop, seed):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, T, HD = q.shape
+        D = HD // heads
+        out = torch.empty_like(q)
+        lse = torch.empty(B * heads * T, dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                                     lse.data_ptr(), B, T, heads, D, HD, float(p_drop),
+                                                     int(seed), _stream()), "pika_attention_fwd")
+        ctx.cfg = (heads, float(p_drop), int(seed))
+        ctx.save_for_backward(q, k, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        heads, p_drop, seed = ctx.cfg
+        B, T, HD = q.shape
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        delta = torch.empty_like(lse)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib().pika_attention_bwd(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, HD // heads, HD,
+                p_drop, seed, _stream()), "pika_attention_bwd")
+        return dq, dk, dv, None, None, None
+
+
 class BatchNormFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over the rows of a (M,C) matrix (include/pika_norm.h); running
     statistics updated in place exactly as nn.BatchNorm1d does (momentum, unbiased variance)."""

@@ -117,6 +117,12 @@ def attention(q, k, v, heads, mask, p_drop, training):
     B, Tq, HD = q.shape
     Tk = k.shape[1]
     D = HD // heads
+    if _hip(q):
+        from .hipops import AttentionFn, attention_ok
+        if attention_ok(q, k, v, heads, mask):
+            drop = p_drop if training else 0.0
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop > 0 else 0  # CPU generator
+            return AttentionFn.apply(q, k, v, heads, drop, seed)
     qh = (q / math.sqrt(D)).view(B, Tq, heads, D).transpose(1, 2)
     kh = k.view(B, Tk, heads, D).transpose(1, 2)
     vh = v.view(B, Tk, heads, D).transpose(1, 2)

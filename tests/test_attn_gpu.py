@@ -1,0 +1,96 @@
+"""Fused self-attention (include/pika_attn.h) vs the fp64 formula of
+trainer/model/multi_headed_attn.py:199-231 (query / sqrt(D), softmax, dropout on the probabilities,
+context = drop_attn @ value)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def reference(q, k, v, heads, keep=None, inv_keep=1.0):
+    B, T, HD = q.shape
+    D = HD // heads
+    qh = (q / math.sqrt(D)).view(B, T, heads, D).transpose(1, 2)
+    kh = k.view(B, T, heads, D).transpose(1, 2)
+    vh = v.view(B, T, heads, D).transpose(1, 2)
+    attn = torch.softmax(qh @ kh.transpose(2, 3), dim=-1)
+    if keep is not None:
+        attn = attn * keep.view(B, heads, T, T).to(attn.dtype) * inv_keep
+    return (attn @ vh).transpose(1, 2).reshape(B, T, HD)
+
+
+def bf16r(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("B,T,H,D", [(1, 1, 1, 64), (2, 64, 2, 64), (2, 100, 3, 64), (1, 77, 2, 128),
+                                     (2, 333, 4, 128), (3, 250, 16, 64)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_attention_forward_backward(hip_device, B, T, H, D, p_drop):
+    from pika_amd.model.hipops import AttentionFn, attention_keep_mask
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    q, k, v, w = [torch.randn(B, T, H * D, generator=g) for _ in range(4)]
+    q = q * 2.0   # sharper softmax
+    seed = 1234 + T
+    dev = [t.to(hip_device).requires_grad_(True) for t in (q, k, v)]
+    out = AttentionFn.apply(*dev, H, p_drop, seed)
+    (out * w.to(hip_device)).sum().backward()
+    keep, inv_keep = None, 1.0
+    if p_drop > 0:
+        keep = attention_keep_mask(B * H, T, p_drop, seed, hip_device).cpu()
+        thr = round(p_drop * 65536)
+        inv_keep = 65536.0 / (65536 - thr)
+        if B * H * T * T > 20000:
+            assert abs(keep.float().mean().item() - (1 - p_drop)) < 4 * math.sqrt(0.16 / keep.numel()) + 1e-4
+        # rows and columns are decorrelated
+        if T >= 64:
+            assert abs(keep.float().mean(dim=-1).std().item() - math.sqrt(0.16 / T)) < 0.3 * math.sqrt(0.16 / T)
+    # the kernel rounds q/sqrt(D)*log2e, k, v (and P, dS, dO) to bf16: compare with the fp64 formula on
+    # the same inputs, tolerance = bf16 operand rounding through a softmax-weighted average
+    ref_in = [t.double().requires_grad_(True) for t in (q, k, v)]
+    ref = reference(*ref_in, H, keep, inv_keep)
+    (ref * w.double()).sum().backward()
+    err = (out.double().cpu() - ref.detach()).abs().max().item()
+    assert err < 3e-2 * ref.detach().abs().max().item() + 1e-3, err
+    for a, b in zip(dev, ref_in):
+        s = b.grad.abs().max().item()
+        e = (a.grad.double().cpu() - b.grad).abs().max().item()
+        assert e < 4e-2 * s + 1e-3, (e, s)
+        # rounding is unbiased: relative L2 error well below the max-norm bound
+        rel = (a.grad.double().cpu() - b.grad).norm() / b.grad.norm().clamp_min(1e-12)
+        assert rel < 1.5e-2, rel
+
+
+def test_attention_module_path(hip_device):
+    """ops.attention routes the encoder's case to the fused kernels (bf16 mode), the parity mode and
+    masked calls to the reference chain; eval mode has no dropout."""
+    from pika_amd import gemm as G
+    from pika_amd.model import ops
+    g = torch.Generator().manual_seed(5)
+    q, k, v = [torch.randn(2, 90, 256, generator=g).to(hip_device) for _ in range(3)]
+    old = G.PRECISION
+    try:
+        G.PRECISION = "fp32"
+        want = ops.attention(q, k, v, 4, None, 0.2, False)
+        G.PRECISION = "bf16"
+        got = ops.attention(q, k, v, 4, None, 0.2, False)
+        assert (got - want).abs().max() < 3e-2
+        torch.manual_seed(3)
+        a = ops.attention(q, k, v, 4, None, 0.2, True)
+        torch.manual_seed(3)
+        b = ops.attention(q, k, v, 4, None, 0.2, True)
+        assert torch.equal(a, b) and not torch.equal(a, got)
+    finally:
+        G.PRECISION = old
+
+
+def test_attention_argument_errors(hip_device):
+    from pika_amd.model.hipops import AttentionFn
+    x = torch.randn(1, 8, 96, device=hip_device)
+    with pytest.raises(RuntimeError):
+        AttentionFn.apply(x, x, x, 2, 0.0, 0)      # D = 48
+    y = torch.randn(1, 8, 128, device=hip_device)
+    with pytest.raises(RuntimeError):
+        AttentionFn.apply(y, y, y, 2, 1.0, 0)      # p_drop out of range
