@@ -398,9 +398,12 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     const int nk = (K + CF::BK - 1) / CF::BK;
     int splitk = 1;
     if (batch == 1 && tiles < 256 && nk >= 32 && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
-        static const int target = [] { const char *e = getenv("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 384; }();
-        splitk = (target + tiles - 1) / tiles;
-        if (splitk > nk / 8) splitk = nk / 8;
+        // one resident workgroup per CU: the largest split that still fits ONE round of 256 workgroups
+        // (a partial second round costs a full tile time, and every extra split adds an atomic pass
+        // over C; measured in tools/dw_bench.py / profiles/r1_dw_split_sweep.txt)
+        static const int target = [] { const char *e = getenv("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+        splitk = target / tiles;
+        if (splitk > nk / 24) splitk = nk / 24;
         if (splitk > 64) splitk = 64;
         if (splitk < 1) splitk = 1;
     }

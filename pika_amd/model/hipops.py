@@ -48,6 +48,17 @@ def colsum(x2d):
     return out
 
 
+def _bf16_operand(t, min_elems=1 << 21):
+    """bf16 copy of a large fp32 activation matrix in the bf16 arithmetic mode.  The MFMA kernel rounds
+    fp32 operands to bf16 on their way into LDS anyway, so results are bit-identical; rounding ONCE
+    here halves the bytes every GEMM that consumes the matrix pulls through L2 (the forward product
+    and the weight-gradient product read the same copy, the three taps of a time-delay operand
+    re-read it)."""
+    if G.PRECISION == "bf16" and t.dtype == torch.float32 and t.numel() >= min_elems and t.shape[-1] % 8 == 0:
+        return t.to(torch.bfloat16)
+    return t
+
+
 def _weight_t(w2d):
     """W^T (K,N) for dX = dY @ W.  Weights are small next to activations; one pass per call."""
     op, rows, K = G.matrix(w2d)
@@ -99,6 +110,7 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or (x2.stride(0) & 3):
             x2 = x2.contiguous()
+        x2 = _bf16_operand(x2)
         N = weight.shape[0]
         out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)  # not a view:
         with torch.cuda.device(x.device):                 # downstream ops may overwrite it in place
@@ -119,10 +131,11 @@ class LinearFn(torch.autograd.Function):
         M = dy2.shape[0]
         dx = dw = db = None
         with torch.cuda.device(dy.device):
+            dyb = _bf16_operand(dy2)
             if ctx.needs_input_grad[0]:
-                dx = _grad_input(dy2, weight).view(*dy.shape[:-1], K)
+                dx = _grad_input(dyb, weight).view(*dy.shape[:-1], K)
             if ctx.needs_input_grad[1]:
-                dw = _grad_weight(dy2, G.matrix(x2)[0], _g(x2), M, K, N)
+                dw = _grad_weight(dyb, G.matrix(x2)[0], _g(x2), M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy2)
         return dx, dw, db, None
@@ -136,7 +149,7 @@ class TimeDelayFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w2d, bias, taps, dil, stride, pad, relu):
-        x = x.contiguous()
+        x = _bf16_operand(x.contiguous())
         Bn, T, C = x.shape
         N = w2d.shape[0]
         with torch.cuda.device(x.device):
@@ -161,14 +174,15 @@ class TimeDelayFn(torch.autograd.Function):
         M = dy2.shape[0]
         dx = dw = db = None
         with torch.cuda.device(dy.device):
+            dyb = _bf16_operand(dy2)
             if ctx.needs_input_grad[0]:
-                dcol = _grad_input(dy2, w2d)  # (M, taps*C)
-                dx = torch.empty_like(x)
+                dcol = _grad_input(dyb, w2d)  # (M, taps*C)
+                dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
                 _lib.check(_lib.lib().pika_col2im(dcol.data_ptr(), dx.data_ptr(), Bn, t_out, T, C,
                                                   taps, stride, dil, pad, _stream()), "pika_col2im")
             if ctx.needs_input_grad[1]:
                 a_op = G.time_delay(x, taps, dil, stride, pad)[0]
-                dw = _grad_weight(dy2, a_op, _g(x), M, K, N)
+                dw = _grad_weight(dyb, a_op, _g(x), M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy2)
         return dx, dw, db, None, None, None, None, None
