@@ -398,12 +398,21 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     const int nk = (K + CF::BK - 1) / CF::BK;
     int splitk = 1;
     if (batch == 1 && tiles < 256 && nk >= 32 && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
-        // one resident workgroup per CU: the largest split that still fits ONE round of 256 workgroups
-        // (a partial second round costs a full tile time, and every extra split adds an atomic pass
-        // over C; measured in tools/dw_bench.py / profiles/r1_dw_split_sweep.txt)
-        static const int target = [] { const char *e = getenv("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
-        splitk = target / tiles;
-        if (splitk > nk / 24) splitk = nk / 24;
+        // One resident workgroup per CU.  Cost of split s in K-tile units: rounds of 256 workgroups x
+        // (K-tiles per workgroup + ~40 of prologue/epilogue) + ~6 per atomic pass over C; the minimum
+        // reproduces the measured optimum on every shape of tools/dw_bench.py
+        // (profiles/r1_dw_split_sweep.txt).  PIKA_GEMM_SPLIT_TARGET=n forces ceil(n / tiles).
+        static const int target = [] { const char *e = getenv("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
+        if (target > 0) {
+            splitk = (target + tiles - 1) / tiles;
+        } else {
+            long long best = -1;
+            for (int sp = 1; sp <= 64 && sp <= nk / 8; ++sp) {
+                const long long cost = (long long)((tiles * sp + 255) / 256) * ((nk + sp - 1) / sp + 40) + 6LL * sp;
+                if (best < 0 || cost < best) { best = cost; splitk = sp; }
+            }
+        }
+        if (splitk > nk / 8) splitk = nk / 8;
         if (splitk > 64) splitk = 64;
         if (splitk < 1) splitk = 1;
     }
@@ -471,6 +480,9 @@ int dispatch_trans(const pika_operand_t *A, const pika_operand_t *B, float *C, l
 
 }  // namespace
 
+int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+                          int M, int N, int K, const float *bias, int flags, hipStream_t s);
+
 extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C,
                             long long ldc, long long c_z_outer, long long c_z_inner, int M, int N,
                             int K, int batch, int z_div, const float *bias, int flags,
@@ -479,6 +491,11 @@ extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, fl
     if (!operand_ok(*A, K, M) || !operand_ok(*B, K, N)) return PIKA_EINVAL;
     if (batch > 65535) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (batch == 1 && !c_z_outer && !c_z_inner) {   // bf16 x bf16: direct-to-LDS ping-pong kernel (gemm_glds.hip)
+        static const bool off = getenv("PIKA_GEMM_NO_PP") != nullptr;
+        const int rc = off ? -100 : pika_internal_gemm_pp(A, B, C, ldc, M, N, K, bias, flags, s);
+        if (rc != -100) return rc;
+    }
     const int key = (A->dtype == PIKA_BF16 ? 2 : 0) | (B->dtype == PIKA_BF16 ? 1 : 0);
 #define ARGS A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, bias, flags, s
     switch (key) {

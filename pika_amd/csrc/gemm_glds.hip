@@ -6,15 +6,19 @@
 // other LDS buffer -- no VGPR staging, no conversion -- and the 16-byte granule index is XOR-ed
 // with (row & 7) on the SOURCE address (LDS image stays lane-linear, as the instruction
 // requires) and again on the fragment read, which makes ds_read_b128 at most 2-way conflicted.
-// Measured (tools/glds_gemm.hip, MI355X): 640-770 TFLOP/s on the joint shapes vs 460-500 for the
-// register-staged kernel of gemm.hip.
+// Two kernels: gemm_glds (256x128 tile, lockstep, 2 barriers per K-step: 640-770 TFLOP/s on the
+// joint shapes) for narrow outputs, and gemm_pp (256x256 tile, two wave groups in ping-pong:
+// 800-1250 TFLOP/s on random data, tools/gemm8.hip) for everything else.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "pika_gemm.h"
 #include "pika_rnnt.h"
 
+#define PIKA_NOT_APPLICABLE (-100)
+
 namespace {
+
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -110,7 +114,240 @@ __global__ __launch_bounds__(THREADS) void gemm_glds(const __bf16 *__restrict__ 
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" kernel: 8 waves (2 x 4), 128 x 64 outputs per wave (128 accumulator
+// VGPRs), K-tile double buffer of 2 x 64 KB filled by global_load_lds.  Waves 0-3 and waves 4-7
+// (the two waves of every SIMD) run ONE barrier apart: every K-tile is four quadrant phases
+// {ds_read fragments + issue loads | 16 MFMAs}, and while one group is in its load segment the
+// other group owns the matrix pipe.  The prefetch of tile t+1 is issued in phases 0-1 of tile t
+// and waited for (vmcnt(0), four segments later, nothing else in flight) in phase 3 before the
+// barrier that lets the other group read it.  Per CU and K-tile: 64 KB from L2 (32 B/clk) and
+// 192 KB of conflict-free ds_read_b128 for 2048 MFMA cycles.
+// A may be a time-delay view (pika_operand_t with pad == 0, C % 64 == 0): a K-tile never straddles
+// a tap, so it only changes the per-tile source offset.
+constexpr int PP_T = 256 * 128, PP_BUF = 2 * PP_T;
+
+#define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+struct PPArgs {
+    const __bf16 *A, *B;
+    float *C;
+    const float *bias;
+    long long a_batch, a_row, a_tap;   // element strides of A: per batch, per output row, per tap
+    long long ldb, ldc;
+    int a_rpb, a_C;                    // rows per batch, channels per tap
+    int M, N, K, relu;
+};
+
+__device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+
+__global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int M = P.M, N = P.N;
+    const int nx = gridDim.x, ntiles = nx * gridDim.y;
+    int tile = blockIdx.y * nx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / nx) * 256, n0 = (tile % nx) * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+
+    const char *pa[4], *pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3), g = (lane & 7) ^ (r & 7);
+        int ra = m0 + r, rb = n0 + r;
+        ra = ra < M ? ra : M - 1;
+        rb = rb < N ? rb : N - 1;
+        const int ab = ra / P.a_rpb, at = ra - ab * P.a_rpb;
+        pa[i] = reinterpret_cast<const char *>(P.A + (long long)ab * P.a_batch + (long long)at * P.a_row) + g * 16;
+        pb[i] = reinterpret_cast<const char *>(P.B + (long long)rb * P.ldb) + g * 16;
+    }
+    const int piece0 = wave * 4 * 1024;
+    auto gl = [&](const char *p, unsigned char *dst) {
+        __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
+    };
+    const int sw0 = (((lane >> 4)) ^ (lane & 7)) << 4, sw1 = sw0 ^ 64;
+    const int aoff = (wr * 128 + (lane & 15)) * 128, boff = PP_T + (wc * 64 + (lane & 15)) * 128;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = P.K / 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gl(pa[i], smem + piece0 + i * 1024);
+        gl(pb[i], smem + PP_T + piece0 + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();   // group 1 runs one segment behind group 0
+
+    bf16x8 fa[4][2], fb[4][2];
+    int tap = 0, c0 = 0;
+    for (int t = 0; t < nt; ++t) {
+        const unsigned char *cur = smem + (t & 1) * PP_BUF;
+        unsigned char *nxt = smem + ((t + 1) & 1) * PP_BUF + piece0;
+        const bool pf = t + 1 < nt;
+        c0 += 64;
+        if (c0 == P.a_C) { c0 = 0; ++tap; }
+        const long long ka = ((long long)tap * P.a_tap + c0) * 2, kb = (long long)(t + 1) * 128;
+        // ---- phase 0: quadrant (m-half 0, n-half 0)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = ldsv(cur + boff + j * 2048 + sw0);
+            fb[j][1] = ldsv(cur + boff + j * 2048 + sw1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = ldsv(cur + aoff + i * 2048 + sw0);
+            fa[i][1] = ldsv(cur + aoff + i * 2048 + sw1);
+        }
+        if (pf) {
+            gl(pa[0] + ka, nxt);
+            gl(pa[1] + ka, nxt + 1024);
+            gl(pa[2] + ka, nxt + 2048);
+        }
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- phase 1: (m-half 0, n-half 1)
+#pragma unroll
+        for (int j = 2; j < 4; ++j) {
+            fb[j][0] = ldsv(cur + boff + j * 2048 + sw0);
+            fb[j][1] = ldsv(cur + boff + j * 2048 + sw1);
+        }
+        if (pf) {
+            gl(pa[3] + ka, nxt + 3072);
+            gl(pb[0] + kb, nxt + PP_T);
+            gl(pb[1] + kb, nxt + PP_T + 1024);
+            gl(pb[2] + kb, nxt + PP_T + 2048);
+            gl(pb[3] + kb, nxt + PP_T + 3072);
+        }
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- phase 2: (m-half 1, n-half 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = ldsv(cur + aoff + (4 + i) * 2048 + sw0);
+            fa[i][1] = ldsv(cur + aoff + (4 + i) * 2048 + sw1);
+        }
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 2; j < 4; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+        // ---- phase 3: (m-half 1, n-half 0); the prefetched tile must have landed before the
+        // barrier that lets the other group start reading it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BAR();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_BAR();
+    }
+    if (wr == 0) PP_BAR();
+
+    const float *bias = P.bias;
+    float *C = P.C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (n + 3 < N) {
+                f32x4 v = acc[i][j];
+                if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
+                if (P.relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                *reinterpret_cast<f32x4 *>(C + (long long)m * P.ldc + n) = v;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) {
+                        float v = acc[i][j][e] + (bias ? bias[n + e] : 0.f);
+                        C[(long long)m * P.ldc + n + e] = P.relu ? fmaxf(v, 0.f) : v;
+                    }
+            }
+        }
+    }
+}
+
+int launch_pp(const PPArgs &P, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if ((P.M + 255) / 256 > 65535) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(gemm_pp, dim3((P.N + 255) / 256, (P.M + 255) / 256), dim3(512), 2 * PP_BUF, s, P);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
+
+// Used by pika_gemm_nt (gemm.hip): returns PIKA_NOT_APPLICABLE when the operands do not fit the
+// direct-to-LDS kernels (then the register-staged kernel runs).
+int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+                          int M, int N, int K, const float *bias, int flags, hipStream_t s) {
+    if (A->dtype != PIKA_BF16 || B->dtype != PIKA_BF16 || A->trans || B->trans) return PIKA_NOT_APPLICABLE;
+    if (flags & ~PIKA_GEMM_RELU) return PIKA_NOT_APPLICABLE;
+    if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
+    // B: plain matrix
+    if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
+        return PIKA_NOT_APPLICABLE;
+    // A: plain matrix or time-delay view whose taps are whole K-tiles and never leave [0, t_in)
+    if (A->pad || (A->ld & 7) || (A->batch_stride & 7) || (reinterpret_cast<uintptr_t>(A->ptr) & 15)) return PIKA_NOT_APPLICABLE;
+    const int a_C = A->C < K ? A->C : K;
+    if ((a_C & 63) || K % a_C) return PIKA_NOT_APPLICABLE;
+    const int taps = K / a_C;
+    if (taps > 1 && (long long)(A->rows_per_batch - 1) * A->stride + (long long)(taps - 1) * A->dil >= A->t_in)
+        return PIKA_NOT_APPLICABLE;
+    if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < 160) return PIKA_NOT_APPLICABLE;
+    PPArgs P{};
+    P.A = static_cast<const __bf16 *>(A->ptr); P.B = static_cast<const __bf16 *>(B->ptr);
+    P.C = C; P.bias = bias; P.ldb = B->ld; P.ldc = ldc;
+    P.a_rpb = A->rows_per_batch; P.a_batch = A->batch_stride; P.a_row = (long long)A->stride * A->ld;
+    P.a_tap = (long long)A->dil * A->ld; P.a_C = a_C;
+    P.M = M; P.N = N; P.K = K; P.relu = (flags & PIKA_GEMM_RELU) ? 1 : 0;
+    return launch_pp(P, s);
+}
 
 extern "C" int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, long long ldb, float *C,
                                  long long ldc, int M, int N, int K, const float *bias, void *stream) {
@@ -118,6 +355,14 @@ extern "C" int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, lo
     if ((K % BK) || (lda & 7) || (ldb & 7) || (ldc & 3) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) |
                                                              reinterpret_cast<uintptr_t>(C)) & 15))
         return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N > BN) {
+        PPArgs P{};
+        P.A = static_cast<const __bf16 *>(A); P.B = static_cast<const __bf16 *>(B); P.C = C; P.bias = bias;
+        P.ldb = ldb; P.ldc = ldc; P.a_rpb = M; P.a_batch = 0; P.a_row = lda; P.a_tap = 0; P.a_C = K;
+        P.M = M; P.N = N; P.K = K; P.relu = 0;
+        return launch_pp(P, s);
+    }
     if ((M + BM - 1) / BM > 65535) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -126,8 +371,7 @@ extern "C" int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, lo
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_glds, dim3((N + BN - 1) / BN, (M + BM - 1) / BM), dim3(THREADS), 2 * BUF,
-                       static_cast<hipStream_t>(stream), static_cast<const __bf16 *>(A),
-                       static_cast<const __bf16 *>(B), C, M, N, K, lda, ldb, ldc, bias);
+    hipLaunchKernelGGL(gemm_glds, dim3((N + BN - 1) / BN, (M + BM - 1) / BM), dim3(THREADS), 2 * BUF, s,
+                       static_cast<const __bf16 *>(A), static_cast<const __bf16 *>(B), C, M, N, K, lda, ldb, ldc, bias);
     return (int)hipGetLastError();
 }

@@ -59,6 +59,14 @@ def _bf16_operand(t, min_elems=1 << 21):
     return t
 
 
+def _weight_for(x, w2d):
+    """The weight in the dtype of its activation operand: a bf16 x bf16 product (K % 64 == 0) runs on the
+    direct-to-LDS kernel (gemm_glds.hip); the bf16 rounding of W is the one the MFMA path applies anyway."""
+    if x.dtype == torch.bfloat16 and w2d.dtype == torch.float32 and w2d.shape[1] % 64 == 0:
+        return w2d.detach().to(torch.bfloat16)
+    return w2d
+
+
 def _weight_t(w2d):
     """W^T (K,N) for dX = dY @ W.  Weights are small next to activations; one pass per call."""
     op, rows, K = G.matrix(w2d)
@@ -114,7 +122,7 @@ class LinearFn(torch.autograd.Function):
         N = weight.shape[0]
         out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)  # not a view:
         with torch.cuda.device(x.device):                 # downstream ops may overwrite it in place
-            G.gemm_nt(x2, weight, bias=bias, relu=relu, out=out.view(-1, N))
+            G.gemm_nt(x2, _weight_for(x2, weight), bias=bias, relu=relu, out=out.view(-1, N))
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x2, weight, out if relu == 1 else None)
@@ -155,7 +163,7 @@ class TimeDelayFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
             y = torch.empty((Bn, t_out, N), dtype=torch.float32, device=x.device)
-            G.launch(a_op, G.matrix(w2d)[0], y, N, M, N, K, bias=bias, relu=relu)
+            G.launch(a_op, G.matrix(_weight_for(x, w2d))[0], y, N, M, N, K, bias=bias, relu=relu)
         ctx.cfg = (taps, dil, stride, pad, relu, t_out)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w2d, y if relu == 1 else None)

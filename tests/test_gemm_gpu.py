@@ -194,3 +194,25 @@ def test_direct_to_lds_bf16_nt(hip_device, M, N, K):
     assert bool((out[:, N:] == -7.0).all())
     with pytest.raises(RuntimeError):
         G.gemm_bf16_nt(a.to(hip_device)[:, :K - 32], b.to(hip_device)[:, :K - 32])
+
+
+@pytest.mark.parametrize("taps,dil,stride,T,C,N,B", [(3, 1, 1, 300, 64, 256, 3), (3, 3, 1, 200, 128, 200, 4),
+                                                     (3, 3, 4, 410, 64, 512, 3), (1, 1, 1, 350, 192, 264, 2)])
+def test_ping_pong_kernel_routes(hip_device, taps, dil, stride, T, C, N, B):
+    """bf16 x bf16 operands (plain and time-delay views, bias, ReLU) take the 256x256 direct-to-LDS kernel
+    inside pika_gemm_nt; PIKA_GEMM_NO_PP-free cross-check against the fp64 product."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(taps * 100 + T)
+    x = torch.randn(B, T, C, generator=g).bfloat16()
+    w = (torch.randn(N, taps * C, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, generator=g)
+    t_out = (T - dil * (taps - 1) - 1) // stride + 1
+    cols = torch.stack([x.double()[:, tap * dil: tap * dil + (t_out - 1) * stride + 1: stride] for tap in range(taps)], 2)
+    want = torch.relu(cols.reshape(B * t_out, taps * C) @ w.double().t() + bias.double())
+    xd, wd = x.to(hip_device), w.to(hip_device)
+    a_op, M, K, t_o = G.time_delay(xd, taps, dil, stride, 0)
+    assert (M, K, t_o) == (B * t_out, taps * C, t_out)
+    out = torch.full((M, N), float("nan"), device=hip_device)
+    G.launch(a_op, G.matrix(wd)[0], out, N, M, N, K, bias=bias.to(hip_device), relu=True)
+    tol = 4e-6 * (cols.reshape(M, K).abs() @ w.double().abs().t()).max().item() + 1e-6
+    assert (out.double().cpu() - want).abs().max() < tol
