@@ -11,6 +11,7 @@
 // 800-1250 TFLOP/s on random data, tools/gemm8.hip) for everything else.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pika_gemm.h"
 #include "pika_rnnt.h"
@@ -307,6 +308,219 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same schedule for C[m,n] = sum_r A[r,m] * B[r,n] with BOTH operands reduction-major in memory
+// (`trans` operands of pika_gemm_nt: weight gradients dW = dY^T X).  A K-tile is 64 reduction rows
+// x 256 output columns per operand ([64][512 B] in LDS); MFMA fragments come out of it with
+// ds_read_b64_tr_b16.  The 32-byte chunk index of a row is XOR-ed with
+// key(r) = (r & 3) | ((r >> 3) & 1) << 2 on the global source address and on the read: the eight
+// (row) x 32 B pieces a 32-lane half of a transpose read touches land on eight distinct bank
+// groups.  Reduction rows past the end and column chunks past the operand width are fetched from a
+// zero page.  Split-K over gridDim.z with an atomic epilogue (C pre-zeroed by the host).
+__device__ __attribute__((aligned(512))) const unsigned int pp_zero_page[128] = {0};
+
+struct TNOperand {
+    const __bf16 *ptr;     // element (r, c): ptr + b*batch + t*row + c,  (b, t) = divmod(r, rpb)
+    long long batch, row;  // element strides
+    int rpb, width;        // rows per batch; number of valid view columns (multiple of 8)
+    int C;                 // channels per tap (column c of the view -> tap = c / C: + tap * tap_stride)
+    long long tap_stride;
+};
+
+struct TNArgs {
+    TNOperand A, B;
+    float *C;
+    long long ldc;
+    int M, N, R;           // output extents, reduction length
+    int tiles_per_split;   // K-tiles (64 rows) per gridDim.z slice
+    int atomic;
+};
+
+__device__ inline bf16x8 lds_tr(const unsigned char *p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * 512));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+struct TNStager {
+    const char *p[4];
+    int tt[4];
+    long long step, wrap;  // bytes per 64 rows; extra bytes when crossing a batch
+    int rpb;
+
+    __device__ inline void init(const TNOperand &o, int c0, int r0, int wave, int lane) {
+        rpb = o.rpb;
+        step = 64 * o.row * 2;
+        wrap = (o.batch - (long long)o.rpb * o.row) * 2;
+        const int tap = c0 / o.C;   // a 256-column block never straddles a tap (C % 256 == 0 or one tap)
+        const long long coff = (long long)tap * o.tap_stride + (c0 - tap * o.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 2 * (wave * 4 + i) + (lane >> 5);           // row inside the K-tile
+            const int key = (row & 3) | (((row >> 3) & 1) << 2);
+            const int g16 = lane & 31, q = (g16 >> 1) ^ key;             // 32-byte chunk, swizzled
+            // columns past the operand width feed output rows/columns that are never stored: re-read
+            // the last valid chunk instead of running off the row
+            const int col = min(q * 16 + (g16 & 1) * 8, o.width - c0 - 8);
+            const int r = r0 + row;
+            const int b = r / o.rpb;
+            tt[i] = r - b * o.rpb;
+            p[i] = reinterpret_cast<const char *>(o.ptr + (long long)b * o.batch + (long long)tt[i] * o.row + coff + col);
+        }
+    }
+    // reduction rows past the end read zeros (for BOTH operands: 0 x garbage could be NaN)
+    __device__ inline const char *src(int i, int r, int R) const {
+        const char *z = reinterpret_cast<const char *>(pp_zero_page) + (threadIdx.x & 31) * 16;
+        return r < R ? p[i] : z;
+    }
+    __device__ inline void advance() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[i] += step;
+            tt[i] += 64;
+            while (tt[i] >= rpb) { tt[i] -= rpb; p[i] += wrap; }
+        }
+    }
+};
+
+#define TN_MFMA(MH, KK)                                                                             \
+    do {                                                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+                acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[(MH) * 4 + i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                              \
+    } while (0)
+
+__global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int nx = gridDim.x, ntiles = nx * gridDim.y;
+    int tile = blockIdx.y * nx + blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile / nx) * 256, n0 = (tile % nx) * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+    const int t_begin = blockIdx.z * P.tiles_per_split;
+    const int t_total = (P.R + 63) / 64;
+    const int nt = min(P.tiles_per_split, t_total - t_begin);
+    if (nt <= 0) return;
+    const int R = P.R;
+
+    TNStager sa, sb;
+    sa.init(P.A, m0, t_begin * 64, wave, lane);
+    sb.init(P.B, n0, t_begin * 64, wave, lane);
+    int rrow = t_begin * 64 + 2 * (wave * 4) + (lane >> 5);   // reduction row of piece 0 (piece i: + 2i)
+    const int piece0 = wave * 4 * 1024;
+    auto gl = [&](const char *p, unsigned char *dst) {
+        __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
+    };
+
+    // transpose-read addressing: lane (g, i16 = 4j + c) supplies row kk*32 + g*8 + j (+4 for the second
+    // read), 8 bytes at column 4c of the fragment's 16-column chunk; key(row) = j | (g & 1) << 2
+    const int g = lane >> 4, jj = (lane & 15) >> 2, cc = lane & 3;
+    const int rbase = (g * 8 + jj) * 512 + cc * 8;
+    const int keyoff = (jj | ((g & 1) << 2)) << 5;
+    const int achunk = wr * 8 * 32, bchunk = PP_T + (wc >> 1) * 8 * 32;
+    const int keyoffb = keyoff ^ ((wc & 1) << 7);   // chunk (wc & 1) * 4 + j inside the 8-chunk group
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gl(sa.src(i, rrow + 2 * i, R), smem + piece0 + i * 1024);
+        gl(sb.src(i, rrow + 2 * i, R), smem + PP_T + piece0 + i * 1024);
+    }
+    sa.advance();
+    sb.advance();
+    rrow += 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BAR();
+    if (wr == 1) PP_BAR();
+
+    // phases of a K-tile: (m-half 0, k 0..31) (m-half 1, k 0..31) (m-half 0, k 32..63) (m-half 1, k 32..63);
+    // 16 MFMAs each; fragment loads 8 / 4 / 8 / 4, prefetch issue 4 / 4 / 0 / 0, pointer update in the last
+    bf16x8 fa[4], fb[4];
+    for (int t = 0; t < nt; ++t) {
+        const unsigned char *cur = smem + (t & 1) * PP_BUF + rbase;
+        unsigned char *nxt = smem + ((t + 1) & 1) * PP_BUF + piece0;
+        const bool pf = t + 1 < nt;
+        // ---- phase 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = lds_tr(cur + bchunk + ((j << 5) ^ keyoffb));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + ((i << 5) ^ keyoff));
+        if (pf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gl(sa.src(i, rrow + 2 * i, R), nxt + i * 1024);
+        }
+        PP_BAR();
+        TN_MFMA(0, 0);
+        PP_BAR();
+        // ---- phase 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + (((4 + i) << 5) ^ keyoff));
+        if (pf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gl(sb.src(i, rrow + 2 * i, R), nxt + PP_T + i * 1024);
+        }
+        PP_BAR();
+        TN_MFMA(1, 0);
+        PP_BAR();
+        // ---- phase 2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = lds_tr(cur + bchunk + ((j << 5) ^ keyoffb) + 32 * 512);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + ((i << 5) ^ keyoff) + 32 * 512);
+        PP_BAR();
+        TN_MFMA(0, 1);
+        PP_BAR();
+        // ---- phase 3: the prefetched tile must have landed before the barrier that lets the other
+        // group start reading it
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + (((4 + i) << 5) ^ keyoff) + 32 * 512);
+        sa.advance();
+        sb.advance();
+        rrow += 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BAR();
+        TN_MFMA(1, 1);
+        PP_BAR();
+    }
+    if (wr == 0) PP_BAR();
+
+    float *C = P.C;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            float *c = C + (long long)m * P.ldc + n;
+            if (P.atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < P.N) atomicAdd(c + e, acc[i][j][e]);
+            } else if (n + 3 < P.N) {
+                *reinterpret_cast<f32x4 *>(c) = acc[i][j];
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < P.N) c[e] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 int launch_pp(const PPArgs &P, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -320,13 +534,60 @@ int launch_pp(const PPArgs &P, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+bool tn_operand(const pika_operand_t &o, int extent, TNOperand &t) {
+    if (o.pad || (o.ld & 7) || (o.batch_stride & 7) || (extent & 7) || (reinterpret_cast<uintptr_t>(o.ptr) & 15)) return false;
+    const bool one_tap = o.C >= extent;
+    if (!one_tap && (o.C & 255)) return false;
+    const int taps = one_tap ? 1 : (extent + o.C - 1) / o.C;
+    if (taps > 1 && (long long)(o.rows_per_batch - 1) * o.stride + (long long)(taps - 1) * o.dil >= o.t_in) return false;
+    t.ptr = static_cast<const __bf16 *>(o.ptr);
+    t.batch = o.batch_stride; t.row = (long long)o.stride * o.ld; t.rpb = o.rows_per_batch;
+    t.width = extent; t.C = one_tap ? (1 << 30) : o.C; t.tap_stride = (long long)o.dil * o.ld;
+    return true;
+}
+
+int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc, int M, int N,
+                 int R, const float *bias, int flags, hipStream_t s) {
+    if (bias || flags || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
+    if (M < 192 || N < 192 || R < 512) return PIKA_NOT_APPLICABLE;
+    TNArgs P{};
+    if (!tn_operand(*A, M, P.A) || !tn_operand(*B, N, P.B)) return PIKA_NOT_APPLICABLE;
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = (R + 63) / 64;
+    int split = 1;
+    long long best = -1;
+    for (int sp = 1; sp <= 64 && sp <= nk / 4; ++sp) {   // same cost model as gemm.hip, larger atomic pass
+        const long long cost = (long long)((tiles * sp + 255) / 256) * ((nk + sp - 1) / sp + 40) + 12LL * sp;
+        if (best < 0 || cost < best) { best = cost; split = sp; }
+    }
+    static const int forced = [] { const char *e = getenv("PIKA_GEMM_TN_SPLIT"); return e ? atoi(e) : 0; }();
+    if (forced > 0) split = forced < nk ? forced : nk;
+    P.C = C; P.ldc = ldc; P.M = M; P.N = N; P.R = R;
+    P.tiles_per_split = (nk + split - 1) / split;
+    split = (nk + P.tiles_per_split - 1) / P.tiles_per_split;
+    P.atomic = split > 1;
+    if (P.atomic) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_tn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_pp_tn, dim3((N + 255) / 256, (M + 255) / 256, split), dim3(512), 2 * PP_BUF, s, P);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // Used by pika_gemm_nt (gemm.hip): returns PIKA_NOT_APPLICABLE when the operands do not fit the
 // direct-to-LDS kernels (then the register-staged kernel runs).
 int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
                           int M, int N, int K, const float *bias, int flags, hipStream_t s) {
-    if (A->dtype != PIKA_BF16 || B->dtype != PIKA_BF16 || A->trans || B->trans) return PIKA_NOT_APPLICABLE;
+    if (A->dtype != PIKA_BF16 || B->dtype != PIKA_BF16 || (A->trans != 0) != (B->trans != 0)) return PIKA_NOT_APPLICABLE;
+    if (A->trans) return launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, s);
     if (flags & ~PIKA_GEMM_RELU) return PIKA_NOT_APPLICABLE;
     if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
     // B: plain matrix

@@ -216,3 +216,29 @@ def test_ping_pong_kernel_routes(hip_device, taps, dil, stride, T, C, N, B):
     G.launch(a_op, G.matrix(wd)[0], out, N, M, N, K, bias=bias.to(hip_device), relu=True)
     tol = 4e-6 * (cols.reshape(M, K).abs() @ w.double().abs().t()).max().item() + 1e-6
     assert (out.double().cpu() - want).abs().max() < tol
+
+
+@pytest.mark.parametrize("Bn,T,C,N,taps,dil,stride,ldpad", [
+    (4, 300, 256, 512, 3, 3, 1, 0),     # time-delay X, batch wrap inside K-tiles, ragged reduction
+    (5, 200, 256, 264, 1, 1, 1, 24),    # plain X, dY wider than its valid columns (zero page past the width)
+    (2, 1100, 512, 1000, 3, 1, 4, 8),   # strided time-delay, output extents not multiples of 256
+])
+def test_ping_pong_weight_gradient(hip_device, Bn, T, C, N, taps, dil, stride, ldpad):
+    """dW = dY^T X with both operands bf16 and reduction-major (`trans`): the 256x256 transpose-read
+    kernel of gemm_glds.hip (split-K + atomics) vs the fp64 im2col product."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(Bn * 1000 + T)
+    x = torch.randn(Bn, T, C, generator=g).bfloat16().to(hip_device)
+    a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, 0)
+    dyp = torch.randn(M, N + ldpad, generator=g).bfloat16().to(hip_device)
+    dy = dyp[:, :N]
+    a_op.trans = 1
+    dy_op = G.matrix(dy)[0]
+    dy_op.trans = 1
+    out = torch.full((N, K), float("nan"), device=hip_device)
+    G.launch(dy_op, a_op, out, K, N, K, M)
+    cols = [x[:, j * dil: j * dil + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
+    a = torch.cat(cols, -1).reshape(M, K).double().cpu()
+    want = dy.double().cpu().t() @ a
+    scale = dy.double().cpu().abs().t() @ a.abs()
+    assert ((out.double().cpu() - want).abs() / scale).max() < 1e-5   # exact bf16 products, fp32 sums

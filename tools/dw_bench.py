@@ -40,6 +40,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "worker":
         worker()
     else:
+        var = os.environ.get("DW_BENCH_VAR", "PIKA_GEMM_SPLIT_TARGET")
         for t in (sys.argv[1:] or ["128", "192", "256", "320", "384", "512", "768", "1024"]):
             subprocess.run([sys.executable, os.path.abspath(__file__), "worker"],
-                           env=dict(os.environ, PIKA_GEMM_SPLIT_TARGET=t), check=False)
+                           env=dict(os.environ, **{var: t, "PIKA_GEMM_SPLIT_TARGET": t}), check=False)
