@@ -20,6 +20,8 @@
 #ifndef PIKA_GEMM_H
 #define PIKA_GEMM_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -55,6 +57,14 @@ typedef struct {
 int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
                  long long c_z_outer, long long c_z_inner, int M, int N, int K, int batch,
                  int z_div, const float *bias, int flags, void *stream);
+
+/* Same, with caller-owned device scratch (16-byte aligned; may be NULL / 0): split-K products whose
+ * partial tiles fit (splits * M * N * 4 bytes) are written there and summed by one streaming kernel
+ * instead of float atomics into C (deterministic, and ~5x cheaper per split on small outputs). */
+int pika_gemm_nt_ws(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
+                    long long c_z_outer, long long c_z_inner, int M, int N, int K, int batch,
+                    int z_div, const float *bias, int flags, void *workspace,
+                    size_t workspace_bytes, void *stream);
 
 /* C[M,N] f32 = A[M,K] bf16 * B[N,K]^T bf16 + bias[n] with direct global->LDS operand loads
  * (gemm_glds.hip).  Requirements: K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned

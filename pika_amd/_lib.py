@@ -29,6 +29,7 @@ SIGNATURES = {
     "pika_specaug_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     # include/pika_gemm.h
     "pika_gemm_nt": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "pika_gemm_nt_ws": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp, ctypes.c_size_t, _vp]),
     "pika_gemm_bf16_nt": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp]),
     # include/pika_attn.h
     "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, ctypes.c_float, ctypes.c_uint, _vp]),

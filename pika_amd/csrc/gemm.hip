@@ -481,19 +481,28 @@ int dispatch_trans(const pika_operand_t *A, const pika_operand_t *B, float *C, l
 }  // namespace
 
 int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
-                          int M, int N, int K, const float *bias, int flags, hipStream_t s);
+                          int M, int N, int K, const float *bias, int flags, void *ws, size_t ws_bytes,
+                          hipStream_t s);
 
 extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C,
                             long long ldc, long long c_z_outer, long long c_z_inner, int M, int N,
                             int K, int batch, int z_div, const float *bias, int flags,
                             void *stream) {
+    return pika_gemm_nt_ws(A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, bias, flags, nullptr, 0,
+                           stream);
+}
+
+extern "C" int pika_gemm_nt_ws(const pika_operand_t *A, const pika_operand_t *B, float *C,
+                               long long ldc, long long c_z_outer, long long c_z_inner, int M, int N,
+                               int K, int batch, int z_div, const float *bias, int flags,
+                               void *workspace, size_t workspace_bytes, void *stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || z_div <= 0) return PIKA_EINVAL;
     if (!operand_ok(*A, K, M) || !operand_ok(*B, K, N)) return PIKA_EINVAL;
     if (batch > 65535) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (batch == 1 && !c_z_outer && !c_z_inner) {   // bf16 x bf16: direct-to-LDS ping-pong kernel (gemm_glds.hip)
         static const bool off = getenv("PIKA_GEMM_NO_PP") != nullptr;
-        const int rc = off ? -100 : pika_internal_gemm_pp(A, B, C, ldc, M, N, K, bias, flags, s);
+        const int rc = off ? -100 : pika_internal_gemm_pp(A, B, C, ldc, M, N, K, bias, flags, workspace, workspace_bytes, s);
         if (rc != -100) return rc;
     }
     const int key = (A->dtype == PIKA_BF16 ? 2 : 0) | (B->dtype == PIKA_BF16 ? 1 : 0);

@@ -334,6 +334,7 @@ struct TNArgs {
     int M, N, R;           // output extents, reduction length
     int tiles_per_split;   // K-tiles (64 rows) per gridDim.z slice
     int atomic;
+    float *ws;             // split-K partials [gridDim.z][M][N] (dense), or null -> atomics into C
 };
 
 __device__ inline bf16x8 lds_tr(const unsigned char *p) {
@@ -499,6 +500,8 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
     if (wr == 0) PP_BAR();
 
     float *C = P.C;
+    long long ldc = P.ldc;
+    if (P.ws) { C = P.ws + (long long)blockIdx.z * P.M * P.N; ldc = P.N; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
@@ -506,8 +509,8 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            float *c = C + (long long)m * P.ldc + n;
-            if (P.atomic) {
+            float *c = C + (long long)m * ldc + n;
+            if (P.atomic && !P.ws) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (n + e < P.N) atomicAdd(c + e, acc[i][j][e]);
@@ -519,6 +522,19 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
             }
         }
     }
+}
+
+// C[m, n] = sum_z ws[z][m][n]  (N % 4 == 0)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C,
+                                                            long long ldc, int M, int N, int splits) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, n4 = N >> 2;
+    if (idx >= (long long)M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (long long)m * n4) * 4;
+    const long long mn = (long long)M * N;
+    const float *p = ws + (long long)m * N + n;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(p);
+    for (int z = 1; z < splits; ++z) acc += *reinterpret_cast<const f32x4 *>(p + z * mn);
+    *reinterpret_cast<f32x4 *>(C + (long long)m * ldc + n) = acc;
 }
 
 int launch_pp(const PPArgs &P, hipStream_t s) {
@@ -547,7 +563,7 @@ bool tn_operand(const pika_operand_t &o, int extent, TNOperand &t) {
 }
 
 int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc, int M, int N,
-                 int R, const float *bias, int flags, hipStream_t s) {
+                 int R, const float *bias, int flags, void *ws, size_t ws_bytes, hipStream_t s) {
     if (bias || flags || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
     if (M < 192 || N < 192 || R < 512) return PIKA_NOT_APPLICABLE;
     TNArgs P{};
@@ -555,17 +571,27 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = (R + 63) / 64;
     int split = 1;
     long long best = -1;
-    for (int sp = 1; sp <= 64 && sp <= nk / 4; ++sp) {   // same cost model as gemm.hip, larger atomic pass
-        const long long cost = (long long)((tiles * sp + 255) / 256) * ((nk + sp - 1) / sp + 40) + 12LL * sp;
+    const size_t slice = (size_t)M * N * sizeof(float);
+    const bool have_ws = ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= 2 * slice;
+    // cost model of gemm.hip; a split costs an atomic pass over C (~12 K-tile times, measured), or ~2 when
+    // the partials go to the caller's workspace and one streaming kernel adds them up
+    const long long per_split = have_ws ? 2 : 12;
+    for (int sp = 1; sp <= 64 && sp <= nk / 4; ++sp) {
+        if (have_ws && sp > 1 && (size_t)sp * slice > ws_bytes) break;
+        const long long cost = (long long)((tiles * sp + 255) / 256) * ((nk + sp - 1) / sp + 40) + per_split * sp;
         if (best < 0 || cost < best) { best = cost; split = sp; }
     }
     static const int forced = [] { const char *e = getenv("PIKA_GEMM_TN_SPLIT"); return e ? atoi(e) : 0; }();
-    if (forced > 0) split = forced < nk ? forced : nk;
+    if (forced > 0) {
+        split = forced < nk ? forced : nk;
+        if (have_ws) while (split > 1 && (size_t)split * slice > ws_bytes) --split;
+    }
     P.C = C; P.ldc = ldc; P.M = M; P.N = N; P.R = R;
     P.tiles_per_split = (nk + split - 1) / split;
     split = (nk + P.tiles_per_split - 1) / P.tiles_per_split;
     P.atomic = split > 1;
-    if (P.atomic) {
+    P.ws = (P.atomic && have_ws) ? static_cast<float *>(ws) : nullptr;
+    if (P.atomic && !P.ws) {
         hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, s);
         if (e != hipSuccess) return (int)e;
     }
@@ -577,6 +603,10 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
         attr_set = true;
     }
     hipLaunchKernelGGL(gemm_pp_tn, dim3((N + 255) / 256, (M + 255) / 256, split), dim3(512), 2 * PP_BUF, s, P);
+    if (P.ws) {
+        const long long n4 = (long long)M * (N >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, P.ws, C, ldc, M, N, split);
+    }
     return (int)hipGetLastError();
 }
 
@@ -585,9 +615,10 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
 // Used by pika_gemm_nt (gemm.hip): returns PIKA_NOT_APPLICABLE when the operands do not fit the
 // direct-to-LDS kernels (then the register-staged kernel runs).
 int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
-                          int M, int N, int K, const float *bias, int flags, hipStream_t s) {
+                          int M, int N, int K, const float *bias, int flags, void *ws, size_t ws_bytes,
+                          hipStream_t s) {
     if (A->dtype != PIKA_BF16 || B->dtype != PIKA_BF16 || (A->trans != 0) != (B->trans != 0)) return PIKA_NOT_APPLICABLE;
-    if (A->trans) return launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, s);
+    if (A->trans) return launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, ws, ws_bytes, s);
     if (flags & ~PIKA_GEMM_RELU) return PIKA_NOT_APPLICABLE;
     if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
     // B: plain matrix

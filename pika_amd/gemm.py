@@ -64,16 +64,30 @@ def _flags(relu, accumulate, precision):
     return (RELU if relu else 0) | (ACCUMULATE if accumulate else 0) | (FP32SPLIT if p == "fp32" else 0)
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 160 << 20
+
+
+def _workspace(device):
+    """Per-device scratch for split-K partial tiles (stream-ordered use on the current stream)."""
+    ws = _WORKSPACE.get(device.index)
+    if ws is None:
+        ws = _WORKSPACE[device.index] = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=False, precision=None,
            batch=1, z_div=1, c_z_outer=0, c_z_inner=0):
     if not out.is_cuda:
         raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
     with torch.cuda.device(out.device):
-        rc = _lib.lib().pika_gemm_nt(ctypes.byref(a_op), ctypes.byref(b_op), out.data_ptr(), ldc,
-                                     c_z_outer, c_z_inner, M, N, K, batch, z_div,
-                                     None if bias is None else bias.data_ptr(),
-                                     _flags(relu, accumulate, precision),
-                                     torch.cuda.current_stream().cuda_stream)
+        ws = _workspace(out.device) if (a_op.trans and b_op.trans) else None
+        rc = _lib.lib().pika_gemm_nt_ws(ctypes.byref(a_op), ctypes.byref(b_op), out.data_ptr(), ldc,
+                                        c_z_outer, c_z_inner, M, N, K, batch, z_div,
+                                        None if bias is None else bias.data_ptr(),
+                                        _flags(relu, accumulate, precision),
+                                        None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                        torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pika_gemm_nt(M=%d,N=%d,K=%d)" % (M, N, K))
     return out
 
