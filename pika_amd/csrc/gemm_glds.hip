@@ -131,6 +131,8 @@ constexpr int PP_T = 256 * 128, PP_BUF = 2 * PP_T;
 
 #define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+__device__ __attribute__((aligned(512))) const unsigned int pp_zero_page[128] = {0};
+
 struct PPArgs {
     const __bf16 *A, *B;
     float *C;
@@ -138,6 +140,8 @@ struct PPArgs {
     long long a_batch, a_row, a_tap;   // element strides of A: per batch, per output row, per tap
     long long ldb, ldc;
     int a_rpb, a_C;                    // rows per batch, channels per tap
+    int a_tin, a_t0, a_tstep, a_dtap;  // source time of (row t, tap) = t * a_tstep + tap * a_dtap - a_t0, zero outside [0, a_tin)
+    int a_bounds;                      // 0: every (row, tap) is in range (no checks in the loop)
     int M, N, K, relu;
 };
 
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
 
     const char *pa[4], *pb[4];
+    int ts[4];   // source time of tap 0 for this lane's row of piece i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3), g = (lane & 7) ^ (r & 7);
@@ -163,9 +168,17 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         ra = ra < M ? ra : M - 1;
         rb = rb < N ? rb : N - 1;
         const int ab = ra / P.a_rpb, at = ra - ab * P.a_rpb;
+        ts[i] = at * P.a_tstep - P.a_t0;
         pa[i] = reinterpret_cast<const char *>(P.A + (long long)ab * P.a_batch + (long long)at * P.a_row) + g * 16;
         pb[i] = reinterpret_cast<const char *>(P.B + (long long)rb * P.ldb) + g * 16;
     }
+    const char *zp = reinterpret_cast<const char *>(pp_zero_page) + (lane & 7) * 16;
+    const int bounds = P.a_bounds;
+    // source of A piece i for tap `tp` at byte offset `off` (rows whose source time is outside the signal read zeros)
+    auto asrc = [&](int i, int tp, long long off) -> const char * {
+        if (!bounds) return pa[i] + off;
+        return (unsigned)(ts[i] + tp * P.a_dtap) < (unsigned)P.a_tin ? pa[i] + off : zp;
+    };
     const int piece0 = wave * 4 * 1024;
     auto gl = [&](const char *p, unsigned char *dst) {
         __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     const int nt = P.K / 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        gl(pa[i], smem + piece0 + i * 1024);
+        gl(asrc(i, 0, 0), smem + piece0 + i * 1024);
         gl(pb[i], smem + PP_T + piece0 + i * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,9 +223,9 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fa[i][1] = ldsv(cur + aoff + i * 2048 + sw1);
         }
         if (pf) {
-            gl(pa[0] + ka, nxt);
-            gl(pa[1] + ka, nxt + 1024);
-            gl(pa[2] + ka, nxt + 2048);
+            gl(asrc(0, tap, ka), nxt);
+            gl(asrc(1, tap, ka), nxt + 1024);
+            gl(asrc(2, tap, ka), nxt + 2048);
         }
         PP_BAR();
         __builtin_amdgcn_s_setprio(1);
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fb[j][1] = ldsv(cur + boff + j * 2048 + sw1);
         }
         if (pf) {
-            gl(pa[3] + ka, nxt + 3072);
+            gl(asrc(3, tap, ka), nxt + 3072);
             gl(pb[0] + kb, nxt + PP_T);
             gl(pb[1] + kb, nxt + PP_T + 1024);
             gl(pb[2] + kb, nxt + PP_T + 2048);
@@ -317,7 +330,6 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 // (row) x 32 B pieces a 32-lane half of a transpose read touches land on eight distinct bank
 // groups.  Reduction rows past the end and column chunks past the operand width are fetched from a
 // zero page.  Split-K over gridDim.z with an atomic epilogue (C pre-zeroed by the host).
-__device__ __attribute__((aligned(512))) const unsigned int pp_zero_page[128] = {0};
 
 struct TNOperand {
     const __bf16 *ptr;     // element (r, c): ptr + b*batch + t*row + c,  (b, t) = divmod(r, rpb)
@@ -625,18 +637,22 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
         return PIKA_NOT_APPLICABLE;
     // A: plain matrix or time-delay view whose taps are whole K-tiles and never leave [0, t_in)
-    if (A->pad || (A->ld & 7) || (A->batch_stride & 7) || (reinterpret_cast<uintptr_t>(A->ptr) & 15)) return PIKA_NOT_APPLICABLE;
+    if ((A->ld & 7) || (A->batch_stride & 7) || (reinterpret_cast<uintptr_t>(A->ptr) & 15)) return PIKA_NOT_APPLICABLE;
     const int a_C = A->C < K ? A->C : K;
     if ((a_C & 63) || K % a_C) return PIKA_NOT_APPLICABLE;
     const int taps = K / a_C;
-    if (taps > 1 && (long long)(A->rows_per_batch - 1) * A->stride + (long long)(taps - 1) * A->dil >= A->t_in)
-        return PIKA_NOT_APPLICABLE;
+    // rows whose source time leaves [0, t_in) (padded convolutions, the transposed convolution of dX) are
+    // redirected to a zero page inside the kernel
+    const bool bounds = A->pad > 0 || (long long)(A->rows_per_batch - 1) * A->stride + (long long)(taps - 1) * A->dil - A->pad >= A->t_in;
     if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < 160) return PIKA_NOT_APPLICABLE;
     PPArgs P{};
     P.A = static_cast<const __bf16 *>(A->ptr); P.B = static_cast<const __bf16 *>(B->ptr);
     P.C = C; P.bias = bias; P.ldb = B->ld; P.ldc = ldc;
     P.a_rpb = A->rows_per_batch; P.a_batch = A->batch_stride; P.a_row = (long long)A->stride * A->ld;
     P.a_tap = (long long)A->dil * A->ld; P.a_C = a_C;
+    P.a_tin = A->t_in; P.a_t0 = A->pad; P.a_tstep = A->stride; P.a_dtap = A->dil; P.a_bounds = bounds ? 1 : 0;
+    // the row pointer of tap 0 starts `pad` source rows before the signal; only ever dereferenced in range
+    P.A -= (long long)A->pad * A->ld;
     P.M = M; P.N = N; P.K = K; P.relu = (flags & PIKA_GEMM_RELU) ? 1 : 0;
     return launch_pp(P, s);
 }

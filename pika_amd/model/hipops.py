@@ -183,7 +183,18 @@ class TimeDelayFn(torch.autograd.Function):
         dx = dw = db = None
         with torch.cuda.device(dy.device):
             dyb = _bf16_operand(dy2)
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and stride == 1 and dyb.dtype == torch.bfloat16 and N % 64 == 0:
+                # transposed convolution as ONE GEMM over a padded time-delay view of dY (taps reversed):
+                # dx[b,ti,c] = sum_{tap',n} dY[b, ti + tap'*dil - pad', n] * W[n, (taps-1-tap')*C + c],
+                # pad' = (taps-1)*dil - pad; rows outside [0,t_out) read as zeros.  No (M, taps*C) column
+                # gradient, no col2im pass.
+                wrev = (w2d.detach().view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, taps * N)
+                        .to(torch.bfloat16))
+                a_op = G.Operand(dyb.data_ptr(), G.PIKA_BF16, T, t_out, t_out * N, N, N, 1, dil,
+                                 (taps - 1) * dil - pad, 0, 0)
+                dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+                G.launch(a_op, G.matrix(wrev)[0], dx.view(-1, C), C, Bn * T, C, taps * N)
+            elif ctx.needs_input_grad[0]:
                 dcol = _grad_input(dyb, w2d)  # (M, taps*C)
                 dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
                 _lib.check(_lib.lib().pika_col2im(dcol.data_ptr(), dx.data_ptr(), Bn, t_out, T, C,

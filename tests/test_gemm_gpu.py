@@ -242,3 +242,41 @@ def test_ping_pong_weight_gradient(hip_device, Bn, T, C, N, taps, dil, stride, l
     want = dy.double().cpu().t() @ a
     scale = dy.double().cpu().abs().t() @ a.abs()
     assert ((out.double().cpu() - want).abs() / scale).max() < 1e-5   # exact bf16 products, fp32 sums
+
+
+@pytest.mark.parametrize("taps,dil,stride,pad,Bn,T,C,N", [(3, 3, 1, 0, 8, 1100, 256, 256), (3, 1, 1, 0, 9, 1000, 256, 320),
+                                                         (5, 1, 1, 4, 8, 1100, 256, 256), (3, 3, 4, 0, 8, 1100, 256, 256)])
+def test_time_delay_fn_bf16_gradients(hip_device, taps, dil, stride, pad, Bn, T, C, N):
+    """TimeDelayFn in the bf16 mode at sizes that take the direct-to-LDS kernels: forward (time-delay view,
+    bias, ReLU), dX as ONE GEMM over the padded, tap-reversed view of dY (stride 1) and dW through the
+    transposed-operand kernel, vs fp64 conv1d autograd on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import TimeDelayFn
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(taps * 10 + dil)
+        x = torch.randn(Bn, T, C, generator=g).bfloat16().float()
+        w = (torch.randn(N, taps * C, generator=g) * 0.05).bfloat16().float()
+        b = torch.randn(N, generator=g)
+        xr = x.double().requires_grad_(True)
+        wr = w.double().requires_grad_(True)
+        br = b.double().requires_grad_(True)
+        w3 = wr.view(N, taps, C).permute(0, 2, 1)                       # (N, C, taps)
+        xin = F.pad(xr.transpose(1, 2), (pad, 0)) if pad else xr.transpose(1, 2)
+        yr = F.conv1d(xin, w3, br, stride=stride, dilation=dil).transpose(1, 2)
+        if pad:
+            yr = yr[:, :T]
+        gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+        (yr * gy.double()).sum().backward()
+        xd = x.to(hip_device).requires_grad_(True)
+        wd = w.to(hip_device).requires_grad_(True)
+        bd = b.to(hip_device).requires_grad_(True)
+        y = TimeDelayFn.apply(xd, wd, bd, taps, dil, stride, pad, 0)
+        assert y.shape == yr.shape
+        assert (y.double().cpu() - yr.detach()).abs().max() < 1e-4 * yr.detach().abs().max()
+        (y * gy.to(hip_device)).sum().backward()
+        for got, want in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+            assert (got.double().cpu() - want).abs().max() < 1e-4 * want.abs().max()
+    finally:
+        G.PRECISION = old

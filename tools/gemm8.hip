@@ -19,8 +19,24 @@ constexpr int T_BYTES = 256 * 128, BUF = 2 * T_BYTES;
 typedef __attribute__((address_space(3))) unsigned int lds_u32;
 typedef const __attribute__((address_space(1))) unsigned int glb_u32;
 
+#ifndef VARIANT
+#define VARIANT 0
+#endif
 #define BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+#if VARIANT == 0
+#define BAR_L() BAR()
+#define BAR_M() BAR()
+#elif VARIANT == 1      // no barrier after the MFMA cluster
+#define BAR_L() BAR()
+#define BAR_M() __builtin_amdgcn_sched_barrier(0)
+#elif VARIANT == 2      // no barrier after the load segment
+#define BAR_L() __builtin_amdgcn_sched_barrier(0)
+#define BAR_M() BAR()
+#else                   // hazards only: one barrier per K-tile
+#define BAR_L() __builtin_amdgcn_sched_barrier(0)
+#define BAR_M() __builtin_amdgcn_sched_barrier(0)
+#endif
 __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
 __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, const __bf16 *__restrict__ B,
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, c
             gl(pa[1] + kadv, nxt + 1024);
             gl(pa[2] + kadv, nxt + 2048);
         }
-        BAR();
+        BAR_L();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, c
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        BAR();
+        BAR_M();
         // ---- phase 1: (m-half 0, n-half 1)
 #pragma unroll
         for (int j = 2; j < 4; ++j) {
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, c
             gl(pb[2] + kadv, nxt + T_BYTES + 2048);
             gl(pb[3] + kadv, nxt + T_BYTES + 3072);
         }
-        BAR();
+        BAR_L();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -129,14 +145,14 @@ __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, c
                 for (int j = 2; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        BAR();
+        BAR_M();
         // ---- phase 2: (m-half 1, n-half 1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = ldsv(cur + aoff + (4 + i) * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + (4 + i) * 2048 + sw1);
         }
-        BAR();
+        BAR_L();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, c
                 for (int j = 2; j < 4; ++j)
                     acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        BAR();
+        BAR_M();
         // ---- phase 3: (m-half 1, n-half 0); the prefetched tile must have landed before the
         // barrier that lets the other group start reading it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void gemm8(const __bf16 *__restrict__ A, c
                 for (int j = 0; j < 2; ++j)
                     acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        BAR();
+        BAR_M();
     }
     if (wr == 0) BAR();
 
