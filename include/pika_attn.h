@@ -8,8 +8,10 @@
  *     drop_attn = dropout(attn); context = drop_attn @ value
  * whose (B,H,T,T) score/probability tensors (2 GB per layer at config 2) are never written here.
  *
- * Tensors: q, k, v, out, dout, dq, dk, dv are f32 (B,T,H*D) with row pitch `ld` floats (head h owns
- * columns [h*D, (h+1)*D)); D is 64 or 128; ld % 4 == 0 and 16-byte aligned bases.
+ * Tensors: q, k, v, dq, dk, dv are f32 (B,T,H*D) with row pitch `ld` floats (so they may be the three
+ * column blocks of one packed (B,T,3*H*D) projection), out and dout with row pitch `ldo`; head h owns
+ * columns [h*D, (h+1)*D); batches are T rows apart; D is 64 or 128; pitches % 4 == 0 and 16-byte
+ * aligned bases.
  * lse (B*H*T,) f32 = log2-domain log-sum-exp of the scaled scores, written by the forward and read
  * by the backward.  Arithmetic: operands rounded to bf16 for the MFMAs, fp32 softmax/accumulation.
  *
@@ -26,14 +28,14 @@ extern "C" {
 #endif
 
 int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
-                       int B, int T, int H, int D, long long ld, float p_drop, unsigned seed,
-                       void *stream);
+                       int B, int T, int H, int D, long long ld, long long ldo, float p_drop,
+                       unsigned seed, void *stream);
 
 /* delta (B*H*T,) f32 is scratch (sum_d out*dout per query row). */
 int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
                        const float *dout, const float *lse, float *delta, float *dq, float *dk,
-                       float *dv, int B, int T, int H, int D, long long ld, float p_drop,
-                       unsigned seed, void *stream);
+                       float *dv, int B, int T, int H, int D, long long ld, long long ldo,
+                       float p_drop, unsigned seed, void *stream);
 
 /* mask (B*H, T, T) u8: 1 where the probability of (query row, key column) is kept. */
 int pika_attention_keep_mask(unsigned char *mask, int BH, int T, float p_drop, unsigned seed,

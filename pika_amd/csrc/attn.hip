@@ -97,7 +97,7 @@ struct Args {
     const float *q, *k, *v, *out, *dout, *lse, *delta;
     float *o, *lse_w, *dq, *dk, *dv;
     int T, H;
-    long long ld;
+    long long ld, ldo;  // row pitch of q/k/v/dq/dk/dv and of out/dout
     float qscale;     // log2(e) / sqrt(D)
     float inv_keep;   // 1 / (1 - p)
     uint32_t seed, thr;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
     l += __shfl_xor(l, 32);
     if (qrow < T) {
         const float sc = A.inv_keep / l;
-        float *o = A.o + boff + (long long)qrow * A.ld + g * 4;
+        float *o = A.o + (long long)b * T * A.ldo + (long long)h * D + (long long)qrow * A.ldo + g * 4;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(o + dt * 16) = oacc[dt] * sc;
         if (g == 0) A.lse_w[(long long)bh * T + qrow] = m + __log2f(l);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(THREADS) void attn_delta_kernel(Args A, float *delt
     const long long row = blockIdx.x;  // b*T + q
     const int b = (int)(row / T), qi = (int)(row - (long long)b * T);
     for (int c = threadIdx.x * 4; c < HD; c += THREADS * 4) {
-        const f32x4 o = *reinterpret_cast<const f32x4 *>(A.out + row * A.ld + c);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dout + row * A.ld + c);
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(A.out + row * A.ldo + c);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dout + row * A.ldo + c);
         float s = o.x * d.x + o.y * d.y + o.z * d.z + o.w * d.w;
 #pragma unroll
         for (int w = 1; w < D / 4; w <<= 1) s += __shfl_xor(s, w);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     const uint32_t bh = (uint32_t)(b * A.H + h);
     bf16x8 qf[KS], dof[KS];
     row_frags<D>(qf, A.q + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
-    row_frags<D>(dof, A.dout + boff + (long long)min(qrow, T - 1) * A.ld, g, 1.f);
+    row_frags<D>(dof, A.dout + (long long)b * T * A.ldo + (long long)h * D + (long long)min(qrow, T - 1) * A.ldo, g, 1.f);
     const float lse = qrow < T ? A.lse[(long long)bh * T + qrow] : INFINITY;
     const float delta = qrow < T ? A.delta[(long long)bh * T + qrow] : 0.f;
     const uint32_t rowh = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qrow);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     for (int qb = 0; qb < T; qb += TILE) {
         __syncthreads();
         load_tile<D>(Qs, A.q + boff + (long long)qb * A.ld, A.ld, T - qb, A.qscale);
-        load_tile<D>(Os, A.dout + boff + (long long)qb * A.ld, A.ld, T - qb, 1.f);
+        load_tile<D>(Os, A.dout + (long long)b * T * A.ldo + (long long)h * D + (long long)qb * A.ldo, A.ldo, T - qb, 1.f);
         if (threadIdx.x < TILE) {
             const int qi = qb + threadIdx.x;
             lse_s[threadIdx.x] = qi < T ? A.lse[(long long)bh * T + qi] : INFINITY;
@@ -349,12 +349,12 @@ inline void dropout_consts(Args &A, float p, unsigned seed) {
 extern "C" {
 
 int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
-                       int B, int T, int H, int D, long long ld, float p_drop, unsigned seed,
-                       void *stream) {
-    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !lse) return PIKA_EINVAL;
+                       int B, int T, int H, int D, long long ld, long long ldo, float p_drop,
+                       unsigned seed, void *stream) {
+    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !lse || ldo < (long long)H * D || (ldo & 3)) return PIKA_EINVAL;
     if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
     Args A{};
-    A.q = q; A.k = k; A.v = v; A.o = out; A.lse_w = lse; A.T = T; A.H = H; A.ld = ld;
+    A.q = q; A.k = k; A.v = v; A.o = out; A.lse_w = lse; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
     A.qscale = 1.4426950408889634f / sqrtf((float)D);
     dropout_consts(A, p_drop, seed);
     const dim3 grid((T + TILE - 1) / TILE, H, B);
@@ -366,15 +366,15 @@ int pika_attention_fwd(const float *q, const float *k, const float *v, float *ou
 
 int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
                        const float *dout, const float *lse, float *delta, float *dq, float *dk,
-                       float *dv, int B, int T, int H, int D, long long ld, float p_drop,
-                       unsigned seed, void *stream) {
+                       float *dv, int B, int T, int H, int D, long long ld, long long ldo,
+                       float p_drop, unsigned seed, void *stream) {
     if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !args_ok(dout, dq, dk, dv, B, T, H, D, ld, p_drop) ||
-        !lse || !delta)
+        !lse || !delta || ldo < (long long)H * D || (ldo & 3))
         return PIKA_EINVAL;
     if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
     Args A{};
     A.q = q; A.k = k; A.v = v; A.out = out; A.dout = dout; A.lse = lse; A.delta = delta;
-    A.dq = dq; A.dk = dk; A.dv = dv; A.T = T; A.H = H; A.ld = ld;
+    A.dq = dq; A.dk = dk; A.dv = dv; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
     A.qscale = 1.4426950408889634f / sqrtf((float)D);
     dropout_consts(A, p_drop, seed);
     const dim3 grid((T + TILE - 1) / TILE, H, B);

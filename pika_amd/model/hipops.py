@@ -354,6 +354,22 @@ def attention_keep_mask(BH, T, p_drop, seed, device):
     return m.bool()
 
 
+def _attn_fwd(q, k, v, out, lse, B, T, heads, D, ld, p_drop, seed):
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                                 lse.data_ptr(), B, T, heads, D, ld, heads * D, float(p_drop),
+                                                 int(seed), _stream()), "pika_attention_fwd")
+
+
+def _attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, T, heads, D, ld, p_drop, seed):
+    delta = torch.empty_like(lse)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().pika_attention_bwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+            delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, D, ld, heads * D,
+            p_drop, seed, _stream()), "pika_attention_bwd")
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(D)) [dropout] v per head on (B,T,H*D) projections
     (multi_headed_attn.py:199-231) without materialising the (B,H,T,T) tensors: include/pika_attn.h."""
@@ -362,13 +378,9 @@ class AttentionFn(torch.autograd.Function):
     def forward(ctx, q, k, v, heads, p_drop, seed):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, T, HD = q.shape
-        D = HD // heads
         out = torch.empty_like(q)
         lse = torch.empty(B * heads * T, dtype=torch.float32, device=q.device)
-        with torch.cuda.device(q.device):
-            _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                                                     lse.data_ptr(), B, T, heads, D, HD, float(p_drop),
-                                                     int(seed), _stream()), "pika_attention_fwd")
+        _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD, p_drop, seed)
         ctx.cfg = (heads, float(p_drop), int(seed))
         ctx.save_for_backward(q, k, v, out, lse)
         return out
@@ -378,15 +390,39 @@ class AttentionFn(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         heads, p_drop, seed = ctx.cfg
         B, T, HD = q.shape
-        dout = dout.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        delta = torch.empty_like(lse)
-        with torch.cuda.device(q.device):
-            _lib.check(_lib.lib().pika_attention_bwd(
-                q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, HD // heads, HD,
-                p_drop, seed, _stream()), "pika_attention_bwd")
+        _attn_bwd(q, k, v, out, dout.contiguous(), lse, dq, dk, dv, B, T, heads, HD // heads, HD, p_drop, seed)
         return dq, dk, dv, None, None, None
+
+
+class PackedAttentionFn(torch.autograd.Function):
+    """The same on ONE packed projection qkv (B,T,3*H*D) = [q | k | v] (self-attention: the three
+    projections share their input, so they are one GEMM); the gradient comes back packed as well."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p_drop, seed):
+        qkv = qkv.contiguous()
+        B, T, HD3 = qkv.shape
+        HD = HD3 // 3
+        q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+        out = torch.empty((B, T, HD), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
+        _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD3, p_drop, seed)
+        ctx.cfg = (heads, float(p_drop), int(seed))
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        heads, p_drop, seed = ctx.cfg
+        B, T, HD3 = qkv.shape
+        HD = HD3 // 3
+        dqkv = torch.empty_like(qkv)
+        _attn_bwd(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], out, dout.contiguous(), lse,
+                  dqkv[..., :HD], dqkv[..., HD:2 * HD], dqkv[..., 2 * HD:], B, T, heads, HD // heads, HD3,
+                  p_drop, seed)
+        return dqkv, None, None, None
 
 
 class BatchNormFn(torch.autograd.Function):

@@ -47,6 +47,12 @@ class MultiHeadedAttention(nn.Module):
     def forward(self, key, value, query, mask=None, layer_cache=None, type=None):
         if layer_cache is not None:
             raise NotImplementedError("layer_cache is off the RNN-T hot path (SURVEY 8a row 7)")
+        if key is value and value is query and ops.self_attention_packed_ok(query, self.head_count, mask):
+            ctx = ops.self_attention_packed(query, self.linear_query.weight, self.linear_query.bias,
+                                            self.linear_keys.weight, self.linear_keys.bias,
+                                            self.linear_values.weight, self.linear_values.bias,
+                                            self.head_count, self.dropout.p, self.training)
+            return ops.linear(ctx, self.final_linear.weight, self.final_linear.bias), None
         k = ops.linear(key, self.linear_keys.weight, self.linear_keys.bias)
         v = ops.linear(value, self.linear_values.weight, self.linear_values.bias)
         q = ops.linear(query, self.linear_query.weight, self.linear_query.bias)

@@ -134,6 +134,26 @@ def attention(q, k, v, heads, mask, p_drop, training):
     return ctx.transpose(1, 2).contiguous().view(B, Tq, HD)
 
 
+def self_attention_packed_ok(x, heads, mask):
+    if not _hip(x):
+        return False
+    from .hipops import attention_ok
+    return attention_ok(x, x, x, heads, mask)
+
+
+def self_attention_packed(x, wq, bq, wk, bk, wv, bv, heads, p_drop, training):
+    """Self-attention context from the layer input: q, k, v projections as ONE GEMM (weights concatenated
+    per call; autograd splits the weight gradient back), then the fused attention core on the packed
+    result.  Same arithmetic as three separate nn.Linear calls."""
+    from .hipops import PackedAttentionFn
+    w = torch.cat([wq, wk, wv], 0)
+    b = torch.cat([bq, bk, bv], 0)
+    qkv = linear(x, w, b)
+    drop = p_drop if training else 0.0
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop > 0 else 0
+    return PackedAttentionFn.apply(qkv, heads, drop, seed)
+
+
 def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
     """Gated joint network over the full (T,U) lattice.
 

@@ -95,3 +95,21 @@ def test_attention_argument_errors(hip_device):
     y = torch.randn(1, 8, 128, device=hip_device)
     with pytest.raises(RuntimeError):
         AttentionFn.apply(y, y, y, 2, 1.0, 0)      # p_drop out of range
+
+
+def test_packed_attention_matches_separate(hip_device):
+    """PackedAttentionFn on [q | k | v] (pitch 3*H*D) is bit-identical to AttentionFn on the three blocks,
+    forward and backward, dropout included."""
+    from pika_amd.model.hipops import AttentionFn, PackedAttentionFn
+    g = torch.Generator().manual_seed(11)
+    B, T, H, D = 2, 150, 4, 64
+    qkv = torch.randn(B, T, 3 * H * D, generator=g).to(hip_device)
+    w = torch.randn(B, T, H * D, generator=g).to(hip_device)
+    a = qkv.clone().requires_grad_(True)
+    out_p = PackedAttentionFn.apply(a, H, 0.2, 99)
+    (out_p * w).sum().backward()
+    parts = [qkv[..., i * H * D:(i + 1) * H * D].clone().requires_grad_(True) for i in range(3)]
+    out_s = AttentionFn.apply(*parts, H, 0.2, 99)
+    (out_s * w).sum().backward()
+    assert torch.equal(out_p, out_s)
+    assert torch.equal(a.grad, torch.cat([p.grad for p in parts], -1))
