@@ -72,6 +72,24 @@ int pika_gemm_nt_ws(const pika_operand_t *A, const pika_operand_t *B, float *C, 
 int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, long long ldb, float *C,
                       long long ldc, int M, int N, int K, const float *bias, void *stream);
 
+/* The same product with a fused bf16 epilogue, for chains whose wide intermediate only ever feeds
+ * another MFMA product (the transformer feed-forward block, reference trainer/model/position_ffn.py:27-39:
+ * w_2(dropout(relu(w_1(x)))) -- the (rows, d_ff) hidden exists only in bf16, ReLU/dropout never run as passes):
+ *   PIKA_EPI_DROPOUT_BF16: out bf16 (pitch ldo) = dropout_p(relu?(A B^T + bias)); the keep decision of element
+ *       (m, n) is a counter-based hash of (seed, m, n), kept values are scaled by 1/(1-p),
+ *       p = round(p_drop * 65536) / 65536; pika_dropout_keep_mask materialises the mask (tests);
+ *   PIKA_EPI_MASK_BF16:    out bf16 = scale * (A B^T) where aux[m,n] > 0 (bf16, pitch ld_aux), else 0 --
+ *       with aux = the forward's dropped hidden this is the ReLU and dropout backward in one.
+ * Requirements as pika_gemm_bf16_nt; ldo, ld_aux % 4 == 0. */
+#define PIKA_EPI_DROPOUT_BF16 1
+#define PIKA_EPI_MASK_BF16 2
+int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long long ldb, void *out,
+                            long long ldo, int M, int N, int K, const float *bias, int mode, int relu,
+                            float p_drop, unsigned seed, const void *aux, long long ld_aux, float scale,
+                            void *stream);
+int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, float p_drop, unsigned seed,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@
 // joint shapes) for narrow outputs, and gemm_pp (256x256 tile, two wave groups in ping-pong:
 // 800-1250 TFLOP/s on random data, tools/gemm8.hip) for everything else.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -143,10 +144,32 @@ struct PPArgs {
     int a_tin, a_t0, a_tstep, a_dtap;  // source time of (row t, tap) = t * a_tstep + tap * a_dtap - a_t0, zero outside [0, a_tin)
     int a_bounds;                      // 0: every (row, tap) is in range (no checks in the loop)
     int M, N, K, relu;
+    // fused epilogues (EPI 1, 2): bf16 output, dropout / auxiliary mask
+    __bf16 *out16;
+    const __bf16 *aux;
+    long long ldo16, ld_aux;
+    float scale;                       // EPI 1: 1/(1-p) for kept values; EPI 2: factor for unmasked values
+    unsigned seed, thr;                // EPI 1: drop where hash16 < thr (thr = 0: no dropout)
 };
+
+// counter-based dropout decisions for the four consecutive columns n..n+3 (n % 4 == 0) of row m
+__device__ inline unsigned pp_mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ inline void pp_keep4(unsigned seed, unsigned m, unsigned n, unsigned thr, bool keep[4]) {
+    const unsigned h = pp_mix32(pp_mix32(seed + m * 0x9E3779B9u) ^ ((n >> 2) * 0x85ebca6bu));
+    unsigned h2 = (h ^ (h >> 15)) * 0x2c1b3c6du;
+    h2 ^= h2 >> 12;
+    keep[0] = (h & 0xffffu) >= thr; keep[1] = (h >> 16) >= thr;
+    keep[2] = (h2 & 0xffffu) >= thr; keep[3] = (h2 >> 16) >= thr;
+}
 
 __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
+// EPI 0: C f32 = act(A B^T + bias).   EPI 1: out16 bf16 = dropout(act(A B^T + bias)).
+// EPI 2: out16 bf16 = scale * (A B^T) where aux > 0, else 0  (ReLU + dropout backward in one mask).
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int M = P.M, N = P.N;
@@ -305,17 +328,47 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            if (n + 3 < N) {
-                f32x4 v = acc[i][j];
-                if (bias) v += *reinterpret_cast<const f32x4 *>(bias + n);
+            if (n >= N) continue;
+            f32x4 v = acc[i][j];
+            if constexpr (EPI != 2) {
+                if (bias) {
+                    if (n + 3 < N) v += *reinterpret_cast<const f32x4 *>(bias + n);
+                    else for (int e = 0; e < 4; ++e) if (n + e < N) v[e] += bias[n + e];
+                }
                 if (P.relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-                *reinterpret_cast<f32x4 *>(C + (long long)m * P.ldc + n) = v;
+            }
+            if constexpr (EPI == 0) {
+                if (n + 3 < N) {
+                    *reinterpret_cast<f32x4 *>(C + (long long)m * P.ldc + n) = v;
+                } else {
+                    for (int e = 0; e < 4; ++e) if (n + e < N) C[(long long)m * P.ldc + n + e] = v[e];
+                }
             } else {
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < N) {
-                        float v = acc[i][j][e] + (bias ? bias[n + e] : 0.f);
-                        C[(long long)m * P.ldc + n + e] = P.relu ? fmaxf(v, 0.f) : v;
+                if constexpr (EPI == 1) {
+                    if (P.thr) {
+                        bool keep[4];
+                        pp_keep4(P.seed, (unsigned)m, (unsigned)n, P.thr, keep);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * P.scale : 0.f;
                     }
+                } else {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    const __bf16 *ap = P.aux + (long long)m * P.ld_aux + n;
+                    if (n + 3 < N) {
+                        const bf16x4 a4 = *reinterpret_cast<const bf16x4 *>(ap);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)a4[e] > 0.f ? v[e] * P.scale : 0.f;
+                    } else {
+                        for (int e = 0; e < 4; ++e) if (n + e < N) v[e] = (float)ap[e] > 0.f ? v[e] * P.scale : 0.f;
+                    }
+                }
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                __bf16 *op = P.out16 + (long long)m * P.ldo16 + n;
+                if (n + 3 < N) {
+                    *reinterpret_cast<bf16x4 *>(op) = __builtin_convertvector(v, bf16x4);
+                } else {
+                    for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = (__bf16)v[e];
+                }
             }
         }
     }
@@ -549,17 +602,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     *reinterpret_cast<f32x4 *>(C + (long long)m * ldc + n) = acc;
 }
 
-int launch_pp(const PPArgs &P, hipStream_t s) {
+template <int EPI>
+int launch_pp_epi(const PPArgs &P, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     if ((P.M + 255) / 256 > 65535) return PIKA_ETOOBIG;
-    hipLaunchKernelGGL(gemm_pp, dim3((P.N + 255) / 256, (P.M + 255) / 256), dim3(512), 2 * PP_BUF, s, P);
+    hipLaunchKernelGGL(gemm_pp<EPI>, dim3((P.N + 255) / 256, (P.M + 255) / 256), dim3(512), 2 * PP_BUF, s, P);
     return (int)hipGetLastError();
+}
+
+int launch_pp(const PPArgs &P, hipStream_t s) { return launch_pp_epi<0>(P, s); }
+
+__global__ __launch_bounds__(256) void pp_keep_mask_kernel(unsigned char *mask, int rows, int cols, unsigned seed,
+                                                           unsigned thr) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, c4 = (cols + 3) >> 2;
+    if (idx >= (long long)rows * c4) return;
+    const int m = (int)(idx / c4), n = (int)(idx - (long long)m * c4) * 4;
+    bool keep[4];
+    pp_keep4(seed, (unsigned)m, (unsigned)n, thr, keep);
+    for (int e = 0; e < 4; ++e)
+        if (n + e < cols) mask[(long long)m * cols + n + e] = (!thr || keep[e]) ? 1 : 0;
 }
 
 bool tn_operand(const pika_operand_t &o, int extent, TNOperand &t) {
@@ -681,5 +748,42 @@ extern "C" int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, lo
     }
     hipLaunchKernelGGL(gemm_glds, dim3((N + BN - 1) / BN, (M + BM - 1) / BM), dim3(THREADS), 2 * BUF, s,
                        static_cast<const __bf16 *>(A), static_cast<const __bf16 *>(B), C, M, N, K, lda, ldb, ldc, bias);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long long ldb, void *out,
+                                       long long ldo, int M, int N, int K, const float *bias, int mode,
+                                       int relu, float p_drop, unsigned seed, const void *aux,
+                                       long long ld_aux, float scale, void *stream) {
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0) return PIKA_EINVAL;
+    if ((K % BK) || (lda & 7) || (ldb & 7) || (ldo & 3) ||
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
+        return PIKA_EINVAL;
+    if (mode != PIKA_EPI_DROPOUT_BF16 && mode != PIKA_EPI_MASK_BF16) return PIKA_EINVAL;
+    if (mode == PIKA_EPI_MASK_BF16 && (!aux || (ld_aux & 3) || (reinterpret_cast<uintptr_t>(aux) & 7))) return PIKA_EINVAL;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return PIKA_EINVAL;
+    PPArgs P{};
+    P.A = static_cast<const __bf16 *>(A); P.B = static_cast<const __bf16 *>(B); P.bias = bias;
+    P.ldb = ldb; P.a_rpb = M; P.a_batch = 0; P.a_row = lda; P.a_tap = 0; P.a_C = K;
+    P.M = M; P.N = N; P.K = K; P.relu = relu ? 1 : 0;
+    P.out16 = static_cast<__bf16 *>(out); P.ldo16 = ldo;
+    P.aux = static_cast<const __bf16 *>(aux); P.ld_aux = ld_aux;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode == PIKA_EPI_DROPOUT_BF16) {
+        P.thr = (unsigned)lrintf(p_drop * 65536.f);
+        P.scale = 65536.f / (float)(65536u - P.thr);
+        P.seed = seed;
+        return launch_pp_epi<1>(P, s);
+    }
+    P.scale = scale;
+    return launch_pp_epi<2>(P, s);
+}
+
+extern "C" int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, float p_drop, unsigned seed,
+                                      void *stream) {
+    if (!mask || rows <= 0 || cols <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) return PIKA_EINVAL;
+    const long long n4 = (long long)rows * ((cols + 3) >> 2);
+    hipLaunchKernelGGL(pp_keep_mask_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), mask, rows, cols, seed, (unsigned)lrintf(p_drop * 65536.f));
     return (int)hipGetLastError();
 }

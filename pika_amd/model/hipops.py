@@ -425,6 +425,84 @@ class PackedAttentionFn(torch.autograd.Function):
         return dqkv, None, None, None
 
 
+EPI_DROPOUT_BF16, EPI_MASK_BF16 = 1, 2
+
+
+def _gemm_epilogue(a, b, out, bias, mode, relu=0, p_drop=0.0, seed=0, aux=None, scale=1.0):
+    M, K = a.shape
+    N = b.shape[0]
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().pika_gemm_bf16_epilogue(
+            a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+            None if bias is None else bias.data_ptr(), mode, relu, float(p_drop), int(seed),
+            None if aux is None else aux.data_ptr(), 0 if aux is None else aux.stride(0), float(scale),
+            _stream()), "pika_gemm_bf16_epilogue(M=%d,N=%d,K=%d)" % (M, N, K))
+    return out
+
+
+def dropout_keep_mask(rows, cols, p_drop, seed, device):
+    """(rows, cols) bool keep-mask of the PIKA_EPI_DROPOUT_BF16 epilogue -- for tests."""
+    m = torch.empty((rows, cols), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().pika_dropout_keep_mask(m.data_ptr(), rows, cols, float(p_drop), int(seed), _stream()),
+                   "pika_dropout_keep_mask")
+    return m.bool()
+
+
+def feed_forward_ok(x, w1, w2):
+    d, f = w1.shape[1], w1.shape[0]
+    return (G.PRECISION == "bf16" and x.is_cuda and x.dtype == torch.float32 and d % 64 == 0 and f % 64 == 0
+            and w2.shape[0] % 64 == 0 and x.numel() // d >= 256)
+
+
+class FeedForwardFn(torch.autograd.Function):
+    """w_2(dropout(relu(w_1(x))))  (position_ffn.py:27-39 without the LayerNorm and the residual).
+
+    The (rows, d_ff) hidden exists only as ONE bf16 matrix: the first GEMM's epilogue applies bias, ReLU and
+    dropout (counter-based mask) and rounds to bf16, which is what the second GEMM would read anyway; in the
+    backward `hidden > 0` is both the ReLU and the dropout mask, applied by the epilogue of dh = dy W2."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p_drop, seed):
+        d = x.shape[-1]
+        xb = x.reshape(-1, d).to(torch.bfloat16)
+        M, F, N2 = xb.shape[0], w1.shape[0], w2.shape[0]
+        h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
+        _gemm_epilogue(xb, w1.detach().to(torch.bfloat16), h, b1, EPI_DROPOUT_BF16, relu=1, p_drop=p_drop, seed=seed)
+        y = torch.empty(x.shape[:-1] + (N2,), dtype=torch.float32, device=x.device)
+        G.gemm_bf16_nt(h, w2.detach().to(torch.bfloat16), bias=b2, out=y.view(-1, N2))
+        ctx.cfg = (float(p_drop), x.shape)
+        ctx.save_for_backward(xb, h, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, h, w1, w2 = ctx.saved_tensors
+        p_drop, xshape = ctx.cfg
+        M, F, N2, d = xb.shape[0], w1.shape[0], w2.shape[0], xb.shape[1]
+        dy2 = dy.reshape(-1, N2).contiguous()
+        dyb = dy2.to(torch.bfloat16)
+        thr = round(p_drop * 65536)
+        dh = torch.empty((M, F), dtype=torch.bfloat16, device=dy.device)
+        _gemm_epilogue(dyb, w2.detach().t().contiguous().to(torch.bfloat16), dh, None, EPI_MASK_BF16, aux=h,
+                       scale=65536.0 / (65536 - thr))
+        dx = dw1 = db1 = dw2 = db2 = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[3]:
+                dw2 = _grad_weight(dyb, G.matrix(h)[0], 8, M, F, N2)
+            if ctx.needs_input_grad[4]:
+                db2 = colsum(dy2)
+            if ctx.needs_input_grad[1]:
+                dw1 = _grad_weight(dh, G.matrix(xb)[0], 8, M, d, F)
+            if ctx.needs_input_grad[2]:
+                db1 = torch.empty(F, dtype=torch.float32, device=dy.device)
+                _lib.check(_lib.lib().pika_colsum_bf16(dh.data_ptr(), F, M, F, db1.data_ptr(), _stream()),
+                           "pika_colsum_bf16")
+            if ctx.needs_input_grad[0]:
+                dx = G.gemm_bf16_nt(dh, w1.detach().t().contiguous().to(torch.bfloat16)).view(xshape)
+        return dx, dw1, db1, dw2, db2, None, None
+
+
 class BatchNormFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over the rows of a (M,C) matrix (include/pika_norm.h); running
     statistics updated in place exactly as nn.BatchNorm1d does (momentum, unbiased variance)."""

@@ -134,6 +134,18 @@ def attention(q, k, v, heads, mask, p_drop, training):
     return ctx.transpose(1, 2).contiguous().view(B, Tq, HD)
 
 
+def feed_forward(xn, w_1, w_2, p_drop):
+    """w_2(dropout(relu(w_1(xn)))) through the fused bf16-hidden path, or None when it does not apply
+    (CPU, parity mode, odd widths): the caller then runs the plain chain."""
+    if not _hip(xn):
+        return None
+    from .hipops import FeedForwardFn, feed_forward_ok
+    if not feed_forward_ok(xn, w_1.weight, w_2.weight):
+        return None
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
+    return FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, seed)
+
+
 def self_attention_packed_ok(x, heads, mask):
     if not _hip(x):
         return False

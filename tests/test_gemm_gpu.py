@@ -280,3 +280,41 @@ def test_time_delay_fn_bf16_gradients(hip_device, taps, dil, stride, pad, Bn, T,
             assert (got.double().cpu() - want).abs().max() < 1e-4 * want.abs().max()
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("M,d,F,p", [(300, 64, 256, 0.0), (1000, 128, 512, 0.2), (513, 64, 192, 0.5)])
+def test_feed_forward_fn(hip_device, M, d, F, p):
+    """FeedForwardFn (bf16-only hidden, ReLU + dropout in the GEMM epilogues) vs the fp64 chain
+    w_2(dropout(relu(w_1(x)))) with the kernel's own keep-mask, on bf16-representable inputs."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import FeedForwardFn, dropout_keep_mask
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(M + F)
+        x = torch.randn(M, d, generator=g).bfloat16().float()
+        w1 = (torch.randn(F, d, generator=g) * 0.2).bfloat16().float()
+        b1 = torch.randn(F, generator=g) * 0.1
+        w2 = (torch.randn(d, F, generator=g) * 0.1).bfloat16().float()
+        b2 = torch.randn(d, generator=g) * 0.1
+        gy = torch.randn(M, d, generator=g)
+        seed = 4242
+        dev = [t.to(hip_device).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = FeedForwardFn.apply(*dev, p, seed)
+        (y * gy.to(hip_device)).sum().backward()
+        keep = dropout_keep_mask(M, F, p, seed, hip_device).cpu()
+        thr = round(p * 65536)
+        if p > 0:
+            assert abs(keep.float().mean().item() - (1 - p)) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-4
+            assert abs(keep.float().mean(0).std().item() - (p * (1 - p) / M) ** 0.5) < 0.3 * (p * (1 - p) / M) ** 0.5
+        ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        h = torch.relu(ref[0] @ ref[1].t() + ref[2]) * keep.double() * (65536.0 / (65536 - thr))
+        yr = h @ ref[3].t() + ref[4]
+        (yr * gy.double()).sum().backward()
+        # the hidden and dh are rounded to bf16 (2^-9 relative per element, unbiased)
+        assert (y.double().cpu() - yr.detach()).abs().max() < 1e-2 * yr.detach().abs().max()
+        for a, b in zip(dev, ref):
+            s = b.grad.abs().max().item()
+            assert (a.grad.double().cpu() - b.grad).abs().max() < 1.5e-2 * s, (a.shape, s)
+            assert (a.grad.double().cpu() - b.grad).norm() < 6e-3 * b.grad.norm()
+    finally:
+        G.PRECISION = old
