@@ -20,10 +20,10 @@ extern "C" {
 int pika_joint_gate_fwd(const float *e1, const float *p1, const float *eg, const float *pg,
                         void *h, int out_dtype, int B, int T, int U, int H, void *stream);
 
-/* Backward of the gate given dh (B,T,U,H) f32: de1/deg (B,T,H) = sum over u, dp1/dpg (B,U,H) =
+/* Backward of the gate given dh (B,T,U,H), dh_dtype PIKA_F32 | PIKA_BF16: de1/deg (B,T,H) = sum over u, dp1/dpg (B,U,H) =
  * sum over t of  dz1 = dh*sig(zg)*(1-tanh(z1)^2),  dzg = dh*tanh(z1)*sig(zg)*(1-sig(zg)).
  * tanh/sigmoid are recomputed from e*,p* (nothing of size B*T*U*H is kept from the forward). */
-int pika_joint_gate_bwd(const float *dh, const float *e1, const float *p1, const float *eg,
+int pika_joint_gate_bwd(const void *dh, int dh_dtype, const float *e1, const float *p1, const float *eg,
                         const float *pg, float *de1, float *dp1, float *deg, float *dpg,
                         int B, int T, int U, int H, void *stream);
 

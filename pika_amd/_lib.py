@@ -46,7 +46,7 @@ SIGNATURES = {
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     # include/pika_joint.h
     "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "pika_joint_gate_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _vp]),
+    "pika_joint_gate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i, _i, _i, _i, _vp]),
     "pika_log_softmax_rows": (_i, [_vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_log_softmax_bwd_rows": (_i, [_vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_log_softmax_bwd_rows_bf16": (_i, [_vp, _vp, _vp, _ll, _i, _ll, _ll, ctypes.c_float, _vp]),

@@ -58,8 +58,18 @@ __device__ inline void gate_grads(float z1, float zg, float dh, float &d1, float
 }
 
 // REDUCE_U: grid (T,B): sums over u -> de1/deg[b,t,:].  else grid (U,B): sums over t -> dp1/dpg.
-template <bool REDUCE_U>
-__global__ void gate_bwd_kernel(const float *__restrict__ dh, const float *__restrict__ e1,
+template <typename TD>
+__device__ inline f32x4 load_dh4(const TD *p) {
+    if constexpr (sizeof(TD) == 4) {
+        return *reinterpret_cast<const f32x4 *>(p);
+    } else {
+        const bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
+template <bool REDUCE_U, typename TD>
+__global__ void gate_bwd_kernel(const TD *__restrict__ dh, const float *__restrict__ e1,
                                 const float *__restrict__ p1, const float *__restrict__ eg,
                                 const float *__restrict__ pg, float *__restrict__ o1,
                                 float *__restrict__ og, int T, int U, int H) {
@@ -74,7 +84,7 @@ __global__ void gate_bwd_kernel(const float *__restrict__ dh, const float *__res
                              reinterpret_cast<const f32x4 *>(p1 + ((size_t)b * U + u) * H)[c];
             const f32x4 zg = reinterpret_cast<const f32x4 *>(eg + ((size_t)b * T + t) * H)[c] +
                              reinterpret_cast<const f32x4 *>(pg + ((size_t)b * U + u) * H)[c];
-            const f32x4 d = reinterpret_cast<const f32x4 *>(dh + (((size_t)b * T + t) * U + u) * H)[c];
+            const f32x4 d = load_dh4<TD>(dh + (((size_t)b * T + t) * U + u) * H + 4 * c);
             float a, g;
             gate_grads(z1.x, zg.x, d.x, a, g); s1.x += a; sg.x += g;
             gate_grads(z1.y, zg.y, d.y, a, g); s1.y += a; sg.y += g;
@@ -341,7 +351,7 @@ int pika_joint_gate_fwd(const float *e1, const float *p1, const float *eg, const
     return (int)hipGetLastError();
 }
 
-int pika_joint_gate_bwd(const float *dh, const float *e1, const float *p1, const float *eg,
+int pika_joint_gate_bwd(const void *dh, int dh_dtype, const float *e1, const float *p1, const float *eg,
                         const float *pg, float *de1, float *dp1, float *deg, float *dpg, int B, int T,
                         int U, int H, void *stream) {
     if (!dh || !e1 || !p1 || !eg || !pg || !de1 || !dp1 || !deg || !dpg || B <= 0 || T <= 0 ||
@@ -350,10 +360,21 @@ int pika_joint_gate_bwd(const float *dh, const float *e1, const float *p1, const
     if (B > 65535) return PIKA_ETOOBIG;
     const int threads = min(1024, ((H / 4 + 63) / 64) * 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3(T, B), dim3(threads), 0, s, dh, e1, p1, eg, pg,
-                       de1, deg, T, U, H);
-    hipLaunchKernelGGL(gate_bwd_kernel<false>, dim3(U, B), dim3(threads), 0, s, dh, e1, p1, eg, pg,
-                       dp1, dpg, T, U, H);
+    if (dh_dtype == PIKA_F32) {
+        const float *d = static_cast<const float *>(dh);
+        hipLaunchKernelGGL((gate_bwd_kernel<true, float>), dim3(T, B), dim3(threads), 0, s, d, e1, p1, eg, pg,
+                           de1, deg, T, U, H);
+        hipLaunchKernelGGL((gate_bwd_kernel<false, float>), dim3(U, B), dim3(threads), 0, s, d, e1, p1, eg, pg,
+                           dp1, dpg, T, U, H);
+    } else if (dh_dtype == PIKA_BF16) {
+        const __bf16 *d = static_cast<const __bf16 *>(dh);
+        hipLaunchKernelGGL((gate_bwd_kernel<true, __bf16>), dim3(T, B), dim3(threads), 0, s, d, e1, p1, eg, pg,
+                           de1, deg, T, U, H);
+        hipLaunchKernelGGL((gate_bwd_kernel<false, __bf16>), dim3(U, B), dim3(threads), 0, s, d, e1, p1, eg, pg,
+                           dp1, dpg, T, U, H);
+    } else {
+        return PIKA_EINVAL;
+    }
     return (int)hipGetLastError();
 }
 

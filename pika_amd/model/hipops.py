@@ -234,12 +234,14 @@ class GateFn(torch.autograd.Function):
         e1, p1, eg, pg = ctx.saved_tensors
         Bn, T, H = e1.shape
         U = p1.shape[1]
-        dh = dh.float().contiguous()
+        if dh.dtype not in (torch.float32, torch.bfloat16):
+            dh = dh.float()
+        dh = dh.contiguous()
         de1, deg = torch.empty_like(e1), torch.empty_like(eg)
         dp1, dpg = torch.empty_like(p1), torch.empty_like(pg)
         with torch.cuda.device(dh.device):
             _lib.check(_lib.lib().pika_joint_gate_bwd(
-                dh.data_ptr(), e1.data_ptr(), p1.data_ptr(), eg.data_ptr(), pg.data_ptr(),
+                dh.data_ptr(), G.PIKA_F32 if dh.dtype == torch.float32 else G.PIKA_BF16, e1.data_ptr(), p1.data_ptr(), eg.data_ptr(), pg.data_ptr(),
                 de1.data_ptr(), dp1.data_ptr(), deg.data_ptr(), dpg.data_ptr(), Bn, T, U, H,
                 _stream()), "pika_joint_gate_bwd")
         return de1, dp1, deg, dpg
@@ -327,7 +329,9 @@ class JointOutFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 wt = torch.zeros((K, Np), dtype=torch.bfloat16, device=dl.device)
                 wt[:, :N] = weight.detach().t()
-                dh = G.gemm_bf16_nt(dl, wt).view(*lp.shape[:-1], K)
+                # bf16 like h itself: autograd would round an fp32 dh to h's dtype anyway (two extra passes)
+                dh = torch.empty(lp.shape[:-1] + (K,), dtype=torch.bfloat16, device=dl.device)
+                _gemm_epilogue(dl, wt, dh.view(-1, K), None, EPI_DROPOUT_BF16)
             if ctx.needs_input_grad[1]:
                 dw = _grad_weight(dl[:, :N], G.matrix(h2)[0], 8, M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:

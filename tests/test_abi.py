@@ -31,9 +31,26 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(handle, name), "libpika_amd.so does not export %s" % name
 
 
+def declared_prototypes():
+    """name -> list of parameter declarations, parsed from include/*.h."""
+    protos = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for name, args in re.findall(r"\b(pika_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+            args = " ".join(args.split())
+            protos[name] = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+    return protos
+
+
 def test_ctypes_table_matches_headers():
     from pika_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
+    protos = declared_prototypes()
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        decl = protos[name]
+        assert len(decl) == len(argtypes), "%s: header has %d parameters, ctypes table %d" % (name, len(decl), len(argtypes))
+        for d, t in zip(decl, argtypes):   # pointers <-> c_void_p, scalars <-> scalars
+            assert ("*" in d) == (t is ctypes.c_void_p), "%s: parameter %r bound as %s" % (name, d, t)
     lib = _lib.lib()
     assert lib.pika_amd_abi_version() == _lib.ABI_VERSION
 
