@@ -15,9 +15,11 @@
  * lse (B*H*T,) f32 = log2-domain log-sum-exp of the scaled scores, written by the forward and read
  * by the backward.  Arithmetic: operands rounded to bf16 for the MFMAs, fp32 softmax/accumulation.
  *
- * Dropout (p_drop in [0,1), 0 = none) is a counter-based hash of (seed, b, h, query, key), so the
- * backward regenerates the forward's mask from `seed`; kept probabilities are scaled by
- * 1/(1-p) where p = round(p_drop*65536)/65536.  pika_attention_keep_mask materialises the mask
+ * Dropout (p_drop in [0,1), 0 = none): the keep decision of (b, h, query, key) is a counter-based hash
+ * of (seed, b, h, query, key); the forward packs the decisions once into `keep_bits`
+ * (u64 [B*H][T][ceil(T/64)], 8 bytes per query row and 64 keys, caller-owned, may be NULL when
+ * p_drop == 0) and all three passes read bits instead of re-hashing.  Kept probabilities are scaled by
+ * 1/(1-p), p = round(p_drop*65536)/65536.  pika_attention_keep_mask materialises the mask as bytes
  * (tests only).  Conventions as in pika_rnnt.h.
  */
 #ifndef PIKA_ATTN_H
@@ -28,12 +30,13 @@ extern "C" {
 #endif
 
 int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
-                       int B, int T, int H, int D, long long ld, long long ldo, float p_drop,
-                       unsigned seed, void *stream);
+                       void *keep_bits, int B, int T, int H, int D, long long ld, long long ldo,
+                       float p_drop, unsigned seed, void *stream);
 
 /* delta (B*H*T,) f32 is scratch (sum_d out*dout per query row). */
 int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
-                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                       const float *dout, const float *lse, const void *keep_bits, float *delta,
+                       float *dq, float *dk,
                        float *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
 

@@ -35,8 +35,8 @@ SIGNATURES = {
                                      ctypes.c_uint, _vp, _ll, ctypes.c_float, _vp]),
     "pika_dropout_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
     # include/pika_attn.h
-    "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, ctypes.c_float, ctypes.c_uint, _vp]),
-    "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
+    "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
                                 ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_attention_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
     # include/pika_ops.h

@@ -36,8 +36,21 @@ __device__ inline uint32_t mix32(uint32_t x) {
 }
 // dropout decision for probability (row = (b*H+h)*T + query, key)
 __device__ inline uint32_t row_hash(uint32_t seed, uint32_t row) { return mix32(seed + row * 0x9E3779B9u); }
+// one hash decides two neighbouring keys (its two 16-bit halves)
 __device__ inline bool keep(uint32_t rowh, uint32_t key, uint32_t thr) {
-    return (mix32(rowh ^ (key * 0x85ebca6bu)) & 0xffffu) >= thr;
+    const uint32_t h = mix32(rowh ^ ((key >> 1) * 0x85ebca6bu));
+    return ((key & 1) ? (h >> 16) : (h & 0xffffu)) >= thr;
+}
+// keep bits of keys kb*64 .. kb*64+63 of one (b,h,query) row
+__device__ inline uint64_t keep_word(uint32_t rowh, uint32_t kb, uint32_t thr) {
+    uint64_t w = 0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < 32; ++j) {
+        const uint32_t h = mix32(rowh ^ ((kb * 32 + j) * 0x85ebca6bu));
+        w |= (uint64_t)((h & 0xffffu) >= thr) << (2 * j);
+        w |= (uint64_t)((h >> 16) >= thr) << (2 * j + 1);
+    }
+    return w;
 }
 
 __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -101,6 +114,8 @@ struct Args {
     float qscale;     // log2(e) / sqrt(D)
     float inv_keep;   // 1 / (1 - p)
     uint32_t seed, thr;
+    const uint64_t *bits;   // keep bits [b*H+h][query][ceil(T/64)] (dropout only)
+    int nkb;
 };
 
 template <int D>
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
     const uint32_t bh = (uint32_t)(b * A.H + h);
     bf16x8 qf[KS];
     row_frags<D>(qf, A.q + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
-    const uint32_t rowh = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qrow);
+    const uint64_t *bits = A.bits + ((long long)bh * T + min(qrow, T - 1)) * A.nkb;
     f32x4 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -150,13 +165,15 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
         bf16x8 pf[2];
+        const uint64_t kw = A.thr ? (bits[kb >> 6] >> (g * 4)) : ~0ull;   // bit kt*16 + r = key kt*16 + g*4 + r
+        const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = ex2(s[kt][r] - mn);
                 lpart += p;
-                if (A.thr && !keep(rowh, (uint32_t)(kb + kt * 16 + g * 4 + r), A.thr)) p = 0.f;
+                if (!(((kt < 2 ? kw0 : kw1) >> ((kt & 1) * 16 + r)) & 1u)) p = 0.f;
                 pf[kt >> 1][(kt & 1) * 4 + r] = (__bf16)p;
             }
 #pragma unroll
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     row_frags<D>(dof, A.dout + (long long)b * T * A.ldo + (long long)h * D + (long long)min(qrow, T - 1) * A.ldo, g, 1.f);
     const float lse = qrow < T ? A.lse[(long long)bh * T + qrow] : INFINITY;
     const float delta = qrow < T ? A.delta[(long long)bh * T + qrow] : 0.f;
-    const uint32_t rowh = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qrow);
+    const uint64_t *bits = A.bits + ((long long)bh * T + min(qrow, T - 1)) * A.nkb;
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -216,6 +233,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
         load_tile<D>(Ks, A.k + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
         load_tile<D>(Vs, A.v + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
         __syncthreads();
+        const uint64_t kw = A.thr ? (bits[kb >> 6] >> (g * 4)) : ~0ull;
+        const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 dsf;
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
                     const int key = kb + kt * 16 + g * 4 + r;
                     const float p = key < T ? ex2(sa[r] - lse) : 0.f;
                     float d = dp[r] * A.inv_keep;
-                    if (A.thr && !keep(rowh, (uint32_t)key, A.thr)) d = 0.f;
+                    if (!(((kt < 2 ? kw0 : kw1) >> ((kt & 1) * 16 + r)) & 1u)) d = 0.f;
                     dsf[half * 4 + r] = (__bf16)(p * (d - delta));
                 }
             }
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[TILE * P];
     __shared__ __attribute__((aligned(16))) __bf16 Os[TILE * P];
     __shared__ float lse_s[TILE], delta_s[TILE];
-    __shared__ uint32_t rowh_s[TILE];
+    __shared__ uint64_t word_s[TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const int T = A.T, h = blockIdx.y, b = blockIdx.z;
     const int krow = blockIdx.x * TILE + wave * 16 + (lane & 15);
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
             const int qi = qb + threadIdx.x;
             lse_s[threadIdx.x] = qi < T ? A.lse[(long long)bh * T + qi] : INFINITY;
             delta_s[threadIdx.x] = qi < T ? A.delta[(long long)bh * T + qi] : 0.f;
-            rowh_s[threadIdx.x] = row_hash(A.seed, bh * (uint32_t)T + (uint32_t)qi);
+            word_s[threadIdx.x] = (A.thr && qi < T) ? A.bits[((long long)bh * T + qi) * A.nkb + blockIdx.x] : ~0ull;
         }
         __syncthreads();
 #pragma unroll
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
                     const int qi = qt * 16 + g * 4 + r;
                     const float p = ex2(sa[r] - lse_s[qi]);
                     float pd = p * A.inv_keep, d = dp[r] * A.inv_keep;
-                    if (A.thr && !keep(rowh_s[qi], (uint32_t)krow, A.thr)) pd = d = 0.f;
+                    if (!((word_s[qi] >> (krow & 63)) & 1ull)) pd = d = 0.f;
                     pdf[half * 4 + r] = (__bf16)pd;
                     dsf[half * 4 + r] = (__bf16)(p * (d - delta_s[qi]));
                 }
@@ -317,6 +336,15 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
             *reinterpret_cast<f32x4 *>(ov + dt * 16) = dv[dt];
         }
     }
+}
+
+// bits[row][kb] for row = (b*H+h)*T + query: one thread per 64-key word
+__global__ __launch_bounds__(THREADS) void keep_bits_kernel(uint64_t *bits, long long rows, int nkb,
+                                                            uint32_t seed, uint32_t thr) {
+    const long long idx = (long long)blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= rows * nkb) return;
+    const long long row = idx / nkb;
+    bits[idx] = keep_word(row_hash(seed, (uint32_t)row), (uint32_t)(idx - row * nkb), thr);
 }
 
 __global__ __launch_bounds__(THREADS) void keep_mask_kernel(unsigned char *mask, long long rows, int T,
@@ -349,8 +377,8 @@ inline void dropout_consts(Args &A, float p, unsigned seed) {
 extern "C" {
 
 int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
-                       int B, int T, int H, int D, long long ld, long long ldo, float p_drop,
-                       unsigned seed, void *stream) {
+                       void *keep_bits, int B, int T, int H, int D, long long ld, long long ldo,
+                       float p_drop, unsigned seed, void *stream) {
     if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !lse || ldo < (long long)H * D || (ldo & 3)) return PIKA_EINVAL;
     if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
     Args A{};
@@ -359,13 +387,22 @@ int pika_attention_fwd(const float *q, const float *k, const float *v, float *ou
     dropout_consts(A, p_drop, seed);
     const dim3 grid((T + TILE - 1) / TILE, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    A.nkb = (T + 63) / 64;
+    if (A.thr) {
+        if (!keep_bits || (reinterpret_cast<uintptr_t>(keep_bits) & 7)) return PIKA_EINVAL;
+        const long long words = (long long)B * H * T * A.nkb;
+        hipLaunchKernelGGL(keep_bits_kernel, dim3((unsigned)((words + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
+                           static_cast<uint64_t *>(keep_bits), (long long)B * H * T, A.nkb, A.seed, A.thr);
+        A.bits = static_cast<const uint64_t *>(keep_bits);
+    }
     if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(THREADS), 0, s, A);
     else hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(THREADS), 0, s, A);
     return (int)hipGetLastError();
 }
 
 int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
-                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                       const float *dout, const float *lse, const void *keep_bits, float *delta,
+                       float *dq, float *dk,
                        float *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream) {
     if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !args_ok(dout, dq, dk, dv, B, T, H, D, ld, p_drop) ||
@@ -377,6 +414,11 @@ int pika_attention_bwd(const float *q, const float *k, const float *v, const flo
     A.dq = dq; A.dk = dk; A.dv = dv; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
     A.qscale = 1.4426950408889634f / sqrtf((float)D);
     dropout_consts(A, p_drop, seed);
+    A.nkb = (T + 63) / 64;
+    if (A.thr) {
+        if (!keep_bits || (reinterpret_cast<uintptr_t>(keep_bits) & 7)) return PIKA_EINVAL;
+        A.bits = static_cast<const uint64_t *>(keep_bits);
+    }
     const dim3 grid((T + TILE - 1) / TILE, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (D == 64) {

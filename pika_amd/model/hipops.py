@@ -359,18 +359,24 @@ def attention_keep_mask(BH, T, p_drop, seed, device):
 
 
 def _attn_fwd(q, k, v, out, lse, B, T, heads, D, ld, p_drop, seed):
+    """Returns the packed keep bits (None without dropout) the backward must be given."""
+    bits = None
+    if p_drop > 0:
+        bits = torch.empty((B * heads, T, (T + 63) // 64), dtype=torch.int64, device=out.device)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                                                 lse.data_ptr(), B, T, heads, D, ld, heads * D, float(p_drop),
+                                                 lse.data_ptr(), None if bits is None else bits.data_ptr(),
+                                                 B, T, heads, D, ld, heads * D, float(p_drop),
                                                  int(seed), _stream()), "pika_attention_fwd")
+    return bits
 
 
-def _attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, T, heads, D, ld, p_drop, seed):
+def _attn_bwd(q, k, v, out, dout, lse, bits, dq, dk, dv, B, T, heads, D, ld, p_drop, seed):
     delta = torch.empty_like(lse)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().pika_attention_bwd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-            delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, D, ld, heads * D,
+            None if bits is None else bits.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, D, ld, heads * D,
             p_drop, seed, _stream()), "pika_attention_bwd")
 
 
@@ -384,18 +390,18 @@ class AttentionFn(torch.autograd.Function):
         B, T, HD = q.shape
         out = torch.empty_like(q)
         lse = torch.empty(B * heads * T, dtype=torch.float32, device=q.device)
-        _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD, p_drop, seed)
+        bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD, p_drop, seed)
         ctx.cfg = (heads, float(p_drop), int(seed))
-        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.save_for_backward(q, k, v, out, lse, bits)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, out, lse = ctx.saved_tensors
+        q, k, v, out, lse, bits = ctx.saved_tensors
         heads, p_drop, seed = ctx.cfg
         B, T, HD = q.shape
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        _attn_bwd(q, k, v, out, dout.contiguous(), lse, dq, dk, dv, B, T, heads, HD // heads, HD, p_drop, seed)
+        _attn_bwd(q, k, v, out, dout.contiguous(), lse, bits, dq, dk, dv, B, T, heads, HD // heads, HD, p_drop, seed)
         return dq, dk, dv, None, None, None
 
 
@@ -411,19 +417,19 @@ class PackedAttentionFn(torch.autograd.Function):
         q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
         out = torch.empty((B, T, HD), dtype=torch.float32, device=qkv.device)
         lse = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
-        _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD3, p_drop, seed)
+        bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD3, p_drop, seed)
         ctx.cfg = (heads, float(p_drop), int(seed))
-        ctx.save_for_backward(qkv, out, lse)
+        ctx.save_for_backward(qkv, out, lse, bits)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, lse = ctx.saved_tensors
+        qkv, out, lse, bits = ctx.saved_tensors
         heads, p_drop, seed = ctx.cfg
         B, T, HD3 = qkv.shape
         HD = HD3 // 3
         dqkv = torch.empty_like(qkv)
-        _attn_bwd(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], out, dout.contiguous(), lse,
+        _attn_bwd(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], out, dout.contiguous(), lse, bits,
                   dqkv[..., :HD], dqkv[..., HD:2 * HD], dqkv[..., 2 * HD:], B, T, heads, HD // heads, HD3,
                   p_drop, seed)
         return dqkv, None, None, None
