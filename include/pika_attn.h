@@ -8,7 +8,10 @@
  *     drop_attn = dropout(attn); context = drop_attn @ value
  * whose (B,H,T,T) score/probability tensors (2 GB per layer at config 2) are never written here.
  *
- * Tensors: q, k, v, dq, dk, dv are f32 (B,T,H*D) with row pitch `ld` floats (so they may be the three
+ * io_dtype PIKA_F32 | PIKA_BF16 (pika_gemm.h) is the element type of q, k, v, out, dout, dq, dk, dv: bf16
+ * when the projections come from / go to MFMA products only (the kernels round to bf16 anyway; pitches
+ * then % 8 == 0).
+ * Tensors: q, k, v, dq, dk, dv are (B,T,H*D) with row pitch `ld` elements (so they may be the three
  * column blocks of one packed (B,T,3*H*D) projection), out and dout with row pitch `ldo`; head h owns
  * columns [h*D, (h+1)*D); batches are T rows apart; D is 64 or 128; pitches % 4 == 0 and 16-byte
  * aligned bases.
@@ -29,15 +32,14 @@
 extern "C" {
 #endif
 
-int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
+int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
                        void *keep_bits, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
 
 /* delta (B*H*T,) f32 is scratch (sum_d out*dout per query row). */
-int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
-                       const float *dout, const float *lse, const void *keep_bits, float *delta,
-                       float *dq, float *dk,
-                       float *dv, int B, int T, int H, int D, long long ld, long long ldo,
+int pika_attention_bwd(const void *q, const void *k, const void *v, const void *out, const void *dout,
+                       int io_dtype, const float *lse, const void *keep_bits, float *delta, void *dq,
+                       void *dk, void *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
 
 /* mask (B*H, T, T) u8: 1 where the probability of (query row, key column) is kept. */

@@ -31,6 +31,17 @@ int pika_bn_backward(const float *dy, const float *x, long long rows, int C, con
                      const float *save_mean, const float *save_rstd, double *sums, float *dx,
                      float *dgamma, float *dbeta, int relu_mask, void *stream);
 
+/* nn.LayerNorm over the last dimension of x (rows, C) f32 contiguous (pre-LN transformer layers,
+ * /root/reference/trainer/model/transformer.py:85-100, position_ffn.py:36): C % 4 == 0, C <= 2048.
+ * y may be written as bf16 (y_dtype PIKA_BF16, pika_gemm.h) when it only feeds MFMA products; mean /
+ * rstd (rows each) are kept for the backward, whose incoming gradient may be bf16 as well.
+ * dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; dgamma = sum dy*xhat; dbeta = sum dy. */
+int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamma, const float *beta,
+                        float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
+int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
+                        const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "pika_attn.h"
+#include "pika_gemm.h"
 #include "pika_rnnt.h"
 
 namespace {
@@ -55,33 +56,69 @@ __device__ inline uint64_t keep_word(uint32_t rowh, uint32_t kb, uint32_t thr) {
 
 __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// 64 x D fp32 rows (pitch ld) -> bf16 LDS tile with pitch D+8; rows >= nvalid are zero-filled.
-template <int D>
-__device__ inline void load_tile(__bf16 *lds, const float *g, long long ld, int nvalid, float scale) {
-    constexpr int P = D + 8, F4 = D / 4, RPP = THREADS / F4;
-    const int c = threadIdx.x % F4, r0 = threadIdx.x / F4;
-    f32x4 v[TILE / RPP];
+// 64 x D rows of T = float | bf16 (pitch ld) -> bf16 LDS tile with pitch D+8; rows >= nvalid are zero-filled.
+template <int D, typename T>
+__device__ inline void load_tile(__bf16 *lds, const T *g, long long ld, int nvalid, float scale) {
+    constexpr int P = D + 8;
+    if constexpr (sizeof(T) == 4) {
+        constexpr int F4 = D / 4, RPP = THREADS / F4;
+        const int c = threadIdx.x % F4, r0 = threadIdx.x / F4;
+        f32x4 v[TILE / RPP];
 #pragma unroll
-    for (int p = 0; p < TILE / RPP; ++p) {
-        const int r = r0 + p * RPP;
-        v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (r < nvalid) v[p] = *reinterpret_cast<const f32x4 *>(g + (long long)r * ld + c * 4);
+        for (int p = 0; p < TILE / RPP; ++p) {
+            const int r = r0 + p * RPP;
+            v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < nvalid) v[p] = *reinterpret_cast<const f32x4 *>(g + (long long)r * ld + c * 4);
+        }
+#pragma unroll
+        for (int p = 0; p < TILE / RPP; ++p)
+            *reinterpret_cast<bf16x4 *>(lds + (r0 + p * RPP) * P + c * 4) = __builtin_convertvector(v[p] * scale, bf16x4);
+    } else {
+        constexpr int F8 = D / 8, RPP = THREADS / F8;
+        const int c = threadIdx.x % F8, r0 = threadIdx.x / F8;
+        bf16x8 v[TILE / RPP];
+#pragma unroll
+        for (int p = 0; p < TILE / RPP; ++p) {
+            const int r = r0 + p * RPP;
+            v[p] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < nvalid) v[p] = *reinterpret_cast<const bf16x8 *>(g + (long long)r * ld + c * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < TILE / RPP; ++p) {
+            if (scale != 1.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[p][e] = (__bf16)((float)v[p][e] * scale);
+            }
+            *reinterpret_cast<bf16x8 *>(lds + (r0 + p * RPP) * P + c * 8) = v[p];
+        }
     }
-#pragma unroll
-    for (int p = 0; p < TILE / RPP; ++p)
-        *reinterpret_cast<bf16x4 *>(lds + (r0 + p * RPP) * P + c * 4) = __builtin_convertvector(v[p] * scale, bf16x4);
 }
 
-// one row of a (.,D) fp32 matrix as D/32 MFMA operand fragments (8 consecutive d per lane)
-template <int D>
-__device__ inline void row_frags(bf16x8 *f, const float *row, int g, float scale) {
+// one row of a (.,D) matrix as D/32 MFMA operand fragments (8 consecutive d per lane)
+template <int D, typename T>
+__device__ inline void row_frags(bf16x8 *f, const T *row, int g, float scale) {
 #pragma unroll
     for (int ks = 0; ks < D / 32; ++ks) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(row + ks * 32 + g * 8) * scale;
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(row + ks * 32 + g * 8 + 4) * scale;
-        f[ks] = bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w,
-                       (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+        if constexpr (sizeof(T) == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(row + ks * 32 + g * 8) * scale;
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(row + ks * 32 + g * 8 + 4) * scale;
+            f[ks] = bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w,
+                           (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+        } else {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(row + ks * 32 + g * 8);
+            if (scale != 1.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] * scale);
+            }
+            f[ks] = v;
+        }
     }
+}
+
+template <typename T>
+__device__ inline void store4(T *p, f32x4 v) {
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4 *>(p) = v;
+    else *reinterpret_cast<bf16x4 *>(p) = __builtin_convertvector(v, bf16x4);
 }
 
 // operand fragment with tile rows as the MFMA row/column index: row r0 + (lane&15), k = kk + g*8..+7
@@ -107,8 +144,10 @@ __device__ inline f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 
 struct Args {
-    const float *q, *k, *v, *out, *dout, *lse, *delta;
-    float *o, *lse_w, *dq, *dk, *dv;
+    const void *q, *k, *v, *out, *dout;   // T = float | bf16 (io dtype)
+    const float *lse, *delta;
+    void *o, *dq, *dk, *dv;
+    float *lse_w;
     int T, H;
     long long ld, ldo;  // row pitch of q/k/v/dq/dk/dv and of out/dout
     float qscale;     // log2(e) / sqrt(D)
@@ -118,8 +157,9 @@ struct Args {
     int nkb;
 };
 
-template <int D>
+template <int D, typename T_>
 __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
+    const T_ *Aq = static_cast<const T_ *>(A.q), *Ak = static_cast<const T_ *>(A.k), *Av = static_cast<const T_ *>(A.v);
     constexpr int P = D + 8, KS = D / 32, DT = D / 16;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[TILE * P];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[TILE * P];
@@ -129,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
     const long long boff = (long long)b * T * A.ld + (long long)h * D;
     const uint32_t bh = (uint32_t)(b * A.H + h);
     bf16x8 qf[KS];
-    row_frags<D>(qf, A.q + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
+    row_frags<D>(qf, Aq + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
     const uint64_t *bits = A.bits + ((long long)bh * T + min(qrow, T - 1)) * A.nkb;
     f32x4 oacc[DT];
 #pragma unroll
@@ -137,8 +177,8 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
     float m = -INFINITY, lpart = 0.f;
     for (int kb = 0; kb < T; kb += TILE) {
         __syncthreads();
-        load_tile<D>(Ks, A.k + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
-        load_tile<D>(Vs, A.v + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Ks, Ak + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vs, Av + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
         __syncthreads();
         f32x4 s[4];
 #pragma unroll
@@ -186,22 +226,32 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
     l += __shfl_xor(l, 32);
     if (qrow < T) {
         const float sc = A.inv_keep / l;
-        float *o = A.o + (long long)b * T * A.ldo + (long long)h * D + (long long)qrow * A.ldo + g * 4;
+        T_ *o = static_cast<T_ *>(A.o) + (long long)b * T * A.ldo + (long long)h * D + (long long)qrow * A.ldo + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(o + dt * 16) = oacc[dt] * sc;
+        for (int dt = 0; dt < DT; ++dt) store4(o + dt * 16, oacc[dt] * sc);
         if (g == 0) A.lse_w[(long long)bh * T + qrow] = m + __log2f(l);
     }
 }
 
 // delta[bh*T + q] = sum_d out[b,q,h,d] * dout[b,q,h,d]; one workgroup per (b,q) row.
-template <int D>
+template <typename T_>
+__device__ inline f32x4 load4(const T_ *p) {
+    if constexpr (sizeof(T_) == 4) {
+        return *reinterpret_cast<const f32x4 *>(p);
+    } else {
+        const bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
+template <int D, typename T_>
 __global__ __launch_bounds__(THREADS) void attn_delta_kernel(Args A, float *delta) {
     const int T = A.T, HD = A.H * D;
     const long long row = blockIdx.x;  // b*T + q
     const int b = (int)(row / T), qi = (int)(row - (long long)b * T);
     for (int c = threadIdx.x * 4; c < HD; c += THREADS * 4) {
-        const f32x4 o = *reinterpret_cast<const f32x4 *>(A.out + row * A.ldo + c);
-        const f32x4 d = *reinterpret_cast<const f32x4 *>(A.dout + row * A.ldo + c);
+        const f32x4 o = load4(static_cast<const T_ *>(A.out) + row * A.ldo + c);
+        const f32x4 d = load4(static_cast<const T_ *>(A.dout) + row * A.ldo + c);
         float s = o.x * d.x + o.y * d.y + o.z * d.z + o.w * d.w;
 #pragma unroll
         for (int w = 1; w < D / 4; w <<= 1) s += __shfl_xor(s, w);
@@ -209,8 +259,10 @@ __global__ __launch_bounds__(THREADS) void attn_delta_kernel(Args A, float *delt
     }
 }
 
-template <int D>
+template <int D, typename T_>
 __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
+    const T_ *Aq = static_cast<const T_ *>(A.q), *Ak = static_cast<const T_ *>(A.k), *Av = static_cast<const T_ *>(A.v);
+    const T_ *Ado = static_cast<const T_ *>(A.dout);
     constexpr int P = D + 8, KS = D / 32, DT = D / 16;
     __shared__ __attribute__((aligned(16))) __bf16 Ks[TILE * P];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[TILE * P];
@@ -220,8 +272,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     const long long boff = (long long)b * T * A.ld + (long long)h * D;
     const uint32_t bh = (uint32_t)(b * A.H + h);
     bf16x8 qf[KS], dof[KS];
-    row_frags<D>(qf, A.q + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
-    row_frags<D>(dof, A.dout + (long long)b * T * A.ldo + (long long)h * D + (long long)min(qrow, T - 1) * A.ldo, g, 1.f);
+    row_frags<D>(qf, Aq + boff + (long long)min(qrow, T - 1) * A.ld, g, A.qscale);
+    row_frags<D>(dof, Ado + (long long)b * T * A.ldo + (long long)h * D + (long long)min(qrow, T - 1) * A.ldo, g, 1.f);
     const float lse = qrow < T ? A.lse[(long long)bh * T + qrow] : INFINITY;
     const float delta = qrow < T ? A.delta[(long long)bh * T + qrow] : 0.f;
     const uint64_t *bits = A.bits + ((long long)bh * T + min(qrow, T - 1)) * A.nkb;
@@ -230,8 +282,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kb = 0; kb < T; kb += TILE) {
         __syncthreads();
-        load_tile<D>(Ks, A.k + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
-        load_tile<D>(Vs, A.v + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Ks, Ak + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vs, Av + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
         __syncthreads();
         const uint64_t kw = A.thr ? (bits[kb >> 6] >> (g * 4)) : ~0ull;
         const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
@@ -262,14 +314,16 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     }
     if (qrow < T) {
         const float sc = rsqrtf((float)D);
-        float *o = A.dq + boff + (long long)qrow * A.ld + g * 4;
+        T_ *o = static_cast<T_ *>(A.dq) + boff + (long long)qrow * A.ld + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(o + dt * 16) = acc[dt] * sc;
+        for (int dt = 0; dt < DT; ++dt) store4(o + dt * 16, acc[dt] * sc);
     }
 }
 
-template <int D>
+template <int D, typename T_>
 __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
+    const T_ *Aq = static_cast<const T_ *>(A.q), *Ak = static_cast<const T_ *>(A.k), *Av = static_cast<const T_ *>(A.v);
+    const T_ *Ado = static_cast<const T_ *>(A.dout);
     constexpr int P = D + 8, KS = D / 32, DT = D / 16;
     __shared__ __attribute__((aligned(16))) __bf16 Qs[TILE * P];
     __shared__ __attribute__((aligned(16))) __bf16 Os[TILE * P];
@@ -281,15 +335,15 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     const long long boff = (long long)b * T * A.ld + (long long)h * D;
     const uint32_t bh = (uint32_t)(b * A.H + h);
     bf16x8 kf[KS], vf[KS];
-    row_frags<D>(kf, A.k + boff + (long long)min(krow, T - 1) * A.ld, g, 1.f);
-    row_frags<D>(vf, A.v + boff + (long long)min(krow, T - 1) * A.ld, g, 1.f);
+    row_frags<D>(kf, Ak + boff + (long long)min(krow, T - 1) * A.ld, g, 1.f);
+    row_frags<D>(vf, Av + boff + (long long)min(krow, T - 1) * A.ld, g, 1.f);
     f32x4 dk[DT], dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int qb = 0; qb < T; qb += TILE) {
         __syncthreads();
-        load_tile<D>(Qs, A.q + boff + (long long)qb * A.ld, A.ld, T - qb, A.qscale);
-        load_tile<D>(Os, A.dout + (long long)b * T * A.ldo + (long long)h * D + (long long)qb * A.ldo, A.ldo, T - qb, 1.f);
+        load_tile<D>(Qs, Aq + boff + (long long)qb * A.ld, A.ld, T - qb, A.qscale);
+        load_tile<D>(Os, Ado + (long long)b * T * A.ldo + (long long)h * D + (long long)qb * A.ldo, A.ldo, T - qb, 1.f);
         if (threadIdx.x < TILE) {
             const int qi = qb + threadIdx.x;
             lse_s[threadIdx.x] = qi < T ? A.lse[(long long)bh * T + qi] : INFINITY;
@@ -328,12 +382,12 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     }
     if (krow < T) {
         const float ln2 = 0.6931471805599453f;  // Qs carries log2(e)/sqrt(D)
-        float *ok = A.dk + boff + (long long)krow * A.ld + g * 4;
-        float *ov = A.dv + boff + (long long)krow * A.ld + g * 4;
+        T_ *ok = static_cast<T_ *>(A.dk) + boff + (long long)krow * A.ld + g * 4;
+        T_ *ov = static_cast<T_ *>(A.dv) + boff + (long long)krow * A.ld + g * 4;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            *reinterpret_cast<f32x4 *>(ok + dt * 16) = dk[dt] * ln2;
-            *reinterpret_cast<f32x4 *>(ov + dt * 16) = dv[dt];
+            store4(ok + dt * 16, dk[dt] * ln2);
+            store4(ov + dt * 16, dv[dt]);
         }
     }
 }
@@ -356,9 +410,9 @@ __global__ __launch_bounds__(THREADS) void keep_mask_kernel(unsigned char *mask,
 }
 
 inline bool args_ok(const void *a, const void *b, const void *c, const void *d, int B, int T, int H, int D,
-                    long long ld, float p) {
+                    long long ld, float p, int g) {
     if (!a || !b || !c || !d || B <= 0 || T <= 0 || H <= 0) return false;
-    if ((D != 64 && D != 128) || ld < (long long)H * D || (ld & 3)) return false;
+    if ((D != 64 && D != 128) || ld < (long long)H * D || (ld & (g - 1))) return false;
     if (!(p >= 0.f && p < 1.f)) return false;
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
          reinterpret_cast<uintptr_t>(d)) & 15)
@@ -372,14 +426,28 @@ inline void dropout_consts(Args &A, float p, unsigned seed) {
     A.seed = seed;
 }
 
+template <int D, typename T_>
+void launch_fwd(const Args &A, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((attn_fwd_kernel<D, T_>), grid, dim3(THREADS), 0, s, A);
+}
+
+template <int D, typename T_>
+void launch_bwd(const Args &A, dim3 grid, int rows, float *delta, hipStream_t s) {
+    hipLaunchKernelGGL((attn_delta_kernel<D, T_>), dim3((unsigned)rows), dim3(THREADS), 0, s, A, delta);
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<D, T_>), grid, dim3(THREADS), 0, s, A);
+    hipLaunchKernelGGL((attn_bwd_q_kernel<D, T_>), grid, dim3(THREADS), 0, s, A);
+}
+
 }  // namespace
 
 extern "C" {
 
-int pika_attention_fwd(const float *q, const float *k, const float *v, float *out, float *lse,
+int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
                        void *keep_bits, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream) {
-    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !lse || ldo < (long long)H * D || (ldo & 3)) return PIKA_EINVAL;
+    if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16) return PIKA_EINVAL;
+    const int g = io_dtype == PIKA_F32 ? 4 : 8;
+    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop, g) || !lse || ldo < (long long)H * D || (ldo & (g - 1))) return PIKA_EINVAL;
     if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
     Args A{};
     A.q = q; A.k = k; A.v = v; A.o = out; A.lse_w = lse; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
@@ -395,18 +463,22 @@ int pika_attention_fwd(const float *q, const float *k, const float *v, float *ou
                            static_cast<uint64_t *>(keep_bits), (long long)B * H * T, A.nkb, A.seed, A.thr);
         A.bits = static_cast<const uint64_t *>(keep_bits);
     }
-    if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(THREADS), 0, s, A);
-    else hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(THREADS), 0, s, A);
+    if (io_dtype == PIKA_F32) {
+        if (D == 64) launch_fwd<64, float>(A, grid, s); else launch_fwd<128, float>(A, grid, s);
+    } else {
+        if (D == 64) launch_fwd<64, __bf16>(A, grid, s); else launch_fwd<128, __bf16>(A, grid, s);
+    }
     return (int)hipGetLastError();
 }
 
-int pika_attention_bwd(const float *q, const float *k, const float *v, const float *out,
-                       const float *dout, const float *lse, const void *keep_bits, float *delta,
-                       float *dq, float *dk,
-                       float *dv, int B, int T, int H, int D, long long ld, long long ldo,
+int pika_attention_bwd(const void *q, const void *k, const void *v, const void *out, const void *dout,
+                       int io_dtype, const float *lse, const void *keep_bits, float *delta, void *dq,
+                       void *dk, void *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream) {
-    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop) || !args_ok(dout, dq, dk, dv, B, T, H, D, ld, p_drop) ||
-        !lse || !delta || ldo < (long long)H * D || (ldo & 3))
+    if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16) return PIKA_EINVAL;
+    const int g = io_dtype == PIKA_F32 ? 4 : 8;
+    if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop, g) || !args_ok(dout, dq, dk, dv, B, T, H, D, ld, p_drop, g) ||
+        !lse || !delta || ldo < (long long)H * D || (ldo & (g - 1)))
         return PIKA_EINVAL;
     if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
     Args A{};
@@ -421,14 +493,10 @@ int pika_attention_bwd(const float *q, const float *k, const float *v, const flo
     }
     const dim3 grid((T + TILE - 1) / TILE, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (D == 64) {
-        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)(B * T)), dim3(THREADS), 0, s, A, delta);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, grid, dim3(THREADS), 0, s, A);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<64>, grid, dim3(THREADS), 0, s, A);
+    if (io_dtype == PIKA_F32) {
+        if (D == 64) launch_bwd<64, float>(A, grid, B * T, delta, s); else launch_bwd<128, float>(A, grid, B * T, delta, s);
     } else {
-        hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)(B * T)), dim3(THREADS), 0, s, A, delta);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<128>, grid, dim3(THREADS), 0, s, A);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<128>, grid, dim3(THREADS), 0, s, A);
+        if (D == 64) launch_bwd<64, __bf16>(A, grid, B * T, delta, s); else launch_bwd<128, __bf16>(A, grid, B * T, delta, s);
     }
     return (int)hipGetLastError();
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pika_gemm.h"
 #include "pika_norm.h"
 #include "pika_rnnt.h"
 
@@ -118,6 +119,125 @@ __global__ __launch_bounds__(256) void bn_param_grad_kernel(const double *__rest
     dgamma[c] = (float)sums[C + c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension (C <= 2048, C % 4 == 0): one wavefront per row, the row lives
+// in registers (LNQ float4 per lane), statistics by xor-shuffles.  Output / incoming gradient may
+// be bf16: the normalised activation only feeds MFMA products (q/k/v and feed-forward GEMMs), so it
+// is rounded once here instead of in a separate pass.
+constexpr int LNQ = 8;   // float4 per lane: C <= 64 * 4 * 8
+typedef float ln_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ln_b4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float ln_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, TO *__restrict__ y,
+                                                     float *__restrict__ mean, float *__restrict__ rstd,
+                                                     long long rows, int C, float eps) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = C >> 2;
+    const ln_f4 *xr = reinterpret_cast<const ln_f4 *>(x + r * C);
+    ln_f4 v[LNQ];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNQ; ++q)
+        if (lane + q * 64 < c4) {
+            v[q] = xr[lane + q * 64];
+            s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        }
+    const float mu = ln_wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNQ; ++q)
+        if (lane + q * 64 < c4) {
+            const ln_f4 d = v[q] - mu;
+            ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    const float rs = rsqrtf(ln_wave_sum(ss) / (float)C + eps);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+    for (int q = 0; q < LNQ; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) {
+            const ln_f4 g = reinterpret_cast<const ln_f4 *>(gamma)[i], b = reinterpret_cast<const ln_f4 *>(beta)[i];
+            const ln_f4 o = (v[q] - mu) * rs * g + b;
+            if constexpr (sizeof(TO) == 4) reinterpret_cast<ln_f4 *>(y + r * C)[i] = o;
+            else reinterpret_cast<ln_b4 *>(y + r * C)[i] = __builtin_convertvector(o, ln_b4);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma += dy * xhat, dbeta += dy
+// (per-lane column partials over the block's rows, one atomicAdd per column per block).
+template <typename TD>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, const float *__restrict__ x,
+                                                     const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, float *__restrict__ dx,
+                                                     float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                     long long rows, int C, int rows_per_block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = C >> 2;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    ln_f4 gm[LNQ], ag[LNQ], ab[LNQ];
+#pragma unroll
+    for (int q = 0; q < LNQ; ++q) {
+        ag[q] = ab[q] = ln_f4{0.f, 0.f, 0.f, 0.f};
+        if (lane + q * 64 < c4) gm[q] = reinterpret_cast<const ln_f4 *>(gamma)[lane + q * 64];
+    }
+    for (long long r = r0 + wave; r < r1; r += 4) {
+        const float mu = mean[r], rs = rstd[r];
+        ln_f4 xh[LNQ], g[LNQ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < LNQ; ++q) {
+            const int i = lane + q * 64;
+            if (i < c4) {
+                ln_f4 d;
+                if constexpr (sizeof(TD) == 4) {
+                    d = reinterpret_cast<const ln_f4 *>(dy + r * C)[i];
+                } else {
+                    const ln_b4 t = reinterpret_cast<const ln_b4 *>(dy + r * C)[i];
+                    d = ln_f4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                }
+                xh[q] = (reinterpret_cast<const ln_f4 *>(x + r * C)[i] - mu) * rs;
+                g[q] = d * gm[q];
+                ag[q] += d * xh[q];
+                ab[q] += d;
+                s1 += (g[q].x + g[q].y) + (g[q].z + g[q].w);
+                const ln_f4 gx = g[q] * xh[q];
+                s2 += (gx.x + gx.y) + (gx.z + gx.w);
+            }
+        }
+        const float m1 = ln_wave_sum(s1) / (float)C, m2 = ln_wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int q = 0; q < LNQ; ++q) {
+            const int i = lane + q * 64;
+            if (i < c4) reinterpret_cast<ln_f4 *>(dx + r * C)[i] = (g[q] - m1 - xh[q] * m2) * rs;
+        }
+    }
+    __shared__ ln_f4 red[2][4][64];
+#pragma unroll
+    for (int q = 0; q < LNQ; ++q) {
+        if (q * 64 >= c4) break;          // uniform
+        __syncthreads();
+        red[0][wave][lane] = ag[q];
+        red[1][wave][lane] = ab[q];
+        __syncthreads();
+        const int i = lane + q * 64;
+        if (wave < 2 && i < c4) {
+            const ln_f4 t = red[wave][0][lane] + red[wave][1][lane] + red[wave][2][lane] + red[wave][3][lane];
+            float *dst = (wave == 0 ? dgamma : dbeta) + 4 * i;
+            atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
+        }
+    }
+}
+
 inline dim3 red_grid(long long rows, int C) {
     return dim3((C + 63) / 64, (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
 }
@@ -167,6 +287,46 @@ int pika_bn_backward(const float *dy, const float *x, long long rows, int C, con
                        save_mean, save_rstd, gamma, sums, dx, relu_mask);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma,
                        dbeta);
+    return (int)hipGetLastError();
+}
+
+int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamma, const float *beta,
+                        float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0) return PIKA_EINVAL;
+    if ((C & 3) || C > 64 * 4 * LNQ || rows > 0x7fffffffLL * 4) return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
+        return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (y_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(y) & 15))
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, x, gamma, beta, static_cast<float *>(y), mean, rstd, rows, C, eps);
+    else if (y_dtype == PIKA_BF16 && !(reinterpret_cast<uintptr_t>(y) & 7))
+        hipLaunchKernelGGL(ln_fwd_kernel<__bf16>, grid, dim3(256), 0, s, x, gamma, beta, static_cast<__bf16 *>(y), mean, rstd, rows, C, eps);
+    else
+        return PIKA_EINVAL;
+    return (int)hipGetLastError();
+}
+
+int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
+                        const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
+                        void *stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return PIKA_EINVAL;
+    if ((C & 3) || C > 64 * 4 * LNQ) return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx) |
+         reinterpret_cast<uintptr_t>(dgamma) | reinterpret_cast<uintptr_t>(dbeta)) & 15)
+        return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    const int rpb = rows >= 4096 ? 32 : 8;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (dy_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(dy) & 15))
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+    else if (dy_dtype == PIKA_BF16 && !(reinterpret_cast<uintptr_t>(dy) & 7))
+        hipLaunchKernelGGL(ln_bwd_kernel<__bf16>, grid, dim3(256), 0, s, static_cast<const __bf16 *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+    else
+        return PIKA_EINVAL;
     return (int)hipGetLastError();
 }
 

@@ -109,20 +109,47 @@ def _grad_input(dy2, w2d):
     return G.gemm_nt(dyp, wt)
 
 
+def _pp_ok(M, N, K):
+    """Shapes the fused bf16 epilogues (pika_gemm_bf16_epilogue) accept."""
+    return K % 64 == 0 and N % 4 == 0 and M >= 1
+
+
+def colsum_any(x2d):
+    if x2d.dtype == torch.float32:
+        return colsum(x2d)
+    out = torch.empty(x2d.shape[1], dtype=torch.float32, device=x2d.device)
+    _lib.check(_lib.lib().pika_colsum_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1],
+                                           out.data_ptr(), _stream()), "pika_colsum_bf16")
+    return out
+
+
 class LinearFn(torch.autograd.Function):
-    """y = act(x @ W^T + b) over the last dim (nn.Linear semantics), optional fused ReLU."""
+    """y = act(x @ W^T + b) over the last dim (nn.Linear semantics), optional fused ReLU.
+
+    bf16 activations: x may be a bf16 tensor (the output of an op whose only consumers are MFMA
+    products: LayerNorm, the attention core) -- then dx comes back bf16 straight from the GEMM epilogue;
+    out_bf16 asks for a bf16 y under the same contract (its gradient arrives bf16, no casts anywhere)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, out_bf16=False):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or (x2.stride(0) & 3):
             x2 = x2.contiguous()
+        ctx.x_bf16 = x.dtype == torch.bfloat16
         x2 = _bf16_operand(x2)
         N = weight.shape[0]
-        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)  # not a view:
-        with torch.cuda.device(x.device):                 # downstream ops may overwrite it in place
-            G.gemm_nt(x2, _weight_for(x2, weight), bias=bias, relu=relu, out=out.view(-1, N))
+        M = x2.shape[0]
+        with torch.cuda.device(x.device):
+            if out_bf16 and x2.dtype == torch.bfloat16 and _pp_ok(M, N, K):
+                out = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
+                _gemm_epilogue(x2, weight.detach().to(torch.bfloat16), out.view(-1, N), bias, EPI_DROPOUT_BF16,
+                               relu=1 if relu else 0)
+            else:
+                out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)  # not a view:
+                G.gemm_nt(x2, _weight_for(x2, weight), bias=bias, relu=relu, out=out.view(-1, N))  # may be
+                if out_bf16:                                                        # overwritten in place
+                    out = out.to(torch.bfloat16)
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x2, weight, out if relu == 1 else None)
@@ -141,12 +168,57 @@ class LinearFn(torch.autograd.Function):
         with torch.cuda.device(dy.device):
             dyb = _bf16_operand(dy2)
             if ctx.needs_input_grad[0]:
-                dx = _grad_input(dyb, weight).view(*dy.shape[:-1], K)
+                if ctx.x_bf16 and dyb.dtype == torch.bfloat16 and N % 64 == 0 and K % 4 == 0:
+                    dx = torch.empty(dy.shape[:-1] + (K,), dtype=torch.bfloat16, device=dy.device)
+                    _gemm_epilogue(dyb, _weight_t(weight), dx.view(-1, K), None, EPI_DROPOUT_BF16)
+                else:
+                    dx = _grad_input(dyb, weight).view(*dy.shape[:-1], K)
+                    if ctx.x_bf16:
+                        dx = dx.to(torch.bfloat16)
             if ctx.needs_input_grad[1]:
                 dw = _grad_weight(dyb, G.matrix(x2)[0], _g(x2), M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                db = colsum(dy2)
-        return dx, dw, db, None
+                db = colsum_any(dy2)
+        return dx, dw, db, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim (include/pika_norm.h); out_bf16: the result only feeds MFMA
+    products, so it is produced (and its gradient accepted) in bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_bf16):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).contiguous()
+        rows = x2.shape[0]
+        dt = torch.bfloat16 if out_bf16 else torch.float32
+        y = torch.empty(x.shape, dtype=dt, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().pika_layer_norm_fwd(
+                x2.data_ptr(), rows, C, weight.data_ptr(), bias.data_ptr(), float(eps), y.data_ptr(),
+                G.PIKA_BF16 if out_bf16 else G.PIKA_F32, mean.data_ptr(), rstd.data_ptr(), _stream()),
+                "pika_layer_norm_fwd")
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dy = dy.contiguous()
+        dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
+        db = torch.empty(C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.lib().pika_layer_norm_bwd(
+                dy.data_ptr(), G.PIKA_F32 if dy.dtype == torch.float32 else G.PIKA_BF16, x2.data_ptr(), rows, C,
+                weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                _stream()), "pika_layer_norm_bwd")
+        return dx, dg, db, None, None
 
 
 class TimeDelayFn(torch.autograd.Function):
@@ -345,7 +417,7 @@ def attention_ok(q, k, v, heads, mask):
     """AttentionFn preconditions: the encoder's self-attention (no mask, Tq == Tk), head width 64
     or 128, bf16 arithmetic mode."""
     D = q.shape[-1] // heads
-    return (G.PRECISION == "bf16" and mask is None and q.is_cuda and q.dtype == torch.float32
+    return (G.PRECISION == "bf16" and mask is None and q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
             and q.shape == k.shape == v.shape and D in (64, 128) and D * heads == q.shape[-1])
 
 
@@ -365,6 +437,7 @@ def _attn_fwd(q, k, v, out, lse, B, T, heads, D, ld, p_drop, seed):
         bits = torch.empty((B * heads, T, (T + 63) // 64), dtype=torch.int64, device=out.device)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                                 G.PIKA_F32 if q.dtype == torch.float32 else G.PIKA_BF16,
                                                  lse.data_ptr(), None if bits is None else bits.data_ptr(),
                                                  B, T, heads, D, ld, heads * D, float(p_drop),
                                                  int(seed), _stream()), "pika_attention_fwd")
@@ -375,7 +448,8 @@ def _attn_bwd(q, k, v, out, dout, lse, bits, dq, dk, dv, B, T, heads, D, ld, p_d
     delta = torch.empty_like(lse)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().pika_attention_bwd(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+            G.PIKA_F32 if q.dtype == torch.float32 else G.PIKA_BF16, lse.data_ptr(),
             None if bits is None else bits.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, D, ld, heads * D,
             p_drop, seed, _stream()), "pika_attention_bwd")
 
@@ -415,7 +489,7 @@ class PackedAttentionFn(torch.autograd.Function):
         B, T, HD3 = qkv.shape
         HD = HD3 // 3
         q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
-        out = torch.empty((B, T, HD), dtype=torch.float32, device=qkv.device)
+        out = torch.empty((B, T, HD), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
         bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD3, p_drop, seed)
         ctx.cfg = (heads, float(p_drop), int(seed))
@@ -429,7 +503,7 @@ class PackedAttentionFn(torch.autograd.Function):
         B, T, HD3 = qkv.shape
         HD = HD3 // 3
         dqkv = torch.empty_like(qkv)
-        _attn_bwd(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], out, dout.contiguous(), lse, bits,
+        _attn_bwd(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], out, dout.to(qkv.dtype).contiguous(), lse, bits,
                   dqkv[..., :HD], dqkv[..., HD:2 * HD], dqkv[..., 2 * HD:], B, T, heads, HD // heads, HD3,
                   p_drop, seed)
         return dqkv, None, None, None
@@ -461,7 +535,7 @@ def dropout_keep_mask(rows, cols, p_drop, seed, device):
 
 def feed_forward_ok(x, w1, w2):
     d, f = w1.shape[1], w1.shape[0]
-    return (G.PRECISION == "bf16" and x.is_cuda and x.dtype == torch.float32 and d % 64 == 0 and f % 64 == 0
+    return (G.PRECISION == "bf16" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and d % 64 == 0 and f % 64 == 0
             and w2.shape[0] % 64 == 0 and x.numel() // d >= 256)
 
 
@@ -475,7 +549,8 @@ class FeedForwardFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, p_drop, seed):
         d = x.shape[-1]
-        xb = x.reshape(-1, d).to(torch.bfloat16)
+        ctx.x_bf16 = x.dtype == torch.bfloat16
+        xb = x.reshape(-1, d).to(torch.bfloat16).contiguous()
         M, F, N2 = xb.shape[0], w1.shape[0], w2.shape[0]
         h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
         _gemm_epilogue(xb, w1.detach().to(torch.bfloat16), h, b1, EPI_DROPOUT_BF16, relu=1, p_drop=p_drop, seed=seed)
@@ -509,7 +584,12 @@ class FeedForwardFn(torch.autograd.Function):
                 _lib.check(_lib.lib().pika_colsum_bf16(dh.data_ptr(), F, M, F, db1.data_ptr(), _stream()),
                            "pika_colsum_bf16")
             if ctx.needs_input_grad[0]:
-                dx = G.gemm_bf16_nt(dh, w1.detach().t().contiguous().to(torch.bfloat16)).view(xshape)
+                w1t = w1.detach().t().contiguous().to(torch.bfloat16)
+                if ctx.x_bf16:
+                    dx = torch.empty(xshape, dtype=torch.bfloat16, device=dy.device)
+                    _gemm_epilogue(dh, w1t, dx.view(-1, d), None, EPI_DROPOUT_BF16)
+                else:
+                    dx = G.gemm_bf16_nt(dh, w1t).view(xshape)
         return dx, dw1, db1, dw2, db2, None, None
 
 

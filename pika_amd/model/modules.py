@@ -18,9 +18,9 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout_2 = nn.Dropout(dropout)
 
     def forward(self, x):
-        y = ops.feed_forward(ops.layer_norm(x, self.layer_norm), self.w_1, self.w_2,
-                             self.dropout_1.p if self.training else 0.0)
-        if y is not None:
+        if ops.feed_forward_applies(x, self.w_1, self.w_2):
+            y = ops.feed_forward(ops.layer_norm(x, self.layer_norm, mfma_only=True), self.w_1, self.w_2,
+                                 self.dropout_1.p if self.training else 0.0)
             return ops.dropout(y, self.dropout_2.p, self.training) + x
         h = ops.linear(ops.layer_norm(x, self.layer_norm), self.w_1.weight, self.w_1.bias, relu=1)
         h = ops.dropout(h, self.dropout_1.p, self.training)
@@ -77,6 +77,7 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, inputs, mask):
-        n = ops.layer_norm(inputs, self.layer_norm)
+        packed = ops.self_attention_packed_ok(inputs, self.self_attn.head_count, mask)
+        n = ops.layer_norm(inputs, self.layer_norm, mfma_only=packed)
         ctx, _ = self.self_attn(n, n, n, mask=mask, type="self")
         return self.feed_forward(ops.dropout(ctx, self.dropout.p, self.training) + inputs)

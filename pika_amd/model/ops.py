@@ -23,12 +23,13 @@ def _gemm_ok(*dims):
     return all(d % 4 == 0 for d in dims)
 
 
-def linear(x, weight, bias=None, relu=False):
-    """nn.Linear semantics (+ optional fused ReLU epilogue); MFMA GEMM kernel on the GPU."""
+def linear(x, weight, bias=None, relu=False, out_bf16=False):
+    """nn.Linear semantics (+ optional fused ReLU epilogue); MFMA GEMM kernel on the GPU.
+    out_bf16 (bf16 mode only): the result only feeds MFMA products."""
     if _hip(x) and _gemm_ok(weight.shape[1]):
         from .hipops import LinearFn
-        return LinearFn.apply(x, weight, bias, relu)
-    y = F.linear(x, weight, bias)
+        return LinearFn.apply(x, weight, bias, relu, bool(out_bf16 and _bf16_mode()))
+    y = F.linear(x.to(weight.dtype), weight, bias)
     return F.relu(y) if relu else y
 
 
@@ -65,7 +66,14 @@ def _bn_momentum(bn):
     return 0.0 if bn.momentum is None else bn.momentum
 
 
-def layer_norm(x, ln):
+def layer_norm(x, ln, mfma_only=False):
+    """nn.LayerNorm over the last dim.  mfma_only: every consumer of the result is an MFMA product
+    (projection / feed-forward GEMMs), so in the bf16 arithmetic mode it is produced in bf16."""
+    C = x.shape[-1]
+    if (_hip(x) and x.dtype == torch.float32 and len(ln.normalized_shape) == 1 and ln.weight is not None
+            and ln.bias is not None and C % 4 == 0 and C <= 2048):
+        from .hipops import LayerNormFn
+        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, bool(mfma_only and _bf16_mode() and C % 64 == 0))
     return F.layer_norm(x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
@@ -134,6 +142,13 @@ def attention(q, k, v, heads, mask, p_drop, training):
     return ctx.transpose(1, 2).contiguous().view(B, Tq, HD)
 
 
+def feed_forward_applies(x, w_1, w_2):
+    if not _hip(x):
+        return False
+    from .hipops import feed_forward_ok
+    return feed_forward_ok(x, w_1.weight, w_2.weight)
+
+
 def feed_forward(xn, w_1, w_2, p_drop):
     """w_2(dropout(relu(w_1(xn)))) through the fused bf16-hidden path, or None when it does not apply
     (CPU, parity mode, odd widths): the caller then runs the plain chain."""
@@ -160,7 +175,7 @@ def self_attention_packed(x, wq, bq, wk, bk, wv, bv, heads, p_drop, training):
     from .hipops import PackedAttentionFn
     w = torch.cat([wq, wk, wv], 0)
     b = torch.cat([bq, bk, bv], 0)
-    qkv = linear(x, w, b)
+    qkv = linear(x, w, b, out_bf16=True)
     drop = p_drop if training else 0.0
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop > 0 else 0
     return PackedAttentionFn.apply(qkv, heads, drop, seed)

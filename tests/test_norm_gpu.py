@@ -34,3 +34,31 @@ def test_batch_norm_forward_backward_running_stats(hip_device, M, C):
     assert torch.allclose(ours.running_mean.double().cpu(), ref2.running_mean, atol=1e-5)
     assert torch.allclose(ours.running_var.double().cpu(), ref2.running_var, rtol=1e-4, atol=1e-5)
     assert int(ours.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("rows,C", [(1, 4), (7, 100), (300, 1024), (5000, 1024), (33, 2048), (65, 64)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_layer_norm_forward_backward(hip_device, rows, C, bf16):
+    """LayerNormFn (include/pika_norm.h) vs torch fp64 layer_norm; the bf16 variant rounds the output once
+    and accepts a bf16 incoming gradient (what the MFMA consumers would do to an fp32 tensor anyway)."""
+    import torch.nn.functional as F
+    from pika_amd.model.hipops import LayerNormFn
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 2 + 0.5
+    w = torch.randn(C, generator=g)
+    b = torch.randn(C, generator=g)
+    gy = torch.randn(rows, C, generator=g)
+    if bf16:
+        gy = gy.bfloat16().float()
+    ref = [t.double().requires_grad_(True) for t in (x, w, b)]
+    yr = F.layer_norm(ref[0], (C,), ref[1], ref[2], 1e-6)
+    (yr * gy.double()).sum().backward()
+    dev = [t.to(hip_device).requires_grad_(True) for t in (x, w, b)]
+    y = LayerNormFn.apply(dev[0], dev[1], dev[2], 1e-6, bf16)
+    assert y.dtype == (torch.bfloat16 if bf16 else torch.float32)
+    tol = 2 ** -8 if bf16 else 2e-6
+    assert (y.double().cpu() - yr.detach()).abs().max() < tol * max(1.0, yr.detach().abs().max().item())
+    (y * gy.to(hip_device).to(y.dtype)).sum().backward()
+    for a, r in zip(dev, ref):
+        s = r.grad.abs().max().item()
+        assert (a.grad.double().cpu() - r.grad).abs().max() < 2e-5 * max(s, 1.0) * (rows ** 0.5 if a.dim() == 1 else 1.0)
