@@ -79,6 +79,17 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
                              const int *labels_lengths, int B, int T, int U1,
                              float *alphas, float *betas, void *stream);
 
+/* For a producer that computed log_probs = log_softmax(scale * logits) itself (the joint network,
+ * trainer/model/transducer.py:108-111): d(loss)/d(logits) as a bf16 matrix (rows = B*T*U1, pitch ld_out,
+ * columns [V, ld_out) zero) straight from the two non-zeros per row that the matching
+ * pika_rnnt_loss_backward call left in `workspace` -- the dense gradient (B,T,U1,V) is written by that
+ * call as the contract demands, but need not be read back:
+ *   out[r, v] = scale * (grad[r, v] - exp(log_probs[r, v]) * sum_v' grad[r, v']).
+ * V % 4 == 0, V <= 5120, ld_out % 4 == 0. */
+int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace, int B, int T, int U1,
+                                   int V, int blank, void *out, long long ld_out, float scale,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

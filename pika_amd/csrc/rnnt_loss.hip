@@ -486,6 +486,49 @@ void launch_ab(const Lattice &L, const int *Tn, const int *Un, float *costs, int
                        L.D);
 }
 
+// d(logits) of log_softmax(scale * logits) under the RNN-T gradient WITHOUT reading the dense gradient:
+// row r of it has at most two non-zeros, kept in meta[r] by the backward call; with s = gb + ge
+//   out[r, v] = scale * ((v == blank) * gb + (v == ye) * ge - exp(lp[r, v]) * s)      (bf16, zero-padded)
+// One wavefront per row (V <= 64*4*CQ, V % 4 == 0), 16-byte loads, 8-byte stores.
+constexpr int CQ = 20;
+typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *__restrict__ lp,
+                                                                   const RowMeta *__restrict__ meta,
+                                                                   __bf16 *__restrict__ out, long long rows,
+                                                                   int V, long long ld_out, int blank,
+                                                                   float scale) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = V >> 2, o4 = (int)(ld_out >> 2);
+    const RowMeta m = meta[r];
+    const float s = m.gb + m.ge;
+    const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * V);
+    cbf16x4 *orow = reinterpret_cast<cbf16x4 *>(out + r * ld_out);
+    f32x4 v[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q)
+        if (lane + q * 64 < c4) v[q] = lrow[lane + q * 64];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        const int i = lane + q * 64;
+        if (i < c4) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 4 * i + e;
+                float g = col == blank ? m.gb : 0.f;
+                if (col == m.ye) g += m.ge;
+                o[e] = scale * (g - __expf(v[q][e]) * s);
+            }
+            orow[i] = __builtin_convertvector(o, cbf16x4);
+        } else if (i < o4) {
+            orow[i] = cbf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -579,6 +622,24 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
     hipLaunchKernelGGL(rnnt_export_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), L.alpha, L.beta, L.off_a, L.off_b,
                        frames_lengths, labels_lengths, B, T, U1, L.Wp, L.D, alphas, betas);
+    return (int)hipGetLastError();
+}
+
+int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace, int B, int T, int U1,
+                                   int V, int blank, void *out, long long ld_out, float scale,
+                                   void *stream) {
+    if (!log_probs || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
+        blank >= V)
+        return PIKA_EINVAL;
+    if ((V & 3) || V > 64 * 4 * CQ || ld_out < V || (ld_out & 3) || ld_out > 64 * 4 * CQ ||
+        (reinterpret_cast<uintptr_t>(log_probs) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
+        return PIKA_EINVAL;
+    const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+    const long long rows = (long long)B * T * U1;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(rnnt_dlogits_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), log_probs, L.meta, static_cast<__bf16 *>(out), rows, V,
+                       ld_out, blank, scale);
     return (int)hipGetLastError();
 }
 

@@ -369,6 +369,8 @@ class JointOutFn(torch.autograd.Function):
               zero-padded reduction), dW2 = d(logits)^T @ h (both read in place as `trans`
               operands), db2 = column sums."""
 
+    compact_hits = 0   # times the backward used the loss' compact gradient (tests / diagnostics)
+
     @staticmethod
     def forward(ctx, h, weight, bias, scale):
         N, K = weight.shape
@@ -394,9 +396,20 @@ class JointOutFn(torch.autograd.Function):
         dh = dw = db = None
         with torch.cuda.device(g.device):
             dl = torch.empty((M, Np), dtype=torch.bfloat16, device=g.device)
-            _lib.check(_lib.lib().pika_log_softmax_bwd_rows_bf16(
-                lp.data_ptr(), g.data_ptr(), dl.data_ptr(), M, N, N, Np, ctx.scale, _stream()),
-                "pika_log_softmax_bwd_rows_bf16")
+            compact = getattr(g, "_pika_compact", None)
+            if (compact is not None and compact.matches(g) and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape)
+                    and N <= 5120):
+                # g is the RNN-T loss' own dense gradient, untouched: take its two non-zeros per row from the
+                # loss workspace instead of reading 4 bytes x B*T*U*V back (include/pika_rnnt.h)
+                B_, T_, U1_, V_, blank = compact.dims
+                _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16(
+                    lp.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_, blank, dl.data_ptr(), Np, ctx.scale,
+                    _stream()), "pika_rnnt_dlogits_compact_bf16")
+                JointOutFn.compact_hits += 1
+            else:
+                _lib.check(_lib.lib().pika_log_softmax_bwd_rows_bf16(
+                    lp.data_ptr(), g.data_ptr(), dl.data_ptr(), M, N, N, Np, ctx.scale, _stream()),
+                    "pika_log_softmax_bwd_rows_bf16")
             del g
             if ctx.needs_input_grad[0]:
                 wt = torch.zeros((K, Np), dtype=torch.bfloat16, device=dl.device)

@@ -75,6 +75,21 @@ def _check_inputs(log_probs, labels, frames_lengths, labels_lengths, blank):
         raise ValueError("U+1=%d > 1024 not supported" % U1)
 
 
+class CompactGrad(object):
+    """What the backward leaves on the dense gradient tensor it returns (`grads._pika_compact`): the
+    workspace whose row metadata hold the (at most two) non-zeros of every V-row.  A consumer that
+    produced log_probs itself (pika_amd.model.hipops.JointOutFn) may use it instead of reading the
+    7.8 GB dense tensor back -- only if the tensor it received IS this tensor, unmodified (`matches`)."""
+
+    __slots__ = ("ws", "dims", "ptr", "version")
+
+    def __init__(self, ws, dims, grads):
+        self.ws, self.dims, self.ptr, self.version = ws, dims, grads.data_ptr(), grads._version
+
+    def matches(self, g):
+        return g.data_ptr() == self.ptr and g._version == self.version and tuple(g.shape) == tuple(self.dims[:4])
+
+
 class _RNNTLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0):
@@ -109,6 +124,7 @@ class _RNNTLossFn(torch.autograd.Function):
                 _lib.check(lib.pika_rnnt_loss_backward(
                     _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
                     _ptr(gc), _ptr(ws), _ptr(grads), _stream()), "pika_rnnt_loss_backward")
+        grads._pika_compact = CompactGrad(ws, (B, T, U1, V, blank), grads)
         return grads, None, None, None, None
 
 

@@ -85,3 +85,42 @@ def test_joint_output_fn(hip_device, M, V, H, scale):
             assert abs((got.double().cpu() - want).mean().item()) < 1e-3 * s
     finally:
         G.PRECISION = old
+
+
+def test_joint_backward_uses_compact_rnnt_gradient(hip_device):
+    """log_probs from JointOutFn straight into the RNN-T loss: the joint backward recognises the loss' own
+    dense gradient tensor and rebuilds d(logits) from the two non-zeros per row kept in the loss workspace
+    (pika_rnnt_dlogits_compact_bf16) -- same parameter gradients as the dense path; any tensor that is
+    not that exact gradient (here: scaled by a hook) takes the dense path."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
+    from pika_amd.rnnt import RNNTLoss
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(3)
+        B, T, U, H, V = 2, 11, 4, 64, 40
+        h = (torch.randn(B, T, U + 1, H, generator=g) * 0.5).bfloat16().to(hip_device)
+        w = (torch.randn(V, H, generator=g) * 0.3).to(hip_device)
+        b = (torch.randn(V, generator=g) * 0.1).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        tl = torch.tensor([T, T - 3], dtype=torch.int32, device=hip_device)
+        ul = torch.tensor([U, U - 1], dtype=torch.int32, device=hip_device)
+
+        def run(hook):
+            hh = h.clone().requires_grad_(True)
+            ww = w.clone().requires_grad_(True)
+            bb = b.clone().requires_grad_(True)
+            lp = JointOutFn.apply(hh, ww, bb, 1.0)
+            if hook:
+                lp.register_hook(lambda t: t * 1.0)     # a NEW tensor reaches the joint backward
+            RNNTLoss().apply(lp, labels, tl, ul).sum().backward()
+            return hh.grad.float(), ww.grad, bb.grad
+        before = JointOutFn.compact_hits
+        compact = run(False)
+        assert JointOutFn.compact_hits == before + 1
+        dense = run(True)
+        assert JointOutFn.compact_hits == before + 1
+        for a, d in zip(compact, dense):
+            assert torch.allclose(a, d, rtol=1e-5, atol=1e-6 * d.abs().max().item())
+    finally:
+        G.PRECISION = old
