@@ -90,6 +90,17 @@ int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long lo
 int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, float p_drop, unsigned seed,
                            void *stream);
 
+/* out f32 (pitch ldo) = dropout_p(A B^T + bias) + residual (f32, pitch ld_res): a projection with its residual
+ * dropout and residual add (reference trainer/model/transformer.py:98-99 `self.dropout(context) + inputs`,
+ * position_ffn.py:38-39 `output + x`) in the product's epilogue; same keep hash as PIKA_EPI_DROPOUT_BF16. */
+int pika_gemm_bf16_dropout_residual(const void *A, long long lda, const void *B, long long ldb, float *out,
+                                    long long ldo, int M, int N, int K, const float *bias, float p_drop,
+                                    unsigned seed, const float *residual, long long ld_res, void *stream);
+/* out bf16 (pitch ld_out) = keep(m,n) ? x * 1/(1-p) : 0 for x f32 (rows, cols), cols % 4 == 0: the backward of
+ * that dropout fused with the bf16 rounding of the gradient's consumers. */
+int pika_dropout_mask_cast_bf16(const float *x, long long ld, int rows, int cols, float p_drop, unsigned seed,
+                                void *out, long long ld_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

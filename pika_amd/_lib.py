@@ -35,6 +35,9 @@ SIGNATURES = {
     "pika_gemm_bf16_epilogue": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _i, _i, ctypes.c_float,
                                      ctypes.c_uint, _vp, _ll, ctypes.c_float, _vp]),
     "pika_dropout_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_gemm_bf16_dropout_residual": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, ctypes.c_float,
+                                             ctypes.c_uint, _vp, _ll, _vp]),
+    "pika_dropout_mask_cast_bf16": (_i, [_vp, _ll, _i, _i, ctypes.c_float, ctypes.c_uint, _vp, _ll, _vp]),
     # include/pika_attn.h
     "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _ll, _ll, ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,

@@ -149,7 +149,9 @@ struct PPArgs {
     const __bf16 *aux;
     long long ldo16, ld_aux;
     float scale;                       // EPI 1: 1/(1-p) for kept values; EPI 2: factor for unmasked values
-    unsigned seed, thr;                // EPI 1: drop where hash16 < thr (thr = 0: no dropout)
+    unsigned seed, thr;                // EPI 1, 3: drop where hash16 < thr (thr = 0: no dropout)
+    const float *res;                  // EPI 3: fp32 residual added after the dropout
+    long long ld_res;
 };
 
 // counter-based dropout decisions for the four consecutive columns n..n+3 (n % 4 == 0) of row m
@@ -169,6 +171,7 @@ __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast
 
 // EPI 0: C f32 = act(A B^T + bias).   EPI 1: out16 bf16 = dropout(act(A B^T + bias)).
 // EPI 2: out16 bf16 = scale * (A B^T) where aux > 0, else 0  (ReLU + dropout backward in one mask).
+// EPI 3: C f32 = dropout(A B^T + bias) + res  (projection + residual dropout + residual add).
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -337,7 +340,18 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 }
                 if (P.relu) v = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
             }
-            if constexpr (EPI == 0) {
+            if constexpr (EPI == 3) {
+                if (P.thr) {
+                    bool keep[4];
+                    pp_keep4(P.seed, (unsigned)m, (unsigned)n, P.thr, keep);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * P.scale : 0.f;
+                }
+                const float *rp = P.res + (long long)m * P.ld_res + n;
+                if (n + 3 < N) v += *reinterpret_cast<const f32x4 *>(rp);
+                else for (int e = 0; e < 4; ++e) if (n + e < N) v[e] += rp[e];
+            }
+            if constexpr (EPI == 0 || EPI == 3) {
                 if (n + 3 < N) {
                     *reinterpret_cast<f32x4 *>(C + (long long)m * P.ldc + n) = v;
                 } else {
@@ -618,6 +632,27 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
 
 int launch_pp(const PPArgs &P, hipStream_t s) { return launch_pp_epi<0>(P, s); }
 
+// out bf16 = keep(m, n) ? x * scale : 0 -- the dropout backward of an EPI 1/3 product fused with the bf16
+// rounding its consumers (dX / dW products) apply anyway.  cols % 4 == 0.
+__global__ __launch_bounds__(256) void pp_mask_cast_kernel(const float *__restrict__ x, long long ld, int rows,
+                                                           int cols, unsigned seed, unsigned thr, float scale,
+                                                           __bf16 *__restrict__ out, long long ld_out) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const int c4 = cols >> 2;
+    const long long total = (long long)rows * c4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int m = (int)(idx / c4), n = (int)(idx - (long long)m * c4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(x + (long long)m * ld + n);
+        if (thr) {
+            bool keep[4];
+            pp_keep4(seed, (unsigned)m, (unsigned)n, thr, keep);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * scale : 0.f;
+        }
+        *reinterpret_cast<bf16x4 *>(out + (long long)m * ld_out + n) = __builtin_convertvector(v, bf16x4);
+    }
+}
+
 __global__ __launch_bounds__(256) void pp_keep_mask_kernel(unsigned char *mask, int rows, int cols, unsigned seed,
                                                            unsigned thr) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, c4 = (cols + 3) >> 2;
@@ -777,6 +812,42 @@ extern "C" int pika_gemm_bf16_epilogue(const void *A, long long lda, const void 
     }
     P.scale = scale;
     return launch_pp_epi<2>(P, s);
+}
+
+extern "C" int pika_gemm_bf16_dropout_residual(const void *A, long long lda, const void *B, long long ldb,
+                                               float *out, long long ldo, int M, int N, int K, const float *bias,
+                                               float p_drop, unsigned seed, const float *residual,
+                                               long long ld_res, void *stream) {
+    if (!A || !B || !out || !residual || M <= 0 || N <= 0 || K <= 0) return PIKA_EINVAL;
+    if ((K % BK) || (lda & 7) || (ldb & 7) || (ldo & 3) || (ld_res & 3) ||
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out) |
+          reinterpret_cast<uintptr_t>(residual)) & 15))
+        return PIKA_EINVAL;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return PIKA_EINVAL;
+    PPArgs P{};
+    P.A = static_cast<const __bf16 *>(A); P.B = static_cast<const __bf16 *>(B); P.bias = bias; P.C = out;
+    P.ldb = ldb; P.ldc = ldo; P.a_rpb = M; P.a_batch = 0; P.a_row = lda; P.a_tap = 0; P.a_C = K;
+    P.M = M; P.N = N; P.K = K; P.relu = 0;
+    P.res = residual; P.ld_res = ld_res;
+    P.thr = (unsigned)lrintf(p_drop * 65536.f);
+    P.scale = 65536.f / (float)(65536u - P.thr);
+    P.seed = seed;
+    return launch_pp_epi<3>(P, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pika_dropout_mask_cast_bf16(const float *x, long long ld, int rows, int cols, float p_drop,
+                                           unsigned seed, void *out, long long ld_out, void *stream) {
+    if (!x || !out || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3) || (ld_out & 3) || ld < cols || ld_out < cols)
+        return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return PIKA_EINVAL;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return PIKA_EINVAL;
+    const unsigned thr = (unsigned)lrintf(p_drop * 65536.f);
+    const long long total = (long long)rows * (cols >> 2);
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pp_mask_cast_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ld, rows, cols, seed, thr,
+                       65536.f / (float)(65536u - thr), static_cast<__bf16 *>(out), ld_out);
+    return (int)hipGetLastError();
 }
 
 extern "C" int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, float p_drop, unsigned seed,

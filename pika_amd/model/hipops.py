@@ -546,6 +546,70 @@ def dropout_keep_mask(rows, cols, p_drop, seed, device):
     return m.bool()
 
 
+def _gemm_dropout_residual(a, b, out, bias, p_drop, seed, residual):
+    M, K = a.shape
+    N = b.shape[0]
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().pika_gemm_bf16_dropout_residual(
+            a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+            None if bias is None else bias.data_ptr(), float(p_drop), int(seed), residual.data_ptr(),
+            residual.stride(0), _stream()), "pika_gemm_bf16_dropout_residual(M=%d,N=%d,K=%d)" % (M, N, K))
+    return out
+
+
+def _mask_cast(x2d, p_drop, seed):
+    """bf16 copy of a gradient with the dropout backward (same hash as the forward epilogue) applied."""
+    out = torch.empty(x2d.shape, dtype=torch.bfloat16, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        _lib.check(_lib.lib().pika_dropout_mask_cast_bf16(
+            x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1], float(p_drop), int(seed), out.data_ptr(),
+            out.stride(0), _stream()), "pika_dropout_mask_cast_bf16")
+    return out
+
+
+def linear_dropout_residual_ok(x, weight, residual):
+    N, K = weight.shape
+    return (G.PRECISION == "bf16" and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.float32
+            and K % 64 == 0 and N % 64 == 0 and residual.shape[-1] == N and residual.is_contiguous())
+
+
+class LinearDropoutResidualFn(torch.autograd.Function):
+    """dropout(x @ W^T + b) + residual in ONE GEMM (x bf16, output fp32): the attention output projection with
+    the layer's residual dropout and add (transformer.py:98-99).  Backward: the dropout mask is re-applied
+    while the incoming gradient is rounded to bf16 for the dX / dW products; the residual gets it as is."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, p_drop, seed):
+        N, K = weight.shape
+        x2 = x.reshape(-1, K).contiguous()
+        out = torch.empty(residual.shape, dtype=torch.float32, device=x.device)
+        _gemm_dropout_residual(x2, weight.detach().to(torch.bfloat16), out.view(-1, N), bias, p_drop, seed,
+                               residual.view(-1, N))
+        ctx.cfg = (float(p_drop), int(seed), x.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, weight = ctx.saved_tensors
+        p_drop, seed, xshape = ctx.cfg
+        N, K = weight.shape
+        d2 = dout.reshape(-1, N).contiguous()
+        M = d2.shape[0]
+        dx = dw = db = None
+        with torch.cuda.device(dout.device):
+            dyb = _mask_cast(d2, p_drop, seed)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(xshape, dtype=torch.bfloat16, device=dout.device)
+                _gemm_epilogue(dyb, _weight_t(weight), dx.view(-1, K), None, EPI_DROPOUT_BF16)
+            if ctx.needs_input_grad[1]:
+                dw = _grad_weight(dyb, G.matrix(x2)[0], 8, M, K, N)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum_any(dyb)
+        return dx, dw, db, (dout if ctx.needs_input_grad[3] else None), None, None
+
+
 def feed_forward_ok(x, w1, w2):
     d, f = w1.shape[1], w1.shape[0]
     return (G.PRECISION == "bf16" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and d % 64 == 0 and f % 64 == 0
@@ -560,7 +624,7 @@ class FeedForwardFn(torch.autograd.Function):
     backward `hidden > 0` is both the ReLU and the dropout mask, applied by the epilogue of dh = dy W2."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, p_drop, seed):
+    def forward(ctx, x, w1, b1, w2, b2, p_drop, seed, residual=None, p2=0.0, seed2=0):
         d = x.shape[-1]
         ctx.x_bf16 = x.dtype == torch.bfloat16
         xb = x.reshape(-1, d).to(torch.bfloat16).contiguous()
@@ -568,7 +632,12 @@ class FeedForwardFn(torch.autograd.Function):
         h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
         _gemm_epilogue(xb, w1.detach().to(torch.bfloat16), h, b1, EPI_DROPOUT_BF16, relu=1, p_drop=p_drop, seed=seed)
         y = torch.empty(x.shape[:-1] + (N2,), dtype=torch.float32, device=x.device)
-        G.gemm_bf16_nt(h, w2.detach().to(torch.bfloat16), bias=b2, out=y.view(-1, N2))
+        if residual is not None:   # dropout_2(w_2(.)) + x of position_ffn.py:38-39 in the second GEMM's epilogue
+            _gemm_dropout_residual(h, w2.detach().to(torch.bfloat16), y.view(-1, N2), b2, p2, seed2,
+                                   residual.contiguous().view(-1, N2))
+        else:
+            G.gemm_bf16_nt(h, w2.detach().to(torch.bfloat16), bias=b2, out=y.view(-1, N2))
+        ctx.res = (residual is not None, float(p2), int(seed2))
         ctx.cfg = (float(p_drop), x.shape)
         ctx.save_for_backward(xb, h, w1, w2)
         return y
@@ -579,7 +648,8 @@ class FeedForwardFn(torch.autograd.Function):
         p_drop, xshape = ctx.cfg
         M, F, N2, d = xb.shape[0], w1.shape[0], w2.shape[0], xb.shape[1]
         dy2 = dy.reshape(-1, N2).contiguous()
-        dyb = dy2.to(torch.bfloat16)
+        has_res, p2, seed2 = ctx.res
+        dyb = _mask_cast(dy2, p2, seed2) if has_res else dy2.to(torch.bfloat16)
         thr = round(p_drop * 65536)
         dh = torch.empty((M, F), dtype=torch.bfloat16, device=dy.device)
         _gemm_epilogue(dyb, w2.detach().t().contiguous().to(torch.bfloat16), dh, None, EPI_MASK_BF16, aux=h,
@@ -589,7 +659,7 @@ class FeedForwardFn(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 dw2 = _grad_weight(dyb, G.matrix(h)[0], 8, M, F, N2)
             if ctx.needs_input_grad[4]:
-                db2 = colsum(dy2)
+                db2 = colsum_any(dyb) if has_res else colsum(dy2)
             if ctx.needs_input_grad[1]:
                 dw1 = _grad_weight(dh, G.matrix(xb)[0], 8, M, d, F)
             if ctx.needs_input_grad[2]:
@@ -603,7 +673,8 @@ class FeedForwardFn(torch.autograd.Function):
                     _gemm_epilogue(dh, w1t, dx.view(-1, d), None, EPI_DROPOUT_BF16)
                 else:
                     dx = G.gemm_bf16_nt(dh, w1t).view(xshape)
-        return dx, dw1, db1, dw2, db2, None, None
+        dres = dy if (has_res and ctx.needs_input_grad[7]) else None
+        return dx, dw1, db1, dw2, db2, None, None, dres, None, None
 
 
 class BatchNormFn(torch.autograd.Function):

@@ -19,9 +19,9 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         if ops.feed_forward_applies(x, self.w_1, self.w_2):
-            y = ops.feed_forward(ops.layer_norm(x, self.layer_norm, mfma_only=True), self.w_1, self.w_2,
-                                 self.dropout_1.p if self.training else 0.0)
-            return ops.dropout(y, self.dropout_2.p, self.training) + x
+            return ops.feed_forward(ops.layer_norm(x, self.layer_norm, mfma_only=True), self.w_1, self.w_2,
+                                    self.dropout_1.p if self.training else 0.0, residual=x,
+                                    p_residual=self.dropout_2.p if self.training else 0.0)
         h = ops.linear(ops.layer_norm(x, self.layer_norm), self.w_1.weight, self.w_1.bias, relu=1)
         h = ops.dropout(h, self.dropout_1.p, self.training)
         y = ops.linear(h, self.w_2.weight, self.w_2.bias)
@@ -48,7 +48,10 @@ class MultiHeadedAttention(nn.Module):
         if max_relative_positions > 0:
             raise NotImplementedError("relative positions are off the RNN-T hot path (SURVEY 8a row 7)")
 
-    def forward(self, key, value, query, mask=None, layer_cache=None, type=None):
+    def forward(self, key, value, query, mask=None, layer_cache=None, type=None, residual=None,
+                residual_dropout=0.0):
+        """residual (not in the reference signature): when given, returns dropout(out) + residual, which the
+        packed self-attention path folds into the output projection."""
         if layer_cache is not None:
             raise NotImplementedError("layer_cache is off the RNN-T hot path (SURVEY 8a row 7)")
         if key is value and value is query and ops.self_attention_packed_ok(query, self.head_count, mask):
@@ -56,6 +59,8 @@ class MultiHeadedAttention(nn.Module):
                                             self.linear_keys.weight, self.linear_keys.bias,
                                             self.linear_values.weight, self.linear_values.bias,
                                             self.head_count, self.dropout.p, self.training)
+            if residual is not None:
+                return ops.linear_dropout_residual(ctx, self.final_linear, residual, residual_dropout), None
             return ops.linear(ctx, self.final_linear.weight, self.final_linear.bias), None
         k = ops.linear(key, self.linear_keys.weight, self.linear_keys.bias)
         v = ops.linear(value, self.linear_values.weight, self.linear_values.bias)
@@ -79,5 +84,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, inputs, mask):
         packed = ops.self_attention_packed_ok(inputs, self.self_attn.head_count, mask)
         n = ops.layer_norm(inputs, self.layer_norm, mfma_only=packed)
+        if packed:   # residual dropout + add folded into the output projection
+            out, _ = self.self_attn(n, n, n, mask=mask, type="self", residual=inputs,
+                                    residual_dropout=self.dropout.p if self.training else 0.0)
+            return self.feed_forward(out)
         ctx, _ = self.self_attn(n, n, n, mask=mask, type="self")
         return self.feed_forward(ops.dropout(ctx, self.dropout.p, self.training) + inputs)

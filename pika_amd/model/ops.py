@@ -149,16 +149,33 @@ def feed_forward_applies(x, w_1, w_2):
     return feed_forward_ok(x, w_1.weight, w_2.weight)
 
 
-def feed_forward(xn, w_1, w_2, p_drop):
+def _seed(p):
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0   # CPU generator: no device sync
+
+
+def feed_forward(xn, w_1, w_2, p_drop, residual=None, p_residual=0.0):
     """w_2(dropout(relu(w_1(xn)))) through the fused bf16-hidden path, or None when it does not apply
-    (CPU, parity mode, odd widths): the caller then runs the plain chain."""
+    (CPU, parity mode, odd widths): the caller then runs the plain chain.  With `residual` the result is
+    dropout_{p_residual}(that) + residual, fused into the second GEMM."""
     if not _hip(xn):
         return None
     from .hipops import FeedForwardFn, feed_forward_ok
     if not feed_forward_ok(xn, w_1.weight, w_2.weight):
         return None
-    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
-    return FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, seed)
+    if residual is not None and residual.dtype == torch.float32:
+        return FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, _seed(p_drop),
+                                   residual, p_residual, _seed(p_residual))
+    y = FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, _seed(p_drop))
+    return y if residual is None else dropout(y, p_residual, p_residual > 0) + residual
+
+
+def linear_dropout_residual(x, lin, residual, p_drop):
+    """dropout_p(lin(x)) + residual; one GEMM when x is a bf16 activation (see LinearDropoutResidualFn)."""
+    if _hip(x):
+        from .hipops import LinearDropoutResidualFn, linear_dropout_residual_ok
+        if linear_dropout_residual_ok(x, lin.weight, residual):
+            return LinearDropoutResidualFn.apply(x, lin.weight, lin.bias, residual, p_drop, _seed(p_drop))
+    return dropout(linear(x, lin.weight, lin.bias), p_drop, p_drop > 0) + residual
 
 
 def self_attention_packed_ok(x, heads, mask):

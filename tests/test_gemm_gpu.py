@@ -318,3 +318,37 @@ def test_feed_forward_fn(hip_device, M, d, F, p):
             assert (a.grad.double().cpu() - b.grad).norm() < 6e-3 * b.grad.norm()
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("M,K,N,p", [(300, 64, 128, 0.0), (1000, 128, 256, 0.2)])
+def test_linear_dropout_residual_fn(hip_device, M, K, N, p):
+    """LinearDropoutResidualFn: dropout(x W^T + b) + residual in one GEMM epilogue, backward with the mask
+    re-applied while rounding the gradient to bf16; vs the fp64 formula with the kernel's own keep mask."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import LinearDropoutResidualFn, dropout_keep_mask
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(M + N)
+        x = torch.randn(M, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) * 0.2).bfloat16().float()
+        b = torch.randn(N, generator=g) * 0.1
+        res = torch.randn(M, N, generator=g)
+        gy = torch.randn(M, N, generator=g)
+        seed = 777
+        xd = x.to(hip_device).requires_grad_(True)
+        wd, bd, rd = [t.to(hip_device).requires_grad_(True) for t in (w, b, res)]
+        y = LinearDropoutResidualFn.apply(xd, wd, bd, rd, p, seed)
+        (y * gy.to(hip_device)).sum().backward()
+        keep = dropout_keep_mask(M, N, p, seed, hip_device).cpu().double()
+        sc = 65536.0 / (65536 - round(p * 65536))
+        xr, wr, br, rr = [t.double().requires_grad_(True) for t in (x.float(), w, b, res)]
+        yr = (xr @ wr.t() + br) * keep * sc + rr
+        (yr * gy.double()).sum().backward()
+        assert (y.double().cpu() - yr.detach()).abs().max() < 1e-4 * yr.detach().abs().max()
+        assert torch.equal(rd.grad.cpu(), gy)                     # the residual gets the gradient as is
+        for got, want in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+            s = want.abs().max().item()
+            assert (got.double().cpu() - want).abs().max() < 1.5e-2 * s
+            assert (got.double().cpu() - want).norm() < 6e-3 * want.norm()
+    finally:
+        G.PRECISION = old
