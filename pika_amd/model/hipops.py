@@ -6,11 +6,18 @@ by pika_transpose_cast (fp32 -> bf16, or fp32 in fp32-split mode, written once),
 pika_colsum, the time-delay adjoint by pika_col2im.
 """
 import ctypes
+import os
 
 import torch
 
 from .. import _lib
 from .. import gemm as G
+
+
+def _fused():
+    """PIKA_NO_FUSED=1 (diagnostics, tools/mode_diff.py) turns the bf16 fast paths off: every product then goes
+    through pika_gemm_nt on fp32 tensors (operands rounded inside the kernel) and torch's attention chain."""
+    return os.environ.get("PIKA_NO_FUSED") is None
 
 
 def _stream():
@@ -54,7 +61,8 @@ def _bf16_operand(t, min_elems=1 << 21):
     here halves the bytes every GEMM that consumes the matrix pulls through L2 (the forward product
     and the weight-gradient product read the same copy, the three taps of a time-delay operand
     re-read it)."""
-    if G.PRECISION == "bf16" and t.dtype == torch.float32 and t.numel() >= min_elems and t.shape[-1] % 8 == 0:
+    if (G.PRECISION == "bf16" and _fused() and t.dtype == torch.float32 and t.numel() >= min_elems
+            and t.shape[-1] % 8 == 0):
         return t.to(torch.bfloat16)
     return t
 
@@ -354,7 +362,7 @@ def joint_out_ok(h, weight):
     """JointOutFn preconditions: bf16 hidden, reduction a multiple of 64, vocabulary a multiple of
     8 (16-byte bf16 granules of the d(logits) copy) that one wave covers (log-softmax row kernels)."""
     N, K = weight.shape
-    return (G.PRECISION == "bf16" and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
+    return (G.PRECISION == "bf16" and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
             and N <= 8192)
 
 
@@ -430,7 +438,7 @@ def attention_ok(q, k, v, heads, mask):
     """AttentionFn preconditions: the encoder's self-attention (no mask, Tq == Tk), head width 64
     or 128, bf16 arithmetic mode."""
     D = q.shape[-1] // heads
-    return (G.PRECISION == "bf16" and mask is None and q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
+    return (G.PRECISION == "bf16" and _fused() and mask is None and q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
             and q.shape == k.shape == v.shape and D in (64, 128) and D * heads == q.shape[-1])
 
 
@@ -569,7 +577,7 @@ def _mask_cast(x2d, p_drop, seed):
 
 def linear_dropout_residual_ok(x, weight, residual):
     N, K = weight.shape
-    return (G.PRECISION == "bf16" and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.float32
+    return (G.PRECISION == "bf16" and _fused() and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.float32
             and K % 64 == 0 and N % 64 == 0 and residual.shape[-1] == N and residual.is_contiguous())
 
 
@@ -612,7 +620,7 @@ class LinearDropoutResidualFn(torch.autograd.Function):
 
 def feed_forward_ok(x, w1, w2):
     d, f = w1.shape[1], w1.shape[0]
-    return (G.PRECISION == "bf16" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and d % 64 == 0 and f % 64 == 0
+    return (G.PRECISION == "bf16" and _fused() and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and d % 64 == 0 and f % 64 == 0
             and w2.shape[0] % 64 == 0 and x.numel() // d >= 256)
 
 
