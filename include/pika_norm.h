@@ -18,17 +18,21 @@ int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *st
 
 /* y = (x - mean) * rstd * gamma + beta with mean/var from `stats` (biased variance, eps inside the
  * sqrt); writes save_mean / save_rstd (C each, for the backward) and, when running_mean != NULL,
- * running = (1-momentum)*running + momentum*{mean, unbiased var}. */
+ * running = (1-momentum)*running + momentum*{mean, unbiased var}.  y_dtype PIKA_F32 | PIKA_BF16 (pika_gemm.h):
+ * bf16 when y only feeds an MFMA product (the next time-delay layer). */
 int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
                   const float *beta, float eps, float momentum, float *running_mean,
-                  float *running_var, float *save_mean, float *save_rstd, float *y, void *stream);
+                  float *running_var, float *save_mean, float *save_rstd, void *y, int y_dtype,
+                  void *stream);
 
 /* Backward, two launches: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (fp64); then
  * dx = gamma*rstd*(dy - sum_dy/rows - xhat*sum_dy_xhat/rows), dgamma = sum dy*xhat, dbeta = sum dy.
  * relu_mask != 0: x is the output of a ReLU (the reference computes bn(relu(conv(.)))) and dx is
- * additionally multiplied by (x > 0), i.e. the ReLU backward is folded into this pass. */
-int pika_bn_backward(const float *dy, const float *x, long long rows, int C, const float *gamma,
-                     const float *save_mean, const float *save_rstd, double *sums, float *dx,
+ * additionally multiplied by (x > 0), i.e. the ReLU backward is folded into this pass.  dy may arrive as bf16
+ * (y was produced as bf16) and dx may be written as bf16 (it only feeds the dX / dW products of the layer that
+ * produced x). */
+int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
+                     const float *save_mean, const float *save_rstd, double *sums, void *dx, int dx_dtype,
                      float *dgamma, float *dbeta, int relu_mask, void *stream);
 
 /* nn.LayerNorm over the last dimension of x (rows, C) f32 contiguous (pre-LN transformer layers,

@@ -60,8 +60,8 @@ SIGNATURES = {
     "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp]),
     "pika_bn_apply": (_i, [_vp, _ll, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp,
-                           _vp, _vp]),
-    "pika_bn_backward": (_i, [_vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+                           _vp, _i, _vp]),
+    "pika_bn_backward": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     # include/pika_decode.h
     "pika_beam_advance": (_i, [_vp, ctypes.c_float, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
                                _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,

@@ -15,34 +15,72 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWS_PER_BLOCK = 512;
 
-// MODE 0: (x, x^2).  MODE 1: (dy, dy*xhat)
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ a,
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ inline f32x4 ld4(const T *p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const f32x4 *>(p);
+    } else {
+        const bf16x4_t v = *reinterpret_cast<const bf16x4_t *>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+template <typename T>
+__device__ inline void st4(T *p, f32x4 v) {
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4 *>(p) = v;
+    else *reinterpret_cast<bf16x4_t *>(p) = __builtin_convertvector(v, bf16x4_t);
+}
+
+// MODE 0: (x, x^2).  MODE 1: (dy, dy*xhat).  Every lane owns 4 consecutive channels (16-byte loads), a wave
+// covers 256 channels of a row, the 4 waves of a block take rows r, r+1, r+2, r+3; four row-steps in flight.
+// `a` is f32 or bf16 (an incoming gradient may be bf16), x always f32.
+template <int MODE, typename TA>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const TA *__restrict__ a,
                                                         const float *__restrict__ x,
                                                         const float *__restrict__ mean,
                                                         const float *__restrict__ rstd,
                                                         long long rows, int C,
                                                         double *__restrict__ out) {
-    __shared__ float p0[4][64], p1[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    __shared__ f32x4 p0[4][64], p1[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
     const long long r0 = (long long)blockIdx.y * ROWS_PER_BLOCK;
     const long long r1 = min(rows, r0 + ROWS_PER_BLOCK);
-    float s0 = 0.f, s1 = 0.f;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
-        for (long long r = r0 + g; r < r1; r += 4) {
-            const float v = a[r * C + c];
-            if (MODE == 0) { s0 += v; s1 += v * v; }
-            else { s0 += v; s1 += v * ((x[r * C + c] - mu) * rs); }
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu;
+        if (MODE) { mu = *reinterpret_cast<const f32x4 *>(mean + c); rs = *reinterpret_cast<const f32x4 *>(rstd + c); }
+        long long r = r0 + g;
+        for (; r + 12 < r1; r += 16) {
+            f32x4 v[4], w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = ld4(a + (r + 4 * q) * C + c);
+                if (MODE) w[q] = *reinterpret_cast<const f32x4 *>(x + (r + 4 * q) * C + c);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s0 += v[q];
+                s1 += MODE ? v[q] * ((w[q] - mu) * rs) : v[q] * v[q];
+            }
+        }
+        for (; r < r1; r += 4) {
+            const f32x4 v = ld4(a + r * C + c);
+            s0 += v;
+            if (MODE) s1 += v * ((*reinterpret_cast<const f32x4 *>(x + r * C + c) - mu) * rs);
+            else s1 += v * v;
         }
     }
-    p0[g][threadIdx.x & 63] = s0;
-    p1[g][threadIdx.x & 63] = s1;
+    p0[g][lane] = s0;
+    p1[g][lane] = s1;
     __syncthreads();
     if (g == 0 && c < C) {
-        const int l = threadIdx.x;
-        atomicAdd(out + c, (double)p0[0][l] + (double)p0[1][l] + (double)p0[2][l] + (double)p0[3][l]);
-        atomicAdd(out + C + c, (double)p1[0][l] + (double)p1[1][l] + (double)p1[2][l] + (double)p1[3][l]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(out + c + e, (double)p0[0][lane][e] + (double)p0[1][lane][e] + (double)p0[2][lane][e] + (double)p0[3][lane][e]);
+            atomicAdd(out + C + c + e, (double)p1[0][lane][e] + (double)p1[1][lane][e] + (double)p1[2][lane][e] + (double)p1[3][lane][e]);
+        }
     }
 }
 
@@ -65,36 +103,38 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restri
     }
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, long long n4,
                                                        int C4, const float *__restrict__ mean,
                                                        const float *__restrict__ rstd,
                                                        const float *__restrict__ gamma,
                                                        const float *__restrict__ beta,
-                                                       float *__restrict__ y) {
+                                                       TO *__restrict__ y) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int c = (int)(i % C4);
         const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
         const f32x4 m = reinterpret_cast<const f32x4 *>(mean)[c], r = reinterpret_cast<const f32x4 *>(rstd)[c];
         const f32x4 g = reinterpret_cast<const f32x4 *>(gamma)[c], b = reinterpret_cast<const f32x4 *>(beta)[c];
-        reinterpret_cast<f32x4 *>(y)[i] = (v - m) * r * g + b;
+        st4(y + 4 * i, (v - m) * r * g + b);
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dy,
+template <typename TD, typename TX>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TD *__restrict__ dy,
                                                            const float *__restrict__ x, long long n4,
                                                            int C4, long long rows,
                                                            const float *__restrict__ mean,
                                                            const float *__restrict__ rstd,
                                                            const float *__restrict__ gamma,
                                                            const double *__restrict__ sums,
-                                                           float *__restrict__ dx, int relu_mask) {
+                                                           TX *__restrict__ dx, int relu_mask) {
     const long long stride = (long long)gridDim.x * 256;
     const float inv = 1.0f / (float)rows;
     const int C = C4 * 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int c = (int)(i % C4);
-        const f32x4 d = reinterpret_cast<const f32x4 *>(dy)[i], v = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 d = ld4(dy + 4 * i), v = reinterpret_cast<const f32x4 *>(x)[i];
         const f32x4 m = reinterpret_cast<const f32x4 *>(mean)[c], r = reinterpret_cast<const f32x4 *>(rstd)[c];
         const f32x4 g = reinterpret_cast<const f32x4 *>(gamma)[c];
         f32x4 sd, sx;
@@ -106,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
             o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f;
             o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
         }
-        reinterpret_cast<f32x4 *>(dx)[i] = o;
+        st4(dx + 4 * i, o);
     }
 }
 
@@ -239,55 +279,78 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
 }
 
 inline dim3 red_grid(long long rows, int C) {
-    return dim3((C + 63) / 64, (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    return dim3((C / 4 + 63) / 64, (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
 }
 inline int ew_grid(long long n4) { return (int)((n4 + 1023) / 1024 < 4096 ? (n4 + 1023) / 1024 : 4096); }
+
+template <typename TD, typename TX>
+int bn_backward_impl(const TD *dy, const float *x, long long rows, int C, const float *gamma,
+                            const float *save_mean, const float *save_rstd, double *sums, TX *dx,
+                            float *dgamma, float *dbeta, int relu_mask, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((bn_reduce_kernel<1, TD>), red_grid(rows, C), dim3(256), 0, s, dy, x, save_mean,
+                       save_rstd, rows, C, sums);
+    const long long n4 = rows * C / 4;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TD, TX>), dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, n4, C / 4, rows,
+                       save_mean, save_rstd, gamma, sums, dx, relu_mask);
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma,
+                       dbeta);
+    return (int)hipGetLastError();
+}
 
 }  // namespace
 
 extern "C" {
 
 int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *stream) {
-    if (!x || !stats || rows <= 0 || C <= 0) return PIKA_EINVAL;
+    if (!x || !stats || rows <= 0 || C <= 0 || (C & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, red_grid(rows, C), dim3(256), 0, s, x, x, nullptr, nullptr,
+    hipLaunchKernelGGL((bn_reduce_kernel<0, float>), red_grid(rows, C), dim3(256), 0, s, x, x, nullptr, nullptr,
                        rows, C, stats);
     return (int)hipGetLastError();
 }
 
 int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
                   const float *beta, float eps, float momentum, float *running_mean,
-                  float *running_var, float *save_mean, float *save_rstd, float *y, void *stream) {
+                  float *running_var, float *save_mean, float *save_rstd, void *y, int y_dtype,
+                  void *stream) {
     if (!x || !stats || !gamma || !beta || !save_mean || !save_rstd || !y || rows <= 0 || C <= 0 || (C & 3))
         return PIKA_EINVAL;
+    if (y_dtype != PIKA_F32 && y_dtype != PIKA_BF16) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, rows, C, eps,
                        momentum, running_mean, running_var, save_mean, save_rstd);
     const long long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
-                       save_rstd, gamma, beta, y);
+    if (y_dtype == PIKA_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
+                           save_rstd, gamma, beta, static_cast<float *>(y));
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<__bf16>, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
+                           save_rstd, gamma, beta, static_cast<__bf16 *>(y));
     return (int)hipGetLastError();
 }
 
-int pika_bn_backward(const float *dy, const float *x, long long rows, int C, const float *gamma,
-                     const float *save_mean, const float *save_rstd, double *sums, float *dx,
+int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
+                     const float *save_mean, const float *save_rstd, double *sums, void *dx, int dx_dtype,
                      float *dgamma, float *dbeta, int relu_mask, void *stream) {
     if (!dy || !x || !gamma || !save_mean || !save_rstd || !sums || !dx || !dgamma || !dbeta ||
         rows <= 0 || C <= 0 || (C & 3))
         return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, red_grid(rows, C), dim3(256), 0, s, dy, x, save_mean,
-                       save_rstd, rows, C, sums);
-    const long long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, n4, C / 4, rows,
-                       save_mean, save_rstd, gamma, sums, dx, relu_mask);
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma,
-                       dbeta);
-    return (int)hipGetLastError();
+    const float *dyf = static_cast<const float *>(dy);
+    const __bf16 *dyb = static_cast<const __bf16 *>(dy);
+    float *dxf = static_cast<float *>(dx);
+    __bf16 *dxb = static_cast<__bf16 *>(dx);
+#define BNB(DY, DX) return bn_backward_impl(DY, x, rows, C, gamma, save_mean, save_rstd, sums, DX, dgamma, dbeta, relu_mask, s)
+    if (dy_dtype == PIKA_F32 && dx_dtype == PIKA_F32) BNB(dyf, dxf);
+    if (dy_dtype == PIKA_F32 && dx_dtype == PIKA_BF16) BNB(dyf, dxb);
+    if (dy_dtype == PIKA_BF16 && dx_dtype == PIKA_F32) BNB(dyb, dxf);
+    if (dy_dtype == PIKA_BF16 && dx_dtype == PIKA_BF16) BNB(dyb, dxb);
+#undef BNB
+    return PIKA_EINVAL;
 }
 
 int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamma, const float *beta,

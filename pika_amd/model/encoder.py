@@ -1,4 +1,5 @@
 """TDNN-Transformer encoder (reference: trainer/model/rnnt_tdnn_transformer.py:27-89)."""
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -38,12 +39,21 @@ class Net(nn.Module):
         C = self.tdnn_nhid
         fuse = ops.fused_relu_bn_ok(x, self.bn_in)   # ReLU fwd in the GEMM epilogue, bwd in the BN backward
         h = ops.linear(x, self.fc_in.weight, self.fc_in.bias, relu=2 if fuse else 1)
-        h = ops.batch_norm(h.reshape(-1, C), self.bn_in, relu_input=fuse).view(B, -1, C)
+        n_layers = len(self.hidden_conv)
+        # a BatchNorm output that only feeds the next time-delay GEMM is produced in bf16 (bf16 mode)
+        feeds_tdnn = fuse and ops.tdnn_bn_ok(h, self.hidden_conv[0].weight, self.hidden_bn[0])
+        h = ops.batch_norm(h.reshape(-1, C), self.bn_in, relu_input=fuse, mfma_only=feeds_tdnn).view(B, -1, C)
         for i, (conv, bn) in enumerate(zip(self.hidden_conv, self.hidden_bn)):
-            fuse = ops.fused_relu_bn_ok(h, bn)
-            h = ops.tdnn(h, conv.weight, conv.bias, conv.dilation[0], conv.stride[0], relu=2 if fuse else 1)
-            h = ops.batch_norm(h.reshape(-1, C), bn, relu_input=fuse).view(B, -1, C)
-            if (i + 1) % 3 == 0:
+            to_transformer = (i + 1) % 3 == 0
+            if ops.tdnn_bn_ok(h, conv.weight, bn):
+                nxt_ok = (not to_transformer and i + 1 < n_layers)
+                h = ops.tdnn_bn(h, conv, bn, mfma_only=nxt_ok)
+            else:
+                fuse = ops.fused_relu_bn_ok(h, bn)
+                h = ops.tdnn(h.float() if h.dtype != torch.float32 else h, conv.weight, conv.bias,
+                             conv.dilation[0], conv.stride[0], relu=2 if fuse else 1)
+                h = ops.batch_norm(h.reshape(-1, C), bn, relu_input=fuse).view(B, -1, C)
+            if to_transformer:
                 h = self.transformer[i // 3](h, mask=None)
         h = ops.batch_norm(h.reshape(-1, C), self.bn_final)
         h = ops.linear(h, self.fc_out.weight, self.fc_out.bias).view(B, -1, self.output_dim)

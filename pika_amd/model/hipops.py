@@ -685,43 +685,116 @@ class FeedForwardFn(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None, None, dres, None, None
 
 
+def _dt(t):
+    return G.PIKA_F32 if t.dtype == torch.float32 else G.PIKA_BF16
+
+
+def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16):
+    """Training-mode statistics + apply; returns (y, mean, rstd)."""
+    M, C = x.shape
+    lib = _lib.lib()
+    stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    y = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), _stream()), "pika_bn_stats")
+    _lib.check(lib.pika_bn_apply(
+        x.data_ptr(), M, C, stats.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps),
+        float(momentum), None if running_mean is None else running_mean.data_ptr(),
+        None if running_var is None else running_var.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        y.data_ptr(), _dt(y), _stream()), "pika_bn_apply")
+    return y, mean, rstd
+
+
+def _bn_backward(dy, x, weight, mean, rstd, relu_mask, dx_bf16):
+    """Returns (dx, dgamma, dbeta); dy f32 | bf16, dx f32 | bf16."""
+    M, C = x.shape
+    if dy.dtype not in (torch.float32, torch.bfloat16):
+        dy = dy.float()
+    dy = dy.contiguous()
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    dx = torch.empty(x.shape, dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=x.device)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    _lib.check(_lib.lib().pika_bn_backward(dy.data_ptr(), _dt(dy), x.data_ptr(), M, C, weight.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
+                                           dx.data_ptr(), _dt(dx), dg.data_ptr(), db.data_ptr(),
+                                           int(relu_mask), _stream()), "pika_bn_backward")
+    return dx, dg, db
+
+
 class BatchNormFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over the rows of a (M,C) matrix (include/pika_norm.h); running
-    statistics updated in place exactly as nn.BatchNorm1d does (momentum, unbiased variance)."""
+    statistics updated in place exactly as nn.BatchNorm1d does (momentum, unbiased variance).
+    out_bf16: the result only feeds an MFMA product (the next time-delay layer)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu_input=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu_input=False, out_bf16=False):
         x = x.contiguous()
         ctx.relu_input = bool(relu_input)
-        M, C = x.shape
-        lib = _lib.lib()
         with torch.cuda.device(x.device):
-            stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-            mean = torch.empty(C, dtype=torch.float32, device=x.device)
-            rstd = torch.empty_like(mean)
-            y = torch.empty_like(x)
-            _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), _stream()), "pika_bn_stats")
-            _lib.check(lib.pika_bn_apply(
-                x.data_ptr(), M, C, stats.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps),
-                float(momentum), None if running_mean is None else running_mean.data_ptr(),
-                None if running_var is None else running_var.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                y.data_ptr(), _stream()), "pika_bn_apply")
+            y, mean, rstd = _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, mean, rstd = ctx.saved_tensors
-        M, C = x.shape
-        dy = dy.contiguous()
         with torch.cuda.device(x.device):
-            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-            dx = torch.empty_like(x)
-            dg = torch.empty(C, dtype=torch.float32, device=x.device)
-            db = torch.empty_like(dg)
-            _lib.check(_lib.lib().pika_bn_backward(dy.data_ptr(), x.data_ptr(), M, C, weight.data_ptr(),
-                                                   mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
-                                                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                                   int(ctx.relu_input), _stream()),
-                       "pika_bn_backward")
-        return dx, dg, db, None, None, None, None, None
+            dx, dg, db = _bn_backward(dy, x, weight, mean, rstd, ctx.relu_input, False)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+class TdnnBnFn(torch.autograd.Function):
+    """bn(relu(time_delay(x)))  (rnnt_tdnn_transformer.py:76-82) as one autograd node: GEMM with bias + ReLU
+    epilogue -> fp32 y -> BatchNorm (batch statistics).  Inside the node the gradient of y never exists in
+    fp32: the BatchNorm backward applies the ReLU mask and writes it as the bf16 matrix the dX / dW products
+    read; with out_bf16 the output (and its incoming gradient) is bf16 too."""
+
+    @staticmethod
+    def forward(ctx, x, w2d, bias, taps, dil, stride, pad, bn_w, bn_b, running_mean, running_var, eps, momentum,
+                out_bf16):
+        ctx.x_bf16 = x.dtype == torch.bfloat16
+        xb = x.contiguous() if ctx.x_bf16 else x.contiguous().to(torch.bfloat16)
+        Bn, T, C = xb.shape
+        N = w2d.shape[0]
+        with torch.cuda.device(x.device):
+            a_op, M, K, t_out = G.time_delay(xb, taps, dil, stride, pad)
+            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+            G.launch(a_op, G.matrix(_weight_for(xb, w2d))[0], y, N, M, N, K, bias=bias, relu=True)
+            out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16)
+        ctx.cfg = (taps, dil, stride, pad, t_out)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(xb, w2d, y, bn_w, mean, rstd)
+        return out.view(Bn, t_out, N)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xb, w2d, y, bn_w, mean, rstd = ctx.saved_tensors
+        taps, dil, stride, pad, t_out = ctx.cfg
+        Bn, T, C = xb.shape
+        N, K = w2d.shape
+        M = y.shape[0]
+        dx = dw = db = None
+        with torch.cuda.device(dout.device):
+            dyb, dg, dbeta = _bn_backward(dout.reshape(M, N), y, bn_w, mean, rstd, True, True)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(xb.shape, dtype=torch.float32, device=dout.device)
+                if stride == 1 and N % 64 == 0:
+                    wrev = (w2d.detach().view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, taps * N)
+                            .to(torch.bfloat16))
+                    a_op = G.Operand(dyb.data_ptr(), G.PIKA_BF16, T, t_out, t_out * N, N, N, 1, dil,
+                                     (taps - 1) * dil - pad, 0, 0)
+                    G.launch(a_op, G.matrix(wrev)[0], dx.view(-1, C), C, Bn * T, C, taps * N)
+                else:
+                    dcol = _grad_input(dyb, w2d)  # (M, taps*C)
+                    _lib.check(_lib.lib().pika_col2im(dcol.data_ptr(), dx.data_ptr(), Bn, t_out, T, C,
+                                                      taps, stride, dil, pad, _stream()), "pika_col2im")
+                if ctx.x_bf16:
+                    dx = dx.to(torch.bfloat16)
+            if ctx.needs_input_grad[1]:
+                a_op = G.time_delay(xb, taps, dil, stride, pad)[0]
+                dw = _grad_weight(dyb, a_op, _g(xb), M, K, N)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum_any(dyb)
+        return dx, dw, db, None, None, None, None, dg, dbeta, None, None, None, None, None

@@ -19,6 +19,29 @@ def _bf16_mode():
     return G.PRECISION == "bf16"
 
 
+def _bf16_fast():
+    """bf16 arithmetic mode with the fused / bf16-activation paths enabled (PIKA_NO_FUSED unset)."""
+    from .hipops import _fused
+    return _bf16_mode() and _fused()
+
+
+def tdnn_bn_ok(x, conv_weight, bn):
+    """bn(relu(tdnn(x))) can run as ONE node (hipops.TdnnBnFn): bf16 fast mode, training statistics, widths
+    the direct-to-LDS kernels take, enough rows to be worth a bf16 copy."""
+    N, _, taps, C = conv_weight.shape
+    return (_hip(x) and _bf16_fast() and fused_relu_bn_ok(x, bn) and C % 64 == 0 and N % 64 == 0
+            and x.dtype in (torch.float32, torch.bfloat16) and x.numel() >= (1 << 21))
+
+
+def tdnn_bn(x, conv, bn, mfma_only=False):
+    from .hipops import TdnnBnFn
+    N, _, taps, C = conv.weight.shape
+    mom = _bn_momentum(bn)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return TdnnBnFn.apply(x, conv.weight.reshape(N, taps * C), conv.bias, taps, conv.dilation[0], conv.stride[0], 0,
+                          bn.weight, bn.bias, rm, rv, bn.eps, mom, bool(mfma_only))
+
+
 def _gemm_ok(*dims):
     return all(d % 4 == 0 for d in dims)
 
@@ -44,15 +67,17 @@ def fused_relu_bn_ok(x, bn):
         torch.is_grad_enabled()
 
 
-def batch_norm(x2d, bn, relu_input=False):
+def batch_norm(x2d, bn, relu_input=False, mfma_only=False):
     """BatchNorm1d over rows of a (M,C) matrix with the module's buffers (train: batch stats).
-    relu_input: x2d is a ReLU output whose backward mask this op's backward must apply."""
+    relu_input: x2d is a ReLU output whose backward mask this op's backward must apply.
+    mfma_only: the result only feeds an MFMA product (bf16 mode: produced in bf16)."""
     train_stats = bn.training or not bn.track_running_stats
     if _hip(x2d) and train_stats and bn.affine and x2d.shape[1] % 4 == 0 and x2d.dtype == torch.float32:
         from .hipops import BatchNormFn
         mom = _bn_momentum(bn)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        return BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom, relu_input)
+        return BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom, relu_input,
+                                 bool(mfma_only and _bf16_fast() and x2d.shape[1] % 64 == 0))
     return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                         bn.training or not bn.track_running_stats,
                         _bn_momentum(bn), bn.eps)

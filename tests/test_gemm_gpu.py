@@ -352,3 +352,46 @@ def test_linear_dropout_residual_fn(hip_device, M, K, N, p):
             assert (got.double().cpu() - want).norm() < 6e-3 * want.norm()
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("taps,dil,stride,out_bf16,x_bf16", [(3, 3, 1, False, False), (3, 1, 1, True, True),
+                                                             (3, 3, 4, False, True)])
+def test_tdnn_bn_fn(hip_device, taps, dil, stride, out_bf16, x_bf16):
+    """TdnnBnFn = bn(relu(time_delay(x))) as one node (bf16 dy inside, optional bf16 in/out) vs fp64 torch
+    (conv1d -> relu -> batch_norm in training mode) on bf16-representable inputs."""
+    import torch.nn.functional as F
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import TdnnBnFn
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(taps * 7 + stride)
+        Bn, T, C, N = 8, 1100, 256, 256
+        x = torch.randn(Bn, T, C, generator=g).bfloat16().float()
+        w = (torch.randn(N, taps * C, generator=g) * 0.05).bfloat16().float()
+        b = torch.randn(N, generator=g) * 0.1
+        gam = torch.rand(N, generator=g) + 0.5
+        bet = torch.randn(N, generator=g) * 0.1
+        ref = [t.double().requires_grad_(True) for t in (x, w, b, gam, bet)]
+        w3 = ref[1].view(N, taps, C).permute(0, 2, 1)
+        yr = torch.relu(F.conv1d(ref[0].transpose(1, 2), w3, ref[2], stride=stride, dilation=dil)).transpose(1, 2)
+        t_out = yr.shape[1]
+        outr = F.batch_norm(yr.reshape(-1, N), None, None, ref[3], ref[4], True, 0.1, 1e-5).view(Bn, t_out, N)
+        gy = torch.randn(outr.shape, generator=g).bfloat16().float()
+        (outr * gy.double()).sum().backward()
+        xd = (x.bfloat16() if x_bf16 else x).to(hip_device).requires_grad_(True)
+        dev = [t.to(hip_device).requires_grad_(True) for t in (w, b, gam, bet)]
+        rm, rv = torch.zeros(N, device=hip_device), torch.ones(N, device=hip_device)
+        out = TdnnBnFn.apply(xd, dev[0], dev[1], taps, dil, stride, 0, dev[2], dev[3], rm, rv, 1e-5, 0.1, out_bf16)
+        assert out.dtype == (torch.bfloat16 if out_bf16 else torch.float32) and out.shape == outr.shape
+        tol = 2 ** -7 if out_bf16 else 2e-4
+        assert (out.double().cpu() - outr.detach()).abs().max() < tol * outr.detach().abs().max()
+        (out * gy.to(hip_device).to(out.dtype)).sum().backward()
+        # running statistics as nn.BatchNorm1d updates them
+        assert torch.allclose(rm.double().cpu(), 0.1 * yr.detach().reshape(-1, N).mean(0), atol=1e-4)
+        for got, want in zip([xd] + dev, ref):
+            s = want.grad.abs().max().item()
+            d = (got.grad.double().cpu() - want.grad)
+            assert d.abs().max() < 3e-2 * s, (tuple(got.shape), d.abs().max().item(), s)   # bf16 dy (2^-9 per element)
+            assert d.norm() < 1e-2 * want.grad.norm()
+    finally:
+        G.PRECISION = old
