@@ -49,6 +49,8 @@ typedef struct {
 #define PIKA_GEMM_RELU 1
 #define PIKA_GEMM_ACCUMULATE 2
 #define PIKA_GEMM_FP32SPLIT 4
+#define PIKA_GEMM_OUT_BF16 8   /* C points to a bf16 matrix (pitch ldc elements); only for bf16 x bf16 products the
+                                * direct-to-LDS kernel takes (K % 64 == 0, >= 160 output tiles), else PIKA_EINVAL */
 
 /* Requirements (16-byte operand loads): K % 4 == 0 unless both operands are `trans` (then the output
  * extents M / N must be multiples of g instead); with g = 4 for f32 / 8 for bf16 operands, C,

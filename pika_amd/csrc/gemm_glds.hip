@@ -732,9 +732,10 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
                           int M, int N, int K, const float *bias, int flags, void *ws, size_t ws_bytes,
                           hipStream_t s) {
     if (A->dtype != PIKA_BF16 || B->dtype != PIKA_BF16 || (A->trans != 0) != (B->trans != 0)) return PIKA_NOT_APPLICABLE;
-    if (A->trans) return launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, ws, ws_bytes, s);
-    if (flags & ~PIKA_GEMM_RELU) return PIKA_NOT_APPLICABLE;
-    if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
+    const bool out16 = (flags & PIKA_GEMM_OUT_BF16) != 0;
+    if (A->trans) return out16 ? PIKA_NOT_APPLICABLE : launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, ws, ws_bytes, s);
+    if (flags & ~(PIKA_GEMM_RELU | PIKA_GEMM_OUT_BF16)) return PIKA_NOT_APPLICABLE;
+    if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & (out16 ? 7 : 15))) return PIKA_NOT_APPLICABLE;
     // B: plain matrix
     if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
         return PIKA_NOT_APPLICABLE;
@@ -756,6 +757,10 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     // the row pointer of tap 0 starts `pad` source rows before the signal; only ever dereferenced in range
     P.A -= (long long)A->pad * A->ld;
     P.M = M; P.N = N; P.K = K; P.relu = (flags & PIKA_GEMM_RELU) ? 1 : 0;
+    if (out16) {   // C is a bf16 matrix with pitch ldc: plain bf16 epilogue (no dropout)
+        P.out16 = reinterpret_cast<__bf16 *>(C); P.ldo16 = ldc; P.thr = 0; P.scale = 1.f;
+        return launch_pp_epi<1>(P, s);
+    }
     return launch_pp(P, s);
 }
 

@@ -64,6 +64,9 @@ def _flags(relu, accumulate, precision):
     return (RELU if relu else 0) | (ACCUMULATE if accumulate else 0) | (FP32SPLIT if p == "fp32" else 0)
 
 
+OUT_BF16 = 8
+
+
 _WORKSPACE = {}
 WORKSPACE_BYTES = 160 << 20
 
@@ -85,7 +88,7 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         rc = _lib.lib().pika_gemm_nt_ws(ctypes.byref(a_op), ctypes.byref(b_op), out.data_ptr(), ldc,
                                         c_z_outer, c_z_inner, M, N, K, batch, z_div,
                                         None if bias is None else bias.data_ptr(),
-                                        _flags(relu, accumulate, precision),
+                                        _flags(relu, accumulate, precision) | (OUT_BF16 if out.dtype == torch.bfloat16 else 0),
                                         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
                                         torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pika_gemm_nt(M=%d,N=%d,K=%d)" % (M, N, K))

@@ -779,7 +779,10 @@ class TdnnBnFn(torch.autograd.Function):
         with torch.cuda.device(dout.device):
             dyb, dg, dbeta = _bn_backward(dout.reshape(M, N), y, bn_w, mean, rstd, True, True)
             if ctx.needs_input_grad[0]:
-                dx = torch.empty(xb.shape, dtype=torch.float32, device=dout.device)
+                # bf16 dx straight from the epilogue when the direct-to-LDS kernel takes the product (its own gate)
+                direct = (ctx.x_bf16 and stride == 1 and N % 64 == 0 and C >= 192 and C % 4 == 0
+                          and ((Bn * T + 255) // 256) * ((C + 255) // 256) >= 160)
+                dx = torch.empty(xb.shape, dtype=torch.bfloat16 if direct else torch.float32, device=dout.device)
                 if stride == 1 and N % 64 == 0:
                     wrev = (w2d.detach().view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, taps * N)
                             .to(torch.bfloat16))
@@ -790,7 +793,7 @@ class TdnnBnFn(torch.autograd.Function):
                     dcol = _grad_input(dyb, w2d)  # (M, taps*C)
                     _lib.check(_lib.lib().pika_col2im(dcol.data_ptr(), dx.data_ptr(), Bn, t_out, T, C,
                                                       taps, stride, dil, pad, _stream()), "pika_col2im")
-                if ctx.x_bf16:
+                if ctx.x_bf16 and dx.dtype != torch.bfloat16:
                     dx = dx.to(torch.bfloat16)
             if ctx.needs_input_grad[1]:
                 a_op = G.time_delay(xb, taps, dil, stride, pad)[0]
