@@ -1,9 +1,15 @@
-"""autograd Functions backed by libpika_amd.so (GPU tensors only).
+"""autograd Functions backed by libpika_amd.so (GPU tensors only; nothing here has a CPU path).
 
-Forward AND backward GEMMs run on the hand-written MFMA kernel (pika_gemm_nt): the backward
-operands that the NT form needs with the other index contiguous (W^T, dY^T, X^T) are produced
-by pika_transpose_cast (fp32 -> bf16, or fp32 in fp32-split mode, written once), bias gradients by
-pika_colsum, the time-delay adjoint by pika_col2im.
+Every product -- forward, dX, dW -- runs on the hand-written MFMA kernels behind pika_gemm_nt /
+pika_gemm_bf16_*: the direct-to-LDS ping-pong kernels for bf16 operands (plain, time-delay and
+reduction-major views), the register-staged kernel for fp32 operands and the exact fp32 parity mode.
+
+In the bf16 arithmetic mode a tensor whose every consumer is an MFMA product is produced in bf16 by the kernel
+that computes it (GEMM epilogues, LayerNorm, BatchNorm, the attention core, the joint gate) and its gradient
+is accepted in bf16; chains whose intermediates only feed further products are single autograd nodes
+(FeedForwardFn, TdnnBnFn, JointOutFn, LinearDropoutResidualFn, PackedAttentionFn) so those intermediates and
+their gradients never exist in fp32.  PIKA_NO_FUSED=1 switches all of that off for diagnostics
+(tools/mode_diff.py): then only the operand rounding inside pika_gemm_nt separates the mode from fp32.
 """
 import ctypes
 import os
