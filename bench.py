@@ -214,9 +214,85 @@ def decode_workload(args, dev, rank):
     return step, float(labels)
 
 
+def mbr_workload(args, dev, rank):
+    """SURVEY 8d M4 (BASELINE configs[3], one GPU): one minimum-Bayes-risk training step as
+    train_transducer_mbr_bmuf_otfaug.py:112-240 runs it -- N-best beam decode (eval mode, beam 4) -> encoder
+    forward -> RNN-T loss on the reference labels, backward (retain graph) -> risk terms (softmax of the N-best
+    scores, edit distances) -> prediction net on the N-best label sequences -> joint along every hypothesis'
+    (t,u) trajectory with the HIP risk-gradient kernel -> inf-norm clip -> Nesterov SGD.  Random weights never
+    emit blank, so fc2 is sharpened and the blank bias calibrated as in the decode workload."""
+    from types import SimpleNamespace
+    from model.transducer import Net
+    from warp_rnnt import RNNTLoss
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd import mbr
+    from pika_amd.model import ops
+    B, T, U, V, beam = args.batch, args.frames, args.labels, args.vocab, args.beam
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
+                          encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
+                          embd_dim=100, padding_idx=V)
+    torch.manual_seed(777 + rank)
+    model = Net(opt, 240, V).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4000 + rank)
+    feats = torch.randn(B, T, 240, generator=g, device=dev).contiguous()
+    x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long, device=dev)
+    labels = torch.randint(1, V, (B, U), generator=g, device=dev)
+    ali = torch.full((B,), U, dtype=torch.int32, device=dev)
+    dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+
+    def decoder(k):
+        return TransducerDecoder(model, batch_size=B, beam_size=k, n_best=k, blk=0, global_scorer=GlobalScorer(),
+                                 sm_scale=0.8, cuda=True, beam_prune=True, args=dargs)
+    model.eval()
+    with torch.no_grad():
+        model.fc2.weight *= 8.0
+        lo, hi = 0.0, 40.0
+        for _ in range(8):
+            mid = 0.5 * (lo + hi)
+            model.fc2.bias[0] = mid
+            ret, _ = decoder(1).decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
+            nlab = np.mean([sum(1 for e in h[0] if int(e) != 0) for h in ret["predictions"]])
+            lo, hi = (mid, hi) if nlab > U else (lo, mid)
+        model.fc2.bias[0] = 0.5 * (lo + hi)
+    for m in model.modules():   # keep the eval-mode model (running statistics) at its calibration point
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.momentum = 0.0
+    dec = decoder(beam)
+    # the step size is negligible on purpose: the calibrated random model must keep emitting ~U labels per
+    # utterance in every timed step (the arithmetic of the update is the same)
+    optim = torch.optim.SGD(model.parameters(), 1e-9, momentum=0.9, nesterov=True)
+    loss_fn = RNNTLoss(blank=0, reduction="sum").apply
+    max_len = [int(v) + U + 3 for v in x_len]
+    info = {}
+
+    def step():
+        model.eval()
+        with torch.no_grad():
+            ret, _ = dec.decode_batch(feats, x_len, max_len)                  # :112-117
+        hyps, scores = ret["predictions"], ret["scores"]
+        model.train()
+        optim.zero_grad(set_to_none=True)
+        enc = model.encode(feats, None)                                       # :124-138
+        sos = torch.zeros(B, 1, dtype=torch.long, device=dev)
+        pred = model.predict(torch.cat((sos, labels), dim=1))
+        lp = ops.joint(enc, pred, model.fc1, model.fc_gate, model.fc2, log_softmax=True)
+        rnnt = 0.1 * loss_fn(lp, labels.int(), x_len.int(), ali).sum()       # rnnt_scale :152-158
+        rnnt.backward(retain_graph=True)
+        prob, dist, seq_grad, nonblk = mbr.risk_terms(hyps, scores, labels, ali, 0, dev)   # :163-195
+        mbr.mbr_backward(model, enc, hyps, seq_grad, nonblk, 0, 0.8)          # :197-235
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+        optim.step()
+        info["risk"] = float((prob * dist).sum())
+        info["hyp_labels"] = float(np.mean([len(h) for row in nonblk for h in row]))
+        return rnnt
+    return step, info
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "train_step", "decode"])
+    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "train_step", "decode", "mbr_step"])
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--pred-net", default="transformer", choices=["transformer", "rnn"])
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,6 +350,38 @@ def main():
                            "audio_seconds": audio_s, "utterances_per_s": B / el,
                            "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
                            "calibration_labels": cal_labels, "timing": step.decoder.timing}}), flush=True)
+        return
+    if args.workload == "mbr_step":
+        step, info = mbr_workload(args, dev, rank)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item()) / args.steps
+        if rank == 0:
+            print(json.dumps({
+                "metric": "utterances/sec MBR train step (T_in=%d,U=%d,V=%d)" % (T, U, V), "value": B * world / el,
+                "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "mbr_step (BASELINE configs[3] / SURVEY 8d M4): N-best decode (beam %d) + encoder "
+                                       "fwd + RNN-T loss bwd + risk terms + trajectory joint with the HIP risk-gradient "
+                                       "kernel + clip + SGD, full config-2 model" % args.beam,
+                           "batch_per_gpu": B, "beam": args.beam, "expected_risk": info.get("risk"),
+                           "hyp_labels": info.get("hyp_labels")}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if args.workload == "train_step":
         out = run_train_step(args, dev, rank, world, args.steps, args.warmup)
