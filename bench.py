@@ -292,7 +292,7 @@ def mbr_workload(args, dev, rank):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "train_step", "decode", "mbr_step"])
+    ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "rnnt_loss_M1p", "train_step", "decode", "mbr_step"])
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--pred-net", default="transformer", choices=["transformer", "rnn"])
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,6 +350,63 @@ def main():
                            "audio_seconds": audio_s, "utterances_per_s": B / el,
                            "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
                            "calibration_labels": cal_labels, "timing": step.decoder.timing}}), flush=True)
+        return
+    if args.workload == "rnnt_loss_M1p":
+        # SURVEY 8d M1': fused boundary logits -> (costs, d/dlogits); no log-prob tensor, no dense lp gradient
+        from pika_amd.rnnt import rnnt_loss_from_logits
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + 100 * rank)
+        logits = torch.randn(B, T, U + 1, V, generator=g, device=dev).requires_grad_(True)
+        g.manual_seed(1235 + 100 * rank)
+        labels = torch.randint(1, V, (B, U), generator=g, device=dev, dtype=torch.int32)
+        tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+        ul = torch.full((B,), U, dtype=torch.int32, device=dev)
+
+        def step():
+            logits.grad = None
+            c = rnnt_loss_from_logits(logits, labels, tl, ul)
+            c.sum().backward()
+            return c
+        for _ in range(args.warmup):
+            step()
+        R.KERNEL_EVENTS = {"fwd": [], "bwd": []}
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            costs = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        ev, R.KERNEL_EVENTS = R.KERNEL_EVENTS, None
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item()) / args.steps
+        if rank == 0:
+            fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
+            bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]]))
+            bytes_per_launch = 3.0 * B * T * (U + 1) * V * 4          # SURVEY 8d M1': 3X
+            achieved = bytes_per_launch / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+            # the composition it replaces, on the same logits
+            lp = torch.log_softmax(logits.detach(), dim=-1)
+            c_ref = RNNTLoss(blank=0).apply(lp, labels, tl, ul)
+            print(json.dumps({
+                "metric": "utterances/sec fused log-softmax + RNNT loss fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
+                "value": B * world / el, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "rnnt_loss_M1p (SURVEY 8d M1'): rnnt_loss_from_logits(randn logits (B,T,U+1,V))"
+                                       ".sum().backward(), fp32 d/dlogits out", "batch_per_gpu": B, "T": T, "U": U, "V": V,
+                           "max_rel_cost_diff_vs_log_softmax_plus_loss": float(((costs - c_ref).abs() / c_ref.abs()).max())},
+                "roofline": {"bound": "hbm", "kernel": "rnnt_lse_gather_kernel + rnnt_dlogits_fused_kernel",
+                             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                             "forward_ms": fwd_ms, "backward_ms": bwd_ms}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if args.workload == "mbr_step":
         step, info = mbr_workload(args, dev, rank)

@@ -90,6 +90,21 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace
                                    int V, int blank, void *out, long long ld_out, float scale,
                                    void *stream);
 
+/* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces
+ * F.log_softmax (trainer/model/transducer.py:111) + the loss + the log-softmax backward for a caller that owns
+ * the joint output.  `logits` (B,T,U1,V) f32 are the RAW fc2 outputs, V % 4 == 0, V <= 5120; lse (B*T*U1) f32
+ * receives the per-row log-sum-exp and must be handed to the backward together with the same logits and
+ * workspace.  grad_logits: f32 (out_dtype 0, ld_out >= V) or bf16 (out_dtype 1; columns [V, ld_out) zeroed).
+ * Traffic 3 x B*T*U1*V*4 bytes (one read for lse + gather, one read + one write for the gradient) against
+ * 6 x for the three separate passes. */
+int pika_rnnt_fused_forward(const float *logits, const int *labels, const int *frames_lengths,
+                            const int *labels_lengths, int B, int T, int U1, int V, int blank, float *costs,
+                            float *lse, void *workspace, void *stream);
+int pika_rnnt_fused_backward(const float *logits, const float *lse, const int *labels,
+                             const int *frames_lengths, const int *labels_lengths, int B, int T, int U1, int V,
+                             int blank, const float *grad_costs, const void *workspace, void *grad_logits,
+                             int out_dtype, long long ld_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -529,6 +529,123 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
     }
 }
 
+int run_alpha_beta(const Lattice &L, const int *frames_lengths, const int *labels_lengths, float *costs, int B,
+                   int T, int U1, hipStream_t s) {
+    switch (L.Wp / 64) {
+        case 1: launch_ab<1>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 2: launch_ab<2>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 3: launch_ab<3>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 4: launch_ab<4>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 6: launch_ab<6>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 8: launch_ab<8>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 12: launch_ab<12>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        case 16: launch_ab<16>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
+        default: return PIKA_ETOOBIG;
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused boundary logits -> (costs, d loss / d logits)  (SURVEY 8d M1'): the log-softmax of the joint output
+// is never materialised.  Pass 1 reads every V-row of the logits once (one wavefront per row, row in
+// registers): log-sum-exp -> lse[row], and the two log-probs the lattice needs go straight into the skewed
+// planes.  After alpha/beta and the row metadata, pass 2 re-reads the logits and writes
+//   grad[r, v] = (v == blank) * gb + (v == ye) * ge - exp(logits[r, v] - lse[r]) * (gb + ge).
+// 3 x B*T*U1*V*4 bytes in total instead of 6 x for log_softmax + loss + log_softmax backward.
+__device__ inline float fwave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ inline float fwave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void rnnt_lse_gather_kernel(
+    const float *__restrict__ logits, const int *__restrict__ labels, const int *__restrict__ Tn_,
+    const int *__restrict__ Un_, long long rows, int T, int U1, int V, int blank, float *__restrict__ lse,
+    float *__restrict__ lpb, float *__restrict__ lpe, int Wp, int D) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = V >> 2;
+    const int u = (int)(r % U1);
+    const int t = (int)((r / U1) % T);
+    const int b = (int)(r / ((long long)U1 * T));
+    const int Tn = clampi(Tn_[b], 1, T), Un = clampi(Un_[b], 0, U1 - 1);
+    if (t >= Tn || u > Un) {            // outside the sub-lattice: no gradient, nothing to gather
+        if (lane == 0) lse[r] = 0.f;
+        return;
+    }
+    const float *row = logits + r * V;
+    const f32x4 *row4 = reinterpret_cast<const f32x4 *>(row);
+    f32x4 v[CQ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q)
+        if (lane + q * 64 < c4) {
+            v[q] = row4[lane + q * 64];
+            m = fmaxf(m, fmaxf(fmaxf(v[q].x, v[q].y), fmaxf(v[q].z, v[q].w)));
+        }
+    m = fwave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q)
+        if (lane + q * 64 < c4)
+            sum += (__expf(v[q].x - m) + __expf(v[q].y - m)) + (__expf(v[q].z - m) + __expf(v[q].w - m));
+    const float l = m + __logf(fwave_sum(sum));
+    if (lane == 0) {
+        lse[r] = l;
+        float ve = NEG;
+        if (u < Un) {
+            const int y = labels[(size_t)b * (U1 - 1) + u];
+            if (y >= 0 && y < V) ve = fmaxf(row[y] - l, NEG);
+        }
+        const size_t o = ((size_t)b * D + (t + u)) * Wp + u;
+        lpb[o] = fmaxf(row[blank] - l, NEG);
+        lpe[o] = ve;
+    }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__restrict__ logits,
+                                                                 const float *__restrict__ lse,
+                                                                 const RowMeta *__restrict__ meta,
+                                                                 TO *__restrict__ out, long long rows, int V,
+                                                                 long long ld_out, int blank) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63, c4 = V >> 2, o4 = (int)(ld_out >> 2);
+    const RowMeta m = meta[r];
+    const float s = m.gb + m.ge, l = lse[r];
+    const bool live = (m.gb != 0.f) || (m.ge != 0.f);
+    const f32x4 *lrow = reinterpret_cast<const f32x4 *>(logits + r * V);
+    f32x4 v[CQ];
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q)
+            if (lane + q * 64 < c4) v[q] = lrow[lane + q * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        const int i = lane + q * 64;
+        if (i >= o4) continue;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (live && i < c4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 4 * i + e;
+                float g = col == blank ? m.gb : 0.f;
+                if (col == m.ye) g += m.ge;
+                o[e] = g - __expf(v[q][e] - l) * s;
+            }
+        }
+        if constexpr (sizeof(TO) == 4) reinterpret_cast<f32x4 *>(out + r * ld_out)[i] = o;
+        else reinterpret_cast<cbf16x4 *>(out + r * ld_out)[i] = __builtin_convertvector(o, cbf16x4);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -552,18 +669,7 @@ int pika_rnnt_loss_forward(const float *log_probs, const int *labels, const int 
     hipLaunchKernelGGL(rnnt_gather_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s,
                        log_probs, labels, frames_lengths, labels_lengths, B, T, U1, V, blank, L.lpb,
                        L.lpe, L.Wp, L.D);
-    switch (L.Wp / 64) {
-        case 1: launch_ab<1>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 2: launch_ab<2>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 3: launch_ab<3>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 4: launch_ab<4>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 6: launch_ab<6>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 8: launch_ab<8>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 12: launch_ab<12>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        case 16: launch_ab<16>(L, frames_lengths, labels_lengths, costs, B, T, U1, s); break;
-        default: return PIKA_ETOOBIG;
-    }
-    return (int)hipGetLastError();
+    return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
 }
 
 int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths, const int *labels_lengths,
@@ -640,6 +746,51 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace
     hipLaunchKernelGGL(rnnt_dlogits_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), log_probs, L.meta, static_cast<__bf16 *>(out), rows, V,
                        ld_out, blank, scale);
+    return (int)hipGetLastError();
+}
+
+int pika_rnnt_fused_forward(const float *logits, const int *labels, const int *frames_lengths,
+                            const int *labels_lengths, int B, int T, int U1, int V, int blank, float *costs,
+                            float *lse, void *workspace, void *stream) {
+    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
+    if (!logits || !frames_lengths || !labels_lengths || !costs || !lse || !workspace) return PIKA_EINVAL;
+    if (U1 > 1 && !labels) return PIKA_EINVAL;
+    if ((V & 3) || V > 64 * 4 * CQ || (reinterpret_cast<uintptr_t>(logits) & 15)) return PIKA_EINVAL;
+    const long long rows = (long long)B * T * U1;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Lattice L = carve(workspace, B, T, U1);
+    hipLaunchKernelGGL(rnnt_lse_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, labels,
+                       frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe, L.Wp, L.D);
+    return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
+}
+
+int pika_rnnt_fused_backward(const float *logits, const float *lse, const int *labels,
+                             const int *frames_lengths, const int *labels_lengths, int B, int T, int U1, int V,
+                             int blank, const float *grad_costs, const void *workspace, void *grad_logits,
+                             int out_dtype, long long ld_out, void *stream) {
+    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
+    if (!logits || !lse || !frames_lengths || !labels_lengths || !workspace || !grad_logits) return PIKA_EINVAL;
+    if (U1 > 1 && !labels) return PIKA_EINVAL;
+    if ((V & 3) || V > 64 * 4 * CQ || ld_out < V || (ld_out & 3) || ld_out > 64 * 4 * CQ ||
+        (reinterpret_cast<uintptr_t>(logits) & 15))
+        return PIKA_EINVAL;
+    if (out_dtype != 0 && out_dtype != 1) return PIKA_EINVAL;   // PIKA_F32 / PIKA_BF16 (pika_gemm.h)
+    if (reinterpret_cast<uintptr_t>(grad_logits) & (out_dtype == 0 ? 15 : 7)) return PIKA_EINVAL;
+    const long long rows = (long long)B * T * U1;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+    hipLaunchKernelGGL(rnnt_rowmeta_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,
+                       labels, frames_lengths, labels_lengths, B, T, U1, V, grad_costs, L.lpb, L.lpe,
+                       L.alpha, L.beta, L.off_a, L.off_b, L.ll, L.Wp, L.D, L.meta);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (out_dtype == 0)
+        hipLaunchKernelGGL(rnnt_dlogits_fused_kernel<float>, grid, dim3(256), 0, s, logits, lse, L.meta,
+                           static_cast<float *>(grad_logits), rows, V, ld_out, blank);
+    else
+        hipLaunchKernelGGL(rnnt_dlogits_fused_kernel<__bf16>, grid, dim3(256), 0, s, logits, lse, L.meta,
+                           static_cast<__bf16 *>(grad_logits), rows, V, ld_out, blank);
     return (int)hipGetLastError();
 }
 

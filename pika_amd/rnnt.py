@@ -128,6 +128,50 @@ class _RNNTLossFn(torch.autograd.Function):
         return grads, None, None, None, None
 
 
+class _FusedLogitsLossFn(torch.autograd.Function):
+    """RNN-T costs straight from the joint's RAW logits (SURVEY 8d M1', include/pika_rnnt.h): the log-softmax
+    is folded into the two passes the loss makes anyway (log-sum-exp + gather; gradient), so the (B,T,U1,V)
+    log-prob tensor and its dense gradient never exist: 3 tensor passes instead of 6."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, frames_lengths, labels_lengths, blank=0):
+        _check_inputs(logits, labels, frames_lengths, labels_lengths, blank)
+        lib = _lib.lib()
+        x = logits.contiguous()
+        labels, frames_lengths, labels_lengths = (t.contiguous() for t in (labels, frames_lengths, labels_lengths))
+        B, T, U1, V = x.shape
+        with torch.cuda.device(x.device):
+            costs = torch.empty(B, dtype=torch.float32, device=x.device)
+            lse = torch.empty(B * T * U1, dtype=torch.float32, device=x.device)
+            ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=x.device)
+            with _timed("fwd"):
+                _lib.check(lib.pika_rnnt_fused_forward(
+                    _ptr(x), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
+                    _ptr(costs), _ptr(lse), _ptr(ws), _stream()), "pika_rnnt_fused_forward")
+        ctx.save_for_backward(x, labels, frames_lengths, labels_lengths, ws, lse)
+        ctx.dims = (B, T, U1, V, blank)
+        return costs
+
+    @staticmethod
+    def backward(ctx, grad_costs):
+        x, labels, frames_lengths, labels_lengths, ws, lse = ctx.saved_tensors
+        B, T, U1, V, blank = ctx.dims
+        gc = grad_costs.to(torch.float32).contiguous()
+        with torch.cuda.device(x.device):
+            grads = torch.empty_like(x)
+            with _timed("bwd"):
+                _lib.check(_lib.lib().pika_rnnt_fused_backward(
+                    _ptr(x), _ptr(lse), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V,
+                    blank, _ptr(gc), _ptr(ws), _ptr(grads), 0, V, _stream()), "pika_rnnt_fused_backward")
+        return grads, None, None, None, None
+
+
+def rnnt_loss_from_logits(logits, labels, frames_lengths, labels_lengths, blank=0):
+    """Per-utterance costs of log_softmax(logits) under the RNN-T loss, differentiable w.r.t. the logits,
+    without materialising the log-probabilities (V % 4 == 0, V <= 5120)."""
+    return _FusedLogitsLossFn.apply(logits, labels, frames_lengths, labels_lengths, blank)
+
+
 def rnnt_loss(log_probs, labels, frames_lengths, labels_lengths, average_frames=False,
               reduction=None, blank=0):
     """Functional form (same keyword surface as warp_rnnt.rnnt_loss)."""

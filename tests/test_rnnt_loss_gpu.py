@@ -190,3 +190,34 @@ def test_full_size_lattice_properties_and_sampled_parity(hip_device):
         assert abs(-g[n].astype(np.float64).sum() - (tl[n] + ul[n])) < 0.02 * (tl[n] + ul[n])
         assert not (g[n, tl[n]:] != 0).any() and not (g[n, :, ul[n] + 1:] != 0).any()
     assert (g != 0).sum() <= int((tl.astype(np.int64) * (ul + 1) * 2).sum())
+
+
+@pytest.mark.parametrize("B,T,U,V,ragged", [(2, 9, 4, 40, True), (3, 50, 12, 5000, True), (1, 1, 0, 8, False),
+                                            (4, 120, 30, 1024, False)])
+def test_fused_logits_loss_matches_log_softmax_plus_loss(hip_device, B, T, U, V, ragged):
+    """pika_rnnt_fused_forward/backward (SURVEY 8d M1\': logits -> costs, d/dlogits, no log-prob tensor) vs
+    the composition it replaces: torch.log_softmax -> RNNTLoss -> autograd."""
+    import torch
+    from pika_amd.rnnt import RNNTLoss, rnnt_loss_from_logits
+    g = torch.Generator().manual_seed(B * 100 + T + U)
+    logits = (torch.randn(B, T, U + 1, V, generator=g) * 2).to(hip_device)
+    labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+    if ragged:
+        tl = torch.randint(max(1, T // 2), T + 1, (B,), generator=g, dtype=torch.int32)
+        ul = torch.randint(0, U + 1, (B,), generator=g, dtype=torch.int32)
+        tl[0], ul[0] = T, U
+    else:
+        tl = torch.full((B,), T, dtype=torch.int32)
+        ul = torch.full((B,), U, dtype=torch.int32)
+    tl, ul = tl.to(hip_device), ul.to(hip_device)
+    w = torch.rand(B, generator=g).to(hip_device) + 0.5          # non-trivial grad_output
+    a = logits.clone().requires_grad_(True)
+    ca = RNNTLoss(blank=0).apply(torch.log_softmax(a, dim=-1), labels, tl, ul)
+    (ca * w).sum().backward()
+    b = logits.clone().requires_grad_(True)
+    cb = rnnt_loss_from_logits(b, labels, tl, ul)
+    (cb * w).sum().backward()
+    assert torch.allclose(ca, cb, rtol=2e-6, atol=1e-4)
+    scale = a.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() < 1e-4 * max(scale, 1.0)   # fp32 exp/log ordering (T=1000 budget)
+    assert torch.isfinite(b.grad).all()
