@@ -133,3 +133,43 @@ def cmvn_offset_scale(stats, repeat=1, floor=1.0e-20):
     if np.min(np.abs(var)) < floor:
         raise ValueError("problematic cmvn_stats, variance too small")
     return np.tile(-mean, repeat), np.tile(1.0 / np.sqrt(var), repeat)
+
+
+def write_int_vectors(path, items, binary=False):
+    """Kaldi int-vector archive (label alignments): text `uttid i1 i2 ...` or binary
+    (`uttid \\0B` + 1-byte size marker 4 + int32 count + per element marker 4 + int32)."""
+    if not binary:
+        with open(path, "w", encoding="utf-8") as f:
+            for key, vec in items:
+                f.write(" ".join([key] + [str(int(v)) for v in vec]) + "\n")
+        return
+    with open(path, "wb") as f:
+        for key, vec in items:
+            f.write(key.encode("utf-8") + b" \0B")
+            f.write(struct.pack("<bi", 4, len(vec)))
+            for v in vec:
+                f.write(struct.pack("<bi", 4, int(v)))
+
+
+def write_text_matrix(path, mat):
+    """Kaldi text matrix ` [\n  r0 ...\n  r1 ... ]` (the CMVN statistics file format)."""
+    mat = np.asarray(mat, dtype=np.float64)
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(" [\n")
+        for i, row in enumerate(mat):
+            f.write("  " + " ".join(repr(float(v)) for v in row) + (" ]\n" if i == len(mat) - 1 else "\n"))
+
+
+def accumulate_cmvn_stats(feature_iter):
+    """2 x (D+1) Kaldi CMVN statistics (row 0: sums + frame count, row 1: sums of squares + 0) from an iterable
+    of (T, D) feature matrices -- what `compute-cmvn-stats` writes and cmvn_offset_scale() consumes."""
+    stats = None
+    for feats in feature_iter:
+        x = np.asarray(feats, dtype=np.float64)
+        if stats is None:
+            stats = np.zeros((2, x.shape[1] + 1))
+        stats[0, :-1] += x.sum(0)
+        stats[1, :-1] += (x * x).sum(0)
+        stats[0, -1] += x.shape[0]
+    return stats
+

@@ -136,3 +136,49 @@ def test_otf_loader_end_to_end_matches_oracle(hip_device, tmp_path):
             assert np.abs(d[b, :lens[b]] - ref).max() < 5e-3
             assert np.array_equal(tgt[b, :alens[b]].numpy(), labels[i])
             i += 1
+
+
+def test_wav_to_seq_and_format_writers(tmp_path):
+    """the PyKaldi-free wav.scp -> .mrk/.seq converter (utils/wav_to_seq.py layout: new file
+    pair every num_wav_per_seq utterances, offsets restart at 0) and the text/binary writers round-trip through
+    the readers the loader uses."""
+    import wave
+    from pika_amd.loader import kaldi_io as K
+    from pika_amd.loader.wav_to_seq import convert
+    rng = np.random.default_rng(3)
+    utts = {}
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for i in range(5):
+            pcm = rng.integers(-20000, 20000, size=int(rng.integers(100, 900))).astype("<i2")
+            utts["utt%d" % i] = pcm
+            with wave.open(str(tmp_path / ("u%d.wav" % i)), "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+            scp.write("utt%d %s\n" % (i, tmp_path / ("u%d.wav" % i)))
+    n = convert("scp:" + str(tmp_path / "wav.scp"), str(tmp_path / "a.mrk"), str(tmp_path / "a.seq"), num_wav_per_seq=2)
+    assert n == 3
+    seen = 0
+    for j in range(n):
+        marks = K.read_mrk(str(tmp_path / ("a.mrk.%d" % j)))
+        assert marks[0][1] == 0                                   # offsets restart in every pair
+        with open(tmp_path / ("a.seq.%d" % j), "rb") as f:
+            for key, off, nb in marks:
+                assert np.array_equal(K.read_pcm(f, off, nb), utts[key])
+                seen += 1
+    assert seen == 5
+    # label archives, text and binary
+    items = [("utt0", [3, 7, 7, 4999]), ("utt1", []), ("utt2", [12])]
+    for binary in (False, True):
+        p = str(tmp_path / ("lab%d.ark" % binary))
+        K.write_int_vectors(p, items, binary=binary)
+        got = list(K.read_int_vectors("ark:" + p))
+        assert [k for k, _ in got] == [k for k, _ in items]
+        assert all(np.array_equal(v, np.array(w, dtype=np.int32)) for (_, v), (_, w) in zip(got, items))
+    # CMVN statistics: accumulate -> text matrix -> offset/scale == direct formula
+    feats = [rng.standard_normal((50, 6)) * 3 + 2, rng.standard_normal((70, 6)) - 1]
+    stats = K.accumulate_cmvn_stats(feats)
+    K.write_text_matrix(str(tmp_path / "cmvn.txt"), stats)
+    back = K.read_text_matrix(str(tmp_path / "cmvn.txt"))
+    assert np.allclose(back, stats)
+    off, scale = K.cmvn_offset_scale(back)
+    allf = np.concatenate(feats)
+    assert np.allclose(off, -allf.mean(0), atol=1e-9) and np.allclose(scale, 1.0 / allf.std(0), atol=1e-9)
