@@ -187,10 +187,23 @@ def decode_workload(args, dev, rank):
     feats = (torch.randn(B, T, 240, generator=g, device=dev)).contiguous()
     x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long, device=dev)
     dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    lm_scorer = synthetic_bigram_matcher(V) if args.fst else None
+    las_fw = las_bw = None
+    SOS, EOS, PAD = V, V + 1, V + 2
+    if args.las:   # forward + backward LAS rescorers, 2-layer BLSTM 1024, mlp attention, random weights
+        from trainer.model import las
+        lopt = SimpleNamespace(rnn_size=1024, encoder_type="rnn", rnn_type="LSTM", brnn=True, enc_layers=2,
+                               dropout=0.0, use_downsampler=False, embd_dim=100, num_heads=1, sampling_decoder=False,
+                               input_feed=1, dec_layers=2, global_attention="mlp", coverage_attn=False,
+                               context_gate=None, copy_attn=False)
+        torch.manual_seed(999)
+        las_fw = las.Net(lopt, 1024, V + 2, PAD).to(dev).eval()
+        las_bw = las.Net(lopt, 1024, V + 2, PAD).to(dev).eval()
 
-    def decoder(beam, nbest):
+    def decoder(beam, nbest, lm=None):
         return TransducerDecoder(model, batch_size=B, beam_size=beam, n_best=nbest, blk=0,
                                  global_scorer=GlobalScorer(), sm_scale=0.8, cuda=True,
+                                 lm_scorer=lm, lm_scorer_scale=0.3,
                                  beam_prune=True, args=dargs)
 
     with torch.no_grad():
@@ -206,12 +219,42 @@ def decode_workload(args, dev, rank):
             else:
                 hi = mid
         model.fc2.bias[0] = 0.5 * (lo + hi)
-    dec = decoder(args.beam, args.beam)
+    dec = decoder(args.beam, args.beam, lm_scorer)
 
     def step():
-        return dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
+        ret, enc_out = dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
+        t0 = time.perf_counter()
+        if las_fw is not None:      # decode_transducer.py:136-156: every n-best entry, forward and reversed
+            hyps = [[[int(e) for e in h if int(e) != 0] for h in ret["predictions"][i]] for i in range(B)]
+            src = enc_out.transpose(0, 1)                                   # (T', B, H)
+            fw = las_fw.score_nbest_batch(src, x_len, hyps, SOS, EOS)
+            bw = las_bw.score_nbest_batch(src, x_len, [[h[::-1] for h in row] for row in hyps], SOS, EOS)
+            ret["las"] = (fw, bw)
+            torch.cuda.synchronize()
+        dec.timing["las_s"] = time.perf_counter() - t0
+        return ret, enc_out
     step.decoder = dec
     return step, float(labels)
+
+
+def synthetic_bigram_matcher(V, seed=123, n_succ=6):
+    """seeded back-off bigram LM over the V-1 labels as an FST (word w has ilabel w+1, back-off
+    label V+1, one disambiguation label V+2), wrapped in the matcher the fused search queries."""
+    from pika_amd.decoder.ngram_fst import NgramFst, SortedMatcher
+    rng = np.random.default_rng(seed)
+    backoff_id, disambig = V + 1, V + 2
+    arcs, finals = [], {0: float(np.float32(rng.uniform(1, 3)))}
+    for w in range(1, V):
+        arcs.append((0, w + 1, float(np.float32(rng.uniform(2, 7))), 1 + w))
+    for w in range(1, V):
+        h = 1 + w
+        for v in rng.choice(np.arange(1, V), size=n_succ, replace=False):
+            arcs.append((h, int(v) + 1, float(np.float32(rng.uniform(0.5, 4))), 1 + int(v)))
+        arcs.append((h, backoff_id, float(np.float32(rng.uniform(0.2, 2))), 0))
+        if w % 3 == 0:
+            finals[h] = float(np.float32(rng.uniform(0.5, 2)))
+    return SortedMatcher(NgramFst.from_arcs(1 + V, arcs, finals), max_num_arcs=V + 4, max_id=V + 3,
+                         backoff_id=backoff_id, disambig_ids=[disambig])
 
 
 def mbr_workload(args, dev, rank):
@@ -303,6 +346,8 @@ def main():
     ap.add_argument("--labels", type=int, default=50)
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--cpu-utts", type=int, default=4)
+    ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
+    ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the secondary full-train-step measurement of the default run")
@@ -346,7 +391,10 @@ def main():
                 "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "decode: B=%d beam=%d n_best=%d, %d-frame utterances, full model "
-                                       "(%s prediction net), sm_scale 0.8" % (B, args.beam, args.beam, T, args.pred_net),
+                                       "(%s prediction net), sm_scale 0.8%s%s" % (
+                                           B, args.beam, args.beam, T, args.pred_net,
+                                           ", bigram FST shallow fusion (host-side state sets)" if args.fst else "",
+                                           ", fw+bw LAS rescoring of the n-best" if args.las else ""),
                            "audio_seconds": audio_s, "utterances_per_s": B / el,
                            "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
                            "calibration_labels": cal_labels, "timing": step.decoder.timing}}), flush=True)

@@ -201,3 +201,45 @@ class Net(nn.Module):
         logp = torch.log_softmax(scale * ops.linear(out, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
         picked = logp.gather(2, tgt.clamp(max=logp.shape[2] - 1).unsqueeze(2)).squeeze(2).cpu()
         return [picked[:len(h) + 1, i].tolist() for i, h in enumerate(hyps)]
+
+    @torch.no_grad()
+    def score_nbest_batch(self, src, lengths, hyps, sos, eos, scale=1.0):
+        """All utterances of a decode batch at once: src (S,B,C) padded encoder outputs, lengths (B,), hyps[b] =
+        list of label lists.  Returns out[b][j] = what score_nbest(src[:len_b, b:b+1], hyps[b])[j] returns.
+        One batched encoder pass and ONE pass of the input-feed decoder over all sum_b len(hyps[b]) hypotheses
+        (decode_transducer.py:136-156 scores them one by one, re-encoding the utterance every time)."""
+        dev = src.device
+        B = src.shape[1]
+        lens = torch.as_tensor(lengths).to(torch.int64).cpu()
+        order = torch.argsort(lens, descending=True, stable=True)          # packed sequences want sorted lengths
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(B)
+        enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
+        S = enc_out.shape[0]
+        owner = torch.tensor([inv[b].item() for b in range(B) for _ in hyps[b]], dtype=torch.long, device=dev)
+        flat = [h for b in range(B) for h in hyps[b]]
+        n = len(flat)
+        L = max(len(h) for h in flat) + 1
+        pad = self.tgt_embeddings.padding_idx
+        tok = torch.full((L, n), pad, dtype=torch.long)
+        tgt = torch.full((L, n), pad, dtype=torch.long)
+        for i, h in enumerate(flat):
+            seq = [sos] + list(h) + [eos]
+            tok[:len(seq) - 1, i] = torch.tensor(seq[:-1])
+            tgt[:len(seq) - 1, i] = torch.tensor(seq[1:])
+        tok, tgt = tok.to(dev), tgt.to(dev)
+        ctx = enc_out[:, owner].contiguous()
+        hid = tuple(e[:, owner].contiguous() for e in enc_hidden)
+        mask = torch.arange(S, device=dev).unsqueeze(0) < lens[order].to(dev)[owner].unsqueeze(1)      # (n,S)
+        out, _ = self.decoder.run(tok, ctx, hid, mask=None if bool(mask.all()) else mask)
+        logp = torch.log_softmax(scale * ops.linear(out, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
+        picked = logp.gather(2, tgt.clamp(max=logp.shape[2] - 1).unsqueeze(2)).squeeze(2).cpu()
+        res, i = [], 0
+        for b in range(B):
+            row = []
+            for h in hyps[b]:
+                row.append(picked[:len(h) + 1, i].tolist())
+                i += 1
+            res.append(row)
+        return res
+

@@ -42,6 +42,28 @@ def run(device):
             assert np.allclose(batched[i], z["%s/las/%d" % (attn, i)], rtol=1e-4, atol=1e-4)
 
 
+def test_batched_nbest_scoring_equals_per_utterance_scoring():
+    """score_nbest_batch (one encoder pass + one decoder pass for a whole ragged decode batch) returns what
+    score_nbest returns utterance by utterance."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from trainer.model import las
+    net = las.Net(LC.opt("mlp"), LC.C_IN, LC.V, LC.PAD)
+    net.load_state_dict(seeded_state_dict(net, 31, scale=0.3))
+    net = net.eval()
+    g = torch.Generator().manual_seed(5)
+    lens = [17, 23, 9]
+    src = torch.zeros(23, 3, LC.C_IN)
+    for b, n in enumerate(lens):
+        src[:n, b] = torch.randn(n, LC.C_IN, generator=g)
+    hyps = [[[3, 7, 7, 12], [5], []], [[8, 1, 30, 2, 2, 19, 4], [2, 2]], [[11]]]
+    got = net.score_nbest_batch(src, lens, hyps, LC.SOS, LC.EOS)
+    for b, n in enumerate(lens):
+        want = net.score_nbest(src[:n, b:b + 1], hyps[b], LC.SOS, LC.EOS)
+        assert len(got[b]) == len(want)
+        for a, w in zip(got[b], want):
+            assert np.allclose(a, w, rtol=1e-5, atol=1e-5)
+
+
 def test_cpu_las_rescore_matches_reference():
     run("cpu")
 
