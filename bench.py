@@ -209,7 +209,10 @@ def decode_workload(args, dev, rank):
     with torch.no_grad():
         model.fc2.weight *= 8.0
         lo, hi = 0.0, 40.0
-        for _ in range(8):  # bisection on the blank bias
+        labels = float("nan")
+        if args.blank_bias is not None:      # profiling runs: skip the calibration decodes
+            lo = hi = args.blank_bias
+        for _ in range(8 if args.blank_bias is None else 0):  # bisection on the blank bias
             mid = 0.5 * (lo + hi)
             model.fc2.bias[0] = mid
             ret, _ = decoder(1, 1).decode_batch(feats[:8], x_len[:8], [int(v) + 100 for v in x_len[:8]])
@@ -219,6 +222,7 @@ def decode_workload(args, dev, rank):
             else:
                 hi = mid
         model.fc2.bias[0] = 0.5 * (lo + hi)
+        decode_workload.blank_bias = 0.5 * (lo + hi)
     dec = decoder(args.beam, args.beam, lm_scorer)
 
     def step():
@@ -346,6 +350,8 @@ def main():
     ap.add_argument("--labels", type=int, default=50)
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--cpu-utts", type=int, default=4)
+    ap.add_argument("--blank-bias", type=float, default=None,
+                    help="decode: use this fc2 blank bias instead of calibrating it (profiling runs)")
     ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -397,7 +403,8 @@ def main():
                                            ", fw+bw LAS rescoring of the n-best" if args.las else ""),
                            "audio_seconds": audio_s, "utterances_per_s": B / el,
                            "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
-                           "calibration_labels": cal_labels, "timing": step.decoder.timing}}), flush=True)
+                           "calibration_labels": cal_labels, "blank_bias": decode_workload.blank_bias,
+                           "timing": step.decoder.timing}}), flush=True)
         return
     if args.workload == "rnnt_loss_M1p":
         # SURVEY 8d M1': fused boundary logits -> (costs, d/dlogits); no log-prob tensor, no dense lp gradient

@@ -32,6 +32,18 @@ int pika_beam_advance(const float *logits, float sm_scale, int first, float *sco
                       long long *prev_k_out, void *cand_ws, int B, int K, int V, int blk,
                       int beam_prune, void *stream);
 
+/* Self-attention of ONE new position per beam row over that row's cached prefix, for the incremental
+ * conv-transformer prediction network (pika_amd/decoder/prednet_cache.py; reference arithmetic
+ * trainer/model/multi_headed_attn.py:199-231 at a single query position with the causal mask, i.e. keys at
+ * positions <= pos).  k_cache / v_cache are flat (nodes, d) f32 tables; row r's prefix is
+ * ancestry[r * ancestry_pitch + j] for j < pos[r] and `node[r]` (the freshly stored position) for j == pos[r];
+ * pos is clamped to L-1.  q, out (rows, d) f32; d % heads == 0, head width a multiple of 4 whose quarter is a
+ * power of two (<= 256), d <= 2048, heads * L * 4 bytes <= 64 KiB. */
+int pika_incremental_attention(const float *q, const float *k_cache, const float *v_cache,
+                               const long long *ancestry, long long ancestry_pitch, const long long *pos,
+                               const long long *node, int rows, int L, int d, int heads, float *out,
+                               void *stream);
+
 #ifdef __cplusplus
 }
 #endif

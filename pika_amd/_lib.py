@@ -65,6 +65,7 @@ SIGNATURES = {
                            _vp, _i, _vp]),
     "pika_bn_backward": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     # include/pika_decode.h
+    "pika_incremental_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pika_beam_advance": (_i, [_vp, ctypes.c_float, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
                                _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
                                _i, _vp]),

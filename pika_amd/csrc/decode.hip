@@ -6,6 +6,7 @@
 // index).  The K*K row winners are merged by a rank sort; the bookkeeping of the reference's
 // `advance` (finish rule, hypotheses, finished list, history) runs on K lanes.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "pika_decode.h"
@@ -197,6 +198,103 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One new position of the conv-transformer prediction net's self-attention for every beam row
+// (decoder/prednet_cache.py): the keys / values of a row's prefix live in flat caches addressed through its
+// ancestry list, so attention is a gather-dot-softmax-gather chain over <= L cache rows of d floats.
+// One workgroup per row, thread t owns the 4 dims [4t, 4t+4) (+1024 per extra chunk); the dh/4 threads of a
+// head reduce their partial dots with xor-shuffles; scores sit in LDS (H x L floats).  Reads 2 x (p+1) x d x 4
+// bytes per row -- the unfused chain (two index_select, two permute copies, two batched M=1 GEMMs, mask,
+// softmax) moved ~12x that.
+typedef float at_f4 __attribute__((ext_vector_type(4)));
+
+template <int NQ>   // float4 chunks per thread: d <= 1024 * NQ
+__global__ __launch_bounds__(256) void incr_attn_kernel(const float *__restrict__ q, const float *__restrict__ Kc,
+                                                        const float *__restrict__ Vc,
+                                                        const long long *__restrict__ anc, long long anc_pitch,
+                                                        const long long *__restrict__ pos,
+                                                        const long long *__restrict__ node, int L, int d, int heads,
+                                                        float scale, float *__restrict__ out) {
+    extern __shared__ float sc[];   // [heads][L]
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int dh = d / heads, g = dh >> 2;           // g threads per head (power of two <= 64)
+    const long long p = min(pos[r], (long long)(L - 1));
+    const long long my_node = node[r];
+    const long long *arow = anc + (long long)r * anc_pitch;
+    at_f4 qv[NQ];
+    bool act[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        const int col = (t + c * 256) * 4;
+        act[c] = col < d;
+        qv[c] = act[c] ? *reinterpret_cast<const at_f4 *>(q + (long long)r * d + col) * scale : at_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // pass 1: scores
+    for (long long j0 = 0; j0 <= p; j0 += 4) {
+        float part[4][NQ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = j0 + u;
+            const long long idx = j > p ? my_node : (j == p ? my_node : arow[j]);
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                part[u][c] = 0.f;
+                if (act[c] && j <= p) {
+                    const at_f4 k4 = *reinterpret_cast<const at_f4 *>(Kc + idx * d + (t + c * 256) * 4);
+                    part[u][c] = qv[c].x * k4.x + qv[c].y * k4.y + qv[c].z * k4.z + qv[c].w * k4.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) {
+                float v = part[u][c];
+                for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o);
+                const int col = (t + c * 256) * 4;
+                if (act[c] && j0 + u <= p && (t & (g - 1)) == 0) sc[(col / dh) * L + (int)(j0 + u)] = v;
+            }
+    }
+    __syncthreads();
+    // pass 2: softmax per head (the g threads of a head cooperate), normalised weights back into LDS
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) {
+        if (!act[c]) continue;
+        const int h = ((t + c * 256) * 4) / dh, lane = t & (g - 1);
+        float m = -INFINITY;
+        for (int j = lane; j <= p; j += g) m = fmaxf(m, sc[h * L + j]);
+        for (int o = 1; o < g; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int j = lane; j <= p; j += g) sum += __expf(sc[h * L + j] - m);
+        for (int o = 1; o < g; o <<= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int j = lane; j <= p; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
+    }
+    __syncthreads();
+    // pass 3: context
+    at_f4 acc[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) acc[c] = at_f4{0.f, 0.f, 0.f, 0.f};
+    for (long long j0 = 0; j0 <= p; j0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = j0 + u;
+            if (j > p) break;
+            const long long idx = j == p ? my_node : arow[j];
+#pragma unroll
+            for (int c = 0; c < NQ; ++c)
+                if (act[c]) {
+                    const int col = (t + c * 256) * 4;
+                    const float a = sc[(col / dh) * L + (int)j];
+                    acc[c] += *reinterpret_cast<const at_f4 *>(Vc + idx * d + col) * a;
+                }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NQ; ++c)
+        if (act[c]) *reinterpret_cast<at_f4 *>(out + (long long)r * d + (t + c * 256) * 4) = acc[c];
+}
+
 }  // namespace
 
 extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first, float *scores,
@@ -234,5 +332,30 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
                        lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist,
                        ys_hist, step_t, eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out,
                        B, K, V, blk);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pika_incremental_attention(const float *q, const float *k_cache, const float *v_cache,
+                                          const long long *ancestry, long long ancestry_pitch,
+                                          const long long *pos, const long long *node, int rows, int L, int d,
+                                          int heads, float *out, void *stream) {
+    if (!q || !k_cache || !v_cache || !ancestry || !pos || !node || !out || rows <= 0 || L <= 0 || d <= 0 || heads <= 0)
+        return PIKA_EINVAL;
+    if (d % heads || (d & 3)) return PIKA_EINVAL;
+    const int dh = d / heads, g = dh >> 2;
+    if ((dh & 3) || g < 1 || g > 64 || (g & (g - 1))) return PIKA_EINVAL;     // dh/4 threads per head, power of two
+    if (d > 2048 || (size_t)heads * L * sizeof(float) > 64 * 1024) return PIKA_ETOOBIG;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) |
+         reinterpret_cast<uintptr_t>(out)) & 15)
+        return PIKA_EINVAL;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const size_t smem = (size_t)heads * L * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d <= 1024)
+        hipLaunchKernelGGL(incr_attn_kernel<1>, dim3(rows), dim3(256), smem, s, q, k_cache, v_cache, ancestry,
+                           ancestry_pitch, pos, node, L, d, heads, scale, out);
+    else
+        hipLaunchKernelGGL(incr_attn_kernel<2>, dim3(rows), dim3(256), smem, s, q, k_cache, v_cache, ancestry,
+                           ancestry_pitch, pos, node, L, d, heads, scale, out);
     return (int)hipGetLastError();
 }

@@ -15,6 +15,7 @@ import math
 
 import torch
 
+from .. import _lib
 from ..model import ops
 
 
@@ -35,6 +36,7 @@ class IncrementalPredNet(object):
         self.wconv = [c.weight.permute(0, 2, 1).reshape(c.weight.shape[0], -1).contiguous()
                       for c in net.conv]                                # tap-major (N, 5*C)
         self.row_ids = torch.arange(rows, device=device)
+        self.fused = True     # HIP incremental-attention kernel on the GPU (include/pika_decode.h)
         # node 0 = the shared SOS position: process it once
         sos = torch.full((rows,), blk, dtype=torch.long, device=device)
         p0 = torch.zeros(rows, dtype=torch.long, device=device)
@@ -73,6 +75,19 @@ class IncrementalPredNet(object):
             self.Kc[l].index_copy_(0, node, k)
             self.Vc[l].index_copy_(0, node, v)
             H, dh = self.heads, self.d // self.heads
+            if self._fused_attention(q_, L):
+                # one HIP launch reads the prefix keys / values straight through the ancestry list
+                ctx = torch.empty_like(q_)
+                with torch.cuda.device(q_.device):
+                    _lib.check(_lib.lib().pika_incremental_attention(
+                        q_.data_ptr(), self.Kc[l].data_ptr(), self.Vc[l].data_ptr(), self.anc.data_ptr(),
+                        self.anc.stride(0), p.data_ptr(), node.data_ptr(), self.rows, L, self.d, H, ctx.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream), "pika_incremental_attention")
+                o = ops.linear(ctx, att.final_linear.weight, att.final_linear.bias) + y
+                ff = layer.feed_forward
+                hmid = ops.relu(ops.linear(ops.layer_norm(o, ff.layer_norm), ff.w_1.weight, ff.w_1.bias))
+                x = ops.linear(hmid, ff.w_2.weight, ff.w_2.bias) + o
+                continue
             Kp = self.Kc[l].index_select(0, anc_now.reshape(-1)).view(self.rows, L, H, dh)
             Vp = self.Vc[l].index_select(0, anc_now.reshape(-1)).view(self.rows, L, H, dh)
             qh = (q_ / math.sqrt(dh)).view(self.rows, H, 1, dh)
@@ -88,6 +103,13 @@ class IncrementalPredNet(object):
         self.anc[:, :L].copy_(torch.where(commit.unsqueeze(1), anc_now, anc))
         out = ops.linear(ops.layer_norm(x, net.layer_norm), net.linear_out.weight, net.linear_out.bias)
         return out
+
+    def _fused_attention(self, q, L):
+        dh = self.d // self.heads
+        g = dh // 4
+        return (q.is_cuda and q.dtype == torch.float32 and self.d % 4 == 0 and dh % 4 == 0 and g >= 1
+                and g <= 64 and (g & (g - 1)) == 0 and self.d <= 2048 and self.heads * L * 4 <= 64 * 1024
+                and self.fused)
 
     def step(self, state, tok, hyp_len, step_t, L):
         """tok (rows,) last symbols; rows with a label (> blank) append it at position hyp_len

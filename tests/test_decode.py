@@ -116,3 +116,36 @@ def test_gpu_fused_advance_kernel_equals_tensor_op_path(hip_device):
                 assert np.allclose(outs[0]["scores"], outs[1]["scores"], atol=2e-4), (dec, beam)
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,L,d,heads", [(5, 1, 64, 4), (37, 17, 256, 4), (64, 48, 1024, 16), (9, 33, 2048, 8), (12, 40, 512, 8)])
+def test_incremental_attention_kernel(hip_device, rows, L, d, heads):
+    """pika_incremental_attention vs the gather / matmul / masked softmax chain of prednet_cache.py on random
+    caches, ancestry lists and positions (keys at positions <= pos, the new position read from `node`)."""
+    import math
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(rows * 7 + L)
+    cap = rows * (L + 2) + 3
+    Kc = torch.randn(cap, d, generator=g).to(hip_device)
+    Vc = torch.randn(cap, d, generator=g).to(hip_device)
+    q = torch.randn(rows, d, generator=g).to(hip_device)
+    anc = torch.randint(0, cap - 1, (rows, L + 3), generator=g).to(hip_device)
+    pos = torch.randint(0, L, (rows,), generator=g).to(hip_device)
+    pos[0] = L - 1
+    node = torch.randint(0, cap - 1, (rows,), generator=g).to(hip_device)
+    out = torch.empty_like(q)
+    rc = _lib.lib().pika_incremental_attention(q.data_ptr(), Kc.data_ptr(), Vc.data_ptr(), anc.data_ptr(), anc.stride(0),
+                                               pos.data_ptr(), node.data_ptr(), rows, L, d, heads, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pika_incremental_attention")
+    dh = d // heads
+    ar = torch.arange(L, device=hip_device).unsqueeze(0)
+    anc_now = torch.where(ar.eq(pos.unsqueeze(1)), node.unsqueeze(1), anc[:, :L])
+    valid = ar <= pos.unsqueeze(1)
+    Kp = Kc.double().index_select(0, anc_now.reshape(-1)).view(rows, L, heads, dh)
+    Vp = Vc.double().index_select(0, anc_now.reshape(-1)).view(rows, L, heads, dh)
+    qh = (q.double() / math.sqrt(dh)).view(rows, heads, 1, dh)
+    sc = torch.matmul(qh, Kp.permute(0, 2, 3, 1)).masked_fill(~valid.view(rows, 1, 1, L), -1e18)
+    want = torch.matmul(torch.softmax(sc, dim=-1), Vp.permute(0, 2, 1, 3)).reshape(rows, d)
+    assert (out.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
