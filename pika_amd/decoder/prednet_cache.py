@@ -37,6 +37,15 @@ class IncrementalPredNet(object):
                       for c in net.conv]                                # tap-major (N, 5*C)
         self.row_ids = torch.arange(rows, device=device)
         self.fused = True     # HIP incremental-attention kernel on the GPU (include/pika_decode.h)
+        # weights are constant while decoding: the three attention projections of a layer become ONE GEMM
+        self.wqkv, self.bqkv = [], []
+        for layer in net.transformer:
+            a = layer.self_attn
+            self.wqkv.append(torch.cat([a.linear_keys.weight, a.linear_values.weight, a.linear_query.weight], 0)
+                             .detach().contiguous())
+            self.bqkv.append(torch.cat([a.linear_keys.bias, a.linear_values.bias, a.linear_query.bias], 0)
+                             .detach().contiguous())
+        self._tap_off = torch.arange(-4, 0, device=device).unsqueeze(0)          # conv taps p-4 .. p-1
         # node 0 = the shared SOS position: process it once
         sos = torch.full((rows,), blk, dtype=torch.long, device=device)
         p0 = torch.zeros(rows, dtype=torch.long, device=device)
@@ -56,22 +65,19 @@ class IncrementalPredNet(object):
         x = net.embeddings(tok.clamp(min=0))
         for l in range(self.nl):
             self.X[l].index_copy_(0, node, x)
-            # causal conv: taps at positions p-4 .. p (zeros left of position 0)
-            taps = []
-            for j in range(4):
-                q = p - 4 + j
-                idx = anc_now.gather(1, q.clamp(min=0).unsqueeze(1)).squeeze(1)
-                idx = torch.where(q >= 0, idx, torch.full_like(idx, self.zero_node))
-                taps.append(self.X[l].index_select(0, idx))
-            taps.append(x)
+            # causal conv: taps at positions p-4 .. p (zeros left of position 0), gathered in one go
+            if l == 0:
+                tq = p.unsqueeze(1) + self._tap_off                                 # (rows, 4)
+                tap_idx = torch.where(tq >= 0, anc_now.gather(1, tq.clamp(min=0)),
+                                      torch.full_like(tq, self.zero_node)).reshape(-1)
+            taps = self.X[l].index_select(0, tap_idx).view(self.rows, -1)           # (rows, 4*C)
             conv = net.conv[l]
-            y = ops.relu(ops.linear(torch.cat(taps, dim=1), self.wconv[l], conv.bias))
+            y = ops.linear(torch.cat((taps, x), dim=1), self.wconv[l], conv.bias, relu=1)
             layer = net.transformer[l]
             att = layer.self_attn
             n = ops.layer_norm(y, layer.layer_norm)
-            k = ops.linear(n, att.linear_keys.weight, att.linear_keys.bias)
-            v = ops.linear(n, att.linear_values.weight, att.linear_values.bias)
-            q_ = ops.linear(n, att.linear_query.weight, att.linear_query.bias)
+            kvq = ops.linear(n, self.wqkv[l], self.bqkv[l])
+            k, v, q_ = kvq[:, :self.d], kvq[:, self.d:2 * self.d], kvq[:, 2 * self.d:].contiguous()
             self.Kc[l].index_copy_(0, node, k)
             self.Vc[l].index_copy_(0, node, v)
             H, dh = self.heads, self.d // self.heads
@@ -85,7 +91,7 @@ class IncrementalPredNet(object):
                         torch.cuda.current_stream().cuda_stream), "pika_incremental_attention")
                 o = ops.linear(ctx, att.final_linear.weight, att.final_linear.bias) + y
                 ff = layer.feed_forward
-                hmid = ops.relu(ops.linear(ops.layer_norm(o, ff.layer_norm), ff.w_1.weight, ff.w_1.bias))
+                hmid = ops.linear(ops.layer_norm(o, ff.layer_norm), ff.w_1.weight, ff.w_1.bias, relu=1)
                 x = ops.linear(hmid, ff.w_2.weight, ff.w_2.bias) + o
                 continue
             Kp = self.Kc[l].index_select(0, anc_now.reshape(-1)).view(self.rows, L, H, dh)
