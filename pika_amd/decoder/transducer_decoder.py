@@ -109,6 +109,10 @@ class TransducerDecoder(object):
         e1_all = ops.linear(enc_out, w1.weight[:, :H].contiguous(), w1.bias)
         eg_all = ops.linear(enc_out, wg.weight[:, :H].contiguous(), wg.bias)
         w1p, wgp = w1.weight[:, H:].contiguous(), wg.weight[:, H:].contiguous()
+        # per step: both prediction halves of the joint as ONE GEMM, one gather of the encoder halves
+        e_all = torch.cat((e1_all, eg_all), dim=2).reshape(B * T, 2 * H)          # row b*T + t = [e1 | eg]
+        wp = torch.cat((w1p, wgp), dim=0).contiguous()                            # (2H, H)
+        brow = (torch.arange(B, device=dev) * T).unsqueeze(1)
 
         t_idx = torch.full((B, K), -1, dtype=torch.long, device=dev)          # :107
         self._inc = None
@@ -128,9 +132,8 @@ class TransducerDecoder(object):
             if not first:
                 self._pred_step(state, inp.reshape(-1), beam, L)
             dec_hid = state[0][-1] if rnn else state[0]                       # (B*K,H)
-            z1 = e1_all[bidx, tg] + ops.linear(dec_hid, w1p).view(B, K, H)
-            zg = eg_all[bidx, tg] + ops.linear(dec_hid, wgp).view(B, K, H)
-            h = torch.tanh(z1) * torch.sigmoid(zg)
+            z = e_all.index_select(0, (brow + tg).reshape(-1)) + ops.linear(dec_hid, wp)   # (B*K, 2H)
+            h = (torch.tanh(z[:, :H]) * torch.sigmoid(z[:, H:])).view(B, K, H)
             logits = ops.linear(h, model.fc2.weight, model.fc2.bias)
             if fused:
                 prev_k = beam.advance_fused(logits.contiguous(), t_idx, num_frames, self.sm_scale,
