@@ -34,15 +34,21 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     headers = glob.glob(os.path.join(INCLUDE, "*.h")) + glob.glob(os.path.join(CSRC, "*.h")) \
         + glob.glob(os.path.join(CSRC, "*.hpp"))
-    objs = []
+    objs, jobs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if force or _stale(obj, [src] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        objs.append(obj)
+    if jobs:   # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4, 8)) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
