@@ -203,7 +203,7 @@ def decode_workload(args, dev, rank):
     def decoder(beam, nbest, lm=None):
         return TransducerDecoder(model, batch_size=B, beam_size=beam, n_best=nbest, blk=0,
                                  global_scorer=GlobalScorer(), sm_scale=0.8, cuda=True,
-                                 lm_scorer=lm, lm_scorer_scale=0.3,
+                                 lm_scorer=lm, lm_scorer_scale=args.fst_scale,
                                  beam_prune=True, args=dargs)
 
     with torch.no_grad():
@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--blank-bias", type=float, default=None,
                     help="decode: use this fc2 blank bias instead of calibrating it (profiling runs)")
     ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
+    ap.add_argument("--fst-scale", type=float, default=0.02,
+                    help="decode --fst: LM weight (small: the synthetic LM is random, the search should keep emitting)")
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
@@ -399,7 +401,7 @@ def main():
                 "config": {"workload": "decode: B=%d beam=%d n_best=%d, %d-frame utterances, full model "
                                        "(%s prediction net), sm_scale 0.8%s%s" % (
                                            B, args.beam, args.beam, T, args.pred_net,
-                                           ", bigram FST shallow fusion (host-side state sets)" if args.fst else "",
+                                           ", bigram FST shallow fusion (device-resident FST, scale %g)" % args.fst_scale if args.fst else "",
                                            ", fw+bw LAS rescoring of the n-best" if args.las else ""),
                            "audio_seconds": audio_s, "utterances_per_s": B / el,
                            "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,

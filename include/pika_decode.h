@@ -29,8 +29,29 @@ int pika_beam_advance(const float *logits, float sm_scale, int first, float *sco
                       long long *hyp_len, int L, long long *ks_hist, long long *ys_hist,
                       const long long *step_t, unsigned char *eos_top, float *fin_score,
                       long long *fin_step, long long *fin_k, long long *fin_n, int fin_cap,
-                      long long *prev_k_out, void *cand_ws, int B, int K, int V, int blk,
-                      int beam_prune, void *stream);
+                      long long *prev_k_out, long long *y_raw, void *cand_ws, int B, int K, int V,
+                      int blk, int beam_prune, void *stream);
+/* y_raw (B,K) i64, may be NULL: the selected symbols BEFORE finished slots are overwritten with eos -- what the
+ * FST update below needs. */
+
+/* N-gram FST shallow fusion on the device, called right after pika_beam_advance of the same step (reference
+ * beam_transducer.py:135-181 with decoder/sorted_matcher.py:24-111).  The FST is an ilabel-sorted CSR table
+ * (offsets i64 (S+1), ilabel i32, weight f32, nextstate i32, final f32 with +inf = not final; DEVICE memory);
+ * disambig_ids is a HOST array of n_disambig <= 4 labels.  Per beam slot a set of at most
+ * pika_fst_states_per_slot() LM states is kept in set_n (B*K) i32, set_state (B*K*S) i32, set_cost (B*K*S) f64
+ * (initialise slot sets to {state 0: 0.0}).  The call re-orders the sets by prev_k, advances them by y_raw + 1
+ * (non-blank symbols; same back-off / disambiguation walk and the same "first smaller wins" update as the
+ * reference), writes lm_scores (B,K), and for the slots that finished in this step (y == eos) adds
+ * lm_scale * (- best final cost) to scores and to the finished-list entries the advance call just appended.
+ * *err is OR-ed with 1 if a set overflowed or a finishing slot had no final state (the reference raises). */
+int pika_fst_advance(const long long *fst_offsets, const int *fst_ilabel, const float *fst_weight,
+                     const int *fst_nextstate, const float *fst_final, int max_num_arcs, int max_id,
+                     int backoff_id, const int *disambig_ids, int n_disambig, const long long *prev_k,
+                     const long long *y_raw, const long long *y, int blk, double nonblk_reward, float lm_scale,
+                     int *set_n, int *set_state, double *set_cost, float *lm_scores, float *scores,
+                     float *fin_score, const long long *fin_n, int fin_cap, int B, int K, int *err,
+                     void *stream);
+int pika_fst_states_per_slot(void);
 
 /* Self-attention of ONE new position per beam row over that row's cached prefix, for the incremental
  * conv-transformer prediction network (pika_amd/decoder/prednet_cache.py; reference arithmetic

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -67,8 +67,11 @@ SIGNATURES = {
     # include/pika_decode.h
     "pika_incremental_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pika_beam_advance": (_i, [_vp, ctypes.c_float, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,
-                               _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i,
+                               _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i,
                                _i, _vp]),
+    "pika_fst_advance": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, ctypes.c_double,
+                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pika_fst_states_per_slot": (_i, []),
     # include/pika_audio.h
     "pika_audio_perturb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp, _vp, _vp]),
     "pika_fbank": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, ctypes.c_float, ctypes.c_float,

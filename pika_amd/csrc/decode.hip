@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(
     long long *__restrict__ ys_hist, const long long *__restrict__ step_t,
     unsigned char *__restrict__ eos_top, float *__restrict__ fin_score,
     long long *__restrict__ fin_step, long long *__restrict__ fin_k, long long *__restrict__ fin_n,
-    int fin_cap, long long *__restrict__ prev_k_out, int B, int K, int V, int blk) {
+    int fin_cap, long long *__restrict__ prev_k_out, long long *__restrict__ y_raw, int B, int K, int V,
+    int blk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
     Cand *cand = reinterpret_cast<Cand *>(hyp_l + K * L);                // [K][K]
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(
         prev_k_out[bk + tid] = pk;
         ks_hist[(s * B + b) * K + tid] = pk;
         const long long yn = fin ? EOS : (long long)ysym;
+        if (y_raw) y_raw[bk + tid] = ysym;          // the symbol before the eos substitution (FST fusion)
         y[bk + tid] = yn;
         ys_hist[((s + 1) * B + b) * K + tid] = yn;
         t_idx[bk + tid] = t_old[pk];                // transducer_decoder.py:201-202
@@ -295,6 +297,153 @@ __global__ __launch_bounds__(256) void incr_attn_kernel(const float *__restrict_
         if (act[c]) *reinterpret_cast<at_f4 *>(out + (long long)r * d + (t + c * 256) * 4) = acc[c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// On-the-fly n-gram FST scoring of the surviving candidates (reference beam_transducer.py:135-181 +
+// decoder/sorted_matcher.py:24-111), device resident: one thread per beam slot, the LM state set of a slot is a
+// small ordered array (insertion order = the reference's dict order, which its "first smaller wins" update
+// depends on), costs in fp64 like the Python floats.  One workgroup per utterance so that every slot reads its
+// PARENT's set before any slot overwrites its own.
+constexpr int FST_SM = 8;        // states per slot (an n-gram LM needs 1-3); overflow raises a flag
+constexpr int FST_MAXDIS = 4;
+
+struct FstDev {
+    const long long *off;
+    const int *il;
+    const float *wt;
+    const int *ns;
+    const float *fin;
+    int max_num_arcs, max_id, backoff_id, ndis;
+    int dis[FST_MAXDIS];
+};
+
+// sorted_matcher.py:30-48: lower bound over a window of max_num_arcs slots whose tail reads as max_id
+__device__ inline long long fst_search(const FstDev &F, int state, int label) {
+    const long long lo = F.off[state], hi = F.off[state + 1];
+    const long long n = hi - lo;
+    const long long w = n < F.max_num_arcs ? n : F.max_num_arcs;
+    long long a = 0, b = w;
+    while (a < b) {
+        const long long m = (a + b) >> 1;
+        if (F.il[lo + m] < label) a = m + 1; else b = m;
+    }
+    long long idx = a;
+    if (idx >= w) idx = (w < F.max_num_arcs && F.max_id >= label) ? w : F.max_num_arcs - 1;
+    if (idx >= n || F.il[lo + idx] != label) return -1;
+    return lo + idx;
+}
+
+__global__ __launch_bounds__(64) void fst_advance_kernel(FstDev F, const long long *__restrict__ prev_k,
+                                                         const long long *__restrict__ y_raw,
+                                                         const long long *__restrict__ y_now, int blk,
+                                                         double nonblk_reward, float lm_scale,
+                                                         int *__restrict__ set_n, int *__restrict__ set_st,
+                                                         double *__restrict__ set_cs,
+                                                         float *__restrict__ lm_scores, float *__restrict__ scores,
+                                                         float *__restrict__ fin_score,
+                                                         const long long *__restrict__ fin_n, int fin_cap, int K,
+                                                         int *__restrict__ err) {
+    __shared__ int fin_flag[64];
+    const int b = blockIdx.x, i = threadIdx.x;
+    const long long bk = (long long)b * K;
+    int pn = 0, pst[FST_SM];
+    double pcs[FST_SM];
+    long long yr = blk;
+    if (i < K) {
+        const long long pk = prev_k[bk + i];
+        yr = y_raw[bk + i];
+        pn = set_n[bk + pk];
+        for (int s = 0; s < FST_SM; ++s) { pst[s] = set_st[(bk + pk) * FST_SM + s]; pcs[s] = set_cs[(bk + pk) * FST_SM + s]; }
+    }
+    __syncthreads();                                   // every parent set is in registers before any write
+    int nn = 0, nst[FST_SM];
+    double ncs[FST_SM];
+    bool overflow = false;
+    if (i < K) {
+        if (yr == blk) {                               // :151-152
+            nn = pn;
+            for (int s = 0; s < FST_SM; ++s) { nst[s] = pst[s]; ncs[s] = pcs[s]; }
+        } else {
+            const int ilabel = (int)yr + 1;            // :139
+            for (int s = 0; s < pn; ++s) {
+                // get_scores: the state itself, then the destinations of its disambiguation arcs
+                for (int d = -1; d < F.ndis; ++d) {
+                    int cur = pst[s];
+                    double bf = 0.0;
+                    if (d >= 0) {
+                        const long long a = fst_search(F, pst[s], F.dis[d]);
+                        if (a < 0) continue;
+                        bf = (double)F.wt[a];
+                        cur = F.ns[a];
+                    }
+                    for (;;) {                         // get_scores_wodisambig: walk the back-off chain
+                        const long long a = fst_search(F, cur, ilabel);
+                        if (a >= 0) {
+                            const double next_cost = pcs[s] + (bf + (double)F.wt[a]);
+                            const int nxt = F.ns[a];
+                            int f = -1;
+                            for (int q = 0; q < nn; ++q) if (nst[q] == nxt) { f = q; break; }
+                            if (f < 0) {
+                                if (nn < FST_SM) { nst[nn] = nxt; ncs[nn] = next_cost - nonblk_reward; ++nn; }
+                                else overflow = true;
+                            } else if (next_cost < ncs[f]) {   // :147-149 (sic: compared without the reward)
+                                ncs[f] = next_cost - nonblk_reward;
+                            }
+                        }
+                        const long long bo = fst_search(F, cur, F.backoff_id);
+                        if (bo < 0) break;
+                        bf += (double)F.wt[bo];
+                        cur = F.ns[bo];
+                    }
+                }
+            }
+        }
+        double mn = INFINITY;
+        for (int q = 0; q < nn; ++q) mn = fmin(mn, ncs[q]);
+        lm_scores[bk + i] = nn ? (float)(-mn) : -1e20f;      // :153-157
+        set_n[bk + i] = nn;
+        for (int s = 0; s < FST_SM; ++s) { set_st[(bk + i) * FST_SM + s] = nst[s]; set_cs[(bk + i) * FST_SM + s] = ncs[s]; }
+    }
+    fin_flag[i] = (i < K && y_now[bk + i] == EOS) ? 1 : 0;
+    __syncthreads();
+    if (i < K && fin_flag[i]) {
+        // final cost (:165-181, sorted_matcher.final_score): min over active states and their disambiguation
+        // destinations of cost + (back-off chain to a final state)
+        double best = INFINITY;
+        for (int s = 0; s < nn; ++s) {
+            for (int d = -1; d < F.ndis; ++d) {
+                int cur = nst[s];
+                double sc = 0.0;
+                if (d >= 0) {
+                    const long long a = fst_search(F, nst[s], F.dis[d]);
+                    if (a < 0) continue;
+                    sc = (double)F.wt[a];
+                    cur = F.ns[a];
+                }
+                bool ok = true;
+                for (;;) {
+                    const float fw = F.fin[cur];
+                    if (isinf(fw)) {
+                        const long long bo = fst_search(F, cur, F.backoff_id);
+                        if (bo < 0) { ok = false; break; }
+                        sc += (double)F.wt[bo];
+                        cur = F.ns[bo];
+                    } else { sc += (double)fw; break; }
+                }
+                if (ok) best = fmin(best, ncs[s] + sc);
+            }
+        }
+        if (isinf(best)) overflow = true;              // the reference would raise on an empty candidate set
+        int total = 0, rank = 0;
+        for (int q = 0; q < K; ++q) { total += fin_flag[q]; rank += (q < i) ? fin_flag[q] : 0; }
+        const float v = scores[bk + i] + lm_scale * (float)(-best);
+        scores[bk + i] = v;                            // `s = self.scores[i]` is a view: the final cost lands here too
+        long long pos = fin_n[b] - total + rank;
+        if (pos > fin_cap - 2) pos = fin_cap - 2;
+        fin_score[(long long)b * fin_cap + pos] = v;
+    }
+    if (overflow) atomicOr(err, 1);
+}
+
 }  // namespace
 
 extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first, float *scores,
@@ -304,8 +453,8 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
                                  long long *ks_hist, long long *ys_hist, const long long *step_t,
                                  unsigned char *eos_top, float *fin_score, long long *fin_step,
                                  long long *fin_k, long long *fin_n, int fin_cap,
-                                 long long *prev_k_out, void *cand_ws, int B, int K, int V, int blk,
-                                 int beam_prune, void *stream) {
+                                 long long *prev_k_out, long long *y_raw, void *cand_ws, int B, int K,
+                                 int V, int blk, int beam_prune, void *stream) {
     if (!logits || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
         !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step ||
         !fin_k || !fin_n || !prev_k_out || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3)
@@ -331,7 +480,7 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
                        (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand), st, cand, first, scores,
                        lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist,
                        ys_hist, step_t, eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out,
-                       B, K, V, blk);
+                       y_raw, B, K, V, blk);
     return (int)hipGetLastError();
 }
 
@@ -359,3 +508,24 @@ extern "C" int pika_incremental_attention(const float *q, const float *k_cache, 
                            ancestry_pitch, pos, node, L, d, heads, scale, out);
     return (int)hipGetLastError();
 }
+
+extern "C" int pika_fst_advance(const long long *fst_offsets, const int *fst_ilabel, const float *fst_weight,
+                                const int *fst_nextstate, const float *fst_final, int max_num_arcs, int max_id,
+                                int backoff_id, const int *disambig_ids, int n_disambig,
+                                const long long *prev_k, const long long *y_raw, const long long *y, int blk,
+                                double nonblk_reward, float lm_scale, int *set_n, int *set_state,
+                                double *set_cost, float *lm_scores, float *scores, float *fin_score,
+                                const long long *fin_n, int fin_cap, int B, int K, int *err, void *stream) {
+    if (!fst_offsets || !fst_ilabel || !fst_weight || !fst_nextstate || !fst_final || !prev_k || !y_raw || !y ||
+        !set_n || !set_state || !set_cost || !lm_scores || !scores || !fin_score || !fin_n || !err || B <= 0 || K <= 0)
+        return PIKA_EINVAL;
+    if (K > 64 || n_disambig < 0 || n_disambig > FST_MAXDIS || (n_disambig && !disambig_ids)) return PIKA_ETOOBIG;
+    FstDev F{fst_offsets, fst_ilabel, fst_weight, fst_nextstate, fst_final, max_num_arcs, max_id, backoff_id, n_disambig, {0, 0, 0, 0}};
+    for (int i = 0; i < n_disambig; ++i) F.dis[i] = disambig_ids[i];     // host array
+    hipLaunchKernelGGL(fst_advance_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), F, prev_k, y_raw,
+                       y, blk, nonblk_reward, lm_scale, set_n, set_state, set_cost, lm_scores, scores, fin_score,
+                       fin_n, fin_cap, K, err);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pika_fst_states_per_slot(void) { return FST_SM; }

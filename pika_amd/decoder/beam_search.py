@@ -24,6 +24,7 @@ class BeamState(object):
         # FST shallow fusion keeps, per slot, the set of active LM states with their costs (:64-70);
         # sets are ragged, so this path runs on the host (one device read per step)
         self.state_sets = [[{0: 0.0} for _ in range(K)] for _ in range(B)] if lm_scorer else None
+        self.fst_dev = None      # device-resident FST + state sets (include/pika_decode.h), set up below
         self.B, self.K, self.V = B, K, vocab
         self.blk, self.n_best, self.beam_prune = blk, n_best, beam_prune
         self.device = device
@@ -52,6 +53,53 @@ class BeamState(object):
         self._earlier = torch.tril(torch.ones(K, K, dtype=torch.bool, device=device), diagonal=-1).unsqueeze(0)
         self._kidx = torch.arange(K, device=device).unsqueeze(0).expand(B, K).contiguous()
         self._brow = (torch.arange(B, device=device) * self.fin_cap).unsqueeze(1)
+        if lm_scorer is not None and device.type == "cuda":
+            self._init_device_fst()
+
+    def _init_device_fst(self):
+        """Upload the matcher's CSR tables and create the per-slot LM state sets on the device, so the FST
+        update runs as one HIP launch per step (and the step stays hipGraph-capturable)."""
+        import ctypes
+        from .. import _lib
+        m = self.lm_scorer
+        f = getattr(m, "fst", None)
+        if f is None or not hasattr(f, "offsets") or len(m.disambig_ids) > 4 or self.K > 64:
+            return
+        dev, n = self.device, self.B * self.K
+        sm = _lib.lib().pika_fst_states_per_slot()
+        d = {"off": torch.as_tensor(f.offsets, dtype=torch.int64, device=dev),
+             "il": torch.as_tensor(f.ilabel, dtype=torch.int32, device=dev),
+             "wt": torch.as_tensor(f.weight, dtype=torch.float32, device=dev),
+             "ns": torch.as_tensor(f.nextstate, dtype=torch.int32, device=dev),
+             "fin": torch.as_tensor(f.final, dtype=torch.float32, device=dev),
+             "dis": (ctypes.c_int * max(len(m.disambig_ids), 1))(*m.disambig_ids), "ndis": len(m.disambig_ids),
+             "set_n": torch.ones(n, dtype=torch.int32, device=dev),               # every slot starts as {0: 0.0}
+             "set_st": torch.zeros(n, sm, dtype=torch.int32, device=dev),
+             "set_cs": torch.zeros(n, sm, dtype=torch.float64, device=dev),
+             "err": torch.zeros(1, dtype=torch.int32, device=dev),
+             "y_raw": torch.zeros(self.B, self.K, dtype=torch.long, device=dev)}
+        self.fst_dev = d
+
+    def _fst_advance_device(self, prev_k, lm_scale):
+        import ctypes
+        from .. import _lib
+        d, m = self.fst_dev, self.lm_scorer
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().pika_fst_advance(
+                d["off"].data_ptr(), d["il"].data_ptr(), d["wt"].data_ptr(), d["ns"].data_ptr(), d["fin"].data_ptr(),
+                int(m.max_num_arcs), int(m.max_id), int(m.backoff_id), ctypes.cast(d["dis"], ctypes.c_void_p), d["ndis"],
+                prev_k.data_ptr(), d["y_raw"].data_ptr(), self.y.data_ptr(), self.blk, float(self.nonblk_reward),
+                float(lm_scale), d["set_n"].data_ptr(), d["set_st"].data_ptr(), d["set_cs"].data_ptr(),
+                self.lm_scores.data_ptr(), self.scores.data_ptr(), self.fin_score.data_ptr(), self.fin_n.data_ptr(),
+                self.fin_cap, self.B, self.K, d["err"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pika_fst_advance")
+
+    def check_fst(self):
+        """After the search: a state set overflowed / a finishing slot had no final state (the host path and the
+        reference would have coped or raised): never return silently wrong scores."""
+        if self.fst_dev is not None and int(self.fst_dev["err"].item()):
+            raise RuntimeError("pika_amd: device FST search overflowed its per-slot state sets (or a finished "
+                               "hypothesis has no final LM state); decode this batch with fused_step=False")
 
     def duplicate_mask(self):
         """beam_transducer.py:106-114: a live slot is disabled if an earlier live slot holds the
@@ -181,7 +229,7 @@ class BeamState(object):
         return out.to(self.device)
 
     def fused_ok(self):
-        return (self.device.type == "cuda" and self.lm_scorer is None and self.K <= 64 and
+        return (self.device.type == "cuda" and (self.lm_scorer is None or self.fst_dev is not None) and self.K <= 64 and
                 self.K <= self.V <= 5120 and self.K * self.hyp.shape[2] * 4 <= 64 * 1024)
 
     def advance_fused(self, logits, t_idx, num_frames, sm_scale, lm_scale, first):
@@ -201,9 +249,12 @@ class BeamState(object):
                 self.hyp_len.data_ptr(), self.hyp.shape[2], self.ks_hist.data_ptr(),
                 self.ys_hist.data_ptr(), self.step_t.data_ptr(), self._eos_u8.data_ptr(),
                 self.fin_score.data_ptr(), self.fin_step.data_ptr(), self.fin_k.data_ptr(),
-                self.fin_n.data_ptr(), self.fin_cap, self._prev_k.data_ptr(), self._cand.data_ptr(), self.B, self.K, self.V,
-                self.blk, int(self.beam_prune), torch.cuda.current_stream().cuda_stream)
+                self.fin_n.data_ptr(), self.fin_cap, self._prev_k.data_ptr(),
+                None if self.fst_dev is None else self.fst_dev["y_raw"].data_ptr(), self._cand.data_ptr(), self.B,
+                self.K, self.V, self.blk, int(self.beam_prune), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "pika_beam_advance")
+        if self.fst_dev is not None:
+            self._fst_advance_device(self._prev_k, lm_scale)
         self.step_t += 1
         self.eos_top.copy_(self._eos_u8.bool())
         return self._prev_k

@@ -152,14 +152,13 @@ class TransducerDecoder(object):
             flags[0] = beam.done().all().long()
             flags[1] = beam.hyp_len.max()
 
-        fused = self.fused_step and beam.fused_ok()
-
         def bucket(max_hyp):  # prefix length (SOS + labels) the prediction net attends over
             return 2 if rnn else min(beam.hyp.shape[2] + 1, ((max_hyp + 1 + 1 + 15) // 16) * 16)
 
         import time as _time
         _t0 = _time.perf_counter()
-        use_graph = enc_out.is_cuda and self.use_graph and self.lm_scorer is None
+        fused = self.fused_step and beam.fused_ok()
+        use_graph = enc_out.is_cuda and self.use_graph and (self.lm_scorer is None or (fused and beam.fst_dev is not None))
         graphs = {}
         n_eager = 0
         step(True, 2)
@@ -182,6 +181,7 @@ class TransducerDecoder(object):
         self.t_idx = t_idx
         self.dec_states = tuple(state) if rnn else state[0]
         _t1 = _time.perf_counter()
+        beam.check_fst()
         preds, scores = beam.results()
         self.timing = {"search_s": _t1 - _t0, "results_s": _time.perf_counter() - _t1,
                        "steps": beam.steps, "graphs": len(graphs)}

@@ -82,6 +82,14 @@ def run(dec, device):
         pre = "%s/%s/" % (dec, name)
         assert np.array_equal(got["hyps"], z[pre + "hyps"]), (dec, name)
         assert np.allclose(got["scores"], z[pre + "scores"], rtol=1e-5, atol=2e-4), (dec, name)
+        if device != "cpu":
+            # the run above used the device-resident FST (one HIP launch per step, hipGraph-captured search);
+            # the host-side state sets (the reference's own data structure) must give the same n-best lists
+            assert d.timing["graphs"] > 0 or d.timing["steps"] <= 3
+            d.fused_step = False
+            ret2, _ = d.decode_batch(x.to(device), x_len.to(device), [int(v) + 100 for v in x_len])
+            got2 = D.pack(ret2["predictions"], ret2["scores"])
+            assert np.array_equal(got2["hyps"], got["hyps"]) and np.allclose(got2["scores"], got["scores"], atol=1e-5)
 
 
 @pytest.mark.parametrize("dec", ["rnn", "transformer"])
@@ -95,5 +103,50 @@ def test_gpu_fused_decode_matches_reference(hip_device):
     old, G.PRECISION = G.PRECISION, "fp32"
     try:
         run("transformer", hip_device)
+        run("rnn", hip_device)
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.gpu
+def test_device_fst_advance_equals_host_state_sets(hip_device):
+    """pika_fst_advance vs BeamState._fst_update/_fst_final (the restatement of beam_transducer.py:135-181 that is
+    pinned by the golden above) on random parents / symbols over several steps: identical sets (same order),
+    lm scores, finished scores."""
+    from pika_amd.decoder.beam_search import BeamState, EOS
+    B, K, V = 5, 6, C.V
+    g = torch.Generator().manual_seed(17)
+    dev_beam = BeamState(B, K, 0, 4, [50] * B, V, hip_device, lm_scorer=matcher(), nonblk_reward=0.2)
+    host_beam = BeamState(B, K, 0, 4, [50] * B, V, torch.device("cpu"), lm_scorer=matcher(), nonblk_reward=0.2)
+    assert dev_beam.fst_dev is not None and host_beam.fst_dev is None
+    d = dev_beam.fst_dev
+    for step in range(12):
+        prev_k = torch.randint(0, K, (B, K), generator=g)
+        y = torch.randint(0, V, (B, K), generator=g)
+        y[torch.rand(B, K, generator=g) < 0.3] = 0                       # blanks keep the parent's set
+        fin = torch.rand(B, K, generator=g) < 0.15
+        scores = torch.randn(B, K, generator=g)
+        # host
+        host_beam._fst_update(prev_k, y)
+        want_fin = scores + 0.5 * host_beam._fst_final(fin)
+        # device: emulate what pika_beam_advance leaves behind (y with eos, finished entries appended in slot order)
+        dev_beam.scores.copy_(scores)
+        d["y_raw"].copy_(y)
+        dev_beam.y.copy_(torch.where(fin, torch.full_like(y, EOS), y))
+        n_old = dev_beam.fin_n.clone()
+        dev_beam.fin_n += fin.sum(1).to(hip_device)
+        dev_beam._fst_advance_device(prev_k.to(hip_device), 0.5)
+        assert torch.allclose(dev_beam.lm_scores.cpu(), host_beam.lm_scores, atol=0, rtol=0)
+        assert torch.allclose(dev_beam.scores.cpu(), torch.where(fin, want_fin, scores), atol=1e-6)
+        sn, st, cs = d["set_n"].cpu().view(B, K), d["set_st"].cpu().view(B, K, -1), d["set_cs"].cpu().view(B, K, -1)
+        for b in range(B):
+            pos = int(n_old[b])
+            for i in range(K):
+                hs = host_beam.state_sets[b][i]
+                assert int(sn[b, i]) == len(hs)
+                assert st[b, i, :len(hs)].tolist() == list(hs.keys())
+                assert cs[b, i, :len(hs)].tolist() == list(hs.values())
+                if fin[b, i]:
+                    assert abs(float(dev_beam.fin_score[b, pos]) - float(want_fin[b, i])) < 1e-6
+                    pos += 1
+    assert int(d["err"].item()) == 0
