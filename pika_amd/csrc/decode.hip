@@ -210,15 +210,20 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(
 // softmax) moved ~12x that.
 typedef float at_f4 __attribute__((ext_vector_type(4)));
 
-template <int NQ>   // float4 chunks per thread: d <= 1024 * NQ
+// Thread layout: the d/4 float4 columns of a row are covered by TPG = d/4 threads (d <= 1024) and the 256-thread
+// workgroup holds G = 256 / TPG such groups that take the prefix positions round-robin (d = 512: two positions
+// in flight per step, twice the loads in flight); for d > 1024 every thread owns NQ column chunks and G = 1.
+template <int NQ>
 __global__ __launch_bounds__(256) void incr_attn_kernel(const float *__restrict__ q, const float *__restrict__ Kc,
                                                         const float *__restrict__ Vc,
                                                         const long long *__restrict__ anc, long long anc_pitch,
                                                         const long long *__restrict__ pos,
                                                         const long long *__restrict__ node, int L, int d, int heads,
-                                                        float scale, float *__restrict__ out) {
-    extern __shared__ float sc[];   // [heads][L]
+                                                        int tpg, float scale, float *__restrict__ out) {
+    extern __shared__ float sc[];   // [heads][L] scores, then [G][d] partial contexts
     const int r = blockIdx.x, t = threadIdx.x;
+    const int G = NQ == 1 ? 256 / tpg : 1;           // position groups
+    const int gi = NQ == 1 ? t / tpg : 0, tl = NQ == 1 ? t - gi * tpg : t;
     const int dh = d / heads, g = dh >> 2;           // g threads per head (power of two <= 64)
     const long long p = min(pos[r], (long long)(L - 1));
     const long long my_node = node[r];
@@ -227,22 +232,22 @@ __global__ __launch_bounds__(256) void incr_attn_kernel(const float *__restrict_
     bool act[NQ];
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
-        const int col = (t + c * 256) * 4;
-        act[c] = col < d;
+        const int col = (tl + c * 256) * 4;
+        act[c] = col < d && gi < G;
         qv[c] = act[c] ? *reinterpret_cast<const at_f4 *>(q + (long long)r * d + col) * scale : at_f4{0.f, 0.f, 0.f, 0.f};
     }
-    // pass 1: scores
-    for (long long j0 = 0; j0 <= p; j0 += 4) {
+    // pass 1: scores; group gi takes positions gi, gi + G, ...
+    for (long long j0 = gi; j0 <= p; j0 += 4 * G) {
         float part[4][NQ];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long long j = j0 + u;
-            const long long idx = j > p ? my_node : (j == p ? my_node : arow[j]);
+            const long long j = j0 + (long long)u * G;
+            const long long idx = j >= p ? my_node : arow[j];
 #pragma unroll
             for (int c = 0; c < NQ; ++c) {
                 part[u][c] = 0.f;
                 if (act[c] && j <= p) {
-                    const at_f4 k4 = *reinterpret_cast<const at_f4 *>(Kc + idx * d + (t + c * 256) * 4);
+                    const at_f4 k4 = *reinterpret_cast<const at_f4 *>(Kc + idx * d + (tl + c * 256) * 4);
                     part[u][c] = qv[c].x * k4.x + qv[c].y * k4.y + qv[c].z * k4.z + qv[c].w * k4.w;
                 }
             }
@@ -253,48 +258,63 @@ __global__ __launch_bounds__(256) void incr_attn_kernel(const float *__restrict_
             for (int c = 0; c < NQ; ++c) {
                 float v = part[u][c];
                 for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o);
-                const int col = (t + c * 256) * 4;
-                if (act[c] && j0 + u <= p && (t & (g - 1)) == 0) sc[(col / dh) * L + (int)(j0 + u)] = v;
+                const int col = (tl + c * 256) * 4;
+                const long long j = j0 + (long long)u * G;
+                if (act[c] && j <= p && (tl & (g - 1)) == 0) sc[(col / dh) * L + (int)j] = v;
             }
     }
     __syncthreads();
-    // pass 2: softmax per head (the g threads of a head cooperate), normalised weights back into LDS
+    // pass 2: softmax per head (the g threads of a head in group 0 cooperate), normalised weights back into LDS
+    if (gi == 0) {
 #pragma unroll
-    for (int c = 0; c < NQ; ++c) {
-        if (!act[c]) continue;
-        const int h = ((t + c * 256) * 4) / dh, lane = t & (g - 1);
-        float m = -INFINITY;
-        for (int j = lane; j <= p; j += g) m = fmaxf(m, sc[h * L + j]);
-        for (int o = 1; o < g; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float sum = 0.f;
-        for (int j = lane; j <= p; j += g) sum += __expf(sc[h * L + j] - m);
-        for (int o = 1; o < g; o <<= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.f / sum;
-        for (int j = lane; j <= p; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
+        for (int c = 0; c < NQ; ++c) {
+            if (!act[c]) continue;
+            const int h = ((tl + c * 256) * 4) / dh, lane = tl & (g - 1);
+            float m = -INFINITY;
+            for (int j = lane; j <= p; j += g) m = fmaxf(m, sc[h * L + j]);
+            for (int o = 1; o < g; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float sum = 0.f;
+            for (int j = lane; j <= p; j += g) sum += __expf(sc[h * L + j] - m);
+            for (int o = 1; o < g; o <<= 1) sum += __shfl_xor(sum, o);
+            const float inv = 1.f / sum;
+            for (int j = lane; j <= p; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
+        }
     }
     __syncthreads();
-    // pass 3: context
+    // pass 3: context, partial per position group
     at_f4 acc[NQ];
 #pragma unroll
     for (int c = 0; c < NQ; ++c) acc[c] = at_f4{0.f, 0.f, 0.f, 0.f};
-    for (long long j0 = 0; j0 <= p; j0 += 4) {
+    for (long long j0 = gi; j0 <= p; j0 += 4 * G) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long long j = j0 + u;
+            const long long j = j0 + (long long)u * G;
             if (j > p) break;
             const long long idx = j == p ? my_node : arow[j];
 #pragma unroll
             for (int c = 0; c < NQ; ++c)
                 if (act[c]) {
-                    const int col = (t + c * 256) * 4;
+                    const int col = (tl + c * 256) * 4;
                     const float a = sc[(col / dh) * L + (int)j];
                     acc[c] += *reinterpret_cast<const at_f4 *>(Vc + idx * d + col) * a;
                 }
         }
     }
+    if (G > 1) {     // sum the groups' partial contexts through LDS (after everyone is done with the weights)
+        __syncthreads();
+        float *part = sc;                              // [G][d]
+        if (act[0]) *reinterpret_cast<at_f4 *>(part + gi * d + tl * 4) = acc[0];
+        __syncthreads();
+        if (gi == 0 && act[0]) {
+            at_f4 s4 = acc[0];
+            for (int k = 1; k < G; ++k) s4 += *reinterpret_cast<const at_f4 *>(part + k * d + tl * 4);
+            *reinterpret_cast<at_f4 *>(out + (long long)r * d + tl * 4) = s4;
+        }
+    } else {
 #pragma unroll
-    for (int c = 0; c < NQ; ++c)
-        if (act[c]) *reinterpret_cast<at_f4 *>(out + (long long)r * d + (t + c * 256) * 4) = acc[c];
+        for (int c = 0; c < NQ; ++c)
+            if (act[c]) *reinterpret_cast<at_f4 *>(out + (long long)r * d + (tl + c * 256) * 4) = acc[c];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -498,14 +518,19 @@ extern "C" int pika_incremental_attention(const float *q, const float *k_cache, 
          reinterpret_cast<uintptr_t>(out)) & 15)
         return PIKA_EINVAL;
     const float scale = 1.0f / sqrtf((float)dh);
-    const size_t smem = (size_t)heads * L * sizeof(float);
+    // threads per position group: the smallest power of two >= d/4 that divides 256 (d <= 1024)
+    int tpg = 256;
+    if (d <= 1024) { tpg = 1; while (tpg < d / 4) tpg <<= 1; }
+    const int G = d <= 1024 ? 256 / tpg : 1;
+    size_t smem = (size_t)heads * L * sizeof(float);
+    if ((size_t)G * d * sizeof(float) > smem) smem = (size_t)G * d * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (d <= 1024)
         hipLaunchKernelGGL(incr_attn_kernel<1>, dim3(rows), dim3(256), smem, s, q, k_cache, v_cache, ancestry,
-                           ancestry_pitch, pos, node, L, d, heads, scale, out);
+                           ancestry_pitch, pos, node, L, d, heads, tpg, scale, out);
     else
         hipLaunchKernelGGL(incr_attn_kernel<2>, dim3(rows), dim3(256), smem, s, q, k_cache, v_cache, ancestry,
-                           ancestry_pitch, pos, node, L, d, heads, scale, out);
+                           ancestry_pitch, pos, node, L, d, heads, 256, scale, out);
     return (int)hipGetLastError();
 }
 

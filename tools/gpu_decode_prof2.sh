@@ -11,7 +11,7 @@ f=max(glob.glob('gpurun_out/prof_dec/**/*_kernel_stats.csv',recursive=True), key
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print("total kernel ms", tot/1e6, "kernels", sum(int(r['Calls']) for r in rows))
-for r in rows[:45]:
+for r in rows[:38]:
     print(r['Name'].replace('(anonymous namespace)::','').replace('at::native::','')[:100].ljust(100), r['Calls'].rjust(6), '%8.1f us avg'%(float(r['AverageNs'])/1e3), '%7.1f ms'%(float(r['TotalDurationNs'])/1e6))
 PY
 rm -rf gpurun_out/prof_dec
