@@ -94,12 +94,10 @@ class BeamState(object):
                 self.fin_cap, self.B, self.K, d["err"].data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "pika_fst_advance")
 
-    def check_fst(self):
-        """After the search: a state set overflowed / a finishing slot had no final state (the host path and the
-        reference would have coped or raised): never return silently wrong scores."""
-        if self.fst_dev is not None and int(self.fst_dev["err"].item()):
-            raise RuntimeError("pika_amd: device FST search overflowed its per-slot state sets (or a finished "
-                               "hypothesis has no final LM state); decode this batch with fused_step=False")
+    def fst_overflowed(self):
+        """After the search: True if a device LM state set overflowed (or a finishing slot had no final LM state,
+        where the reference raises); the caller then re-decodes on the host path -- never silently wrong scores."""
+        return self.fst_dev is not None and bool(int(self.fst_dev["err"].item()))
 
     def duplicate_mask(self):
         """beam_transducer.py:106-114: a live slot is disabled if an earlier live slot holds the

@@ -181,7 +181,17 @@ class TransducerDecoder(object):
         self.t_idx = t_idx
         self.dec_states = tuple(state) if rnn else state[0]
         _t1 = _time.perf_counter()
-        beam.check_fst()
+        if beam.fst_overflowed():
+            # a per-slot LM state set outgrew the device arrays (deep back-off chains x disambiguation arcs):
+            # decode this batch again with the host-side state sets, which are unbounded like the reference's
+            import warnings
+            warnings.warn("pika_amd: device FST state sets overflowed; re-decoding the batch on the host FST path")
+            keep = self.fused_step
+            self.fused_step = False
+            try:
+                return self.decode_batch(x, x_len, max_len)
+            finally:
+                self.fused_step = keep
         preds, scores = beam.results()
         self.timing = {"search_s": _t1 - _t0, "results_s": _time.perf_counter() - _t1,
                        "steps": beam.steps, "graphs": len(graphs)}

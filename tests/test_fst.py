@@ -150,3 +150,30 @@ def test_device_fst_advance_equals_host_state_sets(hip_device):
                     assert abs(float(dev_beam.fin_score[b, pos]) - float(want_fin[b, i])) < 1e-6
                     pos += 1
     assert int(d["err"].item()) == 0
+
+
+@pytest.mark.gpu
+def test_device_fst_overflow_is_flagged(hip_device):
+    """A back-off chain 11 levels deep yields 11 next states for one symbol: more than the device arrays hold.
+    The kernel must raise its flag (TransducerDecoder then re-decodes the batch on the host path)."""
+    from pika_amd.decoder.beam_search import BeamState
+    from pika_amd.decoder.ngram_fst import NgramFst, SortedMatcher
+    V, lab, bo = 30, 5, 40
+    arcs, finals = [], {}
+    for i in range(11):
+        arcs.append((i, lab + 1, 1.0 + i, 20 + i))
+        if i < 10:
+            arcs.append((i, bo, 0.5, i + 1))
+    for i in range(20, 31):
+        finals[i] = 0.0
+    m = SortedMatcher(NgramFst.from_arcs(31, arcs, finals), max_num_arcs=V + 4, max_id=bo + 1, backoff_id=bo,
+                      disambig_ids=[])
+    beam = BeamState(1, 2, 0, 1, [50], V, hip_device, lm_scorer=m)
+    assert beam.fst_dev is not None and not beam.fst_overflowed()
+    beam.fst_dev["y_raw"].fill_(lab)
+    beam.y.fill_(lab)
+    beam._fst_advance_device(torch.zeros(1, 2, dtype=torch.long, device=hip_device), 0.5)
+    assert beam.fst_overflowed()
+    host = BeamState(1, 2, 0, 1, [50], V, torch.device("cpu"), lm_scorer=m)
+    host._fst_update(torch.zeros(1, 2, dtype=torch.long), torch.full((1, 2), lab))
+    assert len(host.state_sets[0][0]) == 11
