@@ -123,3 +123,92 @@ class BmufTrainer(object):
         # reference: reduce(dst=master) then the caller broadcasts; an all-reduce leaves the
         # same value on the master and makes the following broadcast a no-op in effect
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+
+
+class BmufAdamTrainer(object):
+    """BMUF-Adam (Chen et al. 2020), drop-in for trainer.bmuf.BmufAdamTrainer (/root/reference/trainer/bmuf.py:191-333):
+    same constructor (`..., block_momentum, block_lr, sync_period, optim`), `update_and_sync()`, `broadcast`,
+    `sum_reduce`, and the same block update of the parameters AND of Adam's first / second moments, whose
+    averaged, bias-compensated values are written back into the optimizer state (`state['step']` advanced by
+    rho * block_momentum).
+
+    As in BmufTrainer above, the reference's reduce-to-master + master-only update + broadcast of one long vector
+    [delta | exp_avg | exp_avg_sq] becomes ONE all-reduce after which every rank applies the identical update
+    (every rank keeps delta_prev and the block moments); the NaN guard therefore stops all ranks together.
+    The elementwise math is written with the reference's expressions in the reference's order (flat fp32
+    vectors, a handful of streaming torch kernels per block -- the LAS training script that uses this class is
+    outside the RNN-T hot path)."""
+
+    def __init__(self, master_node, rank, world_size, model, block_momentum, block_lr, sync_period, optim,
+                 backend=None):
+        self.master_node, self.rank, self.world_size = master_node, rank, world_size
+        self.model, self.optim = model, optim
+        self.block_momentum, self.block_lr, self.sync_period = block_momentum, block_lr, sync_period
+        params = [p for p in model.parameters()]
+        dev = params[0].device
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend or ("nccl" if dev.type == "cuda" else "gloo"),
+                                    init_method="env://")
+        self.rho = 0.0
+        self.betas = (0.9, 0.999)
+        self.param = torch.nn.utils.parameters_to_vector(model.parameters()).data.clone()
+        dist.broadcast(tensor=self.param, src=master_node, async_op=False)
+        self.num_param = self.param.numel()
+        torch.nn.utils.vector_to_parameters(self.param.clone(), model.parameters())
+        self.delta_prev = torch.zeros_like(self.param)
+        dim = 0
+        for group in optim.param_groups:
+            self.betas = group['betas']
+            for p in group['params']:
+                dim += p.numel()
+        self.exp_avg = torch.zeros(dim, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(dim, dtype=torch.float32, device=dev)
+
+    def _moment_params(self):
+        for group in self.optim.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    yield p
+
+    def update_and_sync(self):
+        delta = self.param - torch.nn.utils.parameters_to_vector(self.model.parameters()).data
+        ps = list(self._moment_params())
+        exp_avg = torch.cat([self.optim.state[p]['exp_avg'].view(-1) for p in ps])
+        exp_avg_sq = torch.cat([self.optim.state[p]['exp_avg_sq'].view(-1) for p in ps])
+        vec = torch.cat([delta, exp_avg, exp_avg_sq])
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        if torch.isnan(vec).sum().item():
+            return STOP
+        self.rho = self.block_momentum * self.rho + self.sync_period
+        n = self.num_param
+        vec = vec / float(self.world_size)
+        self.delta_prev = self.block_momentum * self.delta_prev + \
+            (self.block_lr * (1 - self.block_momentum) * vec[:n])
+        self.param -= (1 + self.block_momentum) * self.delta_prev
+        dim = (vec.numel() - n) // 2
+        beta1_tau = self.betas[0] ** self.sync_period
+        beta2_tau = self.betas[1] ** self.sync_period
+        beta1_rho = self.betas[0] ** (self.rho * self.block_momentum)
+        beta2_rho = self.betas[1] ** (self.rho * self.block_momentum)
+        self.exp_avg = beta1_tau * (beta1_rho - 1) * self.exp_avg
+        self.exp_avg += (1 - beta1_tau * beta1_rho) * vec[n:n + dim]
+        self.exp_avg = self.exp_avg / (1 - beta1_tau)
+        self.exp_avg_sq = beta2_tau * (beta2_rho - 1) * self.exp_avg_sq
+        self.exp_avg_sq += (1 - beta2_tau * beta2_rho) * vec[n + dim:]
+        self.exp_avg_sq = self.exp_avg_sq / (1 - beta2_tau)
+        torch.nn.utils.vector_to_parameters(self.param.clone(), self.model.parameters())
+        ptr = 0
+        for p in ps:                                    # flattened block moments back into the optimizer
+            state = self.optim.state[p]
+            state['step'] += self.rho * self.block_momentum
+            k = state['exp_avg'].numel()
+            state['exp_avg'].copy_(self.exp_avg[ptr:ptr + k].view_as(state['exp_avg']))
+            state['exp_avg_sq'].copy_(self.exp_avg_sq[ptr:ptr + k].view_as(state['exp_avg_sq']))
+            ptr += k
+        return SUCCESS
+
+    def broadcast(self, tensor):
+        dist.broadcast(tensor=tensor, src=self.master_node, async_op=False)
+
+    def sum_reduce(self, tensor):
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)

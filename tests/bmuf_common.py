@@ -54,3 +54,31 @@ def simulate_reference_math(world):
             torch.nn.utils.vector_to_parameters(G.clone(), m.parameters())
         out.append(G.numpy().copy())
     return np.stack(out)
+
+
+# ---- BMUF-Adam scenario (trainer/bmuf.py:191-333) -----------------------------------------------------
+SYNC_PERIOD = 3
+
+
+def make_adam(model):
+    return torch.optim.Adam(model.parameters(), lr=1e-2, betas=(0.9, 0.98))
+
+
+def local_adam_steps(model, optim, rank, rnd):
+    """sync_period local Adam steps on seeded fake gradients (every parameter gets one, so the optimizer
+    state the trainer exchanges exists)."""
+    for k in range(SYNC_PERIOD):
+        g = torch.Generator().manual_seed(1000 * (rank + 1) + 10 * rnd + k)
+        for p in model.parameters():
+            p.grad = torch.randn(p.shape, generator=g) * 0.1
+        optim.step()
+
+
+def adam_state(model, optim):
+    """Flat (params, exp_avg, exp_avg_sq, steps) snapshot."""
+    ps = [p for p in model.parameters()]
+    st = [optim.state[p] for p in ps]
+    return (flat(model),
+            torch.cat([s["exp_avg"].reshape(-1) for s in st]).numpy().copy(),
+            torch.cat([s["exp_avg_sq"].reshape(-1) for s in st]).numpy().copy(),
+            np.array([float(s["step"]) for s in st]))

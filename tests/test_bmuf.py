@@ -69,6 +69,40 @@ def test_matches_reference_golden_and_restatement(tmp_path):
     assert np.allclose(z[0]["rounds"], sim, rtol=3e-7, atol=3e-8)
 
 
+def _adam_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from trainer.bmuf import BmufAdamTrainer
+    model = C.make_model(rank)
+    optim = C.make_adam(model)
+    tr = BmufAdamTrainer(0, rank, world, model, C.BM, C.BLR, C.SYNC_PERIOD, optim)
+    snaps = []
+    for rnd in range(C.ROUNDS):
+        C.local_adam_steps(model, optim, rank, rnd)
+        assert tr.update_and_sync() == 1
+        snaps.append(C.adam_state(model, optim))
+    np.savez(out % rank, params=np.stack([s[0] for s in snaps]), exp_avg=np.stack([s[1] for s in snaps]),
+             exp_avg_sq=np.stack([s[2] for s in snaps]), steps=np.stack([s[3] for s in snaps]), rho=tr.rho)
+    dist.destroy_process_group()
+
+
+def test_bmuf_adam_matches_reference_golden(tmp_path):
+    """BmufAdamTrainer (all-reduce formulation) vs golden from the REFERENCE class run under gloo
+    (tests/golden/make_bmuf_adam_golden.py): parameters, both Adam moments and the step counters after every
+    block, on both ranks."""
+    out = str(tmp_path / "adam%d.npz")
+    mp.spawn(_adam_worker, args=(2, C.free_port(), out), nprocs=2, join=True)
+    z = [np.load(out % r) for r in range(2)]
+    gold = np.load(os.path.join(os.path.dirname(GOLD), "bmuf_adam_ws2.npz"))
+    for r in (0, 1):
+        for k in ("params", "exp_avg", "exp_avg_sq", "steps"):
+            assert np.allclose(z[r][k], gold[k], rtol=3e-7, atol=1e-9), (r, k)
+        assert abs(float(z[r]["rho"]) - float(gold["rho"])) < 1e-12
+    for k in ("params", "exp_avg", "exp_avg_sq"):
+        assert np.array_equal(z[0][k], z[1][k]), "replicas must stay bitwise identical"
+
+
 def test_nan_guard_stops_every_rank_consistently(tmp_path):
     z = _run(tmp_path, inject_nan=True)
     for r in (0, 1):
