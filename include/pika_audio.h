@@ -42,6 +42,16 @@ int pika_fbank(const float *wave, const long long *wave_off, const long long *fr
 int pika_splice_pad(const float *feats, const long long *frame_off, int B, int dim, int lctx,
                     int rctx, int stride, int t_max, float *out, void *stream);
 
+/* Noise / reverberation augmentation on float samples (reference loader/audio.py: add_noise :467-513,
+ * convolve / convolve_and_normalize :426-465; the hooks in otf_utt_loader.py:224-228 are commented out in the
+ * reference).  Building blocks, composed by pika_amd/loader/augment.py:
+ *   pika_audio_sumsq         *out (f64, zeroed by the call) = sum x[i]^2  -> rms_db = 10 log10(max(1e-20, sum/n))
+ *   pika_audio_axpby         y = b*y + a*x   (x may be NULL: plain gain, AudioSegment.gain_db / superimpose)
+ *   pika_audio_convolve_same out[i] = sum_k h[k] x[i + (m-1)/2 - k], i < n  (fftconvolve(x, h, "same"), m <= n) */
+int pika_audio_sumsq(const float *x, long long n, double *out, void *stream);
+int pika_audio_axpby(float *y, const float *x, long long n, float a, float b, void *stream);
+int pika_audio_convolve_same(const float *x, long long n, const float *h, int m, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,9 @@ SIGNATURES = {
                               ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "pika_fst_states_per_slot": (_i, []),
     # include/pika_audio.h
+    "pika_audio_sumsq": (_i, [_vp, _ll, _vp, _vp]),
+    "pika_audio_axpby": (_i, [_vp, _vp, _ll, ctypes.c_float, ctypes.c_float, _vp]),
+    "pika_audio_convolve_same": (_i, [_vp, _ll, _vp, _i, _vp, _vp]),
     "pika_audio_perturb": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _vp, _vp, _vp]),
     "pika_fbank": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, ctypes.c_float, ctypes.c_float,
                         ctypes.c_ulonglong, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

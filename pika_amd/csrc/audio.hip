@@ -175,6 +175,60 @@ __global__ __launch_bounds__(256) void splice_pad_kernel(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Noise / reverberation augmentation on float samples (reference loader/audio.py:174-193, 426-513): sums of
+// squares for the RMS, y += a*x, y *= a, and the "same"-mode convolution with a room impulse response.
+__global__ __launch_bounds__(256) void aug_sumsq_kernel(const float *__restrict__ x, long long n,
+                                                        double *__restrict__ out) {
+    __shared__ double part[4];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double v = (double)x[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void aug_axpy_kernel(float *__restrict__ y, const float *__restrict__ x,
+                                                       long long n, float a, float b) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = b * y[i] + (x ? a * x[i] : 0.f);
+}
+
+// out[i] = sum_k h[k] * x[i + (m-1)/2 - k]  (scipy.signal.fftconvolve(x, h, "same") for len(x) >= len(h)):
+// 256 outputs per workgroup, the impulse response streamed through LDS in chunks of 1024 taps together with
+// the 1279 input samples the chunk touches; fp64 accumulation (the reference convolves through a double FFT
+// of float samples: ~1e-7 relative either way, this keeps the direct sum out of the error budget).
+constexpr int CONV_TAPS = 1024;
+__global__ __launch_bounds__(256) void aug_convolve_same_kernel(const float *__restrict__ x, long long n,
+                                                                const float *__restrict__ h, int m,
+                                                                float *__restrict__ out) {
+    __shared__ float hs[CONV_TAPS], xs[CONV_TAPS + 256];
+    const long long i0 = (long long)blockIdx.x * 256, i = i0 + threadIdx.x;
+    const long long c = (m - 1) / 2;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < m; k0 += CONV_TAPS) {
+        const int kc = min(CONV_TAPS, m - k0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < kc; k += 256) hs[k] = h[k0 + k];
+        // inputs needed: index j = i + c - k for i in [i0, i0+256), k in [k0, k0+kc): j in [i0+c-k0-kc+1, i0+c-k0+255]
+        const long long jlo = i0 + c - k0 - kc + 1;
+        for (int q = threadIdx.x; q < kc + 255; q += 256) {
+            const long long j = jlo + q;
+            xs[q] = (j >= 0 && j < n) ? x[j] : 0.f;
+        }
+        __syncthreads();
+        // j - jlo = (i - i0) + (kc - 1) - (k - k0)
+        const int base = threadIdx.x + kc - 1;
+        for (int k = 0; k < kc; ++k) acc += (double)hs[k] * (double)xs[base - k];
+    }
+    if (i < n) out[i] = (float)acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -222,6 +276,32 @@ int pika_splice_pad(const float *feats, const long long *frame_off, int B, int d
     hipLaunchKernelGGL(splice_pad_kernel, dim3(t_max, B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), feats, frame_off, dim, lctx, rctx, stride,
                        t_max, out);
+    return (int)hipGetLastError();
+}
+
+int pika_audio_sumsq(const float *x, long long n, double *out, void *stream) {
+    if (!x || !out || n <= 0) return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);
+    if (e != hipSuccess) return (int)e;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(aug_sumsq_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, x, n, out);
+    return (int)hipGetLastError();
+}
+
+int pika_audio_axpby(float *y, const float *x, long long n, float a, float b, void *stream) {
+    if (!y || n <= 0) return PIKA_EINVAL;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(aug_axpy_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), y, x, n, a, b);
+    return (int)hipGetLastError();
+}
+
+int pika_audio_convolve_same(const float *x, long long n, const float *h, int m, float *out, void *stream) {
+    if (!x || !h || !out || n <= 0 || m <= 0 || m > n || x == out) return PIKA_EINVAL;
+    if ((n + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(aug_convolve_same_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n, h, m, out);
     return (int)hipGetLastError();
 }
 

@@ -116,3 +116,32 @@ def test_gpu_dither_is_statistical(hip_device):
     ref = F.kaldi_fbank(np.zeros(16000), dither=1.0, rng=rng)
     got = a[0, :, 80:160].cpu().numpy()
     assert abs(got.mean() - ref.mean()) < 0.15 and abs(got.std() - ref.std()) < 0.15
+
+
+@pytest.mark.gpu
+def test_noise_and_reverb_augmentation_match_reference(hip_device):
+    """pika_amd/loader/augment.py vs golden from the reference AudioSegment.add_noise /
+    convolve_and_normalize (tests/golden/make_augment_golden.py): same RNG draw and index rounding, same gains."""
+    import random
+    from pika_amd.loader import augment as A
+    z = np.load(os.path.join(HERE, "golden", "augment.npz"))
+    for k in range(int(z["n_noise"])):
+        snr, seed, err = z["n%d/cfg" % k]
+        sig = torch.from_numpy(z["n%d/sig" % k]).to(hip_device)
+        noi = torch.from_numpy(z["n%d/noise" % k]).to(hip_device)
+        if err:
+            with pytest.raises(ValueError):
+                A.add_noise_(sig, noi, float(snr), rng=random.Random(int(seed)))
+            continue
+        A.add_noise_(sig, noi, float(snr), rng=random.Random(int(seed)))
+        want = z["n%d/out" % k]
+        assert np.abs(sig.cpu().numpy() - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+    for k in range(int(z["n_conv"])):
+        sig = torch.from_numpy(z["c%d/sig" % k]).to(hip_device)
+        rir = torch.from_numpy(z["c%d/rir" % k]).to(hip_device)
+        got = A.convolve_and_normalize(sig, rir).cpu().numpy()
+        want = z["c%d/out" % k]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-4 * np.abs(want).max(), k
+    with pytest.raises(RuntimeError):
+        A.rms_db(torch.zeros(4))                   # no CPU path
