@@ -62,13 +62,32 @@ __global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
     }
     const float *row = logits + (bk + k) * (long long)V;
     float m = -INFINITY;
-    for (int v0 = lane; v0 < V; v0 += 64 * 8) {   // 8 independent loads in flight per lane
-        float t[8];
+    if ((V & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        // 16-byte loads, 8 in flight per lane: a 5000-float row is 3 rounds instead of 10
+        typedef float tk_f4 __attribute__((ext_vector_type(4)));
+        const int V4 = V >> 2;
+        for (int v0 = lane; v0 < V4; v0 += 64 * 8) {
+            tk_f4 t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = v0 + 64 * j < V ? row[v0 + 64 * j] : -INFINITY;
+            for (int j = 0; j < 8; ++j)
+                if (v0 + 64 * j < V4) t[j] = reinterpret_cast<const tk_f4 *>(row)[v0 + 64 * j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (v0 + 64 * j < V) { x[v0 + 64 * j] = sm_scale * t[j]; m = fmaxf(m, sm_scale * t[j]); }
+            for (int j = 0; j < 8; ++j)
+                if (v0 + 64 * j < V4) {
+                    const tk_f4 u = t[j] * sm_scale;
+                    reinterpret_cast<tk_f4 *>(x)[v0 + 64 * j] = u;
+                    m = fmaxf(m, fmaxf(fmaxf(u.x, u.y), fmaxf(u.z, u.w)));
+                }
+        }
+    } else {
+        for (int v0 = lane; v0 < V; v0 += 64 * 8) {   // 8 independent loads in flight per lane
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = v0 + 64 * j < V ? row[v0 + 64 * j] : -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (v0 + 64 * j < V) { x[v0 + 64 * j] = sm_scale * t[j]; m = fmaxf(m, sm_scale * t[j]); }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float s = 0.f;
