@@ -85,10 +85,12 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
  * pika_rnnt_loss_backward call left in `workspace` -- the dense gradient (B,T,U1,V) is written by that
  * call as the contract demands, but need not be read back:
  *   out[r, v] = scale * (grad[r, v] - exp(log_probs[r, v]) * sum_v' grad[r, v']).
+ * colsum (V floats, may be NULL) receives sum_r out[r, :] before the bf16 rounding: the bias gradient of the
+ * layer that produced the logits, without another pass over `out`.
  * V % 4 == 0, V <= 5120, ld_out % 4 == 0. */
 int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace, int B, int T, int U1,
                                    int V, int blank, void *out, long long ld_out, float scale,
-                                   void *stream);
+                                   float *colsum, void *stream);
 
 /* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces
  * F.log_softmax (trainer/model/transducer.py:111) + the loss + the log-softmax backward for a caller that owns

@@ -494,37 +494,65 @@ constexpr int CQ = 20;
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// COLSUM: every wave walks RPW consecutive rows and keeps the column sums of what it writes in registers
+// (d(bias) of the layer that produced the logits); the four waves of a workgroup combine through LDS and issue one
+// atomicAdd per column.
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *__restrict__ lp,
                                                                    const RowMeta *__restrict__ meta,
                                                                    __bf16 *__restrict__ out, long long rows,
                                                                    int V, long long ld_out, int blank,
-                                                                   float scale) {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const int lane = threadIdx.x & 63, c4 = V >> 2, o4 = (int)(ld_out >> 2);
-    const RowMeta m = meta[r];
-    const float s = m.gb + m.ge;
-    const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * V);
-    cbf16x4 *orow = reinterpret_cast<cbf16x4 *>(out + r * ld_out);
-    f32x4 v[CQ];
+                                                                   float scale, int rpw,
+                                                                   float *__restrict__ colsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = V >> 2, o4 = (int)(ld_out >> 2);
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * rpw;
+    f32x4 cs[COLSUM ? CQ : 1];
+    if constexpr (COLSUM) {
 #pragma unroll
-    for (int q = 0; q < CQ; ++q)
-        if (lane + q * 64 < c4) v[q] = lrow[lane + q * 64];
+        for (int q = 0; q < CQ; ++q) cs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long long r = r0; r < r0 + rpw && r < rows; ++r) {
+        const RowMeta m = meta[r];
+        const float s = m.gb + m.ge;
+        const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * V);
+        cbf16x4 *orow = reinterpret_cast<cbf16x4 *>(out + r * ld_out);
+        f32x4 v[CQ];
 #pragma unroll
-    for (int q = 0; q < CQ; ++q) {
-        const int i = lane + q * 64;
-        if (i < c4) {
-            f32x4 o;
+        for (int q = 0; q < CQ; ++q)
+            if (lane + q * 64 < c4) v[q] = lrow[lane + q * 64];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int col = 4 * i + e;
-                float g = col == blank ? m.gb : 0.f;
-                if (col == m.ye) g += m.ge;
-                o[e] = scale * (g - __expf(v[q][e]) * s);
+        for (int q = 0; q < CQ; ++q) {
+            const int i = lane + q * 64;
+            if (i < c4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = 4 * i + e;
+                    float g = col == blank ? m.gb : 0.f;
+                    if (col == m.ye) g += m.ge;
+                    o[e] = scale * (g - __expf(v[q][e]) * s);
+                }
+                orow[i] = __builtin_convertvector(o, cbf16x4);
+                if constexpr (COLSUM) cs[q] += o;
+            } else if (i < o4) {
+                orow[i] = cbf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             }
-            orow[i] = __builtin_convertvector(o, cbf16x4);
-        } else if (i < o4) {
-            orow[i] = cbf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        }
+    }
+    if constexpr (COLSUM) {
+        __shared__ f32x4 red[4][64];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            if (q * 64 >= c4) break;          // uniform
+            __syncthreads();
+            red[wave][lane] = cs[q];
+            __syncthreads();
+            const int i = lane + q * 64;
+            if (wave == 0 && i < c4) {
+                const f32x4 t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+                atomicAdd(colsum + 4 * i + 0, t.x); atomicAdd(colsum + 4 * i + 1, t.y);
+                atomicAdd(colsum + 4 * i + 2, t.z); atomicAdd(colsum + 4 * i + 3, t.w);
+            }
         }
     }
 }
@@ -733,7 +761,7 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
 
 int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace, int B, int T, int U1,
                                    int V, int blank, void *out, long long ld_out, float scale,
-                                   void *stream) {
+                                   float *colsum, void *stream) {
     if (!log_probs || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
         blank >= V)
         return PIKA_EINVAL;
@@ -743,9 +771,20 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace
     const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
     const long long rows = (long long)B * T * U1;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
-    hipLaunchKernelGGL(rnnt_dlogits_compact_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), log_probs, L.meta, static_cast<__bf16 *>(out), rows, V,
-                       ld_out, blank, scale);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (colsum) {
+        hipError_t e = hipMemsetAsync(colsum, 0, (size_t)V * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        const int rpw = rows >= (1 << 18) ? 32 : 4;
+        const long long per_block = 4LL * rpw;
+        hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<true>, dim3((unsigned)((rows + per_block - 1) / per_block)),
+                           dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
+                           scale, rpw, colsum);
+    } else {
+        hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                           log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
+                           static_cast<float *>(nullptr));
+    }
     return (int)hipGetLastError();
 }
 

@@ -410,15 +410,18 @@ class JointOutFn(torch.autograd.Function):
         dh = dw = db = None
         with torch.cuda.device(g.device):
             dl = torch.empty((M, Np), dtype=torch.bfloat16, device=g.device)
+            db_fused = None
             compact = getattr(g, "_pika_compact", None)
             if (compact is not None and compact.matches(g) and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape)
                     and N <= 5120):
                 # g is the RNN-T loss' own dense gradient, untouched: take its two non-zeros per row from the
                 # loss workspace instead of reading 4 bytes x B*T*U*V back (include/pika_rnnt.h)
                 B_, T_, U1_, V_, blank = compact.dims
+                want_db = ctx.has_bias and ctx.needs_input_grad[2]
+                db_fused = torch.empty(N, dtype=torch.float32, device=dl.device) if want_db else None
                 _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16(
                     lp.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_, blank, dl.data_ptr(), Np, ctx.scale,
-                    _stream()), "pika_rnnt_dlogits_compact_bf16")
+                    None if db_fused is None else db_fused.data_ptr(), _stream()), "pika_rnnt_dlogits_compact_bf16")
                 JointOutFn.compact_hits += 1
             else:
                 _lib.check(_lib.lib().pika_log_softmax_bwd_rows_bf16(
@@ -433,7 +436,9 @@ class JointOutFn(torch.autograd.Function):
                 _gemm_epilogue(dl, wt, dh.view(-1, K), None, EPI_DROPOUT_BF16)
             if ctx.needs_input_grad[1]:
                 dw = _grad_weight(dl[:, :N], G.matrix(h2)[0], 8, M, K, N)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if db_fused is not None:
+                db = db_fused           # column sums came out of the d(logits) kernel itself
+            elif ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(N, dtype=torch.float32, device=dl.device)
                 _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
                            "pika_colsum_bf16")

