@@ -395,3 +395,34 @@ def test_tdnn_bn_fn(hip_device, taps, dil, stride, out_bf16, x_bf16):
             assert d.norm() < 1e-2 * want.grad.norm()
     finally:
         G.PRECISION = old
+
+
+def test_bf16_output_flag_on_the_generic_entry(hip_device):
+    """PIKA_GEMM_OUT_BF16 through pika_gemm_nt (G.launch with a bf16 `out`): plain and padded time-delay A operands
+    at a size the direct-to-LDS kernel takes (>= 160 output tiles); equals the fp32 result rounded to bf16.  A
+    product the kernel does not take must be refused, not silently written as fp32."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 10240, 1024, 256
+    a = torch.randn(M, K, generator=g).bfloat16().to(hip_device)
+    b = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(hip_device)
+    bias = torch.randn(N, generator=g).to(hip_device)
+    ref = torch.empty(M, N, device=hip_device)
+    G.launch(G.matrix(a)[0], G.matrix(b)[0], ref, N, M, N, K, bias=bias, relu=True)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=hip_device)
+    G.launch(G.matrix(a)[0], G.matrix(b)[0], out, N, M, N, K, bias=bias, relu=True)
+    assert torch.equal(out, ref.bfloat16())
+    # the transposed convolution of TdnnBnFn.backward: padded, tap-reversed time-delay view of dY, bf16 dx
+    Bn, T, C, taps, dil = 8, 1290, 1024, 3, 3
+    t_out = T - dil * (taps - 1)
+    dy = torch.randn(Bn * t_out, 256, generator=g).bfloat16().to(hip_device)
+    wrev = (torch.randn(C, taps * 256, generator=g) * 0.05).bfloat16().to(hip_device)
+    a_op = G.Operand(dy.data_ptr(), G.PIKA_BF16, T, t_out, t_out * 256, 256, 256, 1, dil, (taps - 1) * dil, 0, 0)
+    dx32 = torch.empty(Bn * T, C, device=hip_device)
+    G.launch(a_op, G.matrix(wrev)[0], dx32, C, Bn * T, C, taps * 256)
+    dx16 = torch.empty(Bn * T, C, dtype=torch.bfloat16, device=hip_device)
+    G.launch(a_op, G.matrix(wrev)[0], dx16, C, Bn * T, C, taps * 256)
+    assert torch.equal(dx16, dx32.bfloat16())
+    small = torch.empty(300, 200, dtype=torch.bfloat16, device=hip_device)
+    with pytest.raises(RuntimeError):
+        G.launch(G.matrix(a[:300])[0], G.matrix(b[:200])[0], small, 200, 300, 200, K)
