@@ -130,6 +130,11 @@ __global__ __launch_bounds__(THREADS) void gemm_glds(const __bf16 *__restrict__ 
 // a tap, so it only changes the per-tile source offset.
 constexpr int PP_T = 256 * 128, PP_BUF = 2 * PP_T;
 
+#ifdef PIKA_PP_TRACE
+#define PP_STAMP(n) do { if (tr_on && t == 8) tr_ph[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP(n) do { } while (0)
+#endif
 #define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 __device__ __attribute__((aligned(512))) const unsigned int pp_zero_page[128] = {0};
@@ -152,6 +157,11 @@ struct PPArgs {
     unsigned seed, thr;                // EPI 1, 3: drop where hash16 < thr (thr = 0: no dropout)
     const float *res;                  // EPI 3: fp32 residual added after the dropout
     long long ld_res;
+    int nx, ntiles;                    // output tiles per row of tiles / in total (filled in by launch_pp_epi)
+    int stagger;                       // start-up spread of the workgroups of one XCD, in s_sleep(127) units (~3.4 us)
+#ifdef PIKA_PP_TRACE
+    unsigned long long *trace;         // tools/pp_trace.hip: [wg < 8][group 2][tile < 16][24] time stamps
+#endif
 };
 
 // counter-based dropout decisions for the four consecutive columns n..n+3 (n % 4 == 0) of row m
@@ -176,28 +186,41 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int M = P.M, N = P.N;
-    const int nx = gridDim.x, ntiles = nx * gridDim.y;
-    int tile = blockIdx.y * nx + blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (tile / nx) * 256, n0 = (tile % nx) * 256;
+    const int nx = P.nx, ntiles = P.ntiles, stride = gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+    // launch slot v -> tile: slots that share v % 8 (one XCD, one L2) get a contiguous run of tiles.  A workgroup
+    // walks the slots blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0 or a single pass), so all its
+    // tiles stay on its own XCD's run
+    auto tile_of = [&](int v) {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    };
 
     const char *pa[4], *pb[4];
     int ts[4];   // source time of tap 0 for this lane's row of piece i
+    int m0, n0;
+    auto setup = [&](int v) {
+        const int tile = tile_of(v);
+        m0 = (tile / nx) * 256; n0 = (tile % nx) * 256;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + (lane >> 3), g = (lane & 7) ^ (r & 7);
-        int ra = m0 + r, rb = n0 + r;
-        ra = ra < M ? ra : M - 1;
-        rb = rb < N ? rb : N - 1;
-        const int ab = ra / P.a_rpb, at = ra - ab * P.a_rpb;
-        ts[i] = at * P.a_tstep - P.a_t0;
-        pa[i] = reinterpret_cast<const char *>(P.A + (long long)ab * P.a_batch + (long long)at * P.a_row) + g * 16;
-        pb[i] = reinterpret_cast<const char *>(P.B + (long long)rb * P.ldb) + g * 16;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int r = (wave * 4 + i) * 8 + (lane >> 3), g = (lane & 7) ^ (r & 7);
+            int ra = m0 + r, rb = n0 + r;
+            ra = ra < M ? ra : M - 1;
+            rb = rb < N ? rb : N - 1;
+            const int ab = ra / P.a_rpb, at = ra - ab * P.a_rpb;
+            ts[i] = at * P.a_tstep - P.a_t0;
+            pa[i] = reinterpret_cast<const char *>(P.A + (long long)ab * P.a_batch + (long long)at * P.a_row) + g * 16;
+            pb[i] = reinterpret_cast<const char *>(P.B + (long long)rb * P.ldb) + g * 16;
+        }
+    };
+    int slot = blockIdx.x;
+    // All workgroups storing their 256 KB output tile at the same moment queue on the HBM write path and then
+    // stay in lock-step (every tile pays the full drain of everybody's stores).  Spreading the start of the 32
+    // workgroups of an XCD over about one tile time lets a tile's stores drain while the other CUs are in
+    // their main loops.
+    for (int d = (((blockIdx.x >> 3) & 31) * P.stagger) >> 5; d > 0; --d) __builtin_amdgcn_s_sleep(127);
+    setup(slot);
     const char *zp = reinterpret_cast<const char *>(pp_zero_page) + (lane & 7) * 16;
     const int bounds = P.a_bounds;
     // source of A piece i for tap `tp` at byte offset `off` (rows whose source time is outside the signal read zeros)
@@ -229,14 +252,40 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     if (wr == 1) PP_BAR();   // group 1 runs one segment behind group 0
 
     bf16x8 fa[4][2], fb[4][2];
+    int gt = 0;   // K-tiles consumed by this workgroup so far: parity = LDS buffer
+#ifdef PIKA_PP_TRACE
+    int tr_tile = 0;
+    unsigned long long tr_stall = 0, tr_stall0 = 0, tr_t0 = 0, tr_rt0 = 0, tr_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_k8 = 0;
+    const bool tr_on = P.trace && blockIdx.x < 8 && (threadIdx.x & 255) == 0;
+#endif
+    for (;;) {
+    const int em0 = m0, en0 = n0;   // the tile being accumulated (setup() moves m0/n0 on to the next one)
+#ifdef PIKA_PP_TRACE
+    if (tr_on) { tr_t0 = __builtin_amdgcn_s_memtime(); tr_rt0 = __builtin_amdgcn_s_memrealtime(); tr_stall = 0; }
+#endif
+    bool more = false;
     int tap = 0, c0 = 0;
-    for (int t = 0; t < nt; ++t) {
-        const unsigned char *cur = smem + (t & 1) * PP_BUF;
-        unsigned char *nxt = smem + ((t + 1) & 1) * PP_BUF + piece0;
-        const bool pf = t + 1 < nt;
-        c0 += 64;
-        if (c0 == P.a_C) { c0 = 0; ++tap; }
-        const long long ka = ((long long)tap * P.a_tap + c0) * 2, kb = (long long)(t + 1) * 128;
+    for (int t = 0; t < nt; ++t, ++gt) {
+        const unsigned char *cur = smem + (gt & 1) * PP_BUF;
+        unsigned char *nxt = smem + ((gt + 1) & 1) * PP_BUF + piece0;
+#ifdef PIKA_PP_TRACE
+        if (tr_on && t == 8) tr_k8 = __builtin_amdgcn_s_memtime();
+#endif
+        bool pf = true;
+        long long ka, kb;
+        if (t + 1 < nt) {
+            c0 += 64;
+            if (c0 == P.a_C) { c0 = 0; ++tap; }
+            ka = ((long long)tap * P.a_tap + c0) * 2; kb = (long long)(t + 1) * 128;
+        } else {
+            // last K-tile of this output tile: the prefetch slot fetches K-tile 0 of the workgroup's NEXT output
+            // tile, so its main loop starts right behind this tile's stores with no load latency in between
+            slot += stride;
+            more = slot < ntiles;
+            pf = more;
+            if (more) setup(slot);
+            tap = 0; c0 = 0; ka = 0; kb = 0;
+        }
         // ---- phase 0: quadrant (m-half 0, n-half 0)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -254,6 +303,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             gl(asrc(2, tap, ka), nxt + 2048);
         }
         PP_BAR();
+        PP_STAMP(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -264,6 +314,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BAR();
+        PP_STAMP(1);
         // ---- phase 1: (m-half 0, n-half 1)
 #pragma unroll
         for (int j = 2; j < 4; ++j) {
@@ -278,6 +329,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             gl(pb[3] + kb, nxt + PP_T + 3072);
         }
         PP_BAR();
+        PP_STAMP(2);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -288,6 +340,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BAR();
+        PP_STAMP(3);
         // ---- phase 2: (m-half 1, n-half 1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -295,6 +348,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fa[i][1] = ldsv(cur + aoff + (4 + i) * 2048 + sw1);
         }
         PP_BAR();
+        PP_STAMP(4);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -305,10 +359,19 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BAR();
+        PP_STAMP(5);
         // ---- phase 3: (m-half 1, n-half 0); the prefetched tile must have landed before the
         // barrier that lets the other group start reading it
+#ifdef PIKA_PP_TRACE
+        unsigned long long tr_a = 0;
+        if (tr_on) tr_a = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PIKA_PP_TRACE
+        if (tr_on) { const unsigned long long d = __builtin_amdgcn_s_memtime() - tr_a; tr_stall += d; if (t == 0) tr_stall0 = d; }
+#endif
         PP_BAR();
+        PP_STAMP(6);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -319,18 +382,22 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         PP_BAR();
+        PP_STAMP(7);
     }
-    if (wr == 0) PP_BAR();
+#ifdef PIKA_PP_TRACE
+    unsigned long long tr_k = 0;
+    if (tr_on) tr_k = __builtin_amdgcn_s_memtime();
+#endif
 
     const float *bias = P.bias;
     float *C = P.C;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        const int m = em0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
             if (n >= N) continue;
             f32x4 v = acc[i][j];
             if constexpr (EPI != 2) {
@@ -386,6 +453,22 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             }
         }
     }
+#ifdef PIKA_PP_TRACE
+    if (tr_on && tr_tile < 16) {
+        unsigned long long *q = P.trace + ((blockIdx.x * 2 + wr) * 16 + tr_tile) * 24;
+        q[6] = tr_k8;
+        for (int e = 0; e < 8; ++e) q[8 + e] = tr_ph[e];
+        q[0] = tr_t0; q[1] = tr_rt0; q[2] = tr_stall; q[3] = tr_stall0; q[4] = tr_k; q[5] = __builtin_amdgcn_s_memtime();
+    }
+    ++tr_tile;
+#endif
+    if (!more) break;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (wr == 0) PP_BAR();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -625,8 +708,25 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    if ((P.M + 255) / 256 > 65535) return PIKA_ETOOBIG;
-    hipLaunchKernelGGL(gemm_pp<EPI>, dim3((P.N + 255) / 256, (P.M + 255) / 256), dim3(512), 2 * PP_BUF, s, P);
+    const long long nt = (long long)((P.N + 255) / 256) * ((P.M + 255) / 256);
+    if (nt > 0x7fffffffLL - 65536) return PIKA_ETOOBIG;
+    PPArgs Q = P;
+    Q.nx = (P.N + 255) / 256; Q.ntiles = (int)nt;
+    // persistent: one workgroup per CU (128 KB of LDS each) walks its share of the output tiles.
+    // PIKA_GEMM_PP_WGS=0 launches one workgroup per tile instead (for A/B timing).
+    static const int wgs = [] {
+        const char *e = getenv("PIKA_GEMM_PP_WGS");
+        if (e) return atoi(e);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus & ~7;
+    }();
+    const int grid = (wgs >= 8 && nt > wgs) ? (wgs & ~7) : (int)nt;
+    static const int stagger_env = [] { const char *e = getenv("PIKA_GEMM_PP_STAGGER"); return e ? atoi(e) : -1; }();
+    Q.stagger = 0;
+    if (grid < nt) Q.stagger = stagger_env >= 0 ? stagger_env : 0;
+    hipLaunchKernelGGL(gemm_pp<EPI>, dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
     return (int)hipGetLastError();
 }
 
