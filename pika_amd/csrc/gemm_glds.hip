@@ -158,7 +158,6 @@ struct PPArgs {
     const float *res;                  // EPI 3: fp32 residual added after the dropout
     long long ld_res;
     int nx, ntiles;                    // output tiles per row of tiles / in total (filled in by launch_pp_epi)
-    int stagger;                       // start-up spread of the workgroups of one XCD, in s_sleep(127) units (~3.4 us)
 #ifdef PIKA_PP_TRACE
     unsigned long long *trace;         // tools/pp_trace.hip: [wg < 8][group 2][tile < 16][24] time stamps
 #endif
@@ -214,13 +213,6 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             pb[i] = reinterpret_cast<const char *>(P.B + (long long)rb * P.ldb) + g * 16;
         }
     };
-    int slot = blockIdx.x;
-    // All workgroups storing their 256 KB output tile at the same moment queue on the HBM write path and then
-    // stay in lock-step (every tile pays the full drain of everybody's stores).  Spreading the start of the 32
-    // workgroups of an XCD over about one tile time lets a tile's stores drain while the other CUs are in
-    // their main loops.
-    for (int d = (((blockIdx.x >> 3) & 31) * P.stagger) >> 5; d > 0; --d) __builtin_amdgcn_s_sleep(127);
-    setup(slot);
     const char *zp = reinterpret_cast<const char *>(pp_zero_page) + (lane & 7) * 16;
     const int bounds = P.a_bounds;
     // source of A piece i for tap `tp` at byte offset `off` (rows whose source time is outside the signal read zeros)
@@ -230,10 +222,35 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     };
     const int piece0 = wave * 4 * 1024;
     auto gl = [&](const char *p, unsigned char *dst) {
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     const int sw0 = (((lane >> 4)) ^ (lane & 7)) << 4, sw1 = sw0 ^ 64;
     const int aoff = (wr * 128 + (lane & 15)) * 128, boff = PP_T + (wc * 64 + (lane & 15)) * 128;
+    const int nt = P.K / 64;
+
+    // The fetch cursor: the K-tile whose eight 1 KB pieces (A0..A3, B0..B3 per wave) are being issued.  It runs
+    // one to two K-tiles ahead of the MFMAs and walks straight from the last K-tile of an output tile into the
+    // first K-tile of the workgroup's next output tile.  pa/pb/ts always belong to the cursor's tile.
+    int x_slot = blockIdx.x, x_kt = 0, x_tap = 0, x_c0 = 0;
+    bool x_ok = true;
+    setup(x_slot);
+    auto advance = [&]() {
+        if (++x_kt < nt) {
+            x_c0 += 64;
+            if (x_c0 == P.a_C) { x_c0 = 0; ++x_tap; }
+        } else {
+            x_kt = 0; x_tap = 0; x_c0 = 0;
+            x_slot += stride;
+            x_ok = x_slot < ntiles;
+            if (x_ok) setup(x_slot);
+        }
+    };
+    auto issue_a = [&](int i, unsigned char *dst) {
+        gl(asrc(i, x_tap, ((long long)x_tap * P.a_tap + x_c0) * 2), dst + i * 1024);
+    };
+    auto issue_b = [&](int i, unsigned char *dst) { gl(pb[i] + (long long)x_kt * 128, dst + PP_T + i * 1024); };
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -241,51 +258,56 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = P.K / 64;
+    // prologue: K-tile 0 in full, and pieces A0..A2 of the K-tile after it (what the loop's last segment would
+    // have issued)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        gl(asrc(i, 0, 0), smem + piece0 + i * 1024);
-        gl(pb[i], smem + PP_T + piece0 + i * 1024);
+        issue_a(i, smem + piece0);
+        issue_b(i, smem + piece0);
+    }
+    advance();
+    if (x_ok) {
+        issue_a(0, smem + PP_BUF + piece0);
+        issue_a(1, smem + PP_BUF + piece0);
+        issue_a(2, smem + PP_BUF + piece0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR();
     if (wr == 1) PP_BAR();   // group 1 runs one segment behind group 0
 
     bf16x8 fa[4][2], fb[4][2];
-    int gt = 0;   // K-tiles consumed by this workgroup so far: parity = LDS buffer
+    // 16 MFMAs of one quadrant; `between(n)` runs after the n-th (load pieces ride in the gaps of the matrix pipe:
+    // issued from a load segment next to the ds_reads they cost 100-185 cycles each, here about 60)
+    auto quadrant = [&](int ia, int j0, auto &&between) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[ia + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j0 + j][kk], fa[i][kk], acc[ia + i][j0 + j], 0, 0, 0);
+                    between(kk * 8 + i * 2 + j);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    int gt = 0, cur_slot = blockIdx.x;   // K-tiles consumed so far (parity = LDS buffer); the tile being accumulated
 #ifdef PIKA_PP_TRACE
     int tr_tile = 0;
     unsigned long long tr_stall = 0, tr_stall0 = 0, tr_t0 = 0, tr_rt0 = 0, tr_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_k8 = 0;
     const bool tr_on = P.trace && blockIdx.x < 8 && (threadIdx.x & 255) == 0;
 #endif
     for (;;) {
-    const int em0 = m0, en0 = n0;   // the tile being accumulated (setup() moves m0/n0 on to the next one)
 #ifdef PIKA_PP_TRACE
     if (tr_on) { tr_t0 = __builtin_amdgcn_s_memtime(); tr_rt0 = __builtin_amdgcn_s_memrealtime(); tr_stall = 0; }
 #endif
-    bool more = false;
-    int tap = 0, c0 = 0;
     for (int t = 0; t < nt; ++t, ++gt) {
         const unsigned char *cur = smem + (gt & 1) * PP_BUF;
-        unsigned char *nxt = smem + ((gt + 1) & 1) * PP_BUF + piece0;
+        unsigned char *xdst = smem + ((gt + 1) & 1) * PP_BUF + piece0;   // rest of the cursor's K-tile (next to be read)
+        unsigned char *ydst = smem + (gt & 1) * PP_BUF + piece0;         // the K-tile after it: this buffer, once read
 #ifdef PIKA_PP_TRACE
         if (tr_on && t == 8) tr_k8 = __builtin_amdgcn_s_memtime();
 #endif
-        bool pf = true;
-        long long ka, kb;
-        if (t + 1 < nt) {
-            c0 += 64;
-            if (c0 == P.a_C) { c0 = 0; ++tap; }
-            ka = ((long long)tap * P.a_tap + c0) * 2; kb = (long long)(t + 1) * 128;
-        } else {
-            // last K-tile of this output tile: the prefetch slot fetches K-tile 0 of the workgroup's NEXT output
-            // tile, so its main loop starts right behind this tile's stores with no load latency in between
-            slot += stride;
-            more = slot < ntiles;
-            pf = more;
-            if (more) setup(slot);
-            tap = 0; c0 = 0; ka = 0; kb = 0;
-        }
         // ---- phase 0: quadrant (m-half 0, n-half 0)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -297,22 +319,14 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fa[i][0] = ldsv(cur + aoff + i * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + i * 2048 + sw1);
         }
-        if (pf) {
-            gl(asrc(0, tap, ka), nxt);
-            gl(asrc(1, tap, ka), nxt + 1024);
-            gl(asrc(2, tap, ka), nxt + 2048);
-        }
         PP_BAR();
         PP_STAMP(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        quadrant(0, 0, [&](int n) {
+            if (x_ok) {
+                if (n == 3) issue_a(3, xdst);
+                if (n == 9) issue_b(0, xdst);
+            }
+        });
         PP_BAR();
         PP_STAMP(1);
         // ---- phase 1: (m-half 0, n-half 1)
@@ -321,47 +335,33 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fb[j][0] = ldsv(cur + boff + j * 2048 + sw0);
             fb[j][1] = ldsv(cur + boff + j * 2048 + sw1);
         }
-        if (pf) {
-            gl(asrc(3, tap, ka), nxt + 3072);
-            gl(pb[0] + kb, nxt + PP_T);
-            gl(pb[1] + kb, nxt + PP_T + 1024);
-            gl(pb[2] + kb, nxt + PP_T + 2048);
-            gl(pb[3] + kb, nxt + PP_T + 3072);
-        }
         PP_BAR();
         PP_STAMP(2);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        quadrant(0, 2, [&](int n) {
+            if (x_ok) {
+                if (n == 2) issue_b(1, xdst);
+                if (n == 7) issue_b(2, xdst);
+                if (n == 12) issue_b(3, xdst);
+            }
+        });
         PP_BAR();
         PP_STAMP(3);
-        // ---- phase 2: (m-half 1, n-half 1)
+        // ---- phase 2: (m-half 1, n-half 1).  Everything of the cursor's K-tile is issued: move the cursor on
+        // (into the workgroup's next output tile behind the last K-tile of this one)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = ldsv(cur + aoff + (4 + i) * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + (4 + i) * 2048 + sw1);
         }
+        if (x_ok) advance();
         PP_BAR();
         PP_STAMP(4);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 2; j < 4; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        quadrant(4, 2, [&](int) {});
         PP_BAR();
         PP_STAMP(5);
-        // ---- phase 3: (m-half 1, n-half 0); the prefetched tile must have landed before the
-        // barrier that lets the other group start reading it
+        // ---- phase 3: (m-half 1, n-half 0).  The K-tile read next must have landed before the barrier that lets
+        // the other group start on it (its last pieces were issued two segments ago).  Behind that barrier BOTH
+        // groups are done reading `cur`, so the first pieces of the K-tile after next go into it.
 #ifdef PIKA_PP_TRACE
         unsigned long long tr_a = 0;
         if (tr_on) tr_a = __builtin_amdgcn_s_memtime();
@@ -372,15 +372,13 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #endif
         PP_BAR();
         PP_STAMP(6);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        quadrant(4, 0, [&](int n) {
+            if (x_ok) {
+                if (n == 2) issue_a(0, ydst);
+                if (n == 7) issue_a(1, ydst);
+                if (n == 12) issue_a(2, ydst);
+            }
+        });
         PP_BAR();
         PP_STAMP(7);
     }
@@ -391,6 +389,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 
     const float *bias = P.bias;
     float *C = P.C;
+    const int etile = tile_of(cur_slot), em0 = (etile / nx) * 256, en0 = (etile % nx) * 256;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = em0 + wr * 128 + i * 16 + (lane & 15);
@@ -462,7 +461,8 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     }
     ++tr_tile;
 #endif
-    if (!more) break;
+    cur_slot += stride;
+    if (cur_slot >= ntiles) break;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -723,9 +723,6 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
         return cus & ~7;
     }();
     const int grid = (wgs >= 8 && nt > wgs) ? (wgs & ~7) : (int)nt;
-    static const int stagger_env = [] { const char *e = getenv("PIKA_GEMM_PP_STAGGER"); return e ? atoi(e) : -1; }();
-    Q.stagger = 0;
-    if (grid < nt) Q.stagger = stagger_env >= 0 ? stagger_env : 0;
     hipLaunchKernelGGL(gemm_pp<EPI>, dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
     return (int)hipGetLastError();
 }
