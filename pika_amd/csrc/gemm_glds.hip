@@ -129,6 +129,9 @@ __global__ __launch_bounds__(THREADS) void gemm_glds(const __bf16 *__restrict__ 
 // A may be a time-delay view (pika_operand_t with pad == 0, C % 64 == 0): a K-tile never straddles
 // a tap, so it only changes the per-tile source offset.
 constexpr int PP_T = 256 * 128, PP_BUF = 2 * PP_T;
+#ifndef PP_GM
+#define PP_GM 4
+#endif
 
 #ifdef PIKA_PP_TRACE
 #define PP_STAMP(n) do { if (tr_on && t == 8) tr_ph[n] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int M = P.M, N = P.N;
     const int nx = P.nx, ntiles = P.ntiles, stride = gridDim.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+    // wave index as a scalar: everything derived from it (LDS destinations = M0, wave-group tests) stays in SGPRs
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = wave >> 2, wc = wave & 3;
     // launch slot v -> tile: slots that share v % 8 (one XCD, one L2) get a contiguous run of tiles.  A workgroup
     // walks the slots blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0 or a single pass), so all its
     // tiles stay on its own XCD's run
@@ -194,32 +198,51 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
         return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     };
+    // ... and the run is walked in bands of PP_GM tile rows, column by column inside a band: the ~32 tiles an XCD
+    // works on at any moment form a PP_GM x (32 / PP_GM) block that shares PP_GM + 32 / PP_GM operand panels in its
+    // L2 instead of the 1 + 32 of a row-major walk (fewer L2 misses = shorter load latency = faster LDS fill)
+    auto tile_mn = [&](int tile, int &tm, int &tn) {
+        const int band = tile / (PP_GM * nx), in = tile - band * (PP_GM * nx);
+        const int rows = min(PP_GM, ntiles / nx - band * PP_GM);
+        tn = in / rows;
+        tm = band * PP_GM + (in - tn * rows);
+    };
 
-    const char *pa[4], *pb[4];
-    int ts[4];   // source time of tap 0 for this lane's row of piece i
-    int m0, n0;
+    // Sources: a scalar 64-bit base per operand and tile plus a 32-bit byte offset per lane and piece (the host
+    // checks they fit), so a load is `global_load_lds v_off, s[base]` with no 64-bit vector arithmetic in the loop.
+    const char *sa;            // A: first row of the cursor's tile
+    unsigned ao[4], bo[4];     // byte offsets of this lane's 16 bytes of piece i from sa / P.B
+    int ts[4];                 // source time of tap 0 for this lane's row of piece i
+    int n0;
+    const int g16 = ((lane & 7) ^ (lane >> 3)) * 16;   // this lane's 16-byte granule of a 128-byte row, XOR-swizzled by row & 7
     auto setup = [&](int v) {
-        const int tile = tile_of(v);
-        m0 = (tile / nx) * 256; n0 = (tile % nx) * 256;
+        int tm, tn;
+        tile_mn(tile_of(v), tm, tn);
+        const int m0 = tm * 256;
+        n0 = tn * 256;
+        const int ab0 = m0 / P.a_rpb, at0 = m0 - ab0 * P.a_rpb;
+        // rows of a later batch may lie BELOW the tile's first row when the batches of a padded time-delay view
+        // overlap in row space: bias the base so that every offset is >= 0
+        long long below = 0;
+        if (min(m0 + 255, M - 1) / P.a_rpb > ab0) below = max(0LL, (long long)at0 * P.a_row - P.a_batch);
+        sa = reinterpret_cast<const char *>(P.A + (long long)ab0 * P.a_batch + (long long)at0 * P.a_row - below);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + (lane >> 3), g = (lane & 7) ^ (r & 7);
-            int ra = m0 + r, rb = n0 + r;
+            // A piece i of a wave: 8 rows of the 64-row block i (blocks 0/1 = the two m-halves of wave group 0,
+            // 2/3 = of group 1), so the pieces a quadrant phase reads are the same pieces for every wave
+            int ra = m0 + i * 64 + wave * 8 + (lane >> 3);
             ra = ra < M ? ra : M - 1;
-            rb = rb < N ? rb : N - 1;
             const int ab = ra / P.a_rpb, at = ra - ab * P.a_rpb;
             ts[i] = at * P.a_tstep - P.a_t0;
-            pa[i] = reinterpret_cast<const char *>(P.A + (long long)ab * P.a_batch + (long long)at * P.a_row) + g * 16;
-            pb[i] = reinterpret_cast<const char *>(P.B + (long long)rb * P.ldb) + g * 16;
+            ao[i] = (unsigned)(((long long)(ab - ab0) * P.a_batch + (long long)(at - at0) * P.a_row + below) * 2) + g16;
+            // B piece i of a wave: rows n0 + (wave * 4 + i) * 8 .. + 7 (clamped to the last row at the edge)
+            int rb = n0 + (wave * 4 + i) * 8 + (lane >> 3);
+            rb = rb < N ? rb : N - 1;
+            bo[i] = (unsigned)((long long)rb * P.ldb * 2) + g16;
         }
     };
     const char *zp = reinterpret_cast<const char *>(pp_zero_page) + (lane & 7) * 16;
     const int bounds = P.a_bounds;
-    // source of A piece i for tap `tp` at byte offset `off` (rows whose source time is outside the signal read zeros)
-    auto asrc = [&](int i, int tp, long long off) -> const char * {
-        if (!bounds) return pa[i] + off;
-        return (unsigned)(ts[i] + tp * P.a_dtap) < (unsigned)P.a_tin ? pa[i] + off : zp;
-    };
     const int piece0 = wave * 4 * 1024;
     auto gl = [&](const char *p, unsigned char *dst) {
         __builtin_amdgcn_sched_barrier(0);
@@ -247,10 +270,18 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             if (x_ok) setup(x_slot);
         }
     };
+    // `dst` = the K-tile buffer.  With `bounds`, rows whose source time is outside the signal read a zero page.
     auto issue_a = [&](int i, unsigned char *dst) {
-        gl(asrc(i, x_tap, ((long long)x_tap * P.a_tap + x_c0) * 2), dst + i * 1024);
+        const char *base = sa + ((long long)x_tap * P.a_tap + x_c0) * 2;
+        if (!bounds) {
+            gl(base + ao[i], dst + i * 8192 + wave * 1024);
+        } else {
+            gl((unsigned)(ts[i] + x_tap * P.a_dtap) < (unsigned)P.a_tin ? base + ao[i] : zp, dst + i * 8192 + wave * 1024);
+        }
     };
-    auto issue_b = [&](int i, unsigned char *dst) { gl(pb[i] + (long long)x_kt * 128, dst + PP_T + i * 1024); };
+    auto issue_b = [&](int i, unsigned char *dst) {
+        gl(reinterpret_cast<const char *>(P.B) + (long long)x_kt * 128 + bo[i], dst + PP_T + piece0 + i * 1024);
+    };
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -258,53 +289,61 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: K-tile 0 in full, and pieces A0..A2 of the K-tile after it (what the loop's last segment would
-    // have issued)
+    // prologue: K-tile 0 in full and the first half (A0 A2 B0 B1) of the K-tile behind it; the cursor stays on that one
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        issue_a(i, smem + piece0);
-        issue_b(i, smem + piece0);
+        issue_a(i, smem);
+        issue_b(i, smem);
     }
     advance();
     if (x_ok) {
-        issue_a(0, smem + PP_BUF + piece0);
-        issue_a(1, smem + PP_BUF + piece0);
-        issue_a(2, smem + PP_BUF + piece0);
+        issue_a(0, smem + PP_BUF);
+        issue_a(2, smem + PP_BUF);
+        issue_b(0, smem + PP_BUF);
+        issue_b(1, smem + PP_BUF);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR();
     if (wr == 1) PP_BAR();   // group 1 runs one segment behind group 0
 
     bf16x8 fa[4][2], fb[4][2];
-    // 16 MFMAs of one quadrant; `between(n)` runs after the n-th (load pieces ride in the gaps of the matrix pipe:
-    // issued from a load segment next to the ds_reads they cost 100-185 cycles each, here about 60)
-    auto quadrant = [&](int ia, int j0, auto &&between) {
+    auto quadrant = [&](int ia, int j0) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 2; ++j)
                     acc[ia + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j0 + j][kk], fa[i][kk], acc[ia + i][j0 + j], 0, 0, 0);
-                    between(kk * 8 + i * 2 + j);
-                }
         __builtin_amdgcn_s_setprio(0);
     };
     int gt = 0, cur_slot = blockIdx.x;   // K-tiles consumed so far (parity = LDS buffer); the tile being accumulated
 #ifdef PIKA_PP_TRACE
     int tr_tile = 0;
-    unsigned long long tr_stall = 0, tr_stall0 = 0, tr_t0 = 0, tr_rt0 = 0, tr_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_k8 = 0;
-    const bool tr_on = P.trace && blockIdx.x < 8 && (threadIdx.x & 255) == 0;
+    unsigned long long tr_t0 = 0, tr_rt0 = 0, tr_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_k8 = 0;
+    const bool tr_on = P.trace && blockIdx.x < 8 && (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) == 0;   // wave-uniform: stamps stay in SGPRs
 #endif
     for (;;) {
 #ifdef PIKA_PP_TRACE
-    if (tr_on) { tr_t0 = __builtin_amdgcn_s_memtime(); tr_rt0 = __builtin_amdgcn_s_memrealtime(); tr_stall = 0; }
+    if (tr_on) { tr_t0 = __builtin_amdgcn_s_memtime(); tr_rt0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
     for (int t = 0; t < nt; ++t, ++gt) {
+        // Load segments (ds_read fragments, two pieces of the fetch cursor's K-tile) alternate with MFMA segments; while
+        // one wave group is in a load segment the other owns the matrix pipe.  The CU takes about one 1 KB piece per
+        // 30-35 cycles whoever issues it, so all four load segments carry exactly two pieces per wave, and a K-tile
+        // is fetched over four consecutive segments that straddle two iterations, into the buffer read two K-tiles
+        // earlier, each pair as soon as BOTH wave groups have retired their reads of the rows it overwrites:
+        //   phase 2 of iteration t:   A0 A2 of K-tile t+2   (read in phase 0 of t by group 0 / 1)
+        //   phase 3 of iteration t:   B0 B1                 (B is last read in phase 1)
+        //   phase 0 of iteration t+1: B2 B3
+        //   phase 1 of iteration t+1: A1 A3                 (m-half 1 of group 0 / 1, read in phase 2 of t)
+        // Loads are never drained: phase 3 waits until all but the last four (A1 A3 of K-tile t+1, A0 A2 of t+2) have
+        // landed -- what phases 0 and 1 of the next iteration read -- and phase 1 until all but the last six, which
+        // retires A1 A3 of THIS K-tile one barrier before phase 2 reads them.  Loads return in order, so the counts
+        // hold whatever the stores of an epilogue in between do.
         const unsigned char *cur = smem + (gt & 1) * PP_BUF;
-        unsigned char *xdst = smem + ((gt + 1) & 1) * PP_BUF + piece0;   // rest of the cursor's K-tile (next to be read)
-        unsigned char *ydst = smem + (gt & 1) * PP_BUF + piece0;         // the K-tile after it: this buffer, once read
+        unsigned char *nxt = smem + ((gt + 1) & 1) * PP_BUF, *nn = smem + (gt & 1) * PP_BUF;
 #ifdef PIKA_PP_TRACE
         if (tr_on && t == 8) tr_k8 = __builtin_amdgcn_s_memtime();
 #endif
@@ -319,14 +358,13 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fa[i][0] = ldsv(cur + aoff + i * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + i * 2048 + sw1);
         }
+        if (x_ok) {
+            issue_b(2, nxt);
+            issue_b(3, nxt);
+        }
         PP_BAR();
         PP_STAMP(0);
-        quadrant(0, 0, [&](int n) {
-            if (x_ok) {
-                if (n == 3) issue_a(3, xdst);
-                if (n == 9) issue_b(0, xdst);
-            }
-        });
+        quadrant(0, 0);
         PP_BAR();
         PP_STAMP(1);
         // ---- phase 1: (m-half 0, n-half 1)
@@ -335,50 +373,45 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             fb[j][0] = ldsv(cur + boff + j * 2048 + sw0);
             fb[j][1] = ldsv(cur + boff + j * 2048 + sw1);
         }
+        if (x_ok) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            issue_a(1, nxt);
+            issue_a(3, nxt);
+            advance();   // (into the workgroup's next output tile behind the last K-tile of this one)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         PP_BAR();
         PP_STAMP(2);
-        quadrant(0, 2, [&](int n) {
-            if (x_ok) {
-                if (n == 2) issue_b(1, xdst);
-                if (n == 7) issue_b(2, xdst);
-                if (n == 12) issue_b(3, xdst);
-            }
-        });
+        quadrant(0, 2);
         PP_BAR();
         PP_STAMP(3);
-        // ---- phase 2: (m-half 1, n-half 1).  Everything of the cursor's K-tile is issued: move the cursor on
-        // (into the workgroup's next output tile behind the last K-tile of this one)
+        // ---- phase 2: (m-half 1, n-half 1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = ldsv(cur + aoff + (4 + i) * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + (4 + i) * 2048 + sw1);
         }
-        if (x_ok) advance();
+        if (x_ok) {
+            issue_a(0, nn);
+            issue_a(2, nn);
+        }
         PP_BAR();
         PP_STAMP(4);
-        quadrant(4, 2, [&](int) {});
+        quadrant(4, 2);
         PP_BAR();
         PP_STAMP(5);
-        // ---- phase 3: (m-half 1, n-half 0).  The K-tile read next must have landed before the barrier that lets
-        // the other group start on it (its last pieces were issued two segments ago).  Behind that barrier BOTH
-        // groups are done reading `cur`, so the first pieces of the K-tile after next go into it.
-#ifdef PIKA_PP_TRACE
-        unsigned long long tr_a = 0;
-        if (tr_on) tr_a = __builtin_amdgcn_s_memtime();
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef PIKA_PP_TRACE
-        if (tr_on) { const unsigned long long d = __builtin_amdgcn_s_memtime() - tr_a; tr_stall += d; if (t == 0) tr_stall0 = d; }
-#endif
+        // ---- phase 3: (m-half 1, n-half 0)
+        if (x_ok) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            issue_b(0, nn);
+            issue_b(1, nn);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         PP_BAR();
         PP_STAMP(6);
-        quadrant(4, 0, [&](int n) {
-            if (x_ok) {
-                if (n == 2) issue_a(0, ydst);
-                if (n == 7) issue_a(1, ydst);
-                if (n == 12) issue_a(2, ydst);
-            }
-        });
+        quadrant(4, 0);
         PP_BAR();
         PP_STAMP(7);
     }
@@ -389,7 +422,9 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 
     const float *bias = P.bias;
     float *C = P.C;
-    const int etile = tile_of(cur_slot), em0 = (etile / nx) * 256, en0 = (etile % nx) * 256;
+    int etm, etn;
+    tile_mn(tile_of(cur_slot), etm, etn);
+    const int em0 = etm * 256, en0 = etn * 256;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = em0 + wr * 128 + i * 16 + (lane & 15);
@@ -453,11 +488,11 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         }
     }
 #ifdef PIKA_PP_TRACE
-    if (tr_on && tr_tile < 16) {
+    if (tr_on && tr_tile < 16 && lane == 0) {
         unsigned long long *q = P.trace + ((blockIdx.x * 2 + wr) * 16 + tr_tile) * 24;
         q[6] = tr_k8;
         for (int e = 0; e < 8; ++e) q[8 + e] = tr_ph[e];
-        q[0] = tr_t0; q[1] = tr_rt0; q[2] = tr_stall; q[3] = tr_stall0; q[4] = tr_k; q[5] = __builtin_amdgcn_s_memtime();
+        q[0] = tr_t0; q[1] = tr_rt0; q[2] = 0; q[3] = 0; q[4] = tr_k; q[5] = __builtin_amdgcn_s_memtime();
     }
     ++tr_tile;
 #endif
@@ -699,8 +734,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     *reinterpret_cast<f32x4 *>(C + (long long)m * ldc + n) = acc;
 }
 
+// gemm_pp addresses a tile's rows by 32-bit byte offsets from the tile's first row (A) and from B
+bool pp_offsets_fit(const PPArgs &P) {
+    if (P.a_rpb <= 0 || P.a_batch < 0 || P.a_row < 0 || P.ldb < 0) return false;
+    if ((long long)P.N * P.ldb >= (1LL << 30)) return false;
+    const long long rpb = P.a_rpb;
+    const long long below = P.M > rpb && (rpb - 1) * P.a_row > P.a_batch ? (rpb - 1) * P.a_row - P.a_batch : 0;
+    return (255 / rpb + 1) * P.a_batch + (rpb < 256 ? rpb : 256) * P.a_row + below < (1LL << 30);
+}
+
 template <int EPI>
 int launch_pp_epi(const PPArgs &P, hipStream_t s) {
+    if (!pp_offsets_fit(P)) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI>),
@@ -854,6 +899,7 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     // the row pointer of tap 0 starts `pad` source rows before the signal; only ever dereferenced in range
     P.A -= (long long)A->pad * A->ld;
     P.M = M; P.N = N; P.K = K; P.relu = (flags & PIKA_GEMM_RELU) ? 1 : 0;
+    if (!pp_offsets_fit(P)) return PIKA_NOT_APPLICABLE;
     if (out16) {   // C is a bf16 matrix with pitch ldc: plain bf16 epilogue (no dropout)
         P.out16 = reinterpret_cast<__bf16 *>(C); P.ldo16 = ldc; P.thr = 0; P.scale = 1.f;
         return launch_pp_epi<1>(P, s);

@@ -39,8 +39,8 @@ int main(int argc, char **argv) {
         for (int t = 0; t < 16; ++t) {
             const unsigned long long *q = q0 + t * 24;
             const double nxt = t < 15 ? (double)(q[24] - q[0]) * tick_us : 0.0;
-            printf("  tile %2d: k-loop %6.2f us (load-wait stalls %5.2f, of which first K-tile %5.2f)  epilogue issue %5.2f us  tile total %6.2f us\n",
-                   t, (q[4] - q[0]) * tick_us, q[2] * tick_us, q[3] * tick_us, (q[5] - q[4]) * tick_us, nxt);
+            printf("  tile %2d: k-loop %6.2f us  epilogue issue %5.2f us  tile total %6.2f us\n",
+                   t, (q[4] - q[0]) * tick_us, (q[5] - q[4]) * tick_us, nxt);
             if (t == 3 || t == 4) {
                 printf("           K-tile 8, cycles from its start to the exit of each of its 8 barriers:");
                 for (int e = 0; e < 8; ++e) printf(" %5lld", (long long)(q[8 + e] - q[6]));
