@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "pika_gemm.h"
 #include "pika_rnnt.h"
@@ -328,7 +329,9 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #ifdef PIKA_PP_TRACE
     if (tr_on) { tr_t0 = __builtin_amdgcn_s_memtime(); tr_rt0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
-    for (int t = 0; t < nt; ++t, ++gt) {
+    // One K-tile.  `sw` = the cursor may step into the workgroup's next output tile in this iteration (the last two
+    // K-tiles of an output tile): kept out of the steady-state loop body, where the lane offsets are loop invariants
+    auto ktile = [&](int t, auto sw) {
         // Load segments (ds_read fragments, two pieces of the fetch cursor's K-tile) alternate with MFMA segments; while
         // one wave group is in a load segment the other owns the matrix pipe.  The CU takes about one 1 KB piece per
         // 30-35 cycles whoever issues it, so all four load segments carry exactly two pieces per wave, and a K-tile
@@ -377,7 +380,13 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             issue_a(1, nxt);
             issue_a(3, nxt);
-            advance();   // (into the workgroup's next output tile behind the last K-tile of this one)
+            if constexpr (decltype(sw)::value) {
+                advance();   // (into the workgroup's next output tile behind the last K-tile of this one)
+            } else {
+                ++x_kt;
+                x_c0 += 64;
+                if (x_c0 == P.a_C) { x_c0 = 0; ++x_tap; }
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -414,6 +423,11 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         quadrant(4, 0);
         PP_BAR();
         PP_STAMP(7);
+    };
+    {
+        int t = 0;
+        for (; t < nt - 2; ++t, ++gt) ktile(t, std::false_type{});
+        for (; t < nt; ++t, ++gt) ktile(t, std::true_type{});
     }
 #ifdef PIKA_PP_TRACE
     unsigned long long tr_k = 0;
