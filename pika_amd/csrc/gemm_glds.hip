@@ -434,13 +434,40 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     if (tr_on) tr_k = __builtin_amdgcn_s_memtime();
 #endif
 
+    // The two wave groups write their halves of the tile at the same time: group 0 lets group 1 catch up here and
+    // runs ahead again behind the epilogue (staggered, each group's epilogue would sit inside the other's barrier wait)
+    if (wr == 0) PP_BAR();
     const float *bias = P.bias;
     float *C = P.C;
     int etm, etn;
     tile_mn(tile_of(cur_slot), etm, etn);
     const int em0 = etm * 256, en0 = etn * 256;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    // residual / mask operands of a column-interior tile are fetched one or two 16-row blocks at a time, ahead
+    // of the arithmetic and the stores: one at a time, every load pays its full latency behind the previous store
+    const bool wide = en0 + 256 <= N;
+    constexpr int EB = EPI == 3 ? 1 : 2;   // 16-row blocks fetched ahead (sixteen registers either way)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int ip = 0; ip < 8; ip += EB) {
+        f32x4 rv[EB][4];
+        bf16x4 av[EB][4];
+        if constexpr (EPI == 2 || EPI == 3) {
+            if (wide) {
+#pragma unroll
+                for (int di = 0; di < EB; ++di) {
+                    const int mr = min(em0 + wr * 128 + (ip + di) * 16 + (lane & 15), M - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+                        if constexpr (EPI == 3) rv[di][j] = *reinterpret_cast<const f32x4 *>(P.res + (long long)mr * P.ld_res + n);
+                        else av[di][j] = *reinterpret_cast<const bf16x4 *>(P.aux + (long long)mr * P.ld_aux + n);
+                    }
+                }
+            }
+        }
+#pragma unroll
+    for (int di = 0; di < EB; ++di) {
+        const int i = ip + di;
         const int m = em0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
@@ -463,7 +490,8 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * P.scale : 0.f;
                 }
                 const float *rp = P.res + (long long)m * P.ld_res + n;
-                if (n + 3 < N) v += *reinterpret_cast<const f32x4 *>(rp);
+                if (wide) v += rv[di][j];
+                else if (n + 3 < N) v += *reinterpret_cast<const f32x4 *>(rp);
                 else for (int e = 0; e < 4; ++e) if (n + e < N) v[e] += rp[e];
             }
             if constexpr (EPI == 0 || EPI == 3) {
@@ -481,17 +509,15 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                         for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * P.scale : 0.f;
                     }
                 } else {
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                     const __bf16 *ap = P.aux + (long long)m * P.ld_aux + n;
-                    if (n + 3 < N) {
-                        const bf16x4 a4 = *reinterpret_cast<const bf16x4 *>(ap);
+                    if (wide || n + 3 < N) {
+                        const bf16x4 a4 = wide ? av[di][j] : *reinterpret_cast<const bf16x4 *>(ap);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (float)a4[e] > 0.f ? v[e] * P.scale : 0.f;
                     } else {
                         for (int e = 0; e < 4; ++e) if (n + e < N) v[e] = (float)ap[e] > 0.f ? v[e] * P.scale : 0.f;
                     }
                 }
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 __bf16 *op = P.out16 + (long long)m * P.ldo16 + n;
                 if (n + 3 < N) {
                     *reinterpret_cast<bf16x4 *>(op) = __builtin_convertvector(v, bf16x4);
@@ -500,6 +526,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 }
             }
         }
+    }
     }
 #ifdef PIKA_PP_TRACE
     if (tr_on && tr_tile < 16 && lane == 0) {
@@ -516,8 +543,8 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) PP_BAR();
     }
-    if (wr == 0) PP_BAR();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [("tdnn_dW", 1024, 3072, 31616), ("proj_dW", 1024, 1024, 31616), ("ffn1_dW", 4096, 1024, 31616),
-          ("ffn2_dW", 1024, 4096, 31616), ("late_dW", 1024, 1024, 7680)]
+          ("ffn2_dW", 1024, 4096, 31616), ("late_dW", 1024, 1024, 7680), ("joint_dW2", 5056, 1024, 391680)]
 
 
 def worker():
