@@ -575,63 +575,78 @@ struct TNArgs {
     float *ws;             // split-K partials [gridDim.z][M][N] (dense), or null -> atomics into C
 };
 
-__device__ inline bf16x8 lds_tr(const unsigned char *p) {
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
+// Transposed fragment read, as raw instructions: through the builtin, hipcc drains every pending LDS-DMA load
+// (s_waitcnt vmcnt(0)) in front of each group of reads, because it cannot tell the rows being read from the rows
+// being prefetched -- that serialises the prefetch with the very phase it is issued in.  The buffers are kept apart
+// by the barrier / vmcnt protocol of the K loop instead.  The two halves land asynchronously: they may only be
+// touched behind TN_WAIT_LDS().
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct TrFrag { s16x4 lo, hi; };
+__device__ inline void lds_tr(TrFrag &f, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(lds_addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f.hi) : "v"(lds_addr));
+}
+__device__ inline bf16x8 tr_join(const TrFrag &f) {
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * 512));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const s16x8 v = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
+#define TN_WAIT_LDS() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// Source addresses of one operand's pieces: a scalar base (first reduction row of the K-tile being fetched) that
+// advances by 64 rows per K-tile, plus 32-bit lane offsets that never change.  Piece i of a wave = reduction rows
+// 2 * (wave * 4 + i), + 1 of the K-tile; a row that runs past the end of its batch (rpb >= 64: at most one batch
+// boundary inside a K-tile) adds `wrap`.  All loop arithmetic is scalar; a load is global_load_lds v_off, s[base].
 struct TNStager {
-    const char *p[4];
-    int tt[4];
-    long long step, wrap;  // bytes per 64 rows; extra bytes when crossing a batch
-    int rpb;
+    const char *base;        // row R0 of the K-tile, column block c0
+    unsigned lo[2];          // lane offset for even / odd pieces: swizzled 16-byte column chunk + (lane >> 5) rows
+    long long rowb;          // bytes per reduction row
+    unsigned wrapb;          // extra bytes when crossing into the next batch (host: 0 <= wrap < 2^30)
+    int rpb, t0;             // rows per batch; row of R0 inside its batch
 
     __device__ inline void init(const TNOperand &o, int c0, int r0, int wave, int lane) {
         rpb = o.rpb;
-        step = 64 * o.row * 2;
-        wrap = (o.batch - (long long)o.rpb * o.row) * 2;
+        rowb = o.row * 2;
+        wrapb = (unsigned)((o.batch - (long long)o.rpb * o.row) * 2);
         const int tap = c0 / o.C;   // a 256-column block never straddles a tap (C % 256 == 0 or one tap)
         const long long coff = (long long)tap * o.tap_stride + (c0 - tap * o.C);
+        const int b0 = r0 / o.rpb;
+        t0 = r0 - b0 * o.rpb;
+        base = reinterpret_cast<const char *>(o.ptr + (long long)b0 * o.batch + (long long)t0 * o.row + coff);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 2 * (wave * 4 + i) + (lane >> 5);           // row inside the K-tile
-            const int key = (row & 3) | (((row >> 3) & 1) << 2);
-            const int g16 = lane & 31, q = (g16 >> 1) ^ key;             // 32-byte chunk, swizzled
+        for (int par = 0; par < 2; ++par) {
+            const int key = (2 * par + (lane >> 5)) | ((wave & 1) << 2);   // key(row) = (row & 3) | ((row >> 3) & 1) << 2
+            const int g16 = lane & 31, q = (g16 >> 1) ^ key;               // 32-byte chunk, swizzled
             // columns past the operand width feed output rows/columns that are never stored: re-read
             // the last valid chunk instead of running off the row
             const int col = min(q * 16 + (g16 & 1) * 8, o.width - c0 - 8);
-            const int r = r0 + row;
-            const int b = r / o.rpb;
-            tt[i] = r - b * o.rpb;
-            p[i] = reinterpret_cast<const char *>(o.ptr + (long long)b * o.batch + (long long)tt[i] * o.row + coff + col);
+            lo[par] = (unsigned)(col * 2) + (unsigned)((lane >> 5) * rowb);
         }
     }
-    // reduction rows past the end read zeros (for BOTH operands: 0 x garbage could be NaN)
-    __device__ inline const char *src(int i, int r, int R) const {
-        const char *z = reinterpret_cast<const char *>(pp_zero_page) + (threadIdx.x & 31) * 16;
-        return r < R ? p[i] : z;
+    // piece i of wave `wave` (scalar); `full` = all 64 rows of the K-tile exist (else rows >= R read zeros, for BOTH
+    // operands: 0 x garbage could be NaN)
+    __device__ inline const char *src(int i, int wave, int lane, bool full, int r0, int R) const {
+        const int row = 2 * (wave * 4 + i);
+        const char *sb = base + (long long)row * rowb;
+        const unsigned off = lo[i & 1] + ((lane >> 5) >= rpb - t0 - row ? wrapb : 0u);
+        if (full) return sb + off;
+        const char *z = reinterpret_cast<const char *>(pp_zero_page) + (lane & 31) * 16;
+        return r0 + row + (lane >> 5) < R ? sb + off : z;
     }
     __device__ inline void advance() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            p[i] += step;
-            tt[i] += 64;
-            while (tt[i] >= rpb) { tt[i] -= rpb; p[i] += wrap; }
-        }
+        t0 += 64;
+        base += 64 * rowb;
+        if (t0 >= rpb) { t0 -= rpb; base += wrapb; }
     }
 };
 
 #define TN_MFMA(MH, KK)                                                                             \
     do {                                                                                            \
+        TN_WAIT_LDS();                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                              \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-                acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[(MH) * 4 + i][j], 0, 0, 0); \
+                acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_join(fb[j]), tr_join(fa[i]), acc[(MH) * 4 + i][j], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                              \
     } while (0)
 
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int m0 = (tile / nx) * 256, n0 = (tile % nx) * 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = wave >> 2, wc = wave & 3;
     const int t_begin = blockIdx.z * P.tiles_per_split;
     const int t_total = (P.R + 63) / 64;
     const int nt = min(P.tiles_per_split, t_total - t_begin);
@@ -654,10 +669,14 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
     TNStager sa, sb;
     sa.init(P.A, m0, t_begin * 64, wave, lane);
     sb.init(P.B, n0, t_begin * 64, wave, lane);
-    int rrow = t_begin * 64 + 2 * (wave * 4) + (lane >> 5);   // reduction row of piece 0 (piece i: + 2i)
+    int r0 = t_begin * 64;   // first reduction row of the K-tile being fetched
     const int piece0 = wave * 4 * 1024;
     auto gl = [&](const char *p, unsigned char *dst) {
         __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
+    };
+    auto issue = [&](const TNStager &st, int i, unsigned char *dst) {
+        if (r0 + 64 <= R) gl(st.src(i, wave, lane, true, r0, R), dst);
+        else gl(st.src(i, wave, lane, false, r0, R), dst);
     };
 
     // transpose-read addressing: lane (g, i16 = 4j + c) supplies row kk*32 + g*8 + j (+4 for the second
@@ -676,60 +695,62 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        gl(sa.src(i, rrow + 2 * i, R), smem + piece0 + i * 1024);
-        gl(sb.src(i, rrow + 2 * i, R), smem + PP_T + piece0 + i * 1024);
+        issue(sa, i, smem + piece0 + i * 1024);
+        issue(sb, i, smem + PP_T + piece0 + i * 1024);
     }
     sa.advance();
     sb.advance();
-    rrow += 64;
+    r0 += 64;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR();
     if (wr == 1) PP_BAR();
 
     // phases of a K-tile: (m-half 0, k 0..31) (m-half 1, k 0..31) (m-half 0, k 32..63) (m-half 1, k 32..63);
     // 16 MFMAs each; fragment loads 8 / 4 / 8 / 4, prefetch issue 4 / 4 / 0 / 0, pointer update in the last
-    bf16x8 fa[4], fb[4];
+    TrFrag fa[4], fb[4];
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lds_u8 *)smem + rbase;
     for (int t = 0; t < nt; ++t) {
-        const unsigned char *cur = smem + (t & 1) * PP_BUF + rbase;
+        const unsigned cur = lds0 + (t & 1) * PP_BUF;
         unsigned char *nxt = smem + ((t + 1) & 1) * PP_BUF + piece0;
         const bool pf = t + 1 < nt;
         // ---- phase 0
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = lds_tr(cur + bchunk + ((j << 5) ^ keyoffb));
+        for (int j = 0; j < 4; ++j) lds_tr(fb[j], cur + bchunk + ((j << 5) ^ keyoffb));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + ((i << 5) ^ keyoff));
+        for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + ((i << 5) ^ keyoff));
         if (pf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gl(sa.src(i, rrow + 2 * i, R), nxt + i * 1024);
+            for (int i = 0; i < 4; ++i) issue(sa, i, nxt + i * 1024);
         }
         PP_BAR();
         TN_MFMA(0, 0);
         PP_BAR();
         // ---- phase 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + (((4 + i) << 5) ^ keyoff));
+        for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + (((4 + i) << 5) ^ keyoff));
         if (pf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gl(sb.src(i, rrow + 2 * i, R), nxt + PP_T + i * 1024);
+            for (int i = 0; i < 4; ++i) issue(sb, i, nxt + PP_T + i * 1024);
         }
         PP_BAR();
         TN_MFMA(1, 0);
         PP_BAR();
         // ---- phase 2
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = lds_tr(cur + bchunk + ((j << 5) ^ keyoffb) + 32 * 512);
+        for (int j = 0; j < 4; ++j) lds_tr(fb[j], cur + bchunk + ((j << 5) ^ keyoffb) + 32 * 512);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + ((i << 5) ^ keyoff) + 32 * 512);
+        for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + ((i << 5) ^ keyoff) + 32 * 512);
         PP_BAR();
         TN_MFMA(0, 1);
         PP_BAR();
         // ---- phase 3: the prefetched tile must have landed before the barrier that lets the other
         // group start reading it
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_tr(cur + achunk + (((4 + i) << 5) ^ keyoff) + 32 * 512);
+        for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + (((4 + i) << 5) ^ keyoff) + 32 * 512);
         sa.advance();
         sb.advance();
-        rrow += 64;
+        r0 += 64;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_BAR();
         TN_MFMA(1, 1);
@@ -847,14 +868,22 @@ __global__ __launch_bounds__(256) void pp_keep_mask_kernel(unsigned char *mask, 
         if (n + e < cols) mask[(long long)m * cols + n + e] = (!thr || keep[e]) ? 1 : 0;
 }
 
-bool tn_operand(const pika_operand_t &o, int extent, TNOperand &t) {
+bool tn_operand(const pika_operand_t &o, int extent, int R, TNOperand &t) {
     if (o.pad || (o.ld & 7) || (o.batch_stride & 7) || (extent & 7) || (reinterpret_cast<uintptr_t>(o.ptr) & 15)) return false;
     const bool one_tap = o.C >= extent;
     if (!one_tap && (o.C & 255)) return false;
     const int taps = one_tap ? 1 : (extent + o.C - 1) / o.C;
     if (taps > 1 && (long long)(o.rows_per_batch - 1) * o.stride + (long long)(taps - 1) * o.dil >= o.t_in) return false;
+    // the kernel's stager: at most one batch boundary inside a 64-row K-tile, batches laid out one after the other
+    const long long row = (long long)o.stride * o.ld;
+    long long batch = o.batch_stride;
+    if (R <= o.rows_per_batch) batch = (long long)o.rows_per_batch * row;   // one batch: its stride is never used
+    {
+        const long long wrap = batch - (long long)o.rows_per_batch * row;
+        if (o.rows_per_batch < 64 || wrap < 0 || wrap >= (1LL << 29) || row >= (1LL << 28)) return false;
+    }
     t.ptr = static_cast<const __bf16 *>(o.ptr);
-    t.batch = o.batch_stride; t.row = (long long)o.stride * o.ld; t.rpb = o.rows_per_batch;
+    t.batch = batch; t.row = row; t.rpb = o.rows_per_batch;
     t.width = extent; t.C = one_tap ? (1 << 30) : o.C; t.tap_stride = (long long)o.dil * o.ld;
     return true;
 }
@@ -864,7 +893,7 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
     if (bias || flags || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15)) return PIKA_NOT_APPLICABLE;
     if (M < 192 || N < 192 || R < 512) return PIKA_NOT_APPLICABLE;
     TNArgs P{};
-    if (!tn_operand(*A, M, P.A) || !tn_operand(*B, N, P.B)) return PIKA_NOT_APPLICABLE;
+    if (!tn_operand(*A, M, R, P.A) || !tn_operand(*B, N, R, P.B)) return PIKA_NOT_APPLICABLE;
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = (R + 63) / 64;
     int split = 1;
     long long best = -1;
