@@ -595,8 +595,11 @@ __device__ inline bf16x8 tr_join(const TrFrag &f) {
 
 // Source addresses of one operand's pieces: a scalar base (first reduction row of the K-tile being fetched) that
 // advances by 64 rows per K-tile, plus 32-bit lane offsets that never change.  Piece i of a wave = reduction rows
-// 2 * (wave * 4 + i), + 1 of the K-tile; a row that runs past the end of its batch (rpb >= 64: at most one batch
+// tn_piece_row(wave, i), + 1 of the K-tile; a row that runs past the end of its batch (rpb >= 64: at most one batch
 // boundary inside a K-tile) adds `wrap`.  All loop arithmetic is scalar; a load is global_load_lds v_off, s[base].
+// first of the two reduction rows of piece i of a wave: pieces 0, 1 lie in rows 0..31 of the K-tile, 2, 3 in rows 32..63
+__device__ inline int tn_piece_row(int wave, int i) { return (i >> 1) * 32 + wave * 4 + (i & 1) * 2; }
+
 struct TNStager {
     const char *base;        // row R0 of the K-tile, column block c0
     unsigned lo[2];          // lane offset for even / odd pieces: swizzled 16-byte column chunk + (lane >> 5) rows
@@ -615,7 +618,7 @@ struct TNStager {
         base = reinterpret_cast<const char *>(o.ptr + (long long)b0 * o.batch + (long long)t0 * o.row + coff);
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
-            const int key = (2 * par + (lane >> 5)) | ((wave & 1) << 2);   // key(row) = (row & 3) | ((row >> 3) & 1) << 2
+            const int key = (2 * par + (lane >> 5)) | (((wave >> 1) & 1) << 2);   // key(row) = (row & 3) | ((row >> 3) & 1) << 2
             const int g16 = lane & 31, q = (g16 >> 1) ^ key;               // 32-byte chunk, swizzled
             // columns past the operand width feed output rows/columns that are never stored: re-read
             // the last valid chunk instead of running off the row
@@ -626,7 +629,7 @@ struct TNStager {
     // piece i of wave `wave` (scalar); `full` = all 64 rows of the K-tile exist (else rows >= R read zeros, for BOTH
     // operands: 0 x garbage could be NaN)
     __device__ inline const char *src(int i, int wave, int lane, bool full, int r0, int R) const {
-        const int row = 2 * (wave * 4 + i);
+        const int row = tn_piece_row(wave, i);
         const char *sb = base + (long long)row * rowb;
         const unsigned off = lo[i & 1] + ((lane >> 5) >= rpb - t0 - row ? wrapb : 0u);
         if (full) return sb + off;
@@ -674,9 +677,13 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
     auto gl = [&](const char *p, unsigned char *dst) {
         __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
     };
-    auto issue = [&](const TNStager &st, int i, unsigned char *dst) {
+    // piece i of an operand's K-tile -> its two rows of the [64][512 B] image (`img` = buffer + 0 / PP_T)
+    auto issue = [&](const TNStager &st, int i, unsigned char *img) {
+        unsigned char *dst = img + tn_piece_row(wave, i) * 512;
+        __builtin_amdgcn_sched_barrier(0);
         if (r0 + 64 <= R) gl(st.src(i, wave, lane, true, r0, R), dst);
         else gl(st.src(i, wave, lane, false, r0, R), dst);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // transpose-read addressing: lane (g, i16 = 4j + c) supplies row kk*32 + g*8 + j (+4 for the second
@@ -693,35 +700,49 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // prologue: K-tile 0 in full and the first two A pieces of the K-tile behind it; the stagers stay on that one
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        issue(sa, i, smem + piece0 + i * 1024);
-        issue(sb, i, smem + PP_T + piece0 + i * 1024);
+        issue(sa, i, smem);
+        issue(sb, i, smem + PP_T);
     }
+    int x_kt = 1;   // the stagers' K-tile (the fetch cursor)
     sa.advance();
     sb.advance();
     r0 += 64;
+    if (x_kt < nt) {
+        issue(sa, 0, smem + PP_BUF);
+        issue(sa, 1, smem + PP_BUF);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PP_BAR();
     if (wr == 1) PP_BAR();
 
-    // phases of a K-tile: (m-half 0, k 0..31) (m-half 1, k 0..31) (m-half 0, k 32..63) (m-half 1, k 32..63);
-    // 16 MFMAs each; fragment loads 8 / 4 / 8 / 4, prefetch issue 4 / 4 / 0 / 0, pointer update in the last
+    // Phases of a K-tile: (m-half 0, k 0..31) (m-half 1, k 0..31) (m-half 0, k 32..63) (m-half 1, k 32..63); 16 MFMAs
+    // each, fragment loads 8 / 4 / 8 / 4.  Every load segment also issues two 1 KB pieces of the fetch cursor's
+    // K-tile into the buffer read two K-tiles earlier, as soon as both wave groups have retired their reads of
+    // those rows:
+    //   phase 3 of iteration t:   A rows 0..31 of K-tile t+2   (rows 0..31 are last read in phase 1)
+    //   phase 0 of iteration t+1: B rows 0..31
+    //   phase 1 of iteration t+1: A rows 32..63               (rows 32..63 are last read in phase 3 of t)
+    //   phase 2 of iteration t+1: B rows 32..63
+    // Loads are never drained: phase 3 waits for all but the last four (rows 32..63 of the next K-tile) before the
+    // barrier that lets the other group read rows 0..31 of it, phase 1 for all but the last four, which retires
+    // rows 32..63 of THIS K-tile one barrier before phase 2 reads them.
     TrFrag fa[4], fb[4];
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     const unsigned lds0 = (unsigned)(unsigned long long)(lds_u8 *)smem + rbase;
     for (int t = 0; t < nt; ++t) {
         const unsigned cur = lds0 + (t & 1) * PP_BUF;
-        unsigned char *nxt = smem + ((t + 1) & 1) * PP_BUF + piece0;
-        const bool pf = t + 1 < nt;
+        unsigned char *nxt = smem + ((t + 1) & 1) * PP_BUF, *nn = smem + (t & 1) * PP_BUF;
         // ---- phase 0
 #pragma unroll
         for (int j = 0; j < 4; ++j) lds_tr(fb[j], cur + bchunk + ((j << 5) ^ keyoffb));
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + ((i << 5) ^ keyoff));
-        if (pf) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) issue(sa, i, nxt + i * 1024);
+        if (x_kt < nt) {
+            issue(sb, 0, nxt + PP_T);
+            issue(sb, 1, nxt + PP_T);
         }
         PP_BAR();
         TN_MFMA(0, 0);
@@ -729,9 +750,12 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
         // ---- phase 1
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + (((4 + i) << 5) ^ keyoff));
-        if (pf) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) issue(sb, i, nxt + PP_T + i * 1024);
+        if (x_kt < nt) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            issue(sa, 2, nxt);
+            issue(sa, 3, nxt);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         PP_BAR();
         TN_MFMA(1, 0);
@@ -741,17 +765,27 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
         for (int j = 0; j < 4; ++j) lds_tr(fb[j], cur + bchunk + ((j << 5) ^ keyoffb) + 32 * 512);
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + ((i << 5) ^ keyoff) + 32 * 512);
+        if (x_kt < nt) {
+            issue(sb, 2, nxt + PP_T);
+            issue(sb, 3, nxt + PP_T);
+            sa.advance();
+            sb.advance();
+            r0 += 64;
+            ++x_kt;
+        }
         PP_BAR();
         TN_MFMA(0, 1);
         PP_BAR();
-        // ---- phase 3: the prefetched tile must have landed before the barrier that lets the other
-        // group start reading it
+        // ---- phase 3
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_tr(fa[i], cur + achunk + (((4 + i) << 5) ^ keyoff) + 32 * 512);
-        sa.advance();
-        sb.advance();
-        r0 += 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (x_kt < nt) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            issue(sa, 0, nn);
+            issue(sa, 1, nn);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         PP_BAR();
         TN_MFMA(1, 1);
         PP_BAR();
