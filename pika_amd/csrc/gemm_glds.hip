@@ -653,6 +653,8 @@ struct TNStager {
         __builtin_amdgcn_s_setprio(0);                                                              \
     } while (0)
 
+// FULL: the reduction length is a multiple of 64 (no K-tile has rows past the end: no zero-page select per lane)
+template <bool FULL>
 __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int nx = gridDim.x, ntiles = nx * gridDim.y;
@@ -681,8 +683,8 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
     auto issue = [&](const TNStager &st, int i, unsigned char *img) {
         unsigned char *dst = img + tn_piece_row(wave, i) * 512;
         __builtin_amdgcn_sched_barrier(0);
-        if (r0 + 64 <= R) gl(st.src(i, wave, lane, true, r0, R), dst);
-        else gl(st.src(i, wave, lane, false, r0, R), dst);
+        if constexpr (FULL) gl(st.src(i, wave, lane, true, r0, R), dst);
+        else gl(st.src(i, wave, lane, r0 + 64 <= R, r0, R), dst);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -957,12 +959,16 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_tn),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_tn<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_tn<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_pp_tn, dim3((N + 255) / 256, (M + 255) / 256, split), dim3(512), 2 * PP_BUF, s, P);
+    const dim3 grid((N + 255) / 256, (M + 255) / 256, split);
+    if (R & 63) hipLaunchKernelGGL(gemm_pp_tn<false>, grid, dim3(512), 2 * PP_BUF, s, P);
+    else hipLaunchKernelGGL(gemm_pp_tn<true>, grid, dim3(512), 2 * PP_BUF, s, P);
     if (P.ws) {
         const long long n4 = (long long)M * (N >> 2);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, P.ws, C, ldc, M, N, split);
