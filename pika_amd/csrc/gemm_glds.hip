@@ -185,7 +185,8 @@ __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast
 // EPI 0: C f32 = act(A B^T + bias).   EPI 1: out16 bf16 = dropout(act(A B^T + bias)).
 // EPI 2: out16 bf16 = scale * (A B^T) where aux > 0, else 0  (ReLU + dropout backward in one mask).
 // EPI 3: C f32 = dropout(A B^T + bias) + res  (projection + residual dropout + residual add).
-template <int EPI>
+// BOUNDS: A is a padded time-delay view (rows whose source time leaves the signal read the zero page)
+template <int EPI, bool BOUNDS>
 __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int M = P.M, N = P.N;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         }
     };
     const char *zp = reinterpret_cast<const char *>(pp_zero_page) + (lane & 7) * 16;
-    const int bounds = P.a_bounds;
+    constexpr bool bounds = BOUNDS;
     const int piece0 = wave * 4 * 1024;
     auto gl = [&](const char *p, unsigned char *dst) {
         __builtin_amdgcn_sched_barrier(0);
@@ -846,8 +847,11 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
     if (!pp_offsets_fit(P)) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
+        if constexpr (EPI <= 1)   // padded time-delay operands only reach the plain epilogues (pika_gemm_nt)
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -866,7 +870,12 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
         return cus & ~7;
     }();
     const int grid = (wgs >= 8 && nt > wgs) ? (wgs & ~7) : (int)nt;
-    hipLaunchKernelGGL(gemm_pp<EPI>, dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
+    if (Q.a_bounds) {
+        if constexpr (EPI <= 1) hipLaunchKernelGGL((gemm_pp<EPI, true>), dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
+        else return PIKA_EINVAL;
+    } else {
+        hipLaunchKernelGGL((gemm_pp<EPI, false>), dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
+    }
     return (int)hipGetLastError();
 }
 
