@@ -171,7 +171,10 @@ def test_time_delay_weight_gradient_in_place(hip_device):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1, 8, 64), (257, 132, 64), (1000, 5000, 1024),
-                                   (777, 1024, 5056)])
+                                   (777, 1024, 5056),
+                                   # more output tiles than CUs: persistent workgroups walk several tiles each, the fetch
+                                   # cursor crosses tile boundaries after 3 / 1 / 2 K-tiles, ragged edge tiles
+                                   (4300, 4000, 192), (4300, 4000, 64), (2100, 8200, 128)])
 def test_direct_to_lds_bf16_nt(hip_device, M, N, K):
     """pika_gemm_bf16_nt (gemm_glds.hip): operands are exactly representable bf16, so the only error
     against the fp64 product is fp32 accumulation."""
@@ -220,6 +223,7 @@ def test_ping_pong_kernel_routes(hip_device, taps, dil, stride, T, C, N, B):
 
 @pytest.mark.parametrize("Bn,T,C,N,taps,dil,stride,ldpad", [
     (4, 300, 256, 512, 3, 3, 1, 0),     # time-delay X, batch wrap inside K-tiles, ragged reduction
+    (4, 310, 256, 512, 3, 3, 1, 0),     # the same with a reduction of 19 whole K-tiles (the no-zero-page instantiation)
     (5, 200, 256, 264, 1, 1, 1, 24),    # plain X, dY wider than its valid columns (zero page past the width)
     (2, 1100, 512, 1000, 3, 1, 4, 8),   # strided time-delay, output extents not multiples of 256
 ])

@@ -46,9 +46,6 @@ if __name__ == "__main__":
         worker()
     else:
         for t in (sys.argv[1:] or ["0", "256"]):
-            wgs, _, stg = t.partition(":")
-            print("--- wgs %s stagger %s" % (wgs, stg or "auto"), flush=True)
-            env = dict(os.environ, PIKA_GEMM_PP_WGS=wgs)
-            if stg:
-                env["PIKA_GEMM_PP_STAGGER"] = stg
-            subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=env, check=False)
+            print("--- PIKA_GEMM_PP_WGS=%s" % t, flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=dict(os.environ, PIKA_GEMM_PP_WGS=t),
+                           check=False)
