@@ -60,12 +60,20 @@ int pika_rnnt_loss_forward(const float *log_probs, const int *labels,
 /* Backward: one streaming pass that writes the dense gradient tensor.
  * `grad_costs` (B,) f32 scales utterance n's gradient (autograd's grad_output);
  * NULL means all ones.  `workspace` must be the buffer filled by the matching
- * forward call (same B,T,U1 and lengths). */
+ * forward call (same B,T,U1 and lengths).
+ * grads == NULL: only the per-row metadata (the at most two non-zeros of every V-row, already scaled by
+ * grad_costs) is left in `workspace`; pika_rnnt_loss_dense_grads writes the dense tensor from it later, and
+ * pika_rnnt_dlogits_compact_bf16 needs nothing else. */
 int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths,
                             const int *labels_lengths,
                             int B, int T, int U1, int V, int blank,
                             const float *grad_costs, const void *workspace,
                             float *grads, void *stream);
+
+/* The streaming pass of pika_rnnt_loss_backward on its own: dense (B,T,U1,V) gradient from the row metadata a
+ * pika_rnnt_loss_backward call (with or without `grads`) left in `workspace`. */
+int pika_rnnt_loss_dense_grads(const void *workspace, int B, int T, int U1, int V, int blank,
+                               float *grads, void *stream);
 
 /* warp_rnnt-shaped one-shot: forward + backward with unit grad_costs. */
 int pika_rnnt_loss_fwd_bwd(const float *log_probs, const int *labels,
@@ -82,8 +90,8 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
 /* For a producer that computed log_probs = log_softmax(scale * logits) itself (the joint network,
  * trainer/model/transducer.py:108-111): d(loss)/d(logits) as a bf16 matrix (rows = B*T*U1, pitch ld_out,
  * columns [V, ld_out) zero) straight from the two non-zeros per row that the matching
- * pika_rnnt_loss_backward call left in `workspace` -- the dense gradient (B,T,U1,V) is written by that
- * call as the contract demands, but need not be read back:
+ * pika_rnnt_loss_backward call left in `workspace` -- the dense gradient (B,T,U1,V) need not be read back,
+ * nor even written (grads == NULL above):
  *   out[r, v] = scale * (grad[r, v] - exp(log_probs[r, v]) * sum_v' grad[r, v']).
  * colsum (V floats, may be NULL) receives sum_r out[r, :] before the bf16 rounding: the bias gradient of the
  * layer that produced the logits, without another pass over `out`.

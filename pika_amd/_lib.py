@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -17,6 +17,7 @@ SIGNATURES = {
     "pika_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
     "pika_rnnt_loss_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pika_rnnt_loss_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pika_rnnt_loss_dense_grads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "pika_rnnt_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _ll, _vp]),

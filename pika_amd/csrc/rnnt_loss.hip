@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__
 
 extern "C" {
 
-int pika_amd_abi_version(void) { return 4; }
+int pika_amd_abi_version(void) { return 5; }
 
 size_t pika_rnnt_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024) return 0;
@@ -700,18 +700,10 @@ int pika_rnnt_loss_forward(const float *log_probs, const int *labels, const int 
     return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
 }
 
-int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths, const int *labels_lengths,
-                            int B, int T, int U1, int V, int blank, const float *grad_costs,
-                            const void *workspace, float *grads, void *stream) {
-    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
-    if (!frames_lengths || !labels_lengths || !workspace || !grads) return PIKA_EINVAL;
-    if (U1 > 1 && !labels) return PIKA_EINVAL;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+namespace {
+// the streaming pass: dense (B,T,U1,V) gradient from the row metadata in the workspace
+int write_dense_grads(const Lattice &L, int B, int T, int U1, int V, int blank, float *grads, hipStream_t s) {
     const size_t nrows = (size_t)B * T * U1;
-    hipLaunchKernelGGL(rnnt_rowmeta_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s,
-                       labels, frames_lengths, labels_lengths, B, T, U1, V, grad_costs, L.lpb, L.lpe,
-                       L.alpha, L.beta, L.off_a, L.off_b, L.ll, L.Wp, L.D, L.meta);
     const size_t n = nrows * (size_t)V;
     const bool vec4 = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(grads) & 15) == 0);
     if (vec4) {
@@ -734,6 +726,31 @@ int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths, const 
                            dim3(256), 0, s, L.meta, n, V, blank, grads);
     }
     return (int)hipGetLastError();
+}
+}  // namespace
+
+int pika_rnnt_loss_backward(const int *labels, const int *frames_lengths, const int *labels_lengths,
+                            int B, int T, int U1, int V, int blank, const float *grad_costs,
+                            const void *workspace, float *grads, void *stream) {
+    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
+    if (!frames_lengths || !labels_lengths || !workspace) return PIKA_EINVAL;
+    if (U1 > 1 && !labels) return PIKA_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+    const size_t nrows = (size_t)B * T * U1;
+    hipLaunchKernelGGL(rnnt_rowmeta_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s,
+                       labels, frames_lengths, labels_lengths, B, T, U1, V, grad_costs, L.lpb, L.lpe,
+                       L.alpha, L.beta, L.off_a, L.off_b, L.ll, L.Wp, L.D, L.meta);
+    if (!grads) return (int)hipGetLastError();   // row metadata only (pika_rnnt.h)
+    return write_dense_grads(L, B, T, U1, V, blank, grads, s);
+}
+
+int pika_rnnt_loss_dense_grads(const void *workspace, int B, int T, int U1, int V, int blank, float *grads,
+                               void *stream) {
+    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
+    if (!workspace || !grads) return PIKA_EINVAL;
+    const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+    return write_dense_grads(L, B, T, U1, V, blank, grads, static_cast<hipStream_t>(stream));
 }
 
 int pika_rnnt_loss_fwd_bwd(const float *log_probs, const int *labels, const int *frames_lengths,

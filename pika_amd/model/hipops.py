@@ -405,15 +405,26 @@ class JointOutFn(torch.autograd.Function):
         N, K = weight.shape
         M = h2.shape[0]
         Np = (N + 63) & ~63
-        if not g.is_contiguous():
-            g = g.contiguous()
+        from ..rnnt import LazyDenseGrad
+        compact = None
+        if isinstance(g, LazyDenseGrad):
+            # the loss' own gradient, never written: its non-zeros are in the loss workspace.  (Once something has
+            # made it dense, or when it does not fit the compact kernel, it is an ordinary tensor from here on.)
+            if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= 5120:
+                compact = g.compact
+            else:
+                g = g.dense()
+        if compact is None:
+            if not g.is_contiguous():
+                g = g.contiguous()
+            c = getattr(g, "_pika_compact", None)
+            if c is not None and c.matches(g) and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= 5120:
+                compact = c
         dh = dw = db = None
-        with torch.cuda.device(g.device):
-            dl = torch.empty((M, Np), dtype=torch.bfloat16, device=g.device)
+        with torch.cuda.device(lp.device):
+            dl = torch.empty((M, Np), dtype=torch.bfloat16, device=lp.device)
             db_fused = None
-            compact = getattr(g, "_pika_compact", None)
-            if (compact is not None and compact.matches(g) and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape)
-                    and N <= 5120):
+            if compact is not None:
                 # g is the RNN-T loss' own dense gradient, untouched: take its two non-zeros per row from the
                 # loss workspace instead of reading 4 bytes x B*T*U*V back (include/pika_rnnt.h)
                 B_, T_, U1_, V_, blank = compact.dims

@@ -242,7 +242,11 @@ def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
         pg = linear(pred, wgp.contiguous())
         h = GateFn.apply(e1, p1, eg, pg)
         if log_softmax and joint_out_ok(h, fc2.weight):
-            return JointOutFn.apply(h, fc2.weight, fc2.bias, scale)
+            lp = JointOutFn.apply(h, fc2.weight, fc2.bias, scale)
+            # its producer can build d(logits) from the loss workspace: the loss may hand back its gradient as a
+            # tensor that is only written if something else looks at it (pika_amd.rnnt.LazyDenseGrad)
+            lp._pika_lazy_grad_ok = True
+            return lp
         out = linear(h, fc2.weight, fc2.bias)
         if log_softmax:
             out = LogSoftmaxFn.apply(out, scale)

@@ -13,7 +13,9 @@ sums (and in the MBR script pre-multiplies by a float, train_transducer_mbr_bmuf
 MI355X-first split: forward runs only gather + alpha/beta (~0.1 ms) and keeps the lattice in a
 34 MB workspace; the dense (B,T,U1,V) gradient is written ONCE, in backward, already scaled
 by autograd's grad_output -- warp_rnnt instead materialises it in forward and multiplies it
-again in backward (3 extra passes over 32 GB at the benchmark shape).
+again in backward (3 extra passes over 32 GB at the benchmark shape).  When log_probs came out of
+this package's own joint network, the gradient goes back as a LazyDenseGrad: the joint's backward
+reads the loss workspace and the dense tensor is written only if anything else touches it.
 """
 import torch
 
@@ -90,10 +92,59 @@ class CompactGrad(object):
         return g.data_ptr() == self.ptr and g._version == self.version and tuple(g.shape) == tuple(self.dims[:4])
 
 
+def _lazy_enabled():
+    import os
+    return os.environ.get("PIKA_RNNT_LAZY_GRAD", "1") != "0"
+
+
+class LazyDenseGrad(torch.Tensor):
+    """The loss' (B,T,U1,V) gradient as a tensor that is only written when somebody looks at it.
+
+    The backward of the loss always leaves the at most two non-zeros of every V-row in its workspace.  A
+    producer that computed log_probs itself and registered for it (`log_probs._pika_lazy_grad_ok = True`, set
+    by pika_amd.model.ops.joint on the output of JointOutFn) gets this object instead of 7.8 GB of mostly zeros;
+    JointOutFn.backward recognises it and builds d(logits) from the workspace (`compact`).  ANY other use -- an
+    aten op on it, autograd accumulating a second gradient into log_probs, a hook, `.grad` of a leaf -- goes
+    through __torch_dispatch__, which first writes the dense tensor (`pika_rnnt_loss_dense_grads`, the very
+    streaming pass the eager path runs) and then runs the op on it: values are identical in every case."""
+
+    @staticmethod
+    def __new__(cls, compact, labels, frames_lengths, labels_lengths):
+        B, T, U1, V, _ = compact.dims
+        r = torch.Tensor._make_wrapper_subclass(cls, (B, T, U1, V), dtype=torch.float32, device=compact.ws.device,
+                                                requires_grad=False)
+        r.compact = compact
+        r._keep = (labels, frames_lengths, labels_lengths)   # the metadata kernel has run; kept for symmetry of lifetimes
+        r._dense = None
+        return r
+
+    def dense(self):
+        if self._dense is None:
+            B, T, U1, V, blank = self.compact.dims
+            ws = self.compact.ws
+            with torch.cuda.device(ws.device):
+                g = torch.empty((B, T, U1, V), dtype=torch.float32, device=ws.device)
+                with _timed("bwd"):
+                    _lib.check(_lib.lib().pika_rnnt_loss_dense_grads(_ptr(ws), B, T, U1, V, blank, _ptr(g), _stream()),
+                               "pika_rnnt_loss_dense_grads")
+            self._dense = g
+        return self._dense
+
+    def __repr__(self):
+        return "LazyDenseGrad(shape=%s, written=%s)" % (tuple(self.shape), self._dense is not None)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        un = lambda t: t.dense() if isinstance(t, LazyDenseGrad) else t   # noqa: E731
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+
 class _RNNTLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0):
         _check_inputs(log_probs, labels, frames_lengths, labels_lengths, blank)
+        ctx.lazy = bool(getattr(log_probs, "_pika_lazy_grad_ok", False)) and _lazy_enabled()
         lib = _lib.lib()
         lp = log_probs.contiguous()
         labels = labels.contiguous()
@@ -118,6 +169,14 @@ class _RNNTLossFn(torch.autograd.Function):
         B, T, U1, V, blank = ctx.dims
         lib = _lib.lib()
         gc = grad_costs.to(torch.float32).contiguous()
+        if ctx.lazy:
+            with torch.cuda.device(ws.device):
+                _lib.check(lib.pika_rnnt_loss_backward(
+                    _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
+                    _ptr(gc), _ptr(ws), None, _stream()), "pika_rnnt_loss_backward")
+            compact = CompactGrad.__new__(CompactGrad)
+            compact.ws, compact.dims, compact.ptr, compact.version = ws, (B, T, U1, V, blank), 0, 0
+            return LazyDenseGrad(compact, labels, frames_lengths, labels_lengths), None, None, None, None
         with torch.cuda.device(ws.device):
             grads = torch.empty((B, T, U1, V), dtype=torch.float32, device=ws.device)
             with _timed("bwd"):

@@ -128,3 +128,65 @@ def test_joint_backward_uses_compact_rnnt_gradient(hip_device):
         assert (a - d).abs().max().item() < 3e-3 * d.abs().max().item()
     finally:
         G.PRECISION = old
+
+
+def test_lazy_rnnt_gradient_is_the_dense_gradient_whenever_anything_looks(hip_device, monkeypatch):
+    """pika_amd.rnnt.LazyDenseGrad: with log_probs tagged by the joint (`_pika_lazy_grad_ok`) the loss hands its
+    gradient back unwritten and the joint backward builds d(logits) from the loss workspace -- bit-identical
+    parameter gradients to the eager compact path.  A hook, a second consumer of log_probs or retain_grad() make
+    autograd touch the tensor: it is then written by the same streaming pass and every value equals the eager run."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
+    from pika_amd.rnnt import RNNTLoss, LazyDenseGrad
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(5)
+        B, T, U, H, V = 3, 9, 5, 64, 48
+        h = (torch.randn(B, T, U + 1, H, generator=g) * 0.5).bfloat16().to(hip_device)
+        w = (torch.randn(V, H, generator=g) * 0.3).to(hip_device)
+        b = (torch.randn(V, generator=g) * 0.1).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        tl = torch.tensor([T, T - 2, T - 4], dtype=torch.int32, device=hip_device)
+        ul = torch.tensor([U, U - 1, U - 3], dtype=torch.int32, device=hip_device)
+        scale = torch.tensor([1.0, 0.5, 2.0], device=hip_device)          # per-utterance grad_output, as in the MBR script
+
+        def run(lazy, mode):
+            monkeypatch.setenv("PIKA_RNNT_LAZY_GRAD", "1" if lazy else "0")
+            hh, ww, bb = (t.clone().requires_grad_(True) for t in (h, w, b))
+            lp = JointOutFn.apply(hh, ww, bb, 1.0)
+            lp._pika_lazy_grad_ok = True                                   # what pika_amd.model.ops.joint does
+            seen = []
+            if mode == "hook":
+                lp.register_hook(lambda t: (seen.append(type(t)), t * 1.0)[1])
+            if mode == "retain":
+                lp.retain_grad()
+            loss = (RNNTLoss().apply(lp, labels, tl, ul) * scale).sum()
+            if mode == "second":
+                loss = loss + 0.25 * (lp * lp).sum()
+            loss.backward()
+            return (hh.grad.float(), ww.grad, bb.grad, None if mode != "retain" else lp.grad, seen)
+
+        hits = JointOutFn.compact_hits
+        eager = run(False, "plain")
+        lazy = run(True, "plain")
+        assert JointOutFn.compact_hits == hits + 2                        # both took the workspace path
+        for a, d in zip(lazy[:2], eager[:2]):
+            assert torch.equal(a, d)
+        # (the bias gradient is summed with float atomics inside the d(logits) kernel: equal up to summation order)
+        assert torch.allclose(lazy[2], eager[2], rtol=1e-5, atol=1e-6 * eager[2].abs().max().item())
+        for mode in ("hook", "second", "retain"):
+            e, l = run(False, mode), run(True, mode)
+            if mode == "retain":
+                # the written lazy gradient goes down the dense d(logits) kernel (it could have been edited in place);
+                # the eager tensor is still recognised as the loss' own: same values up to the bf16 rounding of db
+                assert type(l[3]) is torch.Tensor and torch.equal(l[3], e[3])
+                for a, d in zip(l[:2], e[:2]):
+                    assert torch.allclose(a, d, rtol=1e-5, atol=1e-6 * d.abs().max().item())
+                assert (l[2] - e[2]).abs().max().item() < 3e-3 * e[2].abs().max().item()
+                continue
+            for a, d in zip(l[:3], e[:3]):
+                assert torch.equal(a, d), mode
+            if mode == "hook":
+                assert l[4] == [LazyDenseGrad] and e[4] == [torch.Tensor]
+    finally:
+        G.PRECISION = old
