@@ -95,9 +95,11 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
  *   out[r, v] = scale * (grad[r, v] - exp(log_probs[r, v]) * sum_v' grad[r, v']).
  * colsum (V floats, may be NULL) receives sum_r out[r, :] before the bf16 rounding: the bias gradient of the
  * layer that produced the logits, without another pass over `out`.
+ * lse (rows floats) non-NULL: `log_probs` holds the RAW logits and lse their per-row log-sum-exp (as written by
+ * pika_rnnt_fused_forward) -- the log-probabilities never have to exist (scale must then be 1).
  * V % 4 == 0, V <= 5120, ld_out % 4 == 0. */
-int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace, int B, int T, int U1,
-                                   int V, int blank, void *out, long long ld_out, float scale,
+int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, const void *workspace, int B, int T,
+                                   int U1, int V, int blank, void *out, long long ld_out, float scale,
                                    float *colsum, void *stream);
 
 /* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces

@@ -21,7 +21,7 @@ SIGNATURES = {
     "pika_rnnt_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
-    "pika_rnnt_dlogits_compact_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
+    "pika_rnnt_dlogits_compact_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
     "pika_rnnt_export_lattice": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     # include/pika_bmuf.h
     "pika_bmuf_delta": (_i, [_vp, _vp, _vp, _sz, _vp]),

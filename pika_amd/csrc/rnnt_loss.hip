@@ -503,7 +503,8 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
                                                                    __bf16 *__restrict__ out, long long rows,
                                                                    int V, long long ld_out, int blank,
                                                                    float scale, int rpw,
-                                                                   float *__restrict__ colsum) {
+                                                                   float *__restrict__ colsum,
+                                                                   const float *__restrict__ lse) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = V >> 2, o4 = (int)(ld_out >> 2);
     const long long r0 = ((long long)blockIdx.x * 4 + wave) * rpw;
     f32x4 cs[COLSUM ? CQ : 1];
@@ -514,8 +515,13 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
     for (long long r = r0; r < r0 + rpw && r < rows; ++r) {
         const RowMeta m = meta[r];
         const float s = m.gb + m.ge;
+        const float l = lse ? lse[r] : 0.f;   // `lp` holds raw logits: log-prob = logit - log-sum-exp of its row
         const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * V);
         cbf16x4 *orow = reinterpret_cast<cbf16x4 *>(out + r * ld_out);
+        // rows outside an utterance's sub-lattice carry no gradient and, when `lp` holds raw logits, no defined
+        // log-sum-exp: their exp() must not reach the output (inf * 0).  The row is fetched regardless -- making
+        // the loads wait for the metadata would serialise two memory latencies per row.
+        const bool live = (m.gb != 0.f) || (m.ge != 0.f);
         f32x4 v[CQ];
 #pragma unroll
         for (int q = 0; q < CQ; ++q)
@@ -524,13 +530,15 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
         for (int q = 0; q < CQ; ++q) {
             const int i = lane + q * 64;
             if (i < c4) {
-                f32x4 o;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int col = 4 * i + e;
-                    float g = col == blank ? m.gb : 0.f;
-                    if (col == m.ye) g += m.ge;
-                    o[e] = scale * (g - __expf(v[q][e]) * s);
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = 4 * i + e;
+                        float g = col == blank ? m.gb : 0.f;
+                        if (col == m.ye) g += m.ge;
+                        o[e] = scale * (g - __expf(v[q][e] - l) * s);
+                    }
                 }
                 orow[i] = __builtin_convertvector(o, cbf16x4);
                 if constexpr (COLSUM) cs[q] += o;
@@ -776,8 +784,8 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
     return (int)hipGetLastError();
 }
 
-int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace, int B, int T, int U1,
-                                   int V, int blank, void *out, long long ld_out, float scale,
+int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, const void *workspace, int B, int T,
+                                   int U1, int V, int blank, void *out, long long ld_out, float scale,
                                    float *colsum, void *stream) {
     if (!log_probs || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
         blank >= V)
@@ -796,11 +804,11 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const void *workspace
         const long long per_block = 4LL * rpw;
         hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<true>, dim3((unsigned)((rows + per_block - 1) / per_block)),
                            dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
-                           scale, rpw, colsum);
+                           scale, rpw, colsum, lse);
     } else {
         hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                            log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
-                           static_cast<float *>(nullptr));
+                           static_cast<float *>(nullptr), lse);
     }
     return (int)hipGetLastError();
 }

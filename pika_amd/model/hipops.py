@@ -386,17 +386,24 @@ class JointOutFn(torch.autograd.Function):
     compact_hits = 0   # times the backward used the loss' compact gradient (tests / diagnostics)
 
     @staticmethod
-    def forward(ctx, h, weight, bias, scale):
+    def forward(ctx, h, weight, bias, scale, lazy=False):
         N, K = weight.shape
         h2 = h.reshape(-1, K)
         out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
         G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
+        ctx.scale = float(scale)
+        ctx.has_bias = bias is not None
+        ctx.state = None
+        ctx.save_for_backward(h2, weight, out)
+        if lazy and out.dim() == 4:
+            # the log-softmax pass is deferred until something needs the values (pika_amd.rnnt.LazyLogProbs);
+            # `out` is normalised in place by a raw kernel call, which autograd's version counter does not see
+            from ..rnnt import LazyLogProbs, LogitsState
+            ctx.state = LogitsState(out, scale)
+            return LazyLogProbs(ctx.state)
         with torch.cuda.device(h.device):
             _lib.check(_lib.lib().pika_log_softmax_rows(out.data_ptr(), h2.shape[0], N, N, float(scale),
                                                         _stream()), "pika_log_softmax_rows")
-        ctx.scale = float(scale)
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(h2, weight, out)
         return out
 
     @staticmethod
@@ -407,13 +414,17 @@ class JointOutFn(torch.autograd.Function):
         Np = (N + 63) & ~63
         from ..rnnt import LazyDenseGrad
         compact = None
+        lse = None
         if isinstance(g, LazyDenseGrad):
             # the loss' own gradient, never written: its non-zeros are in the loss workspace.  (Once something has
             # made it dense, or when it does not fit the compact kernel, it is an ordinary tensor from here on.)
             if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= 5120:
                 compact = g.compact
+                lse = g.lse     # the loss read raw logits: `lp` still holds them (or log-probs and lse == 0)
             else:
                 g = g.dense()
+        if lse is None and ctx.state is not None:
+            ctx.state.to_log_probs()       # every other path below needs the log-probabilities in `lp`
         if compact is None:
             if not g.is_contiguous():
                 g = g.contiguous()
@@ -431,7 +442,8 @@ class JointOutFn(torch.autograd.Function):
                 want_db = ctx.has_bias and ctx.needs_input_grad[2]
                 db_fused = torch.empty(N, dtype=torch.float32, device=dl.device) if want_db else None
                 _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16(
-                    lp.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_, blank, dl.data_ptr(), Np, ctx.scale,
+                    lp.data_ptr(), None if lse is None else lse.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_,
+                    blank, dl.data_ptr(), Np, ctx.scale,
                     None if db_fused is None else db_fused.data_ptr(), _stream()), "pika_rnnt_dlogits_compact_bf16")
                 JointOutFn.compact_hits += 1
             else:
@@ -453,7 +465,10 @@ class JointOutFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=dl.device)
                 _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
                            "pika_colsum_bf16")
-        return dh, dw, db, None
+        # the node outlives its backward for as long as anything holds the graph (a returned loss): do not keep the
+        # 7.8 GB logits buffer alive through it
+        ctx.state = None
+        return dh, dw, db, None, None
 
 
 def attention_ok(q, k, v, heads, mask):

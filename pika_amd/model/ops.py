@@ -6,6 +6,8 @@ CPU tensors (module-structure tests, gloo plumbing) use the equivalent torch ops
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -242,9 +244,11 @@ def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
         pg = linear(pred, wgp.contiguous())
         h = GateFn.apply(e1, p1, eg, pg)
         if log_softmax and joint_out_ok(h, fc2.weight):
-            lp = JointOutFn.apply(h, fc2.weight, fc2.bias, scale)
-            # its producer can build d(logits) from the loss workspace: the loss may hand back its gradient as a
-            # tensor that is only written if something else looks at it (pika_amd.rnnt.LazyDenseGrad)
+            from ..rnnt import _lazy_enabled
+            # the log-softmax pass runs only if something other than this package's RNN-T loss needs the values
+            # (pika_amd.rnnt.LazyLogProbs), and the loss may hand back its gradient as a tensor that is only written
+            # if something other than JointOutFn looks at it (pika_amd.rnnt.LazyDenseGrad)
+            lp = JointOutFn.apply(h, fc2.weight, fc2.bias, scale, _lazy_enabled() and os.environ.get("PIKA_LAZY_LOGPROBS", "1") != "0")
             lp._pika_lazy_grad_ok = True
             return lp
         out = linear(h, fc2.weight, fc2.bias)

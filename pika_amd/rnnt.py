@@ -116,6 +116,7 @@ class LazyDenseGrad(torch.Tensor):
         r.compact = compact
         r._keep = (labels, frames_lengths, labels_lengths)   # the metadata kernel has run; kept for symmetry of lifetimes
         r._dense = None
+        r.lse = None
         return r
 
     def dense(self):
@@ -140,25 +141,94 @@ class LazyDenseGrad(torch.Tensor):
         return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
 
 
+class LogitsState(object):
+    """Shared by a LazyLogProbs, the joint node that made it and the losses that consumed it: the (B,T,U1,V)
+    buffer, whether it still holds raw logits, and the log-sum-exp vectors computed from it while it did."""
+
+    __slots__ = ("buf", "scale", "raw", "lse")
+
+    def __init__(self, buf, scale):
+        self.buf, self.scale, self.raw, self.lse = buf, float(scale), True, []
+
+    def to_log_probs(self):
+        """In place: buf <- log_softmax(scale * buf).  Every log-sum-exp taken from the raw logits becomes 0, so a
+        consumer that subtracts it (pika_rnnt_dlogits_compact_bf16) reads the same log-probabilities either way."""
+        if self.raw:
+            B, T, U1, V = self.buf.shape
+            with torch.cuda.device(self.buf.device):
+                _lib.check(_lib.lib().pika_log_softmax_rows(self.buf.data_ptr(), B * T * U1, V, V, self.scale, _stream()),
+                           "pika_log_softmax_rows")
+            for l in self.lse:
+                l.zero_()
+            self.raw = False
+        return self.buf
+
+
+class LazyLogProbs(torch.Tensor):
+    """log_softmax(logits) over the lattice as a tensor whose log-softmax pass only runs if somebody needs the
+    values.  pika_amd.model.hipops.JointOutFn returns it; this module's loss takes the row log-sum-exp and the two
+    log-probs per lattice cell it needs in ONE read of the raw logits (pika_rnnt_fused_forward), and the joint's
+    backward subtracts that log-sum-exp on the fly.  ANY other use -- an aten op, printing, `.float()`, a different
+    loss -- goes through __torch_dispatch__, which first normalises the buffer in place (the same kernel the
+    eager path runs in the forward) and then runs the op on the real log-probabilities."""
+
+    @staticmethod
+    def __new__(cls, state):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(state.buf.shape), dtype=torch.float32,
+                                                device=state.buf.device, requires_grad=False)
+        r.state = state
+        return r
+
+    def dense(self):
+        return self.state.to_log_probs()
+
+    def __repr__(self):
+        return "LazyLogProbs(shape=%s, normalised=%s)" % (tuple(self.shape), not self.state.raw)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        un = lambda t: t.dense() if isinstance(t, LazyLogProbs) else t   # noqa: E731
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+
 class _RNNTLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0):
         _check_inputs(log_probs, labels, frames_lengths, labels_lengths, blank)
         ctx.lazy = bool(getattr(log_probs, "_pika_lazy_grad_ok", False)) and _lazy_enabled()
         lib = _lib.lib()
-        lp = log_probs.contiguous()
         labels = labels.contiguous()
         frames_lengths = frames_lengths.contiguous()
         labels_lengths = labels_lengths.contiguous()
-        B, T, U1, V = lp.shape
-        with torch.cuda.device(lp.device):
-            costs = torch.empty(B, dtype=torch.float32, device=lp.device)
-            ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8,
-                             device=lp.device)
-            with _timed("fwd"):
-                _lib.check(lib.pika_rnnt_loss_forward(
-                    _ptr(lp), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths),
-                    B, T, U1, V, blank, _ptr(costs), _ptr(ws), _stream()), "pika_rnnt_loss_forward")
+        B, T, U1, V = log_probs.shape
+        ctx.lse = None
+        state = log_probs.state if isinstance(log_probs, LazyLogProbs) else None
+        if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= 5120):
+            state = None
+        if state is not None:
+            # raw logits of this package's joint: log-sum-exp + gather in one read, no log-prob tensor
+            x = state.buf
+            with torch.cuda.device(x.device):
+                costs = torch.empty(B, dtype=torch.float32, device=x.device)
+                lse = torch.empty(B * T * U1, dtype=torch.float32, device=x.device)
+                ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=x.device)
+                with _timed("fwd"):
+                    _lib.check(lib.pika_rnnt_fused_forward(
+                        _ptr(x), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
+                        _ptr(costs), _ptr(lse), _ptr(ws), _stream()), "pika_rnnt_fused_forward")
+            state.lse.append(lse)
+            ctx.lse = lse           # not through save_for_backward: to_log_probs() may zero it in place
+        else:
+            lp = log_probs.contiguous()     # (a LazyLogProbs is normalised here)
+            with torch.cuda.device(lp.device):
+                costs = torch.empty(B, dtype=torch.float32, device=lp.device)
+                ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8,
+                                 device=lp.device)
+                with _timed("fwd"):
+                    _lib.check(lib.pika_rnnt_loss_forward(
+                        _ptr(lp), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths),
+                        B, T, U1, V, blank, _ptr(costs), _ptr(ws), _stream()), "pika_rnnt_loss_forward")
         ctx.save_for_backward(labels, frames_lengths, labels_lengths, ws)
         ctx.dims = (B, T, U1, V, blank)
         return costs
@@ -176,7 +246,10 @@ class _RNNTLossFn(torch.autograd.Function):
                     _ptr(gc), _ptr(ws), None, _stream()), "pika_rnnt_loss_backward")
             compact = CompactGrad.__new__(CompactGrad)
             compact.ws, compact.dims, compact.ptr, compact.version = ws, (B, T, U1, V, blank), 0, 0
-            return LazyDenseGrad(compact, labels, frames_lengths, labels_lengths), None, None, None, None
+            lazy = LazyDenseGrad(compact, labels, frames_lengths, labels_lengths)
+            lazy.lse = ctx.lse      # set when the forward read raw logits
+            ctx.lse = None          # (the node may outlive its backward: keep no buffers on it)
+            return lazy, None, None, None, None
         with torch.cuda.device(ws.device):
             grads = torch.empty((B, T, U1, V), dtype=torch.float32, device=ws.device)
             with _timed("bwd"):
