@@ -134,6 +134,12 @@ class LazyDenseGrad(torch.Tensor):
     def __repr__(self):
         return "LazyDenseGrad(shape=%s, written=%s)" % (tuple(self.shape), self._dense is not None)
 
+    def __reduce_ex__(self, proto):
+        return self.dense().__reduce_ex__(proto)
+
+    def __deepcopy__(self, memo):
+        return self.dense().clone()
+
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
         from torch.utils._pytree import tree_map
@@ -184,6 +190,12 @@ class LazyLogProbs(torch.Tensor):
 
     def __repr__(self):
         return "LazyLogProbs(shape=%s, normalised=%s)" % (tuple(self.shape), not self.state.raw)
+
+    def __reduce_ex__(self, proto):     # pickling / torch.save: the real log-probabilities
+        return self.dense().__reduce_ex__(proto)
+
+    def __deepcopy__(self, memo):
+        return self.dense().clone()
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
