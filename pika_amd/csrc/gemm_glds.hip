@@ -1,14 +1,15 @@
-// pika_amd/csrc/gemm_glds.hip -- bf16 x bf16 NT GEMM with direct global->LDS loads for gfx950.
+// pika_amd/csrc/gemm_glds.hip -- bf16 x bf16 GEMMs with direct global->LDS loads (LDS-DMA) for gfx950.
 //
-// C[M,N] f32 = A[M,K] bf16 * B[N,K]^T bf16 (+ bias[n]).  Used where both operands already live in
-// HBM as bf16 (the joint network: hidden h, bf16 weight copies, bf16 d(logits)).  256x128x64 tile,
-// 8 waves; every K-step each wave issues 6 global_load_lds_dwordx4 (1 KiB each) straight into the
-// other LDS buffer -- no VGPR staging, no conversion -- and the 16-byte granule index is XOR-ed
-// with (row & 7) on the SOURCE address (LDS image stays lane-linear, as the instruction
-// requires) and again on the fragment read, which makes ds_read_b128 at most 2-way conflicted.
-// Two kernels: gemm_glds (256x128 tile, lockstep, 2 barriers per K-step: 640-770 TFLOP/s on the
-// joint shapes) for narrow outputs, and gemm_pp (256x256 tile, two wave groups in ping-pong:
-// 800-1250 TFLOP/s on random data, tools/gemm8.hip) for everything else.
+// Used wherever both operands already live in HBM as bf16 (the joint network: hidden h, bf16 weight copies, bf16
+// d(logits); every encoder / transformer product of the bf16 arithmetic mode).  No VGPR staging, no conversion: every
+// wave issues global_load_lds_dwordx4 pieces (1 KiB each) straight into the K-tile buffers; the 16-byte granule index
+// is XOR-ed with (row & 7) on the SOURCE address (the LDS image must stay lane-linear, as the instruction requires)
+// and again on the fragment read, which keeps ds_read_b128 conflict-free.
+//   gemm_pp<EPI, BOUNDS>  C = A B^T (+ fused epilogues), 256x256x64 tile, two wave groups in ping-pong, PERSISTENT
+//                         workgroups, never-drained two-K-tile fetch cursor: 850-1320 TFLOP/s on random data
+//   gemm_pp_tn<FULL>      C = A^T B (weight gradients), same schedule, transposed fragment reads: 700-1000 TFLOP/s
+//   gemm_glds             256x128 tile, lockstep, 2 barriers per K-step, for outputs narrower than 128 columns
+// Measurements and the time-stamp study behind the schedule: profiles/r1_gemm_pp_schedule.txt, tools/pp_trace.hip.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
