@@ -76,3 +76,32 @@ def test_gpu_las_rescore_matches_reference(hip_device):
         run(hip_device)
     finally:
         G.PRECISION = old
+
+
+def test_las_training_step_matches_reference():
+    """One TRAINING step of the LAS model with the calling convention of train_las_bmuf_otfaug.py:227-239 and the
+    decoder cross-entropy of its LASLossCompute: decoder outputs, loss and EVERY parameter gradient equal the
+    reference's (golden recorded from trainer/model/las.py by tests/golden/make_las_train_golden.py)."""
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from model import las                     # what importlib.import_module("model." + nnet_proto) resolves to
+    z = np.load(os.path.join(HERE, "golden", "las_train.npz"))
+    for attn in ("mlp", "general"):
+        net = las.Net(LC.opt(attn), LC.C_IN, LC.V, LC.PAD)
+        net.load_state_dict(seeded_state_dict(net, 31, scale=0.3))
+        net.train()
+        src, tgt, lens = LC.train_batch()
+        outputs, _, _, enc_out = net.forward(src, tgt, lens, None, True, True)
+        assert np.allclose(outputs.detach().numpy(), z["%s/outputs" % attn], rtol=1e-4, atol=1e-5)
+        assert np.allclose(enc_out.detach().numpy(), z["%s/enc_out" % attn], rtol=1e-4, atol=1e-5)
+        logp = F.log_softmax(net.dec_proj(outputs.view(-1, outputs.size(2))), dim=1)
+        loss = F.nll_loss(logp, tgt[1:].contiguous().view(-1), ignore_index=LC.PAD, reduction="sum")
+        loss.backward()
+        assert abs(loss.item() - float(z["%s/loss" % attn])) < 1e-4 * abs(float(z["%s/loss" % attn]))
+        n = 0
+        for k, p in net.named_parameters():
+            want = z["%s/grad/%s" % (attn, k)]
+            got = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+            assert np.allclose(got, want, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(want).max())), (attn, k)
+            n += 1
+        assert n == len([k for k in z.files if k.startswith(attn + "/grad/")])

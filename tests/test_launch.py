@@ -69,3 +69,48 @@ def test_unchanged_training_script_runs_one_epoch(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
     model = torch.load(out / "model.epoch.0.0", weights_only=False)   # whole-module pickle (:363-366)
     assert type(model).__module__ == "pika_amd.model.transducer" and model.fc2.out_features == 50
+
+
+LAS_SCRIPT = "/root/reference/trainer/train_las_bmuf_otfaug.py"
+
+
+@pytest.mark.skipif(not os.path.exists(LAS_SCRIPT), reason="reference tree not present on this box")
+def test_unchanged_las_training_script_runs_one_epoch(tmp_path):
+    """the UNCHANGED LAS rescorer training script (train_las_bmuf_otfaug.py) through
+    `pika_amd.launch`: otf loader with SOS/EOS targets -> shared (frozen) transducer encoder loaded from a
+    whole-module pickle -> `model.las` Net -> its LASLossCompute -> Nesterov SGD -> BMUF sync -> checkpoint.
+    (The script only runs with a shared encoder: without one `len_batch` is never assigned, :205-216.)"""
+    from types import SimpleNamespace
+    lst, conf, pcms, labels = make_corpus(tmp_path, n_utts=4, seed=9, lo=14000, hi=20000)
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    from model.transducer import Net as TransducerNet
+    torch.manual_seed(3)
+    opt = SimpleNamespace(rnn_size=64, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="transformer",
+                          dropout=0.0, enc_layers=2, dec_layers=1, embd_dim=16, padding_idx=50)
+    shared = tmp_path / "shared.mdl"
+    torch.save(TransducerNet(opt, 240, 50), str(shared))
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               PYTHONPATH=os.pathsep.join([ROOT, HERE]), OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "pika_amd.launch", "--preload", "cpu_plumbing", LAS_SCRIPT,
+           "--verbose", "--initial_lr", "0.003", "--final_lr", "0.0001",
+           "--num_batches_per_epoch", "2", "--num_epochs", "1", "--momentum", "0.9", "--block_momentum", "0.9",
+           "--sync_period", "1", "--feats_dim", "80", "--cuda", "--batch_size", "2",
+           "--encoder_type", "rnn", "--brnn", "--enc_layers", "1", "--dec_layers", "1", "--rnn_type", "LSTM",
+           "--rnn_size", "32", "--embd_dim", "16", "--dropout", "0.0", "--global_attention", "mlp",
+           "--input_dim", "64", "--output_dim", "50", "--padding_idx", "50", "--padding_tgt", "50", "--SOS", "0", "--EOS", "1",
+           "--shared_encoder_model", str(shared), "--encoder_lctx", "21", "--encoder_rctx", "21", "--encoder_stride", "4",
+           "--stride", "1", "--queue_size", "4", "--loader", "otf_utt", "--batch_first",
+           "--num_workers", "1", "--sample_rate", "16000", "--feat_config", conf, "--TU_limit", "15000",
+           "--gain_range", "50,10", "--speed_rate", "0.9,1.0,1.1", "--log_per_n_frames", "1", "--max_len", "1600",
+           "--lctx", "1", "--rctx", "1", "--local-rank=0",
+           "las", lst, str(tmp_path / "las.WORKER-ID.log"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = (tmp_path / "las.0.log").read_text()
+    assert "Training Finished" in log and "model proto: las" in log and "DecLoss:" in log
+    losses = [float(l.split("DecLoss:")[1].split()[0]) for l in log.splitlines() if "DecLoss:" in l]
+    assert losses and all(np.isfinite(losses))
+    model = torch.load(out / "model.epoch.0.0", weights_only=False)
+    assert type(model).__module__ == "pika_amd.model.las" and model.dec_proj.out_features == 50
