@@ -64,3 +64,7 @@ L.GpuFrontEnd = _CpuFrontEnd
 _real_device = torch.device
 L.torch = type("T", (), {"device": lambda *a, **k: _real_device("cpu"), "IntTensor": torch.IntTensor,
                          "from_numpy": torch.from_numpy, "tensor": torch.tensor, "int32": torch.int32})
+
+# the MBR script builds tensors through the legacy CUDA type constructors (train_transducer_mbr_bmuf_otfaug.py:167-199)
+torch.cuda.FloatTensor = torch.FloatTensor
+torch.cuda.LongTensor = torch.LongTensor

@@ -114,3 +114,47 @@ def test_unchanged_las_training_script_runs_one_epoch(tmp_path):
     assert losses and all(np.isfinite(losses))
     model = torch.load(out / "model.epoch.0.0", weights_only=False)
     assert type(model).__module__ == "pika_amd.model.las" and model.dec_proj.out_features == 50
+
+
+MBR_SCRIPT = "/root/reference/trainer/train_transducer_mbr_bmuf_otfaug.py"
+
+
+@pytest.mark.skipif(not os.path.exists(MBR_SCRIPT), reason="reference tree not present on this box")
+def test_unchanged_mbr_training_script_runs_one_epoch(tmp_path):
+    """the UNCHANGED MBR fine-tuning script through `pika_amd.launch`: n-best generation with the
+    drop-in TransducerDecoder (beam 3, beam_prune off) inside the training loop, its inline joint + RNN-T loss
+    (a plain log-softmax tensor: the eager path of the loss), edit distances from the `editdistance` shim, the dense
+    one-hot MBR gradient, BMUF sync, checkpoint."""
+    lst, conf, pcms, labels = make_corpus(tmp_path, n_utts=4, seed=8, lo=14000, hi=20000)
+    cmvn = tmp_path / "cmvn.stats"
+    D = 80
+    rng = np.random.default_rng(0)
+    n, mean = 1000.0, rng.normal(8, 1, D)
+    s1 = np.concatenate((mean * n, [n]))
+    s2 = np.concatenate(((mean ** 2 + 4.0) * n, [0.0]))
+    cmvn.write_text(" [\n  " + " ".join("%.10g" % v for v in s1) + "\n  " + " ".join("%.10g" % v for v in s2) + " ]\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               PYTHONPATH=os.pathsep.join([ROOT, HERE]), OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "pika_amd.launch", "--preload", "cpu_plumbing", MBR_SCRIPT,
+           "--verbose", "--optim", "sgd", "--initial_lr", "0.0003", "--final_lr", "0.0001", "--grad_clip", "3.0",
+           "--num_batches_per_epoch", "2", "--num_epochs", "1", "--momentum", "0.9", "--block_momentum", "0.9",
+           "--sync_period", "1", "--feats_dim", "80", "--cuda", "--batch_size", "2", "--encoder_type", "transformer",
+           "--enc_layers", "2", "--decoder_type", "transformer", "--dec_layers", "1", "--rnn_type", "LSTM",
+           "--rnn_size", "64", "--embd_dim", "16", "--dropout", "0.0", "--padding_idx", "50", "--padding_tgt", "50",
+           "--stride", "1", "--queue_size", "4", "--loader", "otf_utt", "--batch_first", "--cmn",
+           "--cmvn_stats", str(cmvn), "--output_dim", "50", "--num_workers", "1", "--sample_rate", "16000",
+           "--feat_config", conf, "--TU_limit", "15000", "--gain_range", "50,10", "--speed_rate", "0.9,1.0,1.1",
+           "--log_per_n_frames", "1", "--max_len", "1600", "--lctx", "1", "--rctx", "1", "--model_lctx", "21",
+           "--model_rctx", "21", "--model_stride", "4", "--beam_size", "3", "--rnnt_scale", "0.01", "--local-rank=0",
+           "transducer", lst, str(tmp_path / "mbr.WORKER-ID.log"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = (tmp_path / "mbr.0.log").read_text()
+    assert "Training Finished" in log and "MBR Loss:" in log and "RNNT Loss:" in log
+    vals = [float(l.split("MBR Loss:")[1].split()[0]) for l in log.splitlines() if l.startswith("MBR Loss:")]
+    assert vals and all(np.isfinite(vals))
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    model = torch.load(out / "model.epoch.0.0", weights_only=False)
+    assert type(model).__module__ == "pika_amd.model.transducer"
