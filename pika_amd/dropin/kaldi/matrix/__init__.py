@@ -1,5 +1,6 @@
 """`from kaldi.matrix import _matrix_ext, DoubleMatrix`
-(trainer/train_transducer_bmuf_otfaug.py:22, used at :342-344)."""
+(trainer/train_transducer_bmuf_otfaug.py:22, used at :342-344; decoder/decode_transducer.py:10 also imports `Vector`,
+which it never uses)."""
 import numpy as np
 
 from pika_amd.loader import kaldi_io
@@ -27,3 +28,10 @@ class _MatrixExt(object):
 
 
 _matrix_ext = _MatrixExt()
+
+
+class Vector(object):
+    """Imported by decode_transducer.py:10 and not used there."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("kaldi.matrix.Vector is not on any path of the scripts (SURVEY 2.1)")

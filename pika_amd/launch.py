@@ -4,7 +4,7 @@
 
 What it absorbs (SURVEY.md 8b "legacy-runtime conventions"), without touching the script:
   * import resolution: `pika_amd/dropin` goes first on sys.path, so `warp_rnnt`, `trainer.*`,
-    `model.*`, `decoder.*`, `loader.*`, `utils.*`, `kaldi`, `editdistance` resolve to this
+    `model.*`, `decoder.*`, `loader.*`, `utils.*`, `kaldi` (matrix / util / fstext), `editdistance` resolve to this
     repository even though the script's own directory is sys.path[0] under plain `python script`;
   * `from torch._six import inf` (removed in torch >= 2.0);
   * `--local-rank=N` (what torch.distributed.launch passes today) -> `--local_rank N`, or the

@@ -158,3 +158,69 @@ def test_unchanged_mbr_training_script_runs_one_epoch(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
     model = torch.load(out / "model.epoch.0.0", weights_only=False)
     assert type(model).__module__ == "pika_amd.model.transducer"
+
+
+DECODE_SCRIPT = "/root/reference/decoder/decode_transducer.py"
+
+
+@pytest.mark.skipif(not os.path.exists(DECODE_SCRIPT), reason="reference tree not present on this box")
+def test_unchanged_decode_script_with_fst_lm_and_las_rescorer(tmp_path):
+    """The UNCHANGED decoding script (the command line of egs/eval_transducer.sh:74-100) through `pika_amd.launch`:
+    Kaldi feature / label archives (utt loader), whole-module pickles of the transducer and of a LAS rescorer, an
+    OpenFST binary n-gram LM (`kaldi.fstext.StdVectorFst.read` -> SortedMatcher shallow fusion), n-best list with
+    scores and per-token LAS scores.  Like the reference, the script stops on the `None` its loader yields last
+    (loader/utt_loader.py:237, decode_transducer.py:108): everything is written and flushed by then."""
+    import struct
+    from types import SimpleNamespace
+    import fst_common as FC
+    from pika_amd.loader import kaldi_io
+    from pika_amd.decoder.ngram_fst import NgramFst
+    V = 50
+    rng = np.random.default_rng(4)
+    utts = [("utt%d" % i, rng.normal(0, 1, (n, 80)).astype(np.float32)) for i, n in enumerate([130, 150, 121, 160])]
+    kaldi_io.write_matrix_ark(str(tmp_path / "feats.ark"), utts)
+    kaldi_io.write_int_vectors(str(tmp_path / "labels.ark"), [(k, np.array([1, 2, 3])) for k, _ in utts], binary=False)
+    (tmp_path / "sym.map").write_text("".join("s%d %d\n" % (i, i) for i in range(V + 1)))
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    from model.transducer import Net
+    from model import las
+    torch.manual_seed(3)
+    opt = SimpleNamespace(rnn_size=64, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="transformer",
+                          dropout=0.0, enc_layers=2, dec_layers=1, embd_dim=16, padding_idx=V)
+    torch.save(Net(opt, 240, V), str(tmp_path / "model.mdl"))
+    lopt = SimpleNamespace(rnn_size=32, encoder_type="rnn", rnn_type="LSTM", brnn=True, enc_layers=1, dropout=0.0,
+                           use_downsampler=False, embd_dim=12, num_heads=1, sampling_decoder=False, input_feed=1,
+                           dec_layers=1, global_attention="mlp", coverage_attn=False, context_gate=None, copy_attn=False)
+    torch.save(las.Net(lopt, 64, V + 1, V + 1), str(tmp_path / "las.mdl"))
+    n, arcs, finals, params = FC.bigram_arcs(V)
+    ref = NgramFst.from_arcs(n, arcs, finals)
+    with open(tmp_path / "g.fst", "wb") as f:          # OpenFST binary (vector / standard, no symbol tables)
+        def s_(t): return struct.pack("<i", len(t)) + t.encode()
+        f.write(struct.pack("<i", 2125659606) + s_("vector") + s_("standard") + struct.pack("<iiQqqq", 2, 0, 0, 0, n, len(arcs)))
+        for st in range(n):
+            lo, hi = ref.offsets[st], ref.offsets[st + 1]
+            f.write(struct.pack("<fq", float(ref.final[st]), hi - lo))
+            for j in range(lo, hi):
+                f.write(struct.pack("<iifi", int(ref.ilabel[j]), int(ref.ilabel[j]), float(ref.weight[j]), int(ref.nextstate[j])))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, HERE]), OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "pika_amd.launch", "--preload", "cpu_plumbing", DECODE_SCRIPT,
+           "--verbose", "--cuda", "--min_len", "50", "--blk", "0", "--batch_first", "--beam_size", "3", "--output_scores",
+           "--sm_scale", "0.8", "--batch_size", "2", "--n_best", "2", "--SOS", "0", "--EOS", str(V), "--padding_idx", str(V),
+           "--loader", "utt", "--lctx", "1", "--rctx", "1", "--feats_dim", "80", "--model_lctx", "21", "--model_rctx", "21",
+           "--model_stride", "4", "--fst_lm", str(tmp_path / "g.fst"), "--fst_lm_scale", "0.3", "--nonblk_reward", "0.5",
+           "--max_num_arcs", str(params["max_num_arcs"]), "--max_id", str(params["max_id"]),
+           "--backoff_id", str(params["backoff_id"]), "--disambig_ids", ",".join(str(d) for d in params["disambig_ids"]),
+           "--las_rescorer_model", str(tmp_path / "las.mdl"),
+           "--symbols_map", str(tmp_path / "sym.map"), str(tmp_path / "model.mdl"),
+           "ark:" + str(tmp_path / "feats.ark"), "ark:" + str(tmp_path / "labels.ark"), str(tmp_path / "hyp.txt")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
+    assert "cannot unpack non-iterable NoneType" in r.stderr, r.stderr[-3000:]     # the reference's own ending
+    lines = (tmp_path / "hyp.txt").read_text().splitlines()
+    assert len(lines) == 4 * 2
+    for ln in lines:
+        fields = ln.split(" ")
+        labels = [t for t in fields[0].split("s") if t]
+        assert all(1 <= int(t) < V for t in labels)
+        vals = [float(v) for v in fields[1:]]
+        assert len(vals) == 1 + len(labels) + 1 and all(np.isfinite(vals))         # beam score + log P(token | prefix) incl. EOS
+        assert all(v <= 1e-6 for v in vals[1:])
