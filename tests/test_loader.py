@@ -182,3 +182,75 @@ def test_wav_to_seq_and_format_writers(tmp_path):
     off, scale = K.cmvn_offset_scale(back)
     allf = np.concatenate(feats)
     assert np.allclose(off, -allf.mean(0), atol=1e-9) and np.allclose(scale, 1.0 / allf.std(0), atol=1e-9)
+
+
+def _oracle_front_end(conf):
+    """CPU stand-in for GpuFrontEnd(cfg, dev, 0, 0, 1): the oracle's perturbation + Kaldi filter banks."""
+    from pika_amd.loader.frontend import FbankConfig
+    cfg = FbankConfig.from_file(conf)
+
+    def fe(pcms, rates, dbs):
+        feats = [F.kaldi_fbank(F.perturb(p, r, d).astype(np.float64), num_bins=cfg.num_mel_bins, low=cfg.low_freq,
+                               high=cfg.high_freq).astype(np.float32) for p, r, d in zip(pcms, rates, dbs)]
+        lens = [f.shape[0] for f in feats]
+        out = np.zeros((len(feats), max(lens), feats[0].shape[1]), np.float32)
+        for i, f in enumerate(feats):
+            out[i, :len(f)] = f
+        return torch.from_numpy(out), lens
+    return fe, cfg
+
+
+def test_global_cmvn_tool_and_wav_to_bytes(tmp_path):
+    """`python -m pika_amd.loader.compute_global_cmvn` (utils/compute_global_cmvn.py: same list walk, same
+    random draws in the same order, per-utterance CMN option, Kaldi text statistics the training scripts read) and
+    `python -m pika_amd.loader.wav_to_bytes` (utils/wav_to_bytes.py).  Host protocol on the oracle front end here;
+    the GPU front end is compared against it in the gpu-marked test below."""
+    import random
+    import wave
+    from pika_amd.loader import compute_global_cmvn as CG, kaldi_io, wav_to_bytes
+    lst, conf, pcms, _ = make_corpus(tmp_path, n_utts=5, seed=11, lo=4000, hi=9000)
+    fe, cfg = _oracle_front_end(conf)
+    for cmn in (False, True):
+        random.seed(5); np.random.seed(6)
+        stats = CG.compute(lst, conf, 80, cmn=cmn, batch=2, front_end=fe)
+        random.seed(5); np.random.seed(6)
+        want = np.zeros((2, 81))
+        for p in pcms:                                            # compute_global_cmvn.py:44-69, one utterance at a time
+            rate = CG.SPEED_RATES[random.randint(0, 2)]
+            db = np.random.uniform(-55, -10)
+            x = F.kaldi_fbank(F.perturb(p, rate, db).astype(np.float64), num_bins=80, low=cfg.low_freq,
+                              high=cfg.high_freq).astype(np.float32).astype(np.float64)
+            if cmn:
+                x = x - x.mean(0)
+            want[0, :-1] += x.sum(0); want[1, :-1] += (x * x).sum(0); want[0, -1] += len(x)
+        assert stats[0, -1] == want[0, -1] and np.allclose(stats, want, rtol=1e-9, atol=1e-6)
+    out = tmp_path / "cmvn.stats"
+    kaldi_io.write_text_matrix(str(out), stats)                   # what main() does with the result
+    back = kaldi_io.read_text_matrix(str(out))
+    assert back.shape == (2, 81) and np.allclose(back, stats, rtol=1e-6)
+    # wav_to_bytes
+    scp = tmp_path / "wav.scp"
+    with open(scp, "w") as f:
+        for i, p in enumerate(pcms[:3]):
+            path = tmp_path / ("u%d.wav" % i)
+            with wave.open(str(path), "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(p.astype("<i2").tobytes())
+            f.write("u%d %s\n" % (i, path))
+    wav_to_bytes.main(["scp:" + str(scp), str(tmp_path / "wav.bytes")])
+    assert (tmp_path / "wav.bytes").read_text().splitlines() == ["u%d %d" % (i, 2 * len(p)) for i, p in enumerate(pcms[:3])]
+
+
+@pytest.mark.gpu
+def test_global_cmvn_tool_on_the_gpu_front_end(hip_device, tmp_path):
+    import random
+    from pika_amd.loader import compute_global_cmvn as CG
+    lst, conf, pcms, _ = make_corpus(tmp_path, n_utts=6, seed=12, lo=4000, hi=9000)
+    fe, _ = _oracle_front_end(conf)
+    random.seed(1); np.random.seed(2)
+    want = CG.compute(lst, conf, 80, cmn=True, batch=4, front_end=fe)
+    random.seed(1); np.random.seed(2)
+    got = CG.compute(lst, conf, 80, cmn=True, batch=4, device=hip_device)
+    assert got[0, -1] == want[0, -1]
+    n = want[0, -1]
+    assert np.allclose(got[0, :-1] / n, want[0, :-1] / n, atol=2e-3)            # per-utterance CMN: sums ~ 0
+    assert np.allclose(got[1, :-1] / n, want[1, :-1] / n, rtol=5e-3)            # second moments of the log-mel features
