@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #endif
     // One K-tile.  `sw` = the cursor may step into the workgroup's next output tile in this iteration (the last two
     // K-tiles of an output tile): kept out of the steady-state loop body, where the lane offsets are loop invariants
-    auto ktile = [&](int t, auto sw) {
+    auto ktile = [&]([[maybe_unused]] int t, auto sw) {   // t: only the time-stamp build looks at it
         // Load segments (ds_read fragments, two pieces of the fetch cursor's K-tile) alternate with MFMA segments; while
         // one wave group is in a load segment the other owns the matrix pipe.  The CU takes about one 1 KB piece per
         // 30-35 cycles whoever issues it, so all four load segments carry exactly two pieces per wave, and a K-tile
@@ -677,7 +677,6 @@ __global__ __launch_bounds__(512) void gemm_pp_tn(TNArgs P) {
     sa.init(P.A, m0, t_begin * 64, wave, lane);
     sb.init(P.B, n0, t_begin * 64, wave, lane);
     int r0 = t_begin * 64;   // first reduction row of the K-tile being fetched
-    const int piece0 = wave * 4 * 1024;
     auto gl = [&](const char *p, unsigned char *dst) {
         __builtin_amdgcn_global_load_lds((glb_u32 *)p, (lds_u32 *)dst, 16, 0, 0);
     };
