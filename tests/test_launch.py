@@ -91,14 +91,21 @@ def test_unchanged_las_training_script_runs_one_epoch(tmp_path):
     torch.save(TransducerNet(opt, 240, 50), str(shared))
     out = tmp_path / "out"
     out.mkdir()
+    cmvn = tmp_path / "cmvn.stats"
+    rng = np.random.default_rng(0)
+    n, mean = 1000.0, rng.normal(8, 1, 80)
+    cmvn.write_text(" [\n  " + " ".join("%.10g" % v for v in np.concatenate((mean * n, [n]))) + "\n  " +
+                    " ".join("%.10g" % v for v in np.concatenate(((mean ** 2 + 4.0) * n, [0.0]))) + " ]\n")
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                PYTHONPATH=os.pathsep.join([ROOT, HERE]), OMP_NUM_THREADS="8")
+    # the options of egs/train_las_rescorer_bmuf_otfaug.sh at toy sizes
     cmd = [sys.executable, "-m", "pika_amd.launch", "--preload", "cpu_plumbing", LAS_SCRIPT,
-           "--verbose", "--initial_lr", "0.003", "--final_lr", "0.0001",
+           "--verbose", "--optim", "sgd", "--initial_lr", "0.003", "--final_lr", "0.0003", "--enc_loss_scale", "0.0",
+           "--dec_loss_scale", "1.0", "--grad_clip", "3.0", "--lr", "0.001", "--cmn", "--cmvn_stats", str(cmvn),
            "--num_batches_per_epoch", "2", "--num_epochs", "1", "--momentum", "0.9", "--block_momentum", "0.9",
            "--sync_period", "1", "--feats_dim", "80", "--cuda", "--batch_size", "2",
-           "--encoder_type", "rnn", "--brnn", "--enc_layers", "1", "--dec_layers", "1", "--rnn_type", "LSTM",
-           "--rnn_size", "32", "--embd_dim", "16", "--dropout", "0.0", "--global_attention", "mlp",
+           "--encoder_type", "rnn", "--decoder_type", "rnn", "--brnn", "--enc_layers", "2", "--dec_layers", "2",
+           "--rnn_type", "LSTM", "--rnn_size", "32", "--embd_dim", "16", "--dropout", "0.2", "--global_attention", "mlp",
            "--input_dim", "64", "--output_dim", "50", "--padding_idx", "50", "--padding_tgt", "50", "--SOS", "0", "--EOS", "1",
            "--shared_encoder_model", str(shared), "--encoder_lctx", "21", "--encoder_rctx", "21", "--encoder_stride", "4",
            "--stride", "1", "--queue_size", "4", "--loader", "otf_utt", "--batch_first",
