@@ -171,7 +171,7 @@ DECODE_SCRIPT = "/root/reference/decoder/decode_transducer.py"
 
 
 @pytest.mark.skipif(not os.path.exists(DECODE_SCRIPT), reason="reference tree not present on this box")
-def test_unchanged_decode_script_with_fst_lm_and_las_rescorer(tmp_path):
+def test_unchanged_decode_script_and_the_eval_recipe_steps_behind_it(tmp_path):
     """The UNCHANGED decoding script (the command line of egs/eval_transducer.sh:74-100) through `pika_amd.launch`:
     Kaldi feature / label archives (utt loader), whole-module pickles of the transducer and of a LAS rescorer, an
     OpenFST binary n-gram LM (`kaldi.fstext.StdVectorFst.read` -> SortedMatcher shallow fusion), n-best list with
@@ -199,6 +199,8 @@ def test_unchanged_decode_script_with_fst_lm_and_las_rescorer(tmp_path):
                            use_downsampler=False, embd_dim=12, num_heads=1, sampling_decoder=False, input_feed=1,
                            dec_layers=1, global_attention="mlp", coverage_attn=False, context_gate=None, copy_attn=False)
     torch.save(las.Net(lopt, 64, V + 1, V + 1), str(tmp_path / "las.mdl"))
+    torch.manual_seed(4)
+    torch.save(las.Net(lopt, 64, V + 1, V + 1), str(tmp_path / "las_bw.mdl"))
     n, arcs, finals, params = FC.bigram_arcs(V)
     ref = NgramFst.from_arcs(n, arcs, finals)
     with open(tmp_path / "g.fst", "wb") as f:          # OpenFST binary (vector / standard, no symbol tables)
@@ -217,7 +219,7 @@ def test_unchanged_decode_script_with_fst_lm_and_las_rescorer(tmp_path):
            "--model_stride", "4", "--fst_lm", str(tmp_path / "g.fst"), "--fst_lm_scale", "0.3", "--nonblk_reward", "0.5",
            "--max_num_arcs", str(params["max_num_arcs"]), "--max_id", str(params["max_id"]),
            "--backoff_id", str(params["backoff_id"]), "--disambig_ids", ",".join(str(d) for d in params["disambig_ids"]),
-           "--las_rescorer_model", str(tmp_path / "las.mdl"),
+           "--las_rescorer_model", str(tmp_path / "las.mdl"), "--las_rescorer_bw_model", str(tmp_path / "las_bw.mdl"),
            "--symbols_map", str(tmp_path / "sym.map"), str(tmp_path / "model.mdl"),
            "ark:" + str(tmp_path / "feats.ark"), "ark:" + str(tmp_path / "labels.ark"), str(tmp_path / "hyp.txt")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=str(tmp_path), timeout=900)
@@ -229,5 +231,21 @@ def test_unchanged_decode_script_with_fst_lm_and_las_rescorer(tmp_path):
         labels = [t for t in fields[0].split("s") if t]
         assert all(1 <= int(t) < V for t in labels)
         vals = [float(v) for v in fields[1:]]
-        assert len(vals) == 1 + len(labels) + 1 and all(np.isfinite(vals))         # beam score + log P(token | prefix) incl. EOS
+        # beam score + forward and backward log P(token | prefix), each over the labels + EOS
+        assert len(vals) == 1 + 2 * (len(labels) + 1) and all(np.isfinite(vals))
         assert all(v <= 1e-6 for v in vals[1:])
+    # the rest of egs/eval_transducer.sh:100-127 on that file: the reference's own n-best reranker (pure Python, run
+    # as it is) and the drop-in one pick the same hypotheses; keys are attached and the result is scored
+    from pika_amd.eval import nbest_rerank, scoring
+    ref_tool = "/root/reference/egs/local/nbest_rerank.py"
+    r2 = subprocess.run([sys.executable, ref_tool, "--las_rescore", "--nbest", "2", str(tmp_path / "hyp.txt"),
+                         str(tmp_path / "raw_ref.hyp")], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    nbest_rerank.main(["--las_rescore", "--nbest", "2", str(tmp_path / "hyp.txt"), str(tmp_path / "raw.hyp")])
+    picked = (tmp_path / "raw.hyp").read_text()
+    assert picked == (tmp_path / "raw_ref.hyp").read_text() and len(picked.splitlines()) == 4
+    hyp_lines = scoring.attach_keys((tmp_path / "labels.ark").read_text().splitlines(), picked.splitlines())
+    assert [l.split()[0] for l in hyp_lines] == [k for k, _ in utts]
+    wer = scoring.compute_wer(["%s %s" % (k, " ".join(l.split()[1:])) for k, l in zip([k for k, _ in utts], hyp_lines)],
+                              hyp_lines)
+    assert wer["words"] > 0 and wer["ins"] == wer["del"] == wer["sub"] == 0 and wer["sent_errs"] == 0
