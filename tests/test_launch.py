@@ -249,3 +249,61 @@ def test_unchanged_decode_script_and_the_eval_recipe_steps_behind_it(tmp_path):
     wer = scoring.compute_wer(["%s %s" % (k, " ".join(l.split()[1:])) for k, l in zip([k for k, _ in utts], hyp_lines)],
                               hyp_lines)
     assert wer["words"] > 0 and wer["ins"] == wer["del"] == wer["sub"] == 0 and wer["sent_errs"] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(SCRIPT), reason="reference tree not present on this box")
+def test_unchanged_training_script_two_workers(tmp_path):
+    """SURVEY 8(e) at the level of the unchanged script: TWO worker processes (what torch.distributed.launch starts,
+    egs/train_transducer_bmuf_otfaug.sh) with WORKER-ID lists and logs, BMUF block sync every batch through the gloo
+    backend (RCCL on a GPU node), loss reduction across workers; both write a checkpoint and, because BMUF ends the
+    epoch with a sync, the two checkpoints hold identical parameters."""
+    lists = []
+    for rank in (0, 1):
+        d = tmp_path / str(rank)
+        d.mkdir()
+        lst, conf, _, _ = make_corpus(d, n_utts=4, seed=20 + rank, lo=14000, hi=20000)
+        lists.append(lst)
+    cmvn = tmp_path / "cmvn.stats"
+    rng = np.random.default_rng(0)
+    n, mean = 1000.0, rng.normal(8, 1, 80)
+    cmvn.write_text(" [\n  " + " ".join("%.10g" % v for v in np.concatenate((mean * n, [n]))) + "\n  " +
+                    " ".join("%.10g" % v for v in np.concatenate(((mean ** 2 + 4.0) * n, [0.0]))) + " ]\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    port = str(free_port())
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   PYTHONPATH=os.pathsep.join([ROOT, HERE]), OMP_NUM_THREADS="4")
+        cmd = [sys.executable, "-m", "pika_amd.launch", "--preload", "cpu_plumbing", SCRIPT,
+               "--verbose", "--optim", "sgd", "--initial_lr", "0.003", "--final_lr", "0.0001", "--grad_clip", "3.0",
+               "--num_batches_per_epoch", "2", "--num_epochs", "1", "--momentum", "0.9", "--block_momentum", "0.9",
+               "--sync_period", "1", "--feats_dim", "80", "--cuda", "--batch_size", "2", "--encoder_type", "transformer",
+               "--enc_layers", "2", "--decoder_type", "transformer", "--dec_layers", "1", "--rnn_type", "LSTM",
+               "--rnn_size", "64", "--embd_dim", "16", "--dropout", "0.0", "--padding_idx", "50", "--padding_tgt", "50",
+               "--stride", "1", "--queue_size", "4", "--loader", "otf_utt", "--batch_first", "--cmn",
+               "--cmvn_stats", str(cmvn), "--output_dim", "50", "--num_workers", "1", "--sample_rate", "16000",
+               "--feat_config", conf, "--TU_limit", "15000", "--gain_range", "50,10", "--speed_rate", "0.9,1.0,1.1",
+               "--log_per_n_frames", "1", "--max_len", "1600", "--lctx", "1", "--rctx", "1", "--model_lctx", "21",
+               "--model_rctx", "21", "--model_stride", "4", "--local-rank=%d" % rank,
+               "transducer", str(tmp_path / "WORKER-ID" / "data.lst"), str(tmp_path / "train.WORKER-ID.log"), str(out)]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      cwd=str(tmp_path)))
+    errs = []
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        errs.append(err)
+    assert [p.returncode for p in procs] == [0, 0], (errs[0][-1500:], errs[1][-1500:])
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    models = [torch.load(out / ("model.epoch.0.%d" % r), weights_only=False) for r in (0, 1)]
+    for r in (0, 1):
+        assert "Training Finished" in (tmp_path / ("train.%d.log" % r)).read_text()
+    for (ka, a), (kb, b) in zip(models[0].state_dict().items(), models[1].state_dict().items()):
+        assert ka == kb
+        if a.dtype.is_floating_point and "running_" not in ka:
+            assert torch.equal(a, b), ka
