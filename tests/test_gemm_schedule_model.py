@@ -108,3 +108,37 @@ def test_the_model_rejects_broken_schedules():
     with pytest.raises(AssertionError):   # TN: rows 32..63 refilled in phase 3 of the iteration that still reads them
         check(TN_READS, [("Alo0", -2, L3), ("Alo1", -2, L3), ("Ahi0", -2, L3), ("Ahi1", -2, L3), ("Blo0", -1, L0),
                          ("Blo1", -1, L0), ("Bhi0", -1, L1), ("Bhi1", -1, L1)], [(L1, 4), (L3, 4)])
+
+
+def test_persistent_tile_walk_covers_every_tile_once():
+    """The slot -> tile map of gemm_pp (XCD-contiguous runs, bands of PP_GM tile rows walked column by column) and the
+    way persistent workgroups step through the slots (blockIdx.x, + gridDim.x, ...), restated from the kernel:
+    every output tile is produced exactly once, for ragged tile grids and any workgroup count the launcher picks."""
+    GM = 4
+
+    def tile_of(v, ntiles):
+        q, r, xcd, idx = ntiles >> 3, ntiles & 7, v & 7, v >> 3
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+
+    def tile_mn(tile, nx, ntiles):
+        band = tile // (GM * nx)
+        inb = tile - band * GM * nx
+        rows = min(GM, ntiles // nx - band * GM)
+        tn = inb // rows
+        return band * GM + inb - tn * rows, tn
+
+    for nx, ny in itertools.product((1, 2, 3, 4, 5, 16, 20, 33), (1, 2, 3, 4, 5, 7, 8, 9, 31, 122, 125)):
+        ntiles = nx * ny
+        for wgs in (256, 304, 8, 16):
+            grid = (wgs & ~7) if (wgs >= 8 and ntiles > wgs) else ntiles        # launch_pp_epi
+            seen = []
+            for w in range(grid):
+                slot = w
+                while slot < ntiles:
+                    tm, tn = tile_mn(tile_of(slot, ntiles), nx, ntiles)
+                    assert 0 <= tm < ny and 0 <= tn < nx
+                    seen.append((tm, tn))
+                    slot += grid
+            assert len(seen) == ntiles and len(set(seen)) == ntiles, (nx, ny, wgs)
+            # all tiles of one workgroup stay on its XCD's run (slots share v % 8)
+            assert grid % 8 == 0 or grid == ntiles
