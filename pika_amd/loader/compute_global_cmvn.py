@@ -65,7 +65,7 @@ def compute(data_lst, feat_config, feat_dim=80, cmn=False, device=None, batch=32
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="global CMVN estimation")
+    ap = argparse.ArgumentParser(description="accumulate global mean / variance statistics of filter-bank features over a training list")
     ap.add_argument("data_lst")
     ap.add_argument("cmvn_stats")
     ap.add_argument("--cmn", action="store_true")

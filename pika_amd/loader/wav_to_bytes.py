@@ -19,7 +19,7 @@ def convert(rspecifier, byte_file):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="wav.scp to byte files, i.e., each line: uttid num_bytes")
+    ap = argparse.ArgumentParser(description="length list of a wav.scp: one `uttid bytes` line per utterance")
     ap.add_argument("wav_rspecifier")
     ap.add_argument("byte_file")
     args, _ = ap.parse_known_args(argv)
