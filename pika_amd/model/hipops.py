@@ -399,8 +399,8 @@ class JointOutFn(torch.autograd.Function):
             # the log-softmax pass is deferred until something needs the values (pika_amd.rnnt.LazyLogProbs);
             # `out` is normalised in place by a raw kernel call, which autograd's version counter does not see
             from ..rnnt import LazyLogProbs, LogitsState
-            ctx.state = LogitsState(out, scale)
-            return LazyLogProbs(ctx.state)
+            ctx.state = LogitsState(scale)
+            return LazyLogProbs(ctx.state, out)
         with torch.cuda.device(h.device):
             _lib.check(_lib.lib().pika_log_softmax_rows(out.data_ptr(), h2.shape[0], N, N, float(scale),
                                                         _stream()), "pika_log_softmax_rows")
@@ -420,11 +420,12 @@ class JointOutFn(torch.autograd.Function):
             # made it dense, or when it does not fit the compact kernel, it is an ordinary tensor from here on.)
             if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= 5120:
                 compact = g.compact
-                lse = g.lse     # the loss read raw logits: `lp` still holds them (or log-probs and lse == 0)
+                if ctx.state is not None and ctx.state.raw:
+                    lse = g.lse     # the loss read the raw logits `lp` still holds: log-prob = logit - lse
             else:
                 g = g.dense()
         if lse is None and ctx.state is not None:
-            ctx.state.to_log_probs()       # every other path below needs the log-probabilities in `lp`
+            ctx.state.to_log_probs(lp)     # every other path below needs the log-probabilities in `lp`
         if compact is None:
             if not g.is_contiguous():
                 g = g.contiguous()
@@ -465,9 +466,6 @@ class JointOutFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=dl.device)
                 _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
                            "pika_colsum_bf16")
-        # the node outlives its backward for as long as anything holds the graph (a returned loss): do not keep the
-        # 7.8 GB logits buffer alive through it
-        ctx.state = None
         return dh, dw, db, None, None
 
 

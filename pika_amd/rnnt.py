@@ -148,45 +148,44 @@ class LazyDenseGrad(torch.Tensor):
 
 
 class LogitsState(object):
-    """Shared by a LazyLogProbs, the joint node that made it and the losses that consumed it: the (B,T,U1,V)
-    buffer, whether it still holds raw logits, and the log-sum-exp vectors computed from it while it did."""
+    """Shared by a LazyLogProbs and the joint node that made it: does the (B,T,U1,V) buffer still hold raw logits?
+    (Small on purpose: autograd nodes outlive their backward for as long as anything holds the graph, so nothing that
+    hangs off them may keep the 7.8 GB buffer alive -- the buffer itself lives in autograd's saved tensors and in the
+    LazyLogProbs the caller holds.)"""
 
-    __slots__ = ("buf", "scale", "raw", "lse")
+    __slots__ = ("scale", "raw")
 
-    def __init__(self, buf, scale):
-        self.buf, self.scale, self.raw, self.lse = buf, float(scale), True, []
+    def __init__(self, scale):
+        self.scale, self.raw = float(scale), True
 
-    def to_log_probs(self):
-        """In place: buf <- log_softmax(scale * buf).  Every log-sum-exp taken from the raw logits becomes 0, so a
-        consumer that subtracts it (pika_rnnt_dlogits_compact_bf16) reads the same log-probabilities either way."""
+    def to_log_probs(self, buf):
+        """In place: buf <- log_softmax(scale * buf), once."""
         if self.raw:
-            B, T, U1, V = self.buf.shape
-            with torch.cuda.device(self.buf.device):
-                _lib.check(_lib.lib().pika_log_softmax_rows(self.buf.data_ptr(), B * T * U1, V, V, self.scale, _stream()),
+            B, T, U1, V = buf.shape
+            with torch.cuda.device(buf.device):
+                _lib.check(_lib.lib().pika_log_softmax_rows(buf.data_ptr(), B * T * U1, V, V, self.scale, _stream()),
                            "pika_log_softmax_rows")
-            for l in self.lse:
-                l.zero_()
             self.raw = False
-        return self.buf
+        return buf
 
 
 class LazyLogProbs(torch.Tensor):
     """log_softmax(logits) over the lattice as a tensor whose log-softmax pass only runs if somebody needs the
     values.  pika_amd.model.hipops.JointOutFn returns it; this module's loss takes the row log-sum-exp and the two
     log-probs per lattice cell it needs in ONE read of the raw logits (pika_rnnt_fused_forward), and the joint's
-    backward subtracts that log-sum-exp on the fly.  ANY other use -- an aten op, printing, `.float()`, a different
-    loss -- goes through __torch_dispatch__, which first normalises the buffer in place (the same kernel the
-    eager path runs in the forward) and then runs the op on the real log-probabilities."""
+    backward subtracts that log-sum-exp on the fly for as long as the buffer is raw.  ANY other use -- an aten op,
+    printing, `.float()`, a different loss -- goes through __torch_dispatch__, which first normalises the buffer in
+    place (the same kernel the eager path runs in the forward) and then runs the op on the real log-probabilities."""
 
     @staticmethod
-    def __new__(cls, state):
-        r = torch.Tensor._make_wrapper_subclass(cls, tuple(state.buf.shape), dtype=torch.float32,
-                                                device=state.buf.device, requires_grad=False)
-        r.state = state
+    def __new__(cls, state, buf):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(buf.shape), dtype=torch.float32, device=buf.device,
+                                                requires_grad=False)
+        r.state, r.buf = state, buf
         return r
 
     def dense(self):
-        return self.state.to_log_probs()
+        return self.state.to_log_probs(self.buf)
 
     def __repr__(self):
         return "LazyLogProbs(shape=%s, normalised=%s)" % (tuple(self.shape), not self.state.raw)
@@ -214,13 +213,13 @@ class _RNNTLossFn(torch.autograd.Function):
         frames_lengths = frames_lengths.contiguous()
         labels_lengths = labels_lengths.contiguous()
         B, T, U1, V = log_probs.shape
-        ctx.lse = None
+        lse = None
         state = log_probs.state if isinstance(log_probs, LazyLogProbs) else None
         if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= 5120):
             state = None
         if state is not None:
             # raw logits of this package's joint: log-sum-exp + gather in one read, no log-prob tensor
-            x = state.buf
+            x = log_probs.buf
             with torch.cuda.device(x.device):
                 costs = torch.empty(B, dtype=torch.float32, device=x.device)
                 lse = torch.empty(B * T * U1, dtype=torch.float32, device=x.device)
@@ -229,8 +228,6 @@ class _RNNTLossFn(torch.autograd.Function):
                     _lib.check(lib.pika_rnnt_fused_forward(
                         _ptr(x), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
                         _ptr(costs), _ptr(lse), _ptr(ws), _stream()), "pika_rnnt_fused_forward")
-            state.lse.append(lse)
-            ctx.lse = lse           # not through save_for_backward: to_log_probs() may zero it in place
         else:
             lp = log_probs.contiguous()     # (a LazyLogProbs is normalised here)
             with torch.cuda.device(lp.device):
@@ -241,13 +238,15 @@ class _RNNTLossFn(torch.autograd.Function):
                     _lib.check(lib.pika_rnnt_loss_forward(
                         _ptr(lp), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths),
                         B, T, U1, V, blank, _ptr(costs), _ptr(ws), _stream()), "pika_rnnt_loss_forward")
-        ctx.save_for_backward(labels, frames_lengths, labels_lengths, ws)
+        # lse: the log-sum-exp of every row of the RAW logits (None when log-probs were read); it only means something
+        # to the joint's backward while its buffer is still raw, which that backward checks itself
+        ctx.save_for_backward(labels, frames_lengths, labels_lengths, ws, lse)
         ctx.dims = (B, T, U1, V, blank)
         return costs
 
     @staticmethod
     def backward(ctx, grad_costs):
-        labels, frames_lengths, labels_lengths, ws = ctx.saved_tensors
+        labels, frames_lengths, labels_lengths, ws, lse = ctx.saved_tensors
         B, T, U1, V, blank = ctx.dims
         lib = _lib.lib()
         gc = grad_costs.to(torch.float32).contiguous()
@@ -259,8 +258,7 @@ class _RNNTLossFn(torch.autograd.Function):
             compact = CompactGrad.__new__(CompactGrad)
             compact.ws, compact.dims, compact.ptr, compact.version = ws, (B, T, U1, V, blank), 0, 0
             lazy = LazyDenseGrad(compact, labels, frames_lengths, labels_lengths)
-            lazy.lse = ctx.lse      # set when the forward read raw logits
-            ctx.lse = None          # (the node may outlive its backward: keep no buffers on it)
+            lazy.lse = lse
             return lazy, None, None, None, None
         with torch.cuda.device(ws.device):
             grads = torch.empty((B, T, U1, V), dtype=torch.float32, device=ws.device)

@@ -167,6 +167,8 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
             if mode == "second":
                 loss = loss + 0.25 * (lp * lp).sum()
             raw_after_forward = lazy and lp.state.raw
+            if mode == "twice":                                            # gradients accumulate: 2 x
+                loss.backward(retain_graph=True)
             loss.backward()
             lpv = lp.detach().clone() if mode == "values" else None        # any aten op sees real log-probs
             return dict(dh=hh.grad.float(), dw=ww.grad, db=bb.grad, lpg=lp.grad if mode == "retain" else None,
@@ -183,7 +185,7 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
         close(lazy["dw"], eager["dw"], 2e-4)
         close(lazy["db"], eager["db"], 2e-4)
         close(lazy["dh"], eager["dh"], 1e-2)                              # bf16 matrices: a few one-ulp flips
-        for mode in ("hook", "second", "retain", "values"):
+        for mode in ("hook", "second", "retain", "values", "twice"):
             e, l = run(False, mode), run(True, mode)
             close(l["costs"], e["costs"], 2e-6)
             close(l["dw"], e["dw"], 2e-4)
@@ -191,6 +193,8 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
             close(l["dh"], e["dh"], 1e-2)
             if mode == "hook":
                 assert l["seen"] == [LazyDenseGrad] and e["seen"] == [torch.Tensor]
+            if mode == "twice":
+                close(l["dw"], 2.0 * lazy["dw"], 2e-4)
             if mode == "second":
                 assert not l["raw"]                                       # lp * lp normalised the buffer before the loss
             if mode == "retain":
