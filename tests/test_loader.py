@@ -254,3 +254,13 @@ def test_global_cmvn_tool_on_the_gpu_front_end(hip_device, tmp_path):
     n = want[0, -1]
     assert np.allclose(got[0, :-1] / n, want[0, :-1] / n, atol=2e-3)            # per-utterance CMN: sums ~ 0
     assert np.allclose(got[1, :-1] / n, want[1, :-1] / n, rtol=5e-3)            # second moments of the log-mel features
+
+
+def test_global_cmvn_tool_has_no_cpu_path(tmp_path):
+    """Without a HIP device the tool refuses (the feature front end is GPU-only; the oracle is for tests)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU box")
+    from pika_amd.loader import compute_global_cmvn as CG
+    lst, conf, _, _ = make_corpus(tmp_path, n_utts=2, seed=13, lo=4000, hi=5000)
+    with pytest.raises((RuntimeError, AssertionError)):
+        CG.compute(lst, conf, 80)
