@@ -123,13 +123,15 @@ __global__ __launch_bounds__(THREADS) void gemm_glds(const __bf16 *__restrict__ 
 // 256 x 256 x 64 "ping-pong" kernel: 8 waves (2 x 4), 128 x 64 outputs per wave (128 accumulator
 // VGPRs), K-tile double buffer of 2 x 64 KB filled by global_load_lds.  Waves 0-3 and waves 4-7
 // (the two waves of every SIMD) run ONE barrier apart: every K-tile is four quadrant phases
-// {ds_read fragments + issue loads | 16 MFMAs}, and while one group is in its load segment the
-// other group owns the matrix pipe.  The prefetch of tile t+1 is issued in phases 0-1 of tile t
-// and waited for (vmcnt(0), four segments later, nothing else in flight) in phase 3 before the
-// barrier that lets the other group read it.  Per CU and K-tile: 64 KB from L2 (32 B/clk) and
-// 192 KB of conflict-free ds_read_b128 for 2048 MFMA cycles.
-// A may be a time-delay view (pika_operand_t with pad == 0, C % 64 == 0): a K-tile never straddles
-// a tap, so it only changes the per-tile source offset.
+// {ds_read fragments + two 1 KB load pieces | 16 MFMAs}, and while one group is in its load segment
+// the other group owns the matrix pipe.  Workgroups are persistent (one per CU); a fetch cursor runs
+// two K-tiles ahead of the MFMAs and across output-tile boundaries, loads are never drained (counted
+// vmcnt, see the K loop), tiles are walked XCD-aware in bands of PP_GM tile rows.  Per CU and K-tile:
+// 64 KB through LDS-DMA (about 30 cycles per 1 KB piece: the resource that bounds the loop) and
+// 192 KB of conflict-free ds_read_b128 for 2176 cycles of MFMA issue.
+// A may be a time-delay view (pika_operand_t, C % 64 == 0): a K-tile never straddles a tap, so it
+// only changes the per-tile source offset; rows whose source time leaves the signal read a zero page
+// (BOUNDS instantiation).  tests/test_gemm_schedule_model.py checks the buffer protocol.
 constexpr int PP_T = 256 * 128, PP_BUF = 2 * PP_T;
 #ifndef PP_GM
 #define PP_GM 4
