@@ -65,18 +65,23 @@ def cpu_baseline(lp, labels, tl, ul, n_utts, min_seconds=10.0):
                                                        x.shape[3], el)}, costs
 
 
-def train_step_workload(args, dev, rank, world):
+def train_step_workload(args, R_):
     """BASELINE.json configs[1] / SURVEY 8d M2: one full training step of the config-2 model fed by
     the HIP loader: pinned int16 audio (10.0 s / utterance, synthetic) -> speed/volume perturbation
     -> fbank (dither 1, as egs/fbank.conf) -> splice -> CMVN -> SpecAugment -> TDNN-Transformer encoder,
     conv-transformer prediction net, gated joint -> RNN-T loss -> backward -> inf-norm clip ->
     Nesterov SGD; with world > 1 a BMUF block sync (RCCL all-reduce of the flat parameter vector)
-    every 5 steps, as in the recipe.  Lattice T' = 240."""
+    every 5 steps, as in the recipe.  Lattice T' = 240.  The loader runs as in the product: a host thread
+    queues raw batches, the device half (upload + front-end kernels) runs on its own stream two batches ahead."""
+    import queue
+    import threading
     from types import SimpleNamespace
     from model.transducer import Net  # drop-in import path of the training script
     from warp_rnnt import RNNTLoss
     from pika_amd.features import SpecAugment, cmvn_apply_
     from pika_amd.loader.frontend import FbankConfig, GpuFrontEnd
+    from pika_amd.loader import otf_utt_loader as L
+    dev, rank, world = R_.dev, R_.rank, R_.world
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
@@ -86,14 +91,30 @@ def train_step_workload(args, dev, rank, world):
     model = Net(opt, 240, V).to(dev)
     model.train()
     cfg = FbankConfig(num_mel_bins=80, low_freq=40, high_freq=-200, dither=1.0, window_type="hamming")
-    fe = GpuFrontEnd(cfg, dev, lctx=1, rctx=1, stride=1)
+    fe = GpuFrontEnd(cfg, dev, lctx=1, rctx=1, stride=1, base_seed=2000 + rank, side_stream=True)
     n_samples = 400 + (T - 1) * 160      # T fbank frames at unchanged speed
     rng = np.random.default_rng(2000 + rank)
     pcms = [np.clip(rng.standard_normal(n_samples) * 3000, -32768, 32767).astype(np.int16) for _ in range(B)]
-    g = torch.Generator(device=dev)
-    g.manual_seed(2000 + rank)
-    labels = torch.randint(1, V, (B, U), generator=g, device=dev)
-    ali = torch.full((B,), U, dtype=torch.int32, device=dev)
+    lab_np = rng.integers(1, V, (B, U)).astype(np.int32)
+    largs = SimpleNamespace(padding_tgt=V, batch_first=True)
+    raw, stop = queue.Queue(4), threading.Event()
+
+    def host_half():    # what otf_utt_loader.host_batches yields: (pcm, speed, target dB, labels, frames) per utterance
+        while not stop.is_set():
+            # speed 1.0 keeps the benchmark shape fixed (T frames); the level perturbation is drawn
+            dbs = rng.uniform(-50.0, -10.0, B)
+            item = [(pcms[i], 1.0, float(dbs[i]), lab_np[i], T) for i in range(B)]
+            while not stop.is_set():
+                try:
+                    raw.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    pass
+        raw.put(None)
+    th = threading.Thread(target=host_half)
+    th.daemon = True
+    th.start()
+    batches = iter(L.DevicePrefetcher(raw, 1, fe, largs))
     offset = torch.full((240,), -8.0, device=dev)
     scale = torch.full((240,), 0.25, device=dev)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
@@ -103,18 +124,18 @@ def train_step_workload(args, dev, rank, world):
     if world > 1:
         from trainer.bmuf import BmufTrainer
         bmuf = BmufTrainer(0, rank, world, model, 0.9, 1.0)
+        bmuf.collective_events = []
 
     def step():
         state["optim"].zero_grad(set_to_none=True)
-        # speed 1.0 keeps the benchmark shape fixed (T frames); the level perturbation is drawn
-        dbs = np.random.uniform(-50.0, -10.0, B)
-        data, flens = fe(pcms, [1.0] * B, list(dbs))
-        lens = torch.tensor(flens, dtype=torch.int32, device=dev)
-        len_b = lens - 42                       # train_transducer_bmuf_otfaug.py:80-82
+        data, target, lens, ali = next(batches)
+        labels = target.to(dev)                 # train_transducer_bmuf_otfaug.py:79-85 (`.cuda(local_rank)`)
+        lens, ali = lens.to(dev), ali.to(dev)
+        len_b = lens - 42                       # :80-82
         len_b = len_b // 4 + (len_b % 4 != 0).int()
         cmvn_apply_(data, offset, scale, cmn=True)
         aug.apply(data)
-        out = model(data, labels, len_b, True)
+        out = model(data, labels.long(), len_b, True)
         loss = loss_fn(out, labels.int(), len_b, ali).sum()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
@@ -125,46 +146,62 @@ def train_step_workload(args, dev, rank, world):
             state["optim"] = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
         return loss
 
+    def close():
+        stop.set()
+        for _ in batches:
+            pass
+        th.join()
+    step.close, step.frontend, step.bmuf = close, fe, bmuf
     flops_per_utt = 730e9  # ~243 GF fwd, x3 fwd+bwd (split fc1/fc_gate)
     return step, flops_per_utt
 
 
-def run_train_step(args, dev, rank, world, steps, warmup):
+def run_train_step(args, R_, steps, warmup):
     from pika_amd import gemm as G
+    world = R_.world
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
-    step, flops_per_utt = train_step_workload(args, dev, rank, world)
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+    step, flops_per_utt = train_step_workload(args, R_)
+    try:
+        for _ in range(warmup):
+            step()
+        if step.bmuf is not None:
+            step.bmuf.collective_events = []
+        fe = step.frontend
+        fe.host_seconds, fe.batches = 0.0, 0
+        el, loss = R_.timed(step, steps, 0)
+        loss = float(loss.item())
+    finally:
+        step.close()
     tf = flops_per_utt * B / (el / steps) / 1e12
-    return {"metric": "utterances/sec RNNT train step (T_in=%d,U=%d,V=%d)" % (T, U, V),
-            "value": B * world / (el / steps), "unit": "utterances/s", "n_gpus": world,
-            "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if G.PRECISION == "bf16" else "f32-split", "data": "synthetic",
-            "config": {"workload": "train_step (BASELINE configs[1]): full PIKA TDNN-Transformer RNN-T, HIP "
-                                   "loader from pinned int16 audio (fbank+splice), CMVN, SpecAugment, fwd, "
-                                   "RNN-T loss, bwd, clip, SGD%s" % (", BMUF all-reduce every 5 steps" if world > 1 else ""),
-                       "batch_per_gpu": B, "T_in": T, "T_enc": 240, "U": U, "V": V,
-                       "global_batch": B * world, "parallelism": "bmuf-dp%d" % world,
-                       "loss": float(loss.item())},
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": tf / 2500.0, "traffic": None}}
+    out = {"metric": "utterances/sec RNNT train step (T_in=%d,U=%d,V=%d)" % (T, U, V),
+           "value": B * world / (el / steps), "unit": "utterances/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if G.PRECISION == "bf16" else "f32-split", "data": "synthetic",
+           "config": {"workload": "train_step (BASELINE configs[1]): full PIKA TDNN-Transformer RNN-T, HIP "
+                                  "loader from pinned int16 audio (fbank+splice) on a side stream, CMVN, SpecAugment, "
+                                  "fwd, RNN-T loss, bwd, clip, SGD%s" % (", BMUF all-reduce every 5 steps" if world > 1 else ""),
+                      "batch_per_gpu": B, "T_in": T, "T_enc": 240, "U": U, "V": V,
+                      "global_batch": B * world, "parallelism": "bmuf-dp%d" % world, "loss": loss},
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": tf / 2500.0, "traffic": None},
+           "loader": {"host_ms_per_batch": fe.host_seconds / max(fe.batches, 1) * 1e3, "batches": fe.batches,
+                      "note": "host time of the loader's device half (staging + launches), spent on the loader "
+                              "thread; its kernels run on a side stream"}}
+    if step.bmuf is not None:
+        evs = step.bmuf.collective_events
+        ms = [a.elapsed_time(b) for a, b in evs]
+        nbytes = step.bmuf.delta.numel() * 4
+        out["bmuf"] = {"syncs": len(ms), "sync_period": 5, "all_reduce_bytes": nbytes,
+                       "all_reduce_ms": float(np.mean(ms)) if ms else None,
+                       "all_reduce_ms_max": float(np.max(ms)) if ms else None, "backend": R_.backend,
+                       # direct (all-to-all reduce-scatter + all-gather: bytes/N per link per phase, every
+                       # link busy) = 0.6 ms at N = 8; a ring all-reduce pushes 2(N-1)/N x the bytes through ONE 153 GB/s
+                       # link per GPU = 4.1 ms at N = 8
+                       "bound_direct_ms": 2.0 * (nbytes / world) / 153e9 * 1e3,
+                       "bound_ring_ms": 2.0 * (world - 1) / world * nbytes / 153e9 * 1e3,
+                       "amortised_ms_per_step": (float(np.mean(ms)) / 5.0) if ms else None}
+    return out
 
 
 def decode_workload(args, dev, rank):
@@ -337,6 +374,317 @@ def mbr_workload(args, dev, rank):
     return step, info
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`bench.py --gpus N` from a plain shell: start N ranks, one per GPU, the way the recipe does
+    (egs/train_transducer_bmuf_otfaug.sh:155-156 launches nproc_per_node workers itself) and the way the driver
+    launches us.  The ranks inherit stdout: rank 0 prints the ONE JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Ranks(object):
+    """Rank bookkeeping + the timing contract: barrier + synchronize on both sides, MAX over ranks."""
+
+    def __init__(self, dry_run):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dry_run = dry_run
+        if dry_run:
+            self.dev = torch.device("cpu")
+        else:
+            if "PIKA_BENCH_DEVICE" in os.environ:      # test hook: several ranks on one GPU (gloo backend)
+                self.local_rank = int(os.environ["PIKA_BENCH_DEVICE"])
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("PIKA_BENCH_BACKEND", "gloo" if dry_run else "nccl")   # "nccl" is RCCL on ROCm
+            dist.init_process_group(backend=backend, init_method="env://")
+            self.backend = backend
+        else:
+            self.backend = None
+
+    def sync(self):
+        if not self.dry_run:
+            torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        if not self.dry_run:
+            torch.cuda.synchronize()
+
+    def timed(self, step, steps, warmup):
+        """warmup untimed steps, then EXACTLY `steps` steps between two barriers; seconds, max over ranks."""
+        last = None
+        for _ in range(warmup):
+            last = step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        self.sync()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, last
+
+    def finish(self):
+        if self.world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def leg_rnnt_loss_m1(args, R_, ragged=False):
+    """Headline: RNNTLoss.apply(...).sum().backward() on a resident (B,T,U+1,V) fp32 lattice."""
+    from warp_rnnt import RNNTLoss  # the drop-in import the reference scripts use
+    from pika_amd import rnnt as R
+    dev, rank, world = R_.dev, R_.rank, R_.world
+    B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    lp, labels, tl, ul = make_inputs(B, T, U, V, dev, 1234 + 100 * rank)
+    if ragged:      # SURVEY 8d M1 ragged variant: T_n ~ U{600..1000}, U_n ~ U{20..50}, seed 1236, labels padded with V
+        g = torch.Generator().manual_seed(1236 + 100 * rank)
+        tl = torch.randint(int(0.6 * T), T + 1, (B,), generator=g).int().to(dev)
+        ul = torch.randint(int(0.4 * U), U + 1, (B,), generator=g).int().to(dev)
+        labels = torch.where(torch.arange(U, device=dev).unsqueeze(0) < ul.unsqueeze(1), labels,
+                             torch.full_like(labels, V))
+    lp.requires_grad_(True)
+    loss_fn = RNNTLoss(blank=0, reduction="sum").apply
+    box = {}
+
+    def step():
+        lp.grad = None
+        box["costs"] = loss_fn(lp, labels, tl, ul)
+        box["costs"].sum().backward()
+
+    for _ in range(args.warmup):
+        step()
+    R.KERNEL_EVENTS = {"fwd": [], "bwd": []}  # HIP events on the launch stream, per C-ABI call
+    el, _ = R_.timed(step, args.steps, 0)
+    ev, R.KERNEL_EVENTS = R.KERNEL_EVENTS, None
+    costs = box["costs"]
+    out = None
+    if rank == 0:
+        ms_step = el / args.steps * 1e3
+        bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]]))
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
+        cells = T * (U + 1)
+        bytes_per_utt = cells * V * 4 + 2 * cells * 4 + 4 * cells * 4  # SURVEY 8d M1
+        achieved = bytes_per_utt * B / (bwd_ms * 1e-3) / 1e9
+        # measured ceiling for a pure write stream of the same size (hipMemsetAsync)
+        gbuf = lp.grad
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            gbuf.zero_()
+        e1.record()
+        torch.cuda.synchronize()
+        fill_gbps = gbuf.numel() * 4 * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "rnnt_grad_pmc.json")
+        if os.path.exists(pmc) and (T, U, V) == (1000, 50, 5000) and not ragged:
+            # PMC counters need their own rocprofv3 passes, so this is NOT measured in this run: it is the committed
+            # measurement of the same kernel at (B=32,T=1000,U=50,V=5000), scaled by the batch
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch") * B / 32.0
+            traffic_src = "profiles/rnnt_grad_pmc.json (separate --pmc WRITE_SIZE / FETCH_SIZE passes, not this run)"
+        out = {
+            "metric": "utterances/sec RNNT fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
+            "value": B * world / (el / args.steps), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "rnnt_loss_M1%s: warp_rnnt.RNNTLoss.apply(...).sum().backward() on "
+                                   "log_softmax(randn) (B,T,U+1,V) fp32, dense grad out" % (
+                                       " (ragged lengths T_n~U{%d..%d}, U_n~U{%d..%d})" % (
+                                           int(0.6 * T), T, int(0.4 * U), U) if ragged else ""),
+                       "batch_per_gpu": B, "T": T, "U": U, "V": V, "global_batch": B * world,
+                       "parallelism": "utterance-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "rnnt_grad_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes_per_utt * B,
+                         "kernel_ms": bwd_ms, "forward_ms": fwd_ms, "measured_fill_GBps": fill_gbps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, c_cpu = cpu_baseline(lp.detach(), labels, tl, ul, min(args.cpu_utts, B))
+            out["cpu_baseline"] = cb
+            c_gpu = costs.detach()[:len(c_cpu)].cpu().numpy()
+            out["cpu_baseline"]["max_rel_cost_diff_vs_gpu"] = float(np.max(np.abs(c_gpu - c_cpu) / np.abs(c_cpu)))
+    lp.grad = None
+    del lp, labels, tl, ul, costs, box
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_train_step(args, R_, steps, warmup, with_cpu):
+    """Secondary leg: BASELINE configs[1]/[2] train step at this N, bf16 and (a few steps) fp32-split arithmetic,
+    the BMUF exchange isolated by HIP events, the loader's host time, and the CPU leg at N=1."""
+    from pika_amd import gemm as G
+    try:
+        ts = run_train_step(args, R_, steps, warmup)
+        keep = ("value", "unit", "ms_per_step", "dtype", "config", "roofline", "bmuf", "loader")
+        ts = {k: ts[k] for k in keep if k in ts}
+        if not args.no_fp32_leg:
+            old, G.PRECISION = G.PRECISION, "fp32"
+            try:
+                f32 = run_train_step(args, R_, 3, 1)
+            finally:
+                G.PRECISION = old
+            ts["fp32_split"] = {"ms_per_step": f32["ms_per_step"], "value": f32["value"], "dtype": f32["dtype"],
+                                "note": "same step with every GEMM as the exact 3-way bf16 split (the 1e-3 parity mode "
+                                        "of tests/test_model.py); loss %.4f vs %.4f in bf16 at the same step count is "
+                                        "NOT comparable (different step counts)" % (
+                                            f32["config"]["loss"], ts["config"]["loss"])}
+        if with_cpu and R_.rank == 0:
+            ts["cpu_baseline"] = cpu_baseline_train_step(args)
+    except Exception as e:  # the headline line must survive a failure of a secondary leg
+        import traceback
+        ts = {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-800:]}
+    torch.cuda.empty_cache()
+    return ts
+
+
+def cpu_baseline_train_step(args, B=2):
+    """CPU leg of the train step: the SAME module tree (reference layer structure) on PyTorch-CPU fp32 stock ops +
+    the oracle's C/OpenMP RNN-T loss, one step at B=2 on this box's host cores.  /root/reference does not exist on the
+    GPU box, so this is a port, not the reference's own files."""
+    from types import SimpleNamespace
+    from model.transducer import Net
+    from oracle import rnnt as O
+    O.build()
+    T, U, V = args.frames, args.labels, args.vocab
+    torch.set_num_threads(os.cpu_count() or 8)
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
+                          encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
+    torch.manual_seed(777)
+    model = Net(opt, 240, V)
+    model.train()
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(B, T, 240, generator=g)
+    labels = torch.randint(1, V, (B, U), generator=g)
+    len_b = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.int32)
+    ali = torch.full((B,), U, dtype=torch.int32)
+    optim = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
+    t0 = time.perf_counter()
+    optim.zero_grad(set_to_none=True)
+    out = model(data, labels, len_b, True)
+    costs, grads = O.rnnt_loss(out.detach().numpy(), labels.int().numpy(), len_b.numpy(), ali.numpy(), dtype=np.float32)
+    out.backward(torch.from_numpy(grads))
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+    optim.step()
+    el = time.perf_counter() - t0
+    return {"value": B / el, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 step, B=%d, T_in=%d, U=%d, V=%d: same module tree on PyTorch-CPU fp32 stock ops + oracle "
+                      "C/OpenMP RNN-T loss + clip + SGD, %.1f s (features given, no audio front end)" % (B, T, U, V, el)}
+
+
+def leg_decode(args, R_, with_cpu):
+    """Second half of BASELINE.json's metric: decode RTF at configs[4] (B=64, beam 16, n_best 16, 10 s utterances)."""
+    from types import SimpleNamespace
+    try:
+        a = SimpleNamespace(**vars(args))
+        a.batch, a.beam, a.frames, a.fst, a.las = 64, 16, 1000, False, False
+        step, cal_labels = decode_workload(a, R_.dev, R_.rank)
+        el, (ret, _) = R_.timed(step, 2, 1)
+        el /= 2
+        audio_s = a.batch * a.frames / 100.0
+        d = decode_report(a, step, ret, el, audio_s, R_.world, cal_labels)
+        d = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")}
+        if with_cpu and R_.rank == 0:
+            d["cpu_baseline"] = cpu_baseline_decode(a, decode_workload.blank_bias)
+    except Exception as e:
+        import traceback
+        d = {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-800:]}
+    torch.cuda.empty_cache()
+    return d
+
+
+def decode_bytes_per_step(model, rows):
+    """Algorithmic HBM bytes of ONE search step: every weight the step multiplies by, once, in bf16
+    (fc2 10.2 MB, the prediction halves of fc1/fc_gate, the prediction network), plus the per-row activations that
+    must cross HBM (gathered encoder halves in, hidden/state rows in and out).  The (rows,V) logits are NOT in it:
+    the fused step keeps them on chip."""
+    H, V = model.hid_dim, model.output_dim
+    w = model.fc2.weight.numel() + 2 * H * H
+    w += sum(p.numel() for p in model.decoder.parameters())
+    act = rows * (2 * H * 4 + 2 * H * 4 + H * 2 * 2)
+    return 2 * w + act
+
+
+def decode_report(a, step, ret, el, audio_s, world, cal_labels):
+    hyps = ret["predictions"]
+    nlab = float(np.mean([sum(1 for e in h[0] if int(e) != 0) for h in hyps]))
+    nsteps = float(np.mean([len(h[0]) + 1 for h in hyps]))
+    tm = step.decoder.timing
+    bps = decode_bytes_per_step(step.decoder.model, a.batch * a.beam)
+    achieved = bps * tm["steps"] / tm["search_s"] / 1e9
+    return {
+        "metric": "decode RTF (wall / audio seconds), batch beam search", "value": el / audio_s,
+        "unit": "RTF", "n_gpus": world, "steps": 2, "warmup": 1,
+        "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "decode (BASELINE configs[4]): B=%d beam=%d n_best=%d, %d-frame utterances, full model "
+                               "(%s prediction net), sm_scale 0.8%s%s; each rank decodes its own batch (replicas)" % (
+                                   a.batch, a.beam, a.beam, a.frames, a.pred_net,
+                                   ", bigram FST shallow fusion (device-resident FST, scale %g)" % a.fst_scale if a.fst else "",
+                                   ", fw+bw LAS rescoring of the n-best" if a.las else ""),
+                   "audio_seconds": audio_s, "utterances_per_s": a.batch * world / el,
+                   "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
+                   "calibration_labels": cal_labels, "blank_bias": decode_workload.blank_bias,
+                   "timing": tm},
+        "roofline": {"bound": "hbm", "kernel": "one beam-search step (all of its kernels; the search is "
+                                               "launch/latency-bound at %d rows)" % (a.batch * a.beam),
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "bytes_per_launch": bps, "search_steps": tm["steps"],
+                     "us_per_search_step": tm["search_s"] / max(tm["steps"], 1) * 1e6,
+                     "search_s": tm["search_s"]}}
+
+
+def cpu_baseline_decode(a, blank_bias, B=4):
+    """CPU leg of the decode: the same search (same module tree, same vectorised beam state, plain torch ops) on
+    PyTorch-CPU fp32 for B=4 utterances of the same length, beam 16.  A port -- the reference's own decoder
+    (per-utterance Python loops) is not on the GPU box."""
+    from types import SimpleNamespace
+    from model.transducer import Net
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    T, V = a.frames, a.vocab
+    torch.set_num_threads(os.cpu_count() or 8)
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type=a.pred_net, brnn=False,
+                          encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
+    torch.manual_seed(777)
+    model = Net(opt, 240, V).eval()
+    with torch.no_grad():
+        model.fc2.weight *= 8.0
+        model.fc2.bias[0] = blank_bias
+    g = torch.Generator().manual_seed(3000)
+    feats = torch.randn(B, T, 240, generator=g)
+    x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long)
+    dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    dec = TransducerDecoder(model, batch_size=B, beam_size=a.beam, n_best=a.beam, blk=0, global_scorer=GlobalScorer(),
+                            sm_scale=0.8, cuda=False, beam_prune=True, args=dargs)
+    t0 = time.perf_counter()
+    dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
+    el = time.perf_counter() - t0
+    return {"value": el / (B * T / 100.0), "unit": "RTF", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "B=%d utterances of %d frames, beam %d: same search on PyTorch-CPU fp32 stock ops, %.1f s, %d steps"
+                      % (B, T, a.beam, el, dec.timing["steps"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "rnnt_loss_M1p", "train_step", "decode", "mbr_step"])
@@ -350,29 +698,44 @@ def main():
     ap.add_argument("--labels", type=int, default=50)
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--cpu-utts", type=int, default=4)
+    ap.add_argument("--ragged", action="store_true", help="rnnt_loss_M1: the ragged-length variant of SURVEY 8d")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"],
+                    help="train_step: GEMM arithmetic (bf16 = config-2 mode; fp32 = exact 3-way bf16 split, the 1e-3 parity mode)")
     ap.add_argument("--blank-bias", type=float, default=None,
                     help="decode: use this fc2 blank bias instead of calibrating it (profiling runs)")
     ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
-    ap.add_argument("--fst-scale", type=float, default=0.02,
-                    help="decode --fst: LM weight (small: the synthetic LM is random, the search should keep emitting)")
+    ap.add_argument("--fst-scale", type=float, default=0.3, help="decode --fst: LM weight")
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the secondary full-train-step measurement of the default run")
+    ap.add_argument("--no-decode", action="store_true", help="skip the secondary decode-RTF measurement of the default run")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-split timing inside the train-step leg")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    dry_run = os.environ.get("PIKA_BENCH_DRYRUN") == "1"     # tests: launch/timing plumbing only, NO product compute
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args.gpus, sys.argv[1:])
+    if env_world is not None and args.gpus > 1 and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, env_world))
+    if not dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    if "PIKA_BENCH_DEVICE" in os.environ:      # test hook: several ranks on one GPU (gloo backend)
-        local_rank = int(os.environ["PIKA_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("PIKA_BENCH_BACKEND", "nccl"), init_method="env://")
+    R_ = Ranks(dry_run)
+    rank, world, dev = R_.rank, R_.world, R_.dev
+    if dry_run:
+        # what the CPU tests run: the rank launch, rendezvous, barrier/max-over-ranks timing and the JSON line,
+        # with a step that does nothing.  Not a measurement and marked as such.
+        el, _ = R_.timed(lambda: time.sleep(0.001), args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (launch plumbing only, no compute)", "value": None, "unit": None,
+                              "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": el / args.steps * 1e3, "backend": R_.backend}), flush=True)
+        R_.finish()
+        return
+    if args.precision is not None:
+        from pika_amd import gemm as G
+        G.PRECISION = args.precision
 
     from warp_rnnt import RNNTLoss  # the drop-in import the reference scripts use
     from pika_amd import rnnt as R
@@ -380,33 +743,13 @@ def main():
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
     if args.workload == "decode":
         step, cal_labels = decode_workload(args, dev, rank)
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ret, _ = step()
-        torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / args.steps
-        audio_s = B * T / 100.0
-        hyps = ret["predictions"]
-        nlab = float(np.mean([sum(1 for e in h[0] if int(e) != 0) for h in hyps]))
-        nsteps = float(np.mean([len(h[0]) + 1 for h in hyps]))
+        el, (ret, _) = R_.timed(step, args.steps, args.warmup)
+        el /= args.steps
         if rank == 0:
-            print(json.dumps({
-                "metric": "decode RTF (wall / audio seconds), batch beam search", "value": el / audio_s,
-                "unit": "RTF", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
-                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "decode: B=%d beam=%d n_best=%d, %d-frame utterances, full model "
-                                       "(%s prediction net), sm_scale 0.8%s%s" % (
-                                           B, args.beam, args.beam, T, args.pred_net,
-                                           ", bigram FST shallow fusion (device-resident FST, scale %g)" % args.fst_scale if args.fst else "",
-                                           ", fw+bw LAS rescoring of the n-best" if args.las else ""),
-                           "audio_seconds": audio_s, "utterances_per_s": B / el,
-                           "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
-                           "calibration_labels": cal_labels, "blank_bias": decode_workload.blank_bias,
-                           "timing": step.decoder.timing}}), flush=True)
+            d = decode_report(args, step, ret, el, B * T / 100.0, world, cal_labels)
+            d["steps"], d["warmup"] = args.steps, args.warmup
+            print(json.dumps(d), flush=True)
+        R_.finish()
         return
     if args.workload == "rnnt_loss_M1p":
         # SURVEY 8d M1': fused boundary logits -> (costs, d/dlogits); no log-prob tensor, no dense lp gradient
@@ -498,108 +841,25 @@ def main():
             dist.destroy_process_group()
         return
     if args.workload == "train_step":
-        out = run_train_step(args, dev, rank, world, args.steps, args.warmup)
+        out = run_train_step(args, R_, args.steps, args.warmup)
         if rank == 0:
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_train_step(args)
             print(json.dumps(out), flush=True)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        R_.finish()
         return
-    lp, labels, tl, ul = make_inputs(B, T, U, V, dev, 1234 + 100 * rank)
-    lp.requires_grad_(True)
-    loss_fn = RNNTLoss(blank=0, reduction="sum").apply
-
-    def step():
-        lp.grad = None
-        costs = loss_fn(lp, labels, tl, ul)
-        costs.sum().backward()
-        return costs
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    R.KERNEL_EVENTS = {"fwd": [], "bwd": []}  # HIP events on the launch stream, per C-ABI call
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        costs = step()
-    barrier()
-    el = time.perf_counter() - t0
-    ev = R.KERNEL_EVENTS
-    R.KERNEL_EVENTS = None
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-
-    if rank == 0:
-        ms_step = el / args.steps * 1e3
-        value = B * world / (el / args.steps)
-        bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]]))
-        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
-        cells = T * (U + 1)
-        bytes_per_utt = cells * V * 4 + 2 * cells * 4 + 4 * cells * 4
-        achieved = bytes_per_utt * B / (bwd_ms * 1e-3) / 1e9
-        # measured ceiling for a pure write stream of the same size (hipMemsetAsync)
-        gbuf = lp.grad
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            gbuf.zero_()
-        e1.record()
-        torch.cuda.synchronize()
-        fill_gbps = gbuf.numel() * 4 * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "rnnt_grad_pmc.json")
-        if os.path.exists(pmc):
-            # measured at (B=32,T=1000,U=50,V=5000); bytes scale with the batch, valid for that lattice only
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch") * B / 32.0 \
-                if (T, U, V) == (1000, 50, 5000) else None
-        out = {
-            "metric": "utterances/sec RNNT fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
-            "value": value, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "rnnt_loss_M1: warp_rnnt.RNNTLoss.apply(...).sum().backward() on "
-                                   "log_softmax(randn) (B,T,U+1,V) fp32, dense grad out",
-                       "batch_per_gpu": B, "T": T, "U": U, "V": V, "global_batch": B * world,
-                       "parallelism": "utterance-sharded x%d, no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "rnnt_grad_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "bytes_per_launch": bytes_per_utt * B,
-                         "kernel_ms": bwd_ms, "forward_ms": fwd_ms,
-                         "measured_fill_GBps": fill_gbps},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            cb, c_cpu = cpu_baseline(lp.detach(), labels, tl, ul, min(args.cpu_utts, B))
-            out["cpu_baseline"] = cb
-            c_gpu = costs.detach()[:len(c_cpu)].cpu().numpy()
-            out["cpu_baseline"]["max_rel_cost_diff_vs_gpu"] = float(
-                np.max(np.abs(c_gpu - c_cpu) / np.abs(c_cpu)))
+    out = leg_rnnt_loss_m1(args, R_, ragged=args.ragged)
     if not args.no_train_step:
-        # secondary measurement in the same run: the full configs[1] training step
-        lp.grad = None
-        gbuf = costs = None  # noqa: F841  (drop the 2 x 32 GB of the loss workload)
-        del lp, labels, tl, ul
-        torch.cuda.empty_cache()
-        try:
-            ts = run_train_step(args, dev, rank, world, max(5, min(args.steps, 10)), 2)
-            ts = {k: ts[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "roofline")}
-        except Exception as e:  # the headline line must survive a failure of the secondary leg
-            ts = {"error": "%s: %s" % (type(e).__name__, e)}
+        ts = leg_train_step(args, R_, max(5, min(args.steps, 10)), 2, world == 1 and not args.no_cpu_baseline)
         if rank == 0:
             out["train_step"] = ts
+    if not args.no_decode:
+        d = leg_decode(args, R_, world == 1 and not args.no_cpu_baseline)
+        if rank == 0:
+            out["decode"] = d
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    R_.finish()
 
 
 if __name__ == "__main__":

@@ -73,10 +73,30 @@ class BmufTrainer(object):
         self.delta_prev = torch.zeros_like(self.param)  # on EVERY rank (reference: master only)
         self.delta = torch.empty_like(self.param)
         self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.collective_events = None     # set to [] to have every all-reduce bracketed by HIP events
+
+    def _rebind_detached_parameters(self):
+        """The reference re-reads the parameters at every sync (`parameters_to_vector`, bmuf.py:84).  Here they are
+        views of `self.local`; anything that re-bound `p.data` since (model.to / .float(), load_state_dict(assign=True),
+        flatten_parameters, module re-wrapping) would silently detach the model from the block update.  Adopt the
+        parameter's CURRENT values and re-point it.  (~300 pointer compares per sync.)"""
+        off, base, n_fixed = 0, self.local.data_ptr(), 0
+        for p in self.model.parameters():
+            k = p.numel()
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32 or p.device != self.local.device:
+                self.local[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.local[off:off + k].view(p.shape)
+                n_fixed += 1
+            off += k
+        if off != self.local.numel():
+            raise RuntimeError("BmufTrainer: the model's parameter count changed since construction "
+                               "(%d -> %d elements)" % (self.local.numel(), off))
+        return n_fixed
 
     # -- the block update ----------------------------------------------------------------
     def update_and_sync(self):
         n = self.param.numel()
+        self._rebind_detached_parameters()
         if self.is_hip:
             lib = _lib.lib()
             with torch.cuda.device(self.param.device):
@@ -84,7 +104,14 @@ class BmufTrainer(object):
                                                self.delta.data_ptr(), n, _stream()), "pika_bmuf_delta")
         else:
             torch.sub(self.param, self.local, out=self.delta)
+        ev = None
+        if self.collective_events is not None and self.is_hip:      # bench.py: HIP events around the exchange step
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_reduce(self.delta, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            ev[1].record()
+            self.collective_events.append(ev)
         if self._has_nan():
             return STOP
         inv_world = 1.0 / float(self.world_size)

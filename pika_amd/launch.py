@@ -1,6 +1,6 @@
 """Runs an UNCHANGED PIKA script against the drop-in packages:
 
-    python -m pika_amd.launch [--preload mod ...] /path/to/pika/trainer/train_transducer_bmuf_otfaug.py <its args>
+    python -m pika_amd.launch [--preload mod ...] [--legacy-int-div] /path/to/pika/trainer/train_transducer_bmuf_otfaug.py <its args>
 
 What it absorbs (SURVEY.md 8b "legacy-runtime conventions"), without touching the script:
   * import resolution: `pika_amd/dropin` goes first on sys.path, so `warp_rnnt`, `trainer.*`,
@@ -10,7 +10,9 @@ What it absorbs (SURVEY.md 8b "legacy-runtime conventions"), without touching th
   * `--local-rank=N` (what torch.distributed.launch passes today) -> `--local_rank N`, or the
     LOCAL_RANK environment variable when neither is given;
   * `torch.load` of whole-module pickles (`weights_only` now defaults to True);
-  * integer-tensor `/` as floor division (torch <= 1.4 semantics the decode scripts rely on).
+  * integer-tensor `/` as integer division (torch <= 1.4 semantics) ONLY on request (`--legacy-int-div`): the one
+    reference line that relies on it (decoder/beam_transducer.py:125) lives in a module the drop-in `decoder`
+    package replaces, so the process-wide patch is off unless a user script of its own needs it.
 """
 import importlib
 import math
@@ -23,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DROPIN = os.path.join(HERE, "dropin")
 
 
-def install_shims():
+def install_shims(legacy_int_div=False):
     import torch
     if "torch._six" not in sys.modules:
         six = types.ModuleType("torch._six")
@@ -37,14 +39,16 @@ def install_shims():
         kw.setdefault("weights_only", False)
         return real_load(*a, **kw)
     torch.load = load
-    true_div = torch.Tensor.__truediv__
+    if legacy_int_div:
+        true_div = torch.Tensor.__truediv__
 
-    def legacy_div(a, b):
-        if not a.dtype.is_floating_point and not a.dtype.is_complex and (
-                isinstance(b, int) or (isinstance(b, torch.Tensor) and not b.dtype.is_floating_point)):
-            return torch.div(a, b, rounding_mode="floor")
-        return true_div(a, b)
-    torch.Tensor.__truediv__ = legacy_div
+        def legacy_div(a, b):
+            if not a.dtype.is_floating_point and not a.dtype.is_complex and (
+                    isinstance(b, int) or (isinstance(b, torch.Tensor) and not b.dtype.is_floating_point
+                                           and not b.dtype.is_complex)):
+                return torch.div(a, b, rounding_mode="trunc")     # C semantics, as torch <= 1.4
+            return true_div(a, b)
+        torch.Tensor.__truediv__ = legacy_div
 
 
 def fix_argv(argv):
@@ -65,8 +69,11 @@ def fix_argv(argv):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    preload = []
-    while argv and argv[0] == "--preload":
+    preload, legacy_int_div = [], False
+    while argv and argv[0] in ("--preload", "--legacy-int-div"):
+        if argv[0] == "--legacy-int-div":
+            legacy_int_div, argv = True, argv[1:]
+            continue
         preload.append(argv[1])
         argv = argv[2:]
     if not argv:
@@ -77,7 +84,7 @@ def main(argv=None):
         if p in sys.path:
             sys.path.remove(p)
         sys.path.insert(0, p)
-    install_shims()
+    install_shims(legacy_int_div)
     for m in preload:
         importlib.import_module(m)
     sys.argv = [script] + fix_argv(argv[1:])

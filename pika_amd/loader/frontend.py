@@ -87,20 +87,64 @@ class FbankConfig(object):
 
 
 class GpuFrontEnd(object):
-    def __init__(self, cfg, device, lctx=1, rctx=1, stride=1):
+    """One call = one batch: pinned host staging -> ONE H2D copy -> perturbation, fbank, splice/pad kernels.
+
+    Host staging is a persistent ring of pinned buffers (a buffer is re-used only after the HIP event recorded
+    behind its upload has completed; nothing is allocated or pinned per batch once the ring has grown to the batch
+    size).  Sample data, the three offset tables and the target levels travel in the SAME buffer, so a batch costs
+    one asynchronous copy.  With `side_stream=True` all device work is issued on the front end's own HIP stream and
+    `ready` (a HIP event) marks its end: the consumer's stream waits on the event (`wait_ready`), the host never
+    does -- batch n+1 is produced while step n computes (otf_utt_loader.DevicePrefetcher drives it from a thread).
+
+    Dither noise is a counter-based generator keyed by (base_seed, front-end instance, batch number): a new front
+    end per epoch (what `dataloader` does) or per rank never replays an earlier sequence."""
+
+    _instances = 0
+
+    def __init__(self, cfg, device, lctx=1, rctx=1, stride=1, base_seed=0, ring=3, side_stream=False):
         if device.type != "cuda":
             raise RuntimeError("pika_amd GpuFrontEnd needs a HIP device (no CPU path)")
         self.cfg, self.device = cfg, device
         self.lctx, self.rctx, self.stride = lctx, rctx, stride
         self.plan = [torch.from_numpy(a).to(device) for a in cfg.mel_plan()]
-        self.seed = 0
+        GpuFrontEnd._instances += 1
+        self.seed_hi = ((int(base_seed) & 0x7FFFFF) << 40) | ((GpuFrontEnd._instances & 0xFF) << 32)
+        self.batch_no = 0
+        self._ring = [None] * max(int(ring), 1)     # [pinned uint8 tensor, event of its last upload]
+        self._slot = 0
+        self.stream = torch.cuda.Stream(device) if side_stream else None
+        self.ready = None                           # event behind the last batch's kernels
+        self.host_seconds, self.batches = 0.0, 0    # host time spent inside __call__ (staging + launches)
+
+    @property
+    def seed(self):
+        return self.seed_hi | (self.batch_no & 0xFFFFFFFF)
+
+    def _stage(self, nbytes):
+        """Next pinned buffer of the ring, at least nbytes long, free of in-flight uploads."""
+        i = self._slot
+        self._slot = (i + 1) % len(self._ring)
+        ent = self._ring[i]
+        if ent is not None:
+            ent[1].synchronize()        # only blocks when the device is a whole ring behind
+        if ent is None or ent[0].numel() < nbytes:
+            cap = max(int(nbytes * 1.25), 1 << 16)
+            ent = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
+            self._ring[i] = ent
+        return ent
+
+    def wait_ready(self, stream=None):
+        """Make `stream` (default: the current one) wait for the last batch; no host wait."""
+        if self.ready is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(self.ready)
 
     def __call__(self, pcms, rates, target_dbs, perturb=True):
         """pcms: list of int16 numpy arrays; rates / target_dbs: per-utterance speed and target
         RMS dB.  Returns (data (B,Tmax,D) f32 on the device, frame lengths list)."""
+        import time
+        t_host = time.perf_counter()
         cfg, dev = self.cfg, self.device
         lib = _lib.lib()
-        st = torch.cuda.current_stream().cuda_stream
         B = len(pcms)
         n_in = [len(p) for p in pcms]
         n_out = [n if (not perturb or r == 1.0) else int(n / r) for n, r in zip(n_in, rates)]
@@ -108,24 +152,37 @@ class GpuFrontEnd(object):
         out_off = np.concatenate(([0], np.cumsum(n_out))).astype(np.int64)
         frames = [cfg.num_frames(n) for n in n_out]
         fr_off = np.concatenate(([0], np.cumsum(frames))).astype(np.int64)
-        host = torch.empty(int(in_off[-1]), dtype=torch.int16).pin_memory()
-        host.numpy()[:] = np.concatenate(pcms) if B else np.zeros(0, np.int16)
-        with torch.cuda.device(dev):
-            pcm_d = host.to(dev, non_blocking=True)
-            offs = torch.from_numpy(np.stack([in_off, out_off, fr_off])).to(dev)
+        # staging layout (bytes): [3 x (B+1) i64 offsets][B f64 target dB][int16 samples]
+        n_samp = int(in_off[-1])
+        o_db = 3 * (B + 1) * 8
+        o_pcm = o_db + B * 8
+        nbytes = o_pcm + 2 * n_samp
+        host, up_ev = self._stage(nbytes)
+        hv = host.numpy()
+        hv[:o_db].view(np.int64).reshape(3, B + 1)[:] = (in_off, out_off, fr_off)
+        hv[o_db:o_pcm].view(np.float64)[:] = np.asarray(list(target_dbs), np.float64)[:B] if B else 0.0
+        if B:
+            np.concatenate(pcms, out=hv[o_pcm:nbytes].view(np.int16))
+        cur = torch.cuda.current_stream(dev)
+        st_t = self.stream or cur
+        with torch.cuda.device(dev), torch.cuda.stream(st_t):
+            st = st_t.cuda_stream
+            stage_d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            stage_d.copy_(host[:nbytes], non_blocking=True)
+            up_ev.record(st_t)
+            base = stage_d.data_ptr()
+            p_in, p_out, p_fr = base, base + (B + 1) * 8, base + 2 * (B + 1) * 8
             wave = torch.empty(max(int(out_off[-1]), 1), dtype=torch.float32, device=dev)
             if perturb:
-                db = torch.tensor(list(target_dbs), dtype=torch.float64, device=dev)
                 sumsq = torch.empty(B, dtype=torch.float64, device=dev)
-                _lib.check(lib.pika_audio_perturb(pcm_d.data_ptr(), offs[0].data_ptr(), offs[1].data_ptr(),
-                                                  db.data_ptr(), B, max(n_out), wave.data_ptr(),
+                _lib.check(lib.pika_audio_perturb(base + o_pcm, p_in, p_out, base + o_db, B, max(n_out), wave.data_ptr(),
                                                   sumsq.data_ptr(), st), "pika_audio_perturb")
             else:
-                wave[:int(out_off[-1])] = pcm_d.float()
+                wave[:int(out_off[-1])] = stage_d[o_pcm:nbytes].view(torch.int16).float()
             total = int(fr_off[-1])
             feats = torch.empty((max(total, 1), cfg.num_mel_bins), dtype=torch.float32, device=dev)
-            self.seed += 1
-            _lib.check(lib.pika_fbank(wave.data_ptr(), offs[1].data_ptr(), offs[2].data_ptr(), B, total,
+            self.batch_no += 1
+            _lib.check(lib.pika_fbank(wave.data_ptr(), p_out, p_fr, B, total,
                                       cfg.frame_len, cfg.shift, cfg.nfft, cfg.preemphasis_coefficient,
                                       cfg.dither, self.seed, cfg.num_mel_bins,
                                       *[p.data_ptr() for p in self.plan], feats.data_ptr(), st), "pika_fbank")
@@ -134,8 +191,14 @@ class GpuFrontEnd(object):
             D = cfg.num_mel_bins * (self.lctx + 1 + self.rctx)
             out = torch.zeros((B, max(t_max, 1), D), dtype=torch.float32, device=dev)
             if t_max > 0:
-                _lib.check(lib.pika_splice_pad(feats.data_ptr(), offs[2].data_ptr(), B, cfg.num_mel_bins,
+                _lib.check(lib.pika_splice_pad(feats.data_ptr(), p_fr, B, cfg.num_mel_bins,
                                                self.lctx, self.rctx, self.stride, t_max, out.data_ptr(),
                                                st), "pika_splice_pad")
+            if self.stream is not None:
+                self.ready = torch.cuda.Event()
+                self.ready.record(st_t)
+                out.record_stream(cur)      # allocated on the side stream, consumed on the caller's
         self.last_feats, self.last_wave, self.last_offsets = feats, wave, (in_off, out_off, fr_off)
+        self.host_seconds += time.perf_counter() - t_host
+        self.batches += 1
         return out, lens

@@ -114,6 +114,52 @@ def assemble(batch, frontend, args):
             torch.tensor([len(a) for a in alis], dtype=torch.int32))
 
 
+class DevicePrefetcher(object):
+    """Runs the device half of the loader (`assemble`: staging, upload, perturbation, fbank, splice) on the front
+    end's side stream from its own thread, `depth` batches ahead of the consumer.  The consumer's stream waits on
+    the batch's HIP event when it takes the batch (no host wait): the front end of batch n+1 overlaps step n.
+    Host batches come from `source` (a queue of raw batches; `None` x n_end marks the end)."""
+
+    _END = object()
+
+    def __init__(self, source, n_end, frontend, args, depth=2):
+        self.frontend, self.args = frontend, args
+        self.out = queue.Queue(max(int(depth), 1))
+        self.thread = Thread(target=self._run, args=(source, n_end))
+        self.thread.daemon = True
+        self.thread.start()
+
+    def _run(self, source, n_end):
+        done = 0
+        try:
+            with torch.cuda.device(self.frontend.device):
+                while done < n_end:
+                    item = source.get()
+                    if item is None:
+                        done += 1
+                        continue
+                    batch = assemble(item, self.frontend, self.args)
+                    self.out.put((batch, self.frontend.ready))
+        except BaseException as e:     # surfaces in the consumer, not in a dead thread
+            self.out.put((e, None))
+            return
+        self.out.put((self._END, None))
+
+    def __iter__(self):
+        while True:
+            batch, ready = self.out.get()
+            if batch is self._END:
+                break
+            if isinstance(batch, BaseException):
+                raise batch
+            if ready is not None:
+                torch.cuda.current_stream(self.frontend.device).wait_event(ready)
+                if batch[0] is not None:
+                    batch[0].record_stream(torch.cuda.current_stream(self.frontend.device))
+            yield batch
+        self.thread.join()
+
+
 def dataloader(data_lst, rir, noise, args, frontend=None):
     """Generator of (data, target, lens, ali_lens) batches (:116-163)."""
     cfg = FbankConfig.from_file(args.feat_config)
@@ -126,21 +172,28 @@ def dataloader(data_lst, rir, noise, args, frontend=None):
     parts = [triplets[i:i + per] for i in range(0, len(triplets), per)]
     assert len(parts) == args.num_workers                                    # :135
     if frontend is None:
-        dev = torch.device("cuda", getattr(args, "local_rank", 0) or 0)
-        frontend = GpuFrontEnd(cfg, dev, args.lctx, args.rctx, args.stride)
+        rank = getattr(args, "local_rank", 0) or 0
+        dev = torch.device("cuda", rank)
+        frontend = GpuFrontEnd(cfg, dev, args.lctx, args.rctx, args.stride,
+                               base_seed=(int(getattr(args, "seed", 0) or 0) * 64 + rank), side_stream=True)
     q = queue.Queue(args.queue_size)
     threads = [Thread(target=put_thread, args=(q, host_batches, part, cfg, args)) for part in parts]
     for t in threads:
         t.daemon = True
         t.start()
-    done = 0
-    while True:
-        item = q.get()
-        if item is None:
-            done += 1
-            if done == args.num_workers:
-                break
-            continue
-        yield assemble(item, frontend, args)
+    if getattr(frontend, "stream", None) is not None:
+        # device half on the front end's own stream, two batches ahead of the training step
+        for batch in DevicePrefetcher(q, args.num_workers, frontend, args):
+            yield batch
+    else:
+        done = 0
+        while True:
+            item = q.get()
+            if item is None:
+                done += 1
+                if done == args.num_workers:
+                    break
+                continue
+            yield assemble(item, frontend, args)
     for t in threads:
         t.join()

@@ -229,7 +229,9 @@ class _RNNTLossFn(torch.autograd.Function):
                         _ptr(x), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
                         _ptr(costs), _ptr(lse), _ptr(ws), _stream()), "pika_rnnt_fused_forward")
         else:
-            lp = log_probs.contiguous()     # (a LazyLogProbs is normalised here)
+            # a LazyLogProbs the fused path cannot take (already read, scaled, V out of the fused kernel's range) is
+            # normalised HERE: `.contiguous()` on the wrapper subclass short-circuits and would hand back the wrapper
+            lp = log_probs.dense() if isinstance(log_probs, LazyLogProbs) else log_probs.contiguous()
             with torch.cuda.device(lp.device):
                 costs = torch.empty(B, dtype=torch.float32, device=lp.device)
                 ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8,

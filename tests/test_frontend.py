@@ -145,3 +145,51 @@ def test_noise_and_reverb_augmentation_match_reference(hip_device):
         assert np.abs(got - want).max() < 1e-4 * np.abs(want).max(), k
     with pytest.raises(RuntimeError):
         A.rms_db(torch.zeros(4))                   # no CPU path
+
+
+@pytest.mark.gpu
+def test_side_stream_prefetch_gives_the_synchronous_batches(hip_device):
+    """The loader's device half on its own stream, driven two batches ahead by DevicePrefetcher (pinned ring, one
+    upload per batch, event hand-off to the consumer's stream), returns exactly what the synchronous front end
+    returns -- including when the consumer's stream is busy and the ring wraps around -- and a new front end (next
+    epoch / other rank) draws different dither noise."""
+    import queue
+    from types import SimpleNamespace
+    from pika_amd.loader.frontend import FbankConfig, GpuFrontEnd
+    from pika_amd.loader import otf_utt_loader as L
+    cfg = FbankConfig(num_mel_bins=80, low_freq=40, high_freq=-200, dither=0.0, window_type="hamming")
+    rng = np.random.default_rng(21)
+    raw_batches = []
+    for n_b in range(7):                                   # > 2 x ring slots: the ring wraps
+        batch = []
+        for _ in range(3):
+            n = int(rng.integers(3000, 20000))
+            pcm = np.clip(rng.standard_normal(n) * 2500, -32768, 32767).astype(np.int16)
+            rate = [0.9, 1.0, 1.1][int(rng.integers(0, 3))]
+            n_out = n if rate == 1.0 else int(n / rate)
+            batch.append((pcm, rate, float(rng.uniform(-50, -10)), rng.integers(1, 50, 4).astype(np.int32),
+                          cfg.num_frames(n_out)))
+        raw_batches.append(batch)
+    args = SimpleNamespace(padding_tgt=99, batch_first=True)
+    sync_fe = GpuFrontEnd(cfg, hip_device, 1, 1, 1)
+    want = [L.assemble(b, sync_fe, args) for b in raw_batches]
+    q = queue.Queue()
+    for b in raw_batches:
+        q.put(b)
+    q.put(None)
+    fe = GpuFrontEnd(cfg, hip_device, 1, 1, 1, side_stream=True)
+    big = torch.randn(4096, 4096, device=hip_device)
+    got = []
+    for batch in L.DevicePrefetcher(q, 1, fe, args):
+        for _ in range(3):
+            big = big @ big * 1e-3                          # keep the consumer's stream busy
+        got.append([t.clone() if torch.is_tensor(t) else t for t in batch])
+    assert len(got) == len(want) and fe.batches == 7 and fe.host_seconds > 0
+    for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2]) and torch.equal(g[3], w[3])
+    # dither: (base seed, instance, batch) keyed -- a second front end never replays the first one's noise
+    cfg_d = FbankConfig(num_mel_bins=80, low_freq=40, high_freq=-200, dither=1.0, window_type="hamming")
+    pcm = np.zeros(16000, np.int16)
+    a = GpuFrontEnd(cfg_d, hip_device, base_seed=7)([pcm], [1.0], [0.0], perturb=False)[0]
+    b = GpuFrontEnd(cfg_d, hip_device, base_seed=7)([pcm], [1.0], [0.0], perturb=False)[0]
+    assert not torch.equal(a, b)

@@ -162,8 +162,11 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
                 lp.register_hook(lambda t: (seen.append(type(t)), t * 1.0)[1])
             if mode == "retain":
                 lp.retain_grad()
+            pre = (lp.detach() * 1.0).sum() if mode == "read_first" else None   # normalises the buffer BEFORE the loss
             costs = RNNTLoss().apply(lp, labels, tl, ul)
             loss = (costs * scale).sum()
+            if mode == "read_first":
+                assert torch.isfinite(pre) and not (lazy and lp.state.raw)
             if mode == "second":
                 loss = loss + 0.25 * (lp * lp).sum()
             raw_after_forward = lazy and lp.state.raw
@@ -185,7 +188,7 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
         close(lazy["dw"], eager["dw"], 2e-4)
         close(lazy["db"], eager["db"], 2e-4)
         close(lazy["dh"], eager["dh"], 1e-2)                              # bf16 matrices: a few one-ulp flips
-        for mode in ("hook", "second", "retain", "values", "twice"):
+        for mode in ("hook", "second", "retain", "values", "twice", "read_first"):
             e, l = run(False, mode), run(True, mode)
             close(l["costs"], e["costs"], 2e-6)
             close(l["dw"], e["dw"], 2e-4)
@@ -204,5 +207,40 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
                 assert type(l["lp"]) is torch.Tensor
                 close(l["lp"], e["lp"], 1e-6)
                 assert torch.allclose(l["lp"].exp().sum(-1), torch.ones_like(l["lp"][..., 0]), atol=1e-5)
+    finally:
+        G.PRECISION = old
+
+
+@pytest.mark.gpu
+def test_lazy_log_probs_outside_the_fused_loss_range(hip_device, monkeypatch):
+    """ADVICE r1 (rnnt.py:232): a LazyLogProbs the fused loss cannot take -- here V = 5128 > 5120, which the joint's
+    lazy output (N <= 8192) allows -- must be normalised by the loss' fallback path, not passed on as the wrapper."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
+    from pika_amd.rnnt import RNNTLoss, LazyLogProbs
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(11)
+        B, T, U, H, V = 2, 5, 3, 64, 5128
+        h = (torch.randn(B, T, U + 1, H, generator=g) * 0.5).bfloat16().to(hip_device)
+        w = (torch.randn(V, H, generator=g) * 0.3).to(hip_device)
+        b = (torch.randn(V, generator=g) * 0.1).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        tl = torch.tensor([T, T - 1], dtype=torch.int32, device=hip_device)
+        ul = torch.tensor([U, U - 2], dtype=torch.int32, device=hip_device)
+
+        def run(lazy):
+            monkeypatch.setenv("PIKA_RNNT_LAZY_GRAD", "1" if lazy else "0")
+            hh, ww, bb = (t.clone().requires_grad_(True) for t in (h, w, b))
+            lp = JointOutFn.apply(hh, ww, bb, 1.0, lazy)
+            lp._pika_lazy_grad_ok = True
+            assert isinstance(lp, LazyLogProbs) == lazy
+            costs = RNNTLoss().apply(lp, labels, tl, ul)
+            costs.sum().backward()
+            return costs.detach(), hh.grad.float(), ww.grad, bb.grad
+        e, l = run(False), run(True)
+        assert torch.isfinite(l[0]).all()
+        for a, d, tol in zip(l, e, (2e-6, 1e-2, 2e-4, 3e-3)):
+            assert (a - d).abs().max().item() <= tol * d.abs().max().item() + 1e-12
     finally:
         G.PRECISION = old

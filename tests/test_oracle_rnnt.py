@@ -1,9 +1,11 @@
 """Pins the CPU restatement of the RNN-T loss (oracle/rnnt_loss_ref.c).
 
 The reference's loss lives in un-vendored `warp_rnnt`, and the reference holds no golden
-vector for it (PARITY UNPINNED), so the oracle is pinned from first principles:
-exhaustive path enumeration, finite differences, alpha/beta consistency, and the committed
-fixture tests/golden/rnnt_loss_small.npz (made by tests/golden/make_rnnt_golden.py).
+vector for it, so the oracle is pinned (a) against the known-answer test that
+warp_rnnt / warp-transducer publish in their own test suites (tests/golden/rnnt_kat.npz: cost AND
+gradient, literals of the upstream tests) and (b) from first principles: exhaustive path enumeration,
+finite differences, alpha/beta consistency, and the committed fixture tests/golden/rnnt_loss_small.npz
+(made by tests/golden/make_rnnt_golden.py).
 """
 import os
 
@@ -14,6 +16,22 @@ from oracle import rnnt as O
 from helpers import make_case
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "rnnt_loss_small.npz")
+KAT = os.path.join(os.path.dirname(__file__), "golden", "rnnt_kat.npz")
+
+
+def test_upstream_known_answer_cost_and_gradient():
+    """warp-transducer tests/test_cpu.cpp::small_test == warp_rnnt's test: acts (1,2,3,5), labels [1,2] -> cost
+    4.495666 and d cost / d acts (the loss is applied to log_softmax(acts)); both oracle precisions."""
+    z = np.load(KAT)
+    acts = z["acts"].astype(np.float64)
+    lp = acts - np.log(np.exp(acts).sum(-1, keepdims=True))
+    for dtype, tol in ((np.float64, 2e-7), (np.float32, 1e-6)):
+        costs, g = O.rnnt_loss(lp.astype(np.float32), z["labels"], z["frames_lengths"], z["labels_lengths"], dtype=dtype)
+        assert abs(costs[0] - z["cost"][0]) < 1e-6                 # published to 7 significant digits
+        # chain rule through log_softmax: d/d acts = g - softmax * sum_v g
+        g = g.astype(np.float64)
+        d_acts = g - np.exp(lp) * g.sum(-1, keepdims=True)
+        assert np.abs(d_acts - z["grads_wrt_acts"]).max() < tol + 2e-7
 
 
 @pytest.mark.parametrize("T,U,V,seed", [(1, 0, 3, 0), (1, 2, 4, 1), (3, 0, 4, 2), (4, 3, 5, 3),

@@ -50,6 +50,20 @@ def test_native_library_is_loaded(hip_device):
     assert "libpika_amd.so" in maps
 
 
+def test_upstream_known_answer(hip_device):
+    """The KAT warp_rnnt / warp-transducer ship (tests/golden/make_rnnt_kat.py): cost 4.495666 and the published
+    gradient w.r.t. the activations, through the product loss + autograd's log_softmax backward."""
+    from pika_amd import rnnt as R
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rnnt_kat.npz"))
+    acts = torch.from_numpy(z["acts"]).to(hip_device).requires_grad_(True)
+    lp = torch.log_softmax(acts, dim=-1)
+    costs = R.RNNTLoss(blank=0, reduction="sum").apply(lp, *[torch.from_numpy(z[k]).to(hip_device) for k in
+                                                             ("labels", "frames_lengths", "labels_lengths")])
+    costs.sum().backward()
+    assert abs(float(costs[0]) - float(z["cost"][0])) < 2e-6
+    assert np.abs(acts.grad.cpu().numpy().astype(np.float64) - z["grads_wrt_acts"]).max() < 1e-6
+
+
 def test_golden_fixture(hip_device):
     z = np.load(GOLD)
     c, g, (a, b) = run_hip(hip_device, z["log_probs"], z["labels"], z["frames_lengths"],
