@@ -130,3 +130,126 @@ def test_risk_grad_kernel(hip_device):
     s.backward()
     assert (ld.grad.double().cpu() - lr.grad).abs().max() < 1e-5
     assert torch.all(ld.grad[5] == 0)
+
+
+# ---- pinned against the reference SCRIPT itself (tests/golden/make_mbr_script_golden.py) ---------------------------
+GOLD_SCRIPT = os.path.join(HERE, "golden", "mbr_script_grads.npz")
+MBR_SCRIPT = "/root/reference/trainer/train_transducer_mbr_bmuf_otfaug.py"
+
+
+@pytest.mark.skipif(not os.path.exists(MBR_SCRIPT), reason="reference tree not present on this box")
+def test_unchanged_mbr_script_on_the_dropins_reproduces_the_reference_gradients(tmp_path):
+    """The UNCHANGED train_transducer_mbr_bmuf_otfaug.py, one batch, every parameter gradient before its first
+    optimizer step: run on the drop-in packages (CPU tensors) vs the golden recorded from the same script on the
+    reference's own trainer.model.* / decoder.* -- same N-best, gradients to 1e-3."""
+    import subprocess
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import mbr_hooks as M
+    from bmuf_common import free_port
+    out = str(tmp_path / "dropin.npz")
+    env = dict(os.environ, MASTER_PORT=str(free_port()), OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "mbr_hooks.py"), "dropin", out], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got, want = np.load(out), np.load(GOLD_SCRIPT)
+    assert np.array_equal(got["hyps"], want["hyps"])
+    assert np.abs(got["scores"] - want["scores"]).max() < 1e-4
+    M.compare(got, want, rel=1e-3)
+
+
+def _native_step_vs_script_golden(device):
+    """pika_amd.mbr (device trajectories, split joint, sparse risk surrogate / HIP risk-gradient kernel) fed with
+    the same seeded model and fixture batch as the golden run of the reference script: same N-best out of the
+    drop-in decoder, and RNN-T + risk gradients equal to what the script's inline code produced."""
+    import argparse
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    import importlib.util
+    import mbr_hooks as M
+    spec = importlib.util.spec_from_file_location(
+        "mbr_fixture_loader", os.path.join(HERE, "golden", "mbr_fixture", "loader", "otf_utt_loader.py"))
+    fixture = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fixture)
+    from oracle.pika_ref import seeded_state_dict
+    from model.transducer import Net
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd import mbr
+    from pika_amd.model import ops
+    want = np.load(GOLD_SCRIPT)
+    ap = argparse.ArgumentParser()
+    for k in ("--encoder_type", "--decoder_type", "--rnn_type"):
+        ap.add_argument(k)
+    for k in ("--enc_layers", "--dec_layers", "--rnn_size", "--embd_dim", "--padding_idx", "--output_dim"):
+        ap.add_argument(k, type=int)
+    ap.add_argument("--dropout", type=float)
+    opt = ap.parse_args(M.MODEL_ARGS)
+    opt.local_rank, opt.brnn = 0, False
+    net = Net(opt, 240, M.V)
+    net.encoder = type(net.encoder)(240, 0, opt.rnn_size, tdnn_nhid=64, tdnn_layers=6)
+    net.pack_seq = False
+    sd = seeded_state_dict(net, 1234)
+    sd["fc2.bias"][0] += 1.5
+    net.load_state_dict(sd)
+    net = net.to(device)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+            m.dropout = 0.0
+    largs = SimpleNamespace(feats_dim=80, lctx=1, rctx=1, batch_size=3, fixture_seed=31, fixture_batches=1,
+                            output_dim=M.V, padding_idx=M.V)
+    data, target, lens, ali = next(iter(fixture.dataloader(None, None, None, largs)))
+    data, target, ali = data.to(device), target.long().to(device), ali.to(device)
+    len_b = lens.to(device) - 24
+    len_b = len_b // 4 + (len_b % 4 != 0).int()
+    beam, blk, sm, rnnt_scale = 3, 0, 0.9, 0.1
+    dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    net.eval()
+    dec = TransducerDecoder(net, 3, beam, n_best=beam, blk=blk, global_scorer=GlobalScorer(), sm_scale=sm,
+                            cuda=(device != "cpu"), beam_prune=False, args=dargs)
+    ret, _ = dec.decode_batch(data, len_b, len_b + ali + 3)                         # :112-117
+    hyps, scores = ret["predictions"], ret["scores"]
+    L = want["hyps"].shape[2]
+    got_h = np.full(want["hyps"].shape, -1, np.int64)
+    for b, row in enumerate(hyps):
+        for j, h in enumerate(row):
+            got_h[b, j, :len(h)] = [int(e) for e in h]
+    assert np.array_equal(got_h, want["hyps"])
+    assert np.abs(np.array([[float(v) for v in r] for r in scores]) - want["scores"]).max() < 2e-3
+    net.train()
+    net.zero_grad()
+    enc = net.encoder(data)                                                       # :124-138
+    sos = torch.zeros(3, 1, dtype=torch.long, device=device)
+    pred = net.predict(torch.cat((sos, target), dim=1))
+    lp = ops.joint(enc, pred, net.fc1, net.fc_gate, net.fc2, log_softmax=True)
+    if device == "cpu":
+        from oracle import rnnt as O
+        costs, g = O.rnnt_loss(lp.detach().numpy(), target.int().numpy(), len_b.int().numpy(), ali.int().numpy(),
+                               dtype=np.float32)
+        lp.backward(rnnt_scale * torch.from_numpy(g), retain_graph=True)          # the checker stands in on CPU
+    else:
+        from pika_amd.rnnt import RNNTLoss
+        (rnnt_scale * RNNTLoss(blank=0).apply(lp, target.int(), len_b.int(), ali.int())).sum().backward(retain_graph=True)
+    prob, dist, seq_grad, nonblk = mbr.risk_terms(hyps, scores, target, ali, blk, enc.device)
+    mbr.mbr_backward(net, enc, hyps, seq_grad, nonblk, blk, sm)
+    grads = {"g%03d" % i: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy()
+             for i, p in enumerate(net.parameters())}
+    got = dict(M.compact(grads), n=np.array(len(grads)))
+    return M, got, want
+
+
+def test_cpu_native_mbr_step_matches_the_reference_script_golden():
+    M, got, want = _native_step_vs_script_golden("cpu")
+    M.compare(got, want, rel=1e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_native_mbr_step_matches_the_reference_script_golden(hip_device):
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        M, got, want = _native_step_vs_script_golden(hip_device)
+    finally:
+        G.PRECISION = old
+    M.compare(got, want, rel=2e-3)
