@@ -110,11 +110,15 @@ def train_step_workload(args, R_):
                     break
                 except queue.Full:
                     pass
-        raw.put(None)
+        try:
+            raw.put(None, timeout=1.0)
+        except queue.Full:
+            pass
     th = threading.Thread(target=host_half)
     th.daemon = True
     th.start()
-    batches = iter(L.DevicePrefetcher(raw, 1, fe, largs))
+    batches_obj = L.DevicePrefetcher(raw, 1, fe, largs)
+    batches = iter(batches_obj)
     offset = torch.full((240,), -8.0, device=dev)
     scale = torch.full((240,), 0.25, device=dev)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
@@ -148,9 +152,13 @@ def train_step_workload(args, R_):
 
     def close():
         stop.set()
-        for _ in batches:
+        t_end = time.time() + 5.0
+        try:
+            while time.time() < t_end:      # drain what is in flight; never block on a dead producer
+                batches_obj.out.get(timeout=0.2)
+        except Exception:
             pass
-        th.join()
+        th.join(timeout=2.0)
     step.close, step.frontend, step.bmuf = close, fe, bmuf
     flops_per_utt = 730e9  # ~243 GF fwd, x3 fwd+bwd (split fc1/fc_gate)
     return step, flops_per_utt
@@ -686,6 +694,9 @@ def cpu_baseline_decode(a, blank_bias, B=4):
 
 
 def main():
+    if os.environ.get("PIKA_BENCH_WATCHDOG"):      # dump every thread's stack if the run exceeds N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PIKA_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "rnnt_loss_M1p", "train_step", "decode", "mbr_step"])
     ap.add_argument("--beam", type=int, default=16)

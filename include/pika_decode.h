@@ -50,7 +50,9 @@ int pika_fst_advance(const long long *fst_offsets, const int *fst_ilabel, const 
                      const long long *y_raw, const long long *y, int blk, double nonblk_reward, float lm_scale,
                      int *set_n, int *set_state, double *set_cost, float *lm_scores, float *scores,
                      float *fin_score, const long long *fin_n, int fin_cap, int B, int K, int *err,
-                     void *stream);
+                     const int *skip, void *stream);
+/* skip (device int32, may be NULL): the call does nothing when *skip != 0 (graph replays after the search ended,
+ * include/pika_decode_step.h). */
 int pika_fst_states_per_slot(void);
 
 /* Self-attention of ONE new position per beam row over that row's cached prefix, for the incremental

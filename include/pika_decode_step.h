@@ -1,0 +1,135 @@
+/*
+ * include/pika_decode_step.h -- C ABI of the per-step kernels of the batch beam search (gfx950).
+ *
+ * One search step of /root/reference/decoder/transducer_decoder.py:123-186 (`decode_batch` loop body:
+ * prediction-network step for the rows that emitted a label :139-171, joint :173-175, log-softmax :177,
+ * BeamMergeTransducer.advance per utterance :182 = decoder/beam_transducer.py:82-187, `_beam_update` :188-202)
+ * as a fixed chain of launches with NO host involvement, so that the chain can be captured once in a hipGraph
+ * and replayed several times per host read:
+ *
+ *   pika_dstep_prep           re-order the prediction-net state / ancestry by the previous step's parents, advance
+ *                             the frame indices of blank rows, embed the new labels, gather the causal-conv taps
+ *   pika_dgemm (x12)          every Linear / causal Conv1d of the conv-transformer prediction net at ONE new
+ *                             position per row, and the prediction half of fc1/fc_gate with the gate
+ *                             tanh(.)*sigmoid(.) (+ gathered encoder half) in its epilogue
+ *   pika_dstep_attention (x2) self-attention of the new position over the row's cached prefix (keys / values of
+ *                             the new position are stored into the caches by the same launch)
+ *   pika_dfc2_topk            fc2 (+bias, x sm_scale) with the log-sum-exp partials and the per-row top-K partials
+ *                             in its epilogue: the (B*K, V) logits never reach HBM
+ *   pika_beam_advance_partials  merges the partials, then the whole of `advance` (as pika_beam_advance,
+ *                             pika_decode.h), the all-done test and the step counter
+ *
+ * Weights are constant while decoding: they are packed ONCE (pika_dpack_weight) into MFMA fragment order, as 1, 2
+ * or 3 bf16 terms (w = hi [+ mid [+ lo]]: 3 terms reproduce fp32 products exactly, 6 MFMAs per product pair).
+ * Activations stay fp32 in memory and are split the same way while they are staged into LDS.
+ *
+ * Conventions as in pika_rnnt.h: caller-owned device memory, no allocation, no host sync, stream = hipStream_t,
+ * returns 0 / PIKA_EINVAL (<0) / hipError_t (>0).  `stop` (int32, device, may be NULL): when *stop != 0 the
+ * state-mutating launches return without touching anything (replays after the search has finished).
+ */
+#ifndef PIKA_DECODE_STEP_H
+#define PIKA_DECODE_STEP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- packed weights ---------------------------------------------------------------------------------------- */
+/* bytes of the packed form of a (N,K) matrix: terms * ceil16(N) * ceil32(K) * 2 */
+size_t pika_dpack_bytes(int N, int K, int terms);
+/* W (N,K) f32, row stride ldw -> packed.  interleave2 != 0: W has 2*N2 rows = [first half | second half]; packed
+ * row 2j = W[j], row 2j+1 = W[N2 + j] (the gate epilogue wants fc1 / fc_gate outputs of one unit side by side). */
+int pika_dpack_weight(const float *W, long long ldw, int N, int K, int terms, int interleave2, void *packed,
+                      void *stream);
+
+/* ---- C = epilogue(A . W^T) --------------------------------------------------------------------------------- */
+#define PIKA_DG_RELU 1      /* max(.,0) after bias                                                   */
+#define PIKA_DG_GATE 2      /* packed W is interleave2: C[r,j] = tanh(acc[2j] + e[g,j]) * sigmoid(acc[2j+1] + e[g,N/2+j]),
+                               g = (r / beam) * T + clamp(t_idx[r], 0, T-1); N counts the 2H interleaved columns */
+#define PIKA_DG_ROWMASK 4   /* rows r with node[r] == skip_node are not stored                        */
+typedef struct {
+    const float *A;          /* (M, Kp) f32, Kp = ceil32(K) columns readable (caller zero-pads)      */
+    long long lda;
+    const void *W;           /* packed, `terms` terms                                                */
+    const float *bias;       /* N or NULL                                                            */
+    const float *res;        /* residual (M, N) added after bias / relu, or NULL                     */
+    long long ldr;
+    float *C;                /* (M, N) [GATE: (M, N/2)]                                              */
+    long long ldc;
+    float *C2;               /* optional second destination, row r -> C2 + node[r] * ldc2, or NULL   */
+    long long ldc2;
+    const long long *node;   /* (M) i64: C2 scatter / ROWMASK                                        */
+    long long skip_node;
+    const float *e_all;      /* GATE: (B*T, N) f32 = [fc1 encoder half + bias | fc_gate half + bias] */
+    const long long *t_idx;  /* GATE: (M) i64                                                        */
+    int T, beam;
+    int M, N, K, terms, flags;
+} pika_dgemm_t;
+int pika_dgemm(const pika_dgemm_t *p, void *stream);
+
+/* ---- prediction-network bookkeeping of one step ---------------------------------------------------------------
+ * rows = B*beam, row r = b*beam + k.  state / anc are double-buffered: step s reads buffer s&1 and writes (s+1)&1.
+ * For every row: parent pr = b*beam + prev_k[r]; state_dst[r] = state_src[pr]; anc_dst[r,:] = anc_src[pr,:];
+ * tok = y[r]; t_idx[r] += (tok == blk); commit = tok > blk; p = min(hyp_len[r], L-1);
+ * node[r] = commit ? 1 + s*rows + r : dump_node; commit: anc_dst[r,p] = node[r];
+ * layer 0: x = emb[max(tok,0)]; X[0][node] = x; A[0][r] = [X[0][anc[p-4]] .. X[0][anc[p-1]] | x]  (zero left of 0)
+ * layer l>0: A[l][r, :4*C[l]] = [X[l][anc[p-4]] .. X[l][anc[p-1]]]   (the fifth block is written by the layer below)
+ * pos[r] = p.  s = *step_t (steps taken so far). */
+#define PIKA_DSTEP_MAX_LAYERS 4
+typedef struct {
+    const long long *prev_k, *y, *hyp_len, *step_t;
+    long long *t_idx;
+    float *state[2];         /* (rows, H)                                                            */
+    long long *anc[2];       /* (rows, L)                                                            */
+    const float *emb;        /* (vocab+1, C[0])                                                      */
+    float *X[PIKA_DSTEP_MAX_LAYERS];   /* (nodes, C[l]) layer-input caches                            */
+    float *A[PIKA_DSTEP_MAX_LAYERS];   /* (rows, lda[l]) causal-conv input matrices, lda[l] >= 5*C[l] */
+    int C[PIKA_DSTEP_MAX_LAYERS];
+    long long lda[PIKA_DSTEP_MAX_LAYERS];
+    long long *node, *pos;   /* (rows) outputs                                                       */
+    long long dump_node, zero_node;
+    int layers, rows, beam, H, L, blk;
+    const int *stop;
+} pika_dstep_prep_t;
+int pika_dstep_prep(const pika_dstep_prep_t *p, void *stream);
+
+/* Self-attention of the new position of every row over its cached prefix (arithmetic of
+ * pika_incremental_attention, pika_decode.h).  kvq (rows, 3d) f32 = [k | v | q] of the new position; k and v are
+ * stored into k_cache / v_cache at node[r] by this launch and read back from kvq for position pos[r]. */
+int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, float *v_cache,
+                         const long long *ancestry, long long ancestry_pitch, const long long *pos,
+                         const long long *node, int rows, int L, int d, int heads, float *out, void *stream);
+
+/* ---- fc2 + log-sum-exp partials + per-row top-K partials -------------------------------------------------------
+ * h (rows, K) f32, W packed (V, K).  Column range s of `splits` (= pika_dfc2_splits(V)) covers
+ * [s*cols, (s+1)*cols), cols = pika_dfc2_cols_per_split().  For every row and range:
+ *   pmax[r*splits+s] = max_c x,  psum[...] = sum_c exp(x - pmax),  x = sm_scale * (h.W^T + bias)[r, c]
+ *   pcand[(r*splits+s)*topk + j] = {x, c} of the j-th largest x of the range (ties: lowest c), j < topk <= 64;
+ *   ranges with fewer than topk columns are filled with {-inf, 0x7fffffff}. */
+int pika_dfc2_splits(int V);
+int pika_dfc2_cols_per_split(void);
+int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K,
+                   int terms, float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream);
+
+/* ---- advance from partials ---------------------------------------------------------------------------------
+ * As pika_beam_advance (pika_decode.h) with the row log-softmax / top-K taken from the partials above, plus:
+ * `first` is read from the device (*step_t == 0); the step counter is incremented by the call;
+ * done[b] (u8) = eos_top[b] && fin_n[b] >= n_best; *stop = all utterances done; *max_hyp = max hyp_len.
+ * sync (int32[8], zeroed once by the caller): [0..3] scratch for the cross-workgroup arrival counts of even / odd
+ * steps; [4] is set once a call was skipped because *stop was already set (the gate of the FST advance that follows). */
+int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
+                               float *scores, const float *lm_scores, float lm_scale, long long *y,
+                               long long *t_idx, const long long *num_frames, const long long *max_len,
+                               long long *hyp, long long *hyp_len, int L, long long *ks_hist,
+                               long long *ys_hist, long long *step_t, unsigned char *eos_top,
+                               float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
+                               int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
+                               int blk, int beam_prune, int n_best, int *stop, long long *max_hyp, int *sync,
+                               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_DECODE_STEP_H */

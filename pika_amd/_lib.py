@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -71,8 +71,20 @@ SIGNATURES = {
                                _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i,
                                _i, _vp]),
     "pika_fst_advance": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, ctypes.c_double,
-                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+                              ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pika_fst_states_per_slot": (_i, []),
+    # include/pika_decode_step.h
+    "pika_dpack_bytes": (_sz, [_i, _i, _i]),
+    "pika_dpack_weight": (_i, [_vp, _ll, _i, _i, _i, _i, _vp, _vp]),
+    "pika_dgemm": (_i, [_vp, _vp]),
+    "pika_dstep_prep": (_i, [_vp, _vp]),
+    "pika_dstep_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pika_dfc2_splits": (_i, [_i]),
+    "pika_dfc2_cols_per_split": (_i, []),
+    "pika_dfc2_topk": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp]),
+    "pika_beam_advance_partials": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                        _vp, _vp, _vp, _vp]),
     # include/pika_audio.h
     "pika_audio_sumsq": (_i, [_vp, _ll, _vp, _vp]),
     "pika_audio_axpby": (_i, [_vp, _vp, _ll, ctypes.c_float, ctypes.c_float, _vp]),

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "pika_decode.h"
+#include "pika_decode_step.h"
 #include "pika_rnnt.h"
 
 namespace {
@@ -133,88 +134,204 @@ __global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
 }
 
 // ---- kernel B: one workgroup per utterance: merge + the bookkeeping of `advance` -------------
-__global__ __launch_bounds__(256) void beam_merge_kernel(
-    const Cand *__restrict__ cand_g, int first, float *__restrict__ scores,
-    const float *__restrict__ lm_scores, float lm_scale, long long *__restrict__ y,
-    long long *__restrict__ t_idx, const long long *__restrict__ num_frames,
-    const long long *__restrict__ max_len, long long *__restrict__ hyp,
-    long long *__restrict__ hyp_len, int L, long long *__restrict__ ks_hist,
-    long long *__restrict__ ys_hist, const long long *__restrict__ step_t,
-    unsigned char *__restrict__ eos_top, float *__restrict__ fin_score,
-    long long *__restrict__ fin_step, long long *__restrict__ fin_k, long long *__restrict__ fin_n,
-    int fin_cap, long long *__restrict__ prev_k_out, long long *__restrict__ y_raw, int B, int K, int V,
-    int blk) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
-    Cand *cand = reinterpret_cast<Cand *>(hyp_l + K * L);                // [K][K]
-    __shared__ float lm_old[MAXK], best_v[MAXK];
-    __shared__ long long t_old[MAXK], len_old[MAXK];
-    __shared__ int best_i[MAXK], fin_flag[MAXK];
+struct BeamState {
+    float *scores; const float *lm_scores; float lm_scale; long long *y; long long *t_idx;
+    const long long *num_frames; const long long *max_len; long long *hyp; long long *hyp_len; int L;
+    long long *ks_hist; long long *ys_hist; const long long *step_t; unsigned char *eos_top; float *fin_score;
+    long long *fin_step; long long *fin_k; long long *fin_n; int fin_cap; long long *prev_k_out; long long *y_raw;
+    int B, K, V, blk;
+};
 
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const long long bk = (long long)b * K;
-    if (tid < K) {
-        lm_old[tid] = lm_scores[bk + tid];
-        t_old[tid] = t_idx[bk + tid];
-        len_old[tid] = hyp_len[bk + tid];
+// Shared scratch of one utterance (static part; hyp_l [K][L] ints and cand [K][K] live in dynamic LDS)
+struct BeamShared {
+    float lm_old[MAXK], best_v[MAXK];
+    long long t_old[MAXK], len_old[MAXK];
+    int best_i[MAXK], fin_flag[MAXK];
+};
+
+__device__ inline void beam_load_state(const BeamState &a, BeamShared &sh, int *hyp_l, int b) {
+    const int tid = threadIdx.x;
+    const long long bk = (long long)b * a.K;
+    if (tid < a.K) {
+        sh.lm_old[tid] = a.lm_scores[bk + tid];
+        sh.t_old[tid] = a.t_idx[bk + tid];
+        sh.len_old[tid] = a.hyp_len[bk + tid];
     }
-    for (int i = tid; i < K * L; i += blockDim.x) hyp_l[i] = (int)hyp[bk * L + i];
-    const int nc = K * K;
-    for (int c = tid; c < nc; c += blockDim.x) cand[c] = cand_g[bk * K + c];
-    __syncthreads();
+    for (int i = tid; i < a.K * a.L; i += blockDim.x) hyp_l[i] = (int)a.hyp[bk * a.L + i];
+}
 
+// cand [K][K] in LDS holds the K best candidates of every row; everything of `advance` after that
+// (beam_transducer.py:119-187) for utterance b.  Ends with every thread past its last global write of the step.
+__device__ inline void beam_merge_and_book(const BeamState &a, BeamShared &sh, const int *hyp_l, const Cand *cand,
+                                           int b) {
+    const int tid = threadIdx.x, K = a.K, L = a.L, V = a.V, B = a.B;
+    const long long bk = (long long)b * K;
+    const int nc = K * K;
     // rank sort of the K*K row winners, value desc / flat index asc (:119-121)
     for (int c = tid; c < nc; c += blockDim.x) {
         const Cand me = cand[c];
         int rank = 0;
         for (int j = 0; j < nc; ++j) rank += better(cand[j].v, cand[j].idx, me.v, me.idx) ? 1 : 0;
-        if (rank < K) { best_v[rank] = me.v; best_i[rank] = me.idx; }
+        if (rank < K) { sh.best_v[rank] = me.v; sh.best_i[rank] = me.idx; }
     }
     __syncthreads();
 
     // ---- bookkeeping on K lanes (:125-187) ---------------------------------------------------
-    const long long s = step_t[0];                  // steps taken before this one
+    const long long s = a.step_t[0];                // steps taken before this one
     const long long n_ys = s + 2;                   // len(next_ys) after the append
     if (tid < K) {
-        const int id = best_i[tid];
+        const int id = sh.best_i[tid];
         const int pk = id / V, ysym = id - pk * V;
-        const float ns = best_v[tid] - lm_scale * lm_old[pk];
-        const bool fin = (ysym == blk && t_old[pk] == num_frames[b] - 1) || (n_ys > max_len[b]);
-        fin_flag[tid] = fin ? 1 : 0;
-        scores[bk + tid] = ns;
-        prev_k_out[bk + tid] = pk;
-        ks_hist[(s * B + b) * K + tid] = pk;
+        const float ns = sh.best_v[tid] - a.lm_scale * sh.lm_old[pk];
+        const bool fin = (ysym == a.blk && sh.t_old[pk] == a.num_frames[b] - 1) || (n_ys > a.max_len[b]);
+        sh.fin_flag[tid] = fin ? 1 : 0;
+        a.scores[bk + tid] = ns;
+        a.prev_k_out[bk + tid] = pk;
+        a.ks_hist[(s * B + b) * K + tid] = pk;
         const long long yn = fin ? EOS : (long long)ysym;
-        if (y_raw) y_raw[bk + tid] = ysym;          // the symbol before the eos substitution (FST fusion)
-        y[bk + tid] = yn;
-        ys_hist[((s + 1) * B + b) * K + tid] = yn;
-        t_idx[bk + tid] = t_old[pk];                // transducer_decoder.py:201-202
-        if (tid == 0 && yn == EOS) eos_top[b] = 1;
-        if (!fin) hyp_len[bk + tid] = len_old[pk] + ((ysym != blk) ? 1 : 0);
+        if (a.y_raw) a.y_raw[bk + tid] = ysym;      // the symbol before the eos substitution (FST fusion)
+        a.y[bk + tid] = yn;
+        a.ys_hist[((s + 1) * B + b) * K + tid] = yn;
+        a.t_idx[bk + tid] = sh.t_old[pk];           // transducer_decoder.py:201-202
+        if (tid == 0 && yn == EOS) a.eos_top[b] = 1;
+        if (!fin) a.hyp_len[bk + tid] = sh.len_old[pk] + ((ysym != a.blk) ? 1 : 0);
     }
     __syncthreads();
     if (tid == 0) {                                  // finished list, slot order (:165-181)
-        long long n = fin_n[b];
+        long long n = a.fin_n[b];
         for (int i = 0; i < K; ++i) {
-            if (!fin_flag[i]) continue;
-            const long long pos = n < fin_cap - 2 ? n : fin_cap - 2;
-            fin_score[(long long)b * fin_cap + pos] = scores[bk + i];
-            fin_step[(long long)b * fin_cap + pos] = n_ys - 1;
-            fin_k[(long long)b * fin_cap + pos] = i;
+            if (!sh.fin_flag[i]) continue;
+            const long long pos = n < a.fin_cap - 2 ? n : a.fin_cap - 2;
+            a.fin_score[(long long)b * a.fin_cap + pos] = a.scores[bk + i];
+            a.fin_step[(long long)b * a.fin_cap + pos] = n_ys - 1;
+            a.fin_k[(long long)b * a.fin_cap + pos] = i;
             ++n;
         }
-        fin_n[b] = n;
+        a.fin_n[b] = n;
     }
     // partial hypotheses: slot i <- parent's labels (+ y), finished slots keep their own (:217-226)
     for (int i = 0; i < K; ++i) {
-        if (fin_flag[i]) continue;
-        const int p = best_i[i] / V, ys_ = best_i[i] - p * V;
-        const int plen = (int)len_old[p];
-        long long *dst = hyp + (bk + i) * L;
+        if (sh.fin_flag[i]) continue;
+        const int p = sh.best_i[i] / V, ys_ = sh.best_i[i] - p * V;
+        const int plen = (int)sh.len_old[p];
+        long long *dst = a.hyp + (bk + i) * L;
         for (int q = tid; q < L; q += blockDim.x) {
             long long v = hyp_l[p * L + q];
-            if (q == plen && ys_ != blk) v = ys_;
+            if (q == plen && ys_ != a.blk) v = ys_;
             dst[q] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_merge_kernel(const Cand *__restrict__ cand_g, BeamState a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
+    Cand *cand = reinterpret_cast<Cand *>(hyp_l + a.K * a.L);            // [K][K]
+    __shared__ BeamShared sh;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    beam_load_state(a, sh, hyp_l, b);
+    const int nc = a.K * a.K;
+    for (int c = tid; c < nc; c += blockDim.x) cand[c] = cand_g[(long long)b * a.K * a.K + c];
+    __syncthreads();
+    beam_merge_and_book(a, sh, hyp_l, cand, b);
+}
+
+// ---- kernel B': the same, with the row log-softmax / top-K built from the partials of pika_dfc2_topk ---------
+// (include/pika_decode_step.h).  Phase 1, one wave per beam row: disabled rows as in kernel A; otherwise
+// log-sum-exp = log sum_s psum_s exp(pmax_s - max), and the K best of the S sorted partial lists by K rounds of
+// "wave arg-max over the S list heads".  Phase 2 = kernel B.  Phase 3: done flags, the all-done stop flag, the
+// longest partial hypothesis and the step counter (last workgroup to arrive).
+__global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restrict__ pmax,
+                                                            const float *__restrict__ psum,
+                                                            const Cand *__restrict__ pcand, int S, BeamState a,
+                                                            int beam_prune, int n_best, int *__restrict__ stop,
+                                                            long long *__restrict__ max_hyp, int *__restrict__ sync,
+                                                            long long *__restrict__ step_rw) {
+    if (*stop) {                                      // a replay after the search has ended: nothing happens, and the
+        if (blockIdx.x == 0 && threadIdx.x == 0) sync[4] = 1;   // FST advance of this (skipped) step must not run either
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
+    Cand *cand = reinterpret_cast<Cand *>(hyp_l + a.K * a.L);            // [K][K]
+    __shared__ BeamShared sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, L = a.L, V = a.V;
+    const long long bk = (long long)b * K;
+    const long long s_now = a.step_t[0];
+    const int first = s_now == 0;
+    beam_load_state(a, sh, hyp_l, b);
+    __syncthreads();
+    for (int k = wave; k < K; k += 4) {
+        bool d;
+        if (first) {
+            d = k != 0;
+        } else {
+            d = a.y[bk + k] == EOS;
+            const long long len = sh.len_old[k];
+            if (!d && beam_prune && len > 0) {
+                for (int j = 0; j < k && !d; ++j) {
+                    if (a.y[bk + j] == EOS || sh.len_old[j] != len) continue;
+                    bool same = true;
+                    for (long long p = lane; p < len; p += 64) same &= hyp_l[j * L + p] == hyp_l[k * L + p];
+                    d = __all(same);
+                }
+            }
+        }
+        Cand *out = cand + k * K;
+        if (d) {
+            if (lane < K) out[lane] = Cand{first ? -3.0e38f : DEAD, k * V + lane};
+            continue;
+        }
+        const long long pi = (bk + k) * S;
+        float m = lane < S ? pmax[pi + lane] : -INFINITY;
+        const float mine = m;
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s = lane < S ? psum[pi + lane] * __expf(mine - m) : 0.f;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float logsum = __logf(s);
+        const float add_s = a.scores[bk + k], add_l = a.lm_scale * sh.lm_old[k];
+        int ptr = 0;
+        const Cand *list = pcand + (pi + (lane < S ? lane : 0)) * K;
+        Cand head = lane < S ? list[0] : Cand{-INFINITY, 0x7fffffff};
+        for (int r = 0; r < K; ++r) {
+            float bv = head.v;
+            int bi = head.idx;
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            if (lane < S && bi == head.idx && bi != 0x7fffffff) {      // the owning list pops its head
+                ++ptr;
+                head = ptr < K ? list[ptr] : Cand{-INFINITY, 0x7fffffff};
+            }
+            if (lane == 0) {
+                float val = (bv - m) - logsum;                 // log_softmax, torch's operation order
+                if (!first) val = (val + add_s) + add_l;       // (:94-97)
+                out[r] = Cand{val, k * V + (bi == 0x7fffffff ? 0 : bi)};
+            }
+        }
+    }
+    __syncthreads();
+    beam_merge_and_book(a, sh, hyp_l, cand, b);
+    __syncthreads();
+    if (tid == 0) {
+        long long mh = 0;
+        for (int i = 0; i < K; ++i) mh = max(mh, a.hyp_len[bk + i]);
+        atomicMax(reinterpret_cast<unsigned long long *>(max_hyp), (unsigned long long)mh);
+        const int done = (a.eos_top[b] && a.fin_n[b] >= n_best) ? 1 : 0;   // beam_transducer.py:189-194
+        const int par = (int)(s_now & 1);
+        atomicAdd(&sync[par * 2 + 1], done);
+        __threadfence();
+        const int ticket = atomicAdd(&sync[par * 2], 1);
+        if (ticket == a.B - 1) {                      // everybody has read step_t and finished its utterance
+            __threadfence();
+            const int ndone = atomicAdd(&sync[par * 2 + 1], 0);
+            if (ndone == a.B) atomicExch(stop, 1);
+            sync[(par ^ 1) * 2] = 0;
+            sync[(par ^ 1) * 2 + 1] = 0;
+            step_rw[0] = s_now + 1;
         }
     }
 }
@@ -380,7 +497,8 @@ __global__ __launch_bounds__(64) void fst_advance_kernel(FstDev F, const long lo
                                                          float *__restrict__ lm_scores, float *__restrict__ scores,
                                                          float *__restrict__ fin_score,
                                                          const long long *__restrict__ fin_n, int fin_cap, int K,
-                                                         int *__restrict__ err) {
+                                                         int *__restrict__ err, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ int fin_flag[64];
     const int b = blockIdx.x, i = threadIdx.x;
     const long long bk = (long long)b * K;
@@ -515,11 +633,39 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
     hipLaunchKernelGGL(beam_row_topk_kernel, dim3((B * K + WAVES - 1) / WAVES), dim3(WAVES * 64),
                        (size_t)WAVES * MAXV * 4, st, logits, sm_scale, first, scores, lm_scores, lm_scale,
                        y, hyp, hyp_len, L, B, K, V, beam_prune, cand);
+    BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
+                eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
     hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256),
-                       (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand), st, cand, first, scores,
-                       lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist,
-                       ys_hist, step_t, eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out,
-                       y_raw, B, K, V, blk);
+                       (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand), st, cand, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
+                                          float *scores, const float *lm_scores, float lm_scale, long long *y,
+                                          long long *t_idx, const long long *num_frames, const long long *max_len,
+                                          long long *hyp, long long *hyp_len, int L, long long *ks_hist,
+                                          long long *ys_hist, long long *step_t, unsigned char *eos_top,
+                                          float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
+                                          int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
+                                          int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
+                                          int *sync, void *stream) {
+    if (!pmax || !psum || !pcand || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
+        !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step || !fin_k || !fin_n ||
+        !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
+        return PIKA_EINVAL;
+    if (K > MAXK || splits > 64 || (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) > 96 * 1024) return PIKA_ETOOBIG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_partials_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
+                eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
+    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(256), (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand),
+                       static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
+                       beam_prune, n_best, stop, max_hyp, sync, step_t);
     return (int)hipGetLastError();
 }
 
@@ -559,7 +705,8 @@ extern "C" int pika_fst_advance(const long long *fst_offsets, const int *fst_ila
                                 const long long *prev_k, const long long *y_raw, const long long *y, int blk,
                                 double nonblk_reward, float lm_scale, int *set_n, int *set_state,
                                 double *set_cost, float *lm_scores, float *scores, float *fin_score,
-                                const long long *fin_n, int fin_cap, int B, int K, int *err, void *stream) {
+                                const long long *fin_n, int fin_cap, int B, int K, int *err, const int *skip,
+                                void *stream) {
     if (!fst_offsets || !fst_ilabel || !fst_weight || !fst_nextstate || !fst_final || !prev_k || !y_raw || !y ||
         !set_n || !set_state || !set_cost || !lm_scores || !scores || !fin_score || !fin_n || !err || B <= 0 || K <= 0)
         return PIKA_EINVAL;
@@ -568,7 +715,7 @@ extern "C" int pika_fst_advance(const long long *fst_offsets, const int *fst_ila
     for (int i = 0; i < n_disambig; ++i) F.dis[i] = disambig_ids[i];     // host array
     hipLaunchKernelGGL(fst_advance_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), F, prev_k, y_raw,
                        y, blk, nonblk_reward, lm_scale, set_n, set_state, set_cost, lm_scores, scores, fin_score,
-                       fin_n, fin_cap, K, err);
+                       fin_n, fin_cap, K, err, skip);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,555 @@
+// pika_amd/csrc/decode_step.hip -- the per-step kernels of the batch beam search (include/pika_decode_step.h).
+//
+// The search is latency-bound (one step = ~34 GFLOP on B*beam = 1024 rows, ~290 dependent steps), so everything
+// here is built for short launches on small M: weights are packed once into MFMA fragment order and streamed by
+// each wave straight from L2 into registers (no LDS for the weight operand: a wave owns its output columns, so
+// there is nothing to share); only the activation tile, which all four waves of a workgroup need, goes through
+// LDS, where fp32 values are split into 1..3 bf16 terms on the way in.  v_mfma_f32_16x16x32_bf16 is issued as
+// D^T = W_frag x A_frag: a lane ends up with 4 consecutive output columns of one row.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pika_decode_step.h"
+#include "pika_rnnt.h"  // PIKA_EINVAL
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PITCH = 40;   // bf16 per LDS row of 32 (80 bytes: the 16 rows of a fragment read hit 16 distinct 4-bank groups)
+
+// ---- weight packing: packed[term][n_tile][k_tile][lane][8], n_tile = 16 columns, k_tile = 32 ----------------
+__global__ void dpack_kernel(const float *__restrict__ W, long long ldw, int N, int K, int NT, int KT, int terms,
+                             int interleave2, __bf16 *__restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)NT * KT * 64;
+    if (gid >= total) return;
+    const int lane = (int)(gid & 63);
+    const long long tile = gid >> 6;
+    const int kt = (int)(tile % KT), nt = (int)(tile / KT);
+    int n = nt * 16 + (lane & 15);
+    const int k0 = kt * 32 + (lane >> 4) * 8;
+    float v[8];
+    int src = n;
+    if (interleave2 && n < N) src = (n & 1) ? (N / 2 + (n >> 1)) : (n >> 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? W[(long long)src * ldw + k0 + j] : 0.f;
+    for (int t = 0; t < terms; ++t) {
+        bf16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = (__bf16)v[j];
+            v[j] -= (float)h[j];
+        }
+        *reinterpret_cast<bf16x8 *>(out + (((long long)t * NT + nt) * KT + kt) * 512 + lane * 8) = h;
+    }
+}
+
+// ---- the shared main loop ------------------------------------------------------------------------------------
+// Workgroup = 256 threads = 4 waves; tile = BM rows x (4 waves x WN x 16) columns; wave w owns column tiles
+// [(ng*4 + w)*WN, +WN).  A (fp32, global) -> registers -> NS bf16 terms -> LDS (double buffered, one barrier per
+// 32-wide k-step); W fragments global -> registers, one k-step ahead.
+template <int BM, int WN, int NS>
+struct Core {
+    static constexpr int MT = BM / 16;
+    static constexpr int APT = BM * 8 / 256;      // float4 loads of A per thread per k-step (BM = 32: 1, 64: 2)
+    static constexpr int LDS_BYTES = 2 * NS * BM * PITCH * 2;
+    static_assert(BM == 32 || BM == 64, "BM");
+
+    f32x4 acc[MT][WN];
+
+    __device__ inline void run(const float *__restrict__ A, long long lda, int M, int m0, const __bf16 *__restrict__ W,
+                               int NT, int KT, int nt0, __bf16 *lds) {
+        const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A loader: float4 index f = tid + 256*i -> row f/8, column group f%8
+        const float *arow[APT];
+        int aoff[APT];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int f = tid + 256 * i, r = f >> 3, c4 = f & 7;
+            arow[i] = (m0 + r < M) ? A + (long long)(m0 + r) * lda + c4 * 4 : nullptr;
+            aoff[i] = r * PITCH + c4 * 4;
+        }
+        const __bf16 *wbase[WN];
+        bool wok[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            wok[j] = nt0 + j < NT;
+            wbase[j] = W + ((long long)(wok[j] ? nt0 + j : 0) * KT) * 512 + lane * 8;
+        }
+        const long long term_stride = (long long)NT * KT * 512;
+        f32x4 araw[APT];
+        bf16x8 wreg[WN][NS], wnext[WN][NS];
+        auto load_a = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < APT; ++i)
+                araw[i] = arow[i] ? *reinterpret_cast<const f32x4 *>(arow[i] + kt * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        auto load_w = [&](int kt, bf16x8 (&dst)[WN][NS]) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    dst[j][s] = *reinterpret_cast<const bf16x8 *>(wbase[j] + s * term_stride + (long long)kt * 512);
+        };
+        auto stage_a = [&](int buf) {
+            __bf16 *dst = lds + buf * (NS * BM * PITCH);
+#pragma unroll
+            for (int i = 0; i < APT; ++i) {
+                f32x4 r = araw[i];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bf16x4 h = __builtin_convertvector(r, bf16x4);
+                    *reinterpret_cast<bf16x4 *>(dst + s * (BM * PITCH) + aoff[i]) = h;
+                    if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
+                }
+            }
+        };
+        load_a(0);
+        load_w(0, wreg);
+        stage_a(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = kt + 1 < KT;
+            if (more) {
+                load_a(kt + 1);
+                load_w(kt + 1, wnext);
+            }
+            const __bf16 *src = lds + (kt & 1) * (NS * BM * PITCH);
+            bf16x8 a[MT][NS];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    a[i][s] = *reinterpret_cast<const bf16x8 *>(src + s * (BM * PITCH) + (i * 16 + (lane & 15)) * PITCH +
+                                                                (lane >> 4) * 8);
+            // products of one kind across all accumulators before the next kind (consecutive MFMAs never share an
+            // accumulator); smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+            constexpr int NP = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
+            constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 6 - NP; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][PW[q]], a[i][PA[q]], acc[i][j], 0, 0, 0);
+            if (more) {
+                stage_a((kt + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) wreg[j][s] = wnext[j][s];
+            }
+            __syncthreads();
+        }
+    }
+};
+
+struct DG {   // device copy of pika_dgemm_t
+    const float *A; long long lda; const __bf16 *W; const float *bias; const float *res; long long ldr;
+    float *C; long long ldc; float *C2; long long ldc2; const long long *node; long long skip_node;
+    const float *e_all; const long long *t_idx; int T, beam, M, N, NT, KT, flags;
+};
+
+template <int BM, int NS>
+__global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Core<BM, 1, NS> core;
+    const int n_groups = (p.NT + 3) / 4;
+    const int mg = blockIdx.x / n_groups, ng = blockIdx.x - mg * n_groups;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = mg * BM, nt0 = ng * 4 + wave;
+    core.run(p.A, p.lda, p.M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem));
+    if (nt0 >= p.NT) return;
+    const int c0 = nt0 * 16 + (lane >> 4) * 4;          // first of this lane's 4 consecutive columns
+    if (c0 >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int r = m0 + i * 16 + (lane & 15);
+        if (r >= p.M) continue;
+        f32x4 v = core.acc[i][0];
+        if (p.flags & PIKA_DG_GATE) {
+            // columns (2j, 2j+1) = (fc1, fc_gate) of joint unit j; this lane holds units c0/2 and c0/2 + 1
+            const int H = p.N >> 1, j0 = c0 >> 1;
+            long long t = p.t_idx[r];
+            t = t < 0 ? 0 : (t > p.T - 1 ? p.T - 1 : t);
+            const float *e = p.e_all + ((long long)(r / p.beam) * p.T + t) * p.N;
+            float o[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float z1 = v[2 * u] + e[j0 + u], zg = v[2 * u + 1] + e[H + j0 + u];
+                o[u] = tanhf(z1) * (1.f / (1.f + expf(-zg)));
+            }
+            float *dst = p.C + (long long)r * p.ldc + j0;
+            dst[0] = o[0];
+            if (j0 + 1 < H) dst[1] = o[1];
+            continue;
+        }
+        const bool full = c0 + 3 < p.N;
+        if (p.bias) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < p.N) v[u] += p.bias[c0 + u];
+        }
+        if (p.flags & PIKA_DG_RELU) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+        }
+        if (p.res) {
+            const float *rp = p.res + (long long)r * p.ldr + c0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < p.N) v[u] += rp[u];
+        }
+        const long long nd = p.node ? p.node[r] : 0;
+        if ((p.flags & PIKA_DG_ROWMASK) && nd == p.skip_node) continue;
+        float *dst = p.C + (long long)r * p.ldc + c0;
+        if (full && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            *reinterpret_cast<f32x4 *>(dst) = v;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < p.N) dst[u] = v[u];
+        }
+        if (p.C2) {
+            float *d2 = p.C2 + nd * p.ldc2 + c0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < p.N) d2[u] = v[u];
+        }
+    }
+}
+
+// ---- prediction-network bookkeeping ----------------------------------------------------------------------------
+struct PrepDev {
+    pika_dstep_prep_t p;
+};
+
+__global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
+    const pika_dstep_prep_t &p = a.p;
+    if (p.stop && *p.stop) return;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const long long s = p.step_t[0];
+    const int src = (int)(s & 1), dst = src ^ 1;
+    const int b = r / p.beam;
+    const long long pr = (long long)b * p.beam + p.prev_k[r];
+    const long long tok = p.y[r];
+    const bool commit = tok > p.blk;
+    long long pos = p.hyp_len[r];
+    if (pos > p.L - 1) pos = p.L - 1;
+    const long long node = commit ? 1 + s * p.rows + r : p.dump_node;
+    // state and ancestry follow the parent (transducer_decoder.py:188-202)
+    const float *ss = p.state[src] + pr * p.H;
+    float *sd = p.state[dst] + (long long)r * p.H;
+    for (int c = tid * 4; c < p.H; c += 1024) {
+        if (c + 3 < p.H) *reinterpret_cast<f32x4 *>(sd + c) = *reinterpret_cast<const f32x4 *>(ss + c);
+        else for (int u = 0; c + u < p.H; ++u) sd[c + u] = ss[c + u];
+    }
+    const long long *as = p.anc[src] + pr * p.L;
+    long long *ad = p.anc[dst] + (long long)r * p.L;
+    for (long long j = tid; j < p.L; j += 256) {
+        long long v = as[j];
+        if (commit && j == pos) v = node;
+        ad[j] = v;
+    }
+    if (tid == 0) {
+        if (tok == p.blk) p.t_idx[r] += 1;                       // :129
+        p.node[r] = node;
+        p.pos[r] = pos;
+    }
+    // taps p-4 .. p-1 through the PARENT's ancestry (positions < p are unchanged by this step)
+    long long tap[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long q = pos - 4 + j;
+        tap[j] = q >= 0 ? as[q] : p.zero_node;
+    }
+    for (int l = 0; l < p.layers; ++l) {
+        const int C = p.C[l];
+        float *arow = p.A[l] + (long long)r * p.lda[l];
+        for (int e = tid; e < 4 * C; e += 256) {
+            const int j = e / C, c = e - j * C;
+            arow[e] = p.X[l][tap[j] * C + c];
+        }
+        if (l == 0) {
+            const long long t0 = tok < 0 ? 0 : tok;
+            for (int c = tid; c < C; c += 256) {
+                const float x = p.emb[t0 * C + c];
+                arow[4 * C + c] = x;
+                p.X[0][node * C + c] = x;
+            }
+        }
+    }
+}
+
+// ---- self-attention of the new position over the cached prefix (see decode.hip incr_attn_kernel) -------------
+// One workgroup per row; thread t owns dims [4t, 4t+4) of the d <= 1024 wide vectors (TPG = d/4 threads), the
+// 256 / TPG thread groups take prefix positions round-robin.
+__global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict__ kvq, long long ldkvq,
+                                                         float *__restrict__ Kc, float *__restrict__ Vc,
+                                                         const long long *__restrict__ anc, long long anc_pitch,
+                                                         const long long *__restrict__ pos,
+                                                         const long long *__restrict__ node, int L, int d, int heads,
+                                                         int tpg, float scale, float *__restrict__ out) {
+    extern __shared__ float sc[];   // [heads][L] scores, then [G][d] partial contexts
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int G = 256 / tpg;
+    const int gi = t / tpg, tl = t - gi * tpg;
+    const int dh = d / heads, g = dh >> 2;           // g threads per head (power of two <= 64)
+    long long p = pos[r];
+    if (p > L - 1) p = L - 1;
+    const long long my_node = node[r];
+    const long long *arow = anc + (long long)r * anc_pitch;
+    const float *row = kvq + (long long)r * ldkvq;
+    const int col = tl * 4;
+    const bool act = gi < G;
+    const f32x4 kn = act ? *reinterpret_cast<const f32x4 *>(row + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 vn = act ? *reinterpret_cast<const f32x4 *>(row + d + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 qv = act ? *reinterpret_cast<const f32x4 *>(row + 2 * d + col) * scale : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (act && gi == 0) {                              // the new position joins the caches
+        *reinterpret_cast<f32x4 *>(Kc + my_node * d + col) = kn;
+        *reinterpret_cast<f32x4 *>(Vc + my_node * d + col) = vn;
+    }
+    for (long long j0 = gi; j0 <= p; j0 += 4 * G) {
+        float part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = j0 + (long long)u * G;
+            part[u] = 0.f;
+            if (act && j <= p) {
+                const f32x4 k4 = j == p ? kn : *reinterpret_cast<const f32x4 *>(Kc + arow[j] * d + col);
+                part[u] = qv.x * k4.x + qv.y * k4.y + qv.z * k4.z + qv.w * k4.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = part[u];
+            for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o);
+            const long long j = j0 + (long long)u * G;
+            if (act && j <= p && (tl & (g - 1)) == 0) sc[(col / dh) * L + (int)j] = v;
+        }
+    }
+    __syncthreads();
+    if (gi == 0 && act) {
+        const int h = col / dh, ln = tl & (g - 1);
+        float m = -INFINITY;
+        for (int j = ln; j <= p; j += g) m = fmaxf(m, sc[h * L + j]);
+        for (int o = 1; o < g; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int j = ln; j <= p; j += g) sum += __expf(sc[h * L + j] - m);
+        for (int o = 1; o < g; o <<= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int j = ln; j <= p; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long long j0 = gi; j0 <= p; j0 += 4 * G) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long j = j0 + (long long)u * G;
+            if (j > p) break;
+            if (act) {
+                const float w = sc[(col / dh) * L + (int)j];
+                const f32x4 v4 = j == p ? vn : *reinterpret_cast<const f32x4 *>(Vc + arow[j] * d + col);
+                acc += v4 * w;
+            }
+        }
+    }
+    if (G > 1) {
+        __syncthreads();
+        float *part = sc;                              // [G][d]
+        if (act) *reinterpret_cast<f32x4 *>(part + gi * d + col) = acc;
+        __syncthreads();
+        if (gi == 0 && act) {
+            f32x4 s4 = acc;
+            for (int k = 1; k < G; ++k) s4 += *reinterpret_cast<const f32x4 *>(part + k * d + col);
+            *reinterpret_cast<f32x4 *>(out + (long long)r * d + col) = s4;
+        }
+    } else if (act) {
+        *reinterpret_cast<f32x4 *>(out + (long long)r * d + col) = acc;
+    }
+}
+
+// ---- fc2 + log-sum-exp partials + top-K partials --------------------------------------------------------------
+constexpr int FC2_BM = 32, FC2_WN = 5, FC2_COLS = 4 * FC2_WN * 16;   // 320 columns per split
+struct Cand { float v; int idx; };
+
+__device__ inline bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+template <int NS>
+__global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict__ h, long long ldh,
+                                                        const __bf16 *__restrict__ W, const float *__restrict__ bias,
+                                                        int rows, int V, int NT, int KT, float sm_scale, int topk,
+                                                        int splits, float *__restrict__ pmax,
+                                                        float *__restrict__ psum, Cand *__restrict__ pcand) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Core<FC2_BM, FC2_WN, NS> core;
+    __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
+    float *slab = reinterpret_cast<float *>(smem + Core<FC2_BM, FC2_WN, NS>::LDS_BYTES);   // [32][FC2_COLS]
+    const int mb = blockIdx.x / splits, sp = blockIdx.x - mb * splits;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = mb * FC2_BM, nt0 = (sp * 4 + wave) * FC2_WN;
+    core.run(h, ldh, rows, m0, W, NT, KT, nt0, lds);
+    // logits of this split -> slab (sm_scale * (acc + bias); columns >= V masked)
+#pragma unroll
+    for (int i = 0; i < FC2_BM / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < FC2_WN; ++j) {
+            const int lc = (wave * FC2_WN + j) * 16 + (lane >> 4) * 4;      // column inside the split
+            const int c = sp * FC2_COLS + lc;
+            f32x4 v = core.acc[i][j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = c + u < V ? sm_scale * (v[u] + (bias ? bias[c + u] : 0.f)) : -INFINITY;
+            *reinterpret_cast<f32x4 *>(slab + (i * 16 + (lane & 15)) * FC2_COLS + lc) = v;
+        }
+    __syncthreads();
+    // 8 rows per wave: max, sum of exponentials, the topk largest (value desc, column asc)
+    constexpr int PL = FC2_COLS / 64;     // 5 values per lane
+    for (int rr = 0; rr < FC2_BM / 4; ++rr) {
+        const int lr = wave * (FC2_BM / 4) + rr, r = m0 + lr;
+        if (r >= rows) break;
+        float x[PL];
+#pragma unroll
+        for (int q = 0; q < PL; ++q) x[q] = slab[lr * FC2_COLS + lane + 64 * q];
+        float m = x[0];
+#pragma unroll
+        for (int q = 1; q < PL; ++q) m = fmaxf(m, x[q]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < PL; ++q) s += x[q] > -INFINITY ? __expf(x[q] - m) : 0.f;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const long long pi = (long long)r * splits + sp;
+        if (lane == 0) { pmax[pi] = m; psum[pi] = s; }
+        Cand *out = pcand + pi * topk;
+        for (int k = 0; k < topk; ++k) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < PL; ++q)
+                if (x[q] > bv) { bv = x[q]; bi = lane + 64 * q; }      // lane-local columns ascend with q: ties keep the lowest
+            const int mine = bi;
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            if (bi == mine && bi != 0x7fffffff) {
+#pragma unroll
+                for (int q = 0; q < PL; ++q)
+                    if (lane + 64 * q == bi) x[q] = -INFINITY;
+            }
+            if (lane == 0) out[k] = Cand{bv, bi == 0x7fffffff ? 0x7fffffff : sp * FC2_COLS + bi};
+        }
+    }
+}
+
+int check(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+template <int BM, int NS>
+void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
+    constexpr size_t lds = Core<BM, 1, NS>::LDS_BYTES;
+    dgemm_kernel<BM, NS><<<dim3(grid), dim3(256), lds, st>>>(p);
+}
+
+template <int NS>
+void launch_fc2(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
+                int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc) {
+    constexpr size_t lds = Core<FC2_BM, FC2_WN, NS>::LDS_BYTES + FC2_BM * FC2_COLS * 4;
+    dfc2_topk_kernel<NS><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax,
+                                                             psum, pc);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pika_dpack_bytes(int N, int K, int terms) {
+    return (size_t)terms * ((N + 15) / 16 * 16) * ((K + 31) / 32 * 32) * 2;
+}
+
+int pika_dpack_weight(const float *W, long long ldw, int N, int K, int terms, int interleave2, void *packed,
+                      void *stream) {
+    if (!W || !packed || N <= 0 || K <= 0 || terms < 1 || terms > 3 || (interleave2 && (N & 1))) return PIKA_EINVAL;
+    const int NT = (N + 15) / 16, KT = (K + 31) / 32;
+    const long long total = (long long)NT * KT * 64;
+    hipLaunchKernelGGL(dpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
+                       NT, KT, terms, interleave2, reinterpret_cast<__bf16 *>(packed));
+    return check(hipGetLastError());
+}
+
+int pika_dgemm(const pika_dgemm_t *q, void *stream) {
+    if (!q || !q->A || !q->W || !q->C || q->M <= 0 || q->N <= 0 || q->K <= 0 || q->terms < 1 || q->terms > 3)
+        return PIKA_EINVAL;
+    if ((q->lda & 3) || (reinterpret_cast<uintptr_t>(q->A) & 15)) return PIKA_EINVAL;
+    if ((q->flags & PIKA_DG_GATE) && (!q->e_all || !q->t_idx || q->T <= 0 || q->beam <= 0 || (q->N & 3))) return PIKA_EINVAL;
+    if (((q->flags & PIKA_DG_ROWMASK) || q->C2) && !q->node) return PIKA_EINVAL;
+    DG p{q->A, q->lda, reinterpret_cast<const __bf16 *>(q->W), q->bias, q->res, q->ldr, q->C, q->ldc, q->C2, q->ldc2,
+         q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags};
+    const int n_groups = (p.NT + 3) / 4;
+    // enough workgroups to cover the chip: 32-row tiles unless 64-row tiles already give > 256 of them
+    const bool big = (long long)((q->M + 63) / 64) * n_groups >= 512;
+    const int BM = big ? 64 : 32;
+    const unsigned grid = (unsigned)(((q->M + BM - 1) / BM) * n_groups);
+    hipStream_t st = (hipStream_t)stream;
+    if (big) {
+        if (q->terms == 1) launch_dgemm<64, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<64, 2>(grid, st, p); else launch_dgemm<64, 3>(grid, st, p);
+    } else {
+        if (q->terms == 1) launch_dgemm<32, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<32, 2>(grid, st, p); else launch_dgemm<32, 3>(grid, st, p);
+    }
+    return check(hipGetLastError());
+}
+
+int pika_dstep_prep(const pika_dstep_prep_t *q, void *stream) {
+    if (!q || q->rows <= 0 || q->layers < 1 || q->layers > PIKA_DSTEP_MAX_LAYERS || q->beam <= 0 || q->H <= 0 || q->L <= 4)
+        return PIKA_EINVAL;
+    PrepDev a{*q};
+    hipLaunchKernelGGL(dstep_prep_kernel, dim3(q->rows), dim3(256), 0, (hipStream_t)stream, a);
+    return check(hipGetLastError());
+}
+
+int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, float *v_cache,
+                         const long long *ancestry, long long ancestry_pitch, const long long *pos,
+                         const long long *node, int rows, int L, int d, int heads, float *out, void *stream) {
+    if (!kvq || !k_cache || !v_cache || !ancestry || !pos || !node || !out || rows <= 0 || L <= 0 || heads <= 0)
+        return PIKA_EINVAL;
+    if (d % heads || d > 1024 || (d & 3) || (ldkvq & 3)) return PIKA_EINVAL;
+    const int dh = d / heads, g = dh >> 2, tpg = d >> 2;
+    if ((dh & 3) || g < 1 || g > 64 || (g & (g - 1)) || 256 % tpg) return PIKA_EINVAL;
+    const int G = 256 / tpg;
+    const size_t lds = sizeof(float) * (size_t)max(heads * L, G * d);
+    if (lds > 64 * 1024) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(dstep_attn_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, kvq, ldkvq, k_cache, v_cache,
+                       ancestry, ancestry_pitch, pos, node, L, d, heads, tpg, 1.f / sqrtf((float)dh), out);
+    return check(hipGetLastError());
+}
+
+int pika_dfc2_splits(int V) { return (V + FC2_COLS - 1) / FC2_COLS; }
+int pika_dfc2_cols_per_split(void) { return FC2_COLS; }
+
+int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
+                   float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream) {
+    if (!h || !W || !pmax || !psum || !pcand || rows <= 0 || V <= 0 || K <= 0 || topk < 1 || topk > 64 || terms < 1 ||
+        terms > 3 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
+        return PIKA_EINVAL;
+    const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
+    const unsigned grid = (unsigned)(((rows + FC2_BM - 1) / FC2_BM) * splits);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
+    Cand *pc = reinterpret_cast<Cand *>(pcand);
+    if (terms == 1) launch_fc2<1>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc);
+    else if (terms == 2) launch_fc2<2>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc);
+    else launch_fc2<3>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc);
+    return check(hipGetLastError());
+}
+
+}  // extern "C"

@@ -80,7 +80,7 @@ class BeamState(object):
              "y_raw": torch.zeros(self.B, self.K, dtype=torch.long, device=dev)}
         self.fst_dev = d
 
-    def _fst_advance_device(self, prev_k, lm_scale):
+    def _fst_advance_device(self, prev_k, lm_scale, skip=None):
         import ctypes
         from .. import _lib
         d, m = self.fst_dev, self.lm_scorer
@@ -91,7 +91,8 @@ class BeamState(object):
                 prev_k.data_ptr(), d["y_raw"].data_ptr(), self.y.data_ptr(), self.blk, float(self.nonblk_reward),
                 float(lm_scale), d["set_n"].data_ptr(), d["set_st"].data_ptr(), d["set_cs"].data_ptr(),
                 self.lm_scores.data_ptr(), self.scores.data_ptr(), self.fin_score.data_ptr(), self.fin_n.data_ptr(),
-                self.fin_cap, self.B, self.K, d["err"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+                self.fin_cap, self.B, self.K, d["err"].data_ptr(), None if skip is None else skip.data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "pika_fst_advance")
 
     def fst_overflowed(self):

@@ -1,0 +1,273 @@
+"""One beam-search step as a fixed chain of HIP launches (include/pika_decode_step.h), captured in ONE hipGraph.
+
+Reference loop body: decoder/transducer_decoder.py:123-186 -- prediction-network step for the rows whose last symbol
+is a label (:139-171; conv-transformer prediction net, trainer/model/rnnt_conv_transformer_lm.py:59-80), joint
+(:173-175), log-softmax (:177), `advance` per utterance (:182, decoder/beam_transducer.py:82-187), `_beam_update`
+(:188-202).  Here, per step and for all B*beam rows at once (row = b*beam + k):
+
+    prep -> [conv -> LN -> qkv -> attention -> out-proj(+res) -> LN -> w1(relu) -> w2(+res)] x layers -> LN -> linear_out
+         -> prediction halves of fc1/fc_gate with the gate in the epilogue -> fc2 with log-sum-exp + top-K partials
+         -> advance from the partials (+ device FST advance)
+
+22 launches (2 layers), no torch ops, no host reads: the (B*beam, V) logits never exist, nothing is cast or
+concatenated per step (weights are packed once per `decode_batch`), and because every buffer has a fixed shape the
+host can replay the graph several times per read of the `stop` flag (state-mutating launches are no-ops once it is set).
+
+Arithmetic: `terms` bf16 terms per operand -- 3 (default) reproduces fp32 products exactly (the parity mode: n-best
+lists identical to the reference's fp32 CPU decoder), 1 is plain bf16 operands.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_vp, _ll, _i = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
+DG_RELU, DG_GATE, DG_ROWMASK = 1, 2, 4
+MAX_LAYERS = 4
+
+
+class DGemm(ctypes.Structure):
+    _fields_ = [("A", _vp), ("lda", _ll), ("W", _vp), ("bias", _vp), ("res", _vp), ("ldr", _ll), ("C", _vp), ("ldc", _ll),
+                ("C2", _vp), ("ldc2", _ll), ("node", _vp), ("skip_node", _ll), ("e_all", _vp), ("t_idx", _vp),
+                ("T", _i), ("beam", _i), ("M", _i), ("N", _i), ("K", _i), ("terms", _i), ("flags", _i)]
+
+
+class DPrep(ctypes.Structure):
+    _fields_ = [("prev_k", _vp), ("y", _vp), ("hyp_len", _vp), ("step_t", _vp), ("t_idx", _vp),
+                ("state", _vp * 2), ("anc", _vp * 2), ("emb", _vp), ("X", _vp * MAX_LAYERS), ("A", _vp * MAX_LAYERS),
+                ("C", _i * MAX_LAYERS), ("lda", _ll * MAX_LAYERS), ("node", _vp), ("pos", _vp), ("dump_node", _ll),
+                ("zero_node", _ll), ("layers", _i), ("rows", _i), ("beam", _i), ("H", _i), ("L", _i), ("blk", _i),
+                ("stop", _vp)]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def supported(model, beam, K):
+    """Transformer prediction net on a HIP device, shapes the kernels take."""
+    dec = getattr(model, "decoder", None)
+    if model.decoder_type == "rnn" or dec is None or not hasattr(dec, "conv") or not beam.fused_ok():
+        return False
+    d = dec.layer_norm.normalized_shape[0]
+    heads = dec.transformer[0].self_attn.head_count
+    dh = d // heads
+    g = dh // 4
+    return (len(dec.conv) <= MAX_LAYERS and d % 4 == 0 and d <= 1024 and 256 % (d // 4) == 0 and dh % 4 == 0
+            and 1 <= g <= 64 and (g & (g - 1)) == 0 and K <= 64 and model.hid_dim % 4 == 0)
+
+
+class PackedWeight(object):
+    def __init__(self, w, terms, interleave2=False):
+        w = w.detach().float().contiguous()
+        self.N, self.K, self.terms = w.shape[0], w.shape[1], terms
+        lib = _lib.lib()
+        self.buf = torch.empty(lib.pika_dpack_bytes(self.N, self.K, terms), dtype=torch.uint8, device=w.device)
+        _lib.check(lib.pika_dpack_weight(w.data_ptr(), w.stride(0), self.N, self.K, terms, int(interleave2),
+                                         self.buf.data_ptr(), _stream()), "pika_dpack_weight")
+        self._keep = w      # stream-ordered use: keep the source alive until the pack kernel has run
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class FusedSearch(object):
+    """Device state + the launch chain of one step for a conv-transformer prediction net."""
+
+    def __init__(self, model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms=3):
+        self.model, self.beam = model, beam
+        net = model.decoder
+        dev = e_all.device
+        self.dev = dev
+        B, K = beam.B, beam.K
+        self.B, self.K, self.rows = B, K, B * K
+        R = self.rows
+        self.T, self.H, self.V = T, model.hid_dim, model.output_dim
+        self.terms = int(terms)
+        self.sm_scale, self.lm_scale = float(sm_scale), float(lm_scale)
+        self.e_all, self.num_frames = e_all.contiguous(), num_frames
+        self.nl = len(net.conv)
+        d = net.layer_norm.normalized_shape[0]
+        self.d, self.heads = d, net.transformer[0].self_attn.head_count
+        self.L = beam.hyp.shape[2] + 1                     # SOS + labels
+        max_steps = beam.s_cap
+        cap = (max_steps + 2) * R + 3
+        self.zero_node, self.dump_node = cap - 2, cap - 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        i64 = dict(dtype=torch.long, device=dev)
+        self.Cin = [c.weight.shape[1] for c in net.conv]
+        self.lda = [_ceil(5 * c, 32) for c in self.Cin]
+        self.X = [torch.zeros(cap, c, **f32) for c in self.Cin]
+        self.Kc = [torch.zeros(cap, d, **f32) for _ in range(self.nl)]
+        self.Vc = [torch.zeros(cap, d, **f32) for _ in range(self.nl)]
+        self.A = [torch.zeros(R, w, **f32) for w in self.lda]
+        self.state = [torch.zeros(R, self.H, **f32) for _ in range(2)]
+        self.anc = [torch.full((R, self.L), self.dump_node, **i64) for _ in range(2)]
+        self.node = torch.zeros(R, **i64)
+        self.pos = torch.zeros(R, **i64)
+        self.t_idx = torch.full((B, K), -1, **i64)                                  # :107
+        self.prev_k = torch.arange(K, device=dev).repeat(B).contiguous()            # identity parents for step 0
+        self.stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sync = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.max_hyp = torch.zeros(1, **i64)
+        self.eos_u8 = torch.zeros(B, dtype=torch.uint8, device=dev)
+        # activations of one step
+        self.y_conv = torch.empty(R, d, **f32)
+        self.ln = torch.empty(R, d, **f32)
+        self.kvq = torch.empty(R, 3 * d, **f32)
+        self.ctx = torch.empty(R, d, **f32)
+        self.o = torch.empty(R, d, **f32)
+        dff = net.transformer[0].feed_forward.w_1.weight.shape[0]
+        self.hmid = torch.empty(R, dff, **f32)
+        self.xfin = torch.empty(R, d, **f32)
+        self.h = torch.empty(R, self.H, **f32)
+        self.mean = torch.empty(R, **f32)
+        self.rstd = torch.empty(R, **f32)
+        lib = _lib.lib()
+        self.splits = lib.pika_dfc2_splits(self.V)
+        self.pmax = torch.empty(R * self.splits, **f32)
+        self.psum = torch.empty(R * self.splits, **f32)
+        self.pcand = torch.empty(R * self.splits * K * 8, dtype=torch.uint8, device=dev)
+        # weights, packed once
+        t = self.terms
+        self.layers = []
+        for l in range(self.nl):
+            conv, layer = net.conv[l], net.transformer[l]
+            att, ff = layer.self_attn, layer.feed_forward
+            wconv = conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1)   # tap-major (N, 5*C)
+            wqkv = torch.cat([att.linear_keys.weight, att.linear_values.weight, att.linear_query.weight], 0)
+            bqkv = torch.cat([att.linear_keys.bias, att.linear_values.bias, att.linear_query.bias], 0).detach().float().contiguous()
+            self.layers.append(dict(
+                conv=PackedWeight(wconv, t), bconv=conv.bias.detach().float().contiguous(),
+                ln1=layer.layer_norm, qkv=PackedWeight(wqkv, t), bqkv=bqkv,
+                fin=PackedWeight(att.final_linear.weight, t), bfin=att.final_linear.bias.detach().float().contiguous(),
+                ln2=ff.layer_norm, w1=PackedWeight(ff.w_1.weight, t), b1=ff.w_1.bias.detach().float().contiguous(),
+                w2=PackedWeight(ff.w_2.weight, t), b2=ff.w_2.bias.detach().float().contiguous()))
+        self.wout = PackedWeight(net.linear_out.weight, t)
+        self.bout = net.linear_out.bias.detach().float().contiguous()
+        H = self.H
+        wp = torch.cat((model.fc1.weight[:, H:], model.fc_gate.weight[:, H:]), dim=0)   # (2H, H) prediction halves
+        self.wp = PackedWeight(wp, t, interleave2=True)
+        self.w2 = PackedWeight(model.fc2.weight, t)
+        self.b2 = model.fc2.bias.detach().float().contiguous()
+        self.emb = net.embeddings.weight.detach().float().contiguous()
+        self.graph = None
+        self._init_sos()
+
+    # ---- launches ------------------------------------------------------------------------------------------
+    def _gemm(self, A, lda, W, bias, C, ldc, M, relu=False, res=None, ldr=0, C2=None, ldc2=0, rowmask=False, gate=False):
+        g = DGemm()
+        g.A, g.lda, g.W, g.bias = _ptr(A), lda, W.buf.data_ptr(), _ptr(bias)
+        g.res, g.ldr, g.C, g.ldc = _ptr(res), ldr, _ptr(C), ldc
+        g.C2, g.ldc2 = _ptr(C2), ldc2
+        g.node, g.skip_node = self.node.data_ptr(), self.dump_node
+        g.e_all, g.t_idx, g.T, g.beam = self.e_all.data_ptr(), self.t_idx.data_ptr(), self.T, self.K
+        g.M, g.N, g.K, g.terms = M, W.N, W.K, W.terms
+        g.flags = (DG_RELU if relu else 0) | (DG_GATE if gate else 0) | (DG_ROWMASK if rowmask else 0)
+        _lib.check(_lib.lib().pika_dgemm(ctypes.byref(g), _stream()), "pika_dgemm(M=%d,N=%d,K=%d)" % (M, W.N, W.K))
+
+    def _layer_norm(self, x, ln, y):
+        rows, C = x.shape
+        _lib.check(_lib.lib().pika_layer_norm_fwd(x.data_ptr(), rows, C, ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                                  float(ln.eps), y.data_ptr(), 0, self.mean.data_ptr(),
+                                                  self.rstd.data_ptr(), _stream()), "pika_layer_norm_fwd")
+
+    def _prednet(self, anc_dst, state_dst):
+        """All layers at the new position of every row; `node` / `pos` / A[l] were prepared."""
+        lib = _lib.lib()
+        R, d = self.rows, self.d
+        for l, w in enumerate(self.layers):
+            self._gemm(self.A[l], self.lda[l], w["conv"], w["bconv"], self.y_conv, d, R, relu=True)
+            self._layer_norm(self.y_conv, w["ln1"], self.ln)
+            self._gemm(self.ln, d, w["qkv"], w["bqkv"], self.kvq, 3 * d, R)
+            _lib.check(lib.pika_dstep_attention(self.kvq.data_ptr(), 3 * d, self.Kc[l].data_ptr(), self.Vc[l].data_ptr(),
+                                                anc_dst.data_ptr(), self.L, self.pos.data_ptr(), self.node.data_ptr(),
+                                                R, self.L, d, self.heads, self.ctx.data_ptr(), _stream()),
+                       "pika_dstep_attention")
+            self._gemm(self.ctx, d, w["fin"], w["bfin"], self.o, d, R, res=self.y_conv, ldr=d)
+            self._layer_norm(self.o, w["ln2"], self.ln)
+            self._gemm(self.ln, d, w["w1"], w["b1"], self.hmid, self.hmid.shape[1], R, relu=True)
+            if l + 1 < self.nl:
+                # the next layer's input: fifth tap block of its conv matrix + its cache row
+                nxt = self.A[l + 1][:, 4 * self.Cin[l + 1]:]
+                self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], nxt, self.lda[l + 1], R, res=self.o, ldr=d,
+                           C2=self.X[l + 1], ldc2=self.Cin[l + 1])
+            else:
+                self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], self.xfin, d, R, res=self.o, ldr=d)
+        self._layer_norm(self.xfin, self.model.decoder.layer_norm, self.ln)
+        # rows that emitted a label get the new state, the others keep the (re-ordered) old one (:139-171)
+        self._gemm(self.ln, d, self.wout, self.bout, state_dst, self.H, R, rowmask=True)
+
+    def _prep(self, parity):
+        p = DPrep()
+        b = self.beam
+        p.prev_k, p.y, p.hyp_len, p.step_t = self.prev_k.data_ptr(), b.y.data_ptr(), b.hyp_len.data_ptr(), b.step_t.data_ptr()
+        p.t_idx = self.t_idx.data_ptr()
+        for i in range(2):
+            p.state[i], p.anc[i] = self.state[i].data_ptr(), self.anc[i].data_ptr()
+        p.emb = self.emb.data_ptr()
+        for l in range(self.nl):
+            p.X[l], p.A[l], p.C[l], p.lda[l] = self.X[l].data_ptr(), self.A[l].data_ptr(), self.Cin[l], self.lda[l]
+        p.node, p.pos = self.node.data_ptr(), self.pos.data_ptr()
+        p.dump_node, p.zero_node = self.dump_node, self.zero_node
+        p.layers, p.rows, p.beam, p.H, p.L, p.blk = self.nl, self.rows, self.K, self.H, self.L, b.blk
+        p.stop = self.stop.data_ptr()
+        _lib.check(_lib.lib().pika_dstep_prep(ctypes.byref(p), _stream()), "pika_dstep_prep")
+
+    def _init_sos(self):
+        """Position 0 (the shared SOS / blank token, transducer_decoder.py:121) for every row: node 0."""
+        R = self.rows
+        with torch.cuda.device(self.dev):
+            self.node.zero_()
+            self.pos.zero_()
+            x0 = self.emb[self.beam.blk].unsqueeze(0)
+            self.X[0][0] = x0[0]
+            self.A[0].zero_()
+            self.A[0][:, 4 * self.Cin[0]:5 * self.Cin[0]] = x0
+            for l in range(1, self.nl):
+                self.A[l].zero_()
+            self.anc[0][:, 0] = 0
+            self._prednet(self.anc[0], self.state[0])
+            for l in range(1, self.nl):     # the scatter of layer inputs went to node 0: nothing else to do
+                pass
+
+    def step_launches(self, parity):
+        """Enqueue one search step that reads state/anc buffer `parity` (= steps taken & 1)."""
+        lib = _lib.lib()
+        b = self.beam
+        dst = parity ^ 1
+        with torch.cuda.device(self.dev):
+            self._prep(parity)
+            self._prednet(self.anc[dst], self.state[dst])
+            self._gemm(self.state[dst], self.H, self.wp, None, self.h, self.H, self.rows, gate=True)
+            _lib.check(lib.pika_dfc2_topk(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
+                                          self.V, self.H, self.terms, self.sm_scale, self.K, self.pmax.data_ptr(),
+                                          self.psum.data_ptr(), self.pcand.data_ptr(), _stream()), "pika_dfc2_topk")
+            fst = b.fst_dev
+            _lib.check(lib.pika_beam_advance_partials(
+                self.pmax.data_ptr(), self.psum.data_ptr(), self.pcand.data_ptr(), self.splits, b.scores.data_ptr(),
+                b.lm_scores.data_ptr(), self.lm_scale, b.y.data_ptr(), self.t_idx.data_ptr(), self.num_frames.data_ptr(),
+                b.max_len.data_ptr(), b.hyp.data_ptr(), b.hyp_len.data_ptr(), b.hyp.shape[2], b.ks_hist.data_ptr(),
+                b.ys_hist.data_ptr(), b.step_t.data_ptr(), self.eos_u8.data_ptr(), b.fin_score.data_ptr(),
+                b.fin_step.data_ptr(), b.fin_k.data_ptr(), b.fin_n.data_ptr(), b.fin_cap, self.prev_k.data_ptr(),
+                None if fst is None else fst["y_raw"].data_ptr(), self.B, self.K, self.V, b.blk, int(b.beam_prune),
+                b.n_best, self.stop.data_ptr(), self.max_hyp.data_ptr(), self.sync.data_ptr(), _stream()),
+                "pika_beam_advance_partials")
+            if fst is not None:
+                b._fst_advance_device(self.prev_k.view(self.B, self.K), self.lm_scale, skip=self.sync[4:5])
+
+    def launches_per_step(self):
+        return 1 + 8 * self.nl + 2 + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
+
+    def final_state(self, steps):
+        """Prediction-net states / frame indices in beam order after the last step (the attributes the reference
+        decoder leaves behind, transducer_decoder.py:107,121,188-202)."""
+        src = self.state[steps & 1]
+        flat = (torch.arange(self.B, device=self.dev).unsqueeze(1) * self.K + self.prev_k.view(self.B, self.K)).reshape(-1)
+        return src.index_select(0, flat), self.t_idx

@@ -48,6 +48,19 @@ class TransducerDecoder(object):
         self.use_graph = True   # capture the steady-state step in a hipGraph on the GPU
         self.fused_step = True   # fused HIP advance kernel on the GPU (include/pika_decode.h)
         self.incremental = True  # transformer prediction net: one new position per step (cached)
+        # GPU, transformer prediction net: the whole step as a fixed launch chain (fused_step.py), replayed
+        # `replays_per_sync` x 2 steps per host read of the stop flag.  decode_terms: bf16 terms per GEMM operand
+        # (3 = fp32-exact products, the parity mode; 1 = plain bf16 operands)
+        import os
+        self.fused_search = os.environ.get("PIKA_DECODE_FUSED_SEARCH", "1") != "0"
+        # decode_precision "fp32" (default): encoder, joint halves and every step GEMM with fp32-exact products --
+        # what "hypotheses identical to the reference's fp32 decoder" needs; "bf16": plain bf16 operands
+        self.decode_precision = os.environ.get("PIKA_DECODE_PRECISION", "fp32")
+        self.replays_per_sync = 4
+
+    @property
+    def decode_terms(self):
+        return 3 if self.decode_precision == "fp32" else 1
 
     # ---- prediction network stepping (fixed shapes: every row is recomputed, rows whose last
     # symbol is not a label keep their state; transducer_decoder.py:139-171) ---------------------
@@ -86,6 +99,16 @@ class TransducerDecoder(object):
     # ---- the search ---------------------------------------------------------------------------
     @torch.no_grad()
     def decode_batch(self, x, x_len, max_len=None):
+        from .. import gemm as G
+        old = G.PRECISION
+        if x.is_cuda and self.decode_precision in ("fp32", "bf16"):
+            G.PRECISION = self.decode_precision
+        try:
+            return self._decode_batch(x, x_len, max_len)
+        finally:
+            G.PRECISION = old
+
+    def _decode_batch(self, x, x_len, max_len=None):
         model, K = self.model, self.beam_size
         if model.pack_seq and x_len is not None:
             enc_out = model.encode(x, x_len)
@@ -114,6 +137,10 @@ class TransducerDecoder(object):
         wp = torch.cat((w1p, wgp), dim=0).contiguous()                            # (2H, H)
         brow = (torch.arange(B, device=dev) * T).unsqueeze(1)
 
+        if enc_out.is_cuda and self.fused_search and self.fused_step and not rnn:
+            from . import fused_step
+            if fused_step.supported(model, beam, K) and (self.lm_scorer is None or beam.fst_dev is not None):
+                return self._search_fused(beam, e_all, T, num_frames, enc_out, x, x_len, max_len)
         t_idx = torch.full((B, K), -1, dtype=torch.long, device=dev)          # :107
         self._inc = None
         if not rnn and self.incremental:
@@ -189,13 +216,58 @@ class TransducerDecoder(object):
             keep = self.fused_step
             self.fused_step = False
             try:
-                return self.decode_batch(x, x_len, max_len)
+                return self._decode_batch(x, x_len, max_len)
             finally:
                 self.fused_step = keep
         preds, scores = beam.results()
         self.timing = {"search_s": _t1 - _t0, "results_s": _time.perf_counter() - _t1,
                        "steps": beam.steps, "graphs": len(graphs)}
         return {"predictions": preds, "scores": scores}, enc_out
+
+
+def _search_fused(self, beam, e_all, T, num_frames, enc_out, x, x_len, max_len):
+    """The search loop on the fixed launch chain of fused_step.FusedSearch: two steps (the double-buffered
+    prediction-net state alternates) per hipGraph, `replays_per_sync` replays per host read."""
+    import time as _time
+    from .fused_step import FusedSearch
+    _t0 = _time.perf_counter()
+    fs = FusedSearch(self.model, beam, e_all, T, num_frames, self.sm_scale, self.lm_scorer_scale, terms=self.decode_terms)
+    fs.step_launches(0)
+    fs.step_launches(1)
+    graph, n_replays = None, 0
+    while not int(fs.stop.item()):
+        if self.use_graph:
+            if graph is None:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    fs.step_launches(0)
+                    fs.step_launches(1)
+            for _ in range(self.replays_per_sync):
+                graph.replay()
+            n_replays += self.replays_per_sync
+        else:
+            fs.step_launches(0)
+            fs.step_launches(1)
+    beam.steps = int(beam.step_t.item())
+    self.dec_states, self.t_idx = fs.final_state(beam.steps)
+    _t1 = _time.perf_counter()
+    if beam.fst_overflowed():
+        import warnings
+        warnings.warn("pika_amd: device FST state sets overflowed; re-decoding the batch on the host FST path")
+        keep = self.fused_step
+        self.fused_step = False
+        try:
+            return self._decode_batch(x, x_len, max_len)
+        finally:
+            self.fused_step = keep
+    preds, scores = beam.results()
+    self.timing = {"search_s": _t1 - _t0, "results_s": _time.perf_counter() - _t1, "steps": beam.steps,
+                   "graphs": 0 if graph is None else 1, "replays": n_replays, "launches_per_step": fs.launches_per_step(),
+                   "terms": self.decode_terms}
+    return {"predictions": preds, "scores": scores}, enc_out
+
+
+TransducerDecoder._search_fused = _search_fused
 
 
 def _las_scores(rescorer, x, tgt, scale=1.0):

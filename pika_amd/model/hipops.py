@@ -368,8 +368,9 @@ def joint_out_ok(h, weight):
     """JointOutFn preconditions: bf16 hidden, reduction a multiple of 64, vocabulary a multiple of
     8 (16-byte bf16 granules of the d(logits) copy) that one wave covers (log-softmax row kernels)."""
     N, K = weight.shape
+    # N <= 5120: what the d(logits) kernels of the backward take (one wave holds a 64-padded row: 64 x 4 x 20 columns)
     return (G.PRECISION == "bf16" and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
-            and N <= 8192)
+            and N <= 5120)
 
 
 class JointOutFn(torch.autograd.Function):

@@ -1,0 +1,201 @@
+"""Per-step decode kernels (include/pika_decode_step.h) against plain fp64 / torch formulas and against the
+logits-materialising advance they replace (pika_beam_advance, itself pinned by the reference-decoder goldens of
+tests/test_decode.py)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("terms,tol", [(1, 2e-2), (2, 2e-4), (3, 2e-6)])
+@pytest.mark.parametrize("M,N,K", [(70, 100, 64), (1024, 512, 2560), (33, 1536, 96), (1024, 2048, 512)])
+def test_dgemm_bias_relu_residual_scatter(hip_device, terms, tol, M, N, K):
+    from pika_amd.decoder.fused_step import DGemm, PackedWeight, DG_RELU, DG_ROWMASK
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K + terms)
+    lda, ldc = K + 32, N + 8
+    A = torch.randn(M, lda, generator=g).to(hip_device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(hip_device)
+    bias = torch.randn(N, generator=g).to(hip_device)
+    res = torch.randn(M, N, generator=g).to(hip_device)
+    node = torch.randperm(M + 5, generator=g)[:M].to(hip_device)
+    skip = int(node[3])
+    C = torch.full((M, ldc), 7.0, device=hip_device)
+    C2 = torch.zeros(M + 5, N, device=hip_device)
+    pw = PackedWeight(W, terms)
+    Kp = (K + 31) // 32 * 32
+    A[:, K:Kp] = 0
+    d = DGemm()
+    d.A, d.lda, d.W, d.bias, d.res, d.ldr = A.data_ptr(), lda, pw.buf.data_ptr(), bias.data_ptr(), res.data_ptr(), N
+    d.C, d.ldc, d.C2, d.ldc2, d.node, d.skip_node = C.data_ptr(), ldc, C2.data_ptr(), N, node.data_ptr(), skip
+    d.M, d.N, d.K, d.terms, d.flags = M, N, K, terms, DG_RELU | DG_ROWMASK
+    _lib.check(_lib.lib().pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm")
+    want = (torch.relu(A[:, :K].double() @ W.double().t() + bias.double()) + res.double())
+    got = C[:, :N].double()
+    scale = want.abs().max().item()
+    keep = node != skip
+    assert (got[keep] - want[keep]).abs().max().item() <= tol * scale
+    assert torch.all(C[~keep][:, :N] == 7.0) and torch.all(C[:, N:] == 7.0)        # masked row, padding untouched
+    assert (C2[node[keep]].double() - want[keep]).abs().max().item() <= tol * scale
+
+
+def test_dgemm_gate_epilogue(hip_device):
+    """Prediction halves of fc1 / fc_gate + gathered encoder halves + tanh * sigmoid (transducer.py:107-109)."""
+    from pika_amd.decoder.fused_step import DGemm, PackedWeight, DG_GATE
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    B, beam, T, H = 3, 4, 11, 64
+    R = B * beam
+    state = torch.randn(R, H, generator=g).to(hip_device)
+    wp = (torch.randn(2 * H, H, generator=g) * 0.2).to(hip_device)
+    e_all = torch.randn(B * T, 2 * H, generator=g).to(hip_device)
+    t_idx = torch.randint(-1, T + 2, (R,), generator=g).to(hip_device)
+    pw = PackedWeight(wp, 3, interleave2=True)
+    out = torch.empty(R, H, device=hip_device)
+    d = DGemm()
+    d.A, d.lda, d.W, d.C, d.ldc = state.data_ptr(), H, pw.buf.data_ptr(), out.data_ptr(), H
+    d.e_all, d.t_idx, d.T, d.beam = e_all.data_ptr(), t_idx.data_ptr(), T, beam
+    d.M, d.N, d.K, d.terms, d.flags = R, 2 * H, H, 3, DG_GATE
+    _lib.check(_lib.lib().pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm gate")
+    z = state.double() @ wp.double().t()
+    rows = torch.arange(R, device=hip_device) // beam * T + t_idx.clamp(0, T - 1)
+    e = e_all[rows].double()
+    want = torch.tanh(z[:, :H] + e[:, :H]) * torch.sigmoid(z[:, H:] + e[:, H:])
+    assert (out.double() - want).abs().max().item() < 2e-6
+
+
+def _beam_inputs(B, K, V, L, g, dev, first):
+    s = dict(scores=torch.randn(B, K, generator=g), lm_scores=torch.zeros(B, K),
+             y=torch.randint(0, V, (B, K), generator=g), t_idx=torch.randint(0, 6, (B, K), generator=g),
+             num_frames=torch.full((B,), 6, dtype=torch.long), max_len=torch.full((B,), 30, dtype=torch.long),
+             hyp=torch.randint(1, V, (B, K, L), generator=g), hyp_len=torch.randint(0, 5, (B, K), generator=g),
+             eos=torch.zeros(B, dtype=torch.uint8))
+    s["y"][0, 1] = -1                                   # an eos row
+    s["hyp"][1, 2] = s["hyp"][1, 0]
+    s["hyp_len"][1, 2] = s["hyp_len"][1, 0] = 3         # a duplicate partial hypothesis
+    s["y"][1, 0] = s["y"][1, 2] = 4
+    if first:
+        s["scores"].zero_()
+        s["y"].zero_()
+        s["hyp_len"].zero_()
+    return {k: v.to(dev) for k, v in s.items()}
+
+
+@pytest.mark.parametrize("V,K,Hd,first", [(100, 4, 64, False), (5000, 16, 128, False), (333, 8, 64, True)])
+@pytest.mark.parametrize("terms", [3, 1])
+def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, first, terms):
+    """fc2 + partial log-sum-exp / top-K + pika_beam_advance_partials == materialised logits -> pika_beam_advance:
+    same parents, symbols, finished lists; scores to fp32 rounding of the log-sum-exp."""
+    from pika_amd.decoder.fused_step import PackedWeight
+    from pika_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(V + K + terms)
+    B, L, blk, S_steps = 3, 12, 0, 40
+    R = B * K
+    h = torch.randn(R, Hd, generator=g).to(hip_device)
+    W = (torch.randn(V, Hd, generator=g) * 0.5).to(hip_device)
+    bias = torch.randn(V, generator=g).to(hip_device)
+    pw = PackedWeight(W, terms)
+    sm = 0.8
+    splits = lib.pika_dfc2_splits(V)
+    pmax = torch.empty(R * splits, device=hip_device)
+    psum = torch.empty(R * splits, device=hip_device)
+    pcand = torch.empty(R * splits * K * 8, dtype=torch.uint8, device=hip_device)
+    _lib.check(lib.pika_dfc2_topk(h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), R, V, Hd, terms, sm, K,
+                                  pmax.data_ptr(), psum.data_ptr(), pcand.data_ptr(), _st()), "pika_dfc2_topk")
+    # the logits the same arithmetic produces (terms-term operands): via a plain dgemm, then the old advance
+    from pika_amd.decoder.fused_step import DGemm
+    logits = torch.empty(R, V, device=hip_device)
+    d = DGemm()
+    d.A, d.lda, d.W, d.bias, d.C, d.ldc = h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), logits.data_ptr(), V
+    d.M, d.N, d.K, d.terms, d.flags = R, V, Hd, terms, 0
+    _lib.check(lib.pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm")
+    if terms == 3:
+        want = h.double() @ W.double().t() + bias.double()
+        assert (logits.double() - want).abs().max().item() < 3e-6 * want.abs().max().item()
+    # partial statistics
+    x = (sm * logits).double()
+    lse = torch.logsumexp(x, dim=1)
+    pm = pmax.view(R, splits).double()
+    got_lse = (psum.view(R, splits).double() * torch.exp(pm - pm.max(1, keepdim=True).values)).sum(1).log() + pm.max(1).values
+    assert (got_lse - lse).abs().max().item() < 1e-5
+
+    def run(use_partials):
+        st = _beam_inputs(B, K, V, L, torch.Generator().manual_seed(9), hip_device, first)
+        ks_hist = torch.zeros(S_steps, B, K, dtype=torch.long, device=hip_device)
+        ys_hist = torch.zeros(S_steps + 1, B, K, dtype=torch.long, device=hip_device)
+        step_t = torch.full((1,), 0 if first else 3, dtype=torch.long, device=hip_device)
+        fin_cap = K * S_steps + 1
+        fin_score = torch.zeros(B, fin_cap, device=hip_device)
+        fin_step = torch.zeros(B, fin_cap, dtype=torch.long, device=hip_device)
+        fin_k = torch.zeros(B, fin_cap, dtype=torch.long, device=hip_device)
+        fin_n = torch.zeros(B, dtype=torch.long, device=hip_device)
+        prev_k = torch.zeros(B, K, dtype=torch.long, device=hip_device)
+        y_raw = torch.zeros(B, K, dtype=torch.long, device=hip_device)
+        stop = torch.zeros(1, dtype=torch.int32, device=hip_device)
+        sync = torch.zeros(8, dtype=torch.int32, device=hip_device)
+        max_hyp = torch.zeros(1, dtype=torch.long, device=hip_device)
+        common = [st["scores"].data_ptr(), st["lm_scores"].data_ptr(), 1.0, st["y"].data_ptr(), st["t_idx"].data_ptr(),
+                  st["num_frames"].data_ptr(), st["max_len"].data_ptr(), st["hyp"].data_ptr(), st["hyp_len"].data_ptr(), L,
+                  ks_hist.data_ptr(), ys_hist.data_ptr(), step_t.data_ptr(), st["eos"].data_ptr(), fin_score.data_ptr(),
+                  fin_step.data_ptr(), fin_k.data_ptr(), fin_n.data_ptr(), fin_cap, prev_k.data_ptr(), y_raw.data_ptr()]
+        if use_partials:
+            _lib.check(lib.pika_beam_advance_partials(pmax.data_ptr(), psum.data_ptr(), pcand.data_ptr(), splits, *common,
+                                                      B, K, V, blk, 1, K, stop.data_ptr(), max_hyp.data_ptr(),
+                                                      sync.data_ptr(), _st()), "pika_beam_advance_partials")
+            assert int(step_t) == (1 if first else 4) and int(max_hyp) == int(st["hyp_len"].max())
+        else:
+            cand = torch.empty(B * K * K * 8, dtype=torch.uint8, device=hip_device)
+            _lib.check(lib.pika_beam_advance(logits.data_ptr(), sm, int(first), *common, cand.data_ptr(), B, K, V, blk, 1,
+                                             _st()), "pika_beam_advance")
+        torch.cuda.synchronize()
+        return dict(st, prev_k=prev_k, y_raw=y_raw, fin_n=fin_n, fin_score=fin_score, fin_k=fin_k, fin_step=fin_step)
+    a, b = run(True), run(False)
+    for k in ("prev_k", "y_raw", "y", "t_idx", "hyp", "hyp_len", "fin_n", "fin_k", "fin_step", "eos"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.allclose(a["scores"], b["scores"], rtol=0, atol=2e-5)
+    assert torch.allclose(a["fin_score"], b["fin_score"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("dec_terms", ["fp32", "bf16"])
+def test_fused_search_equals_stepwise_search(hip_device, dec_terms):
+    """The launch-chain search (hipGraph, several steps per host read) and the op-by-op search return the same
+    n-best lists for the tiny golden model, with and without graph replay."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from types import SimpleNamespace
+    import decode_common as D
+    from test_decode import build
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    net = build("transformer", hip_device)
+    x, x_len = D.inputs()
+    x, x_len_d = x.to(hip_device), x_len.to(hip_device)
+    args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    for name in ("beam4", "beam8", "beam3_short"):
+        cfg = D.SCENARIOS[name]
+        outs = []
+        for fused, graph in ((True, True), (True, False), (False, True)):
+            d = TransducerDecoder(net, batch_size=x.shape[0], beam_size=cfg["beam"], n_best=cfg["n_best"], blk=0,
+                                  global_scorer=GlobalScorer(), sm_scale=cfg["sm_scale"], cuda=True, beam_prune=True, args=args)
+            d.fused_search, d.use_graph, d.decode_precision = fused, graph, dec_terms
+            ret, _ = d.decode_batch(x, x_len_d, D.max_len(cfg, x_len))
+            outs.append(D.pack(ret["predictions"], ret["scores"]))
+            if fused:
+                assert d.timing["launches_per_step"] == 22 and d.timing["steps"] > 5
+        if dec_terms == "fp32":
+            for o in outs[1:]:
+                assert np.array_equal(o["hyps"], outs[0]["hyps"]) and np.array_equal(o["lens"], outs[0]["lens"]), name
+                assert np.allclose(o["scores"], outs[0]["scores"], atol=1e-4)
+        else:       # bf16 operands: graph and eager runs of the SAME chain agree exactly; the op-by-op search rounds
+            assert np.array_equal(outs[0]["hyps"], outs[1]["hyps"])          # elsewhere and may differ on near-ties
