@@ -644,7 +644,8 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
         "metric": "decode RTF (wall / audio seconds), batch beam search", "value": el / audio_s,
         "unit": "RTF", "n_gpus": world, "steps": 2, "warmup": 1,
         "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (3-term bf16 split on MFMA)" if step.decoder.decode_precision == "fp32" else "bf16",
+        "data": "synthetic",
         "config": {"workload": "decode (BASELINE configs[4]): B=%d beam=%d n_best=%d, %d-frame utterances, full model "
                                "(%s prediction net), sm_scale 0.8%s%s; each rank decodes its own batch (replicas)" % (
                                    a.batch, a.beam, a.beam, a.frames, a.pred_net,
@@ -671,7 +672,8 @@ def cpu_baseline_decode(a, blank_bias, B=4):
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
     T, V = a.frames, a.vocab
-    torch.set_num_threads(os.cpu_count() or 8)
+    # the search is ~150 small ops per step: more threads than ~16 only add fork/join time per op
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type=a.pred_net, brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
     torch.manual_seed(777)

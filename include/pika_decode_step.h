@@ -66,17 +66,21 @@ typedef struct {
     const long long *t_idx;  /* GATE: (M) i64                                                        */
     int T, beam;
     int M, N, K, terms, flags;
+    const int *m_dev;        /* device int32 or NULL: only rows < min(M, *m_dev) are computed (compact row lists) */
+    const long long *crow;   /* (M) i64 or NULL: row r of the result is stored at row crow[r] of C     */
 } pika_dgemm_t;
 int pika_dgemm(const pika_dgemm_t *p, void *stream);
 
 /* ---- prediction-network bookkeeping of one step ---------------------------------------------------------------
  * rows = B*beam, row r = b*beam + k.  state / anc are double-buffered: step s reads buffer s&1 and writes (s+1)&1.
  * For every row: parent pr = b*beam + prev_k[r]; state_dst[r] = state_src[pr]; anc_dst[r,:] = anc_src[pr,:];
- * tok = y[r]; t_idx[r] += (tok == blk); commit = tok > blk; p = min(hyp_len[r], L-1);
- * node[r] = commit ? 1 + s*rows + r : dump_node; commit: anc_dst[r,p] = node[r];
- * layer 0: x = emb[max(tok,0)]; X[0][node] = x; A[0][r] = [X[0][anc[p-4]] .. X[0][anc[p-1]] | x]  (zero left of 0)
- * layer l>0: A[l][r, :4*C[l]] = [X[l][anc[p-4]] .. X[l][anc[p-1]]]   (the fifth block is written by the layer below)
- * pos[r] = p.  s = *step_t (steps taken so far). */
+ * tok = y[r]; t_idx[r] += (tok == blk); p = min(hyp_len[r], L-1).  Rows with tok > blk (a label was emitted: the
+ * only rows whose prediction-net state changes, transducer_decoder.py:139-171) get a SLOT in a compact row list
+ * (slot = count[s&1]++, order arbitrary): rowmap[slot] = r; node[slot] = 1 + s*rows + r; pos[slot] = p;
+ * anc_dst[r,p] = node;
+ * layer 0: x = emb[tok]; X[0][node] = x; A[0][slot] = [X[0][anc[p-4]] .. X[0][anc[p-1]] | x]  (zero left of 0)
+ * layer l>0: A[l][slot, :4*C[l]] = [X[l][anc[p-4]] .. X[l][anc[p-1]]]  (the fifth block is written by the layer below)
+ * s = *step_t (steps taken so far).  The prediction-net launches of the step then run on count[s&1] rows. */
 #define PIKA_DSTEP_MAX_LAYERS 4
 typedef struct {
     const long long *prev_k, *y, *hyp_len, *step_t;
@@ -88,7 +92,10 @@ typedef struct {
     float *A[PIKA_DSTEP_MAX_LAYERS];   /* (rows, lda[l]) causal-conv input matrices, lda[l] >= 5*C[l] */
     int C[PIKA_DSTEP_MAX_LAYERS];
     long long lda[PIKA_DSTEP_MAX_LAYERS];
-    long long *node, *pos;   /* (rows) outputs                                                       */
+    long long *node, *pos;   /* (rows) outputs, indexed by SLOT                                      */
+    long long *rowmap;       /* (rows) output: slot -> row                                           */
+    int *count;              /* int32[2]: count[s & 1] += rows that emitted a label (the caller zeroes it; the
+                                advance call re-zeroes the other parity's counter)                   */
     long long dump_node, zero_node;
     int layers, rows, beam, H, L, blk;
     const int *stop;
@@ -100,7 +107,10 @@ int pika_dstep_prep(const pika_dstep_prep_t *p, void *stream);
  * stored into k_cache / v_cache at node[r] by this launch and read back from kvq for position pos[r]. */
 int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, float *v_cache,
                          const long long *ancestry, long long ancestry_pitch, const long long *pos,
-                         const long long *node, int rows, int L, int d, int heads, float *out, void *stream);
+                         const long long *node, const long long *rowmap, const int *m_dev, int rows, int L, int d,
+                         int heads, float *out, void *stream);
+/* kvq / pos / node / out are indexed by slot (< min(rows, *m_dev)); the ancestry row of slot i is rowmap[i]
+ * (identity when rowmap is NULL). */
 
 /* ---- fc2 + log-sum-exp partials + per-row top-K partials -------------------------------------------------------
  * h (rows, K) f32, W packed (V, K).  Column range s of `splits` (= pika_dfc2_splits(V)) covers
@@ -118,7 +128,9 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
  * `first` is read from the device (*step_t == 0); the step counter is incremented by the call;
  * done[b] (u8) = eos_top[b] && fin_n[b] >= n_best; *stop = all utterances done; *max_hyp = max hyp_len.
  * sync (int32[8], zeroed once by the caller): [0..3] scratch for the cross-workgroup arrival counts of even / odd
- * steps; [4] is set once a call was skipped because *stop was already set (the gate of the FST advance that follows). */
+ * steps; [4] is set once a call was skipped because *stop was already set (the gate of the FST advance that follows);
+ * [5], [6] are the compact-row counters of pika_dstep_prep (count = sync + 5): the call zeroes the one the next step
+ * will fill.  Needs K*L*4 + K*K*8 + 4*splits*K*8 bytes of LDS <= 96 KiB (PIKA_ETOOBIG otherwise). */
 int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
                                float *scores, const float *lm_scores, float lm_scale, long long *y,
                                long long *t_idx, const long long *num_frames, const long long *max_len,

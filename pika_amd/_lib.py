@@ -78,7 +78,7 @@ SIGNATURES = {
     "pika_dpack_weight": (_i, [_vp, _ll, _i, _i, _i, _i, _vp, _vp]),
     "pika_dgemm": (_i, [_vp, _vp]),
     "pika_dstep_prep": (_i, [_vp, _vp]),
-    "pika_dstep_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pika_dstep_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pika_dfc2_splits": (_i, [_i]),
     "pika_dfc2_cols_per_split": (_i, []),
     "pika_dfc2_topk": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp]),

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
     Cand *cand = reinterpret_cast<Cand *>(hyp_l + a.K * a.L);            // [K][K]
+    Cand *pool_all = cand + a.K * a.K;                                   // [4 waves][S*K]
     __shared__ BeamShared sh;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, L = a.L, V = a.V;
@@ -291,21 +292,26 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float logsum = __logf(s);
         const float add_s = a.scores[bk + k], add_l = a.lm_scale * sh.lm_old[k];
-        int ptr = 0;
-        const Cand *list = pcand + (pi + (lane < S ? lane : 0)) * K;
-        Cand head = lane < S ? list[0] : Cand{-INFINITY, 0x7fffffff};
+        // all S*K partial candidates of the row into this wave's LDS slab with ONE round of loads, then K rounds of
+        // "lane-local best over its strided share + wave arg-max" (no load sits on the selection's critical path)
+        const int n = S * K;
+        Cand *pool = pool_all + wave * n;
+        const Cand *src = pcand + pi * K;
+        for (int q = lane; q < n; q += 64) pool[q] = src[q];
         for (int r = 0; r < K; ++r) {
-            float bv = head.v;
-            int bi = head.idx;
+            float bv = -INFINITY;
+            int bi = 0x7fffffff, bq = -1;
+            for (int q = lane; q < n; q += 64) {
+                const Cand c = pool[q];
+                if (better(c.v, c.idx, bv, bi)) { bv = c.v; bi = c.idx; bq = q; }
+            }
+            const int my = bi;
             for (int o = 32; o > 0; o >>= 1) {
                 const float ov = __shfl_xor(bv, o);
                 const int oi = __shfl_xor(bi, o);
                 if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
             }
-            if (lane < S && bi == head.idx && bi != 0x7fffffff) {      // the owning list pops its head
-                ++ptr;
-                head = ptr < K ? list[ptr] : Cand{-INFINITY, 0x7fffffff};
-            }
+            if (bq >= 0 && my == bi && bi != 0x7fffffff) pool[bq] = Cand{-INFINITY, 0x7fffffff};   // the owner pops it
             if (lane == 0) {
                 float val = (bv - m) - logsum;                 // log_softmax, torch's operation order
                 if (!first) val = (val + add_s) + add_l;       // (:94-97)
@@ -331,6 +337,7 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
             if (ndone == a.B) atomicExch(stop, 1);
             sync[(par ^ 1) * 2] = 0;
             sync[(par ^ 1) * 2 + 1] = 0;
+            sync[5 + (par ^ 1)] = 0;                  // the compact-row counter the NEXT step's prep will fill
             step_rw[0] = s_now + 1;
         }
     }
@@ -653,7 +660,8 @@ extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, 
         !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step || !fin_k || !fin_n ||
         !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
         return PIKA_EINVAL;
-    if (K > MAXK || splits > 64 || (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) > 96 * 1024) return PIKA_ETOOBIG;
+    const size_t lds_bytes = (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)4 * splits * K * sizeof(Cand);
+    if (K > MAXK || splits > 64 || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_partials_kernel),
@@ -663,8 +671,7 @@ extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, 
     }
     BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
                 eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
-    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(256), (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand),
-                       static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
+    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
                        beam_prune, n_best, stop, max_hyp, sync, step_t);
     return (int)hipGetLastError();
 }

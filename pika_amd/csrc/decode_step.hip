@@ -20,7 +20,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PITCH = 40;   // bf16 per LDS row of 32 (80 bytes: the 16 rows of a fragment read hit 16 distinct 4-bank groups)
 
 // ---- weight packing: packed[term][n_tile][k_tile][lane][8], n_tile = 16 columns, k_tile = 32 ----------------
 __global__ void dpack_kernel(const float *__restrict__ W, long long ldw, int N, int K, int NT, int KT, int terms,
@@ -51,14 +50,18 @@ __global__ void dpack_kernel(const float *__restrict__ W, long long ldw, int N, 
 
 // ---- the shared main loop ------------------------------------------------------------------------------------
 // Workgroup = 256 threads = 4 waves; tile = BM rows x (4 waves x WN x 16) columns; wave w owns column tiles
-// [(ng*4 + w)*WN, +WN).  A (fp32, global) -> registers -> NS bf16 terms -> LDS (double buffered, one barrier per
-// 32-wide k-step); W fragments global -> registers, one k-step ahead.
-template <int BM, int WN, int NS>
+// [(ng*4 + w)*WN, +WN).  One step covers KS k-tiles of 32: A (fp32, global) -> registers -> NS bf16 terms -> LDS
+// (double buffered, one barrier per step); W fragments global -> registers.  Everything of step k+1 is requested
+// before the MFMAs of step k: these launches are latency-bound (one or two workgroups per CU, weights coming from
+// L2 / Infinity Cache), so what counts is bytes in flight per wave -- KS*32 columns per request round.
+template <int BM, int WN, int NS, int KS>
 struct Core {
     static constexpr int MT = BM / 16;
-    static constexpr int APT = BM * 8 / 256;      // float4 loads of A per thread per k-step (BM = 32: 1, 64: 2)
+    static constexpr int BK = 32 * KS;
+    static constexpr int PITCH = BK + 8;          // bf16 per LDS row: the 16 rows of a fragment read start 4 banks apart
+    static constexpr int APT = BM * (BK / 4) / 256;   // float4 loads of A per thread per step
     static constexpr int LDS_BYTES = 2 * NS * BM * PITCH * 2;
-    static_assert(BM == 32 || BM == 64, "BM");
+    static_assert((BM == 32 || BM == 64) && (BM * (BK / 4)) % 256 == 0, "tile");
 
     f32x4 acc[MT][WN];
 
@@ -69,36 +72,39 @@ struct Core {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // A loader: float4 index f = tid + 256*i -> row f/8, column group f%8
+        // A loader: float4 index f = tid + 256*i -> row f / (BK/4), column group f % (BK/4)
         const float *arow[APT];
-        int aoff[APT];
+        int aoff[APT], acol[APT];
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
-            const int f = tid + 256 * i, r = f >> 3, c4 = f & 7;
+            const int f = tid + 256 * i, r = f / (BK / 4), c4 = f % (BK / 4);
             arow[i] = (m0 + r < M) ? A + (long long)(m0 + r) * lda + c4 * 4 : nullptr;
             aoff[i] = r * PITCH + c4 * 4;
+            acol[i] = c4 * 4;
         }
         const __bf16 *wbase[WN];
-        bool wok[WN];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            wok[j] = nt0 + j < NT;
-            wbase[j] = W + ((long long)(wok[j] ? nt0 + j : 0) * KT) * 512 + lane * 8;
-        }
+        for (int j = 0; j < WN; ++j) wbase[j] = W + ((long long)(nt0 + j < NT ? nt0 + j : 0) * KT) * 512 + lane * 8;
         const long long term_stride = (long long)NT * KT * 512;
+        const int Kcols = KT * 32, steps = (KT + KS - 1) / KS;
         f32x4 araw[APT];
-        bf16x8 wreg[WN][NS], wnext[WN][NS];
-        auto load_a = [&](int kt) {
+        bf16x8 wreg[WN][KS][NS], wnext[WN][KS][NS];
+        auto load_a = [&](int st) {
 #pragma unroll
             for (int i = 0; i < APT; ++i)
-                araw[i] = arow[i] ? *reinterpret_cast<const f32x4 *>(arow[i] + kt * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+                araw[i] = (arow[i] && st * BK + acol[i] < Kcols) ? *reinterpret_cast<const f32x4 *>(arow[i] + st * BK)
+                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
         };
-        auto load_w = [&](int kt, bf16x8 (&dst)[WN][NS]) {
+        auto load_w = [&](int st, bf16x8 (&dst)[WN][KS][NS]) {
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    dst[j][s] = *reinterpret_cast<const bf16x8 *>(wbase[j] + s * term_stride + (long long)kt * 512);
+                for (int q = 0; q < KS; ++q) {
+                    const int kt = st * KS + q < KT ? st * KS + q : KT - 1;     // tail: any valid tile (its A is zero)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        dst[j][q][s] = *reinterpret_cast<const bf16x8 *>(wbase[j] + s * term_stride + (long long)kt * 512);
+                }
         };
         auto stage_a = [&](int buf) {
             __bf16 *dst = lds + buf * (NS * BM * PITCH);
@@ -117,37 +123,42 @@ struct Core {
         load_w(0, wreg);
         stage_a(0);
         __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const bool more = kt + 1 < KT;
+        for (int st = 0; st < steps; ++st) {
+            const bool more = st + 1 < steps;
             if (more) {
-                load_a(kt + 1);
-                load_w(kt + 1, wnext);
+                load_a(st + 1);
+                load_w(st + 1, wnext);
             }
-            const __bf16 *src = lds + (kt & 1) * (NS * BM * PITCH);
-            bf16x8 a[MT][NS];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    a[i][s] = *reinterpret_cast<const bf16x8 *>(src + s * (BM * PITCH) + (i * 16 + (lane & 15)) * PITCH +
-                                                                (lane >> 4) * 8);
+            const __bf16 *src = lds + (st & 1) * (NS * BM * PITCH);
             // products of one kind across all accumulators before the next kind (consecutive MFMAs never share an
             // accumulator); smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
             constexpr int NP = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
             constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int q = 6 - NP; q < 6; ++q)
+            for (int q = 0; q < KS; ++q) {
+                bf16x8 a[MT][NS];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][PW[q]], a[i][PA[q]], acc[i][j], 0, 0, 0);
+                    for (int s = 0; s < NS; ++s)
+                        a[i][s] = *reinterpret_cast<const bf16x8 *>(src + s * (BM * PITCH) + (i * 16 + (lane & 15)) * PITCH +
+                                                                    q * 32 + (lane >> 4) * 8);
+#pragma unroll
+                for (int p = 6 - NP; p < 6; ++p)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][q][PW[p]], a[i][PA[p]], acc[i][j], 0, 0, 0);
+            }
             if (more) {
-                stage_a((kt + 1) & 1);
+                stage_a((st + 1) & 1);
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) wreg[j][s] = wnext[j][s];
+                    for (int q = 0; q < KS; ++q)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) wreg[j][q][s] = wnext[j][q][s];
             }
             __syncthreads();
         }
@@ -158,16 +169,34 @@ struct DG {   // device copy of pika_dgemm_t
     const float *A; long long lda; const __bf16 *W; const float *bias; const float *res; long long ldr;
     float *C; long long ldc; float *C2; long long ldc2; const long long *node; long long skip_node;
     const float *e_all; const long long *t_idx; int T, beam, M, N, NT, KT, flags;
+    const int *m_dev; const long long *crow;
 };
+
+// blockIdx -> (row tile, column group) so that a column group always lands on the same XCD (block b runs on XCD
+// b % 8): the row tiles that share a slab of W then share it in that XCD's L2 instead of re-reading it from the
+// Infinity Cache once per row tile.  groups_per_xcd = ceil(n_groups / 8); false = idle workgroup.
+__device__ inline bool xcd_tile(int n_groups, int &mg, int &ng) {
+    const int g = blockIdx.x, xcd = g & 7, i = g >> 3;
+    const int gpx = (n_groups + 7) >> 3;
+    ng = xcd + 8 * (i % gpx);
+    mg = i / gpx;
+    return ng < n_groups;
+}
+
+template <int BM, int NS>
+struct DgCfg { static constexpr int KS = BM == 32 ? 4 : 2; typedef Core<BM, 1, NS, KS> core_t; };
 
 template <int BM, int NS>
 __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Core<BM, 1, NS> core;
+    typename DgCfg<BM, NS>::core_t core;
     const int n_groups = (p.NT + 3) / 4;
-    const int mg = blockIdx.x / n_groups, ng = blockIdx.x - mg * n_groups;
+    int mg, ng;
+    if (!xcd_tile(n_groups, mg, ng)) return;
+    if (p.m_dev) { const int md = *p.m_dev; if (md < p.M) p.M = md; }     // rows actually in use this step
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mg * BM, nt0 = ng * 4 + wave;
+    if (m0 >= p.M) return;
     core.run(p.A, p.lda, p.M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem));
     if (nt0 >= p.NT) return;
     const int c0 = nt0 * 16 + (lane >> 4) * 4;          // first of this lane's 4 consecutive columns
@@ -189,7 +218,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
                 const float z1 = v[2 * u] + e[j0 + u], zg = v[2 * u + 1] + e[H + j0 + u];
                 o[u] = tanhf(z1) * (1.f / (1.f + expf(-zg)));
             }
-            float *dst = p.C + (long long)r * p.ldc + j0;
+            float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + j0;
             dst[0] = o[0];
             if (j0 + 1 < H) dst[1] = o[1];
             continue;
@@ -212,7 +241,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
         }
         const long long nd = p.node ? p.node[r] : 0;
         if ((p.flags & PIKA_DG_ROWMASK) && nd == p.skip_node) continue;
-        float *dst = p.C + (long long)r * p.ldc + c0;
+        float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + c0;
         if (full && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
             *reinterpret_cast<f32x4 *>(dst) = v;
         } else {
@@ -237,6 +266,7 @@ struct PrepDev {
 __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     const pika_dstep_prep_t &p = a.p;
     if (p.stop && *p.stop) return;
+    __shared__ int slot_s;
     const int r = blockIdx.x, tid = threadIdx.x;
     const long long s = p.step_t[0];
     const int src = (int)(s & 1), dst = src ^ 1;
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     const bool commit = tok > p.blk;
     long long pos = p.hyp_len[r];
     if (pos > p.L - 1) pos = p.L - 1;
-    const long long node = commit ? 1 + s * p.rows + r : p.dump_node;
+    const long long node = 1 + s * p.rows + r;
     // state and ancestry follow the parent (transducer_decoder.py:188-202)
     const float *ss = p.state[src] + pr * p.H;
     float *sd = p.state[dst] + (long long)r * p.H;
@@ -256,15 +286,24 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     }
     const long long *as = p.anc[src] + pr * p.L;
     long long *ad = p.anc[dst] + (long long)r * p.L;
-    for (long long j = tid; j < p.L; j += 256) {
+    const long long ncopy = pos + 1 < p.L ? pos + 1 : p.L;      // positions > pos are never read
+    for (long long j = tid; j < ncopy; j += 256) {
         long long v = as[j];
         if (commit && j == pos) v = node;
         ad[j] = v;
     }
     if (tid == 0) {
         if (tok == p.blk) p.t_idx[r] += 1;                       // :129
-        p.node[r] = node;
-        p.pos[r] = pos;
+        // rows that emitted a label get a slot in the compact row list the prediction-net launches work on
+        slot_s = commit ? atomicAdd(p.count + src, 1) : -1;
+    }
+    __syncthreads();
+    if (!commit) return;
+    const int slot = slot_s;
+    if (tid == 0) {
+        p.rowmap[slot] = r;
+        p.node[slot] = node;
+        p.pos[slot] = pos;
     }
     // taps p-4 .. p-1 through the PARENT's ancestry (positions < p are unchanged by this step)
     long long tap[4];
@@ -275,15 +314,14 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     }
     for (int l = 0; l < p.layers; ++l) {
         const int C = p.C[l];
-        float *arow = p.A[l] + (long long)r * p.lda[l];
+        float *arow = p.A[l] + (long long)slot * p.lda[l];
         for (int e = tid; e < 4 * C; e += 256) {
             const int j = e / C, c = e - j * C;
             arow[e] = p.X[l][tap[j] * C + c];
         }
         if (l == 0) {
-            const long long t0 = tok < 0 ? 0 : tok;
             for (int c = tid; c < C; c += 256) {
-                const float x = p.emb[t0 * C + c];
+                const float x = p.emb[tok * C + c];
                 arow[4 * C + c] = x;
                 p.X[0][node * C + c] = x;
             }
@@ -292,95 +330,104 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
 }
 
 // ---- self-attention of the new position over the cached prefix (see decode.hip incr_attn_kernel) -------------
-// One workgroup per row; thread t owns dims [4t, 4t+4) of the d <= 1024 wide vectors (TPG = d/4 threads), the
-// 256 / TPG thread groups take prefix positions round-robin.
+// One workgroup per COMPACT row (slot); thread t owns dims [4t, 4t+4) of the d <= 1024 wide vectors (TPG = d/4
+// threads), the 256 / TPG thread groups take prefix positions round-robin.  The row's ancestry is copied into LDS
+// first, so the gathers of the key / value rows (each a separate 2 KB HBM access) are not chained behind index
+// loads, and 8 of them are in flight per group.
+constexpr int ATT_UNROLL = 8;
 __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict__ kvq, long long ldkvq,
                                                          float *__restrict__ Kc, float *__restrict__ Vc,
                                                          const long long *__restrict__ anc, long long anc_pitch,
                                                          const long long *__restrict__ pos,
-                                                         const long long *__restrict__ node, int L, int d, int heads,
+                                                         const long long *__restrict__ node,
+                                                         const long long *__restrict__ rowmap,
+                                                         const int *__restrict__ m_dev, int L, int d, int heads,
                                                          int tpg, float scale, float *__restrict__ out) {
-    extern __shared__ float sc[];   // [heads][L] scores, then [G][d] partial contexts
-    const int r = blockIdx.x, t = threadIdx.x;
+    extern __shared__ float sc[];   // [heads][L] scores, then [G][d] partial contexts; then L ints of ancestry
+    const int slot = blockIdx.x, t = threadIdx.x;
+    if (m_dev && slot >= *m_dev) return;
+    const long long r = rowmap ? rowmap[slot] : slot;
     const int G = 256 / tpg;
     const int gi = t / tpg, tl = t - gi * tpg;
     const int dh = d / heads, g = dh >> 2;           // g threads per head (power of two <= 64)
-    long long p = pos[r];
+    long long p = pos[slot];
     if (p > L - 1) p = L - 1;
-    const long long my_node = node[r];
-    const long long *arow = anc + (long long)r * anc_pitch;
-    const float *row = kvq + (long long)r * ldkvq;
+    const int np = (int)p;
+    const long long my_node = node[slot];
+    const int sc_floats = max(heads * L, G * d);
+    int *idx = reinterpret_cast<int *>(sc + sc_floats);
+    const long long *arow = anc + r * anc_pitch;
+    for (int j = t; j < np; j += 256) idx[j] = (int)arow[j];
+    const float *row = kvq + (long long)slot * ldkvq;
     const int col = tl * 4;
-    const bool act = gi < G;
-    const f32x4 kn = act ? *reinterpret_cast<const f32x4 *>(row + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 vn = act ? *reinterpret_cast<const f32x4 *>(row + d + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 qv = act ? *reinterpret_cast<const f32x4 *>(row + 2 * d + col) * scale : f32x4{0.f, 0.f, 0.f, 0.f};
-    if (act && gi == 0) {                              // the new position joins the caches
+    const f32x4 kn = *reinterpret_cast<const f32x4 *>(row + col);
+    const f32x4 vn = *reinterpret_cast<const f32x4 *>(row + d + col);
+    const f32x4 qv = *reinterpret_cast<const f32x4 *>(row + 2 * d + col) * scale;
+    if (gi == 0) {                                     // the new position joins the caches
         *reinterpret_cast<f32x4 *>(Kc + my_node * d + col) = kn;
         *reinterpret_cast<f32x4 *>(Vc + my_node * d + col) = vn;
     }
-    for (long long j0 = gi; j0 <= p; j0 += 4 * G) {
-        float part[4];
+    __syncthreads();
+    for (int j0 = gi; j0 <= np; j0 += ATT_UNROLL * G) {
+        f32x4 k4[ATT_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long j = j0 + (long long)u * G;
-            part[u] = 0.f;
-            if (act && j <= p) {
-                const f32x4 k4 = j == p ? kn : *reinterpret_cast<const f32x4 *>(Kc + arow[j] * d + col);
-                part[u] = qv.x * k4.x + qv.y * k4.y + qv.z * k4.z + qv.w * k4.w;
-            }
+        for (int u = 0; u < ATT_UNROLL; ++u) {
+            const int j = j0 + u * G;
+            k4[u] = j < np ? *reinterpret_cast<const f32x4 *>(Kc + (long long)idx[j] * d + col) : kn;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float v = part[u];
+        for (int u = 0; u < ATT_UNROLL; ++u) {
+            const int j = j0 + u * G;
+            float v = qv.x * k4[u].x + qv.y * k4[u].y + qv.z * k4[u].z + qv.w * k4[u].w;
             for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o);
-            const long long j = j0 + (long long)u * G;
-            if (act && j <= p && (tl & (g - 1)) == 0) sc[(col / dh) * L + (int)j] = v;
+            if (j <= np && (tl & (g - 1)) == 0) sc[(col / dh) * L + j] = v;
         }
     }
     __syncthreads();
-    if (gi == 0 && act) {
+    if (gi == 0) {
         const int h = col / dh, ln = tl & (g - 1);
         float m = -INFINITY;
-        for (int j = ln; j <= p; j += g) m = fmaxf(m, sc[h * L + j]);
+        for (int j = ln; j <= np; j += g) m = fmaxf(m, sc[h * L + j]);
         for (int o = 1; o < g; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
         float sum = 0.f;
-        for (int j = ln; j <= p; j += g) sum += __expf(sc[h * L + j] - m);
+        for (int j = ln; j <= np; j += g) sum += __expf(sc[h * L + j] - m);
         for (int o = 1; o < g; o <<= 1) sum += __shfl_xor(sum, o);
         const float inv = 1.f / sum;
-        for (int j = ln; j <= p; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
+        for (int j = ln; j <= np; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
     }
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (long long j0 = gi; j0 <= p; j0 += 4 * G) {
+    for (int j0 = gi; j0 <= np; j0 += ATT_UNROLL * G) {
+        f32x4 v4[ATT_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long j = j0 + (long long)u * G;
-            if (j > p) break;
-            if (act) {
-                const float w = sc[(col / dh) * L + (int)j];
-                const f32x4 v4 = j == p ? vn : *reinterpret_cast<const f32x4 *>(Vc + arow[j] * d + col);
-                acc += v4 * w;
-            }
+        for (int u = 0; u < ATT_UNROLL; ++u) {
+            const int j = j0 + u * G;
+            v4[u] = j < np ? *reinterpret_cast<const f32x4 *>(Vc + (long long)idx[j] * d + col) : vn;
+        }
+#pragma unroll
+        for (int u = 0; u < ATT_UNROLL; ++u) {
+            const int j = j0 + u * G;
+            if (j <= np) acc += v4[u] * sc[(col / dh) * L + j];
         }
     }
+    float *orow = out + (long long)slot * d;
     if (G > 1) {
         __syncthreads();
         float *part = sc;                              // [G][d]
-        if (act) *reinterpret_cast<f32x4 *>(part + gi * d + col) = acc;
+        *reinterpret_cast<f32x4 *>(part + gi * d + col) = acc;
         __syncthreads();
-        if (gi == 0 && act) {
+        if (gi == 0) {
             f32x4 s4 = acc;
             for (int k = 1; k < G; ++k) s4 += *reinterpret_cast<const f32x4 *>(part + k * d + col);
-            *reinterpret_cast<f32x4 *>(out + (long long)r * d + col) = s4;
+            *reinterpret_cast<f32x4 *>(orow + col) = s4;
         }
-    } else if (act) {
-        *reinterpret_cast<f32x4 *>(out + (long long)r * d + col) = acc;
+    } else {
+        *reinterpret_cast<f32x4 *>(orow + col) = acc;
     }
 }
 
 // ---- fc2 + log-sum-exp partials + top-K partials --------------------------------------------------------------
-constexpr int FC2_BM = 32, FC2_WN = 5, FC2_COLS = 4 * FC2_WN * 16;   // 320 columns per split
+constexpr int FC2_BM = 32, FC2_WN = 3, FC2_KS = 2, FC2_COLS = 4 * FC2_WN * 16;   // 192 columns per split
 struct Cand { float v; int idx; };
 
 __device__ inline bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -392,12 +439,15 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
                                                         int splits, float *__restrict__ pmax,
                                                         float *__restrict__ psum, Cand *__restrict__ pcand) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Core<FC2_BM, FC2_WN, NS> core;
+    typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
+    core_t core;
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
-    float *slab = reinterpret_cast<float *>(smem + Core<FC2_BM, FC2_WN, NS>::LDS_BYTES);   // [32][FC2_COLS]
-    const int mb = blockIdx.x / splits, sp = blockIdx.x - mb * splits;
+    float *slab = reinterpret_cast<float *>(smem + core_t::LDS_BYTES);   // [32][FC2_COLS]
+    int mb, sp;
+    if (!xcd_tile(splits, mb, sp)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mb * FC2_BM, nt0 = (sp * 4 + wave) * FC2_WN;
+    if (m0 >= rows) return;
     core.run(h, ldh, rows, m0, W, NT, KT, nt0, lds);
     // logits of this split -> slab (sm_scale * (acc + bias); columns >= V masked)
 #pragma unroll
@@ -413,7 +463,7 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
         }
     __syncthreads();
     // 8 rows per wave: max, sum of exponentials, the topk largest (value desc, column asc)
-    constexpr int PL = FC2_COLS / 64;     // 5 values per lane
+    constexpr int PL = FC2_COLS / 64;     // values per lane
     for (int rr = 0; rr < FC2_BM / 4; ++rr) {
         const int lr = wave * (FC2_BM / 4) + rr, r = m0 + lr;
         if (r >= rows) break;
@@ -457,14 +507,14 @@ int check(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 template <int BM, int NS>
 void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
-    constexpr size_t lds = Core<BM, 1, NS>::LDS_BYTES;
+    constexpr size_t lds = DgCfg<BM, NS>::core_t::LDS_BYTES;
     dgemm_kernel<BM, NS><<<dim3(grid), dim3(256), lds, st>>>(p);
 }
 
 template <int NS>
 void launch_fc2(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
                 int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc) {
-    constexpr size_t lds = Core<FC2_BM, FC2_WN, NS>::LDS_BYTES + FC2_BM * FC2_COLS * 4;
+    constexpr size_t lds = Core<FC2_BM, FC2_WN, NS, FC2_KS>::LDS_BYTES + FC2_BM * FC2_COLS * 4;
     dfc2_topk_kernel<NS><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax,
                                                              psum, pc);
 }
@@ -494,12 +544,13 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     if ((q->flags & PIKA_DG_GATE) && (!q->e_all || !q->t_idx || q->T <= 0 || q->beam <= 0 || (q->N & 3))) return PIKA_EINVAL;
     if (((q->flags & PIKA_DG_ROWMASK) || q->C2) && !q->node) return PIKA_EINVAL;
     DG p{q->A, q->lda, reinterpret_cast<const __bf16 *>(q->W), q->bias, q->res, q->ldr, q->C, q->ldc, q->C2, q->ldc2,
-         q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags};
+         q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags,
+         q->m_dev, q->crow};
     const int n_groups = (p.NT + 3) / 4;
     // enough workgroups to cover the chip: 32-row tiles unless 64-row tiles already give > 256 of them
     const bool big = (long long)((q->M + 63) / 64) * n_groups >= 512;
     const int BM = big ? 64 : 32;
-    const unsigned grid = (unsigned)(((q->M + BM - 1) / BM) * n_groups);
+    const unsigned grid = (unsigned)(((q->M + BM - 1) / BM) * ((n_groups + 7) / 8) * 8);
     hipStream_t st = (hipStream_t)stream;
     if (big) {
         if (q->terms == 1) launch_dgemm<64, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<64, 2>(grid, st, p); else launch_dgemm<64, 3>(grid, st, p);
@@ -519,17 +570,18 @@ int pika_dstep_prep(const pika_dstep_prep_t *q, void *stream) {
 
 int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, float *v_cache,
                          const long long *ancestry, long long ancestry_pitch, const long long *pos,
-                         const long long *node, int rows, int L, int d, int heads, float *out, void *stream) {
+                         const long long *node, const long long *rowmap, const int *m_dev, int rows, int L, int d,
+                         int heads, float *out, void *stream) {
     if (!kvq || !k_cache || !v_cache || !ancestry || !pos || !node || !out || rows <= 0 || L <= 0 || heads <= 0)
         return PIKA_EINVAL;
     if (d % heads || d > 1024 || (d & 3) || (ldkvq & 3)) return PIKA_EINVAL;
     const int dh = d / heads, g = dh >> 2, tpg = d >> 2;
     if ((dh & 3) || g < 1 || g > 64 || (g & (g - 1)) || 256 % tpg) return PIKA_EINVAL;
     const int G = 256 / tpg;
-    const size_t lds = sizeof(float) * (size_t)max(heads * L, G * d);
+    const size_t lds = sizeof(float) * ((size_t)max(heads * L, G * d) + (size_t)L);
     if (lds > 64 * 1024) return PIKA_ETOOBIG;
     hipLaunchKernelGGL(dstep_attn_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, kvq, ldkvq, k_cache, v_cache,
-                       ancestry, ancestry_pitch, pos, node, L, d, heads, tpg, 1.f / sqrtf((float)dh), out);
+                       ancestry, ancestry_pitch, pos, node, rowmap, m_dev, L, d, heads, tpg, 1.f / sqrtf((float)dh), out);
     return check(hipGetLastError());
 }
 
@@ -542,7 +594,7 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
         terms > 3 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
         return PIKA_EINVAL;
     const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
-    const unsigned grid = (unsigned)(((rows + FC2_BM - 1) / FC2_BM) * splits);
+    const unsigned grid = (unsigned)(((rows + FC2_BM - 1) / FC2_BM) * ((splits + 7) / 8) * 8);
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
     Cand *pc = reinterpret_cast<Cand *>(pcand);

@@ -30,13 +30,15 @@ MAX_LAYERS = 4
 class DGemm(ctypes.Structure):
     _fields_ = [("A", _vp), ("lda", _ll), ("W", _vp), ("bias", _vp), ("res", _vp), ("ldr", _ll), ("C", _vp), ("ldc", _ll),
                 ("C2", _vp), ("ldc2", _ll), ("node", _vp), ("skip_node", _ll), ("e_all", _vp), ("t_idx", _vp),
-                ("T", _i), ("beam", _i), ("M", _i), ("N", _i), ("K", _i), ("terms", _i), ("flags", _i)]
+                ("T", _i), ("beam", _i), ("M", _i), ("N", _i), ("K", _i), ("terms", _i), ("flags", _i),
+                ("m_dev", _vp), ("crow", _vp)]
 
 
 class DPrep(ctypes.Structure):
     _fields_ = [("prev_k", _vp), ("y", _vp), ("hyp_len", _vp), ("step_t", _vp), ("t_idx", _vp),
                 ("state", _vp * 2), ("anc", _vp * 2), ("emb", _vp), ("X", _vp * MAX_LAYERS), ("A", _vp * MAX_LAYERS),
-                ("C", _i * MAX_LAYERS), ("lda", _ll * MAX_LAYERS), ("node", _vp), ("pos", _vp), ("dump_node", _ll),
+                ("C", _i * MAX_LAYERS), ("lda", _ll * MAX_LAYERS), ("node", _vp), ("pos", _vp), ("rowmap", _vp),
+                ("count", _vp), ("dump_node", _ll),
                 ("zero_node", _ll), ("layers", _i), ("rows", _i), ("beam", _i), ("H", _i), ("L", _i), ("blk", _i),
                 ("stop", _vp)]
 
@@ -109,8 +111,9 @@ class FusedSearch(object):
         self.A = [torch.zeros(R, w, **f32) for w in self.lda]
         self.state = [torch.zeros(R, self.H, **f32) for _ in range(2)]
         self.anc = [torch.full((R, self.L), self.dump_node, **i64) for _ in range(2)]
-        self.node = torch.zeros(R, **i64)
+        self.node = torch.zeros(R, **i64)          # per SLOT of the compact list of rows that emitted a label
         self.pos = torch.zeros(R, **i64)
+        self.rowmap = torch.arange(R, device=dev)  # slot -> row
         self.t_idx = torch.full((B, K), -1, **i64)                                  # :107
         self.prev_k = torch.arange(K, device=dev).repeat(B).contiguous()            # identity parents for step 0
         self.stop = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -161,8 +164,10 @@ class FusedSearch(object):
         self._init_sos()
 
     # ---- launches ------------------------------------------------------------------------------------------
-    def _gemm(self, A, lda, W, bias, C, ldc, M, relu=False, res=None, ldr=0, C2=None, ldc2=0, rowmask=False, gate=False):
+    def _gemm(self, A, lda, W, bias, C, ldc, M, relu=False, res=None, ldr=0, C2=None, ldc2=0, rowmask=False, gate=False,
+              m_dev=None, crow=None):
         g = DGemm()
+        g.m_dev, g.crow = _ptr(m_dev), _ptr(crow)
         g.A, g.lda, g.W, g.bias = _ptr(A), lda, W.buf.data_ptr(), _ptr(bias)
         g.res, g.ldr, g.C, g.ldc = _ptr(res), ldr, _ptr(C), ldc
         g.C2, g.ldc2 = _ptr(C2), ldc2
@@ -178,31 +183,31 @@ class FusedSearch(object):
                                                   float(ln.eps), y.data_ptr(), 0, self.mean.data_ptr(),
                                                   self.rstd.data_ptr(), _stream()), "pika_layer_norm_fwd")
 
-    def _prednet(self, anc_dst, state_dst):
-        """All layers at the new position of every row; `node` / `pos` / A[l] were prepared."""
+    def _prednet(self, anc_dst, state_dst, count):
+        """All layers at the new position of the `count` (device int32) rows of the compact list; `rowmap` / `node` /
+        `pos` / A[l] were prepared (slot order).  Only these rows' states change (:139-171)."""
         lib = _lib.lib()
         R, d = self.rows, self.d
         for l, w in enumerate(self.layers):
-            self._gemm(self.A[l], self.lda[l], w["conv"], w["bconv"], self.y_conv, d, R, relu=True)
+            self._gemm(self.A[l], self.lda[l], w["conv"], w["bconv"], self.y_conv, d, R, relu=True, m_dev=count)
             self._layer_norm(self.y_conv, w["ln1"], self.ln)
-            self._gemm(self.ln, d, w["qkv"], w["bqkv"], self.kvq, 3 * d, R)
+            self._gemm(self.ln, d, w["qkv"], w["bqkv"], self.kvq, 3 * d, R, m_dev=count)
             _lib.check(lib.pika_dstep_attention(self.kvq.data_ptr(), 3 * d, self.Kc[l].data_ptr(), self.Vc[l].data_ptr(),
                                                 anc_dst.data_ptr(), self.L, self.pos.data_ptr(), self.node.data_ptr(),
-                                                R, self.L, d, self.heads, self.ctx.data_ptr(), _stream()),
-                       "pika_dstep_attention")
-            self._gemm(self.ctx, d, w["fin"], w["bfin"], self.o, d, R, res=self.y_conv, ldr=d)
+                                                self.rowmap.data_ptr(), count.data_ptr(), R, self.L, d, self.heads,
+                                                self.ctx.data_ptr(), _stream()), "pika_dstep_attention")
+            self._gemm(self.ctx, d, w["fin"], w["bfin"], self.o, d, R, res=self.y_conv, ldr=d, m_dev=count)
             self._layer_norm(self.o, w["ln2"], self.ln)
-            self._gemm(self.ln, d, w["w1"], w["b1"], self.hmid, self.hmid.shape[1], R, relu=True)
+            self._gemm(self.ln, d, w["w1"], w["b1"], self.hmid, self.hmid.shape[1], R, relu=True, m_dev=count)
             if l + 1 < self.nl:
                 # the next layer's input: fifth tap block of its conv matrix + its cache row
                 nxt = self.A[l + 1][:, 4 * self.Cin[l + 1]:]
                 self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], nxt, self.lda[l + 1], R, res=self.o, ldr=d,
-                           C2=self.X[l + 1], ldc2=self.Cin[l + 1])
+                           C2=self.X[l + 1], ldc2=self.Cin[l + 1], m_dev=count)
             else:
-                self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], self.xfin, d, R, res=self.o, ldr=d)
+                self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], self.xfin, d, R, res=self.o, ldr=d, m_dev=count)
         self._layer_norm(self.xfin, self.model.decoder.layer_norm, self.ln)
-        # rows that emitted a label get the new state, the others keep the (re-ordered) old one (:139-171)
-        self._gemm(self.ln, d, self.wout, self.bout, state_dst, self.H, R, rowmask=True)
+        self._gemm(self.ln, d, self.wout, self.bout, state_dst, self.H, R, m_dev=count, crow=self.rowmap)
 
     def _prep(self, parity):
         p = DPrep()
@@ -214,7 +219,8 @@ class FusedSearch(object):
         p.emb = self.emb.data_ptr()
         for l in range(self.nl):
             p.X[l], p.A[l], p.C[l], p.lda[l] = self.X[l].data_ptr(), self.A[l].data_ptr(), self.Cin[l], self.lda[l]
-        p.node, p.pos = self.node.data_ptr(), self.pos.data_ptr()
+        p.node, p.pos, p.rowmap = self.node.data_ptr(), self.pos.data_ptr(), self.rowmap.data_ptr()
+        p.count = self.sync[5:7].data_ptr()
         p.dump_node, p.zero_node = self.dump_node, self.zero_node
         p.layers, p.rows, p.beam, p.H, p.L, p.blk = self.nl, self.rows, self.K, self.H, self.L, b.blk
         p.stop = self.stop.data_ptr()
@@ -233,9 +239,9 @@ class FusedSearch(object):
             for l in range(1, self.nl):
                 self.A[l].zero_()
             self.anc[0][:, 0] = 0
-            self._prednet(self.anc[0], self.state[0])
-            for l in range(1, self.nl):     # the scatter of layer inputs went to node 0: nothing else to do
-                pass
+            self.sync[5] = R                # every row is in the compact list (identity rowmap) for this one pass
+            self._prednet(self.anc[0], self.state[0], self.sync[5:6])
+            self.sync[5] = 0
 
     def step_launches(self, parity):
         """Enqueue one search step that reads state/anc buffer `parity` (= steps taken & 1)."""
@@ -244,7 +250,7 @@ class FusedSearch(object):
         dst = parity ^ 1
         with torch.cuda.device(self.dev):
             self._prep(parity)
-            self._prednet(self.anc[dst], self.state[dst])
+            self._prednet(self.anc[dst], self.state[dst], self.sync[5 + parity:6 + parity])
             self._gemm(self.state[dst], self.H, self.wp, None, self.h, self.H, self.rows, gate=True)
             _lib.check(lib.pika_dfc2_topk(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
                                           self.V, self.H, self.terms, self.sm_scale, self.K, self.pmax.data_ptr(),

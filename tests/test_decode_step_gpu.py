@@ -47,6 +47,15 @@ def test_dgemm_bias_relu_residual_scatter(hip_device, terms, tol, M, N, K):
     assert (got[keep] - want[keep]).abs().max().item() <= tol * scale
     assert torch.all(C[~keep][:, :N] == 7.0) and torch.all(C[:, N:] == 7.0)        # masked row, padding untouched
     assert (C2[node[keep]].double() - want[keep]).abs().max().item() <= tol * scale
+    # compact row lists: only the first *m_dev rows are computed, and they land at rows crow[r]
+    md = torch.tensor([M - 7], dtype=torch.int32, device=hip_device)
+    crow = torch.randperm(M, generator=g).to(hip_device)
+    C.fill_(7.0)
+    d.flags, d.C2, d.m_dev, d.crow = DG_RELU, None, md.data_ptr(), crow.data_ptr()
+    _lib.check(_lib.lib().pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm")
+    got = C[:, :N].double()
+    assert (got[crow[:M - 7]] - want[:M - 7]).abs().max().item() <= tol * scale
+    assert torch.all(C[crow[M - 7:]][:, :N] == 7.0)
 
 
 def test_dgemm_gate_epilogue(hip_device):
