@@ -130,7 +130,8 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
  * sync (int32[8], zeroed once by the caller): [0..3] scratch for the cross-workgroup arrival counts of even / odd
  * steps; [4] is set once a call was skipped because *stop was already set (the gate of the FST advance that follows);
  * [5], [6] are the compact-row counters of pika_dstep_prep (count = sync + 5): the call zeroes the one the next step
- * will fill.  Needs K*L*4 + K*K*8 + 4*splits*K*8 bytes of LDS <= 96 KiB (PIKA_ETOOBIG otherwise). */
+ * will fill.  Needs splits*K <= 1024 and K*L*4 + K*K*8 + 4*splits*K*8 bytes of LDS <= 96 KiB
+ * (PIKA_ETOOBIG otherwise). */
 int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
                                float *scores, const float *lm_scores, float lm_scale, long long *y,
                                long long *t_idx, const long long *num_frames, const long long *max_len,

@@ -21,6 +21,12 @@ constexpr int MAXV = 5120, MAXK = 64, WAVES = 4;
 
 struct Cand { float v; int idx; };
 
+// order-preserving map float -> unsigned (a > b <=> fkey_h(a) > fkey_h(b))
+__device__ inline unsigned fkey_h(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 __device__ inline bool better(float va, int ia, float vb, int ib) {
     return va > vb || (va == vb && ia < ib);
 }
@@ -145,10 +151,12 @@ struct BeamState {
 // Shared scratch of one utterance (static part; hyp_l [K][L] ints and cand [K][K] live in dynamic LDS)
 struct BeamShared {
     float lm_old[MAXK], best_v[MAXK];
-    long long t_old[MAXK], len_old[MAXK];
+    long long t_old[MAXK], len_old[MAXK], y_old[MAXK];
     int best_i[MAXK], fin_flag[MAXK];
 };
 
+// Everything in this kernel is a handful of dependent memory round trips (~2 us each at this occupancy), so loops
+// over global memory are issued as batches of 8 independent loads per thread, never one load per iteration.
 __device__ inline void beam_load_state(const BeamState &a, BeamShared &sh, int *hyp_l, int b) {
     const int tid = threadIdx.x;
     const long long bk = (long long)b * a.K;
@@ -156,8 +164,26 @@ __device__ inline void beam_load_state(const BeamState &a, BeamShared &sh, int *
         sh.lm_old[tid] = a.lm_scores[bk + tid];
         sh.t_old[tid] = a.t_idx[bk + tid];
         sh.len_old[tid] = a.hyp_len[bk + tid];
+        sh.y_old[tid] = a.y[bk + tid];
     }
-    for (int i = tid; i < a.K * a.L; i += blockDim.x) hyp_l[i] = (int)a.hyp[bk * a.L + i];
+    __syncthreads();
+    long long ml = 0;
+    for (int i = 0; i < a.K; ++i) ml = max(ml, sh.len_old[i]);
+    const int used = (int)min((long long)a.L, ml + 1);      // labels beyond a slot's length are never read
+    const int n = a.K * used;
+    for (int base = tid; base < n; base += 256 * 8) {
+        long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + u * 256;
+            if (e < n) v[u] = a.hyp[(bk + e / used) * a.L + e % used];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = base + u * 256;
+            if (e < n) hyp_l[(e / used) * a.L + e % used] = (int)v[u];
+        }
+    }
 }
 
 // cand [K][K] in LDS holds the K best candidates of every row; everything of `advance` after that
@@ -215,7 +241,8 @@ __device__ inline void beam_merge_and_book(const BeamState &a, BeamShared &sh, c
         const int p = sh.best_i[i] / V, ys_ = sh.best_i[i] - p * V;
         const int plen = (int)sh.len_old[p];
         long long *dst = a.hyp + (bk + i) * L;
-        for (int q = tid; q < L; q += blockDim.x) {
+        const int ncopy = min(L, plen + 1);          // the parent's labels + the new one; the rest is never read
+        for (int q = tid; q < ncopy; q += blockDim.x) {
             long long v = hyp_l[p * L + q];
             if (q == plen && ys_ != a.blk) v = ys_;
             dst[q] = v;
@@ -234,6 +261,67 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(const Cand *__restrict_
     for (int c = tid; c < nc; c += blockDim.x) cand[c] = cand_g[(long long)b * a.K * a.K + c];
     __syncthreads();
     beam_merge_and_book(a, sh, hyp_l, cand, b);
+}
+
+// The K best of a row's pool of n partial candidates (LDS) -> out[0..K), value = log-softmax (+ running scores):
+// bisection on the order-preserving integer image of the values with ballots + popcounts only (no shuffle chains; see
+// dfc2_topk_kernel), keys held in registers (PLM per lane, n <= 64*PLM).  Candidate indices are unique within a row,
+// so ties at the threshold value are resolved by a second bisection on the index (lowest indices win).  Output order
+// is arbitrary: the merge ranks the K*K row winners anyway.
+template <int PLM>
+__device__ inline void select_row(const Cand *pool, int n, int K, int lane, float m, float logsum, bool first,
+                                  float add_s, float add_l, int kV, Cand *out) {
+    unsigned key[PLM];
+    int cidx[PLM];
+#pragma unroll
+    for (int q = 0; q < PLM; ++q) {
+        const int e = lane + 64 * q;
+        const Cand c = e < n ? pool[e] : Cand{-INFINITY, 0x7fffffff};
+        key[q] = e < n ? fkey_h(c.v) : 0u;      // 0 is below every real key (fkey_h(-inf) = 0x007fffff)
+        cidx[q] = c.idx;
+    }
+    unsigned T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned mid = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < PLM; ++q) cnt += __popcll(__ballot(key[q] >= mid));
+        if (cnt >= K) T = mid;
+    }
+    int n_gt = 0, n_eq = 0;
+#pragma unroll
+    for (int q = 0; q < PLM; ++q) {
+        n_gt += __popcll(__ballot(key[q] > T));
+        n_eq += __popcll(__ballot(key[q] == T));
+    }
+    const int need = K - n_gt;
+    unsigned I = 0xffffffffu;
+    if (n_eq > need) {                          // keep the `need` lowest indices among the ties
+        unsigned lo = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned mid = lo | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < PLM; ++q) cnt += __popcll(__ballot(key[q] == T && (unsigned)cidx[q] < mid));
+            if (cnt <= need) lo = mid;
+        }
+        I = lo;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < PLM; ++q) {
+        const bool sel = key[q] > T || (key[q] == T && T != 0u && (unsigned)cidx[q] < I);
+        const unsigned long long mk = __ballot(sel);
+        const int rk = base + __popcll(mk & lt);
+        if (sel && rk < K) {
+            const float cv = pool[lane + 64 * q].v;
+            float val = (cv - m) - logsum;                 // log_softmax, torch's operation order
+            if (!first) val = (val + add_s) + add_l;       // (:94-97)
+            out[rk] = Cand{val, kV + (cidx[q] == 0x7fffffff ? 0 : cidx[q])};
+        }
+        base += __popcll(mk);
+    }
 }
 
 // ---- kernel B': the same, with the row log-softmax / top-K built from the partials of pika_dfc2_topk ---------
@@ -268,11 +356,11 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
         if (first) {
             d = k != 0;
         } else {
-            d = a.y[bk + k] == EOS;
-            const long long len = sh.len_old[k];
+            d = sh.y_old[k] == EOS;           // (from LDS: a global load per candidate slot here was a chain of
+            const long long len = sh.len_old[k];   //  up to K dependent ~2 us round trips per row)
             if (!d && beam_prune && len > 0) {
                 for (int j = 0; j < k && !d; ++j) {
-                    if (a.y[bk + j] == EOS || sh.len_old[j] != len) continue;
+                    if (sh.y_old[j] == EOS || sh.len_old[j] != len) continue;
                     bool same = true;
                     for (long long p = lane; p < len; p += 64) same &= hyp_l[j * L + p] == hyp_l[k * L + p];
                     d = __all(same);
@@ -297,27 +385,19 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
         const int n = S * K;
         Cand *pool = pool_all + wave * n;
         const Cand *src = pcand + pi * K;
-        for (int q = lane; q < n; q += 64) pool[q] = src[q];
-        for (int r = 0; r < K; ++r) {
-            float bv = -INFINITY;
-            int bi = 0x7fffffff, bq = -1;
-            for (int q = lane; q < n; q += 64) {
-                const Cand c = pool[q];
-                if (better(c.v, c.idx, bv, bi)) { bv = c.v; bi = c.idx; bq = q; }
-            }
-            const int my = bi;
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o);
-                const int oi = __shfl_xor(bi, o);
-                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-            }
-            if (bq >= 0 && my == bi && bi != 0x7fffffff) pool[bq] = Cand{-INFINITY, 0x7fffffff};   // the owner pops it
-            if (lane == 0) {
-                float val = (bv - m) - logsum;                 // log_softmax, torch's operation order
-                if (!first) val = (val + add_s) + add_l;       // (:94-97)
-                out[r] = Cand{val, k * V + (bi == 0x7fffffff ? 0 : bi)};
-            }
+        for (int base = lane; base < n; base += 64 * 8) {      // one batch of independent loads, not a chain
+            Cand c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * 64 < n) c[u] = src[base + u * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * 64 < n) pool[base + u * 64] = c[u];
         }
+        __builtin_amdgcn_wave_barrier();
+        if (n <= 256) select_row<4>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+        else if (n <= 512) select_row<8>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+        else select_row<16>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
     }
     __syncthreads();
     beam_merge_and_book(a, sh, hyp_l, cand, b);
@@ -328,12 +408,11 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
         atomicMax(reinterpret_cast<unsigned long long *>(max_hyp), (unsigned long long)mh);
         const int done = (a.eos_top[b] && a.fin_n[b] >= n_best) ? 1 : 0;   // beam_transducer.py:189-194
         const int par = (int)(s_now & 1);
-        atomicAdd(&sync[par * 2 + 1], done);
-        __threadfence();
-        const int ticket = atomicAdd(&sync[par * 2], 1);
-        if (ticket == a.B - 1) {                      // everybody has read step_t and finished its utterance
-            __threadfence();
-            const int ndone = atomicAdd(&sync[par * 2 + 1], 0);
+        // ONE device-scope atomic carries both the arrival and the done count (high half): no fence, no second
+        // atomic whose order would matter; the last arriver sees everybody's contribution in the value it gets back
+        const unsigned old = atomicAdd(reinterpret_cast<unsigned *>(&sync[par * 2]), (unsigned)(done << 16) + 1u);
+        if ((old & 0xffffu) == (unsigned)(a.B - 1)) {   // everybody has read step_t and finished its utterance
+            const int ndone = (int)(old >> 16) + done;
             if (ndone == a.B) atomicExch(stop, 1);
             sync[(par ^ 1) * 2] = 0;
             sync[(par ^ 1) * 2 + 1] = 0;
@@ -661,7 +740,7 @@ extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, 
         !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
         return PIKA_EINVAL;
     const size_t lds_bytes = (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)4 * splits * K * sizeof(Cand);
-    if (K > MAXK || splits > 64 || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
+    if (K > MAXK || splits > 64 || splits * K > 1024 || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_partials_kernel),

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pika_decode_step.h"
 #include "pika_rnnt.h"  // PIKA_EINVAL
@@ -173,14 +174,26 @@ struct DG {   // device copy of pika_dgemm_t
 };
 
 // blockIdx -> (row tile, column group) so that a column group always lands on the same XCD (block b runs on XCD
-// b % 8): the row tiles that share a slab of W then share it in that XCD's L2 instead of re-reading it from the
-// Infinity Cache once per row tile.  groups_per_xcd = ceil(n_groups / 8); false = idle workgroup.
-__device__ inline bool xcd_tile(int n_groups, int &mg, int &ng) {
+// b % 8) and its row tiles are dispatched back to back: the row tiles that share a slab of W then find it in that
+// XCD's L2 instead of each pulling it from the Infinity Cache at the per-CU fetch rate (a quarter of the L2 rate),
+// and an XCD works on ONE slab at a time (its 4 MiB L2 holds a slab, not all the slabs of its column groups).
+// false = idle workgroup.
+__device__ inline bool xcd_tile(int n_groups, int m_tiles, int &mg, int &ng) {
     const int g = blockIdx.x, xcd = g & 7, i = g >> 3;
-    const int gpx = (n_groups + 7) >> 3;
-    ng = xcd + 8 * (i % gpx);
-    mg = i / gpx;
+    ng = xcd + 8 * (i / m_tiles);
+    mg = i % m_tiles;
     return ng < n_groups;
+}
+
+// The other way round, for many rows (M = B*beam): an XCD owns a band of row tiles -- their A rows (a few hundred
+// KB) stay in its L2 -- and walks the column groups with the band's row tiles dispatched back to back, so a slab of
+// W is fetched from beyond L2 once per XCD (8x in total) instead of once per row tile.
+__device__ inline bool xcd_tile_rows(int n_groups, int m_tiles, int &mg, int &ng) {
+    const int g = blockIdx.x, xcd = g & 7, i = g >> 3;
+    const int band = (m_tiles + 7) >> 3;
+    mg = xcd * band + i % band;
+    ng = i / band;
+    return mg < m_tiles && ng < n_groups;
 }
 
 template <int BM, int NS>
@@ -192,19 +205,20 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
     typename DgCfg<BM, NS>::core_t core;
     const int n_groups = (p.NT + 3) / 4;
     int mg, ng;
-    if (!xcd_tile(n_groups, mg, ng)) return;
-    if (p.m_dev) { const int md = *p.m_dev; if (md < p.M) p.M = md; }     // rows actually in use this step
+    if (!xcd_tile_rows(n_groups, (p.M + BM - 1) / BM, mg, ng)) return;
+    int M = p.M;
+    if (p.m_dev) M = min(M, *p.m_dev);            // rows actually in use this step
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mg * BM, nt0 = ng * 4 + wave;
-    if (m0 >= p.M) return;
-    core.run(p.A, p.lda, p.M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem));
+    if (m0 >= M) return;
+    core.run(p.A, p.lda, M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem));
     if (nt0 >= p.NT) return;
     const int c0 = nt0 * 16 + (lane >> 4) * 4;          // first of this lane's 4 consecutive columns
     if (c0 >= p.N) return;
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
         const int r = m0 + i * 16 + (lane & 15);
-        if (r >= p.M) continue;
+        if (r >= M) continue;
         f32x4 v = core.acc[i][0];
         if (p.flags & PIKA_DG_GATE) {
             // columns (2j, 2j+1) = (fc1, fc_gate) of joint unit j; this lane holds units c0/2 and c0/2 + 1
@@ -331,9 +345,11 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
 
 // ---- self-attention of the new position over the cached prefix (see decode.hip incr_attn_kernel) -------------
 // One workgroup per COMPACT row (slot); thread t owns dims [4t, 4t+4) of the d <= 1024 wide vectors (TPG = d/4
-// threads), the 256 / TPG thread groups take prefix positions round-robin.  The row's ancestry is copied into LDS
-// first, so the gathers of the key / value rows (each a separate 2 KB HBM access) are not chained behind index
-// loads, and 8 of them are in flight per group.
+// threads), the G = 256 / TPG thread groups take prefix positions round-robin.  Every prefix position is a separate
+// 2 KB key row + 2 KB value row somewhere in HBM, so the kernel is a chain of memory round trips: the row's ancestry
+// is copied into LDS first (gathers are not chained behind index loads), keys AND values of 8 positions per group
+// are requested together, and the softmax is the online form (running max / sum per head), i.e. ONE pass over the
+// prefix; the groups' partial (max, sum, context) triples are merged through LDS at the end.
 constexpr int ATT_UNROLL = 8;
 __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict__ kvq, long long ldkvq,
                                                          float *__restrict__ Kc, float *__restrict__ Vc,
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
                                                          const long long *__restrict__ rowmap,
                                                          const int *__restrict__ m_dev, int L, int d, int heads,
                                                          int tpg, float scale, float *__restrict__ out) {
-    extern __shared__ float sc[];   // [heads][L] scores, then [G][d] partial contexts; then L ints of ancestry
+    extern __shared__ float sm_f[];   // [G][d] partial contexts, [G][heads] max, [G][heads] sum, then L ints
     const int slot = blockIdx.x, t = threadIdx.x;
     if (m_dev && slot >= *m_dev) return;
     const long long r = rowmap ? rowmap[slot] : slot;
@@ -354,12 +370,12 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
     if (p > L - 1) p = L - 1;
     const int np = (int)p;
     const long long my_node = node[slot];
-    const int sc_floats = max(heads * L, G * d);
-    int *idx = reinterpret_cast<int *>(sc + sc_floats);
+    float *part = sm_f, *pm = sm_f + G * d, *ps = pm + G * heads;
+    int *idx = reinterpret_cast<int *>(ps + G * heads);
     const long long *arow = anc + r * anc_pitch;
     for (int j = t; j < np; j += 256) idx[j] = (int)arow[j];
     const float *row = kvq + (long long)slot * ldkvq;
-    const int col = tl * 4;
+    const int col = tl * 4, hd = col / dh;
     const f32x4 kn = *reinterpret_cast<const f32x4 *>(row + col);
     const f32x4 vn = *reinterpret_cast<const f32x4 *>(row + d + col);
     const f32x4 qv = *reinterpret_cast<const f32x4 *>(row + 2 * d + col) * scale;
@@ -368,61 +384,52 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
         *reinterpret_cast<f32x4 *>(Vc + my_node * d + col) = vn;
     }
     __syncthreads();
-    for (int j0 = gi; j0 <= np; j0 += ATT_UNROLL * G) {
-        f32x4 k4[ATT_UNROLL];
-#pragma unroll
-        for (int u = 0; u < ATT_UNROLL; ++u) {
-            const int j = j0 + u * G;
-            k4[u] = j < np ? *reinterpret_cast<const f32x4 *>(Kc + (long long)idx[j] * d + col) : kn;
-        }
-#pragma unroll
-        for (int u = 0; u < ATT_UNROLL; ++u) {
-            const int j = j0 + u * G;
-            float v = qv.x * k4[u].x + qv.y * k4[u].y + qv.z * k4[u].z + qv.w * k4[u].w;
-            for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o);
-            if (j <= np && (tl & (g - 1)) == 0) sc[(col / dh) * L + j] = v;
-        }
-    }
-    __syncthreads();
-    if (gi == 0) {
-        const int h = col / dh, ln = tl & (g - 1);
-        float m = -INFINITY;
-        for (int j = ln; j <= np; j += g) m = fmaxf(m, sc[h * L + j]);
-        for (int o = 1; o < g; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float sum = 0.f;
-        for (int j = ln; j <= np; j += g) sum += __expf(sc[h * L + j] - m);
-        for (int o = 1; o < g; o <<= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.f / sum;
-        for (int j = ln; j <= np; j += g) sc[h * L + j] = __expf(sc[h * L + j] - m) * inv;
-    }
-    __syncthreads();
+    float m = -INFINITY, lsum = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int j0 = gi; j0 <= np; j0 += ATT_UNROLL * G) {
-        f32x4 v4[ATT_UNROLL];
+        f32x4 k4[ATT_UNROLL], v4[ATT_UNROLL];
 #pragma unroll
         for (int u = 0; u < ATT_UNROLL; ++u) {
             const int j = j0 + u * G;
-            v4[u] = j < np ? *reinterpret_cast<const f32x4 *>(Vc + (long long)idx[j] * d + col) : vn;
+            const bool old = j < np;
+            k4[u] = old ? *reinterpret_cast<const f32x4 *>(Kc + (long long)idx[j] * d + col) : kn;
+            v4[u] = old ? *reinterpret_cast<const f32x4 *>(Vc + (long long)idx[j] * d + col) : vn;
         }
+        float sc[ATT_UNROLL], cm = -INFINITY;
 #pragma unroll
         for (int u = 0; u < ATT_UNROLL; ++u) {
-            const int j = j0 + u * G;
-            if (j <= np) acc += v4[u] * sc[(col / dh) * L + j];
+            float v = qv.x * k4[u].x + qv.y * k4[u].y + qv.z * k4[u].z + qv.w * k4[u].w;
+            for (int o = 1; o < g; o <<= 1) v += __shfl_xor(v, o);
+            sc[u] = (j0 + u * G <= np) ? v : -INFINITY;
+            cm = fmaxf(cm, sc[u]);
         }
+        const float mn = fmaxf(m, cm), resc = __expf(m - mn);       // m = -inf at the start: exp(-inf) = 0
+        acc *= resc;
+        lsum *= resc;
+#pragma unroll
+        for (int u = 0; u < ATT_UNROLL; ++u) {
+            const float w = __expf(sc[u] - mn);                       // masked positions: exp(-inf) = 0
+            lsum += w;
+            acc += v4[u] * w;
+        }
+        m = mn;
     }
-    float *orow = out + (long long)slot * d;
-    if (G > 1) {
-        __syncthreads();
-        float *part = sc;                              // [G][d]
-        *reinterpret_cast<f32x4 *>(part + gi * d + col) = acc;
-        __syncthreads();
-        if (gi == 0) {
-            f32x4 s4 = acc;
-            for (int k = 1; k < G; ++k) s4 += *reinterpret_cast<const f32x4 *>(part + k * d + col);
-            *reinterpret_cast<f32x4 *>(orow + col) = s4;
+    // merge the position groups: context_g * exp(m_g - M) summed, divided by the merged sum
+    *reinterpret_cast<f32x4 *>(part + gi * d + col) = acc;
+    if ((tl & (g - 1)) == 0) { pm[gi * heads + hd] = m; ps[gi * heads + hd] = lsum; }
+    __syncthreads();
+    if (gi == 0) {
+        float M = -INFINITY;
+        for (int k = 0; k < G; ++k) M = fmaxf(M, pm[k * heads + hd]);
+        f32x4 o4 = {0.f, 0.f, 0.f, 0.f};
+        float tot = 0.f;
+        for (int k = 0; k < G; ++k) {
+            const float mk = pm[k * heads + hd];
+            const float w = mk > -INFINITY ? __expf(mk - M) : 0.f;     // a group without positions
+            o4 += *reinterpret_cast<const f32x4 *>(part + k * d + col) * w;
+            tot += ps[k * heads + hd] * w;
         }
-    } else {
-        *reinterpret_cast<f32x4 *>(orow + col) = acc;
+        *reinterpret_cast<f32x4 *>(out + (long long)slot * d + col) = o4 * (1.f / tot);
     }
 }
 
@@ -431,6 +438,12 @@ constexpr int FC2_BM = 32, FC2_WN = 3, FC2_KS = 2, FC2_COLS = 4 * FC2_WN * 16;  
 struct Cand { float v; int idx; };
 
 __device__ inline bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+// order-preserving map float -> unsigned (a > b <=> fkey(a) > fkey(b); -inf is the smallest non-NaN key)
+__device__ inline unsigned fkey(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 template <int NS>
 __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict__ h, long long ldh,
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
     float *slab = reinterpret_cast<float *>(smem + core_t::LDS_BYTES);   // [32][FC2_COLS]
     int mb, sp;
-    if (!xcd_tile(splits, mb, sp)) return;
+    if (!xcd_tile_rows(splits, (rows + FC2_BM - 1) / FC2_BM, mb, sp)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mb * FC2_BM, nt0 = (sp * 4 + wave) * FC2_WN;
     if (m0 >= rows) return;
@@ -480,25 +493,39 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const long long pi = (long long)r * splits + sp;
         if (lane == 0) { pmax[pi] = m; psum[pi] = s; }
+        // The topk largest WITHOUT cross-lane shuffles (a wave arg-max is 12 dependent LDS-crossbar permutes, and
+        // topk of them per row made this epilogue 4x longer than the product itself): bisect the order-preserving
+        // integer image of the values for the topk-th largest key with ballots + popcounts (scalar unit), then every
+        // lane stores its own survivors at ranks taken from the ballot prefix.  Output order within a range is
+        // arbitrary (the advance re-selects anyway); ties at the threshold go to the lowest columns.
+        unsigned key[PL];
+#pragma unroll
+        for (int q = 0; q < PL; ++q) key[q] = fkey(x[q]);
+        unsigned T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned mid = T | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) cnt += __popcll(__ballot(key[q] >= mid));
+            if (cnt >= topk) T = mid;
+        }
         Cand *out = pcand + pi * topk;
-        for (int k = 0; k < topk; ++k) {
-            float bv = -INFINITY;
-            int bi = 0x7fffffff;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int base = 0;
 #pragma unroll
-            for (int q = 0; q < PL; ++q)
-                if (x[q] > bv) { bv = x[q]; bi = lane + 64 * q; }      // lane-local columns ascend with q: ties keep the lowest
-            const int mine = bi;
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o);
-                const int oi = __shfl_xor(bi, o);
-                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-            }
-            if (bi == mine && bi != 0x7fffffff) {
+        for (int q = 0; q < PL; ++q) {
+            const bool gsel = key[q] > T;
+            const unsigned long long mk = __ballot(gsel);
+            if (gsel) out[base + __popcll(mk & lt)] = Cand{x[q], x[q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
+            base += __popcll(mk);
+        }
 #pragma unroll
-                for (int q = 0; q < PL; ++q)
-                    if (lane + 64 * q == bi) x[q] = -INFINITY;
-            }
-            if (lane == 0) out[k] = Cand{bv, bi == 0x7fffffff ? 0x7fffffff : sp * FC2_COLS + bi};
+        for (int q = 0; q < PL; ++q) {
+            const bool e = key[q] == T;
+            const unsigned long long mk = __ballot(e);
+            const int rk = base + __popcll(mk & lt);
+            if (e && rk < topk) out[rk] = Cand{x[q], x[q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
+            base += __popcll(mk);
         }
     }
 }
@@ -546,12 +573,12 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     DG p{q->A, q->lda, reinterpret_cast<const __bf16 *>(q->W), q->bias, q->res, q->ldr, q->C, q->ldc, q->C2, q->ldc2,
          q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags,
          q->m_dev, q->crow};
+    hipStream_t st = (hipStream_t)stream;
     const int n_groups = (p.NT + 3) / 4;
     // enough workgroups to cover the chip: 32-row tiles unless 64-row tiles already give > 256 of them
     const bool big = (long long)((q->M + 63) / 64) * n_groups >= 512;
     const int BM = big ? 64 : 32;
-    const unsigned grid = (unsigned)(((q->M + BM - 1) / BM) * ((n_groups + 7) / 8) * 8);
-    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((((q->M + BM - 1) / BM + 7) / 8) * 8 * n_groups);
     if (big) {
         if (q->terms == 1) launch_dgemm<64, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<64, 2>(grid, st, p); else launch_dgemm<64, 3>(grid, st, p);
     } else {
@@ -578,7 +605,7 @@ int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, floa
     const int dh = d / heads, g = dh >> 2, tpg = d >> 2;
     if ((dh & 3) || g < 1 || g > 64 || (g & (g - 1)) || 256 % tpg) return PIKA_EINVAL;
     const int G = 256 / tpg;
-    const size_t lds = sizeof(float) * ((size_t)max(heads * L, G * d) + (size_t)L);
+    const size_t lds = sizeof(float) * ((size_t)G * d + 2 * (size_t)G * heads + (size_t)L);
     if (lds > 64 * 1024) return PIKA_ETOOBIG;
     hipLaunchKernelGGL(dstep_attn_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, kvq, ldkvq, k_cache, v_cache,
                        ancestry, ancestry_pitch, pos, node, rowmap, m_dev, L, d, heads, tpg, 1.f / sqrtf((float)dh), out);
@@ -594,7 +621,7 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
         terms > 3 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
         return PIKA_EINVAL;
     const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
-    const unsigned grid = (unsigned)(((rows + FC2_BM - 1) / FC2_BM) * ((splits + 7) / 8) * 8);
+    const unsigned grid = (unsigned)((((rows + FC2_BM - 1) / FC2_BM + 7) / 8) * 8 * splits);
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
     Cand *pc = reinterpret_cast<Cand *>(pcand);

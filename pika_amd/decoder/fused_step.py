@@ -60,6 +60,10 @@ def supported(model, beam, K):
     heads = dec.transformer[0].self_attn.head_count
     dh = d // heads
     g = dh // 4
+    splits = _lib.lib().pika_dfc2_splits(model.output_dim)
+    lds = K * beam.hyp.shape[2] * 4 + K * K * 8 + 4 * splits * K * 8        # pika_beam_advance_partials
+    if splits > 64 or splits * K > 1024 or lds > 96 * 1024:
+        return False
     return (len(dec.conv) <= MAX_LAYERS and d % 4 == 0 and d <= 1024 and 256 % (d // 4) == 0 and dh % 4 == 0
             and 1 <= g <= 64 and (g & (g - 1)) == 0 and K <= 64 and model.hid_dim % 4 == 0)
 

@@ -1,0 +1,68 @@
+"""Full-WIDTH beam-search parity: the architecture and search width of BASELINE.json configs[4]
+(V = 5000, H = 1024, beam 16, n-best 16) on B = 4 utterances, against the n-best lists of the REFERENCE decoder run on
+CPU fp32 (tests/golden/make_decode_full_golden.py).  Hypotheses (blanks included) must be IDENTICAL in the mode
+bench.py decodes in (decode_precision "fp32": encoder, joint and every step GEMM with fp32-exact products); the bf16
+operand mode is compared too and its agreement is printed, not asserted."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import decode_common as D  # noqa: E402
+import decode_full_common as F  # noqa: E402
+from oracle.pika_ref import seeded_state_dict  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "decode_full.npz")
+
+
+def decode(device, precision=None):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd.model import transducer
+    net = F.build(transducer, seeded_state_dict).to(device)
+    x, x_len = F.inputs()
+    args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    d = TransducerDecoder(net, batch_size=F.B, beam_size=F.BEAM, n_best=F.BEAM, blk=0, global_scorer=GlobalScorer(),
+                          sm_scale=F.SM_SCALE, cuda=(device != "cpu"), beam_prune=True, args=args)
+    if precision is not None:
+        d.decode_precision = precision
+    ret, enc = d.decode_batch(x.to(device), x_len.to(device), F.max_len(x_len))
+    return D.pack(ret["predictions"], ret["scores"]), enc, d
+
+
+def check(got, enc, z, enc_tol):
+    es = enc[:, ::7, ::37].float().cpu().numpy()
+    rel = np.abs(es - z["enc_sample"]).max() / np.abs(z["enc_sample"]).max()
+    assert rel < enc_tol, rel
+    assert np.array_equal(got["lens"], z["lens"])
+    assert np.array_equal(got["hyps"], z["hyps"])
+    assert np.allclose(got["scores"], z["scores"], rtol=1e-5, atol=2e-3)
+    return rel
+
+
+def test_cpu_full_width_decode_matches_reference():
+    got, enc, _ = decode("cpu")
+    check(got, enc, np.load(GOLD), 1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_full_width_decode_matches_reference(hip_device):
+    z = np.load(GOLD)
+    got, enc, d = decode(hip_device, "fp32")
+    assert "launches_per_step" in d.timing            # the fused launch-chain search ran
+    rel = check(got, enc, z, 1e-4)
+    print("fp32-exact mode: encoder output max rel err %.2e, n-best identical (%d lists x %d)" % (rel, F.B, F.BEAM))
+    # bf16 operands: how far the same search drifts (reported; near-ties may flip)
+    got16, enc16, _ = decode(hip_device, "bf16")
+    es = enc16[:, ::7, ::37].float().cpu().numpy()
+    rel16 = np.abs(es - z["enc_sample"]).max() / np.abs(z["enc_sample"]).max()
+    same_top1 = sum(int(got16["lens"][b, 0] == z["lens"][b, 0] and
+                        np.array_equal(got16["hyps"][b, 0, :z["lens"][b, 0]], z["hyps"][b, 0, :z["lens"][b, 0]]))
+                    for b in range(F.B))
+    print("bf16 mode: encoder output max rel err %.2e, identical top-1 hypotheses %d / %d" % (rel16, same_top1, F.B))
