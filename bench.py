@@ -575,7 +575,8 @@ def cpu_baseline_train_step(args, B=2):
     from oracle import rnnt as O
     O.build()
     T, U, V = args.frames, args.labels, args.vocab
-    torch.set_num_threads(os.cpu_count() or 8)
+    # 256 hardware threads made this step 10x SLOWER than 32 (fork/join per op on a B=2 batch)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
     torch.manual_seed(777)

@@ -98,9 +98,9 @@ __global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float s = 0.f;
-    for (int v = lane; v < V; v += 64) s += __expf(x[v] - m);
+    for (int v = lane; v < V; v += 64) s += expf(x[v] - m);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float logsum = __logf(s);
+    const float logsum = logf(s);
     const float add_s = scores[bk + k], add_l = lm_scale * lm_scores[bk + k];
     // Lane-local two best entries cached in registers; a lane re-scans its slice only when both
     // were consumed, so a round costs one wave arg-max instead of a V/64-element scan.
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
         float m = lane < S ? pmax[pi + lane] : -INFINITY;
         const float mine = m;
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float s = lane < S ? psum[pi + lane] * __expf(mine - m) : 0.f;
+        float s = lane < S ? psum[pi + lane] * expf(mine - m) : 0.f;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float logsum = __logf(s);
+        const float logsum = logf(s);
         const float add_s = a.scores[bk + k], add_l = a.lm_scale * sh.lm_old[k];
         // all S*K partial candidates of the row into this wave's LDS slab with ONE round of loads, then K rounds of
         // "lane-local best over its strided share + wave arg-max" (no load sits on the selection's critical path)

@@ -403,12 +403,12 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
             sc[u] = (j0 + u * G <= np) ? v : -INFINITY;
             cm = fmaxf(cm, sc[u]);
         }
-        const float mn = fmaxf(m, cm), resc = __expf(m - mn);       // m = -inf at the start: exp(-inf) = 0
+        const float mn = fmaxf(m, cm), resc = expf(m - mn);       // m = -inf at the start: exp(-inf) = 0
         acc *= resc;
         lsum *= resc;
 #pragma unroll
         for (int u = 0; u < ATT_UNROLL; ++u) {
-            const float w = __expf(sc[u] - mn);                       // masked positions: exp(-inf) = 0
+            const float w = expf(sc[u] - mn);                       // masked positions: exp(-inf) = 0
             lsum += w;
             acc += v4[u] * w;
         }
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
         float tot = 0.f;
         for (int k = 0; k < G; ++k) {
             const float mk = pm[k * heads + hd];
-            const float w = mk > -INFINITY ? __expf(mk - M) : 0.f;     // a group without positions
+            const float w = mk > -INFINITY ? expf(mk - M) : 0.f;     // a group without positions
             o4 += *reinterpret_cast<const f32x4 *>(part + k * d + col) * w;
             tot += ps[k * heads + hd] * w;
         }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < PL; ++q) s += x[q] > -INFINITY ? __expf(x[q] - m) : 0.f;
+        for (int q = 0; q < PL; ++q) s += x[q] > -INFINITY ? expf(x[q] - m) : 0.f;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const long long pi = (long long)r * splits + sp;
         if (lane == 0) { pmax[pi] = m; psum[pi] = s; }

