@@ -83,6 +83,9 @@ def train_step_workload(args, R_):
     from pika_amd.loader import otf_utt_loader as L
     dev, rank, world = R_.dev, R_.rank, R_.world
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    from pika_amd import optim as fused_optim
+    fused_optim.install()       # what `python -m pika_amd.launch <training script>` installs: the script's own
+    #                             clip_grad_norm_(inf) / optim.SGD(nesterov) calls below then run as 3 HIP launches
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
                           embd_dim=100, padding_idx=V)

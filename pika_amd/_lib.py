@@ -85,6 +85,10 @@ SIGNATURES = {
     "pika_beam_advance_partials": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                         _vp, _vp, _vp, _vp]),
+    # include/pika_optim.h
+    "pika_multi_absmax": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "pika_multi_scale_by_clip": (_i, [_vp, _vp, _vp, _vp, _i, _vp, ctypes.c_float, _vp]),
+    "pika_multi_sgd_nesterov": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.c_float, ctypes.c_float, _i, _vp]),
     # include/pika_audio.h
     "pika_audio_sumsq": (_i, [_vp, _ll, _vp, _vp]),
     "pika_audio_axpby": (_i, [_vp, _vp, _ll, ctypes.c_float, ctypes.c_float, _vp]),

@@ -10,6 +10,8 @@ What it absorbs (SURVEY.md 8b "legacy-runtime conventions"), without touching th
   * `--local-rank=N` (what torch.distributed.launch passes today) -> `--local_rank N`, or the
     LOCAL_RANK environment variable when neither is given;
   * `torch.load` of whole-module pickles (`weights_only` now defaults to True);
+  * the per-batch `clip_grad_norm_(.., norm_type=inf)` + `optim.SGD(.., nesterov=True).step()` of the training
+    scripts run as three multi-tensor HIP launches (pika_amd/optim.py; stock torch for everything else);
   * integer-tensor `/` as integer division (torch <= 1.4 semantics) ONLY on request (`--legacy-int-div`): the one
     reference line that relies on it (decoder/beam_transducer.py:125) lives in a module the drop-in `decoder`
     package replaces, so the process-wide patch is off unless a user script of its own needs it.
@@ -39,6 +41,10 @@ def install_shims(legacy_int_div=False):
         kw.setdefault("weights_only", False)
         return real_load(*a, **kw)
     torch.load = load
+    # clip_grad_norm_(..., norm_type=inf) + Nesterov optim.SGD.step() of the training scripts as three HIP launches
+    # (pika_amd/optim.py); every other use falls through to torch
+    from . import optim as _optim
+    _optim.install()
     if legacy_int_div:
         true_div = torch.Tensor.__truediv__
 

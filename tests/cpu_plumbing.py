@@ -45,7 +45,9 @@ import pika_amd.loader.otf_utt_loader as L  # noqa: E402
 
 
 class _CpuFrontEnd(object):
-    def __init__(self, cfg, dev, lctx, rctx, stride):
+    stream = None          # no side stream: the loader then assembles batches on the consumer thread
+
+    def __init__(self, cfg, dev, lctx, rctx, stride, base_seed=0, side_stream=False):
         self.cfg, self.lctx, self.rctx, self.stride = cfg, lctx, rctx, stride
 
     def __call__(self, pcms, rates, dbs):
