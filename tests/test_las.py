@@ -78,7 +78,7 @@ def test_gpu_las_rescore_matches_reference(hip_device):
         G.PRECISION = old
 
 
-def test_las_training_step_matches_reference():
+def _las_training_step(device):
     """One TRAINING step of the LAS model with the calling convention of train_las_bmuf_otfaug.py:227-239 and the
     decoder cross-entropy of its LASLossCompute: decoder outputs, loss and EVERY parameter gradient equal the
     reference's (golden recorded from trainer/model/las.py by tests/golden/make_las_train_golden.py)."""
@@ -89,11 +89,12 @@ def test_las_training_step_matches_reference():
     for attn in ("mlp", "general"):
         net = las.Net(LC.opt(attn), LC.C_IN, LC.V, LC.PAD)
         net.load_state_dict(seeded_state_dict(net, 31, scale=0.3))
-        net.train()
+        net = net.to(device).train()
         src, tgt, lens = LC.train_batch()
+        src, tgt = src.to(device), tgt.to(device)
         outputs, _, _, enc_out = net.forward(src, tgt, lens, None, True, True)
-        assert np.allclose(outputs.detach().numpy(), z["%s/outputs" % attn], rtol=1e-4, atol=1e-5)
-        assert np.allclose(enc_out.detach().numpy(), z["%s/enc_out" % attn], rtol=1e-4, atol=1e-5)
+        assert np.allclose(outputs.detach().cpu().numpy(), z["%s/outputs" % attn], rtol=1e-4, atol=1e-5)
+        assert np.allclose(enc_out.detach().cpu().numpy(), z["%s/enc_out" % attn], rtol=1e-4, atol=1e-5)
         logp = F.log_softmax(net.dec_proj(outputs.view(-1, outputs.size(2))), dim=1)
         loss = F.nll_loss(logp, tgt[1:].contiguous().view(-1), ignore_index=LC.PAD, reduction="sum")
         loss.backward()
@@ -101,7 +102,23 @@ def test_las_training_step_matches_reference():
         n = 0
         for k, p in net.named_parameters():
             want = z["%s/grad/%s" % (attn, k)]
-            got = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+            got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu().numpy()
             assert np.allclose(got, want, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(want).max())), (attn, k)
             n += 1
         assert n == len([k for k in z.files if k.startswith(attn + "/grad/")])
+
+
+def test_las_training_step_matches_reference():
+    _las_training_step("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_las_training_step_matches_reference(hip_device):
+    """The same step on the MI355X (Linear layers on the MFMA GEMM in its fp32-exact mode, LSTMs on MIOpen): every
+    parameter gradient against the golden recorded from the reference's trainer/model/las.py."""
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        _las_training_step(hip_device)
+    finally:
+        G.PRECISION = old

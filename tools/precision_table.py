@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Arithmetic mode -> measured error (GPU).  Two panels, printed as markdown:
+
+A. vs the REFERENCE golden (tests/golden/model_tiny_transformer.npz, recorded from the reference model code on
+   PyTorch-CPU fp32): encoder activations, joint log-probs, and the 12+3 recorded parameter gradients.
+B. full config-2 architecture (1024 wide, 9 TDNN + 3 transformer layers, V = 5000), B = 8: bf16 mode against the
+   fp32-exact mode (the one panel A pins): encoder output, per-utterance RNN-T cost, every parameter gradient.
+
+Error measure: max |a - b| / max |b| per tensor (what tests/test_model.py::close asserts at 1e-3 for north_star).
+    python tools/precision_table.py > profiles/r2_precision_table.md"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+import model_common as C  # noqa: E402
+from test_model import ours  # noqa: E402
+from pika_amd import gemm as G  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+print("## A. tiny model vs the reference golden (PyTorch-CPU fp32 of the reference's own model code)\n")
+print("| mode | encoder act. (eval) | joint log-probs (eval) | joint log-probs (train) | worst of the recorded gradients |")
+print("|---|---|---|---|---|")
+z = np.load(os.path.join(ROOT, "tests", "golden", "model_tiny_transformer.npz"))
+for mode in ("fp32", "bf16"):
+    G.PRECISION = mode
+    net = ours("transformer", dev)
+    x, y, y_len, w = [t.to(dev) for t in C.inputs()]
+    net.eval()
+    with torch.no_grad():
+        e_enc = rel(net.encoder(x), z["enc_eval"])
+        e_joint = rel(net(x, y, None, True), z["joint_eval"])
+    net.train()
+    lp = net(x, y, None, True)
+    e_train = rel(lp, z["joint_train"])
+    (lp * w).sum().backward()
+    params = dict(net.named_parameters())
+    worst = max((rel(params[str(k)].grad, z["grad:" + str(k)]), str(k)) for k in z["grad_keys"])
+    print("| %s | %.2e | %.2e | %.2e | %.2e (%s) |" % ("fp32-exact (3-term split, 6 MFMAs)" if mode == "fp32" else "bf16 operands",
+                                                      e_enc, e_joint, e_train, worst[0], worst[1]))
+
+print("\n## B. full config-2 architecture, B = 8, T_in = 420: bf16 mode vs fp32-exact mode\n")
+from pika_amd.model.transducer import Net  # noqa: E402
+from pika_amd.rnnt import RNNTLoss  # noqa: E402
+B, T, U, V = 8, 420, 12, 5000
+opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn",
+                      dropout=0.0, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
+torch.manual_seed(5)
+model = Net(opt, 240, V).to(dev).train()
+for m in model.modules():
+    if isinstance(m, torch.nn.Dropout):
+        m.p = 0.0
+g = torch.Generator().manual_seed(6)
+data = torch.randn(B, T, 240, generator=g).to(dev)
+labels = torch.randint(1, V, (B, U), generator=g).to(dev)
+lens = torch.tensor([T - 7 * i for i in range(B)], dtype=torch.int32, device=dev)
+len_b = lens - 42
+len_b = len_b // 4 + (len_b % 4 != 0).int()
+ali = torch.tensor([U - (i % 3) for i in range(B)], dtype=torch.int32, device=dev)
+bn_state = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+
+
+def run(mode):
+    model.load_state_dict(bn_state, strict=False)
+    model.zero_grad(set_to_none=True)
+    G.PRECISION = mode
+    enc = model.encode(data, None)
+    out = model(data, labels, len_b, True)
+    costs = RNNTLoss(blank=0).apply(out, labels.int(), len_b, ali)
+    costs.sum().backward()
+    return enc.detach(), costs.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+e16, c16, g16 = run("bf16")
+e32, c32, g32 = run("fp32")
+grel = {n: float(((g16[n] - g32[n]).double().norm() / g32[n].double().norm().clamp_min(1e-30))) for n in g32
+        if float(g32[n].double().norm()) > 1e-4 * max(1.0, g32[n].numel() ** 0.5)}
+enc_g = {n: v for n, v in grel.items() if n.startswith("encoder.")}
+oth_g = {n: v for n, v in grel.items() if not n.startswith("encoder.")}
+print("| quantity | bf16 vs fp32-exact |")
+print("|---|---|")
+print("| encoder output (B,T',1024), max abs err / max abs | %.2e |" % rel(e16, e32))
+print("| RNN-T cost per utterance, max rel | %.2e |" % float(((c16 - c32).abs() / c32.abs()).max()))
+print("| prediction-net / joint parameter gradients, worst ||dg||/||g|| | %.2e (%s) |" % max((v, n) for n, v in oth_g.items()))
+print("| encoder parameter gradients, worst ||dg||/||g|| | %.2e (%s) |" % max((v, n) for n, v in enc_g.items()))
+print("| encoder parameter gradients, median ||dg||/||g|| | %.2e |" % float(np.median(list(enc_g.values()))))
