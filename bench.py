@@ -84,7 +84,8 @@ def train_step_workload(args, R_):
     dev, rank, world = R_.dev, R_.rank, R_.world
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
     from pika_amd import optim as fused_optim
-    fused_optim.install()       # what `python -m pika_amd.launch <training script>` installs: the script's own
+    if os.environ.get("PIKA_FUSED_OPTIM", "1") != "0":
+        fused_optim.install()   # what `python -m pika_amd.launch <training script>` installs: the script's own
     #                             clip_grad_norm_(inf) / optim.SGD(nesterov) calls below then run as 3 HIP launches
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
