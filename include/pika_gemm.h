@@ -74,6 +74,14 @@ int pika_gemm_nt_ws(const pika_operand_t *A, const pika_operand_t *B, float *C, 
 int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, long long ldb, float *C,
                       long long ldc, int M, int N, int K, const float *bias, void *stream);
 
+/* pika_gemm_bf16_nt (N > 256) whose epilogue also emits, per output row m and 64-column block b < n_part =
+ * ceil(N/256)*4, the partial log-sum-exp statistics of C's row: pmax[m*n_part + b] = max of the block's columns
+ * (-inf for a block beyond N), psum[...] = sum exp(x - pmax).  The RNN-T loss merges them instead of re-reading the
+ * (B,T,U,V) logits (pika_rnnt_fused_forward_partials, pika_rnnt.h). */
+int pika_gemm_bf16_nt_lse(const void *A, long long lda, const void *B, long long ldb, float *C, long long ldc,
+                          int M, int N, int K, const float *bias, float *pmax, float *psum, int n_part,
+                          void *stream);
+
 /* The same product with a fused bf16 epilogue, for chains whose wide intermediate only ever feeds
  * another MFMA product (the transformer feed-forward block, reference trainer/model/position_ffn.py:27-39:
  * w_2(dropout(relu(w_1(x)))) -- the (rows, d_ff) hidden exists only in bf16, ReLU/dropout never run as passes):

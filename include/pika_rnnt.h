@@ -102,6 +102,14 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
                                    int U1, int V, int blank, void *out, long long ld_out, float scale,
                                    float *colsum, void *stream);
 
+/* pika_rnnt_fused_forward with the row log-sum-exp taken from partial statistics instead of a pass over the logits:
+ * pmax / psum (rows, n_part) as written by pika_gemm_bf16_nt_lse (pika_gemm.h) for the SAME logits.  Reads
+ * 8*n_part bytes + two 64-byte sectors per lattice cell instead of 4*V bytes. */
+int pika_rnnt_fused_forward_partials(const float *logits, const float *pmax, const float *psum, int n_part,
+                                     const int *labels, const int *frames_lengths, const int *labels_lengths, int B,
+                                     int T, int U1, int V, int blank, float *costs, float *lse, void *workspace,
+                                     void *stream);
+
 /* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces
  * F.log_softmax (trainer/model/transducer.py:111) + the loss + the log-softmax backward for a caller that owns
  * the joint output.  `logits` (B,T,U1,V) f32 are the RAW fc2 outputs, V % 4 == 0, V <= 5120; lse (B*T*U1) f32

@@ -20,6 +20,7 @@ SIGNATURES = {
     "pika_rnnt_loss_dense_grads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "pika_rnnt_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pika_rnnt_fused_forward_partials": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
     "pika_rnnt_dlogits_compact_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
     "pika_rnnt_export_lattice": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     "pika_gemm_nt": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "pika_gemm_nt_ws": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp, ctypes.c_size_t, _vp]),
     "pika_gemm_bf16_nt": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp]),
+    "pika_gemm_bf16_nt_lse": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "pika_gemm_bf16_epilogue": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _i, _i, ctypes.c_float,
                                      ctypes.c_uint, _vp, _ll, ctypes.c_float, _vp]),
     "pika_dropout_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),

@@ -164,6 +164,10 @@ struct PPArgs {
     unsigned seed, thr;                // EPI 1, 3: drop where hash16 < thr (thr = 0: no dropout)
     const float *res;                  // EPI 3: fp32 residual added after the dropout
     long long ld_res;
+    // EPI 0, optional: per output row and 64-column block b = (tile column) * 4 + (wave column), the partial
+    // log-sum-exp statistics of the row: lse_pm[m * lse_np + b] = max over the block, lse_ps[...] = sum exp(x - max)
+    float *lse_pm, *lse_ps;
+    int lse_np;
     int nx, ntiles;                    // output tiles per row of tiles / in total (filled in by launch_pp_epi)
 #ifdef PIKA_PP_TRACE
     unsigned long long *trace;         // tools/pp_trace.hip: [wg < 8][group 2][tile < 16][24] time stamps
@@ -474,6 +478,11 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         const int i = ip + di;
         const int m = em0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= M) continue;
+        [[maybe_unused]] f32x4 lv[4];
+        if constexpr (EPI == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lv[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = en0 + wc * 64 + j * 16 + (lane >> 4) * 4;
@@ -497,6 +506,10 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 if (wide) v += rv[di][j];
                 else if (n + 3 < N) v += *reinterpret_cast<const f32x4 *>(rp);
                 else for (int e = 0; e < 4; ++e) if (n + e < N) v[e] += rp[e];
+            }
+            if constexpr (EPI == 0) {
+                if (n + 3 < N) lv[j] = v;
+                else for (int e = 0; e < 4; ++e) if (n + e < N) lv[j][e] = v[e];
             }
             if constexpr (EPI == 0 || EPI == 3) {
                 if (n + 3 < N) {
@@ -527,6 +540,30 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     *reinterpret_cast<bf16x4 *>(op) = __builtin_convertvector(v, bf16x4);
                 } else {
                     for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = (__bf16)v[e];
+                }
+            }
+        }
+        if constexpr (EPI == 0) {
+            if (P.lse_pm) {
+                // the 64 columns this wave holds of row m sit in the 4 lanes {l, l+16, l+32, l+48}, 16 values each
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(lv[j].x, lv[j].y), fmaxf(lv[j].z, lv[j].w)));
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sm = 0.f;
+                if (mx > -INFINITY) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sm += __expf(lv[j][e] - mx);     // masked columns: exp(-inf) = 0
+                }
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                if ((lane >> 4) == 0) {
+                    const long long o = (long long)m * P.lse_np + etn * 4 + wc;
+                    P.lse_pm[o] = mx;
+                    P.lse_ps[o] = sm;
                 }
             }
         }
@@ -1053,6 +1090,21 @@ extern "C" int pika_gemm_bf16_nt(const void *A, long long lda, const void *B, lo
     hipLaunchKernelGGL(gemm_glds, dim3((N + BN - 1) / BN, (M + BM - 1) / BM), dim3(THREADS), 2 * BUF, s,
                        static_cast<const __bf16 *>(A), static_cast<const __bf16 *>(B), C, M, N, K, lda, ldb, ldc, bias);
     return (int)hipGetLastError();
+}
+
+extern "C" int pika_gemm_bf16_nt_lse(const void *A, long long lda, const void *B, long long ldb, float *C, long long ldc,
+                                     int M, int N, int K, const float *bias, float *pmax, float *psum, int n_part,
+                                     void *stream) {
+    if (!A || !B || !C || !pmax || !psum || M <= 0 || N <= 256 || K <= 0 || n_part != ((N + 255) / 256) * 4) return PIKA_EINVAL;
+    if ((K % BK) || (lda & 7) || (ldb & 7) || (ldc & 3) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) |
+                                                             reinterpret_cast<uintptr_t>(C)) & 15))
+        return PIKA_EINVAL;
+    PPArgs P{};
+    P.A = static_cast<const __bf16 *>(A); P.B = static_cast<const __bf16 *>(B); P.C = C; P.bias = bias;
+    P.ldb = ldb; P.ldc = ldc; P.a_rpb = M; P.a_batch = 0; P.a_row = lda; P.a_tap = 0; P.a_C = K;
+    P.M = M; P.N = N; P.K = K; P.relu = 0;
+    P.lse_pm = pmax; P.lse_ps = psum; P.lse_np = n_part;
+    return launch_pp(P, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long long ldb, void *out,

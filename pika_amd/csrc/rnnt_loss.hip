@@ -644,6 +644,51 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather_kernel(
     }
 }
 
+// The same outputs from the per-row partial (max, sum exp) pairs the joint's output GEMM emitted in its epilogue
+// (pika_gemm_bf16_nt_lse): 16 lanes per row merge n_part pairs, then the row's two needed logits are fetched (two
+// 64-byte sectors per lattice cell instead of the whole 20 KB row).
+__global__ __launch_bounds__(256) void rnnt_lse_merge_gather_kernel(
+    const float *__restrict__ logits, const float *__restrict__ pmax, const float *__restrict__ psum, int n_part,
+    const int *__restrict__ labels, const int *__restrict__ Tn_, const int *__restrict__ Un_, long long rows, int T,
+    int U1, int V, int blank, float *__restrict__ lse, float *__restrict__ lpb, float *__restrict__ lpe, int Wp, int D) {
+    const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    const bool in = r < rows;
+    int u = 0, t = 0, b = 0, Tn = 1, Un = 0;
+    if (in) {
+        u = (int)(r % U1);
+        t = (int)((r / U1) % T);
+        b = (int)(r / ((long long)U1 * T));
+        Tn = clampi(Tn_[b], 1, T);
+        Un = clampi(Un_[b], 0, U1 - 1);
+    }
+    const bool live = in && t < Tn && u <= Un;
+    float m = -INFINITY;
+    if (live)
+        for (int q = l16; q < n_part; q += 16) m = fmaxf(m, pmax[r * n_part + q]);
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    if (live)
+        for (int q = l16; q < n_part; q += 16) {
+            const float pm = pmax[r * n_part + q];
+            if (pm > -INFINITY) s += psum[r * n_part + q] * __expf(pm - m);
+        }
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (!in || l16) return;
+    if (!live) { lse[r] = 0.f; return; }
+    const float l = m + __logf(s);
+    lse[r] = l;
+    const float *row = logits + r * V;
+    float ve = NEG;
+    if (u < Un) {
+        const int y = labels[(size_t)b * (U1 - 1) + u];
+        if (y >= 0 && y < V) ve = fmaxf(row[y] - l, NEG);
+    }
+    const size_t o = ((size_t)b * D + (t + u)) * Wp + u;
+    lpb[o] = fmaxf(row[blank] - l, NEG);
+    lpe[o] = ve;
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__restrict__ logits,
                                                                  const float *__restrict__ lse,
@@ -826,6 +871,24 @@ int pika_rnnt_fused_forward(const float *logits, const int *labels, const int *f
     const Lattice L = carve(workspace, B, T, U1);
     hipLaunchKernelGGL(rnnt_lse_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, labels,
                        frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe, L.Wp, L.D);
+    return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
+}
+
+int pika_rnnt_fused_forward_partials(const float *logits, const float *pmax, const float *psum, int n_part,
+                                     const int *labels, const int *frames_lengths, const int *labels_lengths, int B,
+                                     int T, int U1, int V, int blank, float *costs, float *lse, void *workspace,
+                                     void *stream) {
+    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
+    if (!logits || !pmax || !psum || n_part <= 0 || !frames_lengths || !labels_lengths || !costs || !lse || !workspace)
+        return PIKA_EINVAL;
+    if (U1 > 1 && !labels) return PIKA_EINVAL;
+    const long long rows = (long long)B * T * U1;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Lattice L = carve(workspace, B, T, U1);
+    hipLaunchKernelGGL(rnnt_lse_merge_gather_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, logits, pmax,
+                       psum, n_part, labels, frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe,
+                       L.Wp, L.D);
     return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
 }
 

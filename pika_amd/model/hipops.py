@@ -391,17 +391,33 @@ class JointOutFn(torch.autograd.Function):
         N, K = weight.shape
         h2 = h.reshape(-1, K)
         out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
-        G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
         ctx.scale = float(scale)
         ctx.has_bias = bias is not None
         ctx.state = None
-        ctx.save_for_backward(h2, weight, out)
         if lazy and out.dim() == 4:
             # the log-softmax pass is deferred until something needs the values (pika_amd.rnnt.LazyLogProbs);
-            # `out` is normalised in place by a raw kernel call, which autograd's version counter does not see
+            # `out` is normalised in place by a raw kernel call, which autograd's version counter does not see.
+            # The GEMM's epilogue leaves per-row partial (max, sum exp) pairs per 64-column block, from which this
+            # package's loss takes the row log-sum-exp without reading the logits again (include/pika_gemm.h)
             from ..rnnt import LazyLogProbs, LogitsState
             ctx.state = LogitsState(scale)
+            M = h2.shape[0]
+            if scale == 1.0 and N > 256 and os.environ.get("PIKA_JOINT_LSE_EPILOGUE", "1") != "0":
+                n_part = (N + 255) // 256 * 4
+                part = torch.empty((2, M, n_part), dtype=torch.float32, device=h.device)
+                wb = weight.detach().to(torch.bfloat16)
+                with torch.cuda.device(h.device):
+                    _lib.check(_lib.lib().pika_gemm_bf16_nt_lse(
+                        h2.data_ptr(), h2.stride(0), wb.data_ptr(), wb.stride(0), out.data_ptr(), N, M, N, K,
+                        None if bias is None else bias.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), n_part,
+                        _stream()), "pika_gemm_bf16_nt_lse")
+                ctx.state.partials = part
+            else:
+                G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
+            ctx.save_for_backward(h2, weight, out)
             return LazyLogProbs(ctx.state, out)
+        G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
+        ctx.save_for_backward(h2, weight, out)
         with torch.cuda.device(h.device):
             _lib.check(_lib.lib().pika_log_softmax_rows(out.data_ptr(), h2.shape[0], N, N, float(scale),
                                                         _stream()), "pika_log_softmax_rows")

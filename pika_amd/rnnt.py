@@ -153,10 +153,11 @@ class LogitsState(object):
     hangs off them may keep the 7.8 GB buffer alive -- the buffer itself lives in autograd's saved tensors and in the
     LazyLogProbs the caller holds.)"""
 
-    __slots__ = ("scale", "raw")
+    __slots__ = ("scale", "raw", "partials")
 
     def __init__(self, scale):
         self.scale, self.raw = float(scale), True
+        self.partials = None      # (2, rows, n_part) per-row partial (max, sum exp) pairs from the GEMM epilogue
 
     def to_log_probs(self, buf):
         """In place: buf <- log_softmax(scale * buf), once."""
@@ -166,6 +167,7 @@ class LogitsState(object):
                 _lib.check(_lib.lib().pika_log_softmax_rows(buf.data_ptr(), B * T * U1, V, V, self.scale, _stream()),
                            "pika_log_softmax_rows")
             self.raw = False
+            self.partials = None
         return buf
 
 
@@ -224,10 +226,18 @@ class _RNNTLossFn(torch.autograd.Function):
                 costs = torch.empty(B, dtype=torch.float32, device=x.device)
                 lse = torch.empty(B * T * U1, dtype=torch.float32, device=x.device)
                 ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=x.device)
+                part = state.partials
+                state.partials = None          # one use: 250 MB at the benchmark shape
                 with _timed("fwd"):
-                    _lib.check(lib.pika_rnnt_fused_forward(
-                        _ptr(x), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
-                        _ptr(costs), _ptr(lse), _ptr(ws), _stream()), "pika_rnnt_fused_forward")
+                    if part is not None:
+                        _lib.check(lib.pika_rnnt_fused_forward_partials(
+                            _ptr(x), part[0].data_ptr(), part[1].data_ptr(), part.shape[2], _ptr(labels),
+                            _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank, _ptr(costs), _ptr(lse),
+                            _ptr(ws), _stream()), "pika_rnnt_fused_forward_partials")
+                    else:
+                        _lib.check(lib.pika_rnnt_fused_forward(
+                            _ptr(x), _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank,
+                            _ptr(costs), _ptr(lse), _ptr(ws), _stream()), "pika_rnnt_fused_forward")
         else:
             # a LazyLogProbs the fused path cannot take (already read, scaled, V out of the fused kernel's range) is
             # normalised HERE: `.contiguous()` on the wrapper subclass short-circuits and would hand back the wrapper

@@ -259,3 +259,41 @@ def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
                     assert (a - r).norm() <= 6e-2 * r.norm(), (V, read_first, float((a - r).norm() / r.norm()))
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("V", [1000, 5000, 264])
+def test_log_sum_exp_from_the_output_gemm_epilogue(hip_device, monkeypatch, V):
+    """The joint's output GEMM emits per-row partial (max, sum exp) pairs per 64-column block in its epilogue and the
+    loss merges them (pika_gemm_bf16_nt_lse -> pika_rnnt_fused_forward_partials) instead of re-reading the lattice of
+    logits: same costs and parameter gradients as the path that reads the logits for the log-sum-exp."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
+    from pika_amd.rnnt import RNNTLoss, LazyLogProbs
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(V)
+        B, T, U, H = 3, 37, 6, 128
+        h = (torch.randn(B, T, U + 1, H, generator=g) * 0.5).bfloat16().to(hip_device)
+        w = (torch.randn(V, H, generator=g) * 0.3).to(hip_device)
+        b = (torch.randn(V, generator=g) * 2.0).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        tl = torch.tensor([T, T - 5, T - 11], dtype=torch.int32, device=hip_device)
+        ul = torch.tensor([U, U - 1, U - 4], dtype=torch.int32, device=hip_device)
+
+        def run(epi):
+            monkeypatch.setenv("PIKA_JOINT_LSE_EPILOGUE", "1" if epi else "0")
+            hh, ww, bb = (t.clone().requires_grad_(True) for t in (h, w, b))
+            lp = JointOutFn.apply(hh, ww, bb, 1.0, True)
+            lp._pika_lazy_grad_ok = True
+            assert isinstance(lp, LazyLogProbs) and (lp.state.partials is not None) == epi
+            costs = RNNTLoss().apply(lp, labels, tl, ul)
+            assert lp.state.raw
+            costs.sum().backward()
+            return costs.detach(), hh.grad.float(), ww.grad, bb.grad, lp.detach().clone()
+        a, r = run(True), run(False)
+        assert torch.allclose(a[0], r[0], rtol=2e-6, atol=1e-5)
+        for x, y, tol in ((a[1], r[1], 1e-2), (a[2], r[2], 2e-4), (a[3], r[3], 2e-4)):
+            assert (x - y).abs().max().item() <= tol * y.abs().max().item() + 1e-12
+        assert torch.allclose(a[4], r[4], atol=1e-5)          # reading the values normalises both the same way
+    finally:
+        G.PRECISION = old
