@@ -261,10 +261,14 @@ def decode_workload(args, dev, rank):
         labels = float("nan")
         if args.blank_bias is not None:      # profiling runs: skip the calibration decodes
             lo = hi = args.blank_bias
-        for _ in range(8 if args.blank_bias is None else 0):  # bisection on the blank bias
+        # bisection on the blank bias WITH the search that is timed (beam width, n-best, FST fusion): the top-1
+        # hypothesis of the benchmarked configuration then carries ~args.labels labels (a greedy calibration left
+        # the beam-16 / LM-fused searches at 29 / 5 labels per utterance in round 1)
+        for _ in range(9 if args.blank_bias is None else 0):
             mid = 0.5 * (lo + hi)
             model.fc2.bias[0] = mid
-            ret, _ = decoder(1, 1).decode_batch(feats[:8], x_len[:8], [int(v) + 100 for v in x_len[:8]])
+            ret, _ = decoder(args.beam, args.beam, lm_scorer).decode_batch(feats[:8], x_len[:8],
+                                                                         [int(v) + 100 for v in x_len[:8]])
             labels = np.mean([sum(1 for e in h[0] if int(e) != 0) for h in ret["predictions"]])
             if labels > args.labels:
                 lo = mid
@@ -338,18 +342,19 @@ def mbr_workload(args, dev, rank):
     ali = torch.full((B,), U, dtype=torch.int32, device=dev)
     dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
 
-    def decoder(k):
+    def decoder(k):     # as the script builds it (train_transducer_mbr_bmuf_otfaug.py:79-87: beam_prune=False)
         return TransducerDecoder(model, batch_size=B, beam_size=k, n_best=k, blk=0, global_scorer=GlobalScorer(),
-                                 sm_scale=0.8, cuda=True, beam_prune=True, args=dargs)
+                                 sm_scale=0.8, cuda=True, beam_prune=False, args=dargs)
+    max_len = [int(v) + U + 3 for v in x_len]                                 # :114
     model.eval()
     with torch.no_grad():
         model.fc2.weight *= 8.0
         lo, hi = 0.0, 40.0
-        for _ in range(8):
+        for _ in range(9):      # calibrated with the N-best search that is timed: ~U labels per hypothesis
             mid = 0.5 * (lo + hi)
             model.fc2.bias[0] = mid
-            ret, _ = decoder(1).decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
-            nlab = np.mean([sum(1 for e in h[0] if int(e) != 0) for h in ret["predictions"]])
+            ret, _ = decoder(beam).decode_batch(feats, x_len, max_len)
+            nlab = np.mean([sum(1 for e in h if int(e) != 0) for row in ret["predictions"] for h in row])
             lo, hi = (mid, hi) if nlab > U else (lo, mid)
         model.fc2.bias[0] = 0.5 * (lo + hi)
     for m in model.modules():   # keep the eval-mode model (running statistics) at its calibration point
@@ -360,7 +365,6 @@ def mbr_workload(args, dev, rank):
     # utterance in every timed step (the arithmetic of the update is the same)
     optim = torch.optim.SGD(model.parameters(), 1e-9, momentum=0.9, nesterov=True)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
-    max_len = [int(v) + U + 3 for v in x_len]
     info = {}
 
     def step():
@@ -722,7 +726,7 @@ def main():
     ap.add_argument("--blank-bias", type=float, default=None,
                     help="decode: use this fc2 blank bias instead of calibrating it (profiling runs)")
     ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
-    ap.add_argument("--fst-scale", type=float, default=0.3, help="decode --fst: LM weight")
+    ap.add_argument("--fst-scale", type=float, default=0.3, help="decode --fst: LM weight (egs/eval_transducer.sh uses 0.3)")
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
