@@ -361,11 +361,12 @@ def mbr_workload(args, dev, rank):
         if isinstance(m, torch.nn.BatchNorm1d):
             m.momentum = 0.0
     dec = decoder(beam)
+    dec.decode_precision = "bf16"      # N-best generation inside a training step: the training arithmetic
     # the step size is negligible on purpose: the calibrated random model must keep emitting ~U labels per
     # utterance in every timed step (the arithmetic of the update is the same)
     optim = torch.optim.SGD(model.parameters(), 1e-9, momentum=0.9, nesterov=True)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
-    info = {}
+    info = {"blank_bias": float(model.fc2.bias[0])}
 
     def step():
         model.eval()
@@ -704,6 +705,56 @@ def cpu_baseline_decode(a, blank_bias, B=4):
                       % (B, T, a.beam, el, dec.timing["steps"])}
 
 
+def cpu_baseline_mbr(args, blank_bias, B=2):
+    """CPU leg of the MBR step: the same module tree / decoder / risk code on PyTorch-CPU fp32 stock ops + the oracle's
+    RNN-T loss, one step at B=2 (a port: the reference's own files are not on the GPU box)."""
+    from types import SimpleNamespace
+    from model.transducer import Net
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd import mbr
+    from pika_amd.model import ops
+    from oracle import rnnt as O
+    O.build()
+    T, U, V, beam = args.frames, args.labels, args.vocab, args.beam
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn",
+                          dropout=0.2, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
+    torch.manual_seed(777)
+    model = Net(opt, 240, V)
+    with torch.no_grad():
+        model.fc2.weight *= 8.0
+        model.fc2.bias[0] = blank_bias
+    g = torch.Generator().manual_seed(4000)
+    feats = torch.randn(B, T, 240, generator=g)
+    x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long)
+    labels = torch.randint(1, V, (B, U), generator=g)
+    ali = torch.full((B,), U, dtype=torch.int32)
+    dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    dec = TransducerDecoder(model, batch_size=B, beam_size=beam, n_best=beam, blk=0, global_scorer=GlobalScorer(),
+                            sm_scale=0.8, cuda=False, beam_prune=False, args=dargs)
+    optim = torch.optim.SGD(model.parameters(), 1e-9, momentum=0.9, nesterov=True)
+    t0 = time.perf_counter()
+    model.eval()
+    with torch.no_grad():
+        ret, _ = dec.decode_batch(feats, x_len, [int(v) + U + 3 for v in x_len])
+    model.train()
+    optim.zero_grad(set_to_none=True)
+    enc = model.encode(feats, None)
+    pred = model.predict(torch.cat((torch.zeros(B, 1, dtype=torch.long), labels), dim=1))
+    lp = ops.joint(enc, pred, model.fc1, model.fc_gate, model.fc2, log_softmax=True)
+    _, grads = O.rnnt_loss(lp.detach().numpy(), labels.int().numpy(), x_len.int().numpy(), ali.numpy(), dtype=np.float32)
+    lp.backward(0.1 * torch.from_numpy(grads), retain_graph=True)
+    prob, dist_, seq_grad, nonblk = mbr.risk_terms(ret["predictions"], ret["scores"], labels, ali, 0, enc.device)
+    mbr.mbr_backward(model, enc, ret["predictions"], seq_grad, nonblk, 0, 0.8)
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+    optim.step()
+    el = time.perf_counter() - t0
+    return {"value": B / el, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 MBR step, B=%d, beam %d, T_in=%d: same decoder / model / risk code on PyTorch-CPU fp32 stock ops "
+                      "+ oracle C/OpenMP RNN-T loss, %.1f s" % (B, beam, T, el)}
+
+
 def main():
     if os.environ.get("PIKA_BENCH_WATCHDOG"):      # dump every thread's stack if the run exceeds N seconds
         import faulthandler
@@ -848,7 +899,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item()) / args.steps
         if rank == 0:
+            cb = None
+            if world == 1 and not args.no_cpu_baseline:
+                cb = cpu_baseline_mbr(args, float(info.get("blank_bias", 1.0)))
             print(json.dumps({
+                "cpu_baseline": cb,
                 "metric": "utterances/sec MBR train step (T_in=%d,U=%d,V=%d)" % (T, U, V), "value": B * world / el,
                 "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
