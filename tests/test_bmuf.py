@@ -170,3 +170,48 @@ def test_trainer_on_hip_single_rank(hip_device, tmp_path):
         torch.nn.utils.vector_to_parameters(G.clone(), cpu_model.parameters())
         assert np.allclose(C.flat(model), G.numpy(), rtol=1e-6, atol=1e-7)
     dist.destroy_process_group()
+
+
+def _rebind_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from trainer.bmuf import BmufTrainer
+    model = C.make_model(0)
+    tr = BmufTrainer(0, rank, world, model, C.BM, C.BLR)
+    ref = C.make_model(0)                    # the reference formulation re-reads the parameters at every sync
+    flatten = lambda m: torch.cat([p.detach().reshape(-1) for p in m.parameters()])   # noqa: E731
+
+    def assign(m, vec):                      # copies (vector_to_parameters would make the parameters views of vec)
+        off = 0
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(vec[off:off + p.numel()].view_as(p))
+                off += p.numel()
+    g_param = flatten(ref).clone()
+    delta_prev = torch.zeros_like(g_param)
+    for rnd in range(3):
+        if rnd == 1:                         # something re-binds p.data (model.float(), load_state_dict(assign=True), ...)
+            for p in model.parameters():
+                p.data = p.data.clone()
+            assert next(model.parameters()).data_ptr() != tr.local.data_ptr()
+        C.local_step(model, 0, rnd)
+        C.local_step(ref, 0, rnd)
+        assert tr.update_and_sync() == 1
+        # bmuf.py:83-98 with world_size 1
+        delta = g_param - flatten(ref)
+        delta_prev = C.BM * delta_prev + C.BLR * (1 - C.BM) * delta
+        g_param = g_param - (1 + C.BM) * delta_prev
+        assign(ref, g_param)
+        assert np.allclose(C.flat(model), C.flat(ref), rtol=0, atol=1e-6), rnd
+        assert next(model.parameters()).data_ptr() == tr.local.data_ptr()       # re-pointed at the flat vector
+    np.save(out, C.flat(model))
+    dist.destroy_process_group()
+
+
+def test_parameters_rebound_behind_the_trainer_are_adopted(tmp_path):
+    """anything that re-binds `p.data` after construction used to detach the model from the block update
+    silently (delta = 0 forever); update_and_sync now adopts the parameters' current values and re-points them."""
+    out = str(tmp_path / "rebind.npy")
+    mp.spawn(_rebind_worker, args=(1, C.free_port(), out), nprocs=1, join=True)
+    assert np.isfinite(np.load(out)).all()
