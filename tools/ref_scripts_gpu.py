@@ -94,7 +94,7 @@ def run(outdir):
     for name in ("train", "decode"):
         dbs = list((out / ("prof_" + name)).rglob("*_results.db"))
         if dbs:
-            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), str(dbs[0]), "--top", "25"],
+            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_stats.py"), str(dbs[0]), "--top", "120"],
                                  capture_output=True, text=True).stdout
             (out / ("%s_kernel_stats.csv" % name)).write_text(txt)
             for d in dbs:
