@@ -147,6 +147,45 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ d
     dx[idx] = s;
 }
 
+
+// Two-term bf16 split of an f32 operand for the "bf16x3" products (include/pika_ops.h): every thread takes 8
+// consecutive source columns (two 16-byte loads) and writes the three 16-byte segments of its granule.
+// seg_stride = elements between the three segments of one source element, blk = destination elements per source
+// row-block; pad columns [C, Cp) of the concat layout are zero-filled by the threads that own them.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ x, int t_in, int C, int Cp,
+                                                           long long batch_stride, long long ld, int role,
+                                                           long long seg_stride, long long dst_batch,
+                                                           long long dst_ld, long long n_gran,
+                                                           __bf16 *__restrict__ dst) {
+    typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_gran) return;
+    const int gpr = Cp >> 3;                       // granules per destination row
+    const long long row = g / gpr;
+    const int c = (int)(g - row * gpr) << 3;
+    const long long b = row / t_in;
+    const int t = (int)(row - b * t_in);
+    bf8 hi, lo;
+    if (c < C) {                                   // C % 8 == 0: a granule is all source or all padding
+        const float4 *src = reinterpret_cast<const float4 *>(x + b * batch_stride + (long long)t * ld + c);
+        const float4 v0 = src[0], v1 = src[1];
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const __bf16 h = (__bf16)v[i];
+            hi[i] = h;
+            lo[i] = (__bf16)(v[i] - (float)h);     // exact in fp32; the second term carries bits 9..16
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hi[i] = (__bf16)0.f; lo[i] = (__bf16)0.f; }
+    }
+    __bf16 *o = dst + b * dst_batch + (long long)t * dst_ld + c;
+    *reinterpret_cast<bf8 *>(o) = hi;                                        // A side [hi | lo | hi]
+    *reinterpret_cast<bf8 *>(o + seg_stride) = role == 0 ? lo : hi;          // B side [hi | hi | lo]
+    *reinterpret_cast<bf8 *>(o + 2 * seg_stride) = role == 0 ? hi : lo;
+}
+
 }  // namespace
 
 extern "C" {
@@ -186,6 +225,25 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
     hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), dcol, dx, B, t_out, t_in, C, taps, stride,
                        dil, pad);
+    return (int)hipGetLastError();
+}
+
+int pika_split_bf16x3(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
+                      int role, int layout, int Cp, void *dst, void *stream) {
+    if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
+    if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK) return PIKA_EINVAL;
+    if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
+        return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) return PIKA_EINVAL;
+    const long long rows = (long long)n_batch * t_in;
+    const long long n_gran = rows * (Cp >> 3);
+    if ((n_gran + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
+    long long seg_stride, dst_batch, dst_ld;
+    if (layout == PIKA_SPLIT_CONCAT) { dst_ld = 3LL * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
+    else { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n_gran + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, t_in, C, Cp, batch_stride, ld, role, seg_stride,
+                       dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
     return (int)hipGetLastError();
 }
 

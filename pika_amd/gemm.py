@@ -10,9 +10,15 @@ from . import _lib
 PIKA_F32, PIKA_BF16 = 0, 1
 RELU, ACCUMULATE, FP32SPLIT = 1, 2, 4
 
-# "bf16": one MFMA per product (config-2 arithmetic).  "fp32": hi/lo split, ~fp32 accuracy
-# (parity runs).  Overridable per call.
+# "bf16":   one MFMA per product (config-2 arithmetic).
+# "bf16x3": every fp32 operand as two bf16 terms, hi.hi + lo.hi + hi.lo as ONE bf16 product over a three times
+#           longer reduction (include/pika_ops.h: pika_split_bf16x3) -- ~1e-5 relative per product, on the
+#           direct-to-LDS kernels; tensors stay fp32 between products exactly as in the "fp32" mode.
+# "fp32":   exact three-term split, 6 MFMAs on the register-staged kernel (~1e-7; parity runs).
+# Overridable per call.
 PRECISION = os.environ.get("PIKA_GEMM_PRECISION", "bf16")
+PRECISIONS = ("bf16", "bf16x3", "fp32")
+BF16X3_STATS = {"fast": 0, "exact": 0}     # products taken by the split path / handed to the exact path (diagnostics)
 
 
 class Operand(ctypes.Structure):
@@ -59,9 +65,10 @@ def time_delay(x, taps, dil=1, stride=1, pad=0):
 
 def _flags(relu, accumulate, precision):
     p = precision or PRECISION
-    if p not in ("bf16", "fp32"):
+    if p not in PRECISIONS:
         raise ValueError("unknown GEMM precision %r" % (p,))
-    return (RELU if relu else 0) | (ACCUMULATE if accumulate else 0) | (FP32SPLIT if p == "fp32" else 0)
+    # "bf16x3" reaches here only for products its operand split does not take (launch): those run exactly
+    return (RELU if relu else 0) | (ACCUMULATE if accumulate else 0) | (FP32SPLIT if p != "bf16" else 0)
 
 
 OUT_BF16 = 8
@@ -79,10 +86,95 @@ def _workspace(device):
     return ws
 
 
+def _pad64(n):
+    return (n + 63) & ~63
+
+
+def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device):
+    """bf16 [hi|lo|hi] / [hi|hi|lo] copy of an f32 source (pika_split_bf16x3); returns the tensor (flat)."""
+    rows = n_batch * t_in
+    dst = torch.empty(3 * rows * Cp, dtype=torch.bfloat16, device=device)
+    rc = _lib.lib().pika_split_bf16x3(op.ptr, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, dst.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pika_split_bf16x3")
+    return dst
+
+
+def _plain(op, K):
+    return op.C >= K and op.pad == 0 and op.stride == 1
+
+
+def _bf16x3_operands(a_op, b_op, M, N, K, device):
+    """The two operands of a "bf16x3" product as bf16 operands over a reduction of three segments, or None when
+    the split does not apply (bf16 / batched / mixed-orientation operands, extents the 16-byte bf16 loads cannot
+    take): the caller then runs the exact path.  Returns (a3, b3, K3, keep-alive tensors)."""
+    if a_op.dtype != PIKA_F32 or b_op.dtype != PIKA_F32 or bool(a_op.trans) != bool(b_op.trans):
+        return None
+    if a_op.z_outer or a_op.z_inner or b_op.z_outer or b_op.z_inner:
+        return None
+    if not a_op.trans:
+        # reduction index contiguous: segments side by side inside every (tap) block of the reduction
+        if a_op.C < K and b_op.C < K:
+            return None
+        seg = min(a_op.C, b_op.C, K)
+        if seg & 7 or K % seg:
+            return None
+        taps, Cp = K // seg, _pad64(seg)
+        ops, keep = [], []
+        for op, extent, role in ((a_op, M, 0), (b_op, N, 1)):
+            if op.C < K or taps == 1:       # the time-delay view itself, or a plain matrix with one segment per row
+                nb = (extent + op.rows_per_batch - 1) // op.rows_per_batch
+                t = _split(op, nb, op.t_in, seg, op.batch_stride, op.ld, role, 0, Cp, device)
+                # one block: batch stride 0 like every plain matrix (the direct-to-LDS kernel bounds its 32-bit row
+                # offsets by rows_per_tile * pitch + batch stride)
+                new = Operand(t.data_ptr(), PIKA_BF16, op.rows_per_batch, op.t_in, op.t_in * 3 * Cp if nb > 1 else 0,
+                              3 * Cp, 3 * Cp, op.stride, op.dil, op.pad, 0, 0)
+                if op.C >= K:
+                    new.C = 3 * Cp * taps
+            else:                           # plain (rows, taps*seg) matrix against a time-delay view: per-tap segments
+                if op.ld != K or not _plain(op, K):
+                    return None
+                t = _split(op, 1, extent * taps, seg, 0, seg, role, 0, Cp, device)
+                rows = max(extent, 1)
+                new = Operand(t.data_ptr(), PIKA_BF16, rows, rows, 0, taps * 3 * Cp, taps * 3 * Cp, 1, 0, 0, 0, 0)
+            ops.append(new)
+            keep.append(t)
+        return ops[0], ops[1], taps * 3 * Cp, keep
+    # `trans` operands (dW = dY^T X): the reduction runs over the rows -> the three segments are stacked row blocks
+    ops, keep = [], []
+    for op, extent, role in ((a_op, M, 0), (b_op, N, 1)):
+        if op.C & 7 or extent & 7 or op.pad:
+            return None
+        nb = (K + op.rows_per_batch - 1) // op.rows_per_batch
+        if nb * op.rows_per_batch != K:
+            return None
+        t = _split(op, nb, op.t_in, op.C, op.batch_stride, op.ld, role, 1, op.C, device)
+        if nb == 1 and op.t_in == op.rows_per_batch:    # one block: the stack is one plain (3R, C) matrix
+            new = Operand(t.data_ptr(), PIKA_BF16, 3 * K, 3 * K, 0, op.C, op.C, op.stride, op.dil, 0, 0, 0)
+        else:
+            new = Operand(t.data_ptr(), PIKA_BF16, op.rows_per_batch, op.t_in, op.t_in * op.C, op.C, op.C,
+                          op.stride, op.dil, 0, 0, 0)
+        new.trans = 1
+        ops.append(new)
+        keep.append(t)
+    return ops[0], ops[1], 3 * K, keep
+
+
 def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=False, precision=None,
            batch=1, z_div=1, c_z_outer=0, c_z_inner=0):
     if not out.is_cuda:
         raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
+    keep = None
+    if (precision or PRECISION) == "bf16x3":
+        with torch.cuda.device(out.device):
+            sp = (_bf16x3_operands(a_op, b_op, M, N, K, out.device)
+                  if batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32 else None)
+        if sp is not None:
+            a_op, b_op, K, keep = sp        # `keep` holds the split copies until the launch below is enqueued
+            precision = "bf16"
+            BF16X3_STATS["fast"] += 1
+        else:
+            BF16X3_STATS["exact"] += 1
     with torch.cuda.device(out.device):
         ws = _workspace(out.device) if (a_op.trans and b_op.trans) else None
         rc = _lib.lib().pika_gemm_nt_ws(ctypes.byref(a_op), ctypes.byref(b_op), out.data_ptr(), ldc,

@@ -39,8 +39,8 @@ def _pad8(n):
 
 
 def _tdtype():
-    # transposed operands: bf16 halves their traffic; the fp32-split mode needs the fp32 bits
-    return torch.float32 if G.PRECISION == "fp32" else torch.bfloat16
+    # transposed operands: bf16 halves their traffic; the split modes ("fp32", "bf16x3") need the fp32 bits
+    return torch.bfloat16 if G.PRECISION == "bf16" else torch.float32
 
 
 def transpose_cast(op, rows, K, device):
@@ -305,7 +305,7 @@ class GateFn(torch.autograd.Function):
         e1, p1, eg, pg = [t.contiguous() for t in (e1, p1, eg, pg)]
         Bn, T, H = e1.shape
         U = p1.shape[1]
-        dt = torch.float32 if G.PRECISION == "fp32" else torch.bfloat16
+        dt = torch.bfloat16 if G.PRECISION == "bf16" else torch.float32
         h = torch.empty((Bn, T, U, H), dtype=dt, device=e1.device)
         with torch.cuda.device(e1.device):
             _lib.check(_lib.lib().pika_joint_gate_fwd(

@@ -430,3 +430,123 @@ def test_bf16_output_flag_on_the_generic_entry(hip_device):
     small = torch.empty(300, 200, dtype=torch.bfloat16, device=hip_device)
     with pytest.raises(RuntimeError):
         G.launch(G.matrix(a[:300])[0], G.matrix(b[:200])[0], small, 200, 300, 200, K)
+
+
+# ---- "bf16x3": two bf16 terms per fp32 operand, hi.hi + lo.hi + hi.lo as one bf16 product (pika_split_bf16x3) ----
+
+X3_TOL = 4e-5    # 2^-17 per operand + the dropped lo.lo term (2^-18), relative to sum |a||b|; fp32 accumulation on top
+
+
+def _x3_tol(K):
+    return X3_TOL + 2e-6 * max(1.0, K ** 0.5 / 8)
+
+
+def test_split_bf16x3_kernel_layouts(hip_device):
+    """pika_split_bf16x3: hi = bf16(x), lo = bf16(x - hi), both layouts, both roles, zero pad columns, batched source
+    with a pitch and a batch stride."""
+    from pika_amd import _lib
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(3)
+    nb, t_in, C, ld, Cp = 3, 7, 24, 40, 64
+    src = torch.randn(nb, t_in + 2, ld, generator=g).to(hip_device)        # batch stride (t_in+2)*ld, pitch ld
+    hi = src[:, :t_in, :C].bfloat16()
+    lo = (src[:, :t_in, :C] - hi.float()).bfloat16()
+    assert ((src[:, :t_in, :C] - hi.float() - lo.float()).abs() <= 2.0 ** -16 * src[:, :t_in, :C].abs()).all()
+    op = G.Operand(src.data_ptr(), G.PIKA_F32, t_in, t_in, (t_in + 2) * ld, ld, C, 1, 0, 0, 0, 0)
+    for role in (0, 1):
+        segs = (hi, lo, hi) if role == 0 else (hi, hi, lo)
+        cat = G._split(op, nb, t_in, C, (t_in + 2) * ld, ld, role, 0, Cp, hip_device).view(nb, t_in, 3, Cp)
+        stk = G._split(op, nb, t_in, C, (t_in + 2) * ld, ld, role, 1, C, hip_device).view(3, nb, t_in, C)
+        torch.cuda.synchronize()
+        for s in range(3):
+            assert torch.equal(cat[:, :, s, :C], segs[s]) and bool((cat[:, :, s, C:] == 0).all())
+            assert torch.equal(stk[s], segs[s])
+    with pytest.raises(RuntimeError):      # C % 8 != 0 is refused
+        G._split(op, nb, t_in, 20, (t_in + 2) * ld, ld, 0, 0, 64, hip_device)
+    with pytest.raises(RuntimeError):      # the stacked layout has no pad columns
+        _lib.check(_lib.lib().pika_split_bf16x3(src.data_ptr(), nb, t_in, C, (t_in + 2) * ld, ld, 0, 1, Cp,
+                                                src.data_ptr(), None), "pika_split_bf16x3")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (16, 16, 8), (300, 200, 64), (257, 136, 104), (1000, 5000, 1024),
+                                   (2048, 1024, 240), (4096, 2560, 1024), (5120, 1024, 5000), (200, 304, 8192)])
+def test_bf16x3_plain_nt(hip_device, M, N, K):
+    """Plain products in the bf16x3 mode (incl. sizes the direct-to-LDS kernel takes, a reduction that is padded per
+    segment: 240 -> 256, 5000 -> 5056) vs the fp64 product of the RAW fp32 operands."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = (torch.randn(M, K, generator=g) + 0.3 * torch.arange(K) / K).to(hip_device)
+    b = (torch.randn(N, K, generator=g) * (1 + torch.arange(N).unsqueeze(1) / N)).to(hip_device)
+    bias = torch.randn(N, generator=g).to(hip_device)
+    n0 = G.BF16X3_STATS["fast"]
+    out = G.gemm_nt(a, b, bias=bias, relu=True, precision="bf16x3")
+    assert G.BF16X3_STATS["fast"] == n0 + 1            # took the split path, not the exact fallback
+    e = (out.double() - ref(a, b, bias, relu=True)).abs() / err_scale(a, b)
+    assert e.max().item() < _x3_tol(K), e.max().item()
+    # and it IS more than one bf16 term: the one-term product misses the same bound by two orders of magnitude
+    e1 = (G.gemm_nt(a, b, bias=bias, relu=True, precision="bf16").double() - ref(a, b, bias, relu=True)).abs() / err_scale(a, b)
+    assert e1.max().item() > 20 * e.max().item()
+
+
+def test_bf16x3_falls_back_to_the_exact_path(hip_device):
+    """Operands the split cannot take (reduction not a multiple of 8, bf16 operands, batched products) run through
+    the exact three-term kernel: same accuracy class or better, never an error."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(130, 100, generator=g).to(hip_device)
+    b = torch.randn(90, 100, generator=g).to(hip_device)
+    n0 = G.BF16X3_STATS["exact"]
+    out = G.gemm_nt(a, b, precision="bf16x3")
+    assert G.BF16X3_STATS["exact"] == n0 + 1
+    assert ((out.double() - ref(a, b)).abs() / err_scale(a, b)).max() < 2e-6
+
+
+@pytest.mark.parametrize("taps,dil,stride,pad,Bn,T,C,N", [(3, 1, 1, 0, 3, 50, 64, 96), (3, 3, 1, 0, 3, 77, 32, 40),
+                                                         (3, 3, 4, 0, 3, 90, 64, 64), (5, 1, 1, 4, 3, 23, 16, 48),
+                                                         (3, 3, 1, 0, 8, 1100, 256, 512), (5, 1, 1, 4, 8, 1100, 256, 256)])
+def test_bf16x3_time_delay_forward_and_weight_gradient(hip_device, taps, dil, stride, pad, Bn, T, C, N):
+    """Time-delay operands in the bf16x3 mode: forward (per-tap segments on both sides) and the weight gradient with
+    both operands reduction-major (stacked segments; one of them the virtual view), vs fp64 im2col products."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(taps * 100 + dil * 10 + stride + T)
+    x = torch.randn(Bn, T, C, generator=g).to(hip_device)
+    w = torch.randn(N, taps * C, generator=g).to(hip_device)
+    a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
+    out = torch.empty(M, N, device=hip_device)
+    n0 = G.BF16X3_STATS["fast"]
+    G.launch(a_op, G.matrix(w)[0], out, N, M, N, K, precision="bf16x3")
+    xp = torch.nn.functional.pad(x, (0, 0, pad, 0))
+    cols = [xp[:, j * dil: j * dil + (t_out - 1) * stride + 1: stride, :] for j in range(taps)]
+    a = torch.cat(cols, -1).reshape(M, K)
+    assert ((out.double() - ref(a, w)).abs() / err_scale(a, w)).max() < _x3_tol(K)
+    assert G.BF16X3_STATS["fast"] == n0 + 1
+    if pad == 0:
+        dy = torch.randn(M, N, generator=g).to(hip_device)
+        a_op = G.time_delay(x, taps, dil, stride, pad)[0]
+        a_op.trans = 1
+        dy_op = G.matrix(dy)[0]
+        dy_op.trans = 1
+        dw = torch.empty(N, K, device=hip_device)
+        G.launch(dy_op, a_op, dw, K, N, K, M, precision="bf16x3")
+        assert G.BF16X3_STATS["fast"] == n0 + 2
+        want = dy.double().t() @ a.double()
+        assert ((dw.double() - want).abs() / (dy.double().abs().t() @ a.double().abs())).max() < _x3_tol(M)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 40), (304, 256, 1000), (1024, 3072, 5000)])
+def test_bf16x3_transposed_operands(hip_device, M, N, K):
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    at = (torch.randn(K, M, generator=g) + 0.2 * torch.arange(M) / M).to(hip_device)
+    bt = (torch.randn(K, N, generator=g) * (1 + torch.arange(K).unsqueeze(1) / K)).to(hip_device)
+    out = torch.empty(M, N, device=hip_device)
+    n0 = G.BF16X3_STATS["fast"]
+    G.launch(G.matrix_t(at)[0], G.matrix_t(bt)[0], out, N, M, N, K, precision="bf16x3")
+    assert G.BF16X3_STATS["fast"] == n0 + 1
+    want = at.double().t() @ bt.double()
+    scale = at.double().abs().t() @ bt.double().abs()
+    assert ((out.double() - want).abs() / scale).max().item() < _x3_tol(K)
+    # mixed orientation (A normal, B reduction-major) is not split: exact path
+    out2 = torch.empty(M, N, device=hip_device)
+    G.launch(G.matrix(at.t().contiguous())[0], G.matrix_t(bt)[0], out2, N, M, N, K, precision="bf16x3")
+    assert ((out2.double() - want).abs() / scale).max().item() < 2e-6 * max(1.0, K ** 0.5 / 8)

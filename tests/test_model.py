@@ -31,24 +31,38 @@ def close(a, b, rtol=1e-3, atol=1e-5):
     assert err <= rtol * scale + atol, "max err %g vs scale %g" % (err, scale)
 
 
-def run_parity(dec, device):
+def close_in_norm(a, b, rtol, floor):
+    """||a - b|| <= rtol * max(||b||, floor): the measure for gradients of a ReLU network under a different rounding of
+    the forward pass (a pre-activation within the forward error of zero flips its mask and changes ONE gradient path
+    outright: large in the max norm of a small tensor, small in the L2 norm)."""
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err, ref = np.linalg.norm(a - b), max(np.linalg.norm(b), floor)
+    assert err <= rtol * ref, "||err|| %g vs ||ref|| %g" % (err, ref)
+
+
+def run_parity(dec, device, act_rtol=1e-3, grad_norm_rtol=None):
     z = np.load(os.path.join(HERE, "golden", "model_tiny_%s.npz" % dec))
     net = ours(dec, device)
     x, y, y_len, w = [t.to(device) for t in C.inputs()]
     net.eval()
     with torch.no_grad():
-        close(net.encoder(x), z["enc_eval"])
+        close(net.encoder(x), z["enc_eval"], rtol=act_rtol)
         sos = torch.zeros(C.B, 1, dtype=torch.long, device=device)
-        close(net.predict(torch.cat((sos, y), 1)), z["pred_eval"])
-        close(net(x, y, None, True), z["joint_eval"])
-        close(net(x, y, None, False), z["joint_eval_nosm"])
+        close(net.predict(torch.cat((sos, y), 1)), z["pred_eval"], rtol=act_rtol)
+        close(net(x, y, None, True), z["joint_eval"], rtol=act_rtol)
+        close(net(x, y, None, False), z["joint_eval_nosm"], rtol=act_rtol)
     net.train()
     lp = net(x, y, None, True)
-    close(lp, z["joint_train"])
+    close(lp, z["joint_train"], rtol=act_rtol)
     (lp * w).sum().backward()
     params = dict(net.named_parameters())
+    gscale = max(float(np.linalg.norm(z["grad:" + str(k)])) for k in z["grad_keys"])
     for k in z["grad_keys"]:
-        close(params[str(k)].grad, z["grad:" + str(k)], rtol=1e-3, atol=1e-5)
+        if grad_norm_rtol is None:
+            close(params[str(k)].grad, z["grad:" + str(k)], rtol=1e-3, atol=1e-5)
+        else:
+            close_in_norm(params[str(k)].grad, z["grad:" + str(k)], grad_norm_rtol, 1e-3 * gscale)
     close(net.encoder.bn_in.running_mean, z["bn_in_running_mean_after"])
     close(net.encoder.bn_final.running_var, z["bn_final_running_var_after"])
 
@@ -88,14 +102,27 @@ def test_full_size_parameter_count_and_pickle_roundtrip(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("dec", ["transformer", "rnn"])
-def test_gpu_matches_reference_golden(hip_device, dec):
-    """fp32-parity arithmetic (fp32-split split MFMA): 1e-3 rel, the north_star tolerance."""
+def test_gpu_matches_reference_golden(hip_device, dec, mode):
+    """The two arithmetic modes that carry the north_star tolerance (activations and loss within 1e-3 rel of the
+    reference's fp32): "fp32" (exact three-term split, 6 MFMAs: activations AND every recorded gradient at 1e-3, measured
+    1e-6) and "bf16x3" (two terms per operand, one bf16 product over a three times longer reduction on the
+    direct-to-LDS kernels: activations held to 1e-4 here, measured 1.4e-5).  Gradients in the second mode: products are
+    accurate to 1e-5, but a forward pass that differs by 1e-5 flips the ReLU mask of the few pre-activations that close
+    to zero, and each flip changes one gradient path outright -- 1e-2 in the max norm of a (64, 240) tensor from ONE
+    element; tools/precision_table.py shows the exact mode doing the same under a 1e-5 input perturbation.  So they are
+    held in the L2 norm."""
     from pika_amd import gemm as G
     old = G.PRECISION
-    G.PRECISION = "fp32"
+    G.PRECISION = mode
     try:
-        run_parity(dec, hip_device)
+        n0 = G.BF16X3_STATS["fast"]
+        if mode == "fp32":
+            run_parity(dec, hip_device)
+        else:
+            run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=3e-2)
+            assert G.BF16X3_STATS["fast"] > n0 + 20
     finally:
         G.PRECISION = old
 
