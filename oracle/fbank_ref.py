@@ -9,7 +9,11 @@ loader/otf_utt_loader.py:213-250.
   snip-edges framing (25 ms / 10 ms), optional dither, DC removal, pre-emphasis 0.97, Hamming
   window, zero-pad to 512, power spectrum, 80 triangular mel bins on [40, 7800] Hz over FFT bins
   0..255, floor at FLT_EPSILON, log.  float64 internally (truth); dither=0 for parity runs
-  (the recipe's dither=1 makes the reference itself non-deterministic).
+  (the recipe's dither=1 makes the reference itself non-deterministic).  Cross-checked (tests/
+  test_fbank_crosscheck.py) against an independent published implementation of the same Kaldi algorithm,
+  transformers.audio_utils (mel_scale="kaldi", triangularize_in_mel_space): agreement to 1e-7 on the log-mel
+  values for noise / tone / chirp / near-silent / one-frame inputs and two bank layouts.  That is a second
+  witness, not the reference's own PyKaldi build, so the row stays formally unpinned.
 * `change_speed` / `normalize` / `to_int16`: restated from loader/audio.py:217-262,551-603 and
   cross-checked against the reference class itself in tests/golden/make_audio_golden.py.
 * `splice`: loader/otf_utt_loader.py:28-46.
