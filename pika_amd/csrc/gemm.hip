@@ -397,7 +397,9 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     const int tiles = ((N + CF::BN - 1) / CF::BN) * ((M + CF::BM - 1) / CF::BM);
     const int nk = (K + CF::BK - 1) / CF::BK;
     int splitk = 1;
-    if (batch == 1 && tiles < 256 && nk >= 32 && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
+    static const int min_nk = [] { const char *e = getenv("PIKA_GEMM_SPLIT_MIN_NK"); return e ? atoi(e) : 32; }();
+    static const int per_split = [] { const char *e = getenv("PIKA_GEMM_SPLIT_MIN_PER"); return e ? atoi(e) : 8; }();
+    if (batch == 1 && tiles < 256 && nk >= min_nk && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
         // One resident workgroup per CU.  Cost of split s in K-tile units: rounds of 256 workgroups x
         // (K-tiles per workgroup + ~40 of prologue/epilogue) + ~6 per atomic pass over C; the minimum
         // reproduces the measured optimum on every shape of tools/dw_bench.py
@@ -407,12 +409,12 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
             splitk = (target + tiles - 1) / tiles;
         } else {
             long long best = -1;
-            for (int sp = 1; sp <= 64 && sp <= nk / 8; ++sp) {
+            for (int sp = 1; sp <= 64 && sp <= nk / per_split; ++sp) {
                 const long long cost = (long long)((tiles * sp + 255) / 256) * ((nk + sp - 1) / sp + 40) + 6LL * sp;
                 if (best < 0 || cost < best) { best = cost; splitk = sp; }
             }
         }
-        if (splitk > nk / 8) splitk = nk / 8;
+        if (splitk > nk / per_split) splitk = nk / per_split;
         if (splitk > 64) splitk = 64;
         if (splitk < 1) splitk = 1;
     }
@@ -448,6 +450,8 @@ int dispatch(const pika_operand_t *A, const pika_operand_t *B, float *C, long lo
             return PIKA_EINVAL;
     }
     if constexpr (TRA || TRB) {
+        static const int tcfg = [] { const char *e = getenv("PIKA_GEMM_CFG_T"); return e ? atoi(e) : -1; }();
+        if (tcfg == 1) return launch<TA, TB, 1, Cfg<2, 2, 64>, TRA, TRB>(ARGS);
         return launch<TA, TB, 1, Cfg<4, 2, 64>, TRA, TRB>(ARGS);
     } else {
         // measured on MI355X (tools/gemm_bench.py, profiles/r1_gemm_cfg_sweep.txt): 256x128x64 / 8

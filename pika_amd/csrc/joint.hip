@@ -12,19 +12,34 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline float fast_tanh(float x) {
-    // 1 - 2/(e^{2x}+1): exact limits at +-inf, abs error ~1e-7
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+// tanh(z1) and sigmoid(zg) of one element with TWO exponentials and ONE reciprocal (the kernels below are bound by
+// the transcendental pipe: 400 M elements per pass at config 2):
+//   e = exp(2 z1), f = exp(-zg), r = 1 / ((e + 1)(1 + f))
+//   sigmoid = (e + 1) r,   1 - tanh = 2 (1 + f) r =: q,   1 - sigmoid = f (e + 1) r =: ns
+// q and ns carry no cancellation, so the backward factors (1 - tanh^2) = q (2 - q) and sigmoid (1 - sigmoid) keep their
+// relative accuracy in the saturated tails.  The clamps keep the product below FLT_MAX; tanh(+-15) is +-1 in fp32
+// and sigmoid(-50) = 2e-22.
+struct GateVals { float th, sg, q, ns; };
+__device__ inline GateVals gate_vals(float z1, float zg) {
+    z1 = fminf(fmaxf(z1, -15.f), 15.f);
+    zg = fmaxf(zg, -50.f);
+    const float e1 = __expf(2.0f * z1) + 1.0f, f = __expf(-zg), f1 = 1.0f + f;
+    const float r = __builtin_amdgcn_rcpf(e1 * f1);
+    GateVals v;
+    v.sg = e1 * r;
+    v.q = 2.0f * f1 * r;
+    v.th = 1.0f - v.q;
+    v.ns = f * v.sg;
+    return v;
 }
-__device__ inline float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ inline f32x4 gate4(f32x4 z1, f32x4 zg) {
     f32x4 r;
-    r.x = fast_tanh(z1.x) * fast_sigmoid(zg.x);
-    r.y = fast_tanh(z1.y) * fast_sigmoid(zg.y);
-    r.z = fast_tanh(z1.z) * fast_sigmoid(zg.z);
-    r.w = fast_tanh(z1.w) * fast_sigmoid(zg.w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const GateVals v = gate_vals(z1[i], zg[i]);
+        r[i] = v.th * v.sg;
+    }
     return r;
 }
 
@@ -52,9 +67,10 @@ __global__ void gate_fwd_kernel(const float *__restrict__ e1, const float *__res
 }
 
 __device__ inline void gate_grads(float z1, float zg, float dh, float &d1, float &dg) {
-    const float th = fast_tanh(z1), sg = fast_sigmoid(zg);
-    d1 = dh * sg * (1.0f - th * th);
-    dg = dh * th * sg * (1.0f - sg);
+    const GateVals v = gate_vals(z1, zg);
+    const float ds = dh * v.sg;
+    d1 = ds * v.q * (2.0f - v.q);      // sigmoid * (1 - tanh^2)
+    dg = ds * v.th * v.ns;             // tanh * sigmoid * (1 - sigmoid)
 }
 
 // REDUCE_U: grid (T,B): sums over u -> de1/deg[b,t,:].  else grid (U,B): sums over t -> dp1/dpg.

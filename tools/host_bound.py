@@ -1,0 +1,44 @@
+"""Is the eager train step host-bound?  Times K steps of bench.py's train-step workload twice: until the host has
+enqueued them (no sync) and until the device has finished; then a cProfile of 5 steps (top by own time).
+    python tools/host_bound.py [--profile]"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+import bench  # noqa: E402
+
+args = SimpleNamespace(batch=32, frames=1000, labels=50, vocab=5000)
+R_ = bench.Ranks(False)
+step, _ = bench.train_step_workload(args, R_)
+try:
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    K = 10
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("host enqueue %.2f ms/step, device done %.2f ms/step  (host-bound if the two are close)" % (
+        (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3), flush=True)
+    if "--profile" in sys.argv:
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        st = pstats.Stats(pr)
+        st.sort_stats("tottime").print_stats(45)
+finally:
+    step.close()
