@@ -666,7 +666,9 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
         "metric": "decode RTF (wall / audio seconds), batch beam search", "value": el / audio_s,
         "unit": "RTF", "n_gpus": world, "steps": 2, "warmup": 1,
         "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (3-term bf16 split on MFMA)" if step.decoder.decode_precision == "fp32" else "bf16",
+        "vs_baseline": None, "dtype": {"fp32": "f32 (3-term bf16 split on MFMA)",
+                                       "bf16x3": "f32 (encoder: 2 bf16 terms per operand; step GEMMs: 3-term split)"}.get(
+                                           step.decoder.decode_precision, "bf16"),
         "data": "synthetic",
         "config": {"workload": "decode (BASELINE configs[4]): B=%d beam=%d n_best=%d, %d-frame utterances, full model "
                                "(%s prediction net), sm_scale 0.8%s%s; each rank decodes its own batch (replicas)" % (

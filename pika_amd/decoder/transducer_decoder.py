@@ -54,13 +54,15 @@ class TransducerDecoder(object):
         import os
         self.fused_search = os.environ.get("PIKA_DECODE_FUSED_SEARCH", "1") != "0"
         # decode_precision "fp32" (default): encoder, joint halves and every step GEMM with fp32-exact products --
-        # what "hypotheses identical to the reference's fp32 decoder" needs; "bf16": plain bf16 operands
+        # what "hypotheses identical to the reference's fp32 decoder" needs; "bf16x3": the encoder and the joint halves
+        # (the only large products of a decode) with two bf16 terms per operand on the direct-to-LDS kernels (1e-5),
+        # the step GEMMs still exact; "bf16": plain bf16 operands everywhere
         self.decode_precision = os.environ.get("PIKA_DECODE_PRECISION", "fp32")
         self.replays_per_sync = 4
 
     @property
     def decode_terms(self):
-        return 3 if self.decode_precision == "fp32" else 1
+        return 1 if self.decode_precision == "bf16" else 3
 
     # ---- prediction network stepping (fixed shapes: every row is recomputed, rows whose last
     # symbol is not a label keep their state; transducer_decoder.py:139-171) ---------------------
@@ -101,7 +103,7 @@ class TransducerDecoder(object):
     def decode_batch(self, x, x_len, max_len=None):
         from .. import gemm as G
         old = G.PRECISION
-        if x.is_cuda and self.decode_precision in ("fp32", "bf16"):
+        if x.is_cuda and self.decode_precision in ("fp32", "bf16x3", "bf16"):
             G.PRECISION = self.decode_precision
         try:
             return self._decode_batch(x, x_len, max_len)

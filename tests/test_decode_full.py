@@ -42,7 +42,7 @@ def same_entry(got, z, b, j, k=None):
     return int(got["lens"][b, k]) == L and np.array_equal(got["hyps"][b, k, :L], z["hyps"][b, j, :L])
 
 
-def check(got, enc, z, enc_tol, exact):
+def check(got, enc, z, enc_tol, exact, ranks=True):
     """exact: every list identical (CPU: same fp32 library arithmetic as the reference run).  Otherwise (GPU): scores
     are sums of ~150 log-probs of |logit| ~ 30 taken from K = 1024 fp32 accumulations in a different order than the
     CPU GEMM -- 1e-4-level noise per score -- so entries whose reference score is closer than `gap` to a neighbour
@@ -65,10 +65,11 @@ def check(got, enc, z, enc_tol, exact):
             same = same_entry(got, z, b, j)
             n_same += int(same)
             n_sep += int(sep)
-            assert same or not sep, "utterance %d rank %d: separated by > %g from its neighbours but differs" % (b, j, gap)
-            if same:
+            assert same or not sep or not ranks, \
+                "utterance %d rank %d: separated by > %g from its neighbours but differs" % (b, j, gap)
+            if same and ranks:
                 assert abs(got["scores"][b, j] - sc[j]) < 2e-3
-    assert n_same >= 0.85 * B * nb, (n_same, B * nb)
+    assert n_same >= (0.85 if ranks else 0.6) * B * nb, (n_same, B * nb)
     return rel, n_same / float(B * nb)
 
 
@@ -86,6 +87,13 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
     print("fp32-exact mode: encoder output max rel err %.2e; top-1 identical for all %d utterances; %.0f %% of the %d "
           "n-best entries at the reference rank, the rest are swaps among entries < 1e-3 apart in score; max |score "
           "diff| %.2e" % (rel, F.B, 100 * frac, F.B * F.BEAM, float(np.abs(got["scores"] - z["scores"]).max())))
+    # two-term encoder (1e-5 products on the direct-to-LDS kernels, 13 % faster decode), exact step GEMMs: the top-1
+    # hypotheses must still be the reference's; deeper ranks are reported -- an encoder output that differs by 5e-5
+    # moves scores by more than the 1e-3 separation the strict criterion allows, which is why "fp32" stays the default
+    got3, enc3, _ = decode(hip_device, "bf16x3")
+    rel3, frac3 = check(got3, enc3, z, 1e-3, exact=False, ranks=False)
+    print("bf16x3 mode: encoder output max rel err %.2e; top-1 identical for all %d utterances; %.0f %% of the n-best "
+          "entries at the reference rank" % (rel3, F.B, 100 * frac3))
     # bf16 operands: how far the same search drifts (reported; near-ties may flip)
     got16, enc16, _ = decode(hip_device, "bf16")
     es = enc16[:, ::7, ::37].float().cpu().numpy()
