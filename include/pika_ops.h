@@ -30,23 +30,27 @@ int pika_colsum_bf16(const void *x, long long ld, int rows, int cols, float *out
 int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C, int taps,
                 int stride, int dil, int pad, void *stream);
 
-/* Two-term bf16 split of an f32 operand for "bf16x3" products: x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi),
- * |r| <= 2^-17 |x|.  A product A B^T of two such operands is taken as hi.hi + lo.hi + hi.lo (the dropped lo.lo term
- * is below 2^-16 of the leading one) by ONE bf16 GEMM over a three times longer reduction: the A side lays its
- * segments out as [hi | lo | hi], the B side as [hi | hi | lo]  (role 0 / 1).  This gives products accurate to
- * ~1e-5 relative -- inside the 1e-3 the parity statement of the training path asks for -- on the direct-to-LDS
- * bf16 kernels at a third of their rate, instead of the exact 6-MFMA PIKA_GEMM_FP32SPLIT path at a sixth of the
- * register-staged kernel's.
- * Source: n_batch blocks (batch_stride apart) of t_in rows (pitch ld) x C columns, f32, C % 8 == 0.
- *   PIKA_SPLIT_CONCAT: dst (n_batch, t_in, 3*Cp) bf16, segment s of a row at columns [s*Cp, s*Cp + C), the pad
+/* bf16 term split of an f32 operand for K-concatenated products on the bf16 kernels:
+ *   t0 = bf16(x), t1 = bf16(x - t0), t2 = bf16(x - t0 - t1)      (x = t0 + t1 + t2 exactly: 8 + 8 + 8 mantissa bits)
+ * A product A B^T of two split operands is taken by ONE bf16 GEMM over a longer reduction whose segments pair the
+ * terms to keep.  The A side (role 0) and the B side (role 1) lay their segments out as
+ *   n_terms = 2 ("bf16x3"):   A [t0 | t1 | t0]                 B [t0 | t0 | t1]
+ *       -> t0.t0 + t1.t0 + t0.t1; the dropped t1.t1 is below 2^-16 of the leading product: ~1e-5 relative, inside
+ *       the 1e-3 the parity statement of the training path asks for, at a third of the bf16 rate;
+ *   n_terms = 3 (fp32-exact):  A [t0 | t0 | t1 | t0 | t2 | t1]   B [t0 | t1 | t0 | t2 | t0 | t1]
+ *       -> the six products PIKA_GEMM_FP32SPLIT issues (everything above 2^-24 of the leading one), at a sixth of
+ *       the bf16 rate of the direct-to-LDS kernels instead of a sixth of the register-staged kernel's.
+ * Source: n_batch blocks (batch_stride apart) of t_in rows (pitch ld) x C columns, f32, C % 8 == 0.  S = 3 or 6
+ * segments.
+ *   PIKA_SPLIT_CONCAT: dst (n_batch, t_in, S*Cp) bf16, segment s of a row at columns [s*Cp, s*Cp + C), the pad
  *       columns up to Cp zero (Cp >= C, Cp % 8 == 0; Cp % 64 == 0 keeps the direct-to-LDS kernels applicable):
- *       for operands whose reduction index is the contiguous one; a time-delay view over dst has 3*Cp channels.
- *   PIKA_SPLIT_STACK: dst (3, n_batch, t_in, C) bf16, segment s = block s: for `trans` operands, whose reduction
+ *       for operands whose reduction index is the contiguous one; a time-delay view over dst has S*Cp channels.
+ *   PIKA_SPLIT_STACK: dst (S, n_batch, t_in, C) bf16, segment s = block s: for `trans` operands, whose reduction
  *       runs over the rows (Cp must equal C). */
 #define PIKA_SPLIT_CONCAT 0
 #define PIKA_SPLIT_STACK 1
-int pika_split_bf16x3(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
-                      int role, int layout, int Cp, void *dst, void *stream);
+int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
+                          int role, int n_terms, int layout, int Cp, void *dst, void *stream);
 
 #ifdef __cplusplus
 }

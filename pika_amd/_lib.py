@@ -53,7 +53,7 @@ SIGNATURES = {
     "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "pika_colsum_bf16": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "pika_split_bf16x3": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _vp, _vp]),
+    "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
     # include/pika_joint.h
     "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pika_joint_gate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i, _i, _i, _i, _vp]),

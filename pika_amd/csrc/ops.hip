@@ -148,15 +148,17 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ d
 }
 
 
-// Two-term bf16 split of an f32 operand for the "bf16x3" products (include/pika_ops.h): every thread takes 8
-// consecutive source columns (two 16-byte loads) and writes the three 16-byte segments of its granule.
-// seg_stride = elements between the three segments of one source element, blk = destination elements per source
-// row-block; pad columns [C, Cp) of the concat layout are zero-filled by the threads that own them.
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ x, int t_in, int C, int Cp,
-                                                           long long batch_stride, long long ld, int role,
-                                                           long long seg_stride, long long dst_batch,
-                                                           long long dst_ld, long long n_gran,
-                                                           __bf16 *__restrict__ dst) {
+// bf16 term split of an f32 operand for the K-concatenated products (include/pika_ops.h): every thread takes 8
+// consecutive source columns (two 16-byte loads), computes the terms t0 = bf16(x), t1 = bf16(x - t0),
+// t2 = bf16(x - t0 - t1) (exact: 8 + 8 + 8 mantissa bits) and writes the NSEG 16-byte segments of its granule, segment s
+// holding term (pattern >> 2s) & 3.  seg_stride = elements between consecutive segments of one source element; pad
+// columns [C, Cp) of the concat layout are zero-filled by the threads that own them.
+template <int NSEG>
+__global__ __launch_bounds__(256) void split_terms_kernel(const float *__restrict__ x, int t_in, int C, int Cp,
+                                                          long long batch_stride, long long ld, unsigned pattern,
+                                                          long long seg_stride, long long dst_batch,
+                                                          long long dst_ld, long long n_gran,
+                                                          __bf16 *__restrict__ dst) {
     typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_gran) return;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
     const int c = (int)(g - row * gpr) << 3;
     const long long b = row / t_in;
     const int t = (int)(row - b * t_in);
-    bf8 hi, lo;
+    bf8 term[3];
     if (c < C) {                                   // C % 8 == 0: a granule is all source or all padding
         const float4 *src = reinterpret_cast<const float4 *>(x + b * batch_stride + (long long)t * ld + c);
         const float4 v0 = src[0], v1 = src[1];
@@ -173,17 +175,24 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restri
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const __bf16 h = (__bf16)v[i];
-            hi[i] = h;
-            lo[i] = (__bf16)(v[i] - (float)h);     // exact in fp32; the second term carries bits 9..16
+            const float r1 = v[i] - (float)h;      // exact in fp32
+            const __bf16 m = (__bf16)r1;
+            term[0][i] = h;
+            term[1][i] = m;
+            term[2][i] = (__bf16)(r1 - (float)m);  // exact: what is left fits 8 bits
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { hi[i] = (__bf16)0.f; lo[i] = (__bf16)0.f; }
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) term[k][i] = (__bf16)0.f;
     }
     __bf16 *o = dst + b * dst_batch + (long long)t * dst_ld + c;
-    *reinterpret_cast<bf8 *>(o) = hi;                                        // A side [hi | lo | hi]
-    *reinterpret_cast<bf8 *>(o + seg_stride) = role == 0 ? lo : hi;          // B side [hi | hi | lo]
-    *reinterpret_cast<bf8 *>(o + 2 * seg_stride) = role == 0 ? hi : lo;
+#pragma unroll
+    for (int s2 = 0; s2 < NSEG; ++s2) {
+        const unsigned k = (pattern >> (2 * s2)) & 3u;
+        *reinterpret_cast<bf8 *>(o + s2 * seg_stride) = k == 0 ? term[0] : (k == 1 ? term[1] : term[2]);
+    }
 }
 
 }  // namespace
@@ -228,9 +237,10 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
     return (int)hipGetLastError();
 }
 
-int pika_split_bf16x3(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
-                      int role, int layout, int Cp, void *dst, void *stream) {
+int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
+                          int role, int n_terms, int layout, int Cp, void *dst, void *stream) {
     if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
+    if (n_terms != 2 && n_terms != 3) return PIKA_EINVAL;
     if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK) return PIKA_EINVAL;
     if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
         return PIKA_EINVAL;
@@ -238,12 +248,24 @@ int pika_split_bf16x3(const float *x, int n_batch, int t_in, int C, long long ba
     const long long rows = (long long)n_batch * t_in;
     const long long n_gran = rows * (Cp >> 3);
     if ((n_gran + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
+    const int nseg = n_terms == 2 ? 3 : 6;
     long long seg_stride, dst_batch, dst_ld;
-    if (layout == PIKA_SPLIT_CONCAT) { dst_ld = 3LL * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
+    if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
     else { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n_gran + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, t_in, C, Cp, batch_stride, ld, role, seg_stride,
-                       dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
+    // term index per segment, two bits each (segment 0 in the low bits); the pairs (A side, B side) of one segment
+    // are the products kept: two terms  h.h + l.h + h.l;  three terms  h.h + h.m + m.h + h.l + l.h + m.m
+    static const unsigned pat[2][2] = {{0u | 1u << 2 | 0u << 4, 0u | 0u << 2 | 1u << 4},
+                                       {0u | 0u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 1u << 10,
+                                        0u | 1u << 2 | 0u << 4 | 2u << 6 | 0u << 8 | 1u << 10}};
+    const unsigned pattern = pat[n_terms - 2][role];
+    const dim3 grid((unsigned)((n_gran + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nseg == 3)
+        hipLaunchKernelGGL(split_terms_kernel<3>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
+                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
+    else
+        hipLaunchKernelGGL(split_terms_kernel<6>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
+                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
     return (int)hipGetLastError();
 }
 

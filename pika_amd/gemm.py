@@ -12,13 +12,16 @@ RELU, ACCUMULATE, FP32SPLIT = 1, 2, 4
 
 # "bf16":   one MFMA per product (config-2 arithmetic).
 # "bf16x3": every fp32 operand as two bf16 terms, hi.hi + lo.hi + hi.lo as ONE bf16 product over a three times
-#           longer reduction (include/pika_ops.h: pika_split_bf16x3) -- ~1e-5 relative per product, on the
+#           longer reduction (include/pika_ops.h: pika_split_bf16_terms) -- ~1e-5 relative per product, on the
 #           direct-to-LDS kernels; tensors stay fp32 between products exactly as in the "fp32" mode.
-# "fp32":   exact three-term split, 6 MFMAs on the register-staged kernel (~1e-7; parity runs).
+# "fp32":   exact three-term split, the six products above 2^-24 of the leading one (~1e-7; parity runs, decode):
+#           products large enough for the direct-to-LDS kernels take the same K-concatenation with six segments,
+#           everything else the register-staged kernel that issues the 6 MFMAs per loaded tile.
 # Overridable per call.
 PRECISION = os.environ.get("PIKA_GEMM_PRECISION", "bf16")
 PRECISIONS = ("bf16", "bf16x3", "fp32")
-BF16X3_STATS = {"fast": 0, "exact": 0}     # products taken by the split path / handed to the exact path (diagnostics)
+BF16X3_STATS = {"fast": 0, "exact": 0}     # "bf16x3" products taken by the split path / handed to the exact path
+FP32_STATS = {"concat": 0, "staged": 0}    # "fp32" products on the six-segment path / on the register-staged kernel
 
 
 class Operand(ctypes.Structure):
@@ -72,6 +75,10 @@ def _flags(relu, accumulate, precision):
 
 
 OUT_BF16 = 8
+# "fp32" products of direct-to-LDS size as ONE bf16 product over six term segments (PIKA_FP32_CONCAT=0: always the
+# register-staged exact kernel)
+FP32_CONCAT = os.environ.get("PIKA_FP32_CONCAT", "1") != "0"
+FP32_CONCAT_MAX_BYTES = 4 << 30     # per operand copy: 6 segments x 2 bytes x rows x reduction
 
 
 _WORKSPACE = {}
@@ -90,13 +97,15 @@ def _pad64(n):
     return (n + 63) & ~63
 
 
-def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device):
-    """bf16 [hi|lo|hi] / [hi|hi|lo] copy of an f32 source (pika_split_bf16x3); returns the tensor (flat)."""
+def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_terms=2):
+    """bf16 term-segment copy of an f32 source (pika_split_bf16_terms: 3 segments for two terms, 6 for three);
+    returns the tensor (flat)."""
     rows = n_batch * t_in
-    dst = torch.empty(3 * rows * Cp, dtype=torch.bfloat16, device=device)
-    rc = _lib.lib().pika_split_bf16x3(op.ptr, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, dst.data_ptr(),
-                                      torch.cuda.current_stream().cuda_stream)
-    _lib.check(rc, "pika_split_bf16x3")
+    nseg = 3 if n_terms == 2 else 6
+    dst = torch.empty(nseg * rows * Cp, dtype=torch.bfloat16, device=device)
+    rc = _lib.lib().pika_split_bf16_terms(op.ptr, n_batch, t_in, C, batch_stride, ld, role, n_terms, layout, Cp,
+                                          dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pika_split_bf16_terms")
     return dst
 
 
@@ -104,10 +113,18 @@ def _plain(op, K):
     return op.C >= K and op.pad == 0 and op.stride == 1
 
 
-def _bf16x3_operands(a_op, b_op, M, N, K, device):
-    """The two operands of a "bf16x3" product as bf16 operands over a reduction of three segments, or None when
-    the split does not apply (bf16 / batched / mixed-orientation operands, extents the 16-byte bf16 loads cannot
-    take): the caller then runs the exact path.  Returns (a3, b3, K3, keep-alive tensors)."""
+def _direct_to_lds_size(trans, M, N, K):
+    """The size gates of the direct-to-LDS kernels (gemm_glds.hip: pika_internal_gemm_pp / launch_pp_tn)."""
+    if trans:
+        return M >= 192 and N >= 192 and K >= 512
+    return M >= 256 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= 160
+
+
+def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):
+    """The two operands of a K-concatenated product as bf16 operands over a reduction of S = 3 (two terms) or 6 (three
+    terms) segments, or None when the split does not apply (bf16 / batched / mixed-orientation operands, extents the
+    16-byte bf16 loads cannot take): the caller then runs the exact path.  Returns (a3, b3, K3, keep-alive tensors)."""
+    S = 3 if n_terms == 2 else 6
     if a_op.dtype != PIKA_F32 or b_op.dtype != PIKA_F32 or bool(a_op.trans) != bool(b_op.trans):
         return None
     if a_op.z_outer or a_op.z_inner or b_op.z_outer or b_op.z_inner:
@@ -124,22 +141,22 @@ def _bf16x3_operands(a_op, b_op, M, N, K, device):
         for op, extent, role in ((a_op, M, 0), (b_op, N, 1)):
             if op.C < K or taps == 1:       # the time-delay view itself, or a plain matrix with one segment per row
                 nb = (extent + op.rows_per_batch - 1) // op.rows_per_batch
-                t = _split(op, nb, op.t_in, seg, op.batch_stride, op.ld, role, 0, Cp, device)
+                t = _split(op, nb, op.t_in, seg, op.batch_stride, op.ld, role, 0, Cp, device, n_terms)
                 # one block: batch stride 0 like every plain matrix (the direct-to-LDS kernel bounds its 32-bit row
                 # offsets by rows_per_tile * pitch + batch stride)
-                new = Operand(t.data_ptr(), PIKA_BF16, op.rows_per_batch, op.t_in, op.t_in * 3 * Cp if nb > 1 else 0,
-                              3 * Cp, 3 * Cp, op.stride, op.dil, op.pad, 0, 0)
+                new = Operand(t.data_ptr(), PIKA_BF16, op.rows_per_batch, op.t_in, op.t_in * S * Cp if nb > 1 else 0,
+                              S * Cp, S * Cp, op.stride, op.dil, op.pad, 0, 0)
                 if op.C >= K:
-                    new.C = 3 * Cp * taps
+                    new.C = S * Cp * taps
             else:                           # plain (rows, taps*seg) matrix against a time-delay view: per-tap segments
                 if op.ld != K or not _plain(op, K):
                     return None
-                t = _split(op, 1, extent * taps, seg, 0, seg, role, 0, Cp, device)
+                t = _split(op, 1, extent * taps, seg, 0, seg, role, 0, Cp, device, n_terms)
                 rows = max(extent, 1)
-                new = Operand(t.data_ptr(), PIKA_BF16, rows, rows, 0, taps * 3 * Cp, taps * 3 * Cp, 1, 0, 0, 0, 0)
+                new = Operand(t.data_ptr(), PIKA_BF16, rows, rows, 0, taps * S * Cp, taps * S * Cp, 1, 0, 0, 0, 0)
             ops.append(new)
             keep.append(t)
-        return ops[0], ops[1], taps * 3 * Cp, keep
+        return ops[0], ops[1], taps * S * Cp, keep
     # `trans` operands (dW = dY^T X): the reduction runs over the rows -> the three segments are stacked row blocks
     ops, keep = [], []
     for op, extent, role in ((a_op, M, 0), (b_op, N, 1)):
@@ -148,16 +165,16 @@ def _bf16x3_operands(a_op, b_op, M, N, K, device):
         nb = (K + op.rows_per_batch - 1) // op.rows_per_batch
         if nb * op.rows_per_batch != K:
             return None
-        t = _split(op, nb, op.t_in, op.C, op.batch_stride, op.ld, role, 1, op.C, device)
-        if nb == 1 and op.t_in == op.rows_per_batch:    # one block: the stack is one plain (3R, C) matrix
-            new = Operand(t.data_ptr(), PIKA_BF16, 3 * K, 3 * K, 0, op.C, op.C, op.stride, op.dil, 0, 0, 0)
+        t = _split(op, nb, op.t_in, op.C, op.batch_stride, op.ld, role, 1, op.C, device, n_terms)
+        if nb == 1 and op.t_in == op.rows_per_batch:    # one block: the stack is one plain (S*R, C) matrix
+            new = Operand(t.data_ptr(), PIKA_BF16, S * K, S * K, 0, op.C, op.C, op.stride, op.dil, 0, 0, 0)
         else:
             new = Operand(t.data_ptr(), PIKA_BF16, op.rows_per_batch, op.t_in, op.t_in * op.C, op.C, op.C,
                           op.stride, op.dil, 0, 0, 0)
         new.trans = 1
         ops.append(new)
         keep.append(t)
-    return ops[0], ops[1], 3 * K, keep
+    return ops[0], ops[1], S * K, keep
 
 
 def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=False, precision=None,
@@ -165,16 +182,24 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
     if not out.is_cuda:
         raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
     keep = None
-    if (precision or PRECISION) == "bf16x3":
+    p = precision or PRECISION
+    if p == "bf16x3" or (p == "fp32" and not accumulate and FP32_CONCAT):
+        n_terms = 2 if p == "bf16x3" else 3
+        splittable = batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32
+        if n_terms == 3:    # only where the direct-to-LDS kernels will take the product (6x their time beats 6 MFMAs
+            #                 per tile on the register-staged kernel) and the six-segment copies stay moderate (the
+            #                 joint's lattice-sized operands would need 2 x 24 GB of temporaries per product)
+            splittable = (splittable and bool(a_op.trans) == bool(b_op.trans) and _direct_to_lds_size(a_op.trans, M, N, K)
+                          and 12 * max(M, N) * K <= FP32_CONCAT_MAX_BYTES)
         with torch.cuda.device(out.device):
-            sp = (_bf16x3_operands(a_op, b_op, M, N, K, out.device)
-                  if batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32 else None)
+            sp = _bf16x3_operands(a_op, b_op, M, N, K, out.device, n_terms) if splittable else None
+        stats, hit, miss = (BF16X3_STATS, "fast", "exact") if n_terms == 2 else (FP32_STATS, "concat", "staged")
         if sp is not None:
             a_op, b_op, K, keep = sp        # `keep` holds the split copies until the launch below is enqueued
             precision = "bf16"
-            BF16X3_STATS["fast"] += 1
+            stats[hit] += 1
         else:
-            BF16X3_STATS["exact"] += 1
+            stats[miss] += 1
     with torch.cuda.device(out.device):
         ws = _workspace(out.device) if (a_op.trans and b_op.trans) else None
         rc = _lib.lib().pika_gemm_nt_ws(ctypes.byref(a_op), ctypes.byref(b_op), out.data_ptr(), ldc,

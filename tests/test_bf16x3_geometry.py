@@ -52,21 +52,27 @@ def dense(mem, op, extent, K):
     return np.array([[read(mem, op, r, k) for k in range(K)] for r in range(extent)])
 
 
+PATTERNS = {2: ((0, 1, 0), (0, 0, 1)), 3: ((0, 0, 1, 0, 2, 1), (0, 1, 0, 2, 0, 1))}   # include/pika_ops.h
+
+
 def fake_split(mem):
-    def split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device):
+    def split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_terms=2):
         src = mem.bufs[op.ptr]
         x = np.zeros((n_batch, t_in, C))
         for b in range(n_batch):
             for t in range(t_in):
                 off = b * batch_stride + t * ld
                 x[b, t] = src[off: off + C]
-        hi = bf16(x)
-        lo = bf16(x - hi)
-        segs = (hi, lo, hi) if role == 0 else (hi, hi, lo)
+        t0 = bf16(x)
+        t1 = bf16(x - t0)
+        t2 = bf16(x - t0 - t1)
+        assert np.array_equal(t0 + t1 + t2, bf16(x) * 0 + np.asarray(x, np.float32).astype(np.float64))   # exact 8+8+8
+        terms = (t0, t1, t2)
+        segs = [terms[k] for k in PATTERNS[n_terms][role]]
         assert C % 8 == 0 and Cp % 8 == 0 and Cp >= C
         if layout == 0:
-            dst = np.zeros((n_batch, t_in, 3, Cp))
-            for s in range(3):
+            dst = np.zeros((n_batch, t_in, len(segs), Cp))
+            for s in range(len(segs)):
                 dst[:, :, s, :C] = segs[s]
         else:
             assert Cp == C
@@ -80,10 +86,15 @@ def product(mem, a_op, b_op, M, N, K):
 
 
 def check(monkeypatch, mem, a_op, b_op, M, N, K, expect_split=True):
+    for n_terms in (2, 3):
+        check_terms(monkeypatch, mem, a_op, b_op, M, N, K, expect_split, n_terms)
+
+
+def check_terms(monkeypatch, mem, a_op, b_op, M, N, K, expect_split, n_terms):
     monkeypatch.setattr(G, "_split", fake_split(mem))
     want = product(mem, a_op, b_op, M, N, K)
     scale = np.abs(dense(mem, a_op, M, K)) @ np.abs(dense(mem, b_op, N, K)).T
-    sp = G._bf16x3_operands(a_op, b_op, M, N, K, None)
+    sp = G._bf16x3_operands(a_op, b_op, M, N, K, None, n_terms)
     if not expect_split:
         assert sp is None
         return
@@ -93,13 +104,14 @@ def check(monkeypatch, mem, a_op, b_op, M, N, K, expect_split=True):
     assert a_op.trans or K3 % 8 == 0       # the contiguous reduction of 16-byte bf16 loads
     got = product(mem, a3, b3, M, N, K3)
     err = np.abs(got - want) / np.maximum(scale, 1e-30)
-    assert err.max() < 4e-5, err.max()          # a wrong role pairing (lo.lo, or hi.hi twice) misses this by 100x
-    assert err.max() > 0 or K < 4
+    # a wrong role pairing (lo.lo, or hi.hi twice) misses these by orders of magnitude.  Three terms: the dropped
+    # products (m.l, l.m, l.l) are below 2^-24 of the leading one
+    assert err.max() < (4e-5 if n_terms == 2 else 3e-7), err.max()
 
 
 def plain(mem, rng, rows, K, ld=None):
     ld = ld or K
-    buf = rng.standard_normal((rows, ld))
+    buf = rng.standard_normal((rows, ld)).astype(np.float32)
     return G.Operand(mem.put(buf), G.PIKA_F32, rows, rows, 0, ld, K, 1, 0, 0, 0, 0)
 
 
@@ -114,7 +126,7 @@ def test_plain_operands(monkeypatch, M, N, K, lda):
 def test_time_delay_forward_and_weight_gradient(monkeypatch, taps, dil, stride, pad, Bn, T, C):
     mem, rng = Mem(), np.random.default_rng(taps * 10 + T)
     N = 16
-    x = rng.standard_normal((Bn, T, C))
+    x = rng.standard_normal((Bn, T, C)).astype(np.float32)
     t_out = (T + pad - dil * (taps - 1) - 1) // stride + 1 if pad == 0 else T
     M, K = Bn * t_out, taps * C
     a_op = G.Operand(mem.put(x), G.PIKA_F32, t_out, T, T * C, C, C, stride, dil, pad, 0, 0)

@@ -432,7 +432,8 @@ def test_bf16_output_flag_on_the_generic_entry(hip_device):
         G.launch(G.matrix(a[:300])[0], G.matrix(b[:200])[0], small, 200, 300, 200, K)
 
 
-# ---- "bf16x3": two bf16 terms per fp32 operand, hi.hi + lo.hi + hi.lo as one bf16 product (pika_split_bf16x3) ----
+# ---- K-concatenated term products (pika_split_bf16_terms): "bf16x3" = two bf16 terms per fp32 operand, hi.hi + lo.hi +
+# hi.lo as one bf16 product; "fp32" at direct-to-LDS sizes = three terms, six segments ----
 
 X3_TOL = 4e-5    # 2^-17 per operand + the dropped lo.lo term (2^-18), relative to sum |a||b|; fp32 accumulation on top
 
@@ -441,31 +442,61 @@ def _x3_tol(K):
     return X3_TOL + 2e-6 * max(1.0, K ** 0.5 / 8)
 
 
-def test_split_bf16x3_kernel_layouts(hip_device):
-    """pika_split_bf16x3: hi = bf16(x), lo = bf16(x - hi), both layouts, both roles, zero pad columns, batched source
-    with a pitch and a batch stride."""
+def test_split_terms_kernel_layouts(hip_device):
+    """pika_split_bf16_terms: t0 = bf16(x), t1 = bf16(x - t0), t2 = bf16(x - t0 - t1) (exact), two / three terms, both
+    layouts, both roles, zero pad columns, batched source with a pitch and a batch stride."""
     from pika_amd import _lib
     from pika_amd import gemm as G
     g = torch.Generator().manual_seed(3)
     nb, t_in, C, ld, Cp = 3, 7, 24, 40, 64
     src = torch.randn(nb, t_in + 2, ld, generator=g).to(hip_device)        # batch stride (t_in+2)*ld, pitch ld
-    hi = src[:, :t_in, :C].bfloat16()
-    lo = (src[:, :t_in, :C] - hi.float()).bfloat16()
-    assert ((src[:, :t_in, :C] - hi.float() - lo.float()).abs() <= 2.0 ** -16 * src[:, :t_in, :C].abs()).all()
+    x = src[:, :t_in, :C]
+    t0 = x.bfloat16()
+    t1 = (x - t0.float()).bfloat16()
+    t2 = (x - t0.float() - t1.float()).bfloat16()
+    assert torch.equal(t0.float() + t1.float() + t2.float(), x)           # 8 + 8 + 8 mantissa bits: exact
+    terms = (t0, t1, t2)
+    patterns = {2: ((0, 1, 0), (0, 0, 1)), 3: ((0, 0, 1, 0, 2, 1), (0, 1, 0, 2, 0, 1))}    # include/pika_ops.h
     op = G.Operand(src.data_ptr(), G.PIKA_F32, t_in, t_in, (t_in + 2) * ld, ld, C, 1, 0, 0, 0, 0)
-    for role in (0, 1):
-        segs = (hi, lo, hi) if role == 0 else (hi, hi, lo)
-        cat = G._split(op, nb, t_in, C, (t_in + 2) * ld, ld, role, 0, Cp, hip_device).view(nb, t_in, 3, Cp)
-        stk = G._split(op, nb, t_in, C, (t_in + 2) * ld, ld, role, 1, C, hip_device).view(3, nb, t_in, C)
-        torch.cuda.synchronize()
-        for s in range(3):
-            assert torch.equal(cat[:, :, s, :C], segs[s]) and bool((cat[:, :, s, C:] == 0).all())
-            assert torch.equal(stk[s], segs[s])
+    for n_terms in (2, 3):
+        for role in (0, 1):
+            segs = [terms[k] for k in patterns[n_terms][role]]
+            S = len(segs)
+            cat = G._split(op, nb, t_in, C, (t_in + 2) * ld, ld, role, 0, Cp, hip_device, n_terms).view(nb, t_in, S, Cp)
+            stk = G._split(op, nb, t_in, C, (t_in + 2) * ld, ld, role, 1, C, hip_device, n_terms).view(S, nb, t_in, C)
+            torch.cuda.synchronize()
+            for s_ in range(S):
+                assert torch.equal(cat[:, :, s_, :C], segs[s_]) and bool((cat[:, :, s_, C:] == 0).all())
+                assert torch.equal(stk[s_], segs[s_])
     with pytest.raises(RuntimeError):      # C % 8 != 0 is refused
         G._split(op, nb, t_in, 20, (t_in + 2) * ld, ld, 0, 0, 64, hip_device)
     with pytest.raises(RuntimeError):      # the stacked layout has no pad columns
-        _lib.check(_lib.lib().pika_split_bf16x3(src.data_ptr(), nb, t_in, C, (t_in + 2) * ld, ld, 0, 1, Cp,
-                                                src.data_ptr(), None), "pika_split_bf16x3")
+        _lib.check(_lib.lib().pika_split_bf16_terms(src.data_ptr(), nb, t_in, C, (t_in + 2) * ld, ld, 0, 2, 1, Cp,
+                                                    src.data_ptr(), None), "pika_split_bf16_terms")
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 2560, 1024), (10240, 1024, 5000), (41000, 1024, 240)])
+def test_fp32_mode_takes_the_six_segment_path_at_direct_to_lds_sizes(hip_device, M, N, K, monkeypatch):
+    """Exact mode, products large enough for the direct-to-LDS kernels: three terms per operand, six segments, ONE bf16
+    product -- the same six products PIKA_GEMM_FP32SPLIT issues.  Same accuracy bound as the register-staged exact
+    kernel, and the two agree with each other to fp32 accumulation noise."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) + 0.3 * torch.arange(K) / K).to(hip_device)
+    b = (torch.randn(N, K, generator=g) * (1 + torch.arange(N).unsqueeze(1) / N)).to(hip_device)
+    bias = torch.randn(N, generator=g).to(hip_device)
+    n0 = G.FP32_STATS["concat"]
+    out = G.gemm_nt(a, b, bias=bias, relu=True, precision="fp32")
+    assert G.FP32_STATS["concat"] == n0 + 1
+    tol = 1e-6 * max(1.0, K ** 0.5 / 8)
+    e = (out.double() - ref(a, b, bias, relu=True)).abs() / err_scale(a, b)
+    assert e.max().item() < tol, e.max().item()
+    monkeypatch.setattr(G, "FP32_CONCAT", False)
+    s0 = G.FP32_STATS["concat"]
+    staged = G.gemm_nt(a, b, bias=bias, relu=True, precision="fp32")
+    assert G.FP32_STATS["concat"] == s0
+    e2 = (staged.double() - out.double()).abs() / err_scale(a, b)
+    assert e2.max().item() < tol
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (16, 16, 8), (300, 200, 64), (257, 136, 104), (1000, 5000, 1024),
