@@ -1,0 +1,48 @@
+/*
+ * include/pika_las.h -- C ABI of the per-token kernels of LAS n-best rescoring.
+ *
+ * Replaces, inside the input-feed decoder loop of the reference rescorer
+ * (/root/reference/trainer/model/las.py:649-668, one Python iteration per token and per hypothesis):
+ *   - nn.LSTMCell's gate arithmetic (modules/stacked_rnn.py:20-34 stacks the cells), and
+ *   - the "mlp" global attention (modules/global_attention.py:162-248: score(h_t, h_s) = v^T tanh(W_q h_t + U_a h_s),
+ *     softmax over the source positions, context = sum_s a_s h_s),
+ * for ALL n-best hypotheses of a decode batch at once.  The reference materialises tanh(W_q h_t + U_a h_s) as an
+ * (N, S, D) tensor per token (1 GB at 1024 hypotheses x 240 positions x 1024) and re-reads the expanded context; here
+ * the scores, the softmax and the context sum of a hypothesis never leave the workgroup, and the hypotheses of one
+ * utterance share the utterance's (S, D) projections through L2.  Conventions as in pika_rnnt.h (caller-owned device
+ * memory, stream-ordered, no allocation, return code).
+ */
+#ifndef PIKA_LAS_H
+#define PIKA_LAS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gates (N, 4H) f32 = W_ih x + b_ih + W_hh h + b_hh in nn.LSTMCell order [i | f | g | o] (pitch ldg);
+ * c_prev (N, H) contiguous.  c_out (N, H) contiguous (may alias c_prev) = sigmoid(f) c_prev + sigmoid(i) tanh(g);
+ * h = sigmoid(o) tanh(c_out) is written to h_out (pitch ldh) and, when h_out2 != NULL, also to h_out2 (pitch ldh2) --
+ * the decoder keeps h both as the next layer's input block and as the recurrent block of its own next step.
+ * H % 4 == 0, 16-byte aligned rows. */
+int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float *c_out, float *h_out, long long ldh,
+                   float *h_out2, long long ldh2, int N, int H, void *stream);
+
+/* "mlp" attention of N queries over the source positions of their utterances; query n = qidx[i], i < N (qidx NULL:
+ * n = i):
+ *   align[n, s] = sum_d v[d] tanh(wq[n, d] + proj[owner[n], s, d])          s < lens[owner[n]]  (else excluded)
+ *   a[n, :]     = softmax_s align[n, :]
+ *   ctx_out[n, :] = sum_s a[n, s] context[owner[n], s, :]
+ * wq (., D) f32 pitch ldq = W_q h_t + b_q (the caller's GEMM); proj, context (B, S, D) f32 contiguous = U_a h_s and
+ * h_s; owner (.,) int32 utterance of each query; qidx (N,) int32 the queries to process -- consecutive entries
+ * should belong to the same utterance: a workgroup takes 4 of them and loads an utterance's rows once for those that
+ * share it (the caller's active set is a prefix of its length-sorted hypotheses, the list re-orders it by
+ * utterance); lens (B,) int32 valid positions (>= 1); ctx_out (., D) f32 pitch ldo; align_out (., S) f32 or NULL
+ * (the attention weights, for tests).  D % 4 == 0, D <= 1024, S <= 2048. */
+int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, const float *context, const int *owner,
+                           const int *lens, const int *qidx, const float *v, float *ctx_out, long long ldo,
+                           float *align_out, int N, int B, int S, int D, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKA_LAS_H */

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -54,6 +54,9 @@ SIGNATURES = {
     "pika_colsum_bf16": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
+    # include/pika_las.h
+    "pika_lstm_cell": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _vp]),
+    "pika_las_mlp_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _vp]),
     # include/pika_joint.h
     "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pika_joint_gate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i, _i, _i, _i, _vp]),

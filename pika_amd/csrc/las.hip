@@ -1,0 +1,213 @@
+// pika_amd/csrc/las.hip -- per-token kernels of LAS n-best rescoring for gfx950 (include/pika_las.h;
+// reference trainer/model/las.py:649-668, modules/global_attention.py:162-248, modules/stacked_rnn.py:20-34).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pika_las.h"
+#include "pika_rnnt.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// 1 - 2/(e^{2x}+1): exact limits at +-inf (exp -> inf: rcp -> 0; exp -> 0: 1 - 2), abs error ~2e-7
+__device__ inline float tanh_fast(float x) { return 1.0f - 2.0f * rcp(__expf(2.0f * x) + 1.0f); }
+__device__ inline float sigmoid_fast(float x) { return rcp(1.0f + __expf(-x)); }
+
+// one thread per 4 channels of one row
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float *__restrict__ gates, long long ldg,
+                                                        const float *__restrict__ c_prev, float *__restrict__ c_out,
+                                                        float *__restrict__ h_out, long long ldh,
+                                                        float *__restrict__ h_out2, long long ldh2, int N, int H) {
+    const int H4 = H >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * H4) return;
+    const int n = (int)(idx / H4), c = (int)(idx - (long long)n * H4) << 2;
+    const float *g = gates + (long long)n * ldg + c;
+    const f32x4 gi = *reinterpret_cast<const f32x4 *>(g), gf = *reinterpret_cast<const f32x4 *>(g + H);
+    const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + 2 * H), go = *reinterpret_cast<const f32x4 *>(g + 3 * H);
+    const f32x4 cp = *reinterpret_cast<const f32x4 *>(c_prev + (long long)n * H + c);
+    f32x4 cn, h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cn[e] = sigmoid_fast(gf[e]) * cp[e] + sigmoid_fast(gi[e]) * tanh_fast(gg[e]);
+        h[e] = sigmoid_fast(go[e]) * tanh_fast(cn[e]);
+    }
+    *reinterpret_cast<f32x4 *>(c_out + (long long)n * H + c) = cn;
+    *reinterpret_cast<f32x4 *>(h_out + (long long)n * ldh + c) = h;
+    if (h_out2) *reinterpret_cast<f32x4 *>(h_out2 + (long long)n * ldh2 + c) = h;
+}
+
+constexpr int G = 4;          // queries per workgroup
+constexpr int KQ = 4;         // float4 slots per lane: D <= 64 * 4 * KQ = 1024
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ inline float block_reduce(float v, bool is_max, float *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o);
+        v = is_max ? fmaxf(v, w) : v + w;
+    }
+    __syncthreads();                       // `red` may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v = is_max ? fmaxf(v, red[w]) : v + red[w];
+    return v;
+}
+
+// Workgroup = 8 waves = G consecutive entries of the query list; wave w walks the source positions w, w+8, ... ONCE
+// (two waves per SIMD: one computes while the other waits for its rows): a lane holds
+// 4*KQ channels of W_q h_t (every query), of v and of the running context sums; per position one load of the
+// utterance's U_a h_s row and one of its h_s row serve every query of the group that belongs to the utterance.  The
+// softmax is online (running maximum m, running sum l, context sums rescaled when m moves), so the scores never leave
+// the registers; the eight waves' partial (m, l, sums) are merged through LDS at the end.
+constexpr int AW = 8;         // waves per workgroup
+__global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float *__restrict__ wq, long long ldq,
+                                                                const float *__restrict__ proj,
+                                                                const float *__restrict__ context,
+                                                                const int *__restrict__ owner,
+                                                                const int *__restrict__ lens,
+                                                                const int *__restrict__ qidx,
+                                                                const float *__restrict__ v,
+                                                                float *__restrict__ ctx_out, long long ldo,
+                                                                float *__restrict__ align_out, int N, int S, int D) {
+    __shared__ float wm[AW][G], wl[AW][G];
+    __shared__ f32x4 wacc[AW][64 * KQ];         // one query's partial sums of the eight waves (32 KB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D4 = D >> 2;
+    const int i0 = blockIdx.x * G;
+    int nq[G], b[G], len[G];
+    int smax = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const bool ok = i0 + g < N;
+        nq[g] = ok ? (qidx ? qidx[i0 + g] : i0 + g) : 0;        // the query (row of wq / ctx_out / owner) of entry i0+g
+        b[g] = ok ? owner[nq[g]] : -1;
+        len[g] = ok ? min(lens[b[g]], S) : 0;
+        smax = max(smax, len[g]);
+    }
+    f32x4 q[G][KQ], vv[KQ], acc[G][KQ];
+    float m[G], l[G];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        const int j = lane + 64 * k;
+        vv[k] = j < D4 ? reinterpret_cast<const f32x4 *>(v)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            q[g][k] = (j < D4 && b[g] >= 0) ? reinterpret_cast<const f32x4 *>(wq + (long long)nq[g] * ldq)[j]
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) { m[g] = -INFINITY; l[g] = 0.f; }
+    for (int s = wave; s < smax; s += AW) {
+        f32x4 p[KQ], x[KQ];
+        int loaded = -1;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (s >= len[g]) continue;                           // wave-uniform
+            if (b[g] != loaded) {
+                const long long off = ((long long)b[g] * S + s) * D;
+                const f32x4 *prow = reinterpret_cast<const f32x4 *>(proj + off);
+                const f32x4 *crow = reinterpret_cast<const f32x4 *>(context + off);
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) {
+                    const int j = lane + 64 * k;
+                    p[k] = j < D4 ? prow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x[k] = j < D4 ? crow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                loaded = b[g];
+            }
+            float sc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc += vv[k][e] * tanh_fast(q[g][k][e] + p[k][e]);    // v = 0 past D
+            sc = wave_sum(sc);
+            if (align_out && lane == 0) align_out[(long long)nq[g] * S + s] = sc;               // raw, normalised below
+            const float mn = fmaxf(m[g], sc);
+            const float alpha = __expf(m[g] - mn), w = __expf(sc - mn);                            // exp(-inf) = 0
+            m[g] = mn;
+            l[g] = l[g] * alpha + w;
+#pragma unroll
+            for (int k = 0; k < KQ; ++k) acc[g][k] = acc[g][k] * alpha + w * x[k];
+        }
+    }
+    // ---- merge the four waves' partials ----
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) { wm[wave][g] = m[g]; wl[wave][g] = l[g]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (len[g] == 0) continue;                               // block-uniform
+        float M = wm[0][g];                                       // finite: len >= 1
+#pragma unroll
+        for (int w2 = 1; w2 < AW; ++w2) M = fmaxf(M, wm[w2][g]);
+        float L = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < AW; ++w2) L += wl[w2][g] * __expf(wm[w2][g] - M);
+        const float mine = __expf(m[g] - M);
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) wacc[wave][lane + 64 * k] = acc[g][k] * mine;
+        __syncthreads();
+        const int j = threadIdx.x;
+        if (j < D4) {
+            f32x4 t = wacc[0][j];
+#pragma unroll
+            for (int w2 = 1; w2 < AW; ++w2) t += wacc[w2][j];
+            reinterpret_cast<f32x4 *>(ctx_out + (long long)nq[g] * ldo)[j] = t * (1.0f / L);
+        }
+        if (align_out) {   // tests: the weights themselves.  The raw scores were written by this workgroup's lanes
+            float *row = align_out + (long long)nq[g] * S;        // before the barriers above
+            for (int s = threadIdx.x; s < S; s += 64 * AW) row[s] = s < len[g] ? __expf(row[s] - M) / L : 0.f;
+        }
+        __syncthreads();                                         // wacc is reused by the next query
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float *c_out, float *h_out, long long ldh,
+                   float *h_out2, long long ldh2, int N, int H, void *stream) {
+    if (!gates || !c_prev || !c_out || !h_out || N <= 0 || H <= 0) return PIKA_EINVAL;
+    if ((H & 3) || (ldg & 3) || (ldh & 3) || (h_out2 && (ldh2 & 3)) || ldg < 4LL * H || ldh < H) return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(gates) | reinterpret_cast<uintptr_t>(c_prev) | reinterpret_cast<uintptr_t>(c_out) |
+         reinterpret_cast<uintptr_t>(h_out) | reinterpret_cast<uintptr_t>(h_out2)) & 15)
+        return PIKA_EINVAL;
+    const long long total = (long long)N * (H >> 2);
+    if ((total + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), gates, ldg, c_prev, c_out, h_out, ldh, h_out2, ldh2, N, H);
+    return (int)hipGetLastError();
+}
+
+int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, const float *context, const int *owner,
+                           const int *lens, const int *qidx, const float *v, float *ctx_out, long long ldo,
+                           float *align_out, int N, int B, int S, int D, void *stream) {
+    if (!wq || !proj || !context || !owner || !lens || !v || !ctx_out || N <= 0 || B <= 0 || S <= 0 || D <= 0)
+        return PIKA_EINVAL;
+    if ((D & 3) || (ldq & 3) || (ldo & 3) || ldq < D || ldo < D) return PIKA_EINVAL;
+    if (D > 64 * 4 * KQ || S > 2048) return PIKA_ETOOBIG;
+    if ((reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(context) |
+         reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ctx_out)) & 15)
+        return PIKA_EINVAL;
+    hipLaunchKernelGGL(las_mlp_attention_kernel, dim3((unsigned)((N + G - 1) / G)), dim3(64 * AW), 0,
+                       static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
+                       align_out, N, S, D);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

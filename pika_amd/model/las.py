@@ -8,6 +8,9 @@ copy / context gate / downsampler) and anything else raises.
 `score_nbest` is the MI355X-shaped entry: all hypotheses of an utterance are scored in ONE batched
 decoder pass over ONE encoder pass (the reference re-runs the BLSTM encoder and a batch-1 decoder
 loop per hypothesis, decoder/transducer_decoder.py:219-236)."""
+import ctypes
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
@@ -135,8 +138,109 @@ class InputFeedRNNDecoder(nn.Module):
             h = torch.cat([h[0:h.size(0):2], h[1:h.size(0):2]], 2)
         return h
 
-    def run(self, tokens, context, enc_hidden, mask=None):
-        """tokens (L,N) decoder inputs, context (S,N,H).  Returns outputs (L,N,H)."""
+    def _fused_ok(self, context):
+        """The per-token HIP kernels (include/pika_las.h) take the scoring pass: inference on a HIP device, mlp
+        attention, widths of 16-byte granules.  PIKA_LAS_FUSED=0 keeps the op-by-op path (tests compare the two)."""
+        S, _, H = context.shape
+        E = self.embeddings.embedding_size
+        return (context.is_cuda and not torch.is_grad_enabled() and not self.training and self.attn.attn_type == "mlp"
+                and H == self.hidden_size and H % 4 == 0 and H <= 1024 and E % 4 == 0 and S <= 2048
+                and context.dtype == torch.float32 and os.environ.get("PIKA_LAS_FUSED", "1") != "0")
+
+    def _run_fused(self, tokens, context, enc_hidden, owner, lens, n_active=None):
+        """The token loop of `run` for N hypotheses of B utterances (owner (N,) -> utterance, lens (B,) valid source
+        positions) on un-expanded encoder outputs: per token 2 x (one GEMM over [input | h] with [W_ih | W_hh] + one
+        LSTM-cell kernel), the query projection, ONE attention kernel (scores, softmax and context sum of a hypothesis
+        never leave the workgroup; the (N,S,H) tanh tensor of global_attention.py:218-221 does not exist) and the
+        output projection written straight into the result and fed back (input feeding, las.py:649-668).
+        n_active[t] (host ints, non-increasing): only hypotheses [0, n_active[t]) still have a token at step t (the
+        caller sorted them by length), so every launch of step t runs on that prefix of the rows; rows past it are left
+        unwritten in the result."""
+        from .. import _lib
+        from .. import gemm as G
+        lib = _lib.lib()
+        dev = context.device
+        L, N = tokens.shape
+        S, B, H = context.shape
+        E = self.embeddings.embedding_size
+        nl = self.num_layers
+        att = self.attn
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
+            ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
+            proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous()).view(B, S, H)
+            emb = self.embeddings.embeddings(tokens)                                # (L, N, E)
+            own = owner.to(device=dev, dtype=torch.int32).contiguous()
+            ln = lens.to(device=dev, dtype=torch.int32).contiguous()
+            half = G.PRECISION == "bf16"      # weights are re-read every token: keep them in the operand dtype
+
+            def weight(w):
+                w = w.detach()
+                if not half:
+                    return w.contiguous()
+                K8 = (w.shape[1] + 7) & ~7      # bf16 operand rows: readable and zero up to a multiple of 8
+                wb = torch.zeros((w.shape[0], K8), dtype=torch.bfloat16, device=dev)
+                wb[:, :w.shape[1]] = w
+                return wb
+            Wl = [weight(torch.cat([c.weight_ih, c.weight_hh], 1)) for c in self.rnn.layers]
+            bl = [(c.bias_ih + c.bias_hh).detach().contiguous() for c in self.rnn.layers]
+            Wq, bq = weight(att.linear_query.weight), att.linear_query.bias.detach().contiguous()
+            Wo, bo = weight(att.linear_out.weight), att.linear_out.bias.detach().contiguous()
+            v = att.v.weight.detach().reshape(-1).contiguous()
+            # X[0] = [emb_t | feed | h_0], X[l] = [h_{l-1} | h_l]: a layer's input rows, updated in place
+            X = [torch.zeros((N, E + 2 * H), device=dev)] + [torch.zeros((N, 2 * H), device=dev) for _ in range(1, nl)]
+            X[0][:, E + H:] = h0[0][owner]
+            for l in range(1, nl):
+                X[l][:, H:] = h0[l][owner]
+            c = [c0[l][owner].contiguous() for l in range(nl)]
+            CQ = torch.empty((N, 2 * H), device=dev)                                # [context vector | query h_t]
+            gates = torch.empty((N, 4 * H), device=dev)
+            wq = torch.empty((N, H), device=dev)
+            outs = torch.empty((L, N, H), device=dev)
+            # per step: the active hypotheses [0, n) re-ordered by utterance, so that the four queries of an attention
+            # workgroup share the utterance's rows (one upload for all steps)
+            qoff = qlist = None
+            if n_active is not None:
+                import numpy as np
+                own_h = owner.cpu().numpy()
+                by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
+                lists = [by_owner[by_owner < int(k)] for k in n_active]
+                qoff = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+                qlist = torch.from_numpy(np.concatenate(lists) if lists else np.zeros(0, np.int32)).to(dev)
+            for t in range(L):
+                n = N if n_active is None else int(n_active[t])
+                if n <= 0:
+                    break
+                X[0][:n, :E].copy_(emb[t, :n])
+                for l in range(nl):
+                    G.gemm_nt(X[l][:n], Wl[l], bias=bl[l], out=gates[:n])
+                    own_block = X[l][:, (E + H if l == 0 else H):]
+                    nxt = X[l + 1][:, :H] if l + 1 < nl else CQ[:, H:]
+                    _lib.check(lib.pika_lstm_cell(gates.data_ptr(), 4 * H, c[l].data_ptr(), c[l].data_ptr(),
+                                                  own_block.data_ptr(), own_block.stride(0), nxt.data_ptr(),
+                                                  nxt.stride(0), n, H, stream), "pika_lstm_cell")
+                G.gemm_nt(CQ[:n, H:], Wq, bias=bq, out=wq[:n])
+                qi = None if qlist is None else qlist.data_ptr() + 4 * int(qoff[t])
+                _lib.check(lib.pika_las_mlp_attention(wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(),
+                                                      ln.data_ptr(), qi, v.data_ptr(), CQ.data_ptr(), 2 * H, None, n, B, S,
+                                                      H, stream), "pika_las_mlp_attention")
+                G.gemm_nt(CQ[:n], Wo, bias=bo, out=outs[t, :n])
+                X[0][:n, E:E + H].copy_(outs[t, :n])                                # input feeding
+        return outs, None
+
+    def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, n_active=None):
+        """tokens (L,N) decoder inputs, context (S,N,H).  Returns outputs (L,N,H).
+        With `owner` (N,) and `lens` (B,): context / enc_hidden are per UTTERANCE ((S,B,H), (layers,B,H)) and hypothesis
+        n reads utterance owner[n], whose valid source positions are [0, lens[owner[n]])."""
+        if owner is not None:
+            if self._fused_ok(context):
+                return self._run_fused(tokens, context, enc_hidden, owner, lens, n_active)
+            S = context.shape[0]
+            context = context[:, owner].contiguous()
+            enc_hidden = tuple(e[:, owner].contiguous() for e in enc_hidden)
+            mask = torch.arange(S, device=context.device).unsqueeze(0) < lens.to(context.device)[owner].unsqueeze(1)
+            mask = None if bool(mask.all()) else mask
         hidden = tuple(self._fix_enc_hidden(e) for e in enc_hidden)
         ctx = context.transpose(0, 1).contiguous()
         proj = self.attn.project_context(ctx)
@@ -180,27 +284,53 @@ class Net(nn.Module):
         out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
         return out, None, None, enc_out
 
+    def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale):
+        """log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
+        owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).  The hypotheses go through the decoder sorted by
+        length so that step t only runs on those that still have a token (sum of lengths instead of count x longest),
+        and only the (step, hypothesis) pairs that exist are projected onto the vocabulary."""
+        import numpy as np
+        dev = enc_out.device
+        n = len(flat)
+        ntok = np.array([len(h) + 1 for h in flat], dtype=np.int64)           # decoder steps of a hypothesis
+        perm = np.argsort(-ntok, kind="stable")
+        L = int(ntok.max())
+        pad = self.tgt_embeddings.padding_idx
+        tok = np.full((L, n), pad, dtype=np.int64)
+        tgt = np.full((L, n), pad, dtype=np.int64)
+        for col, i in enumerate(perm):
+            h = flat[i]
+            k = len(h) + 1
+            tok[0, col] = sos
+            tok[1:k, col] = h
+            tgt[:k - 1, col] = h
+            tgt[k - 1, col] = eos
+        n_active = (ntok[perm][None, :] > np.arange(L)[:, None]).sum(1)      # (L,), non-increasing
+        tok_d = torch.from_numpy(tok).to(dev)
+        own = owner[torch.from_numpy(perm).to(owner.device)]
+        out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, n_active=n_active)
+        # the pairs (t, col) with col < n_active[t], step-major
+        tt = np.repeat(np.arange(L), n_active)
+        cc = np.concatenate([np.arange(k) for k in n_active])
+        rows = out[torch.from_numpy(tt).to(dev), torch.from_numpy(cc).to(dev)]                    # (R, H)
+        logp = torch.log_softmax(scale * ops.linear(rows, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
+        want = torch.from_numpy(tgt[tt, cc]).to(dev).clamp(max=logp.shape[1] - 1)
+        picked = np.zeros((L, n), dtype=np.float32)
+        picked[tt, cc] = logp.gather(1, want.unsqueeze(1)).squeeze(1).cpu().numpy()
+        res = [None] * n
+        for col, i in enumerate(perm):
+            res[i] = picked[:ntok[i], col].tolist()
+        return res
+
     @torch.no_grad()
     def score_nbest(self, src, hyps, sos, eos, scale=1.0):
         """src (T,1,C) one utterance; hyps: list of label lists.  Returns, per hypothesis, the list
         of log P(token_t | prefix) over `hyp + [eos]` -- what `las_rescore` returns one by one."""
-        n = len(hyps)
         lens = torch.tensor([src.shape[0]], dtype=torch.int32)
         enc_hidden, enc_out = self.encoder(src, lens)
-        L = max(len(h) for h in hyps) + 1
-        pad = self.tgt_embeddings.padding_idx
-        tok = torch.full((L, n), pad, dtype=torch.long, device=src.device)
-        tgt = torch.full((L, n), pad, dtype=torch.long, device=src.device)
-        for i, h in enumerate(hyps):
-            seq = [sos] + list(h) + [eos]
-            tok[:len(seq) - 1, i] = torch.tensor(seq[:-1], device=src.device)
-            tgt[:len(seq) - 1, i] = torch.tensor(seq[1:], device=src.device)
-        ctx = enc_out.expand(-1, n, -1).contiguous()
-        hid = tuple(e.expand(-1, n, -1).contiguous() for e in enc_hidden)
-        out, _ = self.decoder.run(tok, ctx, hid)
-        logp = torch.log_softmax(scale * ops.linear(out, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
-        picked = logp.gather(2, tgt.clamp(max=logp.shape[2] - 1).unsqueeze(2)).squeeze(2).cpu()
-        return [picked[:len(h) + 1, i].tolist() for i, h in enumerate(hyps)]
+        owner = torch.zeros(len(hyps), dtype=torch.long, device=src.device)
+        return self._score_flat(enc_out, enc_hidden, owner, torch.tensor([enc_out.shape[0]], device=src.device),
+                                [list(h) for h in hyps], sos, eos, scale)
 
     @torch.no_grad()
     def score_nbest_batch(self, src, lengths, hyps, sos, eos, scale=1.0):
@@ -215,31 +345,12 @@ class Net(nn.Module):
         inv = torch.empty_like(order)
         inv[order] = torch.arange(B)
         enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
-        S = enc_out.shape[0]
         owner = torch.tensor([inv[b].item() for b in range(B) for _ in hyps[b]], dtype=torch.long, device=dev)
-        flat = [h for b in range(B) for h in hyps[b]]
-        n = len(flat)
-        L = max(len(h) for h in flat) + 1
-        pad = self.tgt_embeddings.padding_idx
-        tok = torch.full((L, n), pad, dtype=torch.long)
-        tgt = torch.full((L, n), pad, dtype=torch.long)
-        for i, h in enumerate(flat):
-            seq = [sos] + list(h) + [eos]
-            tok[:len(seq) - 1, i] = torch.tensor(seq[:-1])
-            tgt[:len(seq) - 1, i] = torch.tensor(seq[1:])
-        tok, tgt = tok.to(dev), tgt.to(dev)
-        ctx = enc_out[:, owner].contiguous()
-        hid = tuple(e[:, owner].contiguous() for e in enc_hidden)
-        mask = torch.arange(S, device=dev).unsqueeze(0) < lens[order].to(dev)[owner].unsqueeze(1)      # (n,S)
-        out, _ = self.decoder.run(tok, ctx, hid, mask=None if bool(mask.all()) else mask)
-        logp = torch.log_softmax(scale * ops.linear(out, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
-        picked = logp.gather(2, tgt.clamp(max=logp.shape[2] - 1).unsqueeze(2)).squeeze(2).cpu()
+        flat = [list(h) for b in range(B) for h in hyps[b]]
+        scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale)
         res, i = [], 0
         for b in range(B):
-            row = []
-            for h in hyps[b]:
-                row.append(picked[:len(h) + 1, i].tolist())
-                i += 1
-            res.append(row)
+            res.append(scores[i:i + len(hyps[b])])
+            i += len(hyps[b])
         return res
 

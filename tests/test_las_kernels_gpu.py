@@ -1,0 +1,114 @@
+"""Per-token kernels of LAS rescoring (include/pika_las.h) vs the torch formulas of the reference modules
+(modules/global_attention.py:162-248 "mlp" attention; nn.LSTMCell as stacked by modules/stacked_rnn.py:20-34), and
+the fused scoring pass of pika_amd.model.las against its own op-by-op pass on a ragged decode batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import las_common as LC  # noqa: E402
+from oracle.pika_ref import seeded_state_dict  # noqa: E402
+
+
+@pytest.mark.parametrize("N,H", [(1, 4), (5, 32), (1024, 1024), (7, 100)])
+def test_lstm_cell(hip_device, N, H):
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(N + H)
+    gates = (torch.randn(N, 4 * H + 8, generator=g) * 3).to(hip_device)          # pitch > 4H
+    gates[0, :4] = torch.tensor([100.0, -100.0, 50.0, -50.0])                    # saturated gates stay finite
+    c_prev = torch.randn(N, H, generator=g).to(hip_device)
+    i, f, gg, o = gates[:, :4 * H].double().chunk(4, dim=1)
+    c_ref = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    c = c_prev.clone()
+    h1 = torch.full((N, H + 4), -7.0, device=hip_device)
+    h2 = torch.full((N, 2 * H), -7.0, device=hip_device)
+    with torch.cuda.device(hip_device):
+        _lib.check(_lib.lib().pika_lstm_cell(gates.data_ptr(), gates.stride(0), c.data_ptr(), c.data_ptr(), h1.data_ptr(),
+                                             h1.stride(0), h2[:, H:].data_ptr(), h2.stride(0), N, H,
+                                             torch.cuda.current_stream().cuda_stream), "pika_lstm_cell")
+    assert (c.double() - c_ref).abs().max() < 2e-6 * max(1.0, c_ref.abs().max().item())
+    assert (h1[:, :H].double() - h_ref).abs().max() < 2e-6 and torch.equal(h1[:, :H], h2[:, H:])
+    assert bool((h1[:, H:] == -7.0).all()) and bool((h2[:, :H] == -7.0).all())
+
+
+@pytest.mark.parametrize("B,S,D,nper", [(1, 5, 4, [1]), (3, 23, 32, [3, 2, 1]), (4, 240, 1024, [16, 16, 5, 16]),
+                                        (2, 300, 100, [7, 9])])
+def test_mlp_attention(hip_device, B, S, D, nper):
+    """Queries of several utterances (groups of 4 straddle utterance boundaries), ragged source lengths."""
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(B * 100 + S + D)
+    owner = torch.tensor([b for b in range(B) for _ in range(nper[b])], dtype=torch.int32)
+    N = owner.numel()
+    lens = torch.tensor([max(1, S - 7 * b) for b in range(B)], dtype=torch.int32)
+    wq = torch.randn(N, D, generator=g)
+    proj = torch.randn(B, S, D, generator=g)
+    ctx = torch.randn(B, S, D, generator=g)
+    v = torch.randn(D, generator=g) * 0.3
+    align = (torch.tanh(wq.double().unsqueeze(1) + proj.double()[owner.long()]) * v.double()).sum(-1)      # (N,S)
+    mask = torch.arange(S).unsqueeze(0) < lens[owner.long()].unsqueeze(1)
+    a_ref = torch.softmax(align.masked_fill(~mask, float("-inf")), -1)
+    c_ref = torch.bmm(a_ref.unsqueeze(1), ctx.double()[owner.long()]).squeeze(1)
+    dev = [t.to(hip_device) for t in (wq, proj, ctx, owner, lens, v)]
+    out = torch.full((N, 2 * D), -7.0, device=hip_device)
+    a_out = torch.full((N, S), -7.0, device=hip_device)
+    with torch.cuda.device(hip_device):
+        _lib.check(_lib.lib().pika_las_mlp_attention(dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(),
+                                                     dev[3].data_ptr(), dev[4].data_ptr(), None, dev[5].data_ptr(),
+                                                     out.data_ptr(), 2 * D, a_out.data_ptr(), N, B, S, D,
+                                                     torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention")
+    assert (a_out.double().cpu() - a_ref).abs().max() < 2e-6
+    assert (out[:, :D].double().cpu() - c_ref).abs().max() < 1e-5
+    assert bool((out[:, D:] == -7.0).all())
+    # a query list: a shuffled subset of the queries; only those rows are written
+    pick = torch.randperm(N, generator=g)[:max(1, N - 2)].to(torch.int32)
+    out2 = torch.full((N, D), -7.0, device=hip_device)
+    with torch.cuda.device(hip_device):
+        qd = pick.to(hip_device)
+        _lib.check(_lib.lib().pika_las_mlp_attention(dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(),
+                                                     dev[3].data_ptr(), dev[4].data_ptr(), qd.data_ptr(), dev[5].data_ptr(),
+                                                     out2.data_ptr(), D, None, pick.numel(), B, S, D,
+                                                     torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention")
+    sel = pick.long()
+    assert (out2[sel].double().cpu() - c_ref[sel]).abs().max() < 1e-5
+    rest = torch.ones(N, dtype=torch.bool)
+    rest[sel] = False
+    assert bool((out2[rest] == -7.0).all())
+
+
+def test_fused_scoring_pass_equals_the_op_by_op_pass(hip_device, monkeypatch):
+    """score_nbest_batch on a ragged decode batch: the per-token kernel chain against the op-by-op decoder loop of the
+    same module (PIKA_LAS_FUSED=0), exact arithmetic mode; and score_nbest (one utterance) the same way."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from trainer.model import las
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        net = las.Net(LC.opt("mlp"), LC.C_IN, LC.V, LC.PAD)
+        net.load_state_dict(seeded_state_dict(net, 31, scale=0.3))
+        net = net.to(hip_device).eval()
+        g = torch.Generator().manual_seed(5)
+        lens = [17, 23, 9]
+        src = torch.zeros(23, 3, LC.C_IN)
+        for b, n in enumerate(lens):
+            src[:n, b] = torch.randn(n, LC.C_IN, generator=g)
+        src = src.to(hip_device)
+        hyps = [[[3, 7, 7, 12], [5], []], [[8, 1, 30, 2, 2, 19, 4], [2, 2]], [[11]]]
+        res = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("PIKA_LAS_FUSED", fused)
+            res[fused] = (net.score_nbest_batch(src, lens, hyps, LC.SOS, LC.EOS),
+                          net.score_nbest(src[:17, 0:1], hyps[0], LC.SOS, LC.EOS))
+        for a, b in zip(res["1"][0], res["0"][0]):
+            for x, y in zip(a, b):
+                assert np.allclose(x, y, rtol=2e-5, atol=2e-5), (x, y)
+        for x, y in zip(res["1"][1], res["0"][1]):
+            assert np.allclose(x, y, rtol=2e-5, atol=2e-5)
+    finally:
+        G.PRECISION = old
