@@ -112,6 +112,38 @@ int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, floa
 /* kvq / pos / node / out are indexed by slot (< min(rows, *m_dev)); the ancestry row of slot i is rowmap[i]
  * (identity when rowmap is NULL). */
 
+/* ---- LSTM prediction network (the shipped recipes' `dec_type=rnn`; reference trainer/model/transducer.py:55-61,
+ * stepped by decoder/transducer_decoder.py:139-148: nn.LSTM on the embedded label, state kept for rows whose last
+ * symbol is not a label) --------------------------------------------------------------------------------------
+ * A row's state is [h_0 | c_0 | h_1 | c_1 | ...] (layers * 2 * H floats), double-buffered like the transformer
+ * state: step s reads buffer s&1 and writes (s+1)&1.  For every row: parent pr = b*beam + prev_k[r];
+ * state_dst[r] = state_src[pr]; tok = y[r]; t_idx[r] += (tok == blk).  Rows with tok > blk get a SLOT in the compact
+ * row list (slot = count[s&1]++): rowmap[slot] = r; A[0][slot] = [emb[tok] (E) | h_0 of the parent (H)];
+ * A[l][slot, H:2H] = h_l of the parent for l > 0 (columns [0, H) of A[l > 0] are written by the cell kernel of layer
+ * l-1; pad columns up to lda[l] are never written: the caller zeroes them once).  The gate products of the step are
+ * then pika_dgemm(A[l], [W_ih | W_hh] packed, bias = b_ih + b_hh) on count rows. */
+typedef struct {
+    const long long *prev_k, *y, *step_t;
+    long long *t_idx;
+    float *state[2];         /* (rows, layers*2*H)                                                   */
+    const float *emb;        /* (vocab+1, E)                                                         */
+    float *A[PIKA_DSTEP_MAX_LAYERS];   /* (rows, lda[l]), lda[0] >= E+H, lda[l>0] >= 2H               */
+    long long lda[PIKA_DSTEP_MAX_LAYERS];
+    long long *rowmap;       /* (rows) output: slot -> row                                           */
+    int *count;              /* int32[2], as in pika_dstep_prep_t                                    */
+    int layers, rows, beam, H, E, blk;
+    const int *stop;
+} pika_dstep_prep_lstm_t;
+int pika_dstep_prep_lstm(const pika_dstep_prep_lstm_t *p, void *stream);
+
+/* gates (slot order, pitch ldg) = [i | f | g | o] pre-activations of layer `layer` (nn.LSTM order) for the first
+ * min(rows, *m_dev) slots -> c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c') written into the state
+ * row rowmap[slot] (pitch state_pitch, blocks 2*layer and 2*layer+1) and, when next_a != NULL, h' also into
+ * next_a[slot, 0:H) (pitch ld_next): the next layer's input row. */
+int pika_dstep_lstm_cell(const float *gates, long long ldg, float *state, long long state_pitch, int layer,
+                         const long long *rowmap, const int *m_dev, float *next_a, long long ld_next, int rows, int H,
+                         void *stream);
+
 /* ---- fc2 + log-sum-exp partials + per-row top-K partials -------------------------------------------------------
  * h (rows, K) f32, W packed (V, K).  Column range s of `splits` (= pika_dfc2_splits(V)) covers
  * [s*cols, (s+1)*cols), cols = pika_dfc2_cols_per_split().  For every row and range:

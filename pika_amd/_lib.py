@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -84,6 +84,8 @@ SIGNATURES = {
     "pika_dpack_weight": (_i, [_vp, _ll, _i, _i, _i, _i, _vp, _vp]),
     "pika_dgemm": (_i, [_vp, _vp]),
     "pika_dstep_prep": (_i, [_vp, _vp]),
+    "pika_dstep_prep_lstm": (_i, [_vp, _vp]),
+    "pika_dstep_lstm_cell": (_i, [_vp, _ll, _vp, _ll, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "pika_dstep_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pika_dfc2_splits": (_i, [_i]),
     "pika_dfc2_cols_per_split": (_i, []),

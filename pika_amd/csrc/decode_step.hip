@@ -343,6 +343,69 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     }
 }
 
+
+// ---- LSTM prediction network (trainer/model/transducer.py:55-61; decoder/transducer_decoder.py:139-148) --------
+// A row's state is [h_0 | c_0 | h_1 | c_1 | ...] (SP = layers * 2 * H floats), double-buffered like the transformer
+// state.  Every row follows its parent; rows that emitted a label get a slot in the compact row list and the input
+// rows of the layers' gate products: A[0][slot] = [emb(label) | h_0], A[l][slot] = [. | h_l] (the first block of
+// A[l > 0] is written by the cell kernel of layer l-1).
+__global__ __launch_bounds__(256) void dstep_prep_lstm_kernel(pika_dstep_prep_lstm_t p) {
+    if (p.stop && *p.stop) return;
+    __shared__ int slot_s;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const long long s = p.step_t[0];
+    const int src = (int)(s & 1), dst = src ^ 1;
+    const int b = r / p.beam;
+    const long long pr = (long long)b * p.beam + p.prev_k[r];
+    const long long tok = p.y[r];
+    const bool commit = tok > p.blk;
+    const long long SP = (long long)p.layers * 2 * p.H;
+    const float *ss = p.state[src] + pr * SP;
+    float *sd = p.state[dst] + (long long)r * SP;
+    for (long long c = tid * 4; c < SP; c += 1024) *reinterpret_cast<f32x4 *>(sd + c) = *reinterpret_cast<const f32x4 *>(ss + c);
+    if (tid == 0) {
+        if (tok == p.blk) p.t_idx[r] += 1;                       // :129
+        slot_s = commit ? atomicAdd(p.count + src, 1) : -1;
+    }
+    __syncthreads();
+    if (!commit) return;
+    const int slot = slot_s;
+    if (tid == 0) p.rowmap[slot] = r;
+    float *a0 = p.A[0] + (long long)slot * p.lda[0];
+    for (int c = tid; c < p.E; c += 256) a0[c] = p.emb[tok * p.E + c];
+    for (int c = tid; c < p.H; c += 256) a0[p.E + c] = ss[c];
+    for (int l = 1; l < p.layers; ++l) {
+        float *al = p.A[l] + (long long)slot * p.lda[l] + p.H;
+        const float *hl = ss + (long long)l * 2 * p.H;
+        for (int c = tid; c < p.H; c += 256) al[c] = hl[c];
+    }
+}
+
+// gates (slot order, [i | f | g | o], nn.LSTM order) -> c', h' of layer `layer` in the state row of the slot's beam
+// row; h' also becomes the first block of the next layer's input row.  libm-grade tanh / exp: the arg-max decisions
+// of the search sit downstream.
+__global__ __launch_bounds__(256) void dstep_lstm_cell_kernel(const float *__restrict__ gates, long long ldg,
+                                                              float *__restrict__ state, long long SP, int layer,
+                                                              const long long *__restrict__ rowmap,
+                                                              const int *__restrict__ m_dev, float *__restrict__ next_a,
+                                                              long long ld_next, int rows, int H) {
+    const int slot = blockIdx.y;
+    const int m = m_dev ? min(rows, *m_dev) : rows;
+    if (slot >= m) return;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    const long long row = rowmap[slot];
+    const float *g = gates + (long long)slot * ldg + c;
+    float *hp = state + row * SP + (long long)layer * 2 * H + c, *cp = hp + H;
+    const float gi = g[0], gf = g[H], gg = g[2 * (long long)H], go = g[3 * (long long)H];
+    const float si = 1.0f / (1.0f + expf(-gi)), sf = 1.0f / (1.0f + expf(-gf)), so = 1.0f / (1.0f + expf(-go));
+    const float cn = sf * cp[0] + si * tanhf(gg);
+    const float h = so * tanhf(cn);
+    cp[0] = cn;
+    hp[0] = h;
+    if (next_a) next_a[(long long)slot * ld_next + c] = h;
+}
+
 // ---- self-attention of the new position over the cached prefix (see decode.hip incr_attn_kernel) -------------
 // One workgroup per COMPACT row (slot); thread t owns dims [4t, 4t+4) of the d <= 1024 wide vectors (TPG = d/4
 // threads), the G = 256 / TPG thread groups take prefix positions round-robin.  Every prefix position is a separate
@@ -592,6 +655,30 @@ int pika_dstep_prep(const pika_dstep_prep_t *q, void *stream) {
         return PIKA_EINVAL;
     PrepDev a{*q};
     hipLaunchKernelGGL(dstep_prep_kernel, dim3(q->rows), dim3(256), 0, (hipStream_t)stream, a);
+    return check(hipGetLastError());
+}
+
+
+int pika_dstep_prep_lstm(const pika_dstep_prep_lstm_t *q, void *stream) {
+    if (!q || q->rows <= 0 || q->layers < 1 || q->layers > PIKA_DSTEP_MAX_LAYERS || q->beam <= 0 || q->H <= 0 || q->E <= 0 ||
+        (q->H & 3))
+        return PIKA_EINVAL;
+    if (!q->prev_k || !q->y || !q->step_t || !q->t_idx || !q->state[0] || !q->state[1] || !q->emb || !q->rowmap || !q->count)
+        return PIKA_EINVAL;
+    for (int l = 0; l < q->layers; ++l)
+        if (!q->A[l] || q->lda[l] < (l == 0 ? q->E + q->H : 2 * q->H)) return PIKA_EINVAL;
+    hipLaunchKernelGGL(dstep_prep_lstm_kernel, dim3(q->rows), dim3(256), 0, (hipStream_t)stream, *q);
+    return check(hipGetLastError());
+}
+
+int pika_dstep_lstm_cell(const float *gates, long long ldg, float *state, long long state_pitch, int layer,
+                         const long long *rowmap, const int *m_dev, float *next_a, long long ld_next, int rows, int H,
+                         void *stream) {
+    if (!gates || !state || !rowmap || rows <= 0 || H <= 0 || layer < 0 || ldg < 4LL * H ||
+        state_pitch < (long long)(layer + 1) * 2 * H)
+        return PIKA_EINVAL;
+    hipLaunchKernelGGL(dstep_lstm_cell_kernel, dim3((H + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, gates, ldg,
+                       state, state_pitch, layer, rowmap, m_dev, next_a, ld_next, rows, H);
     return check(hipGetLastError());
 }
 

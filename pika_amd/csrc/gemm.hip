@@ -399,7 +399,11 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     int splitk = 1;
     static const int min_nk = [] { const char *e = getenv("PIKA_GEMM_SPLIT_MIN_NK"); return e ? atoi(e) : 32; }();
     static const int per_split = [] { const char *e = getenv("PIKA_GEMM_SPLIT_MIN_PER"); return e ? atoi(e) : 8; }();
-    if (batch == 1 && tiles < 256 && nk >= min_nk && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
+    // exact-mode products with the reduction contiguous (forward products: the decode path) never split: the split
+    // sums through float atomics, whose order -- and with it the last bit of the encoder output, and near-ties of a
+    // beam search downstream -- changes from run to run.  Weight gradients (both operands reduction-major) keep it.
+    const bool exact_forward = (flags & PIKA_GEMM_FP32SPLIT) && !TRA && !TRB;
+    if (batch == 1 && tiles < 256 && nk >= min_nk && !exact_forward && !(flags & (PIKA_GEMM_RELU | PIKA_GEMM_ACCUMULATE))) {
         // One resident workgroup per CU.  Cost of split s in K-tile units: rounds of 256 workgroups x
         // (K-tiles per workgroup + ~40 of prologue/epilogue) + ~6 per atomic pass over C; the minimum
         // reproduces the measured optimum on every shape of tools/dw_bench.py

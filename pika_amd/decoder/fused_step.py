@@ -43,6 +43,12 @@ class DPrep(ctypes.Structure):
                 ("stop", _vp)]
 
 
+class DPrepLSTM(ctypes.Structure):
+    _fields_ = [("prev_k", _vp), ("y", _vp), ("step_t", _vp), ("t_idx", _vp), ("state", _vp * 2), ("emb", _vp),
+                ("A", _vp * MAX_LAYERS), ("lda", _ll * MAX_LAYERS), ("rowmap", _vp), ("count", _vp),
+                ("layers", _i), ("rows", _i), ("beam", _i), ("H", _i), ("E", _i), ("blk", _i), ("stop", _vp)]
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -52,20 +58,31 @@ def _stream():
 
 
 def supported(model, beam, K):
-    """Transformer prediction net on a HIP device, shapes the kernels take."""
+    """Conv-transformer or LSTM prediction net on a HIP device, shapes the kernels take."""
     dec = getattr(model, "decoder", None)
-    if model.decoder_type == "rnn" or dec is None or not hasattr(dec, "conv") or not beam.fused_ok():
+    if dec is None or not beam.fused_ok():
+        return False
+    splits = _lib.lib().pika_dfc2_splits(model.output_dim)
+    lds = K * beam.hyp.shape[2] * 4 + K * K * 8 + 4 * splits * K * 8        # pika_beam_advance_partials
+    if splits > 64 or splits * K > 1024 or lds > 96 * 1024 or K > 64 or model.hid_dim % 4:
+        return False
+    if model.decoder_type == "rnn":
+        return (isinstance(dec, torch.nn.LSTM) and not dec.bidirectional and dec.batch_first and dec.bias
+                and getattr(dec, "proj_size", 0) == 0 and dec.num_layers <= MAX_LAYERS and dec.hidden_size == model.hid_dim
+                and model.hid_dim % 32 == 0)      # the joint product reads h in place: whole 32-column K blocks
+    if not hasattr(dec, "conv"):
         return False
     d = dec.layer_norm.normalized_shape[0]
     heads = dec.transformer[0].self_attn.head_count
     dh = d // heads
     g = dh // 4
-    splits = _lib.lib().pika_dfc2_splits(model.output_dim)
-    lds = K * beam.hyp.shape[2] * 4 + K * K * 8 + 4 * splits * K * 8        # pika_beam_advance_partials
-    if splits > 64 or splits * K > 1024 or lds > 96 * 1024:
-        return False
     return (len(dec.conv) <= MAX_LAYERS and d % 4 == 0 and d <= 1024 and 256 % (d // 4) == 0 and dh % 4 == 0
-            and 1 <= g <= 64 and (g & (g - 1)) == 0 and K <= 64 and model.hid_dim % 4 == 0)
+            and 1 <= g <= 64 and (g & (g - 1)) == 0)
+
+
+def make(model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms=3):
+    cls = FusedSearchLSTM if model.decoder_type == "rnn" else FusedSearch
+    return cls(model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms)
 
 
 class PackedWeight(object):
@@ -86,9 +103,10 @@ def _ceil(a, b):
 class FusedSearch(object):
     """Device state + the launch chain of one step for a conv-transformer prediction net."""
 
-    def __init__(self, model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms=3):
+    def _init_common(self, model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms):
+        """What every prediction net shares: beam bookkeeping buffers, the joint's prediction halves and fc2 (packed
+        once), the partial buffers of the fc2 / advance pair."""
         self.model, self.beam = model, beam
-        net = model.decoder
         dev = e_all.device
         self.dev = dev
         B, K = beam.B, beam.K
@@ -98,6 +116,35 @@ class FusedSearch(object):
         self.terms = int(terms)
         self.sm_scale, self.lm_scale = float(sm_scale), float(lm_scale)
         self.e_all, self.num_frames = e_all.contiguous(), num_frames
+        f32 = dict(dtype=torch.float32, device=dev)
+        i64 = dict(dtype=torch.long, device=dev)
+        self.node = torch.zeros(R, **i64)          # per SLOT of the compact list of rows that emitted a label
+        self.rowmap = torch.arange(R, device=dev)  # slot -> row
+        self.t_idx = torch.full((B, K), -1, **i64)                                  # :107
+        self.prev_k = torch.arange(K, device=dev).repeat(B).contiguous()            # identity parents for step 0
+        self.stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sync = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.max_hyp = torch.zeros(1, **i64)
+        self.eos_u8 = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.h = torch.empty(R, self.H, **f32)
+        lib = _lib.lib()
+        self.splits = lib.pika_dfc2_splits(self.V)
+        self.pmax = torch.empty(R * self.splits, **f32)
+        self.psum = torch.empty(R * self.splits, **f32)
+        self.pcand = torch.empty(R * self.splits * K * 8, dtype=torch.uint8, device=dev)
+        H = self.H
+        wp = torch.cat((model.fc1.weight[:, H:], model.fc_gate.weight[:, H:]), dim=0)   # (2H, H) prediction halves
+        self.wp = PackedWeight(wp, self.terms, interleave2=True)
+        self.w2 = PackedWeight(model.fc2.weight, self.terms)
+        self.b2 = model.fc2.bias.detach().float().contiguous()
+        self.dump_node = 0
+        self.graph = None
+
+    def __init__(self, model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms=3):
+        self._init_common(model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms)
+        net = model.decoder
+        dev = self.dev
+        B, K, R = self.B, self.K, self.rows
         self.nl = len(net.conv)
         d = net.layer_norm.normalized_shape[0]
         self.d, self.heads = d, net.transformer[0].self_attn.head_count
@@ -115,15 +162,7 @@ class FusedSearch(object):
         self.A = [torch.zeros(R, w, **f32) for w in self.lda]
         self.state = [torch.zeros(R, self.H, **f32) for _ in range(2)]
         self.anc = [torch.full((R, self.L), self.dump_node, **i64) for _ in range(2)]
-        self.node = torch.zeros(R, **i64)          # per SLOT of the compact list of rows that emitted a label
         self.pos = torch.zeros(R, **i64)
-        self.rowmap = torch.arange(R, device=dev)  # slot -> row
-        self.t_idx = torch.full((B, K), -1, **i64)                                  # :107
-        self.prev_k = torch.arange(K, device=dev).repeat(B).contiguous()            # identity parents for step 0
-        self.stop = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.sync = torch.zeros(8, dtype=torch.int32, device=dev)
-        self.max_hyp = torch.zeros(1, **i64)
-        self.eos_u8 = torch.zeros(B, dtype=torch.uint8, device=dev)
         # activations of one step
         self.y_conv = torch.empty(R, d, **f32)
         self.ln = torch.empty(R, d, **f32)
@@ -133,14 +172,8 @@ class FusedSearch(object):
         dff = net.transformer[0].feed_forward.w_1.weight.shape[0]
         self.hmid = torch.empty(R, dff, **f32)
         self.xfin = torch.empty(R, d, **f32)
-        self.h = torch.empty(R, self.H, **f32)
         self.mean = torch.empty(R, **f32)
         self.rstd = torch.empty(R, **f32)
-        lib = _lib.lib()
-        self.splits = lib.pika_dfc2_splits(self.V)
-        self.pmax = torch.empty(R * self.splits, **f32)
-        self.psum = torch.empty(R * self.splits, **f32)
-        self.pcand = torch.empty(R * self.splits * K * 8, dtype=torch.uint8, device=dev)
         # weights, packed once
         t = self.terms
         self.layers = []
@@ -158,13 +191,7 @@ class FusedSearch(object):
                 w2=PackedWeight(ff.w_2.weight, t), b2=ff.w_2.bias.detach().float().contiguous()))
         self.wout = PackedWeight(net.linear_out.weight, t)
         self.bout = net.linear_out.bias.detach().float().contiguous()
-        H = self.H
-        wp = torch.cat((model.fc1.weight[:, H:], model.fc_gate.weight[:, H:]), dim=0)   # (2H, H) prediction halves
-        self.wp = PackedWeight(wp, t, interleave2=True)
-        self.w2 = PackedWeight(model.fc2.weight, t)
-        self.b2 = model.fc2.bias.detach().float().contiguous()
         self.emb = net.embeddings.weight.detach().float().contiguous()
-        self.graph = None
         self._init_sos()
 
     # ---- launches ------------------------------------------------------------------------------------------
@@ -249,28 +276,33 @@ class FusedSearch(object):
 
     def step_launches(self, parity):
         """Enqueue one search step that reads state/anc buffer `parity` (= steps taken & 1)."""
-        lib = _lib.lib()
-        b = self.beam
         dst = parity ^ 1
         with torch.cuda.device(self.dev):
             self._prep(parity)
             self._prednet(self.anc[dst], self.state[dst], self.sync[5 + parity:6 + parity])
-            self._gemm(self.state[dst], self.H, self.wp, None, self.h, self.H, self.rows, gate=True)
-            _lib.check(lib.pika_dfc2_topk(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
-                                          self.V, self.H, self.terms, self.sm_scale, self.K, self.pmax.data_ptr(),
-                                          self.psum.data_ptr(), self.pcand.data_ptr(), _stream()), "pika_dfc2_topk")
-            fst = b.fst_dev
-            _lib.check(lib.pika_beam_advance_partials(
-                self.pmax.data_ptr(), self.psum.data_ptr(), self.pcand.data_ptr(), self.splits, b.scores.data_ptr(),
-                b.lm_scores.data_ptr(), self.lm_scale, b.y.data_ptr(), self.t_idx.data_ptr(), self.num_frames.data_ptr(),
-                b.max_len.data_ptr(), b.hyp.data_ptr(), b.hyp_len.data_ptr(), b.hyp.shape[2], b.ks_hist.data_ptr(),
-                b.ys_hist.data_ptr(), b.step_t.data_ptr(), self.eos_u8.data_ptr(), b.fin_score.data_ptr(),
-                b.fin_step.data_ptr(), b.fin_k.data_ptr(), b.fin_n.data_ptr(), b.fin_cap, self.prev_k.data_ptr(),
-                None if fst is None else fst["y_raw"].data_ptr(), self.B, self.K, self.V, b.blk, int(b.beam_prune),
-                b.n_best, self.stop.data_ptr(), self.max_hyp.data_ptr(), self.sync.data_ptr(), _stream()),
-                "pika_beam_advance_partials")
-            if fst is not None:
-                b._fst_advance_device(self.prev_k.view(self.B, self.K), self.lm_scale, skip=self.sync[4:5])
+            self._joint_and_advance(self.state[dst], self.H)
+
+    def _joint_and_advance(self, dec_hid, lda):
+        """dec_hid (rows, H) with pitch lda: prediction halves of fc1 / fc_gate with the gate in the epilogue -> fc2
+        with log-sum-exp + top-K partials -> advance from the partials (+ device FST advance)."""
+        lib = _lib.lib()
+        b = self.beam
+        self._gemm(dec_hid, lda, self.wp, None, self.h, self.H, self.rows, gate=True)
+        _lib.check(lib.pika_dfc2_topk(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
+                                      self.V, self.H, self.terms, self.sm_scale, self.K, self.pmax.data_ptr(),
+                                      self.psum.data_ptr(), self.pcand.data_ptr(), _stream()), "pika_dfc2_topk")
+        fst = b.fst_dev
+        _lib.check(lib.pika_beam_advance_partials(
+            self.pmax.data_ptr(), self.psum.data_ptr(), self.pcand.data_ptr(), self.splits, b.scores.data_ptr(),
+            b.lm_scores.data_ptr(), self.lm_scale, b.y.data_ptr(), self.t_idx.data_ptr(), self.num_frames.data_ptr(),
+            b.max_len.data_ptr(), b.hyp.data_ptr(), b.hyp_len.data_ptr(), b.hyp.shape[2], b.ks_hist.data_ptr(),
+            b.ys_hist.data_ptr(), b.step_t.data_ptr(), self.eos_u8.data_ptr(), b.fin_score.data_ptr(),
+            b.fin_step.data_ptr(), b.fin_k.data_ptr(), b.fin_n.data_ptr(), b.fin_cap, self.prev_k.data_ptr(),
+            None if fst is None else fst["y_raw"].data_ptr(), self.B, self.K, self.V, b.blk, int(b.beam_prune),
+            b.n_best, self.stop.data_ptr(), self.max_hyp.data_ptr(), self.sync.data_ptr(), _stream()),
+            "pika_beam_advance_partials")
+        if fst is not None:
+            b._fst_advance_device(self.prev_k.view(self.B, self.K), self.lm_scale, skip=self.sync[4:5])
 
     def launches_per_step(self):
         return 1 + 8 * self.nl + 2 + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
@@ -281,3 +313,92 @@ class FusedSearch(object):
         src = self.state[steps & 1]
         flat = (torch.arange(self.B, device=self.dev).unsqueeze(1) * self.K + self.prev_k.view(self.B, self.K)).reshape(-1)
         return src.index_select(0, flat), self.t_idx
+
+
+class FusedSearchLSTM(FusedSearch):
+    """The same chain for the LSTM prediction net of the shipped recipes (`dec_type=rnn`; trainer/model/transducer.py
+    :55-61, stepped by decoder/transducer_decoder.py:139-148):
+
+        prep (state follows the parent; rows that emitted a label get a slot and their [emb | h] input rows)
+          -> per layer: gates = [x | h] . [W_ih | W_hh]^T + (b_ih + b_hh) on the compact rows -> cell kernel (c', h' into
+             the rows' state; h' is also the first block of the next layer's input row)
+          -> prediction halves of fc1 / fc_gate with the gate in the epilogue (reads h of the last layer in place)
+          -> fc2 with log-sum-exp + top-K partials -> advance
+
+    4 + 2 * layers launches per step (8 for the recipe's two layers) against 22 for the conv-transformer net."""
+
+    def __init__(self, model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms=3):
+        self._init_common(model, beam, e_all, T, num_frames, sm_scale, lm_scale, terms)
+        rnn = model.decoder
+        dev, R, H = self.dev, self.rows, self.H
+        self.nl = rnn.num_layers
+        self.E = model.embed.embedding_dim
+        self.SP = self.nl * 2 * H
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.state = [torch.zeros(R, self.SP, **f32) for _ in range(2)]
+        self.lda = [_ceil(self.E + H, 32)] + [_ceil(2 * H, 32)] * (self.nl - 1)
+        self.A = [torch.zeros(R, w, **f32) for w in self.lda]          # pad columns stay zero
+        self.gates = torch.empty(R, 4 * H, **f32)
+        self.emb = model.embed.weight.detach().float().contiguous()
+        self.Wl, self.bl = [], []
+        for l in range(self.nl):
+            w = torch.cat([getattr(rnn, "weight_ih_l%d" % l), getattr(rnn, "weight_hh_l%d" % l)], 1)
+            self.Wl.append(PackedWeight(w, self.terms))
+            self.bl.append((getattr(rnn, "bias_ih_l%d" % l) + getattr(rnn, "bias_hh_l%d" % l)).detach().float().contiguous())
+        self._init_sos()
+
+    def _layers(self, state_dst, count):
+        lib = _lib.lib()
+        R, H = self.rows, self.H
+        for l in range(self.nl):
+            self._gemm(self.A[l], self.lda[l], self.Wl[l], self.bl[l], self.gates, 4 * H, R, m_dev=count)
+            nxt = self.A[l + 1] if l + 1 < self.nl else None
+            _lib.check(lib.pika_dstep_lstm_cell(self.gates.data_ptr(), 4 * H, state_dst.data_ptr(), self.SP, l,
+                                                self.rowmap.data_ptr(), count.data_ptr(), _ptr(nxt),
+                                                0 if nxt is None else self.lda[l + 1], R, H, _stream()),
+                       "pika_dstep_lstm_cell")
+
+    def _init_sos(self):
+        """Every row starts from the state the LSTM reaches on the SOS / blank token from zeros
+        (transducer_decoder.py:116-117)."""
+        R = self.rows
+        with torch.cuda.device(self.dev):
+            self.A[0][:, :self.E] = self.emb[self.beam.blk].unsqueeze(0)
+            self.sync[5] = R                # every row is in the compact list (identity rowmap) for this one pass
+            self._layers(self.state[0], self.sync[5:6])
+            self.sync[5] = 0
+
+    def _prep(self, parity):
+        p = DPrepLSTM()
+        b = self.beam
+        p.prev_k, p.y, p.step_t = self.prev_k.data_ptr(), b.y.data_ptr(), b.step_t.data_ptr()
+        p.t_idx = self.t_idx.data_ptr()
+        for i in range(2):
+            p.state[i] = self.state[i].data_ptr()
+        p.emb = self.emb.data_ptr()
+        for l in range(self.nl):
+            p.A[l], p.lda[l] = self.A[l].data_ptr(), self.lda[l]
+        p.rowmap = self.rowmap.data_ptr()
+        p.count = self.sync[5:7].data_ptr()
+        p.layers, p.rows, p.beam, p.H, p.E, p.blk = self.nl, self.rows, self.K, self.H, self.E, b.blk
+        p.stop = self.stop.data_ptr()
+        _lib.check(_lib.lib().pika_dstep_prep_lstm(ctypes.byref(p), _stream()), "pika_dstep_prep_lstm")
+
+    def step_launches(self, parity):
+        dst = parity ^ 1
+        with torch.cuda.device(self.dev):
+            self._prep(parity)
+            self._layers(self.state[dst], self.sync[5 + parity:6 + parity])
+            top = self.state[dst][:, (self.nl - 1) * 2 * self.H:]                 # h of the last layer, in place
+            self._joint_and_advance(top, self.SP)
+
+    def launches_per_step(self):
+        return 1 + 2 * self.nl + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
+
+    def final_state(self, steps):
+        """(h, c) as nn.LSTM keeps them, (layers, rows, H) each, in beam order after the last step, and the frame
+        indices (transducer_decoder.py:107,116-117,188-202)."""
+        src = self.state[steps & 1]
+        flat = (torch.arange(self.B, device=self.dev).unsqueeze(1) * self.K + self.prev_k.view(self.B, self.K)).reshape(-1)
+        st = src.index_select(0, flat).view(self.rows, self.nl, 2, self.H)
+        return (st[:, :, 0].transpose(0, 1).contiguous(), st[:, :, 1].transpose(0, 1).contiguous()), self.t_idx

@@ -139,7 +139,7 @@ class TransducerDecoder(object):
         wp = torch.cat((w1p, wgp), dim=0).contiguous()                            # (2H, H)
         brow = (torch.arange(B, device=dev) * T).unsqueeze(1)
 
-        if enc_out.is_cuda and self.fused_search and self.fused_step and not rnn:
+        if enc_out.is_cuda and self.fused_search and self.fused_step:
             from . import fused_step
             if fused_step.supported(model, beam, K) and (self.lm_scorer is None or beam.fst_dev is not None):
                 return self._search_fused(beam, e_all, T, num_frames, enc_out, x, x_len, max_len)
@@ -231,9 +231,9 @@ def _search_fused(self, beam, e_all, T, num_frames, enc_out, x, x_len, max_len):
     """The search loop on the fixed launch chain of fused_step.FusedSearch: two steps (the double-buffered
     prediction-net state alternates) per hipGraph, `replays_per_sync` replays per host read."""
     import time as _time
-    from .fused_step import FusedSearch
+    from . import fused_step
     _t0 = _time.perf_counter()
-    fs = FusedSearch(self.model, beam, e_all, T, num_frames, self.sm_scale, self.lm_scorer_scale, terms=self.decode_terms)
+    fs = fused_step.make(self.model, beam, e_all, T, num_frames, self.sm_scale, self.lm_scorer_scale, terms=self.decode_terms)
     fs.step_launches(0)
     fs.step_launches(1)
     graph, n_replays = None, 0

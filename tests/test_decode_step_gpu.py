@@ -176,10 +176,12 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
     assert torch.allclose(a["fin_score"], b["fin_score"], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("pred_net", ["transformer", "rnn"])
 @pytest.mark.parametrize("dec_terms", ["fp32", "bf16"])
-def test_fused_search_equals_stepwise_search(hip_device, dec_terms):
+def test_fused_search_equals_stepwise_search(hip_device, dec_terms, pred_net):
     """The launch-chain search (hipGraph, several steps per host read) and the op-by-op search return the same
-    n-best lists for the tiny golden model, with and without graph replay."""
+    n-best lists for the tiny golden model, with and without graph replay -- conv-transformer prediction net (22
+    launches per step) and the LSTM prediction net of the shipped recipes (4 + 2 per layer)."""
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
     from types import SimpleNamespace
@@ -187,7 +189,8 @@ def test_fused_search_equals_stepwise_search(hip_device, dec_terms):
     from test_decode import build
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
-    net = build("transformer", hip_device)
+    net = build(pred_net, hip_device)
+    want_launches = 22 if pred_net == "transformer" else 4 + 2 * net.decoder.num_layers
     x, x_len = D.inputs()
     x, x_len_d = x.to(hip_device), x_len.to(hip_device)
     args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
@@ -201,7 +204,7 @@ def test_fused_search_equals_stepwise_search(hip_device, dec_terms):
             ret, _ = d.decode_batch(x, x_len_d, D.max_len(cfg, x_len))
             outs.append(D.pack(ret["predictions"], ret["scores"]))
             if fused:
-                assert d.timing["launches_per_step"] == 22 and d.timing["steps"] > 5
+                assert d.timing["launches_per_step"] == want_launches and d.timing["steps"] > 5
         if dec_terms == "fp32":
             for o in outs[1:]:
                 assert np.array_equal(o["hyps"], outs[0]["hyps"]) and np.array_equal(o["lens"], outs[0]["lens"]), name
