@@ -276,12 +276,37 @@ class Net(nn.Module):
                                            opt.global_attention, opt.coverage_attn, opt.context_gate,
                                            opt.copy_attn, opt.dropout, self.tgt_embeddings)
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_enc_cache"] = None          # the memo of the last scoring call is not part of a checkpoint
+        return state
+
     def forward(self, src, tgt, lengths, dec_state=None, enable_dec=True, enable_enc=True):
         if not enable_enc or not enable_dec or dec_state is not None:
             raise NotImplementedError("LAS training/pre-training paths are out of scope (SURVEY 2.1)")
         tgt = tgt[:-1]                                               # las.py:66 (exclude EOS)
-        enc_hidden, enc_out = self.encoder(src, lengths)
-        out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
+        if not torch.is_grad_enabled():
+            # the rescoring loop of decode_transducer.py:136-156 calls this for every n-best entry and direction of the
+            # SAME utterance: keep the last encoder pass (keyed by the storage, shape and version of src)
+            key = (src.data_ptr(), tuple(src.shape), src._version, src.device, tuple(int(v) for v in torch.as_tensor(lengths).view(-1)))
+            hit = getattr(self, "_enc_cache", None)
+            if hit is not None and hit[0] == key and not self.training:
+                enc_hidden, enc_out = hit[1]
+            else:
+                enc_hidden, enc_out = self.encoder(src, lengths)
+                self._enc_cache = (key, (enc_hidden, enc_out))
+        else:
+            self._enc_cache = None
+            enc_hidden, enc_out = self.encoder(src, lengths)
+        if not torch.is_grad_enabled() and enc_out.is_cuda:
+            # scoring (decoder/transducer_decoder.py:219-253 calls this once per hypothesis): the per-token kernel chain,
+            # every column its own utterance
+            n = enc_out.shape[1]
+            ln = torch.as_tensor(lengths).to(device=enc_out.device, dtype=torch.long).view(-1)
+            out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden,
+                                      owner=torch.arange(n, device=enc_out.device), lens=ln)
+        else:
+            out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
         return out, None, None, enc_out
 
     def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale):

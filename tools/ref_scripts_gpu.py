@@ -2,7 +2,8 @@
 """Runs the UNCHANGED reference scripts on the MI355X through `python -m pika_amd.launch` with NO preload:
 trainer/train_transducer_bmuf_otfaug.py (1 epoch x 20 batches of a synthetic corpus, full-width model, HIP loader,
 HIP RNN-T loss, BMUF with the RCCL backend) and then decoder/decode_transducer.py on the checkpoint it wrote
-(command line of egs/eval_transducer.sh:74-101 without the optional LM / rescorers).
+(command line of egs/eval_transducer.sh:74-101 with forward + backward LAS rescorers -- randomly initialised 2-layer BLSTM
+1024 / mlp-attention models pickled like trained ones -- and without the optional FST LM).
 
 The scripts are NOT part of this repository: `stage` copies the two files from /root/reference into the git-ignored
 scratch directory _ref_scratch/ (so that they travel with the gpurun snapshot), `clean` removes it again.
@@ -80,11 +81,23 @@ def run(outdir):
     kaldi_io.write_matrix_ark(str(work / "feats.ark"), utts)
     kaldi_io.write_int_vectors(str(work / "labels.ark"), [(k, np.array([1, 2, 3])) for k, _ in utts], binary=False)
     (work / "sym.map").write_text("".join("s%d %d\n" % (i, i) for i in range(V + 1)))
+    # forward / backward LAS rescorers as whole-module pickles (what train_las_bmuf_otfaug.py writes)
+    import torch
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    from model import las
+    lopt = SimpleNamespace(rnn_size=1024, encoder_type="rnn", rnn_type="LSTM", brnn=True, enc_layers=2, dropout=0.0,
+                           use_downsampler=False, embd_dim=100, num_heads=1, sampling_decoder=False, input_feed=1,
+                           dec_layers=2, global_attention="mlp", coverage_attn=False, context_gate=None, copy_attn=False)
+    for seed, name in ((3, "las.mdl"), (4, "las_bw.mdl")):
+        torch.manual_seed(seed)
+        torch.save(las.Net(lopt, 1024, V + 1, V + 1), str(work / name))
     decode = [sys.executable, "-m", "pika_amd.launch", os.path.join(SCRATCH, FILES[1]),
               "--verbose", "--cuda", "--min_len", "50", "--blk", "0", "--batch_first", "--beam_size", "8", "--output_scores",
               "--sm_scale", "0.8", "--batch_size", "8", "--n_best", "4", "--SOS", "0", "--EOS", str(V), "--padding_idx", str(V),
               "--loader", "utt", "--lctx", "1", "--rctx", "1", "--feats_dim", "80", "--model_lctx", "21", "--model_rctx", "21",
-              "--model_stride", "4", "--symbols_map", str(work / "sym.map"), str(model),
+              "--model_stride", "4", "--las_rescorer_model", str(work / "las.mdl"), "--las_rescorer_bw_model", str(work / "las_bw.mdl"),
+              "--symbols_map", str(work / "sym.map"), str(model),
               "ark:" + str(work / "feats.ark"), "ark:" + str(work / "labels.ark"), str(out / "hyp.txt")]
     prof = ["rocprofv3", "--kernel-trace", "--stats", "-d", str(out / "prof_decode"), "-o", "decode", "--"]
     r = subprocess.run(prof + decode, env=env, cwd=str(work), capture_output=True, text=True)
