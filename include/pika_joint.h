@@ -50,6 +50,13 @@ int pika_log_softmax_bwd_rows_bf16(const float *lp, const float *g, void *out, l
 int pika_mbr_risk_grad_rows(float *lp, const int *sym, const float *val, long long rows, int cols,
                             long long ld, float scale, void *stream);
 
+/* Levenshtein distances of the N-best against their references (reference: editdistance.eval(hyp, ref) once per
+ * hypothesis, trainer/train_transducer_mbr_bmuf_otfaug.py:186-190 -- editdistance==0.5.2, requirements.txt:1).
+ * HOST function (no device work, no stream): pair i compares the int32 sequences seqs[a_off[i] .. a_off[i] + a_len[i])
+ * and seqs[b_off[i] .. b_off[i] + b_len[i]); out[i] = minimum number of insertions, deletions and substitutions. */
+int pika_edit_distances(const int *seqs, const long long *a_off, const int *a_len, const long long *b_off,
+                        const int *b_len, int n_pairs, int *out);
+
 #ifdef __cplusplus
 }
 #endif

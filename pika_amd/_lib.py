@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "pika_log_softmax_bwd_rows": (_i, [_vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_log_softmax_bwd_rows_bf16": (_i, [_vp, _vp, _vp, _ll, _i, _ll, _ll, ctypes.c_float, _vp]),
     "pika_mbr_risk_grad_rows": (_i, [_vp, _vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
+    "pika_edit_distances": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     # include/pika_norm.h
     "pika_layer_norm_fwd": (_i, [_vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp]),
     "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -444,3 +444,33 @@ int pika_log_softmax_bwd_rows_bf16(const float *lp, const float *g, void *out, l
 }
 
 }  // extern "C"
+
+// host-side Levenshtein distances (include/pika_joint.h): two rolling rows per pair
+extern "C" int pika_edit_distances(const int *seqs, const long long *a_off, const int *a_len, const long long *b_off,
+                                   const int *b_len, int n_pairs, int *out) {
+    if (!seqs || !a_off || !a_len || !b_off || !b_len || !out || n_pairs < 0) return PIKA_EINVAL;
+    int cap = 0;
+    for (int i = 0; i < n_pairs; ++i) {
+        if (a_len[i] < 0 || b_len[i] < 0) return PIKA_EINVAL;
+        if (b_len[i] > cap) cap = b_len[i];
+    }
+    int *row = new int[2 * (size_t)(cap + 1)];
+    for (int i = 0; i < n_pairs; ++i) {
+        const int *a = seqs + a_off[i], *b = seqs + b_off[i];
+        const int na = a_len[i], nb = b_len[i];
+        int *prev = row, *cur = row + cap + 1;
+        for (int j = 0; j <= nb; ++j) prev[j] = j;
+        for (int x = 1; x <= na; ++x) {
+            cur[0] = x;
+            for (int j = 1; j <= nb; ++j) {
+                const int sub = prev[j - 1] + (a[x - 1] != b[j - 1]);
+                const int del = prev[j] + 1, ins = cur[j - 1] + 1;
+                cur[j] = sub < del ? (sub < ins ? sub : ins) : (del < ins ? del : ins);
+            }
+            int *t = prev; prev = cur; cur = t;
+        }
+        out[i] = prev[nb];
+    }
+    delete[] row;
+    return PIKA_OK;
+}

@@ -12,11 +12,38 @@ halves (encoder half computed once per utterance, not per hypothesis); the dense
 never exists -- `RiskFn` returns the surrogate  sum_rows val * log_softmax(scale*logits)[row, sym]
 and its backward writes d/dlogits in place with one HIP kernel (pika_mbr_risk_grad_rows).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import _lib
 from .model import ops
+
+
+def _ints(h):
+    """A hypothesis as a list of ints: the decoder hands back lists of 0-dim tensors (what the reference's scripts
+    index), one conversion per hypothesis instead of one per symbol."""
+    if len(h) and torch.is_tensor(h[0]):
+        return torch.stack(list(h)).tolist()
+    return [int(e) for e in h]
+
+
+def edit_distances(pairs):
+    """Levenshtein distance of every (a, b) pair of int sequences in ONE library call (pika_edit_distances: host
+    code of libpika_amd.so; the reference calls editdistance.eval per hypothesis)."""
+    if not pairs:
+        return []
+    flat, a_off, a_len, b_off, b_len = [], [], [], [], []
+    for a, b in pairs:
+        a_off.append(len(flat)); a_len.append(len(a)); flat.extend(a)
+        b_off.append(len(flat)); b_len.append(len(b)); flat.extend(b)
+    seqs = np.asarray(flat if flat else [0], dtype=np.int32)
+    ao, bo = np.asarray(a_off, dtype=np.int64), np.asarray(b_off, dtype=np.int64)
+    al, bl = np.asarray(a_len, dtype=np.int32), np.asarray(b_len, dtype=np.int32)
+    out = np.zeros(len(pairs), dtype=np.int32)
+    _lib.check(_lib.lib().pika_edit_distances(seqs.ctypes.data, ao.ctypes.data, al.ctypes.data, bo.ctypes.data,
+                                              bl.ctypes.data, len(pairs), out.ctypes.data), "pika_edit_distances")
+    return out.tolist()
 
 
 def edit_distance(a, b):
@@ -70,9 +97,11 @@ def risk_terms(hyps, scores, targets, target_lens, blk, device):
     seq_grad (B,beam) and the blank-free hypotheses."""
     B, beam = len(hyps), len(hyps[0])
     prob = F.softmax(torch.tensor([[float(s) for s in row] for row in scores], device=device), dim=1)
-    nonblk = [[[int(e) for e in h if int(e) != blk] for h in row] for row in hyps]
-    dist = torch.tensor([[float(edit_distance(targets[b][:int(target_lens[b])].tolist(), nonblk[b][j]))
-                          for j in range(beam)] for b in range(B)], device=device)
+    nonblk = [[[e for e in _ints(h) if e != blk] for h in row] for row in hyps]
+    tl = [int(v) for v in torch.as_tensor(target_lens).tolist()]
+    refs = torch.as_tensor(targets).tolist()
+    d = edit_distances([(refs[b][:tl[b]], nonblk[b][j]) for b in range(B) for j in range(beam)])
+    dist = torch.tensor(d, dtype=torch.float32).view(B, beam).to(device)
     avg = (prob * dist).sum(dim=1, keepdim=True)
     return prob, dist, prob * (dist - avg), nonblk
 
@@ -85,19 +114,20 @@ def mbr_backward(model, enc, hyps, seq_grad, nonblk, blk, sm_scale):
     T, H = enc.shape[1], enc.shape[2]
     pad = model.embed.padding_idx
     Umax = max(len(h) for row in nonblk for h in row)
-    y = torch.full((B * beam, Umax), pad, dtype=torch.long, device=dev)
     S = max(max(len(h) for row in hyps for h in row), 1)
-    sym = torch.full((B * beam, S), blk, dtype=torch.long, device=dev)
-    slen = torch.zeros(B * beam, dtype=torch.long, device=dev)
+    y_h = np.full((B * beam, max(Umax, 0)), pad, dtype=np.int64)       # built on the host, ONE upload each
+    sym_h = np.full((B * beam, S), blk, dtype=np.int64)
+    slen_h = np.zeros(B * beam, dtype=np.int64)
     for b in range(B):
         for j in range(beam):
             r = b * beam + j
             if nonblk[b][j]:
-                y[r, :len(nonblk[b][j])] = torch.tensor(nonblk[b][j], device=dev)
-            h = [int(e) for e in hyps[b][j]]
+                y_h[r, :len(nonblk[b][j])] = nonblk[b][j]
+            h = _ints(hyps[b][j])
             if h:
-                sym[r, :len(h)] = torch.tensor(h, device=dev)
-            slen[r] = len(h)
+                sym_h[r, :len(h)] = h
+            slen_h[r] = len(h)
+    y, sym, slen = (torch.from_numpy(a).to(dev) for a in (y_h, sym_h, slen_h))
     sos = torch.zeros(B * beam, 1, dtype=torch.long, device=dev)
     pred = model.predict(torch.cat((sos, y), dim=1))                          # (bb, U, H)   :198-206
     # trajectory: before step s the path has consumed t = #blanks, u = #labels of steps < s  (:212-217)

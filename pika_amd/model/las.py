@@ -288,13 +288,17 @@ class Net(nn.Module):
         if not torch.is_grad_enabled():
             # the rescoring loop of decode_transducer.py:136-156 calls this for every n-best entry and direction of the
             # SAME utterance: keep the last encoder pass (keyed by the storage, shape and version of src)
-            key = (src.data_ptr(), tuple(src.shape), src._version, src.device, tuple(int(v) for v in torch.as_tensor(lengths).view(-1)))
+            try:
+                key = (src.data_ptr(), tuple(src.shape), src._version, src.device,
+                       tuple(int(v) for v in torch.as_tensor(lengths).view(-1)))
+            except RuntimeError:        # inference-mode tensors carry no version counter: no memo
+                key = None
             hit = getattr(self, "_enc_cache", None)
-            if hit is not None and hit[0] == key and not self.training:
+            if key is not None and hit is not None and hit[0] == key and not self.training:
                 enc_hidden, enc_out = hit[1]
             else:
                 enc_hidden, enc_out = self.encoder(src, lengths)
-                self._enc_cache = (key, (enc_hidden, enc_out))
+                self._enc_cache = None if key is None else (key, (enc_hidden, enc_out))
         else:
             self._enc_cache = None
             enc_hidden, enc_out = self.encoder(src, lengths)

@@ -253,3 +253,17 @@ def test_gpu_native_mbr_step_matches_the_reference_script_golden(hip_device):
     finally:
         G.PRECISION = old
     M.compare(got, want, rel=2e-3)
+
+
+def test_edit_distances_library_call_equals_the_python_dp():
+    """pika_edit_distances (host code of libpika_amd.so, all N-best pairs of a batch in one call) against the plain
+    dynamic programme and hand cases -- what editdistance.eval returns (requirements.txt:1 of the reference)."""
+    import random
+    from pika_amd import mbr
+    assert mbr.edit_distances([([1, 2, 3], [1, 2, 3]), ([], [4, 5]), ([7], []), ([1, 2, 3, 4], [2, 3, 5]), ([], [])]) == \
+        [0, 2, 1, 2, 0]
+    random.seed(3)
+    pairs = [([random.randrange(6) for _ in range(random.randrange(0, 40))],
+              [random.randrange(6) for _ in range(random.randrange(0, 25))]) for _ in range(200)]
+    assert mbr.edit_distances(pairs) == [mbr.edit_distance(a, b) for a, b in pairs]
+    assert mbr.edit_distances([]) == []
