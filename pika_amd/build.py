@@ -15,6 +15,11 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libpika_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+# Per-file code-generation options.  attn.hip: MFMA results in VGPRs instead of AGPRs -- the online softmax reads every
+# score and rescales every context accumulator each key tile, so the AGPR form costs ~80 v_accvgpr_read/write per tile
+# per wave in kernels that are bound by VALU issue (419 -> 343 instructions in the forward loop, same arithmetic).
+# PIKA_ATTN_AGPR=1 builds the AGPR form for A/B runs.
+EXTRA_FLAGS = {"attn.hip": [] if os.environ.get("PIKA_ATTN_AGPR") else ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -37,8 +42,8 @@ def build(force=False, verbose=False):
     objs, jobs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + headers):
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
         objs.append(obj)
     if jobs:   # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor

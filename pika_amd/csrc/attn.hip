@@ -56,6 +56,25 @@ __device__ inline uint64_t keep_word(uint32_t rowh, uint32_t kb, uint32_t thr) {
 
 __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// x where bit `bit` of `word` is set, else +0: a sign-extended one-bit field (0 / ~0) ANDed onto the value -- two
+// instructions per element instead of shift / and / compare / select
+__device__ inline float keep_if(float x, uint32_t word, int bit) {      // `bit` is a constant after unrolling
+    const int m = __builtin_amdgcn_sbfe((int)word, (unsigned)bit, 1u);
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
+}
+template <int BIT>
+__device__ inline float keep_bit(float x, uint32_t word) {
+    const int m = __builtin_amdgcn_sbfe((int)word, BIT, 1);
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
+}
+// two fp32 -> one packed bf16 pair (v_cvt_pk_bf16_f32), as the low / high half of a 32-bit lane of an MFMA operand
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pack2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // 64 x D rows of T = float | bf16 (pitch ld) -> bf16 LDS tile with pitch D+8; rows >= nvalid are zero-filled.
 template <int D, typename T>
 __device__ inline void load_tile(__bf16 *lds, const T *g, long long ld, int nvalid, float scale) {
@@ -207,15 +226,22 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
         bf16x8 pf[2];
         const uint64_t kw = A.thr ? (bits[kb >> 6] >> (g * 4)) : ~0ull;   // bit kt*16 + r = key kt*16 + g*4 + r
         const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
+        {
+            float p[4][4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = ex2(s[kt][r] - mn);
-                lpart += p;
-                if (!(((kt < 2 ? kw0 : kw1) >> ((kt & 1) * 16 + r)) & 1u)) p = 0.f;
-                pf[kt >> 1][(kt & 1) * 4 + r] = (__bf16)p;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    p[kt][r] = ex2(s[kt][r] - mn);
+                    lpart += p[kt][r];
+                }
+#define PIKA_KEEP(kt, r) keep_bit<((kt) & 1) * 16 + (r)>(p[kt][r], (kt) < 2 ? kw0 : kw1)
+#define PIKA_PAIR(kt, r) pack2(PIKA_KEEP(kt, r), PIKA_KEEP(kt, (r) + 1))
+            pf[0] = __builtin_bit_cast(bf16x8, u32x4{PIKA_PAIR(0, 0), PIKA_PAIR(0, 2), PIKA_PAIR(1, 0), PIKA_PAIR(1, 2)});
+            pf[1] = __builtin_bit_cast(bf16x8, u32x4{PIKA_PAIR(2, 0), PIKA_PAIR(2, 2), PIKA_PAIR(3, 0), PIKA_PAIR(3, 2)});
+#undef PIKA_PAIR
+#undef PIKA_KEEP
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -289,7 +315,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
         const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 dsf;
+            uint32_t dsw[4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int kt = 2 * s2 + half;
@@ -299,15 +325,18 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
                     sa = mfma(frag_n<P>(Ks, kt * 16, ks * 32, lane), qf[ks], sa);
                     dp = mfma(frag_n<P>(Vs, kt * 16, ks * 32, lane), dof[ks], dp);
                 }
+                float ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb + kt * 16 + g * 4 + r;
                     const float p = key < T ? ex2(sa[r] - lse) : 0.f;
-                    float d = dp[r] * A.inv_keep;
-                    if (!(((kt < 2 ? kw0 : kw1) >> ((kt & 1) * 16 + r)) & 1u)) d = 0.f;
-                    dsf[half * 4 + r] = (__bf16)(p * (d - delta));
+                    const float d = keep_if(dp[r] * A.inv_keep, s2 == 0 ? kw0 : kw1, half * 16 + r);
+                    ds[r] = p * (d - delta);
                 }
+                dsw[half * 2] = pack2(ds[0], ds[1]);
+                dsw[half * 2 + 1] = pack2(ds[2], ds[3]);
             }
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsw[0], dsw[1], dsw[2], dsw[3]});
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma(frag_t<P>(Ks, dt * 16, s2 * 32, lane), dsf, acc[dt]);
         }
@@ -328,10 +357,12 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     __shared__ __attribute__((aligned(16))) __bf16 Qs[TILE * P];
     __shared__ __attribute__((aligned(16))) __bf16 Os[TILE * P];
     __shared__ float lse_s[TILE], delta_s[TILE];
-    __shared__ uint64_t word_s[TILE];
+    __shared__ uint32_t wlo_s[TILE], whi_s[TILE];     // the two halves of every query's keep word for this key block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const int T = A.T, h = blockIdx.y, b = blockIdx.z;
     const int krow = blockIdx.x * TILE + wave * 16 + (lane & 15);
+    const bool kbit_hi = (krow & 32) != 0;
+    const int kbit = krow & 31;
     const long long boff = (long long)b * T * A.ld + (long long)h * D;
     const uint32_t bh = (uint32_t)(b * A.H + h);
     bf16x8 kf[KS], vf[KS];
@@ -348,12 +379,14 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
             const int qi = qb + threadIdx.x;
             lse_s[threadIdx.x] = qi < T ? A.lse[(long long)bh * T + qi] : INFINITY;
             delta_s[threadIdx.x] = qi < T ? A.delta[(long long)bh * T + qi] : 0.f;
-            word_s[threadIdx.x] = (A.thr && qi < T) ? A.bits[((long long)bh * T + qi) * A.nkb + blockIdx.x] : ~0ull;
+            const uint64_t w64 = (A.thr && qi < T) ? A.bits[((long long)bh * T + qi) * A.nkb + blockIdx.x] : ~0ull;
+            wlo_s[threadIdx.x] = (uint32_t)w64;
+            whi_s[threadIdx.x] = (uint32_t)(w64 >> 32);
         }
         __syncthreads();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 pdf, dsf;
+            uint32_t pdw[4], dsw[4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int qt = 2 * s2 + half;
@@ -363,16 +396,24 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
                     sa = mfma(frag_n<P>(Qs, qt * 16, ks * 32, lane), kf[ks], sa);
                     dp = mfma(frag_n<P>(Os, qt * 16, ks * 32, lane), vf[ks], dp);
                 }
+                float pdv[4], dsv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qt * 16 + g * 4 + r;
                     const float p = ex2(sa[r] - lse_s[qi]);
-                    float pd = p * A.inv_keep, d = dp[r] * A.inv_keep;
-                    if (!((word_s[qi] >> (krow & 63)) & 1ull)) pd = d = 0.f;
-                    pdf[half * 4 + r] = (__bf16)pd;
-                    dsf[half * 4 + r] = (__bf16)(p * (d - delta_s[qi]));
+                    // this lane's key is bit (krow & 63) of the query's keep word: the half that holds it, then one
+                    // sign-extended bit field as an AND mask for both products
+                    const uint32_t wd = kbit_hi ? whi_s[qi] : wlo_s[qi];
+                    const int m = __builtin_amdgcn_sbfe((int)wd, (unsigned)kbit, 1u);
+                    pdv[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, p * A.inv_keep) & m);
+                    const float d = __builtin_bit_cast(float, __builtin_bit_cast(int, dp[r] * A.inv_keep) & m);
+                    dsv[r] = p * (d - delta_s[qi]);
                 }
+                pdw[half * 2] = pack2(pdv[0], pdv[1]); pdw[half * 2 + 1] = pack2(pdv[2], pdv[3]);
+                dsw[half * 2] = pack2(dsv[0], dsv[1]); dsw[half * 2 + 1] = pack2(dsv[2], dsv[3]);
             }
+            const bf16x8 pdf = __builtin_bit_cast(bf16x8, u32x4{pdw[0], pdw[1], pdw[2], pdw[3]});
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsw[0], dsw[1], dsw[2], dsw[3]});
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 dv[dt] = mfma(frag_t<P>(Os, dt * 16, s2 * 32, lane), pdf, dv[dt]);
