@@ -4,6 +4,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pika_las.h"
 #include "pika_rnnt.h"
 
@@ -94,29 +96,40 @@ __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float 
         len[g] = ok ? min(lens[b[g]], S) : 0;
         smax = max(smax, len[g]);
     }
+    // sum_d v_d tanh(z_d) = sum_d v_d - 2 sum_d v_d / (e^{2 z_d} + 1): per element ONE fma (z scaled for exp2), one
+    // exp2, one add, one reciprocal and one fma -- the kernel is bound by VALU / transcendental issue
+    constexpr float C2 = 2.8853900817779268f;      // 2 * log2(e)
     f32x4 q[G][KQ], vv[KQ], acc[G][KQ];
     float m[G], l[G];
+    float vsum = 0.f;
 #pragma unroll
     for (int k = 0; k < KQ; ++k) {
         const int j = lane + 64 * k;
-        vv[k] = j < D4 ? reinterpret_cast<const f32x4 *>(v)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v4 = j < D4 ? reinterpret_cast<const f32x4 *>(v)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        vsum += (v4.x + v4.y) + (v4.z + v4.w);
+        vv[k] = v4 * -2.0f;                         // zero past D: those lanes contribute nothing
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            q[g][k] = (j < D4 && b[g] >= 0) ? reinterpret_cast<const f32x4 *>(wq + (long long)nq[g] * ldq)[j]
+            q[g][k] = (j < D4 && b[g] >= 0) ? reinterpret_cast<const f32x4 *>(wq + (long long)nq[g] * ldq)[j] * C2
                                             : f32x4{0.f, 0.f, 0.f, 0.f};
             acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    vsum = wave_sum(vsum);
 #pragma unroll
     for (int g = 0; g < G; ++g) { m[g] = -INFINITY; l[g] = 0.f; }
-    for (int s = wave; s < smax; s += AW) {
-        f32x4 p[KQ], x[KQ];
-        int loaded = -1;
+    // the common case -- every query of the group belongs to one utterance -- without the per-query reload test
+    // (its register copies were a sixth of the loop)
+    bool uni = true;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (s >= len[g]) continue;                           // wave-uniform
-            if (b[g] != loaded) {
-                const long long off = ((long long)b[g] * S + s) * D;
+    for (int g = 1; g < G; ++g) uni = uni && (b[g] < 0 || b[g] == b[0]);
+    auto walk = [&](auto uniform_tag) {
+        constexpr bool UNI = decltype(uniform_tag)::value;
+        for (int s = wave; s < smax; s += AW) {
+            f32x4 p[KQ], x[KQ];
+            int loaded = -1;
+            if constexpr (UNI) {
+                const long long off = ((long long)b[0] * S + s) * D;
                 const f32x4 *prow = reinterpret_cast<const f32x4 *>(proj + off);
                 const f32x4 *crow = reinterpret_cast<const f32x4 *>(context + off);
 #pragma unroll
@@ -125,24 +138,45 @@ __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float 
                     p[k] = j < D4 ? prow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
                     x[k] = j < D4 ? crow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                loaded = b[g];
             }
-            float sc = 0.f;
 #pragma unroll
-            for (int k = 0; k < KQ; ++k)
+            for (int g = 0; g < G; ++g) {
+                if (s >= len[g]) continue;                           // wave-uniform
+                if constexpr (!UNI) {
+                    if (b[g] != loaded) {
+                        const long long off = ((long long)b[g] * S + s) * D;
+                        const f32x4 *prow = reinterpret_cast<const f32x4 *>(proj + off);
+                        const f32x4 *crow = reinterpret_cast<const f32x4 *>(context + off);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sc += vv[k][e] * tanh_fast(q[g][k][e] + p[k][e]);    // v = 0 past D
-            sc = wave_sum(sc);
-            if (align_out && lane == 0) align_out[(long long)nq[g] * S + s] = sc;               // raw, normalised below
-            const float mn = fmaxf(m[g], sc);
-            const float alpha = __expf(m[g] - mn), w = __expf(sc - mn);                            // exp(-inf) = 0
-            m[g] = mn;
-            l[g] = l[g] * alpha + w;
+                        for (int k = 0; k < KQ; ++k) {
+                            const int j = lane + 64 * k;
+                            p[k] = j < D4 ? prow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                            x[k] = j < D4 ? crow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        loaded = b[g];
+                    }
+                }
+                float part = 0.f;
 #pragma unroll
-            for (int k = 0; k < KQ; ++k) acc[g][k] = acc[g][k] * alpha + w * x[k];
+                for (int k = 0; k < KQ; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf(p[k][e], C2, q[g][k][e]));   // e^{2z}
+                        part = __builtin_fmaf(vv[k][e], rcp(ex + 1.0f), part);         // inf -> 0, 0 -> -2 v
+                    }
+                const float sc = vsum + wave_sum(part);
+                if (align_out && lane == 0) align_out[(long long)nq[g] * S + s] = sc;  // raw, normalised below
+                const float mn = fmaxf(m[g], sc);
+                const float alpha = __expf(m[g] - mn), w = __expf(sc - mn);            // exp(-inf) = 0
+                m[g] = mn;
+                l[g] = l[g] * alpha + w;
+#pragma unroll
+                for (int k = 0; k < KQ; ++k) acc[g][k] = acc[g][k] * alpha + w * x[k];
+            }
         }
-    }
-    // ---- merge the four waves' partials ----
+    };
+    if (uni) walk(std::true_type{}); else walk(std::false_type{});
+    // ---- merge the eight waves' partials ----
     if (lane == 0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) { wm[wave][g] = m[g]; wl[wave][g] = l[g]; }
