@@ -565,6 +565,108 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
     }
 }
 
+
+// The same on 8-column granules (V % 8 == 0, ld_out % 8 == 0, V <= 512 * NIT): a lane loads two adjacent 16-byte
+// groups and stores ONE 16-byte bf16 granule, nothing of the row is staged in registers (the row log-sum-exp is
+// known: every element is one fma + exp2 + mul), and the two special columns of a row are patched under
+// wave-uniform tests instead of two compares per element -- a third of the instructions of the kernel above, 120
+// registers instead of 289 (one wave per SIMD before), so the loads of several rows are in flight per CU.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+template <int NIT>
+__global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const float *__restrict__ lp,
+                                                                    const RowMeta *__restrict__ meta,
+                                                                    __bf16 *__restrict__ out, long long rows,
+                                                                    int V, long long ld_out, int blank,
+                                                                    float scale, int rpw,
+                                                                    float *__restrict__ colsum,
+                                                                    const float *__restrict__ lse) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * rpw;
+    float cs[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[it][e] = 0.f;
+    const int gb_lane = (blank >> 3) & 63;                       // the lane that stores the granule of the blank column
+    float cs_blank = 0.f;
+    for (long long r = r0; r < r0 + rpw && r < rows; ++r) {
+        const RowMeta m = meta[r];
+        const float ssum = m.gb + m.ge;
+        const bool live = (m.gb != 0.f) || (m.ge != 0.f);       // wave-uniform; dead rows are zeros (see above)
+        const float nl2 = lse ? -lse[r] * LOG2E : 0.f;
+        const float k = -scale * ssum;
+        const float *lrow = lp + r * V;
+        __bf16 *orow = out + r * ld_out;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (lane + 64 * it) * 8;
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            if (live) {
+                const float *src = lrow + (c < V ? c : 0);       // always a valid address; the store is guarded
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(src);
+                const f32x4 b2 = *reinterpret_cast<const f32x4 *>(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = k * __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], LOG2E, nl2));
+                    o[4 + e] = k * __builtin_amdgcn_exp2f(__builtin_fmaf(b2[e], LOG2E, nl2));
+                }
+            }
+            if (c < V) {
+                cbf16x8 w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (__bf16)o[e];
+                *reinterpret_cast<cbf16x8 *>(orow + c) = w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[it][e] += o[e];
+            } else if (c < ld_out) {
+                cbf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+                *reinterpret_cast<cbf16x8 *>(orow + c) = z;
+            }
+        }
+        // the (at most two) columns that carry an extra term: the lane that stored their granule stores the element
+        // again (same thread, same address: program order), their share of the column sums goes in separately
+        if (live) {
+            if (lane == gb_lane && m.gb != 0.f) {
+                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf(lrow[blank], LOG2E, nl2));
+                orow[blank] = (__bf16)(v + scale * m.gb);
+                cs_blank += scale * m.gb;
+            }
+            const int ye = m.ye;
+            if (ye >= 0 && m.ge != 0.f && lane == ((ye >> 3) & 63)) {
+                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf(lrow[ye], LOG2E, nl2));
+                float add = scale * m.ge;
+                if (ye == blank && m.gb != 0.f) add += scale * m.gb;         // never in practice (labels > blank)
+                orow[ye] = (__bf16)(v + add);
+                atomicAdd(colsum + ye, scale * m.ge);
+            }
+        }
+    }
+    __shared__ float red[4][64][9];      // pitch 9: the 8 floats of a lane never share a bank with its neighbour's
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const bool any = it * 512 < V;    // uniform
+        __syncthreads();
+        if (any) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave][lane][e] = cs[it][e];
+        }
+        __syncthreads();
+        const int c = (lane + 64 * it) * 8;
+        if (any && wave == 0 && c < V) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                atomicAdd(colsum + c + e, (red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e]));
+        }
+    }
+    if (cs_blank != 0.f) atomicAdd(colsum + blank, cs_blank);
+}
+
 int run_alpha_beta(const Lattice &L, const int *frames_lengths, const int *labels_lengths, float *costs, int B,
                    int T, int U1, hipStream_t s) {
     switch (L.Wp / 64) {
@@ -847,6 +949,14 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
         if (e != hipSuccess) return (int)e;
         const int rpw = rows >= (1 << 18) ? 32 : 4;
         const long long per_block = 4LL * rpw;
+        static const bool wide_off = getenv("PIKA_DLOGITS_NARROW") != nullptr;     // A/B: the 4-column kernel
+        if (!wide_off && !(V & 7) && !(ld_out & 7) && V > 512 * 9 && ld_out <= 512 * 10 &&
+            !(reinterpret_cast<uintptr_t>(out) & 15)) {
+            hipLaunchKernelGGL(rnnt_dlogits_compact8_kernel<10>, dim3((unsigned)((rows + per_block - 1) / per_block)),
+                               dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
+                               scale, rpw, colsum, lse);
+            return (int)hipGetLastError();
+        }
         hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<true>, dim3((unsigned)((rows + per_block - 1) / per_block)),
                            dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
                            scale, rpw, colsum, lse);

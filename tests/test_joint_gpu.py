@@ -87,8 +87,10 @@ def test_joint_output_fn(hip_device, M, V, H, scale):
         G.PRECISION = old
 
 
-def test_joint_backward_uses_compact_rnnt_gradient(hip_device):
-    """log_probs from JointOutFn straight into the RNN-T loss: the joint backward recognises the loss' own
+@pytest.mark.parametrize("V", [40, 5000, 4616])
+def test_joint_backward_uses_compact_rnnt_gradient(hip_device, V):
+    """(V = 5000 / 4616 take the 8-column d(logits) kernel, 40 the 4-column one.)
+    log_probs from JointOutFn straight into the RNN-T loss: the joint backward recognises the loss' own
     dense gradient tensor and rebuilds d(logits) from the two non-zeros per row kept in the loss workspace
     (pika_rnnt_dlogits_compact_bf16) -- same parameter gradients as the dense path; any tensor that is
     not that exact gradient (here: scaled by a hook) takes the dense path."""
@@ -98,7 +100,7 @@ def test_joint_backward_uses_compact_rnnt_gradient(hip_device):
     old, G.PRECISION = G.PRECISION, "bf16"
     try:
         g = torch.Generator().manual_seed(3)
-        B, T, U, H, V = 2, 11, 4, 64, 40
+        B, T, U, H = 2, 11, 4, 64
         h = (torch.randn(B, T, U + 1, H, generator=g) * 0.5).bfloat16().to(hip_device)
         w = (torch.randn(V, H, generator=g) * 0.3).to(hip_device)
         b = (torch.randn(V, generator=g) * 0.1).to(hip_device)
