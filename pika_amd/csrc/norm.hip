@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void bn_param_grad_kernel(const double *__rest
 // in registers (LNQ float4 per lane), statistics by xor-shuffles.  Output / incoming gradient may
 // be bf16: the normalised activation only feeds MFMA products (q/k/v and feed-forward GEMMs), so it
 // is rounded once here instead of in a separate pass.
-constexpr int LNQ = 8;   // float4 per lane: C <= 64 * 4 * 8
+constexpr int LNQ_MAX = 8;   // float4 per lane: C <= 64 * 4 * 8.  The kernels are instantiated for 2 / 4 / 8 (C <= 512 /
+                           // 1024 / 2048): at C = 1024 the row arrays of the backward take 80 registers instead of 160 --
+                           // four waves per SIMD instead of two on kernels that are chains of row-sized memory round trips
 typedef float ln_f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 ln_b4 __attribute__((ext_vector_type(4)));
 
@@ -174,7 +176,7 @@ __device__ inline float ln_wave_sum(float v) {
     return v;
 }
 
-template <typename TO>
+template <typename TO, int LNQ>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, TO *__restrict__ y,
                                                      float *__restrict__ mean, float *__restrict__ rstd,
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma += dy * xhat, dbeta += dy
 // (per-lane column partials over the block's rows, one atomicAdd per column per block).
-template <typename TD>
+template <typename TD, int LNQ>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ gamma, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
@@ -264,13 +266,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
     __shared__ ln_f4 red[2][4][64];
 #pragma unroll
     for (int q = 0; q < LNQ; ++q) {
-        if (q * 64 >= c4) break;          // uniform
+        const bool any = q * 64 < c4;     // uniform
         __syncthreads();
-        red[0][wave][lane] = ag[q];
-        red[1][wave][lane] = ab[q];
+        if (any) {
+            red[0][wave][lane] = ag[q];
+            red[1][wave][lane] = ab[q];
+        }
         __syncthreads();
         const int i = lane + q * 64;
-        if (wave < 2 && i < c4) {
+        if (any && wave < 2 && i < c4) {
             const ln_f4 t = red[wave][0][lane] + red[wave][1][lane] + red[wave][2][lane] + red[wave][3][lane];
             float *dst = (wave == 0 ? dgamma : dbeta) + 4 * i;
             atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
@@ -356,17 +360,21 @@ int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long row
 int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamma, const float *beta,
                         float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0) return PIKA_EINVAL;
-    if ((C & 3) || C > 64 * 4 * LNQ || rows > 0x7fffffffLL * 4) return PIKA_EINVAL;
+    if ((C & 3) || C > 64 * 4 * LNQ_MAX || rows > 0x7fffffffLL * 4) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
         return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((rows + 3) / 4));
+#define PIKA_LN_FWD(TO, Q) hipLaunchKernelGGL((ln_fwd_kernel<TO, Q>), grid, dim3(256), 0, s, x, gamma, beta, static_cast<TO *>(y), mean, rstd, rows, C, eps)
+#define PIKA_LN_FWD_Q(TO) do { if (C <= 512) PIKA_LN_FWD(TO, 2); else if (C <= 1024) PIKA_LN_FWD(TO, 4); else PIKA_LN_FWD(TO, 8); } while (0)
     if (y_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(y) & 15))
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, x, gamma, beta, static_cast<float *>(y), mean, rstd, rows, C, eps);
+        PIKA_LN_FWD_Q(float);
     else if (y_dtype == PIKA_BF16 && !(reinterpret_cast<uintptr_t>(y) & 7))
-        hipLaunchKernelGGL(ln_fwd_kernel<__bf16>, grid, dim3(256), 0, s, x, gamma, beta, static_cast<__bf16 *>(y), mean, rstd, rows, C, eps);
+        PIKA_LN_FWD_Q(__bf16);
     else
         return PIKA_EINVAL;
+#undef PIKA_LN_FWD_Q
+#undef PIKA_LN_FWD
     return (int)hipGetLastError();
 }
 
@@ -374,7 +382,7 @@ int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long 
                         const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
                         void *stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return PIKA_EINVAL;
-    if ((C & 3) || C > 64 * 4 * LNQ) return PIKA_EINVAL;
+    if ((C & 3) || C > 64 * 4 * LNQ_MAX) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx) |
          reinterpret_cast<uintptr_t>(dgamma) | reinterpret_cast<uintptr_t>(dbeta)) & 15)
         return PIKA_EINVAL;
@@ -384,12 +392,16 @@ int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long 
     if (e != hipSuccess) return (int)e;
     const int rpb = rows >= 4096 ? 32 : 8;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+#define PIKA_LN_BWD(TD, Q) hipLaunchKernelGGL((ln_bwd_kernel<TD, Q>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb)
+#define PIKA_LN_BWD_Q(TD) do { if (C <= 512) PIKA_LN_BWD(TD, 2); else if (C <= 1024) PIKA_LN_BWD(TD, 4); else PIKA_LN_BWD(TD, 8); } while (0)
     if (dy_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(dy) & 15))
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(256), 0, s, static_cast<const float *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+        PIKA_LN_BWD_Q(float);
     else if (dy_dtype == PIKA_BF16 && !(reinterpret_cast<uintptr_t>(dy) & 7))
-        hipLaunchKernelGGL(ln_bwd_kernel<__bf16>, grid, dim3(256), 0, s, static_cast<const __bf16 *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb);
+        PIKA_LN_BWD_Q(__bf16);
     else
         return PIKA_EINVAL;
+#undef PIKA_LN_BWD_Q
+#undef PIKA_LN_BWD
     return (int)hipGetLastError();
 }
 
