@@ -4,6 +4,7 @@
 // atomicAdd per column per block.  Elementwise passes: 16-byte accesses, channel parameters from
 // L2.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "pika_gemm.h"
@@ -390,7 +391,11 @@ int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long 
     hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    const int rpb = rows >= 4096 ? 32 : 8;
+    static const int rpb_env = [] { const char *e = getenv("PIKA_LN_BWD_RPB"); return e ? atoi(e) : 0; }();   // A/B runs
+    // rows per workgroup: every workgroup ends with 2*C column-sum atomics onto the same addresses, so few rows per
+    // workgroup are bound by that contention and many by the row chain (measured at 31808 x 1024, tools/ln_bwd_bench.py:
+    // 8: 483 us, 16: 299, 32: 231, 64: 197, 128: 215, 256: 286 per backward)
+    const int rpb = rpb_env > 0 ? rpb_env : (rows >= 16384 ? 64 : rows >= 4096 ? 32 : 8);
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
 #define PIKA_LN_BWD(TD, Q) hipLaunchKernelGGL((ln_bwd_kernel<TD, Q>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb)
 #define PIKA_LN_BWD_Q(TD) do { if (C <= 512) PIKA_LN_BWD(TD, 2); else if (C <= 1024) PIKA_LN_BWD(TD, 4); else PIKA_LN_BWD(TD, 8); } while (0)
