@@ -14,7 +14,14 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int ROWS_PER_BLOCK = 512;
+// rows per reduction workgroup (PIKA_BN_RPB overrides for A/B runs): fewer rows = more workgroups in flight on a pass
+// that is all memory round trips, but more fp64 atomics per column
+// tools/bn_bench.py at 31808 x 1024: statistics 25 / 32 / 48 / 66 us for 512 / 256 / 128 / 64 rows, backward (two input
+// streams, longer chains) 107 / 91 / 101 / 121 us
+inline int bn_rows_per_block(int mode) {
+    static const int v = [] { const char *e = getenv("PIKA_BN_RPB"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 0; }();
+    return v ? v : (mode ? 256 : 512);
+}
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
@@ -41,13 +48,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TA *__restrict__ a
                                                         const float *__restrict__ x,
                                                         const float *__restrict__ mean,
                                                         const float *__restrict__ rstd,
-                                                        long long rows, int C,
+                                                        long long rows, int C, int rows_per_block,
                                                         double *__restrict__ out) {
     __shared__ f32x4 p0[4][64], p1[4][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 4;
-    const long long r0 = (long long)blockIdx.y * ROWS_PER_BLOCK;
-    const long long r1 = min(rows, r0 + ROWS_PER_BLOCK);
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu;
@@ -283,8 +290,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
     }
 }
 
-inline dim3 red_grid(long long rows, int C) {
-    return dim3((C / 4 + 63) / 64, (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+inline dim3 red_grid(long long rows, int C, int mode) {
+    const int rpb = bn_rows_per_block(mode);
+    return dim3((C / 4 + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
 }
 inline int ew_grid(long long n4) { return (int)((n4 + 1023) / 1024 < 4096 ? (n4 + 1023) / 1024 : 4096); }
 
@@ -294,8 +302,8 @@ int bn_backward_impl(const TD *dy, const float *x, long long rows, int C, const 
                             float *dgamma, float *dbeta, int relu_mask, hipStream_t s) {
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((bn_reduce_kernel<1, TD>), red_grid(rows, C), dim3(256), 0, s, dy, x, save_mean,
-                       save_rstd, rows, C, sums);
+    hipLaunchKernelGGL((bn_reduce_kernel<1, TD>), red_grid(rows, C, 1), dim3(256), 0, s, dy, x, save_mean,
+                       save_rstd, rows, C, bn_rows_per_block(1), sums);
     const long long n4 = rows * C / 4;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TD, TX>), dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, n4, C / 4, rows,
                        save_mean, save_rstd, gamma, sums, dx, relu_mask);
@@ -313,8 +321,8 @@ int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *st
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((bn_reduce_kernel<0, float>), red_grid(rows, C), dim3(256), 0, s, x, x, nullptr, nullptr,
-                       rows, C, stats);
+    hipLaunchKernelGGL((bn_reduce_kernel<0, float>), red_grid(rows, C, 0), dim3(256), 0, s, x, x, nullptr, nullptr,
+                       rows, C, bn_rows_per_block(0), stats);
     return (int)hipGetLastError();
 }
 
