@@ -3,7 +3,7 @@
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_g
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_g -- python $R/bench.py --workload train_step --steps 2 --warmup 1 --batch 32 > $R/gpurun_out/pmc_g.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_g -- python $R/bench.py --workload train_step --steps 2 --warmup 1 --batch 32 --no-cpu-baseline --no-fp32-leg > $R/gpurun_out/pmc_g.log 2>&1
 cd $R
 tail -2 gpurun_out/pmc_g.log | cut -c1-300
 python - <<'PY'
