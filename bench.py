@@ -189,7 +189,8 @@ def run_train_step(args, R_, steps, warmup):
            "value": B * world / (el / steps), "unit": "utterances/s", "n_gpus": world,
            "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": {"bf16": "bf16", "bf16x3": "f32 as 2 bf16 terms (3 MFMA products)"}.get(G.PRECISION, "f32-split"),
+           "dtype": {"bf16": "bf16", "bf16x3": "f32 as 2 bf16 terms (3 MFMA products)%s" % (
+               "; joint lattice products bf16" if G.X3_JOINT_BF16 else "")}.get(G.PRECISION, "f32-split"),
            "data": "synthetic",
            "config": {"workload": "train_step (BASELINE configs[1]): full PIKA TDNN-Transformer RNN-T, HIP "
                                   "loader from pinned int16 audio (fbank+splice) on a side stream, CMVN, SpecAugment, "
@@ -569,9 +570,12 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
             ts["bf16x3"] = {"ms_per_step": x3["ms_per_step"], "value": x3["value"], "dtype": x3["dtype"],
                             "roofline_frac": x3["roofline"]["frac"],
                             "products": {"split": fast, "exact_fallback": exact},
-                            "note": "same step with every fp32 GEMM operand as two bf16 terms and hi.hi + lo.hi + hi.lo as "
-                                    "ONE bf16 product over a 3x longer reduction on the direct-to-LDS kernels; fp32 tensors "
-                                    "between products, torch attention chain: activations and loss within 1e-4 of the exact "
+                            "note": "same step with every fp32 GEMM operand of the encoder, the prediction network and "
+                                    "the joint's projections as two bf16 terms and hi.hi + lo.hi + hi.lo as ONE bf16 product "
+                                    "over a 3x longer reduction on the direct-to-LDS kernels (fp32 tensors between products, "
+                                    "torch attention chain); the joint's lattice products (fc2 and its gradients) on bf16 "
+                                    "operands as in config 2 (PIKA_X3_JOINT=x3: two terms there too, 122 ms): encoder "
+                                    "activations 1e-4 and loss 2e-4 of the exact "
                                     "mode, i.e. inside the 1e-3 of north_star (tests/test_model.py, "
                                     "tests/test_train_step_gpu.py, profiles/r2_precision_table.md)"}
             ts["fp32_split"] = {"ms_per_step": f32["ms_per_step"], "value": f32["value"], "dtype": f32["dtype"],

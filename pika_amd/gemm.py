@@ -20,6 +20,16 @@ RELU, ACCUMULATE, FP32SPLIT = 1, 2, 4
 # Overridable per call.
 PRECISION = os.environ.get("PIKA_GEMM_PRECISION", "bf16")
 PRECISIONS = ("bf16", "bf16x3", "fp32")
+# "bf16x3": the joint's lattice products (fc2 over the (B,T,U) lattice and its two gradient products: half of a training
+# step's FLOPs, on a hidden the gate kernel writes once) stay in the config-2 bf16 arithmetic by default -- the
+# encoder, the prediction network and the joint's projections are what the parity statement (encoder activations,
+# loss) rests on, and the loss moves by ~1e-5 (profiles/r2_precision_table.md).  PIKA_X3_JOINT=x3: two terms there too.
+X3_JOINT_BF16 = os.environ.get("PIKA_X3_JOINT", "bf16") != "x3"
+
+
+def joint_in_bf16():
+    """The joint's lattice products run on bf16 operands: mode "bf16", or "bf16x3" with the default above."""
+    return PRECISION == "bf16" or (PRECISION == "bf16x3" and X3_JOINT_BF16)
 BF16X3_STATS = {"fast": 0, "exact": 0}     # "bf16x3" products taken by the split path / handed to the exact path
 FP32_STATS = {"concat": 0, "staged": 0}    # "fp32" products on the six-segment path / on the register-staged kernel
 
@@ -183,6 +193,12 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
     keep = None
     p = precision or PRECISION
+    if a_op.dtype == PIKA_BF16 and b_op.dtype == PIKA_BF16:
+        p = precision = "bf16"              # a product of bf16 operands has nothing to split, whatever the mode
+    elif p != "bf16" and (a_op.dtype == PIKA_BF16 or b_op.dtype == PIKA_BF16) and (a_op.trans or b_op.trans):
+        # one bf16 operand against a reduction-major fp32 one (a weight gradient whose activation was stored in bf16):
+        # the exact kernel does not take that pairing; the stored operand already carries the bf16 rounding
+        p = precision = "bf16"
     if p == "bf16x3" or (p == "fp32" and not accumulate and FP32_CONCAT):
         n_terms = 2 if p == "bf16x3" else 3
         splittable = batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32

@@ -305,7 +305,7 @@ class GateFn(torch.autograd.Function):
         e1, p1, eg, pg = [t.contiguous() for t in (e1, p1, eg, pg)]
         Bn, T, H = e1.shape
         U = p1.shape[1]
-        dt = torch.bfloat16 if G.PRECISION == "bf16" else torch.float32
+        dt = torch.bfloat16 if G.joint_in_bf16() else torch.float32
         h = torch.empty((Bn, T, U, H), dtype=dt, device=e1.device)
         with torch.cuda.device(e1.device):
             _lib.check(_lib.lib().pika_joint_gate_fwd(
@@ -369,7 +369,7 @@ def joint_out_ok(h, weight):
     8 (16-byte bf16 granules of the d(logits) copy) that one wave covers (log-softmax row kernels)."""
     N, K = weight.shape
     # N <= 5120: what the d(logits) kernels of the backward take (one wave holds a 64-padded row: 64 x 4 x 20 columns)
-    return (G.PRECISION == "bf16" and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
+    return (G.joint_in_bf16() and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
             and N <= 5120)
 
 

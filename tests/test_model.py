@@ -114,8 +114,9 @@ def test_gpu_matches_reference_golden(hip_device, dec, mode):
     element; tools/precision_table.py shows the exact mode doing the same under a 1e-5 input perturbation.  So they are
     held in the L2 norm."""
     from pika_amd import gemm as G
-    old = G.PRECISION
+    old, old_joint = G.PRECISION, G.X3_JOINT_BF16
     G.PRECISION = mode
+    G.X3_JOINT_BF16 = False          # every product in two terms, the joint's lattice products included
     try:
         n0 = G.BF16X3_STATS["fast"]
         if mode == "fp32":
@@ -124,7 +125,7 @@ def test_gpu_matches_reference_golden(hip_device, dec, mode):
             run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=3e-2)
             assert G.BF16X3_STATS["fast"] > n0 + 20
     finally:
-        G.PRECISION = old
+        G.PRECISION, G.X3_JOINT_BF16 = old, old_joint
 
 
 @pytest.mark.gpu

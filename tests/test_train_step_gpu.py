@@ -66,15 +66,30 @@ def test_bf16x3_mode_matches_parity_mode_on_the_full_architecture(hip_device):
     differs by 5e-5 flips the ReLU mask of ~1e-5 of the 3.4 M pre-activations per layer, see tests/test_model.py) --
     an order of magnitude inside the one-term bf16 mode on every count."""
     from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
     run = _harness(hip_device)
-    old = G.PRECISION
+    old, old_joint = G.PRECISION, G.X3_JOINT_BF16
     try:
+        G.X3_JOINT_BF16 = False      # the pure two-term arithmetic: the joint's lattice products too
         n0, e0 = G.BF16X3_STATS["fast"], G.BF16X3_STATS["exact"]
         c3, g3 = run("bf16x3")
         fast, exact = G.BF16X3_STATS["fast"] - n0, G.BF16X3_STATS["exact"] - e0
         c32, g32 = run("fp32")
+        # the default of the mode (what bench.py times): the joint's lattice products on bf16 operands as in config 2,
+        # everything the parity statement names -- encoder, prediction network, projections, loss -- unchanged in kind
+        G.X3_JOINT_BF16 = True
+        hits = JointOutFn.compact_hits
+        ch, gh = run("bf16x3")
+        assert JointOutFn.compact_hits == hits + 1
     finally:
-        G.PRECISION = old
+        G.PRECISION, G.X3_JOINT_BF16 = old, old_joint
+    assert ((ch - c32).abs() / c32.abs()).max() < 2e-4, (ch, c32)          # the LOSS stays two orders inside 1e-3
+    for n in g32:
+        nb = g32[n].norm().item()
+        if nb < 1e-4 * max(1.0, g32[n].numel() ** 0.5):
+            continue
+        rel = ((gh[n] - g32[n]).norm() / nb).item()
+        assert rel < (5e-2 if n.startswith("encoder.") else 3e-2), (n, rel)   # joint gradients: bf16 d(logits)
     print("bf16x3 products: %d split, %d exact" % (fast, exact))
     assert fast > 120 and exact < fast // 4
     assert ((c3 - c32).abs() / c32.abs()).max() < 1e-5, (c3, c32)
