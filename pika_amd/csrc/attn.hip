@@ -59,12 +59,14 @@ __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 // x where bit `bit` of `word` is set, else +0: a sign-extended one-bit field (0 / ~0) ANDed onto the value -- two
 // instructions per element instead of shift / and / compare / select
 __device__ inline float keep_if(float x, uint32_t word, int bit) {      // `bit` is a constant after unrolling
-    const int m = __builtin_amdgcn_sbfe((int)word, (unsigned)bit, 1u);
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "v"(bit));
     return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
 }
 template <int BIT>
 __device__ inline float keep_bit(float x, uint32_t word) {
-    const int m = __builtin_amdgcn_sbfe((int)word, BIT, 1);
+    int m;      // v_bfe_i32 spelled out: the optimizer turns the builtin back into and / compare / select
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
     return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m);
 }
 // two fp32 -> one packed bf16 pair (v_cvt_pk_bf16_f32), as the low / high half of a 32-bit lane of an MFMA operand
