@@ -32,13 +32,26 @@
 extern "C" {
 #endif
 
+/* mask: NULL, or (B, T, T) bytes shared by the heads of a batch element: non-zero = the score of (query row, key
+ * column) is replaced by -1e18 before the softmax (multi_headed_attn.py:215-217; the prediction network's causal +
+ * padding mask, rnnt_conv_transformer_lm.py:65-69).  The backward must be given the same mask. */
 int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
-                       void *keep_bits, int B, int T, int H, int D, long long ld, long long ldo,
+                       void *keep_bits, const void *mask, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
+
+/* The forward in TWO-TERM arithmetic: q, k, v are the bf16 "hi" planes of two-term tensors x = hi + lo whose "lo"
+ * planes lie lo_off elements behind (the packed projection written by pika_gemm_bf16_ex with out_lo); both products
+ * keep hi.hi + lo.hi + hi.lo on the matrix cores, the softmax runs in fp32, and the context is written as two bf16
+ * planes (out, out + out_lo_off) as well: scores and context to ~1e-5 instead of the 4e-3 of one bf16 term -- the
+ * forward of the train step that carries the 1e-3 parity statement.  lse / keep_bits / mask as above;
+ * the backward is pika_attention_bwd on the hi planes (io_dtype PIKA_BF16). */
+int pika_attention_fwd_two_term(const void *q, const void *k, const void *v, long long lo_off, void *out,
+                                long long out_lo_off, float *lse, void *keep_bits, const void *mask, int B, int T,
+                                int H, int D, long long ld, long long ldo, float p_drop, unsigned seed, void *stream);
 
 /* delta (B*H*T,) f32 is scratch (sum_d out*dout per query row). */
 int pika_attention_bwd(const void *q, const void *k, const void *v, const void *out, const void *dout,
-                       int io_dtype, const float *lse, const void *keep_bits, float *delta, void *dq,
+                       int io_dtype, const float *lse, const void *keep_bits, const void *mask, float *delta, void *dq,
                        void *dk, void *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
 

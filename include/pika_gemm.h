@@ -44,6 +44,13 @@ typedef struct {
                           *    row over the channel-like one (matrix stored [k][row], output index
                           *    contiguous): dY and X in dW = dY^T X, W in dX = dY W.  No transposed copy
                           *    is made: the kernel uses the gfx950 LDS transpose read. */
+    int seg;             /* pika_gemm_bf16_ex only, bf16, else 0: a TWO-TERM operand x = hi + lo stored as two bf16
+                          * planes of `seg` columns per source row (seg % 64 == 0), the "lo" plane lo_off elements
+                          * behind the "hi" plane `ptr` addresses.  It presents C = 3 * seg reduction columns per tap,
+                          * the segments [hi | lo | hi]; against a B whose rows hold [hi | hi | lo] per tap
+                          * (pika_split_bf16_terms, role 1) the product is hi.hi + lo.hi + hi.lo: both operands to
+                          * 16 mantissa bits, ~1e-5 relative, at a third of the bf16 rate. */
+    long long lo_off;
 } pika_operand_t;
 
 #define PIKA_GEMM_RELU 1
@@ -91,8 +98,10 @@ int pika_gemm_bf16_nt_lse(const void *A, long long lda, const void *B, long long
  *   PIKA_EPI_MASK_BF16:    out bf16 = scale * (A B^T) where aux[m,n] > 0 (bf16, pitch ld_aux), else 0 --
  *       with aux = the forward's dropped hidden this is the ReLU and dropout backward in one.
  * Requirements as pika_gemm_bf16_nt; ldo, ld_aux % 4 == 0. */
+#define PIKA_EPI_F32 0
 #define PIKA_EPI_DROPOUT_BF16 1
 #define PIKA_EPI_MASK_BF16 2
+#define PIKA_EPI_DROPOUT_RESIDUAL 3
 int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long long ldb, void *out,
                             long long ldo, int M, int N, int K, const float *bias, int mode, int relu,
                             float p_drop, unsigned seed, const void *aux, long long ld_aux, float scale,
@@ -110,6 +119,37 @@ int pika_gemm_bf16_dropout_residual(const void *A, long long lda, const void *B,
  * that dropout fused with the bf16 rounding of the gradient's consumers. */
 int pika_dropout_mask_cast_bf16(const float *x, long long ld, int rows, int cols, float p_drop, unsigned seed,
                                 void *out, long long ld_out, void *stream);
+
+/* Every product / epilogue combination of the direct-to-LDS kernel behind ONE entry: A is an operand descriptor (bf16;
+ * plain or time-delay view with C % 64 == 0; optionally two-term, see pika_operand_t.seg), B a plain bf16 (N, K) matrix.
+ *   PIKA_EPI_F32:              out f32 = relu?(A B^T + bias)
+ *   PIKA_EPI_DROPOUT_BF16:     out bf16 = dropout_p(relu?(A B^T + bias)); with out_lo != NULL the value is written as TWO
+ *                              bf16 terms, out = bf16(v) and out_lo = bf16(v - out) (same pitch): the two-term operand of
+ *                              the next product of a forward pass that carries activations to 16 mantissa bits
+ *   PIKA_EPI_MASK_BF16:        out bf16 = scale * (A B^T) where aux > 0
+ *   PIKA_EPI_DROPOUT_RESIDUAL: out f32 = dropout_p(A B^T + bias) + residual
+ * (semantics of the dedicated entries above).  No size gate: small products run correctly, on 256 x 256 tiles.
+ * Returns PIKA_EINVAL for operands the kernel does not take (K % 64, alignments, padded views with the last two). */
+typedef struct {
+    pika_operand_t A;
+    const void *B;
+    long long ldb;
+    int M, N, K;
+    const float *bias;
+    int relu;
+    int epilogue;
+    void *out;
+    void *out_lo;
+    long long ldo;
+    float p_drop;
+    unsigned seed;
+    const void *aux;
+    long long ld_aux;
+    float scale;
+    const float *residual;
+    long long ld_res;
+} pika_gemm_ex_t;
+int pika_gemm_bf16_ex(const pika_gemm_ex_t *g, void *stream);
 
 #ifdef __cplusplus
 }

@@ -19,11 +19,13 @@ int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *st
 /* y = (x - mean) * rstd * gamma + beta with mean/var from `stats` (biased variance, eps inside the
  * sqrt); writes save_mean / save_rstd (C each, for the backward) and, when running_mean != NULL,
  * running = (1-momentum)*running + momentum*{mean, unbiased var}.  y_dtype PIKA_F32 | PIKA_BF16 (pika_gemm.h):
- * bf16 when y only feeds an MFMA product (the next time-delay layer). */
+ * bf16 when y only feeds an MFMA product (the next time-delay layer).  y_lo (NULL, or a second bf16 plane of the same
+ * shape; needs y_dtype PIKA_BF16): receives bf16(value - y), making (y, y_lo) the two-term operand of a forward product
+ * that carries activations to 16 mantissa bits (pika_gemm.h: pika_operand_t.seg). */
 int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
                   const float *beta, float eps, float momentum, float *running_mean,
                   float *running_var, float *save_mean, float *save_rstd, void *y, int y_dtype,
-                  void *stream);
+                  void *y_lo, void *stream);
 
 /* Backward, two launches: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (fp64); then
  * dx = gamma*rstd*(dy - sum_dy/rows - xhat*sum_dy_xhat/rows), dgamma = sum dy*xhat, dbeta = sum dy.
@@ -38,10 +40,10 @@ int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long row
 /* nn.LayerNorm over the last dimension of x (rows, C) f32 contiguous (pre-LN transformer layers,
  * /root/reference/trainer/model/transformer.py:85-100, position_ffn.py:36): C % 4 == 0, C <= 2048.
  * y may be written as bf16 (y_dtype PIKA_BF16, pika_gemm.h) when it only feeds MFMA products; mean /
- * rstd (rows each) are kept for the backward, whose incoming gradient may be bf16 as well.
+ * rstd (rows each) are kept for the backward, whose incoming gradient may be bf16 as well; y_lo as in pika_bn_apply.
  * dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; dgamma = sum dy*xhat; dbeta = sum dy. */
 int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamma, const float *beta,
-                        float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
+                        float eps, void *y, int y_dtype, void *y_lo, float *mean, float *rstd, void *stream);
 int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
                         const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
                         void *stream);

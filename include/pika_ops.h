@@ -46,9 +46,13 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
  *       columns up to Cp zero (Cp >= C, Cp % 8 == 0; Cp % 64 == 0 keeps the direct-to-LDS kernels applicable):
  *       for operands whose reduction index is the contiguous one; a time-delay view over dst has S*Cp channels.
  *   PIKA_SPLIT_STACK: dst (S, n_batch, t_in, C) bf16, segment s = block s: for `trans` operands, whose reduction
- *       runs over the rows (Cp must equal C). */
+ *       runs over the rows (Cp must equal C).
+ *   PIKA_SPLIT_PAIR (n_terms = 2, role ignored): dst (2, n_batch, t_in, Cp) bf16, plane 0 = t0 ("hi"), plane 1 = t1
+ *       ("lo"), pad columns zero: the two-term A operand of pika_gemm_bf16_ex (pika_operand_t.seg = Cp,
+ *       lo_off = n_batch * t_in * Cp). */
 #define PIKA_SPLIT_CONCAT 0
 #define PIKA_SPLIT_STACK 1
+#define PIKA_SPLIT_PAIR 2
 int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
                           int role, int n_terms, int layout, int Cp, void *dst, void *stream);
 

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -43,9 +43,12 @@ SIGNATURES = {
     "pika_gemm_bf16_dropout_residual": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, ctypes.c_float,
                                              ctypes.c_uint, _vp, _ll, _vp]),
     "pika_dropout_mask_cast_bf16": (_i, [_vp, _ll, _i, _i, ctypes.c_float, ctypes.c_uint, _vp, _ll, _vp]),
+    "pika_gemm_bf16_ex": (_i, [_vp, _vp]),
     # include/pika_attn.h
-    "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _ll, _ll, ctypes.c_float, ctypes.c_uint, _vp]),
-    "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
+    "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_attention_fwd_two_term": (_i, [_vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
+                                         ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
                                 ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_attention_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
     # include/pika_ops.h
@@ -66,11 +69,11 @@ SIGNATURES = {
     "pika_mbr_risk_grad_rows": (_i, [_vp, _vp, _vp, _ll, _i, _ll, ctypes.c_float, _vp]),
     "pika_edit_distances": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     # include/pika_norm.h
-    "pika_layer_norm_fwd": (_i, [_vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp]),
+    "pika_layer_norm_fwd": (_i, [_vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp]),
     "pika_bn_apply": (_i, [_vp, _ll, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp,
-                           _vp, _i, _vp]),
+                           _vp, _i, _vp, _vp]),
     "pika_bn_backward": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     # include/pika_decode.h
     "pika_incremental_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

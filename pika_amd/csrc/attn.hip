@@ -176,7 +176,13 @@ struct Args {
     uint32_t seed, thr;
     const uint64_t *bits;   // keep bits [b*H+h][query][ceil(T/64)] (dropout only)
     int nkb;
+    const unsigned char *mask;   // optional (B, T, T) bytes, non-zero = score masked to -1e18 (multi_headed_attn.py:217)
+    long long lo_off, olo_off;   // two-term forward: element offset of the "lo" planes of q/k/v and of out
 };
+
+// masked_fill(mask, -1e18) in the kernels' log2 domain (scores carry log2(e)): a FINITE fill, as in the reference -- a
+// row whose keys are all masked comes out uniform, not NaN
+constexpr float MASKED = -1.4426950408889634e18f;
 
 template <int D, typename T_>
 __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
@@ -207,6 +213,16 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
             s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) s[kt] = mfma(frag_n<P>(Ks, kt * 16, ks * 32, lane), qf[ks], s[kt]);
+        }
+        if (A.mask) {
+            const unsigned char *mrow = A.mask + ((long long)b * T + min(qrow, T - 1)) * T;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + kt * 16 + g * 4 + r;
+                    if (key < T && mrow[key]) s[kt][r] = MASKED;
+                }
         }
         if (kb + TILE > T) {
 #pragma unroll
@@ -257,6 +273,146 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
         T_ *o = static_cast<T_ *>(A.o) + (long long)b * T * A.ldo + (long long)h * D + (long long)qrow * A.ldo + g * 4;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) store4(o + dt * 16, oacc[dt] * sc);
+        if (g == 0) A.lse_w[(long long)bh * T + qrow] = m + __log2f(l);
+    }
+}
+
+
+// Forward in TWO-TERM arithmetic (the parity-carrying train step: DESIGN 6.1): q, k, v arrive as bf16 "hi" planes with
+// a "lo" plane A.lo_off elements behind (x = hi + lo to 16 mantissa bits: the EPI 1 two-term output of the packed
+// projection GEMM), and both products keep the three leading term products on the matrix cores:
+//   S^T = Kh.qh + Kl.qh + Kh.ql        O^T = Vh^T.ph + Vl^T.ph + Vh^T.pl
+// with the softmax in fp32 in between (p = ph + pl split in registers).  The context goes out as two planes as well
+// (A.olo_off), the two-term operand of the output projection.  The backward runs on the hi planes (bf16 kernels above).
+// Same tiling as attn_fwd_kernel; the four 64-row tiles (K / V, hi / lo) take 36 / 68 KB of dynamic LDS for D = 64 / 128.
+__device__ inline float hi_of(uint32_t w, int half) {     // the bf16 in the low / high half of w as a float
+    return __builtin_bit_cast(float, half ? (w & 0xffff0000u) : (w << 16));
+}
+template <int D>
+__device__ inline void row_frags2(bf16x8 *fh, bf16x8 *fl, const __bf16 *hi, const __bf16 *lo, int g, float scale) {
+#pragma unroll
+    for (int ks = 0; ks < D / 32; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(hi + ks * 32 + g * 8);
+        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(lo + ks * 32 + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = ((float)a[e] + (float)b[e]) * scale;
+            const __bf16 h = (__bf16)x;
+            fh[ks][e] = h;
+            fl[ks][e] = (__bf16)(x - (float)h);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void attn_fwd2_kernel(Args A) {
+    const __bf16 *Aq = static_cast<const __bf16 *>(A.q), *Ak = static_cast<const __bf16 *>(A.k), *Av = static_cast<const __bf16 *>(A.v);
+    constexpr int P = D + 8, KS = D / 32, DT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    __bf16 *Kh = reinterpret_cast<__bf16 *>(smem2), *Kl = Kh + TILE * P, *Vh = Kl + TILE * P, *Vl = Vh + TILE * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int T = A.T, h = blockIdx.y, b = blockIdx.z;
+    const int qrow = blockIdx.x * TILE + wave * 16 + (lane & 15);
+    const long long boff = (long long)b * T * A.ld + (long long)h * D;
+    const uint32_t bh = (uint32_t)(b * A.H + h);
+    bf16x8 qh[KS], ql[KS];
+    {
+        const __bf16 *qp = Aq + boff + (long long)min(qrow, T - 1) * A.ld;
+        row_frags2<D>(qh, ql, qp, qp + A.lo_off, g, A.qscale);
+    }
+    const uint64_t *bits = A.bits + ((long long)bh * T + min(qrow, T - 1)) * A.nkb;
+    const unsigned char *mrow = A.mask ? A.mask + ((long long)b * T + min(qrow, T - 1)) * T : nullptr;
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lpart = 0.f;
+    for (int kb = 0; kb < T; kb += TILE) {
+        __syncthreads();
+        load_tile<D>(Kh, Ak + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Kl, Ak + A.lo_off + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vh, Av + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vl, Av + A.lo_off + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {     // small terms first
+                const bf16x8 kh = frag_n<P>(Kh, kt * 16, ks * 32, lane);
+                s[kt] = mfma(frag_n<P>(Kl, kt * 16, ks * 32, lane), qh[ks], s[kt]);
+                s[kt] = mfma(kh, ql[ks], s[kt]);
+                s[kt] = mfma(kh, qh[ks], s[kt]);
+            }
+        }
+        if (mrow) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + kt * 16 + g * 4 + r;
+                    if (key < T && mrow[key]) s[kt][r] = MASKED;
+                }
+        }
+        if (kb + TILE > T) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb + kt * 16 + g * 4 + r >= T) s[kt][r] = -INFINITY;
+        }
+        float mb = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) mb = fmaxf(mb, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        mb = fmaxf(mb, __shfl_xor(mb, 16));
+        mb = fmaxf(mb, __shfl_xor(mb, 32));
+        const float mn = fmaxf(m, mb), alpha = ex2(m - mn);
+        m = mn;
+        lpart *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
+        const uint64_t kw = A.thr ? (bits[kb >> 6] >> (g * 4)) : ~0ull;   // bit kt*16 + r = key kt*16 + g*4 + r
+        const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
+        uint32_t wh[8], wl[8];      // word 2*kt + j = keys (kt*16 + g*4 + 2j, +1): the k-slots of MFMA s2 = kt / 2
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float p0 = ex2(s[kt][2 * j] - mn), p1 = ex2(s[kt][2 * j + 1] - mn);
+                lpart += p0 + p1;
+                const uint32_t kwd = kt < 2 ? kw0 : kw1;
+                p0 = keep_if(p0, kwd, (kt & 1) * 16 + 2 * j);
+                p1 = keep_if(p1, kwd, (kt & 1) * 16 + 2 * j + 1);
+                const uint32_t w = pack2(p0, p1);
+                wh[2 * kt + j] = w;
+                wl[2 * kt + j] = pack2(p0 - hi_of(w, 0), p1 - hi_of(w, 1));
+            }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 ph = __builtin_bit_cast(bf16x8, u32x4{wh[4 * s2], wh[4 * s2 + 1], wh[4 * s2 + 2], wh[4 * s2 + 3]});
+            const bf16x8 pl = __builtin_bit_cast(bf16x8, u32x4{wl[4 * s2], wl[4 * s2 + 1], wl[4 * s2 + 2], wl[4 * s2 + 3]});
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vh = frag_t<P>(Vh, dt * 16, s2 * 32, lane);
+                oacc[dt] = mfma(frag_t<P>(Vl, dt * 16, s2 * 32, lane), ph, oacc[dt]);
+                oacc[dt] = mfma(vh, pl, oacc[dt]);
+                oacc[dt] = mfma(vh, ph, oacc[dt]);
+            }
+        }
+    }
+    float l = lpart;
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qrow < T) {
+        const float sc = A.inv_keep / l;
+        __bf16 *o = static_cast<__bf16 *>(A.o) + (long long)b * T * A.ldo + (long long)h * D + (long long)qrow * A.ldo + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const f32x4 v = oacc[dt] * sc;
+            const bf16x4 hi4 = __builtin_convertvector(v, bf16x4);
+            *reinterpret_cast<bf16x4 *>(o + dt * 16) = hi4;
+            *reinterpret_cast<bf16x4 *>(o + A.olo_off + dt * 16) = __builtin_convertvector(v - __builtin_convertvector(hi4, f32x4), bf16x4);
+        }
         if (g == 0) A.lse_w[(long long)bh * T + qrow] = m + __log2f(l);
     }
 }
@@ -331,6 +487,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb + kt * 16 + g * 4 + r;
+                    if (A.mask && key < T && A.mask[((long long)b * T + min(qrow, T - 1)) * T + key]) sa[r] = MASKED;
                     const float p = key < T ? ex2(sa[r] - lse) : 0.f;
                     const float d = keep_if(dp[r] * A.inv_keep, s2 == 0 ? kw0 : kw1, half * 16 + r);
                     ds[r] = p * (d - delta);
@@ -402,6 +559,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qt * 16 + g * 4 + r;
+                    if (A.mask && qb + qi < T && A.mask[((long long)b * T + qb + qi) * T + min(krow, T - 1)]) sa[r] = MASKED;
                     const float p = ex2(sa[r] - lse_s[qi]);
                     // this lane's key is bit (krow & 63) of the query's keep word: the half that holds it, then one
                     // sign-extended bit field as an AND mask for both products
@@ -485,16 +643,19 @@ void launch_bwd(const Args &A, dim3 grid, int rows, float *delta, hipStream_t s)
 
 extern "C" {
 
-int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
-                       void *keep_bits, int B, int T, int H, int D, long long ld, long long ldo,
-                       float p_drop, unsigned seed, void *stream) {
-    if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16) return PIKA_EINVAL;
+static int attention_fwd_impl(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
+                              void *keep_bits, const unsigned char *mask, long long lo_off, long long olo_off, int B, int T,
+                              int H, int D, long long ld, long long ldo, float p_drop, unsigned seed, void *stream) {
+    if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16 && io_dtype != -2) return PIKA_EINVAL;
+    const bool two_term = io_dtype == -2;
+    if (two_term) io_dtype = PIKA_BF16;
     const int g = io_dtype == PIKA_F32 ? 4 : 8;
     if (!args_ok(q, k, v, out, B, T, H, D, ld, p_drop, g) || !lse || ldo < (long long)H * D || (ldo & (g - 1))) return PIKA_EINVAL;
     if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
     Args A{};
     A.q = q; A.k = k; A.v = v; A.o = out; A.lse_w = lse; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
     A.qscale = 1.4426950408889634f / sqrtf((float)D);
+    A.mask = mask; A.lo_off = lo_off; A.olo_off = olo_off;
     dropout_consts(A, p_drop, seed);
     const dim3 grid((T + TILE - 1) / TILE, H, B);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -506,7 +667,19 @@ int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, i
                            static_cast<uint64_t *>(keep_bits), (long long)B * H * T, A.nkb, A.seed, A.thr);
         A.bits = static_cast<const uint64_t *>(keep_bits);
     }
-    if (io_dtype == PIKA_F32) {
+    if (two_term) {
+        if ((lo_off & 7) || (olo_off & 7)) return PIKA_EINVAL;
+        const size_t lds = (size_t)4 * TILE * (D + 8) * sizeof(__bf16);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd2_kernel<128>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE * 136 * 2);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        if (D == 64) hipLaunchKernelGGL(attn_fwd2_kernel<64>, grid, dim3(THREADS), lds, s, A);
+        else hipLaunchKernelGGL(attn_fwd2_kernel<128>, grid, dim3(THREADS), lds, s, A);
+    } else if (io_dtype == PIKA_F32) {
         if (D == 64) launch_fwd<64, float>(A, grid, s); else launch_fwd<128, float>(A, grid, s);
     } else {
         if (D == 64) launch_fwd<64, __bf16>(A, grid, s); else launch_fwd<128, __bf16>(A, grid, s);
@@ -514,8 +687,23 @@ int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, i
     return (int)hipGetLastError();
 }
 
+int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
+                       void *keep_bits, const void *mask, int B, int T, int H, int D, long long ld, long long ldo,
+                       float p_drop, unsigned seed, void *stream) {
+    if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16) return PIKA_EINVAL;
+    return attention_fwd_impl(q, k, v, out, io_dtype, lse, keep_bits, static_cast<const unsigned char *>(mask), 0, 0, B, T, H,
+                              D, ld, ldo, p_drop, seed, stream);
+}
+
+int pika_attention_fwd_two_term(const void *q, const void *k, const void *v, long long lo_off, void *out,
+                                long long out_lo_off, float *lse, void *keep_bits, const void *mask, int B, int T,
+                                int H, int D, long long ld, long long ldo, float p_drop, unsigned seed, void *stream) {
+    return attention_fwd_impl(q, k, v, out, -2, lse, keep_bits, static_cast<const unsigned char *>(mask), lo_off, out_lo_off,
+                              B, T, H, D, ld, ldo, p_drop, seed, stream);
+}
+
 int pika_attention_bwd(const void *q, const void *k, const void *v, const void *out, const void *dout,
-                       int io_dtype, const float *lse, const void *keep_bits, float *delta, void *dq,
+                       int io_dtype, const float *lse, const void *keep_bits, const void *mask, float *delta, void *dq,
                        void *dk, void *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream) {
     if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16) return PIKA_EINVAL;
@@ -528,6 +716,7 @@ int pika_attention_bwd(const void *q, const void *k, const void *v, const void *
     A.q = q; A.k = k; A.v = v; A.out = out; A.dout = dout; A.lse = lse; A.delta = delta;
     A.dq = dq; A.dk = dk; A.dv = dv; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
     A.qscale = 1.4426950408889634f / sqrtf((float)D);
+    A.mask = static_cast<const unsigned char *>(mask);
     dropout_consts(A, p_drop, seed);
     A.nkb = (T + 63) / 64;
     if (A.thr) {

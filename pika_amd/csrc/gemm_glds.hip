@@ -155,9 +155,14 @@ struct PPArgs {
     int a_rpb, a_C;                    // rows per batch, channels per tap
     int a_tin, a_t0, a_tstep, a_dtap;  // source time of (row t, tap) = t * a_tstep + tap * a_dtap - a_t0, zero outside [0, a_tin)
     int a_bounds;                      // 0: every (row, tap) is in range (no checks in the loop)
+    // two-term A operand (pika_operand_t.seg): the a_C = 3 * a_seg reduction columns of a tap are the segments
+    // [hi | lo | hi] of a_seg columns each; "lo" columns are read a_lo elements behind the same "hi" column
+    int a_seg;
+    long long a_lo;
     int M, N, K, relu;
     // fused epilogues (EPI 1, 2): bf16 output, dropout / auxiliary mask
     __bf16 *out16;
+    __bf16 *out16_lo;                  // EPI 1, optional: second plane, bf16(v - (float)bf16(v)) of what out16 received
     const __bf16 *aux;
     long long ldo16, ld_aux;
     float scale;                       // EPI 1: 1/(1-p) for kept values; EPI 2: factor for unmasked values
@@ -265,15 +270,26 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     // The fetch cursor: the K-tile whose eight 1 KB pieces (A0..A3, B0..B3 per wave) are being issued.  It runs
     // one to two K-tiles ahead of the MFMAs and walks straight from the last K-tile of an output tile into the
     // first K-tile of the workgroup's next output tile.  pa/pb/ts always belong to the cursor's tile.
+    // x_src = where the 64 reduction columns at x_c0 of the tap lie in memory, in elements from the tap's first
+    // column: x_c0 itself, or for a two-term operand the column inside its [hi | lo | hi] segment (+ a_lo for "lo")
     int x_slot = blockIdx.x, x_kt = 0, x_tap = 0, x_c0 = 0;
+    long long x_src = 0;
     bool x_ok = true;
     setup(x_slot);
+    auto next_cols = [&]() {
+        x_c0 += 64;
+        x_src += 64;
+        if (x_c0 == P.a_C) { x_c0 = 0; x_src = 0; ++x_tap; }
+        else if (P.a_seg) {
+            if (x_c0 == P.a_seg) x_src = P.a_lo;
+            else if (x_c0 == 2 * P.a_seg) x_src = 0;
+        }
+    };
     auto advance = [&]() {
         if (++x_kt < nt) {
-            x_c0 += 64;
-            if (x_c0 == P.a_C) { x_c0 = 0; ++x_tap; }
+            next_cols();
         } else {
-            x_kt = 0; x_tap = 0; x_c0 = 0;
+            x_kt = 0; x_tap = 0; x_c0 = 0; x_src = 0;
             x_slot += stride;
             x_ok = x_slot < ntiles;
             if (x_ok) setup(x_slot);
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     };
     // `dst` = the K-tile buffer.  With `bounds`, rows whose source time is outside the signal read a zero page.
     auto issue_a = [&](int i, unsigned char *dst) {
-        const char *base = sa + ((long long)x_tap * P.a_tap + x_c0) * 2;
+        const char *base = sa + ((long long)x_tap * P.a_tap + x_src) * 2;
         if (!bounds) {
             gl(base + ao[i], dst + i * 8192 + wave * 1024);
         } else {
@@ -392,8 +408,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 advance();   // (into the workgroup's next output tile behind the last K-tile of this one)
             } else {
                 ++x_kt;
-                x_c0 += 64;
-                if (x_c0 == P.a_C) { x_c0 = 0; ++x_tap; }
+                next_cols();
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -536,10 +551,19 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     }
                 }
                 __bf16 *op = P.out16 + (long long)m * P.ldo16 + n;
+                const bf16x4 hi4 = __builtin_convertvector(v, bf16x4);
                 if (n + 3 < N) {
-                    *reinterpret_cast<bf16x4 *>(op) = __builtin_convertvector(v, bf16x4);
+                    *reinterpret_cast<bf16x4 *>(op) = hi4;
                 } else {
-                    for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = (__bf16)v[e];
+                    for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = hi4[e];
+                }
+                if constexpr (EPI == 1) {
+                    if (P.out16_lo) {      // the second term of the value: what the bf16 rounding above dropped
+                        const bf16x4 lo4 = __builtin_convertvector(v - __builtin_convertvector(hi4, f32x4), bf16x4);
+                        __bf16 *lp = P.out16_lo + (long long)m * P.ldo16 + n;
+                        if (n + 3 < N) *reinterpret_cast<bf16x4 *>(lp) = lo4;
+                        else for (int e = 0; e < 4; ++e) if (n + e < N) lp[e] = lo4[e];
+                    }
                 }
             }
         }
@@ -888,7 +912,7 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
-        if constexpr (EPI <= 1)   // padded time-delay operands only reach the plain epilogues (pika_gemm_nt)
+        if constexpr (EPI <= 1)   // padded time-delay operands only reach the plain epilogues (pika_gemm_nt, pika_gemm_bf16_ex)
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<EPI, true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
         if (e != hipSuccess) return (int)e;
@@ -1024,6 +1048,32 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
     return (int)hipGetLastError();
 }
 
+// The A side of a PPArgs from an operand descriptor: a plain bf16 matrix or a time-delay view whose taps are whole
+// K-tiles; rows whose source time leaves [0, t_in) (padded convolutions, the transposed convolution of dX) are
+// redirected to a zero page inside the kernel (a_bounds).  A two-term operand (seg > 0) presents 3 * seg reduction
+// columns per tap, [hi | lo | hi], over seg stored columns and a second plane lo_off elements behind the first.
+bool pp_fill_a(const pika_operand_t &A, int K, PPArgs &P) {
+    if (A.dtype != PIKA_BF16 || A.trans || (A.ld & 7) || (A.batch_stride & 7) || (reinterpret_cast<uintptr_t>(A.ptr) & 15))
+        return false;
+    const int a_C = A.C < K ? A.C : K;
+    if ((a_C & 63) || K % a_C) return false;
+    if (A.seg) {
+        if (A.seg < 0 || (A.seg & 63) || a_C != 3 * A.seg || (A.lo_off & 7)) return false;
+    } else if (A.lo_off) {
+        return false;
+    }
+    const int taps = K / a_C;
+    const bool bounds = A.pad > 0 || (long long)(A.rows_per_batch - 1) * A.stride + (long long)(taps - 1) * A.dil - A.pad >= A.t_in;
+    P.A = static_cast<const __bf16 *>(A.ptr);
+    P.a_rpb = A.rows_per_batch; P.a_batch = A.batch_stride; P.a_row = (long long)A.stride * A.ld;
+    P.a_tap = (long long)A.dil * A.ld; P.a_C = a_C;
+    P.a_tin = A.t_in; P.a_t0 = A.pad; P.a_tstep = A.stride; P.a_dtap = A.dil; P.a_bounds = bounds ? 1 : 0;
+    P.a_seg = A.seg; P.a_lo = A.lo_off;
+    // the row pointer of tap 0 starts `pad` source rows before the signal; only ever dereferenced in range
+    P.A -= (long long)A.pad * A.ld;
+    return true;
+}
+
 }  // namespace
 
 // Used by pika_gemm_nt (gemm.hip): returns PIKA_NOT_APPLICABLE when the operands do not fit the
@@ -1039,23 +1089,11 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     // B: plain matrix
     if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
         return PIKA_NOT_APPLICABLE;
-    // A: plain matrix or time-delay view whose taps are whole K-tiles and never leave [0, t_in)
-    if ((A->ld & 7) || (A->batch_stride & 7) || (reinterpret_cast<uintptr_t>(A->ptr) & 15)) return PIKA_NOT_APPLICABLE;
-    const int a_C = A->C < K ? A->C : K;
-    if ((a_C & 63) || K % a_C) return PIKA_NOT_APPLICABLE;
-    const int taps = K / a_C;
-    // rows whose source time leaves [0, t_in) (padded convolutions, the transposed convolution of dX) are
-    // redirected to a zero page inside the kernel
-    const bool bounds = A->pad > 0 || (long long)(A->rows_per_batch - 1) * A->stride + (long long)(taps - 1) * A->dil - A->pad >= A->t_in;
     if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < 160) return PIKA_NOT_APPLICABLE;
     PPArgs P{};
-    P.A = static_cast<const __bf16 *>(A->ptr); P.B = static_cast<const __bf16 *>(B->ptr);
+    if (!pp_fill_a(*A, K, P)) return PIKA_NOT_APPLICABLE;
+    P.B = static_cast<const __bf16 *>(B->ptr);
     P.C = C; P.bias = bias; P.ldb = B->ld; P.ldc = ldc;
-    P.a_rpb = A->rows_per_batch; P.a_batch = A->batch_stride; P.a_row = (long long)A->stride * A->ld;
-    P.a_tap = (long long)A->dil * A->ld; P.a_C = a_C;
-    P.a_tin = A->t_in; P.a_t0 = A->pad; P.a_tstep = A->stride; P.a_dtap = A->dil; P.a_bounds = bounds ? 1 : 0;
-    // the row pointer of tap 0 starts `pad` source rows before the signal; only ever dereferenced in range
-    P.A -= (long long)A->pad * A->ld;
     P.M = M; P.N = N; P.K = K; P.relu = (flags & PIKA_GEMM_RELU) ? 1 : 0;
     if (!pp_offsets_fit(P)) return PIKA_NOT_APPLICABLE;
     if (out16) {   // C is a bf16 matrix with pitch ldc: plain bf16 epilogue (no dropout)
@@ -1178,4 +1216,44 @@ extern "C" int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, f
     hipLaunchKernelGGL(pp_keep_mask_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), mask, rows, cols, seed, (unsigned)lrintf(p_drop * 65536.f));
     return (int)hipGetLastError();
+}
+
+// One entry for every product / epilogue combination of the direct-to-LDS kernel (include/pika_gemm.h).
+extern "C" int pika_gemm_bf16_ex(const pika_gemm_ex_t *g, void *stream) {
+    if (!g || !g->A.ptr || !g->B || !g->out || g->M <= 0 || g->N <= 0 || g->K <= 0) return PIKA_EINVAL;
+    if ((g->K % BK) || (g->ldb & 7) || (g->ldo & 3) || (reinterpret_cast<uintptr_t>(g->B) & 15)) return PIKA_EINVAL;
+    if (g->ldb < g->K) return PIKA_EINVAL;
+    if (!(g->p_drop >= 0.f && g->p_drop < 1.f)) return PIKA_EINVAL;
+    PPArgs P{};
+    if (!pp_fill_a(g->A, g->K, P)) return PIKA_EINVAL;
+    P.B = static_cast<const __bf16 *>(g->B); P.ldb = g->ldb; P.bias = g->bias;
+    P.M = g->M; P.N = g->N; P.K = g->K; P.relu = g->relu ? 1 : 0;
+    P.thr = (unsigned)lrintf(g->p_drop * 65536.f);
+    P.scale = 65536.f / (float)(65536u - P.thr);
+    P.seed = g->seed;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (g->epilogue) {
+        case PIKA_EPI_F32:
+            if (reinterpret_cast<uintptr_t>(g->out) & 15) return PIKA_EINVAL;
+            P.C = static_cast<float *>(g->out); P.ldc = g->ldo;
+            return launch_pp_epi<0>(P, s);
+        case PIKA_EPI_DROPOUT_BF16:
+            if ((reinterpret_cast<uintptr_t>(g->out) | reinterpret_cast<uintptr_t>(g->out_lo)) & 7) return PIKA_EINVAL;
+            P.out16 = static_cast<__bf16 *>(g->out); P.out16_lo = static_cast<__bf16 *>(g->out_lo); P.ldo16 = g->ldo;
+            return launch_pp_epi<1>(P, s);
+        case PIKA_EPI_MASK_BF16:
+            if (P.a_bounds || !g->aux || (g->ld_aux & 3) || ((reinterpret_cast<uintptr_t>(g->aux) | reinterpret_cast<uintptr_t>(g->out)) & 7))
+                return PIKA_EINVAL;
+            P.out16 = static_cast<__bf16 *>(g->out); P.ldo16 = g->ldo;
+            P.aux = static_cast<const __bf16 *>(g->aux); P.ld_aux = g->ld_aux; P.scale = g->scale; P.relu = 0;
+            return launch_pp_epi<2>(P, s);
+        case PIKA_EPI_DROPOUT_RESIDUAL:
+            if (P.a_bounds || !g->residual || (g->ld_res & 3) ||
+                ((reinterpret_cast<uintptr_t>(g->residual) | reinterpret_cast<uintptr_t>(g->out)) & 15))
+                return PIKA_EINVAL;
+            P.C = static_cast<float *>(g->out); P.ldc = g->ldo; P.res = g->residual; P.ld_res = g->ld_res; P.relu = 0;
+            return launch_pp_epi<3>(P, s);
+        default:
+            return PIKA_EINVAL;
+    }
 }

@@ -117,14 +117,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
                                                        const float *__restrict__ rstd,
                                                        const float *__restrict__ gamma,
                                                        const float *__restrict__ beta,
-                                                       TO *__restrict__ y) {
+                                                       TO *__restrict__ y, TO *__restrict__ y_lo) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int c = (int)(i % C4);
         const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
         const f32x4 m = reinterpret_cast<const f32x4 *>(mean)[c], r = reinterpret_cast<const f32x4 *>(rstd)[c];
         const f32x4 g = reinterpret_cast<const f32x4 *>(gamma)[c], b = reinterpret_cast<const f32x4 *>(beta)[c];
-        st4(y + 4 * i, (v - m) * r * g + b);
+        const f32x4 o = (v - m) * r * g + b;
+        st4(y + 4 * i, o);
+        if constexpr (sizeof(TO) == 2) {     // two-term output: the second plane holds what the bf16 rounding dropped
+            if (y_lo) st4(y_lo + 4 * i, o - __builtin_convertvector(__builtin_convertvector(o, bf16x4_t), f32x4));
+        }
     }
 }
 
@@ -187,6 +191,7 @@ __device__ inline float ln_wave_sum(float v) {
 template <typename TO, int LNQ>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, TO *__restrict__ y,
+                                                     TO *__restrict__ y_lo,
                                                      float *__restrict__ mean, float *__restrict__ rstd,
                                                      long long rows, int C, float eps) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -217,8 +222,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
         if (i < c4) {
             const ln_f4 g = reinterpret_cast<const ln_f4 *>(gamma)[i], b = reinterpret_cast<const ln_f4 *>(beta)[i];
             const ln_f4 o = (v[q] - mu) * rs * g + b;
-            if constexpr (sizeof(TO) == 4) reinterpret_cast<ln_f4 *>(y + r * C)[i] = o;
-            else reinterpret_cast<ln_b4 *>(y + r * C)[i] = __builtin_convertvector(o, ln_b4);
+            if constexpr (sizeof(TO) == 4) {
+                reinterpret_cast<ln_f4 *>(y + r * C)[i] = o;
+            } else {
+                const ln_b4 hi = __builtin_convertvector(o, ln_b4);
+                reinterpret_cast<ln_b4 *>(y + r * C)[i] = hi;
+                if (y_lo)   // two-term output: the second plane holds what the bf16 rounding dropped
+                    reinterpret_cast<ln_b4 *>(y_lo + r * C)[i] = __builtin_convertvector(o - __builtin_convertvector(hi, ln_f4), ln_b4);
+            }
         }
     }
 }
@@ -329,20 +340,21 @@ int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *st
 int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
                   const float *beta, float eps, float momentum, float *running_mean,
                   float *running_var, float *save_mean, float *save_rstd, void *y, int y_dtype,
-                  void *stream) {
+                  void *y_lo, void *stream) {
     if (!x || !stats || !gamma || !beta || !save_mean || !save_rstd || !y || rows <= 0 || C <= 0 || (C & 3))
         return PIKA_EINVAL;
     if (y_dtype != PIKA_F32 && y_dtype != PIKA_BF16) return PIKA_EINVAL;
+    if (y_lo && (y_dtype != PIKA_BF16 || (reinterpret_cast<uintptr_t>(y_lo) & 7))) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, rows, C, eps,
                        momentum, running_mean, running_var, save_mean, save_rstd);
     const long long n4 = rows * C / 4;
     if (y_dtype == PIKA_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
-                           save_rstd, gamma, beta, static_cast<float *>(y));
+                           save_rstd, gamma, beta, static_cast<float *>(y), static_cast<float *>(nullptr));
     else
         hipLaunchKernelGGL(bn_apply_kernel<__bf16>, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
-                           save_rstd, gamma, beta, static_cast<__bf16 *>(y));
+                           save_rstd, gamma, beta, static_cast<__bf16 *>(y), static_cast<__bf16 *>(y_lo));
     return (int)hipGetLastError();
 }
 
@@ -367,14 +379,15 @@ int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long row
 }
 
 int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamma, const float *beta,
-                        float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream) {
+                        float eps, void *y, int y_dtype, void *y_lo, float *mean, float *rstd, void *stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0) return PIKA_EINVAL;
+    if (y_lo && (y_dtype != PIKA_BF16 || (reinterpret_cast<uintptr_t>(y_lo) & 7))) return PIKA_EINVAL;
     if ((C & 3) || C > 64 * 4 * LNQ_MAX || rows > 0x7fffffffLL * 4) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15)
         return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((rows + 3) / 4));
-#define PIKA_LN_FWD(TO, Q) hipLaunchKernelGGL((ln_fwd_kernel<TO, Q>), grid, dim3(256), 0, s, x, gamma, beta, static_cast<TO *>(y), mean, rstd, rows, C, eps)
+#define PIKA_LN_FWD(TO, Q) hipLaunchKernelGGL((ln_fwd_kernel<TO, Q>), grid, dim3(256), 0, s, x, gamma, beta, static_cast<TO *>(y), static_cast<TO *>(y_lo), mean, rstd, rows, C, eps)
 #define PIKA_LN_FWD_Q(TO) do { if (C <= 512) PIKA_LN_FWD(TO, 2); else if (C <= 1024) PIKA_LN_FWD(TO, 4); else PIKA_LN_FWD(TO, 8); } while (0)
     if (y_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(y) & 15))
         PIKA_LN_FWD_Q(float);

@@ -241,26 +241,31 @@ int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long lon
                           int role, int n_terms, int layout, int Cp, void *dst, void *stream) {
     if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
     if (n_terms != 2 && n_terms != 3) return PIKA_EINVAL;
-    if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK) return PIKA_EINVAL;
+    if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK && layout != PIKA_SPLIT_PAIR) return PIKA_EINVAL;
+    if (layout == PIKA_SPLIT_PAIR && n_terms != 2) return PIKA_EINVAL;
     if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
         return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) return PIKA_EINVAL;
     const long long rows = (long long)n_batch * t_in;
     const long long n_gran = rows * (Cp >> 3);
     if ((n_gran + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
-    const int nseg = n_terms == 2 ? 3 : 6;
+    const int nseg = layout == PIKA_SPLIT_PAIR ? 2 : (n_terms == 2 ? 3 : 6);
     long long seg_stride, dst_batch, dst_ld;
-    if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
+    if (layout == PIKA_SPLIT_PAIR) { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
+    else if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
     else { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
     // term index per segment, two bits each (segment 0 in the low bits); the pairs (A side, B side) of one segment
     // are the products kept: two terms  h.h + l.h + h.l;  three terms  h.h + h.m + m.h + h.l + l.h + m.m
     static const unsigned pat[2][2] = {{0u | 1u << 2 | 0u << 4, 0u | 0u << 2 | 1u << 4},
                                        {0u | 0u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 1u << 10,
                                         0u | 1u << 2 | 0u << 4 | 2u << 6 | 0u << 8 | 1u << 10}};
-    const unsigned pattern = pat[n_terms - 2][role];
+    const unsigned pattern = layout == PIKA_SPLIT_PAIR ? (0u | 1u << 2) : pat[n_terms - 2][role];
     const dim3 grid((unsigned)((n_gran + 255) / 256));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (nseg == 3)
+    if (nseg == 2)
+        hipLaunchKernelGGL(split_terms_kernel<2>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
+                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
+    else if (nseg == 3)
         hipLaunchKernelGGL(split_terms_kernel<3>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
                            seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
     else

@@ -211,7 +211,7 @@ class FusedSearch(object):
     def _layer_norm(self, x, ln, y):
         rows, C = x.shape
         _lib.check(_lib.lib().pika_layer_norm_fwd(x.data_ptr(), rows, C, ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                                  float(ln.eps), y.data_ptr(), 0, self.mean.data_ptr(),
+                                                  float(ln.eps), y.data_ptr(), 0, None, self.mean.data_ptr(),
                                                   self.rstd.data_ptr(), _stream()), "pika_layer_norm_fwd")
 
     def _prednet(self, anc_dst, state_dst, count):

@@ -17,9 +17,16 @@ RELU, ACCUMULATE, FP32SPLIT = 1, 2, 4
 # "fp32":   exact three-term split, the six products above 2^-24 of the leading one (~1e-7; parity runs, decode):
 #           products large enough for the direct-to-LDS kernels take the same K-concatenation with six segments,
 #           everything else the register-staged kernel that issues the 6 MFMAs per loaded tile.
+# "mixed":  the train-step default that carries the parity statement of north_star (encoder activations and loss within
+#           1e-3 of the reference's fp32): FORWARD products of the encoder, the prediction network and the joint's
+#           projections in two bf16 terms per operand (hi.hi + lo.hi + hi.lo on the direct-to-LDS kernel through a
+#           segment map, pika_operand_t.seg: activations travel between products as two bf16 planes "hi" / "lo" written by
+#           the producing epilogue, LayerNorm, BatchNorm or attention kernel), the fused attention forward in the same
+#           arithmetic; the joint's lattice products and EVERY backward product on one bf16 term, reading the hi planes.
+#           Exact forward ReLU / dropout masks, bf16 gradients.
 # Overridable per call.
 PRECISION = os.environ.get("PIKA_GEMM_PRECISION", "bf16")
-PRECISIONS = ("bf16", "bf16x3", "fp32")
+PRECISIONS = ("bf16", "bf16x3", "fp32", "mixed")
 # "bf16x3": the joint's lattice products (fc2 over the (B,T,U) lattice and its two gradient products: half of a training
 # step's FLOPs, on a hidden the gate kernel writes once) stay in the config-2 bf16 arithmetic by default -- the
 # encoder, the prediction network and the joint's projections are what the parity statement (encoder activations,
@@ -29,7 +36,12 @@ X3_JOINT_BF16 = os.environ.get("PIKA_X3_JOINT", "bf16") != "x3"
 
 def joint_in_bf16():
     """The joint's lattice products run on bf16 operands: mode "bf16", or "bf16x3" with the default above."""
-    return PRECISION == "bf16" or (PRECISION == "bf16x3" and X3_JOINT_BF16)
+    return PRECISION in ("bf16", "mixed") or (PRECISION == "bf16x3" and X3_JOINT_BF16)
+
+
+def bf16_backward():
+    """Modes whose backward products run on one bf16 term (and whose activations between MFMA products are bf16 planes)."""
+    return PRECISION in ("bf16", "mixed")
 BF16X3_STATS = {"fast": 0, "exact": 0}     # "bf16x3" products taken by the split path / handed to the exact path
 FP32_STATS = {"concat": 0, "staged": 0}    # "fp32" products on the six-segment path / on the register-staged kernel
 
@@ -39,7 +51,7 @@ class Operand(ctypes.Structure):
                 ("t_in", ctypes.c_int), ("batch_stride", ctypes.c_longlong), ("ld", ctypes.c_longlong),
                 ("C", ctypes.c_int), ("stride", ctypes.c_int), ("dil", ctypes.c_int),
                 ("pad", ctypes.c_int), ("z_outer", ctypes.c_longlong), ("z_inner", ctypes.c_longlong),
-                ("trans", ctypes.c_int)]
+                ("trans", ctypes.c_int), ("seg", ctypes.c_int), ("lo_off", ctypes.c_longlong)]
 
 
 def _dtype(t):
@@ -80,6 +92,8 @@ def _flags(relu, accumulate, precision):
     p = precision or PRECISION
     if p not in PRECISIONS:
         raise ValueError("unknown GEMM precision %r" % (p,))
+    if p == "mixed":
+        p = "bf16"      # "mixed" forward products come through gemm_ex; what reaches pika_gemm_nt is the backward
     # "bf16x3" reaches here only for products its operand split does not take (launch): those run exactly
     return (RELU if relu else 0) | (ACCUMULATE if accumulate else 0) | (FP32SPLIT if p != "bf16" else 0)
 
@@ -193,6 +207,8 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
     keep = None
     p = precision or PRECISION
+    if p == "mixed":
+        p = precision = "bf16"
     if a_op.dtype == PIKA_BF16 and b_op.dtype == PIKA_BF16:
         p = precision = "bf16"              # a product of bf16 operands has nothing to split, whatever the mode
     elif p != "bf16" and (a_op.dtype == PIKA_BF16 or b_op.dtype == PIKA_BF16) and (a_op.trans or b_op.trans):
@@ -261,3 +277,86 @@ def gemm_bf16_nt(a, b, bias=None, out=None):
                                           torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pika_gemm_bf16_nt(M=%d,N=%d,K=%d)" % (M, N, K))
     return out
+
+
+# ---- pika_gemm_bf16_ex: every epilogue of the direct-to-LDS kernel over an operand descriptor (two-term operands) ----
+EPI_F32, EPI_DROPOUT_BF16, EPI_MASK_BF16, EPI_DROPOUT_RESIDUAL = 0, 1, 2, 3
+
+
+class GemmEx(ctypes.Structure):
+    _fields_ = [("A", Operand), ("B", ctypes.c_void_p), ("ldb", ctypes.c_longlong), ("M", ctypes.c_int),
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("bias", ctypes.c_void_p), ("relu", ctypes.c_int),
+                ("epilogue", ctypes.c_int), ("out", ctypes.c_void_p), ("out_lo", ctypes.c_void_p),
+                ("ldo", ctypes.c_longlong), ("p_drop", ctypes.c_float), ("seed", ctypes.c_uint),
+                ("aux", ctypes.c_void_p), ("ld_aux", ctypes.c_longlong), ("scale", ctypes.c_float),
+                ("residual", ctypes.c_void_p), ("ld_res", ctypes.c_longlong)]
+
+
+def gemm_ex(a_op, b, M, N, K, epilogue, out, out_lo=None, bias=None, relu=False, p_drop=0.0, seed=0, aux=None,
+            scale=1.0, residual=None):
+    """out = epilogue(A b^T): `a_op` an Operand (bf16; two-term with seg / lo_off), `b` a bf16 (N, >= K) matrix."""
+    if not out.is_cuda:
+        raise RuntimeError("pika_amd.gemm: tensors must live on a HIP device (no CPU path)")
+    assert b.dtype == torch.bfloat16 and b.dim() == 2 and b.stride(1) == 1 and b.shape[1] >= K and b.shape[0] >= N
+    assert out.stride(-1) == 1
+    g = GemmEx()
+    g.A = a_op
+    g.B, g.ldb, g.M, g.N, g.K = b.data_ptr(), b.stride(0), M, N, K
+    g.bias = None if bias is None else bias.data_ptr()
+    g.relu, g.epilogue = int(bool(relu)), epilogue
+    g.out, g.ldo = out.data_ptr(), out.stride(-2)
+    if out_lo is not None:
+        assert out_lo.stride(-2) == out.stride(-2) and out_lo.dtype == out.dtype == torch.bfloat16
+        g.out_lo = out_lo.data_ptr()
+    g.p_drop, g.seed = float(p_drop), int(seed)
+    if aux is not None:
+        g.aux, g.ld_aux = aux.data_ptr(), aux.stride(-2)
+    g.scale = float(scale)
+    if residual is not None:
+        g.residual, g.ld_res = residual.data_ptr(), residual.stride(-2)
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().pika_gemm_bf16_ex(ctypes.byref(g), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pika_gemm_bf16_ex(M=%d,N=%d,K=%d,epi=%d)" % (M, N, K, epilogue))
+    return out
+
+
+def split_pair(x2d, Cp=None):
+    """(hi, lo) bf16 planes (rows, Cp) of an f32 (rows, C) matrix (C % 8 == 0; columns [C, Cp) zero): x = hi + lo to 16
+    mantissa bits.  The planes share one buffer (lo directly behind hi)."""
+    assert x2d.dim() == 2 and x2d.dtype == torch.float32 and x2d.stride(1) == 1 and x2d.shape[1] % 8 == 0
+    rows, C = x2d.shape
+    Cp = _pad64(C) if Cp is None else Cp
+    buf = torch.empty((2, rows, Cp), dtype=torch.bfloat16, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = _lib.lib().pika_split_bf16_terms(x2d.data_ptr(), 1, rows, C, 0, x2d.stride(0), 0, 2, 2, Cp, buf.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pika_split_bf16_terms(pair)")
+    return buf[0], buf[1]
+
+
+def split_weight(w2d, taps=1):
+    """The B side of a two-term product: a bf16 (N, taps * 3 * Cp) copy of the f32 weight (N, taps * C) whose rows hold
+    [hi | hi | lo] per tap, Cp = C padded to a multiple of 64."""
+    N, K = w2d.shape
+    C = K // taps
+    assert C * taps == K and C % 8 == 0
+    w = w2d.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    Cp = _pad64(C)
+    op = Operand(w.data_ptr(), PIKA_F32, N * taps, N * taps, 0, C, C, 1, 0, 0, 0, 0)
+    with torch.cuda.device(w.device):
+        t = _split(op, 1, N * taps, C, 0, C, 1, 0, Cp, w.device, 2)
+    return t.view(N, taps * 3 * Cp)
+
+
+def pair_operand(hi, lo, rows, Cp, taps=1, dil=1, stride=1, pad=0, rows_per_batch=None, t_in=None, batch_stride=0):
+    """Operand descriptor of the two-term A side over the planes (hi, lo), each (.., Cp) with row pitch hi.stride(-2)."""
+    ld = hi.stride(-2)
+    lo_off = (lo.data_ptr() - hi.data_ptr()) // 2
+    assert lo.stride(-2) == ld and Cp % 64 == 0 and lo_off % 8 == 0
+    rpb = rows if rows_per_batch is None else rows_per_batch
+    op = Operand(hi.data_ptr(), PIKA_BF16, rpb, rpb if t_in is None else t_in, batch_stride, ld, 3 * Cp, stride, dil, pad,
+                 0, 0)
+    op.seg, op.lo_off = Cp, lo_off
+    return op

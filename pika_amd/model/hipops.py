@@ -40,7 +40,67 @@ def _pad8(n):
 
 def _tdtype():
     # transposed operands: bf16 halves their traffic; the split modes ("fp32", "bf16x3") need the fp32 bits
-    return torch.bfloat16 if G.PRECISION == "bf16" else torch.float32
+    return torch.bfloat16 if G.bf16_backward() else torch.float32
+
+
+def _mixed():
+    """Two-term forward / bf16 backward (pika_amd.gemm.PRECISION == "mixed")."""
+    return G.PRECISION == "mixed" and _fused()
+
+
+class Pair(object):
+    """A two-term activation x = hi + lo: two bf16 planes of one buffer (lo directly behind hi), written by the kernel
+    that produces the activation and read by the forward product that consumes it (gemm.pair_operand).  `hi` is the
+    tensor the bf16 mode would carry -- it is what autograd differentiates and what the backward products read; `lo`
+    is a non-differentiable companion.  Only what the model code needs of the tensor interface is provided."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def empty(shape, device):
+        buf = torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device)
+        return Pair(buf[0], buf[1])
+
+    shape = property(lambda self: self.hi.shape)
+    dtype = property(lambda self: self.hi.dtype)
+    device = property(lambda self: self.hi.device)
+    is_cuda = property(lambda self: self.hi.is_cuda)
+
+    def dim(self):
+        return self.hi.dim()
+
+    def size(self, *a):
+        return self.hi.size(*a)
+
+    def numel(self):
+        return self.hi.numel()
+
+    def view(self, *shape):
+        return Pair(self.hi.view(*shape), self.lo.view(*shape))
+
+    def reshape(self, *shape):
+        return Pair(self.hi.view(*shape), self.lo.view(*shape))     # planes are contiguous: never a copy
+
+    def contiguous(self):
+        return self
+
+    def float(self):
+        return self.hi.float() + self.lo.float()
+
+
+def _planes(x, x_lo, K):
+    """The two planes (rows, Cp) of the A side of a two-term product and Cp: from a pair that crosses autograd nodes
+    (x bf16 + x_lo, K % 64 == 0) or by splitting an f32 tensor here (K % 8 == 0; columns [K, Cp) zero)."""
+    if x.dtype == torch.bfloat16:
+        assert x_lo is not None and K % 64 == 0 and x.is_contiguous() and x_lo.is_contiguous()
+        return x.view(-1, K), x_lo.view(-1, K), K
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or (x2.stride(0) & 3):
+        x2 = x2.contiguous()
+    hi, lo = G.split_pair(x2.float() if x2.dtype != torch.float32 else x2)
+    return hi, lo, hi.shape[1]
 
 
 def transpose_cast(op, rows, K, device):
@@ -67,7 +127,7 @@ def _bf16_operand(t, min_elems=1 << 21):
     here halves the bytes every GEMM that consumes the matrix pulls through L2 (the forward product
     and the weight-gradient product read the same copy, the three taps of a time-delay operand
     re-read it)."""
-    if (G.PRECISION == "bf16" and _fused() and t.dtype == torch.float32 and t.numel() >= min_elems
+    if (G.bf16_backward() and _fused() and t.dtype == torch.float32 and t.numel() >= min_elems
             and t.shape[-1] % 8 == 0):
         return t.to(torch.bfloat16)
     return t
@@ -145,12 +205,36 @@ class LinearFn(torch.autograd.Function):
     out_bf16 asks for a bf16 y under the same contract (its gradient arrives bf16, no casts anywhere)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, out_bf16=False):
+    def forward(ctx, x, weight, bias, relu, out_bf16=False, x_lo=None, out_pair=False):
         K = x.shape[-1]
+        ctx.set_materialize_grads(False)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.x_bf16 = x.dtype == torch.bfloat16
+        if _mixed() and K % 8 == 0 and (x_lo is not None or x.dtype == torch.float32):
+            # two-term forward product: hi.hi + lo.hi + hi.lo over a three times longer reduction (gemm.pair_operand)
+            N = weight.shape[0]
+            with torch.cuda.device(x.device):
+                hi, lo, Cp = _planes(x, x_lo, K)
+                M = hi.shape[0]
+                a_op = G.pair_operand(hi, lo, M, Cp)
+                wb = G.split_weight(weight)
+                if out_pair:
+                    out = Pair.empty(x.shape[:-1] + (N,), x.device)
+                    G.gemm_ex(a_op, wb, M, N, 3 * Cp, G.EPI_DROPOUT_BF16, out.hi.view(-1, N), out_lo=out.lo.view(-1, N),
+                              bias=bias, relu=relu)
+                else:
+                    out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+                    G.gemm_ex(a_op, wb, M, N, 3 * Cp, G.EPI_F32, out.view(-1, N), bias=bias, relu=relu)
+            y = out.hi if out_pair else out
+            ctx.save_for_backward(hi[:, :K], weight, y if relu == 1 else None)   # the backward reads the hi plane
+            if out_pair:
+                ctx.mark_non_differentiable(out.lo)
+                return out.hi, out.lo
+            return out
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or (x2.stride(0) & 3):
             x2 = x2.contiguous()
-        ctx.x_bf16 = x.dtype == torch.bfloat16
         x2 = _bf16_operand(x2)
         N = weight.shape[0]
         M = x2.shape[0]
@@ -161,16 +245,15 @@ class LinearFn(torch.autograd.Function):
                                relu=1 if relu else 0)
             else:
                 out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)  # not a view:
-                G.gemm_nt(x2, _weight_for(x2, weight), bias=bias, relu=relu, out=out.view(-1, N))  # may be
+                G.gemm_nt(x2, _weight_for(x2, weight), bias=bias, relu=relu, out=out.view(-1, N),  # may be
+                          precision="fp32" if (_mixed() and x2.dtype == torch.float32) else None)
                 if out_bf16:                                                        # overwritten in place
                     out = out.to(torch.bfloat16)
-        ctx.relu = relu
-        ctx.has_bias = bias is not None
         ctx.save_for_backward(x2, weight, out if relu == 1 else None)
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x2, weight, y = ctx.saved_tensors
         N, K = weight.shape
         dy2 = dy.reshape(-1, N)
@@ -193,7 +276,7 @@ class LinearFn(torch.autograd.Function):
                 dw = _grad_weight(dyb, G.matrix(x2)[0], _g(x2), M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum_any(dy2)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -201,24 +284,30 @@ class LayerNormFn(torch.autograd.Function):
     products, so it is produced (and its gradient accepted) in bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_bf16):
+    def forward(ctx, x, weight, bias, eps, out_bf16, out_pair=False):
         C = x.shape[-1]
         x2 = x.reshape(-1, C).contiguous()
         rows = x2.shape[0]
+        ctx.set_materialize_grads(False)
+        out_bf16 = out_bf16 or out_pair
         dt = torch.bfloat16 if out_bf16 else torch.float32
-        y = torch.empty(x.shape, dtype=dt, device=x.device)
+        pair = Pair.empty(x.shape, x.device) if out_pair else None      # two planes: y = hi + lo
+        y = pair.hi if out_pair else torch.empty(x.shape, dtype=dt, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(_lib.lib().pika_layer_norm_fwd(
                 x2.data_ptr(), rows, C, weight.data_ptr(), bias.data_ptr(), float(eps), y.data_ptr(),
-                G.PIKA_BF16 if out_bf16 else G.PIKA_F32, mean.data_ptr(), rstd.data_ptr(), _stream()),
-                "pika_layer_norm_fwd")
+                G.PIKA_BF16 if out_bf16 else G.PIKA_F32, pair.lo.data_ptr() if out_pair else None, mean.data_ptr(),
+                rstd.data_ptr(), _stream()), "pika_layer_norm_fwd")
         ctx.save_for_backward(x2, weight, mean, rstd)
+        if out_pair:
+            ctx.mark_non_differentiable(pair.lo)
+            return pair.hi, pair.lo
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x2, weight, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
         if dy.dtype not in (torch.float32, torch.bfloat16):
@@ -232,7 +321,7 @@ class LayerNormFn(torch.autograd.Function):
                 dy.data_ptr(), G.PIKA_F32 if dy.dtype == torch.float32 else G.PIKA_BF16, x2.data_ptr(), rows, C,
                 weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                 _stream()), "pika_layer_norm_bwd")
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 class TimeDelayFn(torch.autograd.Function):
@@ -243,13 +332,28 @@ class TimeDelayFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w2d, bias, taps, dil, stride, pad, relu):
-        x = _bf16_operand(x.contiguous())
         Bn, T, C = x.shape
         N = w2d.shape[0]
+        if _mixed() and x.dtype == torch.float32 and C % 8 == 0:
+            # two-term forward product over a time-delay view of the two planes (3 * Cp reduction columns per tap)
+            with torch.cuda.device(x.device):
+                hi, lo, Cp = _planes(x.contiguous(), None, C)
+                t_out = G.time_delay(x, taps, dil, stride, pad)[3]
+                a_op = G.pair_operand(hi, lo, Bn * t_out, Cp, taps, dil, stride, pad, rows_per_batch=t_out, t_in=T,
+                                      batch_stride=T * Cp)
+                y = torch.empty((Bn, t_out, N), dtype=torch.float32, device=x.device)
+                G.gemm_ex(a_op, G.split_weight(w2d, taps), Bn * t_out, N, taps * 3 * Cp, G.EPI_F32, y.view(-1, N), bias=bias,
+                          relu=relu)
+            ctx.cfg = (taps, dil, stride, pad, relu, t_out)
+            ctx.has_bias = bias is not None
+            ctx.save_for_backward(hi.view(Bn, T, Cp)[:, :, :C], w2d, y if relu == 1 else None)
+            return y
+        x = _bf16_operand(x.contiguous())
         with torch.cuda.device(x.device):
             a_op, M, K, t_out = G.time_delay(x, taps, dil, stride, pad)
             y = torch.empty((Bn, t_out, N), dtype=torch.float32, device=x.device)
-            G.launch(a_op, G.matrix(_weight_for(x, w2d))[0], y, N, M, N, K, bias=bias, relu=relu)
+            G.launch(a_op, G.matrix(_weight_for(x, w2d))[0], y, N, M, N, K, bias=bias, relu=relu,
+                     precision="fp32" if (_mixed() and x.dtype == torch.float32) else None)
         ctx.cfg = (taps, dil, stride, pad, relu, t_out)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w2d, y if relu == 1 else None)
@@ -490,7 +594,9 @@ def attention_ok(q, k, v, heads, mask):
     """AttentionFn preconditions: the encoder's self-attention (no mask, Tq == Tk), head width 64
     or 128, bf16 arithmetic mode."""
     D = q.shape[-1] // heads
-    return (G.PRECISION == "bf16" and _fused() and mask is None and q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
+    if mask is not None and (mask.dim() != 3 or mask.shape[1] != q.shape[1] or mask.shape[2] != k.shape[1]):
+        return False
+    return (G.bf16_backward() and _fused() and q.is_cuda and q.dtype in (torch.float32, torch.bfloat16)
             and q.shape == k.shape == v.shape and D in (64, 128) and D * heads == q.shape[-1])
 
 
@@ -503,27 +609,41 @@ def attention_keep_mask(BH, T, p_drop, seed, device):
     return m.bool()
 
 
-def _attn_fwd(q, k, v, out, lse, B, T, heads, D, ld, p_drop, seed):
-    """Returns the packed keep bits (None without dropout) the backward must be given."""
+def _mask_bytes(mask):
+    """(B, Tq, Tk) uint8 copy of a boolean attention mask (non-zero = masked), or None."""
+    return None if mask is None else mask.to(torch.uint8).contiguous()
+
+
+def _attn_fwd(q, k, v, out, lse, B, T, heads, D, ld, p_drop, seed, mask=None, lo_off=None, out_lo_off=0):
+    """Returns the packed keep bits (None without dropout) the backward must be given.  lo_off: q, k, v (and out) are the
+    hi planes of two-term tensors whose lo planes lie lo_off (out_lo_off) elements behind: two-term forward."""
     bits = None
     if p_drop > 0:
         bits = torch.empty((B * heads, T, (T + 63) // 64), dtype=torch.int64, device=out.device)
     with torch.cuda.device(out.device):
-        _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                                                 G.PIKA_F32 if q.dtype == torch.float32 else G.PIKA_BF16,
-                                                 lse.data_ptr(), None if bits is None else bits.data_ptr(),
-                                                 B, T, heads, D, ld, heads * D, float(p_drop),
-                                                 int(seed), _stream()), "pika_attention_fwd")
+        if lo_off is not None:
+            _lib.check(_lib.lib().pika_attention_fwd_two_term(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), lo_off, out.data_ptr(), out_lo_off, lse.data_ptr(),
+                None if bits is None else bits.data_ptr(), None if mask is None else mask.data_ptr(), B, T, heads, D, ld,
+                heads * D, float(p_drop), int(seed), _stream()), "pika_attention_fwd_two_term")
+        else:
+            _lib.check(_lib.lib().pika_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                                     G.PIKA_F32 if q.dtype == torch.float32 else G.PIKA_BF16,
+                                                     lse.data_ptr(), None if bits is None else bits.data_ptr(),
+                                                     None if mask is None else mask.data_ptr(),
+                                                     B, T, heads, D, ld, heads * D, float(p_drop),
+                                                     int(seed), _stream()), "pika_attention_fwd")
     return bits
 
 
-def _attn_bwd(q, k, v, out, dout, lse, bits, dq, dk, dv, B, T, heads, D, ld, p_drop, seed):
+def _attn_bwd(q, k, v, out, dout, lse, bits, dq, dk, dv, B, T, heads, D, ld, p_drop, seed, mask=None):
     delta = torch.empty_like(lse)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().pika_attention_bwd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
             G.PIKA_F32 if q.dtype == torch.float32 else G.PIKA_BF16, lse.data_ptr(),
-            None if bits is None else bits.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, D, ld, heads * D,
+            None if bits is None else bits.data_ptr(), None if mask is None else mask.data_ptr(), delta.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, T, heads, D, ld, heads * D,
             p_drop, seed, _stream()), "pika_attention_bwd")
 
 
@@ -532,24 +652,26 @@ class AttentionFn(torch.autograd.Function):
     (multi_headed_attn.py:199-231) without materialising the (B,H,T,T) tensors: include/pika_attn.h."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, p_drop, seed):
+    def forward(ctx, q, k, v, heads, p_drop, seed, mask=None):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, T, HD = q.shape
         out = torch.empty_like(q)
         lse = torch.empty(B * heads * T, dtype=torch.float32, device=q.device)
-        bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD, p_drop, seed)
+        mask = _mask_bytes(mask)
+        bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD, p_drop, seed, mask)
         ctx.cfg = (heads, float(p_drop), int(seed))
-        ctx.save_for_backward(q, k, v, out, lse, bits)
+        ctx.save_for_backward(q, k, v, out, lse, bits, mask)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, out, lse, bits = ctx.saved_tensors
+        q, k, v, out, lse, bits, mask = ctx.saved_tensors
         heads, p_drop, seed = ctx.cfg
         B, T, HD = q.shape
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-        _attn_bwd(q, k, v, out, dout.contiguous(), lse, bits, dq, dk, dv, B, T, heads, HD // heads, HD, p_drop, seed)
-        return dq, dk, dv, None, None, None
+        _attn_bwd(q, k, v, out, dout.contiguous(), lse, bits, dq, dk, dv, B, T, heads, HD // heads, HD, p_drop, seed,
+                  mask)
+        return dq, dk, dv, None, None, None, None
 
 
 class PackedAttentionFn(torch.autograd.Function):
@@ -557,29 +679,39 @@ class PackedAttentionFn(torch.autograd.Function):
     projections share their input, so they are one GEMM); the gradient comes back packed as well."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, p_drop, seed):
+    def forward(ctx, qkv, heads, p_drop, seed, qkv_lo=None, mask=None):
         qkv = qkv.contiguous()
         B, T, HD3 = qkv.shape
         HD = HD3 // 3
+        ctx.set_materialize_grads(False)
         q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
-        out = torch.empty((B, T, HD), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
-        bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD3, p_drop, seed)
+        mask = _mask_bytes(mask)
         ctx.cfg = (heads, float(p_drop), int(seed))
-        ctx.save_for_backward(qkv, out, lse, bits)
+        if qkv_lo is not None:      # two-term forward: (qkv, qkv_lo) -> (out, out_lo); the backward reads the hi planes
+            assert qkv.dtype == torch.bfloat16 and qkv_lo.is_contiguous()
+            pair = Pair.empty((B, T, HD), qkv.device)
+            bits = _attn_fwd(q, k, v, pair.hi, lse, B, T, heads, HD // heads, HD3, p_drop, seed, mask,
+                             lo_off=(qkv_lo.data_ptr() - qkv.data_ptr()) // 2, out_lo_off=pair.hi.numel())
+            ctx.save_for_backward(qkv, pair.hi, lse, bits, mask)
+            ctx.mark_non_differentiable(pair.lo)
+            return pair.hi, pair.lo
+        out = torch.empty((B, T, HD), dtype=qkv.dtype, device=qkv.device)
+        bits = _attn_fwd(q, k, v, out, lse, B, T, heads, HD // heads, HD3, p_drop, seed, mask)
+        ctx.save_for_backward(qkv, out, lse, bits, mask)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        qkv, out, lse, bits = ctx.saved_tensors
+    def backward(ctx, dout, *_):
+        qkv, out, lse, bits, mask = ctx.saved_tensors
         heads, p_drop, seed = ctx.cfg
         B, T, HD3 = qkv.shape
         HD = HD3 // 3
         dqkv = torch.empty_like(qkv)
         _attn_bwd(qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:], out, dout.to(qkv.dtype).contiguous(), lse, bits,
                   dqkv[..., :HD], dqkv[..., HD:2 * HD], dqkv[..., 2 * HD:], B, T, heads, HD // heads, HD3,
-                  p_drop, seed)
-        return dqkv, None, None, None
+                  p_drop, seed, mask)
+        return dqkv, None, None, None, None, None
 
 
 EPI_DROPOUT_BF16, EPI_MASK_BF16 = 1, 2
@@ -629,7 +761,7 @@ def _mask_cast(x2d, p_drop, seed):
 
 def linear_dropout_residual_ok(x, weight, residual):
     N, K = weight.shape
-    return (G.PRECISION == "bf16" and _fused() and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.float32
+    return (G.bf16_backward() and _fused() and x.is_cuda and x.dtype == torch.bfloat16 and residual.dtype == torch.float32
             and K % 64 == 0 and N % 64 == 0 and residual.shape[-1] == N and residual.is_contiguous())
 
 
@@ -639,12 +771,19 @@ class LinearDropoutResidualFn(torch.autograd.Function):
     while the incoming gradient is rounded to bf16 for the dX / dW products; the residual gets it as is."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, p_drop, seed):
+    def forward(ctx, x, weight, bias, residual, p_drop, seed, x_lo=None):
         N, K = weight.shape
         x2 = x.reshape(-1, K).contiguous()
         out = torch.empty(residual.shape, dtype=torch.float32, device=x.device)
-        _gemm_dropout_residual(x2, weight.detach().to(torch.bfloat16), out.view(-1, N), bias, p_drop, seed,
-                               residual.view(-1, N))
+        if x_lo is not None:        # two-term forward product
+            with torch.cuda.device(x.device):
+                hi, lo, Cp = _planes(x, x_lo, K)
+                G.gemm_ex(G.pair_operand(hi, lo, hi.shape[0], Cp), G.split_weight(weight), hi.shape[0], N, 3 * Cp,
+                          G.EPI_DROPOUT_RESIDUAL, out.view(-1, N), bias=bias, p_drop=p_drop, seed=seed,
+                          residual=residual.view(-1, N))
+        else:
+            _gemm_dropout_residual(x2, weight.detach().to(torch.bfloat16), out.view(-1, N), bias, p_drop, seed,
+                                   residual.view(-1, N))
         ctx.cfg = (float(p_drop), int(seed), x.shape)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x2, weight)
@@ -667,12 +806,12 @@ class LinearDropoutResidualFn(torch.autograd.Function):
                 dw = _grad_weight(dyb, G.matrix(x2)[0], 8, M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum_any(dyb)
-        return dx, dw, db, (dout if ctx.needs_input_grad[3] else None), None, None
+        return dx, dw, db, (dout if ctx.needs_input_grad[3] else None), None, None, None
 
 
 def feed_forward_ok(x, w1, w2):
     d, f = w1.shape[1], w1.shape[0]
-    return (G.PRECISION == "bf16" and _fused() and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and d % 64 == 0 and f % 64 == 0
+    return (G.bf16_backward() and _fused() and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and d % 64 == 0 and f % 64 == 0
             and w2.shape[0] % 64 == 0 and x.numel() // d >= 256)
 
 
@@ -684,9 +823,29 @@ class FeedForwardFn(torch.autograd.Function):
     backward `hidden > 0` is both the ReLU and the dropout mask, applied by the epilogue of dh = dy W2."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, p_drop, seed, residual=None, p2=0.0, seed2=0):
+    def forward(ctx, x, w1, b1, w2, b2, p_drop, seed, residual=None, p2=0.0, seed2=0, x_lo=None):
         d = x.shape[-1]
         ctx.x_bf16 = x.dtype == torch.bfloat16
+        if _mixed() and (x_lo is not None or x.dtype == torch.float32):
+            # both products in two terms; the hidden exists as two bf16 planes written by the first product's epilogue
+            F, N2 = w1.shape[0], w2.shape[0]
+            with torch.cuda.device(x.device):
+                xh, xl, Cp = _planes(x, x_lo, d)
+                M = xh.shape[0]
+                hp = Pair.empty((M, F), x.device)
+                G.gemm_ex(G.pair_operand(xh, xl, M, Cp), G.split_weight(w1), M, F, 3 * Cp, G.EPI_DROPOUT_BF16, hp.hi,
+                          out_lo=hp.lo, bias=b1, relu=True, p_drop=p_drop, seed=seed)
+                y = torch.empty(x.shape[:-1] + (N2,), dtype=torch.float32, device=x.device)
+                a2 = G.pair_operand(hp.hi, hp.lo, M, F)
+                if residual is not None:
+                    G.gemm_ex(a2, G.split_weight(w2), M, N2, 3 * F, G.EPI_DROPOUT_RESIDUAL, y.view(-1, N2), bias=b2,
+                              p_drop=p2, seed=seed2, residual=residual.contiguous().view(-1, N2))
+                else:
+                    G.gemm_ex(a2, G.split_weight(w2), M, N2, 3 * F, G.EPI_F32, y.view(-1, N2), bias=b2)
+            ctx.res = (residual is not None, float(p2), int(seed2))
+            ctx.cfg = (float(p_drop), x.shape)
+            ctx.save_for_backward(xh, hp.hi, w1, w2)
+            return y
         xb = x.reshape(-1, d).to(torch.bfloat16).contiguous()
         M, F, N2 = xb.shape[0], w1.shape[0], w2.shape[0]
         h = torch.empty((M, F), dtype=torch.bfloat16, device=x.device)
@@ -734,28 +893,29 @@ class FeedForwardFn(torch.autograd.Function):
                 else:
                     dx = G.gemm_bf16_nt(dh, w1t).view(xshape)
         dres = dy if (has_res and ctx.needs_input_grad[7]) else None
-        return dx, dw1, db1, dw2, db2, None, None, dres, None, None
+        return dx, dw1, db1, dw2, db2, None, None, dres, None, None, None
 
 
 def _dt(t):
     return G.PIKA_F32 if t.dtype == torch.float32 else G.PIKA_BF16
 
 
-def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16):
-    """Training-mode statistics + apply; returns (y, mean, rstd)."""
+def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16, out_pair=False):
+    """Training-mode statistics + apply; returns (y, mean, rstd); with out_pair y is a Pair (two bf16 planes)."""
     M, C = x.shape
     lib = _lib.lib()
     stats = torch.empty(2 * C, dtype=torch.float64, device=x.device)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    y = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    pair = Pair.empty(x.shape, x.device) if out_pair else None
+    y = pair.hi if out_pair else torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), _stream()), "pika_bn_stats")
     _lib.check(lib.pika_bn_apply(
         x.data_ptr(), M, C, stats.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps),
         float(momentum), None if running_mean is None else running_mean.data_ptr(),
         None if running_var is None else running_var.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-        y.data_ptr(), _dt(y), _stream()), "pika_bn_apply")
-    return y, mean, rstd
+        y.data_ptr(), _dt(y), pair.lo.data_ptr() if out_pair else None, _stream()), "pika_bn_apply")
+    return (pair if out_pair else y), mean, rstd
 
 
 def _bn_backward(dy, x, weight, mean, rstd, relu_mask, dx_bf16):
@@ -781,20 +941,25 @@ class BatchNormFn(torch.autograd.Function):
     out_bf16: the result only feeds an MFMA product (the next time-delay layer)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu_input=False, out_bf16=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu_input=False, out_bf16=False,
+                out_pair=False):
         x = x.contiguous()
         ctx.relu_input = bool(relu_input)
+        ctx.set_materialize_grads(False)
         with torch.cuda.device(x.device):
-            y, mean, rstd = _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16)
+            y, mean, rstd = _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16, out_pair)
         ctx.save_for_backward(x, weight, mean, rstd)
+        if out_pair:
+            ctx.mark_non_differentiable(y.lo)
+            return y.hi, y.lo
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, weight, mean, rstd = ctx.saved_tensors
         with torch.cuda.device(x.device):
             dx, dg, db = _bn_backward(dy, x, weight, mean, rstd, ctx.relu_input, False)
-        return dx, dg, db, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 class TdnnBnFn(torch.autograd.Function):
@@ -805,23 +970,41 @@ class TdnnBnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w2d, bias, taps, dil, stride, pad, bn_w, bn_b, running_mean, running_var, eps, momentum,
-                out_bf16):
+                out_bf16, x_lo=None, out_pair=False):
         ctx.x_bf16 = x.dtype == torch.bfloat16
-        xb = x.contiguous() if ctx.x_bf16 else x.contiguous().to(torch.bfloat16)
-        Bn, T, C = xb.shape
+        ctx.set_materialize_grads(False)
+        Bn, T, C = x.shape
         N = w2d.shape[0]
-        with torch.cuda.device(x.device):
-            a_op, M, K, t_out = G.time_delay(xb, taps, dil, stride, pad)
-            y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-            G.launch(a_op, G.matrix(_weight_for(xb, w2d))[0], y, N, M, N, K, bias=bias, relu=True)
-            out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16)
+        if _mixed() and (x_lo is not None or x.dtype == torch.float32):
+            # two-term forward product over a time-delay view of the two planes; y, the BatchNorm input, stays fp32
+            with torch.cuda.device(x.device):
+                hi, lo, Cp = _planes(x.contiguous(), x_lo, C)
+                t_out = G.time_delay(x, taps, dil, stride, pad)[3]
+                M = Bn * t_out
+                a_op = G.pair_operand(hi, lo, M, Cp, taps, dil, stride, pad, rows_per_batch=t_out, t_in=T,
+                                      batch_stride=T * Cp)
+                y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+                G.gemm_ex(a_op, G.split_weight(w2d, taps), M, N, taps * 3 * Cp, G.EPI_F32, y, bias=bias, relu=True)
+                out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16, out_pair)
+            xb = hi.view(Bn, T, Cp)
+        else:
+            xb = x.contiguous() if ctx.x_bf16 else x.contiguous().to(torch.bfloat16)
+            with torch.cuda.device(x.device):
+                a_op, M, K, t_out = G.time_delay(xb, taps, dil, stride, pad)
+                y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+                G.launch(a_op, G.matrix(_weight_for(xb, w2d))[0], y, N, M, N, K, bias=bias, relu=True)
+                out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16)
         ctx.cfg = (taps, dil, stride, pad, t_out)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(xb, w2d, y, bn_w, mean, rstd)
+        if isinstance(out, Pair):
+            o_hi, o_lo = out.hi.view(Bn, t_out, N), out.lo.view(Bn, t_out, N)
+            ctx.mark_non_differentiable(o_lo)
+            return o_hi, o_lo
         return out.view(Bn, t_out, N)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_):
         xb, w2d, y, bn_w, mean, rstd = ctx.saved_tensors
         taps, dil, stride, pad, t_out = ctx.cfg
         Bn, T, C = xb.shape
@@ -852,4 +1035,4 @@ class TdnnBnFn(torch.autograd.Function):
                 dw = _grad_weight(dyb, a_op, _g(xb), M, K, N)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum_any(dyb)
-        return dx, dw, db, None, None, None, None, dg, dbeta, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, dg, dbeta, None, None, None, None, None, None, None

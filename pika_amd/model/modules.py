@@ -58,7 +58,7 @@ class MultiHeadedAttention(nn.Module):
             ctx = ops.self_attention_packed(query, self.linear_query.weight, self.linear_query.bias,
                                             self.linear_keys.weight, self.linear_keys.bias,
                                             self.linear_values.weight, self.linear_values.bias,
-                                            self.head_count, self.dropout.p, self.training)
+                                            self.head_count, self.dropout.p, self.training, mask)
             if residual is not None:
                 return ops.linear_dropout_residual(ctx, self.final_linear, residual, residual_dropout), None
             return ops.linear(ctx, self.final_linear.weight, self.final_linear.bias), None

@@ -17,8 +17,28 @@ def _hip(x):
 
 
 def _bf16_mode():
+    """Modes whose activations between MFMA products are bf16: "bf16" (one plane) and "mixed" (two planes, hipops.Pair)."""
     from .. import gemm as G
-    return G.PRECISION == "bf16"
+    return G.bf16_backward()
+
+
+def _mixed():
+    from .hipops import _mixed as m
+    return m()
+
+
+def _pair(ret):
+    """(hi, lo) returned by an autograd Function with a two-term output -> hipops.Pair; tensors pass through."""
+    if isinstance(ret, tuple):
+        from .hipops import Pair
+        return Pair(ret[0], ret[1])
+    return ret
+
+
+def _hi_lo(x):
+    """(tensor, lo plane or None) of an activation that may be a hipops.Pair."""
+    from .hipops import Pair
+    return (x.hi, x.lo) if isinstance(x, Pair) else (x, None)
 
 
 def _bf16_fast():
@@ -40,8 +60,10 @@ def tdnn_bn(x, conv, bn, mfma_only=False):
     N, _, taps, C = conv.weight.shape
     mom = _bn_momentum(bn)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return TdnnBnFn.apply(x, conv.weight.reshape(N, taps * C), conv.bias, taps, conv.dilation[0], conv.stride[0], 0,
-                          bn.weight, bn.bias, rm, rv, bn.eps, mom, bool(mfma_only))
+    x, x_lo = _hi_lo(x)
+    return _pair(TdnnBnFn.apply(x, conv.weight.reshape(N, taps * C), conv.bias, taps, conv.dilation[0], conv.stride[0], 0,
+                                bn.weight, bn.bias, rm, rv, bn.eps, mom, bool(mfma_only), x_lo,
+                                bool(mfma_only) and _mixed()))
 
 
 def _gemm_ok(*dims):
@@ -53,7 +75,9 @@ def linear(x, weight, bias=None, relu=False, out_bf16=False):
     out_bf16 (bf16 mode only): the result only feeds MFMA products."""
     if _hip(x) and _gemm_ok(weight.shape[1]):
         from .hipops import LinearFn
-        return LinearFn.apply(x, weight, bias, relu, bool(out_bf16 and _bf16_mode()))
+        x, x_lo = _hi_lo(x)
+        return _pair(LinearFn.apply(x, weight, bias, relu, bool(out_bf16 and _bf16_mode()), x_lo,
+                                    bool(out_bf16) and _mixed() and weight.shape[0] % 64 == 0))
     y = F.linear(x.to(weight.dtype), weight, bias)
     return F.relu(y) if relu else y
 
@@ -78,8 +102,9 @@ def batch_norm(x2d, bn, relu_input=False, mfma_only=False):
         from .hipops import BatchNormFn
         mom = _bn_momentum(bn)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-        return BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom, relu_input,
-                                 bool(mfma_only and _bf16_fast() and x2d.shape[1] % 64 == 0))
+        narrow = bool(mfma_only and _bf16_fast() and x2d.shape[1] % 64 == 0)
+        return _pair(BatchNormFn.apply(x2d, bn.weight, bn.bias, rm, rv, bn.eps, mom, relu_input, narrow,
+                                       narrow and _mixed()))
     return F.batch_norm(x2d, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                         bn.training or not bn.track_running_stats,
                         _bn_momentum(bn), bn.eps)
@@ -100,7 +125,8 @@ def layer_norm(x, ln, mfma_only=False):
     if (_hip(x) and x.dtype == torch.float32 and len(ln.normalized_shape) == 1 and ln.weight is not None
             and ln.bias is not None and C % 4 == 0 and C <= 2048):
         from .hipops import LayerNormFn
-        return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, bool(mfma_only and _bf16_mode() and C % 64 == 0))
+        narrow = bool(mfma_only and _bf16_mode() and C % 64 == 0)
+        return _pair(LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, narrow, narrow and _mixed()))
     return F.layer_norm(x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
@@ -154,10 +180,10 @@ def attention(q, k, v, heads, mask, p_drop, training):
     D = HD // heads
     if _hip(q):
         from .hipops import AttentionFn, attention_ok
-        if attention_ok(q, k, v, heads, mask):
+        if attention_ok(q, k, v, heads, mask) and not _mixed():
             drop = p_drop if training else 0.0
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop > 0 else 0  # CPU generator
-            return AttentionFn.apply(q, k, v, heads, drop, seed)
+            return AttentionFn.apply(q, k, v, heads, drop, seed, mask)
     qh = (q / math.sqrt(D)).view(B, Tq, heads, D).transpose(1, 2)
     kh = k.view(B, Tk, heads, D).transpose(1, 2)
     vh = v.view(B, Tk, heads, D).transpose(1, 2)
@@ -189,10 +215,11 @@ def feed_forward(xn, w_1, w_2, p_drop, residual=None, p_residual=0.0):
     from .hipops import FeedForwardFn, feed_forward_ok
     if not feed_forward_ok(xn, w_1.weight, w_2.weight):
         return None
+    xn, x_lo = _hi_lo(xn)
     if residual is not None and residual.dtype == torch.float32:
         return FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, _seed(p_drop),
-                                   residual, p_residual, _seed(p_residual))
-    y = FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, _seed(p_drop))
+                                   residual, p_residual, _seed(p_residual), x_lo)
+    y = FeedForwardFn.apply(xn, w_1.weight, w_1.bias, w_2.weight, w_2.bias, p_drop, _seed(p_drop), None, 0.0, 0, x_lo)
     return y if residual is None else dropout(y, p_residual, p_residual > 0) + residual
 
 
@@ -201,7 +228,8 @@ def linear_dropout_residual(x, lin, residual, p_drop):
     if _hip(x):
         from .hipops import LinearDropoutResidualFn, linear_dropout_residual_ok
         if linear_dropout_residual_ok(x, lin.weight, residual):
-            return LinearDropoutResidualFn.apply(x, lin.weight, lin.bias, residual, p_drop, _seed(p_drop))
+            x, x_lo = _hi_lo(x)
+            return LinearDropoutResidualFn.apply(x, lin.weight, lin.bias, residual, p_drop, _seed(p_drop), x_lo)
     return dropout(linear(x, lin.weight, lin.bias), p_drop, p_drop > 0) + residual
 
 
@@ -212,17 +240,18 @@ def self_attention_packed_ok(x, heads, mask):
     return attention_ok(x, x, x, heads, mask)
 
 
-def self_attention_packed(x, wq, bq, wk, bk, wv, bv, heads, p_drop, training):
+def self_attention_packed(x, wq, bq, wk, bk, wv, bv, heads, p_drop, training, mask=None):
     """Self-attention context from the layer input: q, k, v projections as ONE GEMM (weights concatenated
     per call; autograd splits the weight gradient back), then the fused attention core on the packed
-    result.  Same arithmetic as three separate nn.Linear calls."""
+    result.  Same arithmetic as three separate nn.Linear calls.  "mixed" mode: the projection is written as two bf16
+    planes and the attention forward runs in two-term arithmetic (hipops.PackedAttentionFn)."""
     from .hipops import PackedAttentionFn
     w = torch.cat([wq, wk, wv], 0)
     b = torch.cat([bq, bk, bv], 0)
-    qkv = linear(x, w, b, out_bf16=True)
+    qkv, qkv_lo = _hi_lo(linear(x, w, b, out_bf16=True))
     drop = p_drop if training else 0.0
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop > 0 else 0
-    return PackedAttentionFn.apply(qkv, heads, drop, seed)
+    return _pair(PackedAttentionFn.apply(qkv, heads, drop, seed, qkv_lo, mask))
 
 
 def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):

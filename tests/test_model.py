@@ -102,7 +102,7 @@ def test_full_size_parameter_count_and_pickle_roundtrip(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "mixed"])
 @pytest.mark.parametrize("dec", ["transformer", "rnn"])
 def test_gpu_matches_reference_golden(hip_device, dec, mode):
     """The two arithmetic modes that carry the north_star tolerance (activations and loss within 1e-3 rel of the
@@ -121,6 +121,10 @@ def test_gpu_matches_reference_golden(hip_device, dec, mode):
         n0 = G.BF16X3_STATS["fast"]
         if mode == "fp32":
             run_parity(dec, hip_device)
+        elif mode == "mixed":
+            # the train-step default: two-term forward (activations as in "bf16x3"), bf16 backward (gradients in the L2 norm
+            # at the bf16 operand budget)
+            run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=6e-2)
         else:
             run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=3e-2)
             assert G.BF16X3_STATS["fast"] > n0 + 20
