@@ -240,7 +240,10 @@ def test_mixed_mode_layers_match_fp32_mode(hip_device):
     o32, g32, x32 = run("fp32")
     om, gm, xm = run("mixed")
     assert ((om - o32).abs().max() / o32.abs().max()).item() < 1e-4
+    gmax = max(g.norm().item() for g in g32.values())
     for n in g32:
+        if g32[n].norm().item() < 1e-5 * gmax:      # zero up to rounding (key biases: the softmax is shift-invariant)
+            continue
         rel = ((gm[n] - g32[n]).norm() / g32[n].norm()).item()
         assert rel < 3e-2, (n, rel)
     assert ((xm - x32).norm() / x32.norm()).item() < 3e-2

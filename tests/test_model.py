@@ -41,7 +41,7 @@ def close_in_norm(a, b, rtol, floor):
     assert err <= rtol * ref, "||err|| %g vs ||ref|| %g" % (err, ref)
 
 
-def run_parity(dec, device, act_rtol=1e-3, grad_norm_rtol=None):
+def run_parity(dec, device, act_rtol=1e-3, grad_norm_rtol=None, joint_rtol=None):
     z = np.load(os.path.join(HERE, "golden", "model_tiny_%s.npz" % dec))
     net = ours(dec, device)
     x, y, y_len, w = [t.to(device) for t in C.inputs()]
@@ -50,11 +50,12 @@ def run_parity(dec, device, act_rtol=1e-3, grad_norm_rtol=None):
         close(net.encoder(x), z["enc_eval"], rtol=act_rtol)
         sos = torch.zeros(C.B, 1, dtype=torch.long, device=device)
         close(net.predict(torch.cat((sos, y), 1)), z["pred_eval"], rtol=act_rtol)
-        close(net(x, y, None, True), z["joint_eval"], rtol=act_rtol)
-        close(net(x, y, None, False), z["joint_eval_nosm"], rtol=act_rtol)
+        joint_rtol = act_rtol if joint_rtol is None else joint_rtol
+        close(net(x, y, None, True), z["joint_eval"], rtol=joint_rtol)
+        close(net(x, y, None, False), z["joint_eval_nosm"], rtol=joint_rtol)
     net.train()
     lp = net(x, y, None, True)
-    close(lp, z["joint_train"], rtol=act_rtol)
+    close(lp, z["joint_train"], rtol=joint_rtol)
     (lp * w).sum().backward()
     params = dict(net.named_parameters())
     gscale = max(float(np.linalg.norm(z["grad:" + str(k)])) for k in z["grad_keys"])
@@ -124,7 +125,8 @@ def test_gpu_matches_reference_golden(hip_device, dec, mode):
         elif mode == "mixed":
             # the train-step default: two-term forward (activations as in "bf16x3"), bf16 backward (gradients in the L2 norm
             # at the bf16 operand budget)
-            run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=6e-2)
+            # at the bf16 operand budget); the joint's lattice product (fc2) runs on ONE bf16 term in this mode: logits to 4e-3 of their scale
+            run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=6e-2, joint_rtol=4e-3)
         else:
             run_parity(dec, hip_device, act_rtol=1e-4, grad_norm_rtol=3e-2)
             assert G.BF16X3_STATS["fast"] > n0 + 20
