@@ -127,7 +127,15 @@ def train_step_workload(args, R_):
     scale = torch.full((240,), 0.25, device=dev)
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
     aug = SpecAugment(15, 35)
-    state = {"optim": torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True), "n": 0}
+    def make_optim():
+        return torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
+    # PIKA_TRAIN_GRAPH=0: the eager launch sequence of the reference loop; default: the same sequence captured once into a
+    # hipGraph (pika_amd/train_graph.py) -- forward, loss, backward, clip and SGD are one graph launch per step
+    graphed = None
+    if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0":
+        from pika_amd.train_graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, loss_fn, make_optim, clip=3.0, warmup=2)
+    state = {"optim": graphed.optimizer if graphed is not None else make_optim(), "n": 0}
     bmuf = None
     if world > 1:
         from trainer.bmuf import BmufTrainer
@@ -135,7 +143,6 @@ def train_step_workload(args, R_):
         bmuf.collective_events = []
 
     def step():
-        state["optim"].zero_grad(set_to_none=True)
         data, target, lens, ali = next(batches)
         labels = target.to(dev)                 # train_transducer_bmuf_otfaug.py:79-85 (`.cuda(local_rank)`)
         lens, ali = lens.to(dev), ali.to(dev)
@@ -143,18 +150,27 @@ def train_step_workload(args, R_):
         len_b = len_b // 4 + (len_b % 4 != 0).int()
         cmvn_apply_(data, offset, scale, cmn=True)
         aug.apply(data)
-        out = model(data, labels.long(), len_b, True)
-        loss = loss_fn(out, labels.int(), len_b, ali).sum()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
-        state["optim"].step()
+        if graphed is not None:
+            loss = graphed(data, labels, len_b, ali)
+        else:
+            state["optim"].zero_grad(set_to_none=True)
+            out = model(data, labels.long(), len_b, True)
+            loss = loss_fn(out, labels.int(), len_b, ali).sum()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+            state["optim"].step()
         state["n"] += 1
         if bmuf is not None and state["n"] % 5 == 0:      # sync_period 5 (:112-123)
             assert bmuf.update_and_sync()
-            state["optim"] = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
+            if graphed is not None:
+                graphed.reset_momentum()        # = a fresh optimizer (:121), at the addresses the graph holds
+            else:
+                state["optim"] = make_optim()
         return loss
 
     def close():
+        if graphed is not None:
+            graphed.close()
         stop.set()
         t_end = time.time() + 5.0
         try:
@@ -198,7 +214,9 @@ def run_train_step(args, R_, steps, warmup):
                                   "loader from pinned int16 audio (fbank+splice) on a side stream, CMVN, SpecAugment, "
                                   "fwd, RNN-T loss, bwd, clip, SGD%s" % (", BMUF all-reduce every 5 steps" if world > 1 else ""),
                       "batch_per_gpu": B, "T_in": T, "T_enc": 240, "U": U, "V": V,
-                      "global_batch": B * world, "parallelism": "bmuf-dp%d" % world, "loss": loss},
+                      "global_batch": B * world, "parallelism": "bmuf-dp%d" % world, "loss": loss,
+                      "launch": "one hipGraph per step (forward, loss, backward, clip, SGD)"
+                                if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0" else "eager (~650 launches per step)"},
            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": tf / 2500.0, "traffic": None},
            "loader": {"host_ms_per_batch": fe.host_seconds / max(fe.batches, 1) * 1e3, "batches": fe.batches,

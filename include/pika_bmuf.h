@@ -32,9 +32,11 @@ int pika_bmuf_nan_flag(const float *delta, size_t n, int *flag, void *stream);
  *   d          = delta[i] * inv_world
  *   delta_prev = block_momentum * delta_prev + block_lr * (1 - block_momentum) * d
  *   global    -= (1 + block_momentum) * delta_prev
- *   local      = global                      (replaces broadcast + _copy_vec_to_param) */
+ *   local      = global                      (replaces broadcast + _copy_vec_to_param)
+ * skip_flag: NULL, or the device int pika_bmuf_nan_flag wrote: when it is set the call changes nothing -- the STOP branch
+ * of bmuf.py:89-90 decided on the device, so the host can read the flag later without a blocking read in between. */
 int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float *local, size_t n,
-                     float inv_world, float block_momentum, float block_lr, void *stream);
+                     float inv_world, float block_momentum, float block_lr, const int *skip_flag, void *stream);
 
 #ifdef __cplusplus
 }

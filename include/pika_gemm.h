@@ -109,6 +109,13 @@ int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long lo
 int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, float p_drop, unsigned seed,
                            void *stream);
 
+/* Registers (NULL: clears) a device word that EVERY kernel of this library that takes a dropout seed adds to it when it
+ * runs (GEMM epilogues, pika_dropout_mask_cast_bf16, the attention keep bits, the two keep-mask helpers).  A training
+ * step captured once into a hipGraph replays the seeds it was captured with; with the caller changing this word between
+ * replays every replay draws new masks, forward and backward of one replay agree.  Process-wide; the word must stay
+ * allocated while registered. */
+int pika_set_dropout_salt(const unsigned *device_word);
+
 /* out f32 (pitch ldo) = dropout_p(A B^T + bias) + residual (f32, pitch ld_res): a projection with its residual
  * dropout and residual add (reference trainer/model/transformer.py:98-99 `self.dropout(context) + inputs`,
  * position_ffn.py:38-39 `output + x`) in the product's epilogue; same keep hash as PIKA_EPI_DROPOUT_BF16. */

@@ -28,7 +28,7 @@ SIGNATURES = {
     "pika_bmuf_delta": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "pika_bmuf_nan_flag": (_i, [_vp, _sz, _vp, _vp]),
     "pika_bmuf_update": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float,
-                              ctypes.c_float, _vp]),
+                              ctypes.c_float, _vp, _vp]),
     # include/pika_feat.h
     "pika_cmvn_apply": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "pika_specaug_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -40,6 +40,7 @@ SIGNATURES = {
     "pika_gemm_bf16_epilogue": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _i, _i, ctypes.c_float,
                                      ctypes.c_uint, _vp, _ll, ctypes.c_float, _vp]),
     "pika_dropout_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_set_dropout_salt": (_i, [_vp]),
     "pika_gemm_bf16_dropout_residual": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, ctypes.c_float,
                                              ctypes.c_uint, _vp, _ll, _vp]),
     "pika_dropout_mask_cast_bf16": (_i, [_vp, _ll, _i, _i, ctypes.c_float, ctypes.c_uint, _vp, _ll, _vp]),

@@ -73,6 +73,13 @@ class BmufTrainer(object):
         self.delta_prev = torch.zeros_like(self.param)  # on EVERY rank (reference: master only)
         self.delta = torch.empty_like(self.param)
         self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.is_hip:
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._flag_event = torch.cuda.Event()
+        self._stop_pending = False
+        # True: update_and_sync() returns STOP for the block whose summed delta holds a NaN (one blocking read per
+        # sync, the reference's timing); False (default): at the NEXT call -- the device has already skipped the update
+        self.sync_stop = os.environ.get("PIKA_BMUF_SYNC_STOP", "0") == "1"
         self.collective_events = None     # set to [] to have every all-reduce bracketed by HIP events
 
     def _rebind_detached_parameters(self):
@@ -96,6 +103,11 @@ class BmufTrainer(object):
     # -- the block update ----------------------------------------------------------------
     def update_and_sync(self):
         n = self.param.numel()
+        if self.is_hip and self._stop_pending:      # the previous block's flag (its copy finished long ago)
+            self._flag_event.synchronize()
+            self._stop_pending = False
+            if int(self._flag_host[0]):
+                return STOP
         self._rebind_detached_parameters()
         if self.is_hip:
             lib = _lib.lib()
@@ -112,35 +124,40 @@ class BmufTrainer(object):
         if ev is not None:
             ev[1].record()
             self.collective_events.append(ev)
-        if self._has_nan():
-            return STOP
         inv_world = 1.0 / float(self.world_size)
         bm, blr = self.block_momentum, self.block_lr
         if self.is_hip:
+            # the NaN guard of bmuf.py:89-90 is decided ON THE DEVICE: the flag kernel runs, and the update kernel leaves
+            # every vector untouched when the flag is set -- no blocking read between the all-reduce and the update.  The
+            # host learns of it from a pinned copy of the flag: at once with sync_stop (the reference's timing), else at
+            # the next call (every rank holds the same summed delta, so every rank stops at the same call)
             with torch.cuda.device(self.param.device):
+                self._flag.zero_()
+                _lib.check(lib.pika_bmuf_nan_flag(self.delta.data_ptr(), n, self._flag.data_ptr(), _stream()),
+                           "pika_bmuf_nan_flag")
                 _lib.check(lib.pika_bmuf_update(self.delta.data_ptr(), self.delta_prev.data_ptr(),
                                                 self.param.data_ptr(), self.local.data_ptr(), n,
-                                                inv_world, bm, blr, _stream()), "pika_bmuf_update")
-        else:
-            # device-agnostic restatement of the same four lines, used when the model is on the
-            # CPU (gloo plumbing tests); float32 scalars rounded exactly as the kernel rounds them
-            f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
-            c = f32(f32(blr) * f32(1.0 - f32(bm)))
-            self.delta.mul_(f32(inv_world))
-            self.delta_prev.mul_(f32(bm)).add_(self.delta * c)
-            self.param.sub_(self.delta_prev * f32(1.0 + f32(bm)))
-            self.local.copy_(self.param)
+                                                inv_world, bm, blr, self._flag.data_ptr(), _stream()), "pika_bmuf_update")
+                self._flag_host.copy_(self._flag, non_blocking=True)
+                self._flag_event.record()
+            if self.sync_stop:
+                self._flag_event.synchronize()
+                if int(self._flag_host[0]):
+                    return STOP
+            else:
+                self._stop_pending = True
+            return SUCCESS
+        if bool(torch.isnan(self.delta).any().item()):
+            return STOP
+        # device-agnostic restatement of the same four lines, used when the model is on the
+        # CPU (gloo plumbing tests); float32 scalars rounded exactly as the kernel rounds them
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
+        c = f32(f32(blr) * f32(1.0 - f32(bm)))
+        self.delta.mul_(f32(inv_world))
+        self.delta_prev.mul_(f32(bm)).add_(self.delta * c)
+        self.param.sub_(self.delta_prev * f32(1.0 + f32(bm)))
+        self.local.copy_(self.param)
         return SUCCESS
-
-    def _has_nan(self):
-        if self.is_hip:
-            lib = _lib.lib()
-            self._flag.zero_()
-            with torch.cuda.device(self.param.device):
-                _lib.check(lib.pika_bmuf_nan_flag(self.delta.data_ptr(), self.delta.numel(),
-                                                  self._flag.data_ptr(), _stream()), "pika_bmuf_nan_flag")
-            return bool(self._flag.item())
-        return bool(torch.isnan(self.delta).any().item())
 
     # -- small-tensor helpers used for the epoch loss (train_transducer_bmuf_otfaug.py:140-143)
     def broadcast(self, tensor):

@@ -19,6 +19,7 @@
 #include "pika_attn.h"
 #include "pika_gemm.h"
 #include "pika_rnnt.h"
+#include "pika_internal.h"
 
 namespace {
 
@@ -595,7 +596,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
 
 // bits[row][kb] for row = (b*H+h)*T + query: one thread per 64-key word
 __global__ __launch_bounds__(THREADS) void keep_bits_kernel(uint64_t *bits, long long rows, int nkb,
-                                                            uint32_t seed, uint32_t thr) {
+                                                            uint32_t seed, uint32_t thr, const unsigned *__restrict__ salt) {
+    if (salt) seed += *salt;       // pika_set_dropout_salt: new masks per replay of a captured launch sequence
     const long long idx = (long long)blockIdx.x * THREADS + threadIdx.x;
     if (idx >= rows * nkb) return;
     const long long row = idx / nkb;
@@ -603,7 +605,8 @@ __global__ __launch_bounds__(THREADS) void keep_bits_kernel(uint64_t *bits, long
 }
 
 __global__ __launch_bounds__(THREADS) void keep_mask_kernel(unsigned char *mask, long long rows, int T,
-                                                            uint32_t seed, uint32_t thr) {
+                                                            uint32_t seed, uint32_t thr, const unsigned *__restrict__ salt) {
+    if (salt) seed += *salt;
     const long long row = blockIdx.x;  // bh*T + q
     const uint32_t rowh = row_hash(seed, (uint32_t)row);
     for (int key = threadIdx.x; key < T; key += THREADS)
@@ -664,7 +667,8 @@ static int attention_fwd_impl(const void *q, const void *k, const void *v, void 
         if (!keep_bits || (reinterpret_cast<uintptr_t>(keep_bits) & 7)) return PIKA_EINVAL;
         const long long words = (long long)B * H * T * A.nkb;
         hipLaunchKernelGGL(keep_bits_kernel, dim3((unsigned)((words + THREADS - 1) / THREADS)), dim3(THREADS), 0, s,
-                           static_cast<uint64_t *>(keep_bits), (long long)B * H * T, A.nkb, A.seed, A.thr);
+                           static_cast<uint64_t *>(keep_bits), (long long)B * H * T, A.nkb, A.seed, A.thr,
+                           pika_internal_dropout_salt());
         A.bits = static_cast<const uint64_t *>(keep_bits);
     }
     if (two_term) {
@@ -740,7 +744,8 @@ int pika_attention_keep_mask(unsigned char *mask, int BH, int T, float p_drop, u
     Args A{};
     dropout_consts(A, p_drop, seed);
     hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)(BH * T)), dim3(THREADS), 0,
-                       static_cast<hipStream_t>(stream), mask, (long long)BH * T, T, A.seed, A.thr);
+                       static_cast<hipStream_t>(stream), mask, (long long)BH * T, T, A.seed, A.thr,
+                       pika_internal_dropout_salt());
     return (int)hipGetLastError();
 }
 

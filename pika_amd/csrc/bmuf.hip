@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void bmuf_update_kernel(const float *__restric
                                                           float *__restrict__ dprev,
                                                           float *__restrict__ g,
                                                           float *__restrict__ l, size_t n,
-                                                          float inv_world, float bm, float blr) {
+                                                          float inv_world, float bm, float blr,
+                                                          const int *__restrict__ skip_flag) {
+    if (skip_flag && *skip_flag) return;     // a NaN in the summed delta: leave every vector as it is (bmuf.py:89-90)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if constexpr (VEC) {
@@ -108,16 +110,16 @@ int pika_bmuf_nan_flag(const float *delta, size_t n, int *flag, void *stream) {
 }
 
 int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float *local, size_t n,
-                     float inv_world, float block_momentum, float block_lr, void *stream) {
+                     float inv_world, float block_momentum, float block_lr, const int *skip_flag, void *stream) {
     if (!delta || !delta_prev || !global || !local) return PIKA_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (aligned16(delta) && aligned16(delta_prev) && aligned16(global) && aligned16(local))
         hipLaunchKernelGGL(bmuf_update_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, delta,
-                           delta_prev, global, local, n, inv_world, block_momentum, block_lr);
+                           delta_prev, global, local, n, inv_world, block_momentum, block_lr, skip_flag);
     else
         hipLaunchKernelGGL(bmuf_update_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, delta,
-                           delta_prev, global, local, n, inv_world, block_momentum, block_lr);
+                           delta_prev, global, local, n, inv_world, block_momentum, block_lr, skip_flag);
     return (int)hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 
 #include "pika_gemm.h"
 #include "pika_rnnt.h"
+#include "pika_internal.h"
 
 #define PIKA_NOT_APPLICABLE (-100)
 
@@ -167,6 +168,7 @@ struct PPArgs {
     long long ldo16, ld_aux;
     float scale;                       // EPI 1: 1/(1-p) for kept values; EPI 2: factor for unmasked values
     unsigned seed, thr;                // EPI 1, 3: drop where hash16 < thr (thr = 0: no dropout)
+    const unsigned *salt;              // optional device word added to seed (pika_set_dropout_salt; filled in by launch_pp_epi)
     const float *res;                  // EPI 3: fp32 residual added after the dropout
     long long ld_res;
     // EPI 0, optional: per output row and 64-column block b = (tile column) * 4 + (wave column), the partial
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     // runs ahead again behind the epilogue (staggered, each group's epilogue would sit inside the other's barrier wait)
     if (wr == 0) PP_BAR();
     const float *bias = P.bias;
+    [[maybe_unused]] const unsigned seed = P.seed + ((P.thr && P.salt) ? *P.salt : 0u);
     float *C = P.C;
     int etm, etn;
     tile_mn(tile_of(cur_slot), etm, etn);
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             if constexpr (EPI == 3) {
                 if (P.thr) {
                     bool keep[4];
-                    pp_keep4(P.seed, (unsigned)m, (unsigned)n, P.thr, keep);
+                    pp_keep4(seed, (unsigned)m, (unsigned)n, P.thr, keep);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * P.scale : 0.f;
                 }
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 if constexpr (EPI == 1) {
                     if (P.thr) {
                         bool keep[4];
-                        pp_keep4(P.seed, (unsigned)m, (unsigned)n, P.thr, keep);
+                        pp_keep4(seed, (unsigned)m, (unsigned)n, P.thr, keep);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * P.scale : 0.f;
                     }
@@ -922,6 +925,7 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
     if (nt > 0x7fffffffLL - 65536) return PIKA_ETOOBIG;
     PPArgs Q = P;
     Q.nx = (P.N + 255) / 256; Q.ntiles = (int)nt;
+    Q.salt = pika_internal_dropout_salt();
     // persistent: one workgroup per CU (128 KB of LDS each) walks its share of the output tiles.
     // PIKA_GEMM_PP_WGS=0 launches one workgroup per tile instead (for A/B timing).
     static const int wgs = [] {
@@ -948,8 +952,10 @@ int launch_pp(const PPArgs &P, hipStream_t s) { return launch_pp_epi<0>(P, s); }
 // rounding its consumers (dX / dW products) apply anyway.  cols % 4 == 0.
 __global__ __launch_bounds__(256) void pp_mask_cast_kernel(const float *__restrict__ x, long long ld, int rows,
                                                            int cols, unsigned seed, unsigned thr, float scale,
-                                                           __bf16 *__restrict__ out, long long ld_out) {
+                                                           __bf16 *__restrict__ out, long long ld_out,
+                                                           const unsigned *__restrict__ salt) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    if (thr && salt) seed += *salt;
     const int c4 = cols >> 2;
     const long long total = (long long)rows * c4;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -966,7 +972,8 @@ __global__ __launch_bounds__(256) void pp_mask_cast_kernel(const float *__restri
 }
 
 __global__ __launch_bounds__(256) void pp_keep_mask_kernel(unsigned char *mask, int rows, int cols, unsigned seed,
-                                                           unsigned thr) {
+                                                           unsigned thr, const unsigned *__restrict__ salt) {
+    if (salt) seed += *salt;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, c4 = (cols + 3) >> 2;
     if (idx >= (long long)rows * c4) return;
     const int m = (int)(idx / c4), n = (int)(idx - (long long)m * c4) * 4;
@@ -1205,7 +1212,7 @@ extern "C" int pika_dropout_mask_cast_bf16(const float *x, long long ld, int row
     const long long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(pp_mask_cast_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ld, rows, cols, seed, thr,
-                       65536.f / (float)(65536u - thr), static_cast<__bf16 *>(out), ld_out);
+                       65536.f / (float)(65536u - thr), static_cast<__bf16 *>(out), ld_out, pika_internal_dropout_salt());
     return (int)hipGetLastError();
 }
 
@@ -1214,7 +1221,8 @@ extern "C" int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, f
     if (!mask || rows <= 0 || cols <= 0 || !(p_drop >= 0.f && p_drop < 1.f)) return PIKA_EINVAL;
     const long long n4 = (long long)rows * ((cols + 3) >> 2);
     hipLaunchKernelGGL(pp_keep_mask_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), mask, rows, cols, seed, (unsigned)lrintf(p_drop * 65536.f));
+                       static_cast<hipStream_t>(stream), mask, rows, cols, seed, (unsigned)lrintf(p_drop * 65536.f),
+                       pika_internal_dropout_salt());
     return (int)hipGetLastError();
 }
 

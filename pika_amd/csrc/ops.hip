@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include "pika_ops.h"
+#include "pika_internal.h"
 #include "pika_rnnt.h"
 
 namespace {
@@ -197,7 +198,15 @@ __global__ __launch_bounds__(256) void split_terms_kernel(const float *__restric
 
 }  // namespace
 
+static const unsigned *g_dropout_salt = nullptr;
+const unsigned *pika_internal_dropout_salt() { return g_dropout_salt; }
+
 extern "C" {
+
+int pika_set_dropout_salt(const unsigned *device_word) {
+    g_dropout_salt = device_word;
+    return 0;
+}
 
 int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, long long ld_out,
                         int out_dtype, void *stream) {

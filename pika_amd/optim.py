@@ -38,14 +38,41 @@ class _Tables(object):
         self.ct = torch.tensor(ct, dtype=torch.int32, device=device)
         self.co = torch.tensor(co, dtype=torch.int64, device=device)
         self.cl = torch.tensor(cl, dtype=torch.int32, device=device)
-        self.host = torch.empty(3, self.n, dtype=torch.int64).pin_memory()
+        # pinned staging: a ring of RING generations of the three pointer rows.  The copy out of a row is asynchronous,
+        # and a host that runs ahead of the device (no .item() between optimizer steps) must not rewrite a row whose copy
+        # has not executed yet: a row is re-used only after the event recorded behind its last copy has completed.
+        self.host = torch.empty(self.RING, 3, self.n, dtype=torch.int64).pin_memory()
         self.host_np = self.host.numpy()            # element writes through torch cost ~5 us each; numpy: one call
+        self.events = [[None] * 3 for _ in range(self.RING)]
+        self.gen = [0, 0, 0]
+        # staging rows owned by hipGraph captures (allocated up front: no host allocation while a stream captures); a
+        # captured copy node reads its host source at every replay, so such a row is written once and never again
+        self.cap_host = torch.empty(self.CAPTURES * 3, self.n, dtype=torch.int64).pin_memory()
+        self.cap_np = self.cap_host.numpy()
+        self.n_captured = 0
         self.dev = torch.empty(3, self.n, dtype=torch.int64, device=device)
         self.norm = torch.zeros(1, dtype=torch.float32, device=device)
 
+    RING, CAPTURES = 8, 8
+
     def upload(self, row, tensors):
-        self.host_np[row, :] = [t.data_ptr() for t in tensors]
-        self.dev[row].copy_(self.host[row], non_blocking=True)
+        ptrs = [t.data_ptr() for t in tensors]
+        if torch.cuda.is_current_stream_capturing():
+            if self.n_captured >= self.cap_host.shape[0]:
+                raise RuntimeError("pika_amd.optim: more than %d optimizer captures of one parameter set" % self.CAPTURES)
+            k, self.n_captured = self.n_captured, self.n_captured + 1
+            self.cap_np[k, :] = ptrs
+            self.dev[row].copy_(self.cap_host[k], non_blocking=True)
+            return self.dev[row].data_ptr()
+        g = self.gen[row] = (self.gen[row] + 1) % self.RING
+        ev = self.events[g][row]
+        if ev is not None:
+            ev.synchronize()
+        self.host_np[g, row, :] = ptrs
+        self.dev[row].copy_(self.host[g, row], non_blocking=True)
+        if ev is None:
+            ev = self.events[g][row] = torch.cuda.Event()
+        ev.record()
         return self.dev[row].data_ptr()
 
 

@@ -129,7 +129,7 @@ def test_fused_kernels_match_reference_math(hip_device):
         ref_dp = bm * dp + (blr * (1 - bm) * ref_d)
         ref_G = G - (1 + bm) * ref_dp
         _lib.check(lib.pika_bmuf_update(summed.data_ptr(), dpd.data_ptr(), Gd.data_ptr(), Ld.data_ptr(),
-                                        n, 1.0 / world, bm, blr, st), "update")
+                                        n, 1.0 / world, bm, blr, None, st), "update")
         torch.cuda.synchronize()
         assert torch.allclose(dpd.cpu(), ref_dp, rtol=1e-6, atol=1e-7)
         assert torch.allclose(Gd.cpu(), ref_G, rtol=1e-6, atol=1e-7)

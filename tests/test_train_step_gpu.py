@@ -138,3 +138,109 @@ def test_bf16_mode_matches_parity_mode_on_the_full_architecture(hip_device):
         else:
             assert cos > 0.998 and rel < 0.06, (n, cos, rel)
     print("worst relative gradient difference:", worst)
+
+
+def _small_step_harness(hip_device, dropout):
+    sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
+    from pika_amd import optim as fused_optim
+    from pika_amd.model.transducer import Net
+    from pika_amd.rnnt import RNNTLoss
+    B, T, U, V = 4, 300, 8, 500
+    opt = SimpleNamespace(rnn_size=256, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn",
+                          dropout=dropout, enc_layers=4, dec_layers=1, embd_dim=64, padding_idx=V)
+    torch.manual_seed(11)
+    model = Net(opt, 240, V).to(hip_device).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = dropout
+    g = torch.Generator().manual_seed(12)
+    batches = []
+    for _ in range(5):
+        data = torch.randn(B, T, 240, generator=g).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=g).to(hip_device)
+        len_b = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.int32, device=hip_device)
+        ali = torch.full((B,), U, dtype=torch.int32, device=hip_device)
+        batches.append((data, labels, len_b, ali))
+    return model, RNNTLoss(blank=0).apply, batches, fused_optim
+
+
+@pytest.mark.parametrize("mode", ["mixed", "bf16"])
+def test_graphed_train_step_equals_the_eager_step(hip_device, mode):
+    """pika_amd.train_graph.GraphedTrainStep: the captured launch sequence is the eager one -- the losses of two eager +
+    three replayed steps equal those of five eager steps, and so do the parameter updates (dropout off; up to the order
+    of the float atomics in the BatchNorm / split-K reductions, which a ReLU network amplifies: in the L2 norm)."""
+    import copy
+    from pika_amd import gemm as G
+    from pika_amd.train_graph import GraphedTrainStep
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0)
+    ref = copy.deepcopy(model)
+    init = [p.detach().clone() for p in model.parameters()]
+    old = G.PRECISION
+    G.PRECISION = mode
+    fused_optim.install()
+    try:
+        def make(m):
+            return lambda: torch.optim.SGD(m.parameters(), 0.0005, momentum=0.9, nesterov=True)
+        o = make(ref)()
+        ref_losses = []
+        for b in batches:
+            o.zero_grad(set_to_none=True)
+            out = ref(b[0], b[1].long(), b[2], True)
+            loss = loss_fn(out, b[1].int(), b[2], b[3]).sum()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 3.0, norm_type=float("inf"))
+            o.step()
+            ref_losses.append(loss.item())
+        gs = GraphedTrainStep(model, loss_fn, make(model), clip=3.0, warmup=2)
+        losses = [gs(*b).item() for b in batches]
+        assert len(gs.graphs) == 1
+        gs.close()
+    finally:
+        fused_optim.uninstall()
+        G.PRECISION = old
+    assert torch.allclose(torch.tensor(losses), torch.tensor(ref_losses), rtol=5e-4), (losses, ref_losses)
+    worst = []
+    for (n, p), q, p0 in zip(model.named_parameters(), ref.parameters(), init):
+        moved = (q - p0).norm().item()
+        worst.append(((p - q).norm().item() / max(moved, 1e-12), n, moved))
+    big = max(w[2] for w in worst)
+    worst = sorted((w for w in worst if w[2] > 1e-3 * big), reverse=True)     # parameters that moved at all (key biases and
+    #                                                biases in front of a BatchNorm have gradients that are rounding noise)
+    print("largest relative update differences:", worst[:5])
+    assert worst[0][0] < 0.1, worst[:5]
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            assert torch.allclose(v, ref.state_dict()[k], rtol=1e-2, atol=1e-3), k
+
+
+def test_graphed_train_step_draws_new_dropout_masks_per_replay(hip_device):
+    """Dropout inside the captured sequence: seeds are baked into the graph, the device-side salt
+    (pika_set_dropout_salt) is not -- replays of the SAME batch with a zero learning rate give different losses, and
+    the keep masks of one salt value are reproducible (forward and backward of a replay agree)."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import dropout_keep_mask
+    from pika_amd.train_graph import GraphedTrainStep
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.2)
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        gs = GraphedTrainStep(model, loss_fn, lambda: torch.optim.SGD(model.parameters(), 0.0, momentum=0.9, nesterov=True),
+                              clip=3.0, warmup=1)
+        losses = [gs(*batches[0]).item() for _ in range(5)]
+        assert len(set(round(v, 3) for v in losses[1:])) >= 3, losses      # replays differ from each other
+        m1 = dropout_keep_mask(64, 256, 0.3, 5, hip_device)
+        m2 = dropout_keep_mask(64, 256, 0.3, 5, hip_device)
+        assert torch.equal(m1, m2)
+        gs.salt.random_()
+        assert not torch.equal(dropout_keep_mask(64, 256, 0.3, 5, hip_device), m1)
+        gs.close()
+        m3 = dropout_keep_mask(64, 256, 0.3, 5, hip_device)     # salt cleared: the unsalted mask
+        gs2_salt = torch.zeros(1, dtype=torch.int32, device=hip_device)
+        from pika_amd import _lib
+        _lib.lib().pika_set_dropout_salt(gs2_salt.data_ptr())
+        assert torch.equal(dropout_keep_mask(64, 256, 0.3, 5, hip_device), m3)    # salt 0 == no salt
+        _lib.lib().pika_set_dropout_salt(None)
+    finally:
+        fused_optim.uninstall()
+        G.PRECISION = old
