@@ -171,16 +171,17 @@ __device__ inline void beam_load_state(const BeamState &a, BeamShared &sh, int *
     for (int i = 0; i < a.K; ++i) ml = max(ml, sh.len_old[i]);
     const int used = (int)min((long long)a.L, ml + 1);      // labels beyond a slot's length are never read
     const int n = a.K * used;
-    for (int base = tid; base < n; base += 256 * 8) {
+    const int nth = blockDim.x;
+    for (int base = tid; base < n; base += nth * 8) {
         long long v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = base + u * 256;
+            const int e = base + u * nth;
             if (e < n) v[u] = a.hyp[(bk + e / used) * a.L + e % used];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = base + u * 256;
+            const int e = base + u * nth;
             if (e < n) hyp_l[(e / used) * a.L + e % used] = (int)v[u];
         }
     }
@@ -329,20 +330,28 @@ __device__ inline void select_row(const Cand *pool, int n, int K, int lane, floa
 // log-sum-exp = log sum_s psum_s exp(pmax_s - max), and the K best of the S sorted partial lists by K rounds of
 // "wave arg-max over the S list heads".  Phase 2 = kernel B.  Phase 3: done flags, the all-done stop flag, the
 // longest partial hypothesis and the step counter (last workgroup to arrive).
-__global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restrict__ pmax,
+// Launched with min(16, K) waves per utterance: every beam row gets a wave of its own for phase 1 (the four rows a wave
+// took in turn at 256 threads were four dependent chains of row-sized round trips: 70 us of a 600 us step).
+__global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__restrict__ pmax,
                                                             const float *__restrict__ psum,
                                                             const Cand *__restrict__ pcand, int S, BeamState a,
                                                             int beam_prune, int n_best, int *__restrict__ stop,
                                                             long long *__restrict__ max_hyp, int *__restrict__ sync,
                                                             long long *__restrict__ step_rw) {
     if (*stop) {                                      // a replay after the search has ended: nothing happens, and the
-        if (blockIdx.x == 0 && threadIdx.x == 0) sync[4] = 1;   // FST advance of this (skipped) step must not run either
+        if (blockIdx.x == 0 && threadIdx.x == 0) {    // FST advance of this (skipped) step must not run either
+            sync[4] = 1;
+            // both compact-row counters: the prediction-network launches of the remaining replays then run on ZERO rows
+            // (the LSTM cell kernel updates its state in place -- a stale count would advance the final states again)
+            sync[5] = 0;
+            sync[6] = 0;
+        }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *hyp_l = reinterpret_cast<int *>(smem);                          // [K][L]
     Cand *cand = reinterpret_cast<Cand *>(hyp_l + a.K * a.L);            // [K][K]
-    Cand *pool_all = cand + a.K * a.K;                                   // [4 waves][S*K]
+    Cand *pool_all = cand + a.K * a.K;                                   // [waves][S*K]
     __shared__ BeamShared sh;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, L = a.L, V = a.V;
@@ -351,7 +360,8 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
     const int first = s_now == 0;
     beam_load_state(a, sh, hyp_l, b);
     __syncthreads();
-    for (int k = wave; k < K; k += 4) {
+    const int nwaves = blockDim.x >> 6;
+    for (int k = wave; k < K; k += nwaves) {
         bool d;
         if (first) {
             d = k != 0;
@@ -413,7 +423,13 @@ __global__ __launch_bounds__(256) void beam_partials_kernel(const float *__restr
         const unsigned old = atomicAdd(reinterpret_cast<unsigned *>(&sync[par * 2]), (unsigned)(done << 16) + 1u);
         if ((old & 0xffffu) == (unsigned)(a.B - 1)) {   // everybody has read step_t and finished its utterance
             const int ndone = (int)(old >> 16) + done;
-            if (ndone == a.B) atomicExch(stop, 1);
+            if (ndone == a.B) {
+                atomicExch(stop, 1);
+                // the launches of the remaining (skipped) steps address the counters by the parity they were captured
+                // with: this step's counter must read zero too, or an in-place LSTM cell update would run again on the
+                // rows of this step (final_state() would then return advanced states)
+                sync[5 + par] = 0;
+            }
             sync[(par ^ 1) * 2] = 0;
             sync[(par ^ 1) * 2 + 1] = 0;
             sync[5 + (par ^ 1)] = 0;                  // the compact-row counter the NEXT step's prep will fill
@@ -739,7 +755,12 @@ extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, 
         !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step || !fin_k || !fin_n ||
         !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
         return PIKA_EINVAL;
-    const size_t lds_bytes = (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)4 * splits * K * sizeof(Cand);
+    // a wave per beam row (at most 16), fewer when their candidate pools would not fit the LDS budget
+    int waves = K < 16 ? K : 16;
+    auto lds_for = [&](int w) { return (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)w * splits * K * sizeof(Cand); };
+    while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
+    if (waves < 4) waves = 4;
+    const size_t lds_bytes = lds_for(waves);
     if (K > MAXK || splits > 64 || splits * K > 1024 || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -750,7 +771,7 @@ extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, 
     }
     BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
                 eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
-    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
+    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(64 * waves), lds_bytes, static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
                        beam_prune, n_best, stop, max_hyp, sync, step_t);
     return (int)hipGetLastError();
 }

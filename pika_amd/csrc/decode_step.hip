@@ -66,8 +66,10 @@ struct Core {
 
     f32x4 acc[MT][WN];
 
+    // Kvalid: columns of A that hold data (a multiple of 4): columns [Kvalid, KT*32) are NOT read -- the packed weight
+    // is zero there, but garbage times zero is NaN when the garbage is not finite
     __device__ inline void run(const float *__restrict__ A, long long lda, int M, int m0, const __bf16 *__restrict__ W,
-                               int NT, int KT, int nt0, __bf16 *lds) {
+                               int NT, int KT, int nt0, __bf16 *lds, int Kvalid) {
         const int tid = threadIdx.x, lane = tid & 63;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -87,7 +89,7 @@ struct Core {
 #pragma unroll
         for (int j = 0; j < WN; ++j) wbase[j] = W + ((long long)(nt0 + j < NT ? nt0 + j : 0) * KT) * 512 + lane * 8;
         const long long term_stride = (long long)NT * KT * 512;
-        const int Kcols = KT * 32, steps = (KT + KS - 1) / KS;
+        const int Kcols = Kvalid < KT * 32 ? Kvalid : KT * 32, steps = (KT + KS - 1) / KS;
         f32x4 araw[APT];
         bf16x8 wreg[WN][KS][NS], wnext[WN][KS][NS];
         auto load_a = [&](int st) {
@@ -171,6 +173,7 @@ struct DG {   // device copy of pika_dgemm_t
     float *C; long long ldc; float *C2; long long ldc2; const long long *node; long long skip_node;
     const float *e_all; const long long *t_idx; int T, beam, M, N, NT, KT, flags;
     const int *m_dev; const long long *crow;
+    int Kvalid;   // K when K % 4 == 0 (columns beyond are never read), else ceil32(K) (the caller zero-pads, as the header says)
 };
 
 // blockIdx -> (row tile, column group) so that a column group always lands on the same XCD (block b runs on XCD
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mg * BM, nt0 = ng * 4 + wave;
     if (m0 >= M) return;
-    core.run(p.A, p.lda, M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem));
+    core.run(p.A, p.lda, M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem), p.Kvalid);
     if (nt0 >= p.NT) return;
     const int c0 = nt0 * 16 + (lane >> 4) * 4;          // first of this lane's 4 consecutive columns
     if (c0 >= p.N) return;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
                                                         const __bf16 *__restrict__ W, const float *__restrict__ bias,
                                                         int rows, int V, int NT, int KT, float sm_scale, int topk,
                                                         int splits, float *__restrict__ pmax,
-                                                        float *__restrict__ psum, Cand *__restrict__ pcand) {
+                                                        float *__restrict__ psum, Cand *__restrict__ pcand, int Kvalid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
     core_t core;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mb * FC2_BM, nt0 = (sp * 4 + wave) * FC2_WN;
     if (m0 >= rows) return;
-    core.run(h, ldh, rows, m0, W, NT, KT, nt0, lds);
+    core.run(h, ldh, rows, m0, W, NT, KT, nt0, lds, Kvalid);
     // logits of this split -> slab (sm_scale * (acc + bias); columns >= V masked)
 #pragma unroll
     for (int i = 0; i < FC2_BM / 16; ++i)
@@ -603,10 +606,10 @@ void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
 
 template <int NS>
 void launch_fc2(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
-                int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc) {
+                int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K) {
     constexpr size_t lds = Core<FC2_BM, FC2_WN, NS, FC2_KS>::LDS_BYTES + FC2_BM * FC2_COLS * 4;
     dfc2_topk_kernel<NS><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax,
-                                                             psum, pc);
+                                                             psum, pc, (K & 3) ? KT * 32 : K);
 }
 
 }  // namespace
@@ -635,7 +638,7 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     if (((q->flags & PIKA_DG_ROWMASK) || q->C2) && !q->node) return PIKA_EINVAL;
     DG p{q->A, q->lda, reinterpret_cast<const __bf16 *>(q->W), q->bias, q->res, q->ldr, q->C, q->ldc, q->C2, q->ldc2,
          q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags,
-         q->m_dev, q->crow};
+         q->m_dev, q->crow, (q->K & 3) ? ((q->K + 31) / 32) * 32 : q->K};
     hipStream_t st = (hipStream_t)stream;
     const int n_groups = (p.NT + 3) / 4;
     // enough workgroups to cover the chip: 32-row tiles unless 64-row tiles already give > 256 of them
@@ -712,9 +715,9 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
     Cand *pc = reinterpret_cast<Cand *>(pcand);
-    if (terms == 1) launch_fc2<1>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc);
-    else if (terms == 2) launch_fc2<2>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc);
-    else launch_fc2<3>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc);
+    if (terms == 1) launch_fc2<1>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else if (terms == 2) launch_fc2<2>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else launch_fc2<3>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
     return check(hipGetLastError());
 }
 

@@ -59,6 +59,7 @@ class TransducerDecoder(object):
         # the step GEMMs still exact; "bf16": plain bf16 operands everywhere
         self.decode_precision = os.environ.get("PIKA_DECODE_PRECISION", "fp32")
         self.replays_per_sync = 4
+        self.groups_in_flight = 3       # groups of replays queued ahead of the host's look at the stop flag
 
     @property
     def decode_terms(self):
@@ -237,17 +238,33 @@ def _search_fused(self, beam, e_all, T, num_frames, enc_out, x, x_len, max_len):
     fs.step_launches(0)
     fs.step_launches(1)
     graph, n_replays = None, 0
-    while not int(fs.stop.item()):
-        if self.use_graph:
-            if graph is None:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    fs.step_launches(0)
-                    fs.step_launches(1)
+    if self.use_graph:
+        # The host never waits for the device while the search runs: groups of `replays_per_sync` replays (2 steps each)
+        # are kept `groups_in_flight` deep, each followed by an asynchronous copy of the stop flag into its own pinned
+        # word; the host looks at the OLDEST group's word (its event has long completed by the time the queue is full).
+        # Launches behind the end of the search are no-ops (every state-mutating kernel returns when `stop` is set).
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fs.step_launches(0)
+            fs.step_launches(1)
+        depth = max(int(self.groups_in_flight), 1)
+        flags = torch.zeros(depth, dtype=torch.int32).pin_memory()
+        events = [torch.cuda.Event() for _ in range(depth)]
+        queued = 0
+        while True:
+            slot = queued % depth
+            if queued >= depth:                     # the slot's previous group: had the search ended by then?
+                events[slot].synchronize()
+                if int(flags[slot]):
+                    break
             for _ in range(self.replays_per_sync):
                 graph.replay()
             n_replays += self.replays_per_sync
-        else:
+            flags[slot:slot + 1].copy_(fs.stop, non_blocking=True)
+            events[slot].record()
+            queued += 1
+    else:
+        while not int(fs.stop.item()):
             fs.step_launches(0)
             fs.step_launches(1)
     beam.steps = int(beam.step_t.item())

@@ -108,7 +108,16 @@ def assemble(batch, frontend, args):
     for i, a in enumerate(alis):
         target[i, :len(a)] = a
     if not args.batch_first:
-        data = data.transpose(0, 1).contiguous()
+        st = getattr(frontend, "stream", None)
+        if st is not None:
+            # the feature kernels were issued on the front end's own stream: the transposing copy must run behind them
+            # on THAT stream, and `ready` must cover it (the consumer only waits on the event)
+            with torch.cuda.stream(st):
+                data = data.transpose(0, 1).contiguous()
+                frontend.ready = torch.cuda.Event()
+                frontend.ready.record(st)
+        else:
+            data = data.transpose(0, 1).contiguous()
         target = target.T.copy()
     return (data, torch.from_numpy(target), torch.tensor(lens, dtype=torch.int32),
             torch.tensor([len(a) for a in alis], dtype=torch.int32))

@@ -287,18 +287,22 @@ class Net(nn.Module):
         tgt = tgt[:-1]                                               # las.py:66 (exclude EOS)
         if not torch.is_grad_enabled():
             # the rescoring loop of decode_transducer.py:136-156 calls this for every n-best entry and direction of the
-            # SAME utterance: keep the last encoder pass (keyed by the storage, shape and version of src)
+            # SAME utterance: keep the last encoder pass.  The entry HOLDS `src` (its storage cannot be freed and handed to
+            # another utterance of the same shape while the entry lives) and is matched by identity of that storage, its
+            # version counter and the version counters of the encoder's weights (load_state_dict / optimizer steps)
             try:
-                key = (src.data_ptr(), tuple(src.shape), src._version, src.device,
-                       tuple(int(v) for v in torch.as_tensor(lengths).view(-1)))
+                key = (src.data_ptr(), tuple(src.shape), tuple(src.stride()), src._version, src.device,
+                       tuple(int(v) for v in torch.as_tensor(lengths).view(-1)),
+                       tuple(p._version for p in self.encoder.parameters()))
             except RuntimeError:        # inference-mode tensors carry no version counter: no memo
                 key = None
             hit = getattr(self, "_enc_cache", None)
-            if key is not None and hit is not None and hit[0] == key and not self.training:
+            if (key is not None and hit is not None and hit[0] == key and not self.training
+                    and hit[2].untyped_storage().data_ptr() == src.untyped_storage().data_ptr()):
                 enc_hidden, enc_out = hit[1]
             else:
                 enc_hidden, enc_out = self.encoder(src, lengths)
-                self._enc_cache = None if key is None else (key, (enc_hidden, enc_out))
+                self._enc_cache = None if key is None else (key, (enc_hidden, enc_out), src)
         else:
             self._enc_cache = None
             enc_hidden, enc_out = self.encoder(src, lengths)

@@ -107,3 +107,44 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
                         np.array_equal(got16["hyps"][b, 0, :z["lens"][b, 0]], z["hyps"][b, 0, :z["lens"][b, 0]]))
                     for b in range(F.B))
     print("bf16 mode: encoder output max rel err %.2e, identical top-1 hypotheses %d / %d" % (rel16, same_top1, F.B))
+
+
+GREEDY = os.path.join(HERE, "golden", "decode_full_greedy.npz")
+
+
+def decode_greedy(device, precision=None):
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd.model import transducer
+    net = F.build(transducer, seeded_state_dict).to(device)
+    x, x_len = F.inputs()
+    args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    d = TransducerDecoder(net, batch_size=F.B, beam_size=1, n_best=1, blk=0, global_scorer=GlobalScorer(),
+                          sm_scale=F.SM_SCALE, cuda=(device != "cpu"), beam_prune=True, args=args)
+    if precision is not None:
+        d.decode_precision = precision
+    ret, _ = d.decode_batch(x.to(device), x_len.to(device), F.max_len(x_len))
+    return D.pack(ret["predictions"], ret["scores"]), d
+
+
+def test_cpu_full_width_greedy_matches_reference():
+    z = np.load(GREEDY)
+    got, _ = decode_greedy("cpu")
+    assert np.array_equal(got["lens"], z["lens"]) and np.array_equal(got["hyps"], z["hyps"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_gpu_full_width_greedy_is_identical_to_the_reference(hip_device, precision):
+    """Greedy search (beam 1) on the full-width model: the case north_star words as bit-exact.  The reference's own
+    decisions along the four greedy paths are separated by >= 0.044 in log-probability (recorded in the golden:
+    `min_margin`), two orders above the fp32 accumulation noise of a 1024-term product, so the hypotheses -- blanks
+    included -- must be IDENTICAL, in the default decode arithmetic and with the two-term encoder."""
+    z = np.load(GREEDY)
+    assert float(z["min_margin"]) > 1e-2
+    got, d = decode_greedy(hip_device, precision)
+    assert "launches_per_step" in d.timing            # the fused launch-chain search ran
+    assert np.array_equal(got["lens"], z["lens"]), (got["lens"], z["lens"])
+    assert np.array_equal(got["hyps"], z["hyps"])
+    assert np.abs(got["scores"] - z["scores"]).max() < 2e-3
