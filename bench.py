@@ -238,6 +238,24 @@ def run_train_step(args, R_, steps, warmup):
     return out
 
 
+def trained_like_bn_statistics(model, feats):
+    """BatchNorm running statistics as a trained model carries them.  With the initial (0, 1) statistics the random
+    encoder's eval-mode output does not vary over time at all (every frame of an utterance gives the joint the same
+    input, so a search emits either only labels or only blanks).  One train-mode pass, momentum 1 = batch statistics."""
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.momentum = 1.0
+        drops = [(m, m.p) for m in model.modules() if isinstance(m, torch.nn.Dropout)]
+        for m, _ in drops:
+            m.p = 0.0
+        model.train()
+        model.encoder(feats)
+        model.eval()
+        for m, p in drops:
+            m.p = p
+
+
 def decode_workload(args, dev, rank):
     """batch beam decode, B utterances x beam 16, 10 s of synthetic fbank each,
     full-size model with random weights.  Random weights never emit blank, so fc2 is sharpened
@@ -277,6 +295,7 @@ def decode_workload(args, dev, rank):
                                  lm_scorer=lm, lm_scorer_scale=args.fst_scale,
                                  beam_prune=True, args=dargs)
 
+    trained_like_bn_statistics(model, feats[:min(B, 4)])
     with torch.no_grad():
         model.fc2.weight *= 8.0
         lo, hi = 0.0, 40.0
@@ -289,9 +308,11 @@ def decode_workload(args, dev, rank):
         for _ in range(9 if args.blank_bias is None else 0):
             mid = 0.5 * (lo + hi)
             model.fc2.bias[0] = mid
-            ret, _ = decoder(args.beam, args.beam, lm_scorer).decode_batch(feats[:8], x_len[:8],
-                                                                         [int(v) + 100 for v in x_len[:8]])
-            labels = np.mean([sum(1 for e in h[0] if int(e) != 0) for h in ret["predictions"]])
+            nc = min(B, 16)
+            ret, _ = decoder(args.beam, args.beam, lm_scorer).decode_batch(feats[:nc], x_len[:nc],
+                                                                         [int(v) + 100 for v in x_len[:nc]])
+            # the median: the label count of a random model is heavy-tailed across utterances
+            labels = float(np.median([sum(1 for e in h[0] if int(e) != 0) for h in ret["predictions"]]))
             if labels > args.labels:
                 lo = mid
             else:
@@ -368,6 +389,7 @@ def mbr_workload(args, dev, rank):
         return TransducerDecoder(model, batch_size=B, beam_size=k, n_best=k, blk=0, global_scorer=GlobalScorer(),
                                  sm_scale=0.8, cuda=True, beam_prune=False, args=dargs)
     max_len = [int(v) + U + 3 for v in x_len]                                 # :114
+    trained_like_bn_statistics(model, feats[:min(B, 4)])
     model.eval()
     with torch.no_grad():
         model.fc2.weight *= 8.0
@@ -727,7 +749,8 @@ def decode_bytes_per_step(model, rows):
 
 def decode_report(a, step, ret, el, audio_s, world, cal_labels):
     hyps = ret["predictions"]
-    nlab = float(np.mean([sum(1 for e in h[0] if int(e) != 0) for h in hyps]))
+    counts = sorted(sum(1 for e in h[0] if int(e) != 0) for h in hyps)
+    nlab = float(np.mean(counts))
     nsteps = float(np.mean([len(h[0]) + 1 for h in hyps]))
     tm = step.decoder.timing
     bps = decode_bytes_per_step(step.decoder.model, a.batch * a.beam)
@@ -746,7 +769,9 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
                                    ", bigram FST shallow fusion (device-resident FST, scale %g)" % a.fst_scale if a.fst else "",
                                    ", fw+bw LAS rescoring of the n-best" if a.las else ""),
                    "audio_seconds": audio_s, "utterances_per_s": a.batch * world / el,
-                   "labels_per_utt_top1": nlab, "search_steps_top1": nsteps,
+                   "labels_per_utt_top1": nlab, "labels_per_utt_top1_quartiles": [
+                       counts[0], counts[len(counts) // 4], counts[len(counts) // 2], counts[(3 * len(counts)) // 4], counts[-1]],
+                   "search_steps_top1": nsteps,
                    "calibration_labels": cal_labels, "blank_bias": decode_workload.blank_bias,
                    "timing": tm},
         "roofline": {"bound": "hbm", "kernel": "one beam-search step (all of its kernels; the search is "
@@ -777,6 +802,7 @@ def cpu_baseline_decode(a, blank_bias, B=4):
         model.fc2.bias[0] = blank_bias
     g = torch.Generator().manual_seed(3000)
     feats = torch.randn(B, T, 240, generator=g)
+    trained_like_bn_statistics(model, feats[:min(B, 4)])
     x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long)
     dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
     dec = TransducerDecoder(model, batch_size=B, beam_size=a.beam, n_best=a.beam, blk=0, global_scorer=GlobalScorer(),
@@ -811,6 +837,10 @@ def cpu_baseline_mbr(args, blank_bias, B=2):
         model.fc2.bias[0] = blank_bias
     g = torch.Generator().manual_seed(4000)
     feats = torch.randn(B, T, 240, generator=g)
+    trained_like_bn_statistics(model, feats)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.momentum = 0.0
     x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long)
     labels = torch.randint(1, V, (B, U), generator=g)
     ali = torch.full((B,), U, dtype=torch.int32)
