@@ -326,11 +326,21 @@ def decode_workload(args, dev, rank):
         t0 = time.perf_counter()
         if las_fw is not None:      # decode_transducer.py:136-156: every n-best entry, forward and reversed
             hyps = [[[int(e) for e in h if int(e) != 0] for h in ret["predictions"][i]] for i in range(B)]
+            # the random model's n-best lists hold "runaway" entries of up to max_len labels (a search stuck in a label
+            # cycle at one frame: DESIGN 6); a trained model emits ~U per utterance.  Rescoring cost is tokens x
+            # hypotheses, so entries are cut to 2U labels for this leg -- stated in the line (las_max_labels)
+            cap = 2 * args.labels
+            dec.timing["las_truncated"] = sum(1 for row in hyps for h in row if len(h) > cap)
+            hyps = [[h[:cap] for h in row] for row in hyps]
+            dec.timing["las_max_labels"] = cap
+            dec.timing["las_pairs"] = sum(len(h) + 1 for row in hyps for h in row)
             src = enc_out.transpose(0, 1)                                   # (T', B, H)
             fw = las_fw.score_nbest_batch(src, x_len, hyps, SOS, EOS)
             bw = las_bw.score_nbest_batch(src, x_len, [[h[::-1] for h in row] for row in hyps], SOS, EOS)
             ret["las"] = (fw, bw)
             torch.cuda.synchronize()
+            if getattr(las_fw, "phase_times", None):
+                dec.timing["las_phases_ms"] = {"fw": las_fw.phase_times, "bw": las_bw.phase_times}
         dec.timing["las_s"] = time.perf_counter() - t0
         return ret, enc_out
     step.decoder = dec

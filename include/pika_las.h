@@ -23,9 +23,9 @@ extern "C" {
  * c_prev (N, H) contiguous.  c_out (N, H) contiguous (may alias c_prev) = sigmoid(f) c_prev + sigmoid(i) tanh(g);
  * h = sigmoid(o) tanh(c_out) is written to h_out (pitch ldh) and, when h_out2 != NULL, also to h_out2 (pitch ldh2) --
  * the decoder keeps h both as the next layer's input block and as the recurrent block of its own next step.
- * H % 4 == 0, 16-byte aligned rows. */
+ * H % 4 == 0, 16-byte aligned rows.  n_dev: NULL, or a device int: only rows < min(N, *n_dev) are processed. */
 int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float *c_out, float *h_out, long long ldh,
-                   float *h_out2, long long ldh2, int N, int H, void *stream);
+                   float *h_out2, long long ldh2, int N, int H, const int *n_dev, void *stream);
 
 /* "mlp" attention of N queries over the source positions of their utterances; query n = qidx[i], i < N (qidx NULL:
  * n = i):
@@ -37,10 +37,24 @@ int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float
  * should belong to the same utterance: a workgroup takes 4 of them and loads an utterance's rows once for those that
  * share it (the caller's active set is a prefix of its length-sorted hypotheses, the list re-orders it by
  * utterance); lens (B,) int32 valid positions (>= 1); ctx_out (., D) f32 pitch ldo; align_out (., S) f32 or NULL
- * (the attention weights, for tests).  D % 4 == 0, D <= 1024, S <= 2048. */
+ * (the attention weights, for tests).  D % 4 == 0, D <= 1024, S <= 2048.
+ * n_dev / qoff_dev: NULL, or device ints: the launch processes min(N, *n_dev) list entries starting at qidx + *qoff_dev
+ * (one launch captured into a hipGraph serves every token of a pass; N then sizes the grid for the largest step). */
 int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, const float *context, const int *owner,
                            const int *lens, const int *qidx, const float *v, float *ctx_out, long long ldo,
-                           float *align_out, int N, int B, int S, int D, void *stream);
+                           float *align_out, int N, int B, int S, int D, const int *n_dev, const int *qoff_dev,
+                           void *stream);
+
+/* The token loop of a rescoring pass as ONE captured launch sequence replayed once per token: every per-token quantity
+ * lives on the device.  step int32[4] = {t, n, qoff, -} (the caller starts it at {-1, 0, 0, 0});
+ * pika_las_step_advance: t += 1, n = n_active[t], qoff = qoffs[t] (0 beyond L) -- n is what the m_dev / n_dev
+ * parameters of pika_dgemm, pika_lstm_cell and pika_las_mlp_attention point at;
+ * pika_las_embed_rows: for r < n: x0[r, 0:E] = emb[tokens[t, r], :] (the decoder's layer-0 input rows, pitch ldx) and
+ * crow[r] = t * N + r (the row of the (L, N, H) result the token's output projection writes through pika_dgemm's
+ * crow).  tokens (L, N) int64, E % 4 == 0. */
+int pika_las_step_advance(int *step, const int *n_active, const int *qoffs, int L, void *stream);
+int pika_las_embed_rows(const int *step, const long long *tokens, const float *emb, float *x0, long long ldx,
+                        long long *crow, int N, int E, void *stream);
 
 #ifdef __cplusplus
 }

@@ -59,8 +59,10 @@ SIGNATURES = {
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
     # include/pika_las.h
-    "pika_lstm_cell": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _vp]),
-    "pika_las_mlp_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _vp]),
+    "pika_lstm_cell": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _vp, _vp]),
+    "pika_las_mlp_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pika_las_step_advance": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "pika_las_embed_rows": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _vp]),
     # include/pika_joint.h
     "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pika_joint_gate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i, _i, _i, _i, _vp]),

@@ -22,8 +22,10 @@ __device__ inline float sigmoid_fast(float x) { return rcp(1.0f + __expf(-x)); }
 __global__ __launch_bounds__(256) void lstm_cell_kernel(const float *__restrict__ gates, long long ldg,
                                                         const float *__restrict__ c_prev, float *__restrict__ c_out,
                                                         float *__restrict__ h_out, long long ldh,
-                                                        float *__restrict__ h_out2, long long ldh2, int N, int H) {
+                                                        float *__restrict__ h_out2, long long ldh2, int N, int H,
+                                                        const int *__restrict__ n_dev) {
     const int H4 = H >> 2;
+    if (n_dev) N = min(N, *n_dev);       // rows in use this step (a launch captured once, replayed per token)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * H4) return;
     const int n = (int)(idx / H4), c = (int)(idx - (long long)n * H4) << 2;
@@ -81,8 +83,13 @@ __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float 
                                                                 const int *__restrict__ qidx,
                                                                 const float *__restrict__ v,
                                                                 float *__restrict__ ctx_out, long long ldo,
-                                                                float *__restrict__ align_out, int N, int S, int D) {
+                                                                float *__restrict__ align_out, int N, int S, int D,
+                                                                const int *__restrict__ n_dev,
+                                                                const int *__restrict__ qoff_dev) {
     __shared__ float wm[AW][G], wl[AW][G];
+    if (n_dev) N = min(N, *n_dev);       // queries in use this step
+    if (qoff_dev && qidx) qidx += *qoff_dev;   // ... and where their list starts
+    if ((int)blockIdx.x * G >= N) return;
     __shared__ f32x4 wacc[AW][64 * KQ];         // one query's partial sums of the eight waves (32 KB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D4 = D >> 2;
     const int i0 = blockIdx.x * G;
@@ -210,12 +217,56 @@ __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float 
     }
 }
 
+// ---- the per-token bookkeeping of a rescoring pass captured as ONE launch sequence (include/pika_las.h) ----------
+// step = {t, n, qoff, -}: advanced by one thread in front of every token's launches
+__global__ void las_step_advance_kernel(int *__restrict__ step, const int *__restrict__ n_active,
+                                        const int *__restrict__ qoff, int L) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = step[0] + 1;
+        step[0] = t;
+        step[1] = t < L ? n_active[t] : 0;
+        step[2] = t < L ? qoff[t] : 0;
+    }
+}
+
+// rows r < n of the decoder's layer-0 input get the embedding of token (t, r); crow[r] = t * N + r addresses the row of
+// the (L, N, H) result this token's output projection writes
+__global__ __launch_bounds__(256) void las_embed_rows_kernel(const int *__restrict__ step,
+                                                             const long long *__restrict__ tokens,
+                                                             const float *__restrict__ emb, float *__restrict__ x0,
+                                                             long long ldx, long long *__restrict__ crow, int N, int E) {
+    const int t = step[0], n = min(N, step[1]);
+    const int E4 = E >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * E4) return;
+    const int r = (int)(idx / E4), c = (int)(idx - (long long)r * E4) << 2;
+    const long long tok = tokens[(long long)t * N + r];
+    *reinterpret_cast<f32x4 *>(x0 + (long long)r * ldx + c) = *reinterpret_cast<const f32x4 *>(emb + tok * E + c);
+    if (c == 0) crow[r] = (long long)t * N + r;
+}
+
 }  // namespace
 
 extern "C" {
 
+int pika_las_step_advance(int *step, const int *n_active, const int *qoff, int L, void *stream) {
+    if (!step || !n_active || !qoff || L <= 0) return PIKA_EINVAL;
+    hipLaunchKernelGGL(las_step_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), step, n_active, qoff, L);
+    return (int)hipGetLastError();
+}
+
+int pika_las_embed_rows(const int *step, const long long *tokens, const float *emb, float *x0, long long ldx,
+                        long long *crow, int N, int E, void *stream) {
+    if (!step || !tokens || !emb || !x0 || !crow || N <= 0 || E <= 0 || (E & 3) || (ldx & 3) || ldx < E) return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(x0)) & 15) return PIKA_EINVAL;
+    const long long total = (long long)N * (E >> 2);
+    hipLaunchKernelGGL(las_embed_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), step, tokens, emb, x0, ldx, crow, N, E);
+    return (int)hipGetLastError();
+}
+
 int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float *c_out, float *h_out, long long ldh,
-                   float *h_out2, long long ldh2, int N, int H, void *stream) {
+                   float *h_out2, long long ldh2, int N, int H, const int *n_dev, void *stream) {
     if (!gates || !c_prev || !c_out || !h_out || N <= 0 || H <= 0) return PIKA_EINVAL;
     if ((H & 3) || (ldg & 3) || (ldh & 3) || (h_out2 && (ldh2 & 3)) || ldg < 4LL * H || ldh < H) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(gates) | reinterpret_cast<uintptr_t>(c_prev) | reinterpret_cast<uintptr_t>(c_out) |
@@ -224,13 +275,14 @@ int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float
     const long long total = (long long)N * (H >> 2);
     if ((total + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
     hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), gates, ldg, c_prev, c_out, h_out, ldh, h_out2, ldh2, N, H);
+                       static_cast<hipStream_t>(stream), gates, ldg, c_prev, c_out, h_out, ldh, h_out2, ldh2, N, H, n_dev);
     return (int)hipGetLastError();
 }
 
 int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, const float *context, const int *owner,
                            const int *lens, const int *qidx, const float *v, float *ctx_out, long long ldo,
-                           float *align_out, int N, int B, int S, int D, void *stream) {
+                           float *align_out, int N, int B, int S, int D, const int *n_dev, const int *qoff_dev,
+                           void *stream) {
     if (!wq || !proj || !context || !owner || !lens || !v || !ctx_out || N <= 0 || B <= 0 || S <= 0 || D <= 0)
         return PIKA_EINVAL;
     if ((D & 3) || (ldq & 3) || (ldo & 3) || ldq < D || ldo < D) return PIKA_EINVAL;
@@ -240,7 +292,7 @@ int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, co
         return PIKA_EINVAL;
     hipLaunchKernelGGL(las_mlp_attention_kernel, dim3((unsigned)((N + G - 1) / G)), dim3(64 * AW), 0,
                        static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
-                       align_out, N, S, D);
+                       align_out, N, S, D, n_dev, qoff_dev);
     return (int)hipGetLastError();
 }
 

@@ -18,6 +18,23 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 from . import ops
 
 
+def _phase_timer(net, dev):
+    """PIKA_LAS_TIMING=1: wall time of the phases of a scoring pass (device-synchronised) into net.phase_times."""
+    if os.environ.get("PIKA_LAS_TIMING") != "1" or dev.type != "cuda":
+        return lambda name: None
+    import time
+    torch.cuda.synchronize(dev)
+    state = {"t": time.perf_counter()}
+    net.phase_times = []
+
+    def tick(name):
+        torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        net.phase_times.append((name, (now - state["t"]) * 1e3))
+        state["t"] = now
+    return tick
+
+
 class LASRNNEncoder(nn.Module):
     def __init__(self, rnn_type, bidirectional, num_layers, hidden_size, dropout, input_dim):
         super().__init__()
@@ -153,6 +170,9 @@ class InputFeedRNNDecoder(nn.Module):
         LSTM-cell kernel), the query projection, ONE attention kernel (scores, softmax and context sum of a hypothesis
         never leave the workgroup; the (N,S,H) tanh tensor of global_attention.py:218-221 does not exist) and the
         output projection written straight into the result and fed back (input feeding, las.py:649-668).
+        The nine launches of a token are captured ONCE into a hipGraph and replayed per token: the step index, the
+        number of active hypotheses and the query-list offset are device words a one-thread kernel advances
+        (PIKA_LAS_GRAPH=0: the same launches issued from Python per token).
         n_active[t] (host ints, non-increasing): only hypotheses [0, n_active[t]) still have a token at step t (the
         caller sorted them by length), so every launch of step t runs on that prefix of the rows; rows past it are left
         unwritten in the result."""
@@ -170,23 +190,17 @@ class InputFeedRNNDecoder(nn.Module):
             h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
             ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
             proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous()).view(B, S, H)
-            emb = self.embeddings.embeddings(tokens)                                # (L, N, E)
             own = owner.to(device=dev, dtype=torch.int32).contiguous()
             ln = lens.to(device=dev, dtype=torch.int32).contiguous()
-            half = G.PRECISION == "bf16"      # weights are re-read every token: keep them in the operand dtype
-
-            def weight(w):
-                w = w.detach()
-                if not half:
-                    return w.contiguous()
-                K8 = (w.shape[1] + 7) & ~7      # bf16 operand rows: readable and zero up to a multiple of 8
-                wb = torch.zeros((w.shape[0], K8), dtype=torch.bfloat16, device=dev)
-                wb[:, :w.shape[1]] = w
-                return wb
-            Wl = [weight(torch.cat([c.weight_ih, c.weight_hh], 1)) for c in self.rnn.layers]
-            bl = [(c.bias_ih + c.bias_hh).detach().contiguous() for c in self.rnn.layers]
-            Wq, bq = weight(att.linear_query.weight), att.linear_query.bias.detach().contiguous()
-            Wo, bo = weight(att.linear_out.weight), att.linear_out.bias.detach().contiguous()
+            half = G.PRECISION in ("bf16", "mixed")
+            # weights packed once per pass into MFMA fragment order (pika_dpack_weight): 1 bf16 term per operand in the
+            # bf16 arithmetic mode, 3 (fp32-exact products) otherwise
+            from ..decoder.fused_step import DGemm, PackedWeight
+            terms = 1 if half else 3
+            Wl = [PackedWeight(torch.cat([c.weight_ih, c.weight_hh], 1), terms) for c in self.rnn.layers]
+            bl = [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.rnn.layers]
+            Wq, bq = PackedWeight(att.linear_query.weight, terms), att.linear_query.bias.detach().float().contiguous()
+            Wo, bo = PackedWeight(att.linear_out.weight, terms), att.linear_out.bias.detach().float().contiguous()
             v = att.v.weight.detach().reshape(-1).contiguous()
             # X[0] = [emb_t | feed | h_0], X[l] = [h_{l-1} | h_l]: a layer's input rows, updated in place
             X = [torch.zeros((N, E + 2 * H), device=dev)] + [torch.zeros((N, 2 * H), device=dev) for _ in range(1, nl)]
@@ -198,35 +212,79 @@ class InputFeedRNNDecoder(nn.Module):
             gates = torch.empty((N, 4 * H), device=dev)
             wq = torch.empty((N, H), device=dev)
             outs = torch.empty((L, N, H), device=dev)
-            # per step: the active hypotheses [0, n) re-ordered by utterance, so that the four queries of an attention
-            # workgroup share the utterance's rows (one upload for all steps)
-            qoff = qlist = None
-            if n_active is not None:
-                import numpy as np
-                own_h = owner.cpu().numpy()
-                by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
-                lists = [by_owner[by_owner < int(k)] for k in n_active]
-                qoff = np.concatenate([[0], np.cumsum([len(x) for x in lists])])
-                qlist = torch.from_numpy(np.concatenate(lists) if lists else np.zeros(0, np.int32)).to(dev)
-            for t in range(L):
-                n = N if n_active is None else int(n_active[t])
-                if n <= 0:
-                    break
-                X[0][:n, :E].copy_(emb[t, :n])
+            # Every per-token quantity lives on the device, so ONE captured launch sequence serves all tokens
+            # (include/pika_las.h): step = {t, n, qoff}; the active hypotheses [0, n) of a step re-ordered by utterance,
+            # so that the four queries of an attention workgroup share the utterance's rows
+            import numpy as np
+            own_h = owner.cpu().numpy()
+            by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
+            n_act = np.full(L, N, np.int32) if n_active is None else np.asarray(n_active, np.int32)
+            lists = [by_owner[by_owner < int(k)] for k in n_act]
+            qoff = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
+            qlist = torch.from_numpy(np.concatenate(lists) if lists else np.zeros(0, np.int32)).to(dev)
+            n_act_d = torch.from_numpy(n_act).to(dev)
+            qoff_d = torch.from_numpy(qoff[:L].copy()).to(dev)
+            step = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)
+            n_dev = step[1:2]
+            crow = torch.zeros(N, dtype=torch.long, device=dev)
+            iden = torch.arange(N, dtype=torch.long, device=dev)
+            emb_w = self.embeddings.embeddings.weight.detach().float().contiguous()
+            tok = tokens.contiguous()
+            n_max = int(n_act.max())
+
+            def dgemm(A, lda, W, bias, C, ldc, crow_=None, C2=None, ldc2=0):
+                g = DGemm()
+                g.A, g.lda, g.W, g.bias = A.data_ptr(), lda, W.buf.data_ptr(), bias.data_ptr()
+                g.C, g.ldc = C.data_ptr(), ldc
+                if C2 is not None:
+                    g.C2, g.ldc2, g.node = C2.data_ptr(), ldc2, iden.data_ptr()
+                g.skip_node = -1
+                g.M, g.N, g.K, g.terms, g.flags = n_max, W.N, W.K, W.terms, 0
+                g.m_dev = n_dev.data_ptr()
+                if crow_ is not None:
+                    g.crow = crow_.data_ptr()
+                _lib.check(lib.pika_dgemm(ctypes.byref(g), torch.cuda.current_stream().cuda_stream),
+                           "pika_dgemm(M=%d,N=%d,K=%d)" % (n_max, W.N, W.K))
+
+            def token_step():
+                st = torch.cuda.current_stream().cuda_stream
+                _lib.check(lib.pika_las_step_advance(step.data_ptr(), n_act_d.data_ptr(), qoff_d.data_ptr(), L, st),
+                           "pika_las_step_advance")
+                _lib.check(lib.pika_las_embed_rows(step.data_ptr(), tok.data_ptr(), emb_w.data_ptr(), X[0].data_ptr(),
+                                                   X[0].stride(0), crow.data_ptr(), n_max, E, st), "pika_las_embed_rows")
                 for l in range(nl):
-                    G.gemm_nt(X[l][:n], Wl[l], bias=bl[l], out=gates[:n])
+                    dgemm(X[l], X[l].stride(0), Wl[l], bl[l], gates, 4 * H)
                     own_block = X[l][:, (E + H if l == 0 else H):]
                     nxt = X[l + 1][:, :H] if l + 1 < nl else CQ[:, H:]
                     _lib.check(lib.pika_lstm_cell(gates.data_ptr(), 4 * H, c[l].data_ptr(), c[l].data_ptr(),
                                                   own_block.data_ptr(), own_block.stride(0), nxt.data_ptr(),
-                                                  nxt.stride(0), n, H, stream), "pika_lstm_cell")
-                G.gemm_nt(CQ[:n, H:], Wq, bias=bq, out=wq[:n])
-                qi = None if qlist is None else qlist.data_ptr() + 4 * int(qoff[t])
+                                                  nxt.stride(0), n_max, H, n_dev.data_ptr(), st), "pika_lstm_cell")
+                dgemm(CQ[:, H:], 2 * H, Wq, bq, wq, H)
                 _lib.check(lib.pika_las_mlp_attention(wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(),
-                                                      ln.data_ptr(), qi, v.data_ptr(), CQ.data_ptr(), 2 * H, None, n, B, S,
-                                                      H, stream), "pika_las_mlp_attention")
-                G.gemm_nt(CQ[:n], Wo, bias=bo, out=outs[t, :n])
-                X[0][:n, E:E + H].copy_(outs[t, :n])                                # input feeding
+                                                      ln.data_ptr(), qlist.data_ptr(), v.data_ptr(), CQ.data_ptr(), 2 * H,
+                                                      None, n_max, B, S, H, n_dev.data_ptr(), step[2:3].data_ptr(), st),
+                           "pika_las_mlp_attention")
+                # output projection of [context | h_t]: into row (t, r) of the result AND into the feed block of the
+                # layer-0 input rows (input feeding, las.py:649-668)
+                dgemm(CQ, 2 * H, Wo, bo, outs.view(L * N, H), H, crow_=crow, C2=X[0][:, E:], ldc2=X[0].stride(0))
+
+            token_step()                                      # token 0, eagerly (lazy kernel attributes reach their state)
+            if L > 1:
+                if os.environ.get("PIKA_LAS_GRAPH", "1") != "0":
+                    cur = torch.cuda.current_stream()
+                    side = torch.cuda.Stream(dev)
+                    side.wait_stream(cur)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        graph.capture_begin(capture_error_mode="thread_local")
+                        token_step()
+                        graph.capture_end()
+                    cur.wait_stream(side)
+                    for _ in range(L - 1):
+                        graph.replay()
+                else:
+                    for _ in range(L - 1):
+                        token_step()
         return outs, None
 
     def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, n_active=None):
@@ -317,7 +375,7 @@ class Net(nn.Module):
             out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
         return out, None, None, enc_out
 
-    def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale):
+    def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None):
         """log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
         owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).  The hypotheses go through the decoder sorted by
         length so that step t only runs on those that still have a token (sum of lengths instead of count x longest),
@@ -341,7 +399,10 @@ class Net(nn.Module):
         n_active = (ntok[perm][None, :] > np.arange(L)[:, None]).sum(1)      # (L,), non-increasing
         tok_d = torch.from_numpy(tok).to(dev)
         own = owner[torch.from_numpy(perm).to(owner.device)]
+        _tick = _tick or (lambda name: None)
+        _tick("host prep")
         out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, n_active=n_active)
+        _tick("token loop (%d tokens, %d hypotheses, %d pairs)" % (L, n, int(n_active.sum())))
         # the pairs (t, col) with col < n_active[t], step-major
         tt = np.repeat(np.arange(L), n_active)
         cc = np.concatenate([np.arange(k) for k in n_active])
@@ -350,9 +411,11 @@ class Net(nn.Module):
         want = torch.from_numpy(tgt[tt, cc]).to(dev).clamp(max=logp.shape[1] - 1)
         picked = np.zeros((L, n), dtype=np.float32)
         picked[tt, cc] = logp.gather(1, want.unsqueeze(1)).squeeze(1).cpu().numpy()
+        _tick("vocabulary projection + log-softmax + gather")
         res = [None] * n
         for col, i in enumerate(perm):
             res[i] = picked[:ntok[i], col].tolist()
+        _tick("host lists")
         return res
 
     @torch.no_grad()
@@ -377,10 +440,12 @@ class Net(nn.Module):
         order = torch.argsort(lens, descending=True, stable=True)          # packed sequences want sorted lengths
         inv = torch.empty_like(order)
         inv[order] = torch.arange(B)
+        _tick = _phase_timer(self, dev)
         enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
+        _tick("encoder")
         owner = torch.tensor([inv[b].item() for b in range(B) for _ in hyps[b]], dtype=torch.long, device=dev)
         flat = [list(h) for b in range(B) for h in hyps[b]]
-        scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale)
+        scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick)
         res, i = [], 0
         for b in range(B):
             res.append(scores[i:i + len(hyps[b])])

@@ -31,7 +31,7 @@ def test_lstm_cell(hip_device, N, H):
     h2 = torch.full((N, 2 * H), -7.0, device=hip_device)
     with torch.cuda.device(hip_device):
         _lib.check(_lib.lib().pika_lstm_cell(gates.data_ptr(), gates.stride(0), c.data_ptr(), c.data_ptr(), h1.data_ptr(),
-                                             h1.stride(0), h2[:, H:].data_ptr(), h2.stride(0), N, H,
+                                             h1.stride(0), h2[:, H:].data_ptr(), h2.stride(0), N, H, None,
                                              torch.cuda.current_stream().cuda_stream), "pika_lstm_cell")
     assert (c.double() - c_ref).abs().max() < 2e-6 * max(1.0, c_ref.abs().max().item())
     assert (h1[:, :H].double() - h_ref).abs().max() < 2e-6 and torch.equal(h1[:, :H], h2[:, H:])
@@ -61,7 +61,7 @@ def test_mlp_attention(hip_device, B, S, D, nper):
     with torch.cuda.device(hip_device):
         _lib.check(_lib.lib().pika_las_mlp_attention(dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(),
                                                      dev[3].data_ptr(), dev[4].data_ptr(), None, dev[5].data_ptr(),
-                                                     out.data_ptr(), 2 * D, a_out.data_ptr(), N, B, S, D,
+                                                     out.data_ptr(), 2 * D, a_out.data_ptr(), N, B, S, D, None, None,
                                                      torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention")
     assert (a_out.double().cpu() - a_ref).abs().max() < 2e-6
     assert (out[:, :D].double().cpu() - c_ref).abs().max() < 1e-5
@@ -73,7 +73,7 @@ def test_mlp_attention(hip_device, B, S, D, nper):
         qd = pick.to(hip_device)
         _lib.check(_lib.lib().pika_las_mlp_attention(dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(),
                                                      dev[3].data_ptr(), dev[4].data_ptr(), qd.data_ptr(), dev[5].data_ptr(),
-                                                     out2.data_ptr(), D, None, pick.numel(), B, S, D,
+                                                     out2.data_ptr(), D, None, pick.numel(), B, S, D, None, None,
                                                      torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention")
     sel = pick.long()
     assert (out2[sel].double().cpu() - c_ref[sel]).abs().max() < 1e-5
