@@ -190,6 +190,9 @@ def run_train_step(args, R_, steps, warmup):
     B, T, U, V = args.batch, args.frames, args.labels, args.vocab
     step, flops_per_utt = train_step_workload(args, R_)
     try:
+        # untimed: the caller's warmup steps, and with the captured launch mode at least the two eager steps + the step
+        # that captures the graph (the capture itself costs ~25 ms and belongs to no step)
+        warmup = max(warmup, 3) if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0" else warmup
         for _ in range(warmup):
             step()
         if step.bmuf is not None:
