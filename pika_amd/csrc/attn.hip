@@ -444,7 +444,7 @@ __global__ __launch_bounds__(THREADS) void attn_delta_kernel(Args A, float *delt
     }
 }
 
-template <int D, typename T_>
+template <int D, typename T_, bool MASK>
 __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     const T_ *Aq = static_cast<const T_ *>(A.q), *Ak = static_cast<const T_ *>(A.k), *Av = static_cast<const T_ *>(A.v);
     const T_ *Ado = static_cast<const T_ *>(A.dout);
@@ -488,7 +488,9 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb + kt * 16 + g * 4 + r;
-                    if (A.mask && key < T && A.mask[((long long)b * T + min(qrow, T - 1)) * T + key]) sa[r] = MASKED;
+                    if constexpr (MASK) {      // a separate instantiation: these kernels are bound by VALU issue
+                        if (key < T && A.mask[((long long)b * T + min(qrow, T - 1)) * T + key]) sa[r] = MASKED;
+                    }
                     const float p = key < T ? ex2(sa[r] - lse) : 0.f;
                     const float d = keep_if(dp[r] * A.inv_keep, s2 == 0 ? kw0 : kw1, half * 16 + r);
                     ds[r] = p * (d - delta);
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
     }
 }
 
-template <int D, typename T_>
+template <int D, typename T_, bool MASK>
 __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     const T_ *Aq = static_cast<const T_ *>(A.q), *Ak = static_cast<const T_ *>(A.k), *Av = static_cast<const T_ *>(A.v);
     const T_ *Ado = static_cast<const T_ *>(A.dout);
@@ -560,7 +562,9 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qt * 16 + g * 4 + r;
-                    if (A.mask && qb + qi < T && A.mask[((long long)b * T + qb + qi) * T + min(krow, T - 1)]) sa[r] = MASKED;
+                    if constexpr (MASK) {
+                        if (qb + qi < T && A.mask[((long long)b * T + qb + qi) * T + min(krow, T - 1)]) sa[r] = MASKED;
+                    }
                     const float p = ex2(sa[r] - lse_s[qi]);
                     // this lane's key is bit (krow & 63) of the query's keep word: the half that holds it, then one
                     // sign-extended bit field as an AND mask for both products
@@ -638,8 +642,13 @@ void launch_fwd(const Args &A, dim3 grid, hipStream_t s) {
 template <int D, typename T_>
 void launch_bwd(const Args &A, dim3 grid, int rows, float *delta, hipStream_t s) {
     hipLaunchKernelGGL((attn_delta_kernel<D, T_>), dim3((unsigned)rows), dim3(THREADS), 0, s, A, delta);
-    hipLaunchKernelGGL((attn_bwd_kv_kernel<D, T_>), grid, dim3(THREADS), 0, s, A);
-    hipLaunchKernelGGL((attn_bwd_q_kernel<D, T_>), grid, dim3(THREADS), 0, s, A);
+    if (A.mask) {
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<D, T_, true>), grid, dim3(THREADS), 0, s, A);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<D, T_, true>), grid, dim3(THREADS), 0, s, A);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<D, T_, false>), grid, dim3(THREADS), 0, s, A);
+        hipLaunchKernelGGL((attn_bwd_q_kernel<D, T_, false>), grid, dim3(THREADS), 0, s, A);
+    }
 }
 
 }  // namespace
