@@ -32,9 +32,11 @@
 extern "C" {
 #endif
 
-/* mask: NULL, or (B, T, T) bytes shared by the heads of a batch element: non-zero = the score of (query row, key
- * column) is replaced by -1e18 before the softmax (multi_headed_attn.py:215-217; the prediction network's causal +
- * padding mask, rnnt_conv_transformer_lm.py:65-69).  The backward must be given the same mask. */
+/* mask: NULL, or the PACKED attention mask of pika_attention_mask_bits, u64 [B][T][ceil(T/64)], shared by the heads of a
+ * batch element: bit (key & 63) of word key >> 6 of query row q set = the score of (q, key) is replaced by -1e18 before
+ * the softmax (multi_headed_attn.py:215-217; the prediction network's causal + padding mask,
+ * rnnt_conv_transformer_lm.py:65-69).  One 8-byte word per query row and 64 keys, read exactly as the dropout keep
+ * bits are.  The backward must be given the same mask. */
 int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
                        void *keep_bits, const void *mask, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
@@ -54,6 +56,9 @@ int pika_attention_bwd(const void *q, const void *k, const void *v, const void *
                        int io_dtype, const float *lse, const void *keep_bits, const void *mask, float *delta, void *dq,
                        void *dk, void *dv, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream);
+
+/* bits u64 [B][T][ceil(T/64)] from a byte mask (B, T, T) (non-zero = masked). */
+int pika_attention_mask_bits(const unsigned char *mask, int B, int T, void *bits, void *stream);
 
 /* mask (B*H, T, T) u8: 1 where the probability of (query row, key column) is kept. */
 int pika_attention_keep_mask(unsigned char *mask, int BH, int T, float p_drop, unsigned seed,

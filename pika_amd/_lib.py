@@ -52,6 +52,7 @@ SIGNATURES = {
     "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
                                 ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_attention_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_attention_mask_bits": (_i, [_vp, _i, _i, _vp, _vp]),
     # include/pika_ops.h
     "pika_transpose_cast": (_i, [_vp, _i, _i, _vp, _ll, _i, _vp]),
     "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp]),

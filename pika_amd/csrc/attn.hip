@@ -177,7 +177,8 @@ struct Args {
     uint32_t seed, thr;
     const uint64_t *bits;   // keep bits [b*H+h][query][ceil(T/64)] (dropout only)
     int nkb;
-    const unsigned char *mask;   // optional (B, T, T) bytes, non-zero = score masked to -1e18 (multi_headed_attn.py:217)
+    const uint64_t *mask;        // optional packed mask [b][query][ceil(T/64)]: bit (key & 63) of word key >> 6 set = the
+                                 // score is masked to -1e18 (multi_headed_attn.py:217); pika_attention_mask_bits packs it
     long long lo_off, olo_off;   // two-term forward: element offset of the "lo" planes of q/k/v and of out
 };
 
@@ -215,15 +216,13 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(Args A) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) s[kt] = mfma(frag_n<P>(Ks, kt * 16, ks * 32, lane), qf[ks], s[kt]);
         }
-        if (A.mask) {
-            const unsigned char *mrow = A.mask + ((long long)b * T + min(qrow, T - 1)) * T;
+        if (A.mask) {      // one 8-byte word per query row and key tile, as the dropout keep bits
+            const uint64_t mw = A.mask[((long long)b * T + min(qrow, T - 1)) * A.nkb + (kb >> 6)] >> (g * 4);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kb + kt * 16 + g * 4 + r;
-                    if (key < T && mrow[key]) s[kt][r] = MASKED;
-                }
+                for (int r = 0; r < 4; ++r)
+                    if ((mw >> (kt * 16 + r)) & 1ull) s[kt][r] = MASKED;
         }
         if (kb + TILE > T) {
 #pragma unroll
@@ -322,7 +321,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd2_kernel(Args A) {
         row_frags2<D>(qh, ql, qp, qp + A.lo_off, g, A.qscale);
     }
     const uint64_t *bits = A.bits + ((long long)bh * T + min(qrow, T - 1)) * A.nkb;
-    const unsigned char *mrow = A.mask ? A.mask + ((long long)b * T + min(qrow, T - 1)) * T : nullptr;
+    const uint64_t *mrow = A.mask ? A.mask + ((long long)b * T + min(qrow, T - 1)) * A.nkb : nullptr;
     f32x4 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -347,13 +346,12 @@ __global__ __launch_bounds__(THREADS) void attn_fwd2_kernel(Args A) {
             }
         }
         if (mrow) {
+            const uint64_t mw = mrow[kb >> 6] >> (g * 4);
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kb + kt * 16 + g * 4 + r;
-                    if (key < T && mrow[key]) s[kt][r] = MASKED;
-                }
+                for (int r = 0; r < 4; ++r)
+                    if ((mw >> (kt * 16 + r)) & 1ull) s[kt][r] = MASKED;
         }
         if (kb + TILE > T) {
 #pragma unroll
@@ -472,6 +470,8 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
         __syncthreads();
         const uint64_t kw = A.thr ? (bits[kb >> 6] >> (g * 4)) : ~0ull;
         const uint32_t kw0 = (uint32_t)kw, kw1 = (uint32_t)(kw >> 32);
+        [[maybe_unused]] uint64_t mw = 0;
+        if constexpr (MASK) mw = A.mask[((long long)b * T + min(qrow, T - 1)) * A.nkb + (kb >> 6)] >> (g * 4);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             uint32_t dsw[4];
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_q_kernel(Args A) {
                 for (int r = 0; r < 4; ++r) {
                     const int key = kb + kt * 16 + g * 4 + r;
                     if constexpr (MASK) {      // a separate instantiation: these kernels are bound by VALU issue
-                        if (key < T && A.mask[((long long)b * T + min(qrow, T - 1)) * T + key]) sa[r] = MASKED;
+                        if ((mw >> (kt * 16 + r)) & 1ull) sa[r] = MASKED;
                     }
                     const float p = key < T ? ex2(sa[r] - lse) : 0.f;
                     const float d = keep_if(dp[r] * A.inv_keep, s2 == 0 ? kw0 : kw1, half * 16 + r);
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
     __shared__ __attribute__((aligned(16))) __bf16 Os[TILE * P];
     __shared__ float lse_s[TILE], delta_s[TILE];
     __shared__ uint32_t wlo_s[TILE], whi_s[TILE];     // the two halves of every query's keep word for this key block
+    __shared__ uint32_t mlo_s[TILE], mhi_s[TILE];     // ... and of its mask word (MASK)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const int T = A.T, h = blockIdx.y, b = blockIdx.z;
     const int krow = blockIdx.x * TILE + wave * 16 + (lane & 15);
@@ -544,6 +545,11 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
             const uint64_t w64 = (A.thr && qi < T) ? A.bits[((long long)bh * T + qi) * A.nkb + blockIdx.x] : ~0ull;
             wlo_s[threadIdx.x] = (uint32_t)w64;
             whi_s[threadIdx.x] = (uint32_t)(w64 >> 32);
+            if constexpr (MASK) {
+                const uint64_t m64 = qi < T ? A.mask[((long long)b * T + qi) * A.nkb + blockIdx.x] : 0ull;
+                mlo_s[threadIdx.x] = (uint32_t)m64;
+                mhi_s[threadIdx.x] = (uint32_t)(m64 >> 32);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_kv_kernel(Args A) {
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qt * 16 + g * 4 + r;
                     if constexpr (MASK) {
-                        if (qb + qi < T && A.mask[((long long)b * T + qb + qi) * T + min(krow, T - 1)]) sa[r] = MASKED;
+                        if (((kbit_hi ? mhi_s[qi] : mlo_s[qi]) >> kbit) & 1u) sa[r] = MASKED;
                     }
                     const float p = ex2(sa[r] - lse_s[qi]);
                     // this lane's key is bit (krow & 63) of the query's keep word: the half that holds it, then one
@@ -606,6 +612,20 @@ __global__ __launch_bounds__(THREADS) void keep_bits_kernel(uint64_t *bits, long
     if (idx >= rows * nkb) return;
     const long long row = idx / nkb;
     bits[idx] = keep_word(row_hash(seed, (uint32_t)row), (uint32_t)(idx - row * nkb), thr);
+}
+
+// packed attention mask: bits[(b*T + q)*nkb + w] bit j = mask[b][q][w*64 + j] != 0 (keys beyond T: clear)
+__global__ __launch_bounds__(THREADS) void mask_bits_kernel(const unsigned char *__restrict__ mask, uint64_t *__restrict__ bits,
+                                                            long long rows, int T, int nkb) {
+    const long long idx = (long long)blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= rows * nkb) return;
+    const long long row = idx / nkb;
+    const int w = (int)(idx - row * nkb);
+    const unsigned char *m = mask + row * T + (long long)w * 64;
+    uint64_t v = 0;
+    const int n = min(64, T - w * 64);
+    for (int j = 0; j < n; ++j) v |= (uint64_t)(m[j] != 0) << j;
+    bits[idx] = v;
 }
 
 __global__ __launch_bounds__(THREADS) void keep_mask_kernel(unsigned char *mask, long long rows, int T,
@@ -656,7 +676,7 @@ void launch_bwd(const Args &A, dim3 grid, int rows, float *delta, hipStream_t s)
 extern "C" {
 
 static int attention_fwd_impl(const void *q, const void *k, const void *v, void *out, int io_dtype, float *lse,
-                              void *keep_bits, const unsigned char *mask, long long lo_off, long long olo_off, int B, int T,
+                              void *keep_bits, const uint64_t *mask, long long lo_off, long long olo_off, int B, int T,
                               int H, int D, long long ld, long long ldo, float p_drop, unsigned seed, void *stream) {
     if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16 && io_dtype != -2) return PIKA_EINVAL;
     const bool two_term = io_dtype == -2;
@@ -704,14 +724,14 @@ int pika_attention_fwd(const void *q, const void *k, const void *v, void *out, i
                        void *keep_bits, const void *mask, int B, int T, int H, int D, long long ld, long long ldo,
                        float p_drop, unsigned seed, void *stream) {
     if (io_dtype != PIKA_F32 && io_dtype != PIKA_BF16) return PIKA_EINVAL;
-    return attention_fwd_impl(q, k, v, out, io_dtype, lse, keep_bits, static_cast<const unsigned char *>(mask), 0, 0, B, T, H,
+    return attention_fwd_impl(q, k, v, out, io_dtype, lse, keep_bits, static_cast<const uint64_t *>(mask), 0, 0, B, T, H,
                               D, ld, ldo, p_drop, seed, stream);
 }
 
 int pika_attention_fwd_two_term(const void *q, const void *k, const void *v, long long lo_off, void *out,
                                 long long out_lo_off, float *lse, void *keep_bits, const void *mask, int B, int T,
                                 int H, int D, long long ld, long long ldo, float p_drop, unsigned seed, void *stream) {
-    return attention_fwd_impl(q, k, v, out, -2, lse, keep_bits, static_cast<const unsigned char *>(mask), lo_off, out_lo_off,
+    return attention_fwd_impl(q, k, v, out, -2, lse, keep_bits, static_cast<const uint64_t *>(mask), lo_off, out_lo_off,
                               B, T, H, D, ld, ldo, p_drop, seed, stream);
 }
 
@@ -729,7 +749,7 @@ int pika_attention_bwd(const void *q, const void *k, const void *v, const void *
     A.q = q; A.k = k; A.v = v; A.out = out; A.dout = dout; A.lse = lse; A.delta = delta;
     A.dq = dq; A.dk = dk; A.dv = dv; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
     A.qscale = 1.4426950408889634f / sqrtf((float)D);
-    A.mask = static_cast<const unsigned char *>(mask);
+    A.mask = static_cast<const uint64_t *>(mask);
     dropout_consts(A, p_drop, seed);
     A.nkb = (T + 63) / 64;
     if (A.thr) {
@@ -743,6 +763,15 @@ int pika_attention_bwd(const void *q, const void *k, const void *v, const void *
     } else {
         if (D == 64) launch_bwd<64, __bf16>(A, grid, B * T, delta, s); else launch_bwd<128, __bf16>(A, grid, B * T, delta, s);
     }
+    return (int)hipGetLastError();
+}
+
+int pika_attention_mask_bits(const unsigned char *mask, int B, int T, void *bits, void *stream) {
+    if (!mask || !bits || B <= 0 || T <= 0 || (reinterpret_cast<uintptr_t>(bits) & 7)) return PIKA_EINVAL;
+    const int nkb = (T + 63) / 64;
+    const long long words = (long long)B * T * nkb;
+    hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)((words + THREADS - 1) / THREADS)), dim3(THREADS), 0,
+                       static_cast<hipStream_t>(stream), mask, static_cast<uint64_t *>(bits), (long long)B * T, T, nkb);
     return (int)hipGetLastError();
 }
 

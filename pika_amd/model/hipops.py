@@ -610,8 +610,18 @@ def attention_keep_mask(BH, T, p_drop, seed, device):
 
 
 def _mask_bytes(mask):
-    """(B, Tq, Tk) uint8 copy of a boolean attention mask (non-zero = masked), or None."""
-    return None if mask is None else mask.to(torch.uint8).contiguous()
+    """The packed form the attention kernels read (include/pika_attn.h: u64 [B][T][ceil(T/64)], bit set = masked) of a
+    boolean (B, T, T) attention mask, or None."""
+    if mask is None:
+        return None
+    B, T, Tk = mask.shape
+    assert T == Tk
+    m8 = mask.to(torch.uint8).contiguous()
+    bits = torch.empty((B, T, (T + 63) // 64), dtype=torch.int64, device=mask.device)
+    with torch.cuda.device(mask.device):
+        _lib.check(_lib.lib().pika_attention_mask_bits(m8.data_ptr(), B, T, bits.data_ptr(), _stream()),
+                   "pika_attention_mask_bits")
+    return bits
 
 
 def _attn_fwd(q, k, v, out, lse, B, T, heads, D, ld, p_drop, seed, mask=None, lo_off=None, out_lo_off=0):
