@@ -1038,7 +1038,8 @@ def main():
                 "metric": "utterances/sec MBR train step (T_in=%d,U=%d,V=%d)" % (T, U, V), "value": B * world / el,
                 "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16", "data": "synthetic",
+                "dtype": "N-best search: bf16 operands; training part: %s" % __import__("pika_amd.gemm", fromlist=["x"]).PRECISION,
+                "data": "synthetic",
                 "config": {"workload": "mbr_step (BASELINE configs[3] / SURVEY 8d M4): N-best decode (beam %d) + encoder "
                                        "fwd + RNN-T loss bwd + risk terms + trajectory joint with the HIP risk-gradient "
                                        "kernel + clip + SGD, full config-2 model" % args.beam,

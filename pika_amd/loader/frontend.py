@@ -112,6 +112,8 @@ class GpuFrontEnd(object):
         self.batch_no = 0
         self._ring = [None] * max(int(ring), 1)     # [pinned uint8 tensor, event of its last upload]
         self._slot = 0
+        self._ring_small = [None] * (2 * max(int(ring), 1))   # the same for the batch's label / length arrays
+        self._slot_small = 0
         self.stream = torch.cuda.Stream(device) if side_stream else None
         self.ready = None                           # event behind the last batch's kernels
         self.host_seconds, self.batches = 0.0, 0    # host time spent inside __call__ (staging + launches)
@@ -129,9 +131,48 @@ class GpuFrontEnd(object):
             ent[1].synchronize()        # only blocks when the device is a whole ring behind
         if ent is None or ent[0].numel() < nbytes:
             cap = max(int(nbytes * 1.25), 1 << 16)
-            ent = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
+            # blocking=True: a loader thread that is a whole ring ahead SLEEPS on the event instead of spinning on a core
+            # the eight ranks of a node share
+            ent = [torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.cuda.Event(blocking=True)]
             self._ring[i] = ent
         return ent
+
+    def upload_int32(self, arrays):
+        """The batch's small integer arrays (padded targets, frame and label lengths) as device tensors: packed into ONE
+        pinned buffer of a ring, ONE asynchronous copy on the front end's stream, covered by `ready` -- the training
+        thread then has no synchronous host-to-device copy left (a pageable `.cuda()` waits, spinning, for everything
+        queued before it: 40 ms of CPU per step).  Returns int32 device tensors shaped like the inputs."""
+        arrays = [np.ascontiguousarray(a, dtype=np.int32) for a in arrays]
+        sizes = [a.size for a in arrays]
+        total = max(sum(sizes), 1)
+        i = self._slot_small
+        self._slot_small = (i + 1) % len(self._ring_small)
+        ent = self._ring_small[i]
+        if ent is not None:
+            ent[1].synchronize()
+        if ent is None or ent[0].numel() < total:
+            ent = [torch.empty(max(2 * total, 4096), dtype=torch.int32).pin_memory(), torch.cuda.Event(blocking=True)]
+            self._ring_small[i] = ent
+        host = ent[0].numpy()
+        off = 0
+        for a in arrays:
+            host[off:off + a.size] = a.reshape(-1)
+            off += a.size
+        dev = self.device
+        st_t = self.stream or torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev), torch.cuda.stream(st_t):
+            d = torch.empty(total, dtype=torch.int32, device=dev)
+            d.copy_(ent[0][:total], non_blocking=True)
+            ent[1].record(st_t)
+            if self.stream is not None:
+                self.ready = torch.cuda.Event()
+                self.ready.record(st_t)
+                d.record_stream(torch.cuda.current_stream(dev))
+        out, off = [], 0
+        for a, n in zip(arrays, sizes):
+            out.append(d[off:off + n].view(a.shape))
+            off += n
+        return out
 
     def wait_ready(self, stream=None):
         """Make `stream` (default: the current one) wait for the last batch; no host wait."""

@@ -107,8 +107,8 @@ def assemble(batch, frontend, args):
     target = np.full((len(batch), umax), args.padding_tgt, np.int32)
     for i, a in enumerate(alis):
         target[i, :len(a)] = a
+    st = getattr(frontend, "stream", None)
     if not args.batch_first:
-        st = getattr(frontend, "stream", None)
         if st is not None:
             # the feature kernels were issued on the front end's own stream: the transposing copy must run behind them
             # on THAT stream, and `ready` must cover it (the consumer only waits on the event)
@@ -119,8 +119,14 @@ def assemble(batch, frontend, args):
         else:
             data = data.transpose(0, 1).contiguous()
         target = target.T.copy()
-    return (data, torch.from_numpy(target), torch.tensor(lens, dtype=torch.int32),
-            torch.tensor([len(a) for a in alis], dtype=torch.int32))
+    ali_lens = np.array([len(a) for a in alis], np.int32)
+    if st is not None and getattr(args, "device_targets", True):
+        # targets and lengths travel with the batch (one pinned upload on the front end's stream): the script's own
+        # `.cuda(local_rank)` on them (train_transducer_bmuf_otfaug.py:79-85) is then a no-op instead of three
+        # synchronous copies per step
+        t_d, l_d, a_d = frontend.upload_int32([target, np.asarray(lens, np.int32), ali_lens])
+        return data, t_d, l_d, a_d
+    return (data, torch.from_numpy(target), torch.tensor(lens, dtype=torch.int32), torch.from_numpy(ali_lens))
 
 
 class DevicePrefetcher(object):
