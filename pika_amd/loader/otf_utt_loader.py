@@ -169,8 +169,9 @@ class DevicePrefetcher(object):
                 raise batch
             if ready is not None:
                 torch.cuda.current_stream(self.frontend.device).wait_event(ready)
-                if batch[0] is not None:
-                    batch[0].record_stream(torch.cuda.current_stream(self.frontend.device))
+                for t in batch:
+                    if t is not None and t.is_cuda:
+                        t.record_stream(torch.cuda.current_stream(self.frontend.device))
             yield batch
         self.thread.join()
 

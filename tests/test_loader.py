@@ -127,6 +127,9 @@ def test_otf_loader_end_to_end_matches_oracle(hip_device, tmp_path):
     for data, tgt, lens, alens in got:
         assert data.is_cuda and data.shape[2] == L.get_inputdim(args) == 240
         d = data.cpu().numpy()
+        # targets and lengths arrive on the device with the batch (the script's `.cuda()` on them is a no-op)
+        assert tgt.is_cuda and lens.is_cuda and alens.is_cuda and tgt.dtype == lens.dtype == alens.dtype == torch.int32
+        tgt, lens, alens = tgt.cpu(), lens.cpu(), alens.cpu()
         for b in range(3):
             spr, db = draws[i]
             wav = F.perturb(pcms[i], spr, db).astype(np.float64)
