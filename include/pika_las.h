@@ -56,6 +56,29 @@ int pika_las_step_advance(int *step, const int *n_active, const int *qoffs, int 
 int pika_las_embed_rows(const int *step, const long long *tokens, const float *emb, float *x0, long long ldx,
                         long long *crow, int N, int E, void *stream);
 
+/* The rescorer's encoder: one (bi)directional nn.LSTM layer over a padded batch of packed sequences
+ * (/root/reference/trainer/model/las.py:44-75: pack_padded_sequence -> nn.LSTM -> pad_packed_sequence), the whole
+ * recurrence as ONE persistent launch (pika_amd/csrc/blstm.hip).  D directions (1 or 2: [forward, reverse]), hidden size
+ * H per direction (H % 128 == 0, H <= 512), B utterances of lens[b] <= S valid positions.
+ *   pika_blstm_pack: w_hh (D, 4H, H) f32 = weight_hh_l{k}[_reverse], gate order [i | f | g | o] -> `packed`
+ *     (pika_blstm_packed_bytes(D, H) bytes, 16-byte aligned): two bf16 terms in MFMA fragment order.
+ *   pika_blstm_layer: gx (S, B, D*4H) f32 = W_ih x_t + b_ih + b_hh of every position and direction (the caller's GEMM);
+ *     out (S, B, D*H) f32 = the layer's output, zeros at positions >= lens[b] (fully written); h_n, c_n (D, B, H) f32 =
+ *     the state after each sequence's last position (forward) / first position (reverse).  Recurrent products:
+ *     hi.hi + lo.hi + hi.lo over bf16 terms of h and W_hh with fp32 accumulation (an fp32 product to ~2^-17).
+ *     work: pika_blstm_work_bytes(S, B, D, H) bytes of device scratch (16-byte aligned; one 16 x H word slot per step and
+ *     (direction, 16-row block): 65 MB at S = 250, B = 64, H = 512), no initialisation needed.
+ *     The D * ceil(B/16) * H/16 workgroups of the launch exchange hidden states inside the kernel, so all of them must
+ *     be resident: PIKA_ETOOBIG when the device has fewer CUs (the caller falls back to its library LSTM).
+ *   pika_blstm_status: synchronises the stream and returns the launch's error word in *host_out (non-zero: a workgroup
+ *     gave up waiting for its peers after ~2 s, the outputs are invalid). */
+long long pika_blstm_packed_bytes(int D, int H);
+long long pika_blstm_work_bytes(int S, int B, int D, int H);
+int pika_blstm_pack(const float *w_hh, int D, int H, void *packed, void *stream);
+int pika_blstm_layer(const float *gx, const void *w_packed, const int *lens, float *out, float *h_n, float *c_n,
+                     void *work, long long work_bytes, int S, int B, int D, int H, void *stream);
+int pika_blstm_status(const void *work, int *host_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

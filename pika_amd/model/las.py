@@ -46,7 +46,83 @@ class LASRNNEncoder(nn.Module):
         self.rnn = nn.LSTM(input_size=input_dim, hidden_size=hidden_size // dirs, num_layers=num_layers,
                            dropout=dropout, bidirectional=bidirectional)
 
+    def _fused_ok(self, input, lengths, hidden):
+        """The persistent-kernel path (include/pika_las.h: pika_blstm_layer): inference on a HIP device, fp32, zero
+        initial state, hidden size per direction a multiple of 128 up to 512.  PIKA_LAS_BLSTM=0 keeps nn.LSTM."""
+        r = self.rnn
+        return (input.is_cuda and lengths is not None and hidden is None and not torch.is_grad_enabled()
+                and not self.training and input.dtype == torch.float32 and input.dim() == 3 and r.bias
+                and not r.batch_first and r.proj_size == 0 and r.hidden_size % 128 == 0 and r.hidden_size <= 512
+                and r.input_size % 8 == 0 and os.environ.get("PIKA_LAS_BLSTM", "1") != "0")
+
+    def _forward_fused(self, input, lengths):
+        """nn.LSTM over pack_padded_sequence(input, lengths) -> pad_packed_sequence, per layer: the input projections of
+        every position and both directions as ONE GEMM (exact products), then the recurrence of both directions as ONE
+        persistent launch whose workgroups keep their slice of W_hh in registers (pika_amd/csrc/blstm.hip)."""
+        import ctypes
+        from .. import _lib
+        from .. import gemm as G
+        lib = _lib.lib()
+        r = self.rnn
+        dev = input.device
+        D, H = (2 if r.bidirectional else 1), r.hidden_size
+        S, B, _ = input.shape
+        lens_h = torch.as_tensor(lengths).view(-1).to(torch.int64).cpu()
+        s_out = int(lens_h.max())
+        lens_d = lens_h.to(device=dev, dtype=torch.int32)
+        x = input[:s_out].contiguous()
+        S = s_out
+        hs, cs = [], []
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            wbytes = lib.pika_blstm_work_bytes(S, B, D, H)
+            if wbytes < 0:
+                return None
+            work = torch.empty(int(wbytes), dtype=torch.uint8, device=dev)
+            for k in range(r.num_layers):
+                sfx = ["", "_reverse"][:D]
+                w_ih = torch.cat([getattr(r, "weight_ih_l%d%s" % (k, s)).detach() for s in sfx], 0).float().contiguous()
+                w_hh = torch.stack([getattr(r, "weight_hh_l%d%s" % (k, s)).detach() for s in sfx], 0).float().contiguous()
+                bias = torch.cat([(getattr(r, "bias_ih_l%d%s" % (k, s)) + getattr(r, "bias_hh_l%d%s" % (k, s))).detach()
+                                  for s in sfx], 0).float().contiguous()
+                packed = torch.empty(int(lib.pika_blstm_packed_bytes(D, H)), dtype=torch.uint8, device=dev)
+                _lib.check(lib.pika_blstm_pack(w_hh.data_ptr(), D, H, packed.data_ptr(), st), "pika_blstm_pack")
+                gx = G.gemm_nt(x.view(S * B, x.shape[2]), w_ih, bias=bias, precision="fp32")       # (S*B, D*4H)
+                out = torch.empty((S, B, D * H), device=dev)
+                h_n, c_n = torch.empty((D, B, H), device=dev), torch.empty((D, B, H), device=dev)
+                rc = lib.pika_blstm_layer(gx.data_ptr(), packed.data_ptr(), lens_d.data_ptr(), out.data_ptr(),
+                                          h_n.data_ptr(), c_n.data_ptr(), work.data_ptr(), int(wbytes), S, B, D, H, st)
+                if rc == -2 and k == 0:          # PIKA_ETOOBIG: more workgroups than CUs (the grid must be resident)
+                    return None
+                _lib.check(rc, "pika_blstm_layer(S=%d,B=%d,D=%d,H=%d)" % (S, B, D, H))
+                hs.append(h_n)
+                cs.append(c_n)
+                x = out
+                failed = work[:4].view(torch.int32).clone() if k == 0 else failed | work[:4].view(torch.int32)
+            # the launch's error word (a workgroup gave up waiting for its peers: the grid was not resident) travels to
+            # a pinned word behind the last layer; check_status() -- called where the caller synchronises anyway -- reads it
+            if self._status is None:
+                self._status = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+            word, ev = self._status
+            word.copy_(failed, non_blocking=True)
+            ev.record()
+        return (torch.cat(hs, 0), torch.cat(cs, 0)), x
+
+    _status = None
+
+    def check_status(self):
+        """Raises if the last persistent-kernel pass did not complete (blocks until that pass has finished)."""
+        if self._status is not None:
+            word, ev = self._status
+            ev.synchronize()
+            if int(word[0]):
+                raise RuntimeError("pika_blstm_layer: workgroups gave up waiting for their peers (grid not resident)")
+
     def forward(self, input, lengths=None, hidden=None):
+        if self._fused_ok(input, lengths, hidden):
+            res = self._forward_fused(input, lengths)
+            if res is not None:
+                return res
         packed = input
         if lengths is not None:
             packed = pack_padded_sequence(input, lengths.view(-1).tolist(), enforce_sorted=False)
@@ -189,10 +265,13 @@ class InputFeedRNNDecoder(nn.Module):
             stream = torch.cuda.current_stream().cuda_stream
             h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
             ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
-            proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous()).view(B, S, H)
+            # "mixed" is a training arithmetic (bf16 backward): a scoring pass under it runs its forward grade, i.e. exact
+            infer = "fp32" if G.PRECISION == "mixed" else None
+            proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous(),
+                             precision=infer).view(B, S, H)
             own = owner.to(device=dev, dtype=torch.int32).contiguous()
             ln = lens.to(device=dev, dtype=torch.int32).contiguous()
-            half = G.PRECISION in ("bf16", "mixed")
+            half = G.PRECISION == "bf16"
             # weights packed once per pass into MFMA fragment order (pika_dpack_weight): 1 bf16 term per operand in the
             # bf16 arithmetic mode, 3 (fp32-exact products) otherwise
             from ..decoder.fused_step import DGemm, PackedWeight
@@ -425,8 +504,10 @@ class Net(nn.Module):
         lens = torch.tensor([src.shape[0]], dtype=torch.int32)
         enc_hidden, enc_out = self.encoder(src, lens)
         owner = torch.zeros(len(hyps), dtype=torch.long, device=src.device)
-        return self._score_flat(enc_out, enc_hidden, owner, torch.tensor([enc_out.shape[0]], device=src.device),
-                                [list(h) for h in hyps], sos, eos, scale)
+        res = self._score_flat(enc_out, enc_hidden, owner, torch.tensor([enc_out.shape[0]], device=src.device),
+                               [list(h) for h in hyps], sos, eos, scale)
+        self.encoder.check_status()
+        return res
 
     @torch.no_grad()
     def score_nbest_batch(self, src, lengths, hyps, sos, eos, scale=1.0):
@@ -446,6 +527,7 @@ class Net(nn.Module):
         owner = torch.tensor([inv[b].item() for b in range(B) for _ in hyps[b]], dtype=torch.long, device=dev)
         flat = [list(h) for b in range(B) for h in hyps[b]]
         scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick)
+        self.encoder.check_status()
         res, i = [], 0
         for b in range(B):
             res.append(scores[i:i + len(hyps[b])])

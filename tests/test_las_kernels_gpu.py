@@ -112,3 +112,40 @@ def test_fused_scoring_pass_equals_the_op_by_op_pass(hip_device, monkeypatch):
             assert np.allclose(x, y, rtol=2e-5, atol=2e-5)
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("S,B,D,H,In,layers", [(9, 5, 2, 128, 64, 1), (40, 37, 2, 512, 256, 2), (25, 16, 1, 256, 128, 2),
+                                               (12, 64, 2, 384, 64, 1)])
+def test_blstm_encoder_matches_nn_lstm(hip_device, monkeypatch, S, B, D, H, In, layers):
+    """The persistent-kernel encoder (pika_blstm_layer: recurrent weights in registers, hidden states exchanged between
+    workgroups inside the launch) against torch's nn.LSTM over the same packed sequences in float64 on the CPU:
+    outputs (zeros at padded positions), final hidden and cell states of every layer and direction; ragged lengths,
+    a batch that does not fill its last 16-row block, an utterance of length 1."""
+    from pika_amd.model import las
+    torch.manual_seed(S * 1000 + B)
+    enc = las.LASRNNEncoder("LSTM", D == 2, layers, D * H, 0.0, In).eval()
+    for p in enc.parameters():                                   # recurrent gains well above the default 1/sqrt(H)
+        p.data.uniform_(-2.0 / H ** 0.5, 2.0 / H ** 0.5)
+    x = torch.randn(S, B, In)
+    lens = torch.randint(1, S + 1, (B,))
+    lens[0], lens[B // 2] = S, 1
+    ref = enc.double()
+    with torch.no_grad():
+        (h_ref, c_ref), out_ref = ref(x.double(), lens)
+    enc = enc.float().to(hip_device)
+    with torch.no_grad():
+        assert enc._fused_ok(x.to(hip_device), lens, None)
+        (h, c), out = enc(x.to(hip_device), lens)
+    enc.check_status()
+    assert out.shape == out_ref.shape and h.shape == h_ref.shape
+    for got, want, name in ((out, out_ref, "out"), (h, h_ref, "h_n"), (c, c_ref, "c_n")):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err < 2e-5 * max(1.0, want.abs().max().item()), (name, err)
+    pad = torch.arange(out.shape[0]).view(-1, 1) >= lens.view(1, -1)
+    assert bool((out.cpu()[pad] == 0).all())
+    # the library path (what PIKA_LAS_BLSTM=0 runs) agrees too
+    monkeypatch.setenv("PIKA_LAS_BLSTM", "0")
+    with torch.no_grad():
+        assert not enc._fused_ok(x.to(hip_device), lens, None)
+        (h2, c2), out2 = enc(x.to(hip_device), lens)
+    assert (out2 - out).abs().max().item() < 5e-5 and (h2 - h).abs().max().item() < 5e-5
