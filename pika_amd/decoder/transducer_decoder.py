@@ -50,20 +50,23 @@ class TransducerDecoder(object):
         self.incremental = True  # transformer prediction net: one new position per step (cached)
         # GPU, transformer prediction net: the whole step as a fixed launch chain (fused_step.py), replayed
         # `replays_per_sync` x 2 steps per host read of the stop flag.  decode_terms: bf16 terms per GEMM operand
-        # (3 = fp32-exact products, the parity mode; 1 = plain bf16 operands)
+        # (3 = fp32-exact products; 2 = hi.hi + hi.lo + lo.hi, an fp32 product to ~2^-17; 1 = plain bf16 operands)
         import os
         self.fused_search = os.environ.get("PIKA_DECODE_FUSED_SEARCH", "1") != "0"
-        # decode_precision "fp32" (default): encoder, joint halves and every step GEMM with fp32-exact products --
-        # what "hypotheses identical to the reference's fp32 decoder" needs; "bf16x3": the encoder and the joint halves
-        # (the only large products of a decode) with two bf16 terms per operand on the direct-to-LDS kernels (1e-5),
-        # the step GEMMs still exact; "bf16": plain bf16 operands everywhere
+        # decode_precision "fp32" (default): every product of the decode -- encoder, joint halves, step GEMMs, fc2 --
+        # with three bf16 terms per operand, six MFMA products (exact fp32 products): on the full-width golden every
+        # n-best entry separated from its neighbours by > 1e-3 in score sits at its reference rank, scores within 3e-4.
+        # "bf16x3": two bf16 terms per operand (hi.hi + hi.lo + lo.hi, an fp32 product to ~2^-17): 14 % less search
+        # time, top-1 and greedy hypotheses still identical to the reference's, but scores move by up to 2e-3 and one
+        # separated deep-rank entry of the golden swaps (tools/decode_two_term_check.py) -- an option, not the default.
+        # "bf16": plain bf16 operands.
         self.decode_precision = os.environ.get("PIKA_DECODE_PRECISION", "fp32")
         self.replays_per_sync = 4
         self.groups_in_flight = 3       # groups of replays queued ahead of the host's look at the stop flag
 
     @property
     def decode_terms(self):
-        return 1 if self.decode_precision == "bf16" else 3
+        return {"bf16": 1, "bf16x3": 2}.get(self.decode_precision, 3)
 
     # ---- prediction network stepping (fixed shapes: every row is recomputed, rows whose last
     # symbol is not a label keep their state; transducer_decoder.py:139-171) ---------------------

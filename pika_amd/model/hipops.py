@@ -211,7 +211,7 @@ class LinearFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.x_bf16 = x.dtype == torch.bfloat16
-        if _mixed() and K % 8 == 0 and (x_lo is not None or x.dtype == torch.float32):
+        if _mixed() and K % 8 == 0 and weight.shape[0] % 4 == 0 and (x_lo is not None or x.dtype == torch.float32):
             # two-term forward product: hi.hi + lo.hi + hi.lo over a three times longer reduction (gemm.pair_operand)
             N = weight.shape[0]
             with torch.cuda.device(x.device):
@@ -232,6 +232,8 @@ class LinearFn(torch.autograd.Function):
                 ctx.mark_non_differentiable(out.lo)
                 return out.hi, out.lo
             return out
+        if x_lo is not None:        # a two-plane input of a product the two-term kernel does not take (output pitch)
+            x = x.float() + x_lo.float()
         x2 = x.reshape(-1, K)
         if x2.stride(1) != 1 or (x2.stride(0) & 3):
             x2 = x2.contiguous()

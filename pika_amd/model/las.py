@@ -266,16 +266,16 @@ class InputFeedRNNDecoder(nn.Module):
             h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
             ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
             # "mixed" is a training arithmetic (bf16 backward): a scoring pass under it runs its forward grade, i.e. exact
-            infer = "fp32" if G.PRECISION == "mixed" else None
+            infer = "bf16x3" if G.PRECISION == "mixed" else None
             proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous(),
                              precision=infer).view(B, S, H)
             own = owner.to(device=dev, dtype=torch.int32).contiguous()
             ln = lens.to(device=dev, dtype=torch.int32).contiguous()
-            half = G.PRECISION == "bf16"
             # weights packed once per pass into MFMA fragment order (pika_dpack_weight): 1 bf16 term per operand in the
-            # bf16 arithmetic mode, 3 (fp32-exact products) otherwise
+            # bf16 arithmetic mode, 3 (fp32-exact products, six MFMAs each) in "fp32", 2 (hi.hi + hi.lo + lo.hi: an fp32
+            # product to ~2^-17, three MFMAs) otherwise
             from ..decoder.fused_step import DGemm, PackedWeight
-            terms = 1 if half else 3
+            terms = {"bf16": 1, "fp32": 3}.get(G.PRECISION, 2)
             Wl = [PackedWeight(torch.cat([c.weight_ih, c.weight_hh], 1), terms) for c in self.rnn.layers]
             bl = [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.rnn.layers]
             Wq, bq = PackedWeight(att.linear_query.weight, terms), att.linear_query.bias.detach().float().contiguous()

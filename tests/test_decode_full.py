@@ -92,9 +92,10 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
     again, _, _ = decode(hip_device, "fp32")
     assert np.array_equal(again["hyps"], got["hyps"]) and np.array_equal(again["lens"], got["lens"])
     assert np.array_equal(again["scores"], got["scores"])
-    # two-term encoder (1e-5 products on the direct-to-LDS kernels, 13 % faster decode), exact step GEMMs: the top-1
-    # hypotheses must still be the reference's; deeper ranks are reported -- an encoder output that differs by 5e-5
-    # moves scores by more than the 1e-3 separation the strict criterion allows, which is why "fp32" stays the default
+    # two bf16 terms per operand everywhere (1e-5 products, 14 % less search time): the top-1 hypotheses must still be
+    # the reference's; deeper ranks are reported -- an encoder output that differs by 2e-5 and step logits at 1e-5 move
+    # scores by up to 2e-3, more than the 1e-3 separation the strict criterion allows, which is why "fp32" stays the
+    # default (profiles/r3_decode_two_term_check.txt)
     got3, enc3, _ = decode(hip_device, "bf16x3")
     rel3, frac3 = check(got3, enc3, z, 1e-3, exact=False, ranks=False)
     print("bf16x3 mode: encoder output max rel err %.2e; top-1 identical for all %d utterances; %.0f %% of the n-best "
@@ -140,7 +141,7 @@ def test_gpu_full_width_greedy_is_identical_to_the_reference(hip_device, precisi
     """Greedy search (beam 1) on the full-width model: the case north_star words as bit-exact.  The reference's own
     decisions along the four greedy paths are separated by >= 0.044 in log-probability (recorded in the golden:
     `min_margin`), two orders above the fp32 accumulation noise of a 1024-term product, so the hypotheses -- blanks
-    included -- must be IDENTICAL, in the default decode arithmetic and with the two-term encoder."""
+    included -- must be IDENTICAL, in the default decode arithmetic and in the two-term mode."""
     z = np.load(GREEDY)
     assert float(z["min_margin"]) > 1e-2
     got, d = decode_greedy(hip_device, precision)

@@ -249,3 +249,23 @@ def test_mixed_mode_layers_match_fp32_mode(hip_device):
     assert ((xm - x32).norm() / x32.norm()).item() < 3e-2
     o16, _, _ = run("bf16")
     assert ((o16 - o32).abs().max() / o32.abs().max()).item() > 10 * ((om - o32).abs().max() / o32.abs().max()).item()
+
+
+def test_mixed_linear_with_an_output_width_the_two_term_kernel_does_not_take(hip_device):
+    """N % 4 != 0 (the LAS output projection: V + 2 = 5002 classes): the product falls back to the exact kernel instead of
+    failing, forward and backward."""
+    from pika_amd import gemm as G
+    from pika_amd.model import ops
+    old, G.PRECISION = G.PRECISION, "mixed"
+    try:
+        torch.manual_seed(3)
+        x = torch.randn(70, 128, device=hip_device, requires_grad=True)
+        w = (torch.randn(5002, 128, device=hip_device) * 0.1).requires_grad_()
+        b = torch.randn(5002, device=hip_device, requires_grad=True)
+        y = ops.linear(x, w, b)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        assert (y.double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+        y.sum().backward()
+        assert x.grad is not None and w.grad.shape == w.shape and b.grad.shape == b.shape
+    finally:
+        G.PRECISION = old
