@@ -755,7 +755,9 @@ def leg_decode(args, R_, with_cpu):
                     "labels_per_utt_top1": fd["config"]["labels_per_utt_top1"],
                     "note": "configs[4] in full: bigram FST shallow fusion inside the launch chain (scale %.2f) + fw/bw LAS "
                             "rescoring of all %d x %d hypotheses as one per-token kernel chain per model; synthetic LM and "
-                            "random LAS weights (2-layer BLSTM 1024, mlp attention)" % (f.fst_scale, f.batch, f.beam)}
+                            "random LAS weights (2-layer BLSTM 1024, mlp attention); n-best entries cut to 2U labels (runaway hypotheses "
+                            "of the random model); LAS products: two bf16 terms per operand, encoder input projections exact"
+                            % (f.fst_scale, f.batch, f.beam)}
                 del fstep, fret
             except Exception as e:
                 d["with_fst_and_las"] = {"error": "%s: %s" % (type(e).__name__, e)}
