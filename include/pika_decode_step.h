@@ -20,8 +20,10 @@
  *                             pika_decode.h), the all-done test and the step counter
  *
  * Weights are constant while decoding: they are packed ONCE (pika_dpack_weight) into MFMA fragment order, as 1, 2
- * or 3 bf16 terms (w = hi [+ mid [+ lo]]: 3 terms reproduce fp32 products exactly, 6 MFMAs per product pair).
- * Activations stay fp32 in memory and are split the same way while they are staged into LDS.
+ * or 3 bf16 terms (w = hi [+ mid [+ lo]]: 3 terms reproduce fp32 products exactly, 6 MFMAs per product pair), or --
+ * terms = 4 -- as two fp16 terms w = hi + 2^-11 lo' (lo' = fp16((w - hi) 2^11): 22 mantissa bits per operand; the kernels
+ * keep hi.hi and the cross products hi.lo' + lo'.hi in separate accumulators: an fp32 product to ~2^-22 with 3 MFMAs;
+ * needs |values| < 65504).  Activations stay fp32 in memory and are split the same way while they are staged into LDS.
  *
  * Conventions as in pika_rnnt.h: caller-owned device memory, no allocation, no host sync, stream = hipStream_t,
  * returns 0 / PIKA_EINVAL (<0) / hipError_t (>0).  `stop` (int32, device, may be NULL): when *stop != 0 the
@@ -37,7 +39,7 @@ extern "C" {
 #endif
 
 /* ---- packed weights ---------------------------------------------------------------------------------------- */
-/* bytes of the packed form of a (N,K) matrix: terms * ceil16(N) * ceil32(K) * 2 */
+/* bytes of the packed form of a (N,K) matrix: planes * ceil16(N) * ceil32(K) * 2, planes = terms (2 for terms = 4) */
 size_t pika_dpack_bytes(int N, int K, int terms);
 /* W (N,K) f32, row stride ldw -> packed.  interleave2 != 0: W has 2*N2 rows = [first half | second half]; packed
  * row 2j = W[j], row 2j+1 = W[N2 + j] (the gate epilogue wants fc1 / fc_gate outputs of one unit side by side). */

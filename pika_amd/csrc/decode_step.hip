@@ -20,6 +20,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// terms == 4 ("two fp16 terms"): x = hi + 2^-11 lo', hi = fp16(x), lo' = fp16((x - hi) * 2^11) -- the second term is kept
+// at the magnitude of the first (never subnormal where hi is not), and the kernels accumulate hi.hi and the two cross
+// products hi.lo' + lo'.hi in SEPARATE accumulators, combined as acc + 2^-11 accx at the end.  22 mantissa bits per operand:
+// an fp32 product to ~2^-22 with three MFMAs (three bf16 terms: exact, six MFMAs).  Needs |x| < 65504.
+constexpr int TERMS_F16X2 = 4;
+constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
+__host__ __device__ constexpr int planes_of(int terms) { return terms == TERMS_F16X2 ? 2 : terms; }
 
 
 // ---- weight packing: packed[term][n_tile][k_tile][lane][8], n_tile = 16 columns, k_tile = 32 ----------------
@@ -38,6 +48,17 @@ __global__ void dpack_kernel(const float *__restrict__ W, long long ldw, int N, 
     if (interleave2 && n < N) src = (n & 1) ? (N / 2 + (n >> 1)) : (n >> 1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? W[(long long)src * ldw + k0 + j] : 0.f;
+    if (terms == TERMS_F16X2) {
+        f16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = (_Float16)v[j];
+            l[j] = (_Float16)((v[j] - (float)h[j]) * LO_SCALE);
+        }
+        *reinterpret_cast<f16x8 *>(out + (((long long)0 * NT + nt) * KT + kt) * 512 + lane * 8) = h;
+        *reinterpret_cast<f16x8 *>(out + (((long long)1 * NT + nt) * KT + kt) * 512 + lane * 8) = l;
+        return;
+    }
     for (int t = 0; t < terms; ++t) {
         bf16x8 h;
 #pragma unroll
@@ -55,8 +76,10 @@ __global__ void dpack_kernel(const float *__restrict__ W, long long ldw, int N, 
 // (double buffered, one barrier per step); W fragments global -> registers.  Everything of step k+1 is requested
 // before the MFMAs of step k: these launches are latency-bound (one or two workgroups per CU, weights coming from
 // L2 / Infinity Cache), so what counts is bytes in flight per wave -- KS*32 columns per request round.
-template <int BM, int WN, int NS, int KS>
+template <int BM, int WN, int NSM, int KS>
 struct Core {
+    static constexpr bool F16 = NSM == TERMS_F16X2;     // two fp16 terms (see TERMS_F16X2); else NSM bf16 terms
+    static constexpr int NS = planes_of(NSM);           // 16-bit planes per operand
     static constexpr int MT = BM / 16;
     static constexpr int BK = 32 * KS;
     static constexpr int PITCH = BK + 8;          // bf16 per LDS row: the 16 rows of a fragment read start 4 banks apart
@@ -114,14 +137,30 @@ struct Core {
 #pragma unroll
             for (int i = 0; i < APT; ++i) {
                 f32x4 r = araw[i];
+                if constexpr (F16) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const bf16x4 h = __builtin_convertvector(r, bf16x4);
-                    *reinterpret_cast<bf16x4 *>(dst + s * (BM * PITCH) + aoff[i]) = h;
-                    if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
+                    for (int e = 0; e < 4; ++e) r[e] = fminf(fmaxf(r[e], -65504.f), 65504.f);   // saturate, never inf
+                    const f16x4 h = __builtin_convertvector(r, f16x4);
+                    const f16x4 l = __builtin_convertvector((r - __builtin_convertvector(h, f32x4)) * LO_SCALE, f16x4);
+                    *reinterpret_cast<f16x4 *>(dst + aoff[i]) = h;
+                    *reinterpret_cast<f16x4 *>(dst + BM * PITCH + aoff[i]) = l;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const bf16x4 h = __builtin_convertvector(r, bf16x4);
+                        *reinterpret_cast<bf16x4 *>(dst + s * (BM * PITCH) + aoff[i]) = h;
+                        if (s + 1 < NS) r = r - __builtin_convertvector(h, f32x4);
+                    }
                 }
             }
         };
+        [[maybe_unused]] f32x4 accx[MT][WN];     // cross products of the fp16 two-term mode
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         load_a(0);
         load_w(0, wreg);
         stage_a(0);
@@ -146,6 +185,24 @@ struct Core {
                     for (int s = 0; s < NS; ++s)
                         a[i][s] = *reinterpret_cast<const bf16x8 *>(src + s * (BM * PITCH) + (i * 16 + (lane & 15)) * PITCH +
                                                                     q * 32 + (lane >> 4) * 8);
+                if constexpr (F16) {
+                    auto f16 = [](const bf16x8 &v) { return __builtin_bit_cast(f16x8, v); };
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f16(wreg[j][q][1]), f16(a[i][0]), accx[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f16(wreg[j][q][0]), f16(a[i][1]), accx[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f16(wreg[j][q][0]), f16(a[i][0]), acc[i][j], 0, 0, 0);
+                } else {
 #pragma unroll
                 for (int p = 6 - NP; p < 6; ++p)
 #pragma unroll
@@ -153,6 +210,7 @@ struct Core {
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][q][PW[p]], a[i][PA[p]], acc[i][j], 0, 0, 0);
+                }
             }
             if (more) {
                 stage_a((st + 1) & 1);
@@ -164,6 +222,12 @@ struct Core {
                         for (int s = 0; s < NS; ++s) wreg[j][q][s] = wnext[j][q][s];
             }
             __syncthreads();
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] += accx[i][j] * LO_UNSCALE;
         }
     }
 };
@@ -617,12 +681,12 @@ void launch_fc2(unsigned grid, hipStream_t st, const float *h, long long ldh, co
 extern "C" {
 
 size_t pika_dpack_bytes(int N, int K, int terms) {
-    return (size_t)terms * ((N + 15) / 16 * 16) * ((K + 31) / 32 * 32) * 2;
+    return (size_t)planes_of(terms) * ((N + 15) / 16 * 16) * ((K + 31) / 32 * 32) * 2;
 }
 
 int pika_dpack_weight(const float *W, long long ldw, int N, int K, int terms, int interleave2, void *packed,
                       void *stream) {
-    if (!W || !packed || N <= 0 || K <= 0 || terms < 1 || terms > 3 || (interleave2 && (N & 1))) return PIKA_EINVAL;
+    if (!W || !packed || N <= 0 || K <= 0 || terms < 1 || terms > 4 || (interleave2 && (N & 1))) return PIKA_EINVAL;
     const int NT = (N + 15) / 16, KT = (K + 31) / 32;
     const long long total = (long long)NT * KT * 64;
     hipLaunchKernelGGL(dpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K,
@@ -631,7 +695,7 @@ int pika_dpack_weight(const float *W, long long ldw, int N, int K, int terms, in
 }
 
 int pika_dgemm(const pika_dgemm_t *q, void *stream) {
-    if (!q || !q->A || !q->W || !q->C || q->M <= 0 || q->N <= 0 || q->K <= 0 || q->terms < 1 || q->terms > 3)
+    if (!q || !q->A || !q->W || !q->C || q->M <= 0 || q->N <= 0 || q->K <= 0 || q->terms < 1 || q->terms > 4)
         return PIKA_EINVAL;
     if ((q->lda & 3) || (reinterpret_cast<uintptr_t>(q->A) & 15)) return PIKA_EINVAL;
     if ((q->flags & PIKA_DG_GATE) && (!q->e_all || !q->t_idx || q->T <= 0 || q->beam <= 0 || (q->N & 3))) return PIKA_EINVAL;
@@ -646,9 +710,11 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     const int BM = big ? 64 : 32;
     const unsigned grid = (unsigned)((((q->M + BM - 1) / BM + 7) / 8) * 8 * n_groups);
     if (big) {
-        if (q->terms == 1) launch_dgemm<64, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<64, 2>(grid, st, p); else launch_dgemm<64, 3>(grid, st, p);
+        if (q->terms == 1) launch_dgemm<64, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<64, 2>(grid, st, p);
+        else if (q->terms == 3) launch_dgemm<64, 3>(grid, st, p); else launch_dgemm<64, 4>(grid, st, p);
     } else {
-        if (q->terms == 1) launch_dgemm<32, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<32, 2>(grid, st, p); else launch_dgemm<32, 3>(grid, st, p);
+        if (q->terms == 1) launch_dgemm<32, 1>(grid, st, p); else if (q->terms == 2) launch_dgemm<32, 2>(grid, st, p);
+        else if (q->terms == 3) launch_dgemm<32, 3>(grid, st, p); else launch_dgemm<32, 4>(grid, st, p);
     }
     return check(hipGetLastError());
 }
@@ -708,7 +774,7 @@ int pika_dfc2_cols_per_split(void) { return FC2_COLS; }
 int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
                    float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream) {
     if (!h || !W || !pmax || !psum || !pcand || rows <= 0 || V <= 0 || K <= 0 || topk < 1 || topk > 64 || terms < 1 ||
-        terms > 3 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
+        terms > 4 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
         return PIKA_EINVAL;
     const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
     const unsigned grid = (unsigned)((((rows + FC2_BM - 1) / FC2_BM + 7) / 8) * 8 * splits);
@@ -717,7 +783,8 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
     Cand *pc = reinterpret_cast<Cand *>(pcand);
     if (terms == 1) launch_fc2<1>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
     else if (terms == 2) launch_fc2<2>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else launch_fc2<3>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else if (terms == 3) launch_fc2<3>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else launch_fc2<4>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
     return check(hipGetLastError());
 }
 

@@ -53,12 +53,15 @@ class TransducerDecoder(object):
         # (3 = fp32-exact products; 2 = hi.hi + hi.lo + lo.hi, an fp32 product to ~2^-17; 1 = plain bf16 operands)
         import os
         self.fused_search = os.environ.get("PIKA_DECODE_FUSED_SEARCH", "1") != "0"
-        # decode_precision "fp32" (default): every product of the decode -- encoder, joint halves, step GEMMs, fc2 --
-        # with three bf16 terms per operand, six MFMA products (exact fp32 products): on the full-width golden every
-        # n-best entry separated from its neighbours by > 1e-3 in score sits at its reference rank, scores within 3e-4.
-        # "bf16x3": two bf16 terms per operand (hi.hi + hi.lo + lo.hi, an fp32 product to ~2^-17): 14 % less search
-        # time, top-1 and greedy hypotheses still identical to the reference's, but scores move by up to 2e-3 and one
-        # separated deep-rank entry of the golden swaps (tools/decode_two_term_check.py) -- an option, not the default.
+        # decode_precision "fp32" (default): fp32-grade products everywhere.  The encoder and the joint halves (once per
+        # batch) run on three bf16 terms per operand, six MFMA products: exact fp32 products.  The step products (prediction
+        # network, joint, fc2: 340 steps per batch) run on two fp16 terms per operand (include/pika_decode_step.h, terms = 4:
+        # 22 mantissa bits per operand, hi.hi and the cross products in separate accumulators: an fp32 product to ~2^-22
+        # with three MFMAs).  On the full-width golden every n-best entry separated from its neighbours by > 1e-3 in score
+        # sits at its reference rank and scores agree within 3e-4 -- the same as with exact step products
+        # (decode_precision "fp32-exact": three bf16 terms there too, 17 % more search time).
+        # "bf16x3": two bf16 terms per operand everywhere (an fp32 product to ~2^-17; encoder 20 ms faster per batch, top-1
+        # and greedy hypotheses identical to the reference's, scores within 2e-3: tools/decode_two_term_check.py).
         # "bf16": plain bf16 operands.
         self.decode_precision = os.environ.get("PIKA_DECODE_PRECISION", "fp32")
         self.replays_per_sync = 4
@@ -66,7 +69,7 @@ class TransducerDecoder(object):
 
     @property
     def decode_terms(self):
-        return {"bf16": 1, "bf16x3": 2}.get(self.decode_precision, 3)
+        return {"bf16": 1, "bf16x3": 2, "fp32-exact": 3}.get(self.decode_precision, 4)
 
     # ---- prediction network stepping (fixed shapes: every row is recomputed, rows whose last
     # symbol is not a label keep their state; transducer_decoder.py:139-171) ---------------------
@@ -107,8 +110,10 @@ class TransducerDecoder(object):
     def decode_batch(self, x, x_len, max_len=None):
         from .. import gemm as G
         old = G.PRECISION
-        if x.is_cuda and self.decode_precision in ("fp32", "bf16x3", "bf16"):
-            G.PRECISION = self.decode_precision
+        if x.is_cuda:
+            if self.decode_precision not in ("fp32", "fp32-exact", "fp16x2", "bf16x3", "bf16"):
+                raise ValueError("unknown decode_precision %r" % (self.decode_precision,))
+            G.PRECISION = self.decode_precision if self.decode_precision in ("bf16x3", "bf16") else "fp32"
         try:
             return self._decode_batch(x, x_len, max_len)
         finally:

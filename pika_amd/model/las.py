@@ -272,10 +272,11 @@ class InputFeedRNNDecoder(nn.Module):
             own = owner.to(device=dev, dtype=torch.int32).contiguous()
             ln = lens.to(device=dev, dtype=torch.int32).contiguous()
             # weights packed once per pass into MFMA fragment order (pika_dpack_weight): 1 bf16 term per operand in the
-            # bf16 arithmetic mode, 3 (fp32-exact products, six MFMAs each) in "fp32", 2 (hi.hi + hi.lo + lo.hi: an fp32
-            # product to ~2^-17, three MFMAs) otherwise
+            # bf16 arithmetic mode; otherwise two fp16 terms (terms = 4: 22 mantissa bits per operand, an fp32 product to
+            # ~2^-22 with three MFMAs -- the decoder's activations are bounded, far inside fp16's range);
+            # PIKA_LAS_TERMS=3: three bf16 terms, exact fp32 products, six MFMAs
             from ..decoder.fused_step import DGemm, PackedWeight
-            terms = {"bf16": 1, "fp32": 3}.get(G.PRECISION, 2)
+            terms = 1 if G.PRECISION == "bf16" else int(os.environ.get("PIKA_LAS_TERMS", "4"))
             Wl = [PackedWeight(torch.cat([c.weight_ih, c.weight_hh], 1), terms) for c in self.rnn.layers]
             bl = [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.rnn.layers]
             Wq, bq = PackedWeight(att.linear_query.weight, terms), att.linear_query.bias.detach().float().contiguous()

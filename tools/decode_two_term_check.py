@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_decode_full as T  # noqa: E402
 
 z = np.load(T.GOLD)
-for prec in ("fp32", "bf16x3"):
+for prec in ("fp32", "fp32-exact", "bf16x3"):
     got, enc, d = T.decode("cuda:0", prec)
     es = enc[:, ::7, ::37].float().cpu().numpy()
     rel = np.abs(es - z["enc_sample"]).max() / np.abs(z["enc_sample"]).max()
