@@ -342,6 +342,8 @@ def decode_workload(args, dev, rank):
             bw = las_bw.score_nbest_batch(src, x_len, [[h[::-1] for h in row] for row in hyps], SOS, EOS)
             ret["las"] = (fw, bw)
             torch.cuda.synchronize()
+            # decoder row steps actually computed: entries of an utterance that share a prefix share its rows
+            dec.timing["las_row_steps"] = {"fw": getattr(las_fw, "last_pass", None), "bw": getattr(las_bw, "last_pass", None)}
             if getattr(las_fw, "phase_times", None):
                 dec.timing["las_phases_ms"] = {"fw": las_fw.phase_times, "bw": las_bw.phase_times}
         dec.timing["las_s"] = time.perf_counter() - t0
@@ -749,11 +751,14 @@ def leg_decode(args, R_, with_cpu):
                 d["with_fst_and_las"] = {
                     "value": fd["value"], "unit": "RTF", "ms_per_step": fd["ms_per_step"],
                     "search_s": tm["search_s"], "las_rescoring_s": tm["las_s"], "launches_per_step": tm["launches_per_step"],
+                    "las_row_steps": tm.get("las_row_steps"),
                     "labels_per_utt_top1": fd["config"]["labels_per_utt_top1"],
                     "note": "configs[4] in full: bigram FST shallow fusion inside the launch chain (scale %.2f) + fw/bw LAS "
                             "rescoring of all %d x %d hypotheses as one per-token kernel chain per model; synthetic LM and "
                             "random LAS weights (2-layer BLSTM 1024, mlp attention); n-best entries cut to 2U labels (runaway hypotheses "
-                            "of the random model); LAS products: two fp16 terms per operand (~2^-22), encoder input projections exact"
+                            "of the random model); entries that share a token prefix share its decoder rows (las_row_steps vs pairs in "
+                            "timing; same values as scoring every entry from scratch); LAS products: two fp16 terms per "
+                            "operand (~2^-22), encoder input projections exact"
                             % (f.fst_scale, f.batch, f.beam)}
                 del fstep, fret
             except Exception as e:

@@ -70,6 +70,10 @@ typedef struct {
     int M, N, K, terms, flags;
     const int *m_dev;        /* device int32 or NULL: only rows < min(M, *m_dev) are computed (compact row lists) */
     const long long *crow;   /* (M) i64 or NULL: row r of the result is stored at row crow[r] of C     */
+    const int *rowlist;      /* NULL, or a gather list (device int32): launch row e < M stands for row
+                                r = rowlist[*rowoff_dev + e] of A, res, node, crow, t_idx and C (the rows of a launch are
+                                then any subset of the buffers' rows; buffers stay where they are)          */
+    const int *rowoff_dev;   /* device int32 offset into rowlist, or NULL (0)                               */
 } pika_dgemm_t;
 int pika_dgemm(const pika_dgemm_t *p, void *stream);
 

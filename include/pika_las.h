@@ -23,9 +23,12 @@ extern "C" {
  * c_prev (N, H) contiguous.  c_out (N, H) contiguous (may alias c_prev) = sigmoid(f) c_prev + sigmoid(i) tanh(g);
  * h = sigmoid(o) tanh(c_out) is written to h_out (pitch ldh) and, when h_out2 != NULL, also to h_out2 (pitch ldh2) --
  * the decoder keeps h both as the next layer's input block and as the recurrent block of its own next step.
- * H % 4 == 0, 16-byte aligned rows.  n_dev: NULL, or a device int: only rows < min(N, *n_dev) are processed. */
+ * H % 4 == 0, 16-byte aligned rows.  n_dev: NULL, or a device int: only rows < min(N, *n_dev) are processed.
+ * rowlist / rowoff_dev: NULL, or a gather list (device int32) and its device offset: launch row e stands for row
+ * rowlist[*rowoff_dev + e] of every operand (the rows of a launch are then any subset of the buffers' rows). */
 int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float *c_out, float *h_out, long long ldh,
-                   float *h_out2, long long ldh2, int N, int H, const int *n_dev, void *stream);
+                   float *h_out2, long long ldh2, int N, int H, const int *n_dev, const int *rowlist,
+                   const int *rowoff_dev, void *stream);
 
 /* "mlp" attention of N queries over the source positions of their utterances; query n = qidx[i], i < N (qidx NULL:
  * n = i):
@@ -49,12 +52,23 @@ int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, co
  * lives on the device.  step int32[4] = {t, n, qoff, -} (the caller starts it at {-1, 0, 0, 0});
  * pika_las_step_advance: t += 1, n = n_active[t], qoff = qoffs[t] (0 beyond L) -- n is what the m_dev / n_dev
  * parameters of pika_dgemm, pika_lstm_cell and pika_las_mlp_attention point at;
- * pika_las_embed_rows: for r < n: x0[r, 0:E] = emb[tokens[t, r], :] (the decoder's layer-0 input rows, pitch ldx) and
- * crow[r] = t * N + r (the row of the (L, N, H) result the token's output projection writes through pika_dgemm's
- * crow).  tokens (L, N) int64, E % 4 == 0. */
+ * pika_las_embed_rows: for e < n, r = rowlist ? rowlist[qoff + e] : e: x0[r, 0:E] = emb[tokens[t, r], :] (the decoder's
+ * layer-0 input rows, pitch ldx) and crow[r] = t * N + r (the row of the (L, N, H) result the token's output projection
+ * writes through pika_dgemm's crow).  tokens (L, N) int64, E % 4 == 0.  rowlist: the per-step lists of ACTIVE rows
+ * (the same lists the attention kernel takes as its query lists), concatenated; step[2] is the offset of step t's. */
 int pika_las_step_advance(int *step, const int *n_active, const int *qoffs, int L, void *stream);
+/* Prefix sharing: the n-best entries of an utterance that share a token prefix share the decoder rows of that prefix (the
+ * reference scores every entry from scratch, decoder/transducer_decoder.py:219-253: same values).  At the step t a
+ * hypothesis leaves the shared prefix its row inherits the recurrent state of the row that computed the prefix: for
+ * k in [fork_off[t], fork_off[t+1]) and every segment i < nseg (<= PIKA_LAS_FORK_SEGS):
+ *   base[i][fork_dst[k], col0[i] : col0[i] + ncols[i]] = base[i][fork_src[k], same columns]   (row pitch ld[i], floats)
+ * t = step[0] (after pika_las_step_advance); fork_off int32[L + 1]; max_forks = the largest number of forks of a step
+ * (sizes the grid).  Source and destination rows of a step are disjoint.  Columns / pitches multiples of 4. */
+#define PIKA_LAS_FORK_SEGS 8
+int pika_las_fork_rows(const int *step, const int *fork_off, const int *fork_dst, const int *fork_src, int max_forks,
+                       int nseg, float *const *base, const long long *ld, const int *col0, const int *ncols, void *stream);
 int pika_las_embed_rows(const int *step, const long long *tokens, const float *emb, float *x0, long long ldx,
-                        long long *crow, int N, int E, void *stream);
+                        long long *crow, int N, int E, const int *rowlist, void *stream);
 
 /* The rescorer's encoder: one (bi)directional nn.LSTM layer over a padded batch of packed sequences
  * (/root/reference/trainer/model/las.py:44-75: pack_padded_sequence -> nn.LSTM -> pad_packed_sequence), the whole

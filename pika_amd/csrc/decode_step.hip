@@ -91,8 +91,9 @@ struct Core {
 
     // Kvalid: columns of A that hold data (a multiple of 4): columns [Kvalid, KT*32) are NOT read -- the packed weight
     // is zero there, but garbage times zero is NaN when the garbage is not finite
+    // rows: NULL, or the gather list of the launch: launch row e reads row rows[e] of A
     __device__ inline void run(const float *__restrict__ A, long long lda, int M, int m0, const __bf16 *__restrict__ W,
-                               int NT, int KT, int nt0, __bf16 *lds, int Kvalid) {
+                               int NT, int KT, int nt0, __bf16 *lds, int Kvalid, const int *__restrict__ rows = nullptr) {
         const int tid = threadIdx.x, lane = tid & 63;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -104,7 +105,7 @@ struct Core {
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int f = tid + 256 * i, r = f / (BK / 4), c4 = f % (BK / 4);
-            arow[i] = (m0 + r < M) ? A + (long long)(m0 + r) * lda + c4 * 4 : nullptr;
+            arow[i] = (m0 + r < M) ? A + (long long)(rows ? rows[m0 + r] : m0 + r) * lda + c4 * 4 : nullptr;
             aoff[i] = r * PITCH + c4 * 4;
             acol[i] = c4 * 4;
         }
@@ -237,6 +238,7 @@ struct DG {   // device copy of pika_dgemm_t
     float *C; long long ldc; float *C2; long long ldc2; const long long *node; long long skip_node;
     const float *e_all; const long long *t_idx; int T, beam, M, N, NT, KT, flags;
     const int *m_dev; const long long *crow;
+    const int *rowlist; const int *rowoff_dev;
     int Kvalid;   // K when K % 4 == 0 (columns beyond are never read), else ceil32(K) (the caller zero-pads, as the header says)
 };
 
@@ -278,14 +280,17 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mg * BM, nt0 = ng * 4 + wave;
     if (m0 >= M) return;
-    core.run(p.A, p.lda, M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem), p.Kvalid);
+    // launch rows as a gather list: launch row e stands for row rows[e] of A, res, node, crow, t_idx and C
+    const int *rows = p.rowlist ? p.rowlist + (p.rowoff_dev ? *p.rowoff_dev : 0) : nullptr;
+    core.run(p.A, p.lda, M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem), p.Kvalid, rows);
     if (nt0 >= p.NT) return;
     const int c0 = nt0 * 16 + (lane >> 4) * 4;          // first of this lane's 4 consecutive columns
     if (c0 >= p.N) return;
 #pragma unroll
     for (int i = 0; i < BM / 16; ++i) {
-        const int r = m0 + i * 16 + (lane & 15);
-        if (r >= M) continue;
+        const int e_ = m0 + i * 16 + (lane & 15);
+        if (e_ >= M) continue;
+        const int r = rows ? rows[e_] : e_;
         f32x4 v = core.acc[i][0];
         if (p.flags & PIKA_DG_GATE) {
             // columns (2j, 2j+1) = (fc1, fc_gate) of joint unit j; this lane holds units c0/2 and c0/2 + 1
@@ -702,7 +707,7 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     if (((q->flags & PIKA_DG_ROWMASK) || q->C2) && !q->node) return PIKA_EINVAL;
     DG p{q->A, q->lda, reinterpret_cast<const __bf16 *>(q->W), q->bias, q->res, q->ldr, q->C, q->ldc, q->C2, q->ldc2,
          q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags,
-         q->m_dev, q->crow, (q->K & 3) ? ((q->K + 31) / 32) * 32 : q->K};
+         q->m_dev, q->crow, q->rowlist, q->rowoff_dev, (q->K & 3) ? ((q->K + 31) / 32) * 32 : q->K};
     hipStream_t st = (hipStream_t)stream;
     const int n_groups = (p.NT + 3) / 4;
     // enough workgroups to cover the chip: 32-row tiles unless 64-row tiles already give > 256 of them

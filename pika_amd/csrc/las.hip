@@ -23,12 +23,14 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float *__restrict_
                                                         const float *__restrict__ c_prev, float *__restrict__ c_out,
                                                         float *__restrict__ h_out, long long ldh,
                                                         float *__restrict__ h_out2, long long ldh2, int N, int H,
-                                                        const int *__restrict__ n_dev) {
+                                                        const int *__restrict__ n_dev, const int *__restrict__ rowlist,
+                                                        const int *__restrict__ rowoff_dev) {
     const int H4 = H >> 2;
     if (n_dev) N = min(N, *n_dev);       // rows in use this step (a launch captured once, replayed per token)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * H4) return;
-    const int n = (int)(idx / H4), c = (int)(idx - (long long)n * H4) << 2;
+    const int e_ = (int)(idx / H4), c = (int)(idx - (long long)e_ * H4) << 2;
+    const int n = rowlist ? rowlist[(rowoff_dev ? *rowoff_dev : 0) + e_] : e_;     // launch rows as a gather list
     const float *g = gates + (long long)n * ldg + c;
     const f32x4 gi = *reinterpret_cast<const f32x4 *>(g), gf = *reinterpret_cast<const f32x4 *>(g + H);
     const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + 2 * H), go = *reinterpret_cast<const f32x4 *>(g + 3 * H);
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float *__restrict_
     if (h_out2) *reinterpret_cast<f32x4 *>(h_out2 + (long long)n * ldh2 + c) = h;
 }
 
-constexpr int G = 4;          // queries per workgroup
+constexpr int GQ = 4;         // queries per workgroup (1 when the launch has few queries: a group's queries are walked in turn)
 constexpr int KQ = 4;         // float4 slots per lane: D <= 64 * 4 * KQ = 1024
 
 __device__ inline float wave_sum(float v) {
@@ -75,6 +77,7 @@ __device__ inline float block_reduce(float v, bool is_max, float *red) {
 // softmax is online (running maximum m, running sum l, context sums rescaled when m moves), so the scores never leave
 // the registers; the eight waves' partial (m, l, sums) are merged through LDS at the end.
 constexpr int AW = 8;         // waves per workgroup
+template <int G>
 __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float *__restrict__ wq, long long ldq,
                                                                 const float *__restrict__ proj,
                                                                 const float *__restrict__ context,
@@ -234,20 +237,58 @@ __global__ void las_step_advance_kernel(int *__restrict__ step, const int *__res
 __global__ __launch_bounds__(256) void las_embed_rows_kernel(const int *__restrict__ step,
                                                              const long long *__restrict__ tokens,
                                                              const float *__restrict__ emb, float *__restrict__ x0,
-                                                             long long ldx, long long *__restrict__ crow, int N, int E) {
+                                                             long long ldx, long long *__restrict__ crow, int N, int E,
+                                                             const int *__restrict__ rowlist) {
     const int t = step[0], n = min(N, step[1]);
     const int E4 = E >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * E4) return;
-    const int r = (int)(idx / E4), c = (int)(idx - (long long)r * E4) << 2;
+    const int e_ = (int)(idx / E4), c = (int)(idx - (long long)e_ * E4) << 2;
+    const int r = rowlist ? rowlist[step[2] + e_] : e_;       // the step's active rows (the attention's query list)
     const long long tok = tokens[(long long)t * N + r];
     *reinterpret_cast<f32x4 *>(x0 + (long long)r * ldx + c) = *reinterpret_cast<const f32x4 *>(emb + tok * E + c);
     if (c == 0) crow[r] = (long long)t * N + r;
 }
 
+// hypotheses that share a prefix share the decoder rows of that prefix; at the step a hypothesis leaves the prefix it
+// inherits the recurrent state of the row that computed it: segment s of row dst <- the same columns of row src
+struct ForkSegs { float *base[PIKA_LAS_FORK_SEGS]; long long ld[PIKA_LAS_FORK_SEGS]; int col0[PIKA_LAS_FORK_SEGS], ncols[PIKA_LAS_FORK_SEGS]; };
+__global__ __launch_bounds__(256) void las_fork_rows_kernel(const int *__restrict__ step, const int *__restrict__ fork_off,
+                                                            const int *__restrict__ fork_dst,
+                                                            const int *__restrict__ fork_src, ForkSegs g) {
+    const int t = step[0];
+    const int k0 = fork_off[t], k1 = fork_off[t + 1];
+    const int sgm = blockIdx.y;
+    float *base = g.base[sgm];
+    const long long ld = g.ld[sgm];
+    const int c0 = g.col0[sgm], n4 = g.ncols[sgm] >> 2;
+    for (int k = k0 + blockIdx.x; k < k1; k += gridDim.x) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(base + (long long)fork_src[k] * ld + c0);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(base + (long long)fork_dst[k] * ld + c0);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pika_las_fork_rows(const int *step, const int *fork_off, const int *fork_dst, const int *fork_src, int max_forks,
+                       int nseg, float *const *base, const long long *ld, const int *col0, const int *ncols, void *stream) {
+    if (!step || !fork_off || !fork_dst || !fork_src || !base || !ld || !col0 || !ncols) return PIKA_EINVAL;
+    if (nseg < 1 || nseg > PIKA_LAS_FORK_SEGS || max_forks < 0) return PIKA_EINVAL;
+    if (max_forks == 0) return PIKA_OK;
+    ForkSegs g{};
+    for (int i = 0; i < nseg; ++i) {
+        if (!base[i] || (ld[i] & 3) || (col0[i] & 3) || (ncols[i] & 3) || ncols[i] <= 0 ||
+            (reinterpret_cast<uintptr_t>(base[i]) & 15))
+            return PIKA_EINVAL;
+        g.base[i] = base[i]; g.ld[i] = ld[i]; g.col0[i] = col0[i]; g.ncols[i] = ncols[i];
+    }
+    hipLaunchKernelGGL(las_fork_rows_kernel, dim3((unsigned)(max_forks < 256 ? max_forks : 256), (unsigned)nseg), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), step, fork_off, fork_dst, fork_src, g);
+    return (int)hipGetLastError();
+}
 
 int pika_las_step_advance(int *step, const int *n_active, const int *qoff, int L, void *stream) {
     if (!step || !n_active || !qoff || L <= 0) return PIKA_EINVAL;
@@ -256,17 +297,18 @@ int pika_las_step_advance(int *step, const int *n_active, const int *qoff, int L
 }
 
 int pika_las_embed_rows(const int *step, const long long *tokens, const float *emb, float *x0, long long ldx,
-                        long long *crow, int N, int E, void *stream) {
+                        long long *crow, int N, int E, const int *rowlist, void *stream) {
     if (!step || !tokens || !emb || !x0 || !crow || N <= 0 || E <= 0 || (E & 3) || (ldx & 3) || ldx < E) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(x0)) & 15) return PIKA_EINVAL;
     const long long total = (long long)N * (E >> 2);
     hipLaunchKernelGGL(las_embed_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), step, tokens, emb, x0, ldx, crow, N, E);
+                       static_cast<hipStream_t>(stream), step, tokens, emb, x0, ldx, crow, N, E, rowlist);
     return (int)hipGetLastError();
 }
 
 int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float *c_out, float *h_out, long long ldh,
-                   float *h_out2, long long ldh2, int N, int H, const int *n_dev, void *stream) {
+                   float *h_out2, long long ldh2, int N, int H, const int *n_dev, const int *rowlist,
+                   const int *rowoff_dev, void *stream) {
     if (!gates || !c_prev || !c_out || !h_out || N <= 0 || H <= 0) return PIKA_EINVAL;
     if ((H & 3) || (ldg & 3) || (ldh & 3) || (h_out2 && (ldh2 & 3)) || ldg < 4LL * H || ldh < H) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(gates) | reinterpret_cast<uintptr_t>(c_prev) | reinterpret_cast<uintptr_t>(c_out) |
@@ -275,7 +317,8 @@ int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float
     const long long total = (long long)N * (H >> 2);
     if ((total + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
     hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), gates, ldg, c_prev, c_out, h_out, ldh, h_out2, ldh2, N, H, n_dev);
+                       static_cast<hipStream_t>(stream), gates, ldg, c_prev, c_out, h_out, ldh, h_out2, ldh2, N, H, n_dev,
+                       rowlist, rowoff_dev);
     return (int)hipGetLastError();
 }
 
@@ -290,9 +333,16 @@ int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, co
     if ((reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(context) |
          reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ctx_out)) & 15)
         return PIKA_EINVAL;
-    hipLaunchKernelGGL(las_mlp_attention_kernel, dim3((unsigned)((N + G - 1) / G)), dim3(64 * AW), 0,
-                       static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
-                       align_out, N, S, D, n_dev, qoff_dev);
+    // few queries (a rescoring pass whose n-best entries share their prefixes): one query per workgroup -- a workgroup's
+    // time is (positions / 8 waves) x (queries of the group), and the CUs are not all busy anyway
+    if (N <= 512)
+        hipLaunchKernelGGL(las_mlp_attention_kernel<1>, dim3((unsigned)N), dim3(64 * AW), 0,
+                           static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
+                           align_out, N, S, D, n_dev, qoff_dev);
+    else
+        hipLaunchKernelGGL(las_mlp_attention_kernel<GQ>, dim3((unsigned)((N + GQ - 1) / GQ)), dim3(64 * AW), 0,
+                           static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
+                           align_out, N, S, D, n_dev, qoff_dev);
     return (int)hipGetLastError();
 }
 

@@ -31,7 +31,7 @@ class DGemm(ctypes.Structure):
     _fields_ = [("A", _vp), ("lda", _ll), ("W", _vp), ("bias", _vp), ("res", _vp), ("ldr", _ll), ("C", _vp), ("ldc", _ll),
                 ("C2", _vp), ("ldc2", _ll), ("node", _vp), ("skip_node", _ll), ("e_all", _vp), ("t_idx", _vp),
                 ("T", _i), ("beam", _i), ("M", _i), ("N", _i), ("K", _i), ("terms", _i), ("flags", _i),
-                ("m_dev", _vp), ("crow", _vp)]
+                ("m_dev", _vp), ("crow", _vp), ("rowlist", _vp), ("rowoff_dev", _vp)]
 
 
 class DPrep(ctypes.Structure):

@@ -240,7 +240,7 @@ class InputFeedRNNDecoder(nn.Module):
                 and H == self.hidden_size and H % 4 == 0 and H <= 1024 and E % 4 == 0 and S <= 2048
                 and context.dtype == torch.float32 and os.environ.get("PIKA_LAS_FUSED", "1") != "0")
 
-    def _run_fused(self, tokens, context, enc_hidden, owner, lens, n_active=None):
+    def _run_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None):
         """The token loop of `run` for N hypotheses of B utterances (owner (N,) -> utterance, lens (B,) valid source
         positions) on un-expanded encoder outputs: per token 2 x (one GEMM over [input | h] with [W_ih | W_hh] + one
         LSTM-cell kernel), the query projection, ONE attention kernel (scores, softmax and context sum of a hypothesis
@@ -249,9 +249,11 @@ class InputFeedRNNDecoder(nn.Module):
         The nine launches of a token are captured ONCE into a hipGraph and replayed per token: the step index, the
         number of active hypotheses and the query-list offset are device words a one-thread kernel advances
         (PIKA_LAS_GRAPH=0: the same launches issued from Python per token).
-        n_active[t] (host ints, non-increasing): only hypotheses [0, n_active[t]) still have a token at step t (the
-        caller sorted them by length), so every launch of step t runs on that prefix of the rows; rows past it are left
-        unwritten in the result."""
+        spans = (first, end) host int arrays (N,): hypothesis row r takes part in steps first[r] <= t < end[r] (None:
+        every row in every step).  The rows of a step form a gather list (ordered by utterance, so that the queries of an
+        attention workgroup share the utterance's rows) that EVERY launch of the step runs on; rows outside it are left
+        unwritten in the result.  forks = (fork_off, dst, src): rows whose span starts at t > 0 inherit the recurrent
+        state of row src at the top of step t (pika_las_fork_rows)."""
         from .. import _lib
         from .. import gemm as G
         lib = _lib.lib()
@@ -298,10 +300,13 @@ class InputFeedRNNDecoder(nn.Module):
             import numpy as np
             own_h = owner.cpu().numpy()
             by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
-            n_act = np.full(L, N, np.int32) if n_active is None else np.asarray(n_active, np.int32)
-            lists = [by_owner[by_owner < int(k)] for k in n_act]
-            qoff = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
-            qlist = torch.from_numpy(np.concatenate(lists) if lists else np.zeros(0, np.int32)).to(dev)
+            first = np.zeros(N, np.int64) if spans is None else np.asarray(spans[0], np.int64)
+            end = np.full(N, L, np.int64) if spans is None else np.asarray(spans[1], np.int64)
+            f_o, e_o = first[by_owner], end[by_owner]
+            lists = [by_owner[(f_o <= t) & (t < e_o)] for t in range(L)]
+            n_act = np.asarray([len(x) for x in lists], np.int32)
+            qoff = np.concatenate([[0], np.cumsum(n_act)]).astype(np.int32)
+            qlist = torch.from_numpy(np.concatenate(lists).astype(np.int32) if N else np.zeros(0, np.int32)).to(dev)
             n_act_d = torch.from_numpy(n_act).to(dev)
             qoff_d = torch.from_numpy(qoff[:L].copy()).to(dev)
             step = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)
@@ -321,24 +326,42 @@ class InputFeedRNNDecoder(nn.Module):
                 g.skip_node = -1
                 g.M, g.N, g.K, g.terms, g.flags = n_max, W.N, W.K, W.terms, 0
                 g.m_dev = n_dev.data_ptr()
+                g.rowlist, g.rowoff_dev = qlist.data_ptr(), step[2:3].data_ptr()      # the step's active rows
                 if crow_ is not None:
                     g.crow = crow_.data_ptr()
                 _lib.check(lib.pika_dgemm(ctypes.byref(g), torch.cuda.current_stream().cuda_stream),
                            "pika_dgemm(M=%d,N=%d,K=%d)" % (n_max, W.N, W.K))
 
+            fork = None
+            if forks is not None and len(forks[1]):
+                # rows that leave a shared prefix at step t inherit [feed | h_0], h_l and c_l of the row that computed it
+                f_off, f_dst, f_src = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in forks)
+                segs = [(X[0], E, 2 * H)] + [(X[l], H, H) for l in range(1, nl)] + [(c[l], 0, H) for l in range(nl)]
+                ns = len(segs)
+                fork = (f_off, f_dst, f_src, int(np.diff(forks[0]).max()), ns,
+                        (ctypes.c_void_p * ns)(*[t_.data_ptr() for t_, _, _ in segs]),
+                        (ctypes.c_longlong * ns)(*[t_.stride(0) for t_, _, _ in segs]),
+                        (ctypes.c_int * ns)(*[c0 for _, c0, _ in segs]), (ctypes.c_int * ns)(*[nc for _, _, nc in segs]))
+
             def token_step():
                 st = torch.cuda.current_stream().cuda_stream
                 _lib.check(lib.pika_las_step_advance(step.data_ptr(), n_act_d.data_ptr(), qoff_d.data_ptr(), L, st),
                            "pika_las_step_advance")
+                if fork is not None:
+                    _lib.check(lib.pika_las_fork_rows(step.data_ptr(), fork[0].data_ptr(), fork[1].data_ptr(),
+                                                      fork[2].data_ptr(), fork[3], fork[4], fork[5], fork[6], fork[7],
+                                                      fork[8], st), "pika_las_fork_rows")
                 _lib.check(lib.pika_las_embed_rows(step.data_ptr(), tok.data_ptr(), emb_w.data_ptr(), X[0].data_ptr(),
-                                                   X[0].stride(0), crow.data_ptr(), n_max, E, st), "pika_las_embed_rows")
+                                                   X[0].stride(0), crow.data_ptr(), N, E, qlist.data_ptr(), st),
+                           "pika_las_embed_rows")
                 for l in range(nl):
                     dgemm(X[l], X[l].stride(0), Wl[l], bl[l], gates, 4 * H)
                     own_block = X[l][:, (E + H if l == 0 else H):]
                     nxt = X[l + 1][:, :H] if l + 1 < nl else CQ[:, H:]
                     _lib.check(lib.pika_lstm_cell(gates.data_ptr(), 4 * H, c[l].data_ptr(), c[l].data_ptr(),
                                                   own_block.data_ptr(), own_block.stride(0), nxt.data_ptr(),
-                                                  nxt.stride(0), n_max, H, n_dev.data_ptr(), st), "pika_lstm_cell")
+                                                  nxt.stride(0), n_max, H, n_dev.data_ptr(), qlist.data_ptr(),
+                                                  step[2:3].data_ptr(), st), "pika_lstm_cell")
                 dgemm(CQ[:, H:], 2 * H, Wq, bq, wq, H)
                 _lib.check(lib.pika_las_mlp_attention(wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(),
                                                       ln.data_ptr(), qlist.data_ptr(), v.data_ptr(), CQ.data_ptr(), 2 * H,
@@ -367,13 +390,14 @@ class InputFeedRNNDecoder(nn.Module):
                         token_step()
         return outs, None
 
-    def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, n_active=None):
+    def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, spans=None, forks=None):
         """tokens (L,N) decoder inputs, context (S,N,H).  Returns outputs (L,N,H).
         With `owner` (N,) and `lens` (B,): context / enc_hidden are per UTTERANCE ((S,B,H), (layers,B,H)) and hypothesis
         n reads utterance owner[n], whose valid source positions are [0, lens[owner[n]])."""
         if owner is not None:
             if self._fused_ok(context):
-                return self._run_fused(tokens, context, enc_hidden, owner, lens, n_active)
+                return self._run_fused(tokens, context, enc_hidden, owner, lens, spans, forks)
+            assert forks is None, "prefix sharing needs the fused token loop"
             S = context.shape[0]
             context = context[:, owner].contiguous()
             enc_hidden = tuple(e[:, owner].contiguous() for e in enc_hidden)
@@ -457,44 +481,92 @@ class Net(nn.Module):
 
     def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None):
         """log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
-        owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).  The hypotheses go through the decoder sorted by
-        length so that step t only runs on those that still have a token (sum of lengths instead of count x longest),
-        and only the (step, hypothesis) pairs that exist are projected onto the vocabulary."""
+        owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).
+
+        Decoder step t of a hypothesis is a function of its first t tokens only, and the n-best entries of an utterance
+        are near-duplicates: the entries that share a prefix share the decoder rows of that prefix (a trie per utterance;
+        the first entry that has a prefix computes it).  A hypothesis gets a row of its own at the step it leaves every
+        earlier entry's prefix (`act`), where it inherits the recurrent state of the row that computed the prefix so far
+        (pika_las_fork_rows inside the captured token loop), and keeps it until its last token: step t runs on the rows
+        with act <= t < steps -- one per DISTINCT prefix of length t (every launch of the token loop takes a gather list of
+        rows).  The values are those of scoring every entry from scratch, as the reference does
+        (decoder/transducer_decoder.py:219-253).  Without sharing (PIKA_LAS_SHARE_PREFIXES=0, or the op-by-op decoder
+        path: training mode, CPU) step t runs on the hypotheses that still have a token.  Only the distinct (step, row)
+        pairs are projected onto the vocabulary."""
         import numpy as np
         dev = enc_out.device
         n = len(flat)
         ntok = np.array([len(h) + 1 for h in flat], dtype=np.int64)           # decoder steps of a hypothesis
-        perm = np.argsort(-ntok, kind="stable")
         L = int(ntok.max())
         pad = self.tgt_embeddings.padding_idx
+        own_h = owner.cpu().numpy()
+        # ---- the prefix tries: rep[i][t] = the first hypothesis of the utterance with the prefix flat[i][:t] ----
+        share = (os.environ.get("PIKA_LAS_SHARE_PREFIXES", "1") != "0" and owner is not None
+                 and self.decoder._fused_ok(enc_out))
+        rep = None
+        if share:
+            rep, act = [None] * n, np.full(n, L + 1, np.int64)
+            tries = {}
+            for i, h in enumerate(flat):
+                node = tries.setdefault(int(own_h[i]), {"who": i})
+                r = [node["who"]]
+                for tokv in h:
+                    node = node.setdefault(int(tokv), {"who": i})
+                    r.append(node["who"])
+                rep[i] = r
+                mine = [t for t, w in enumerate(r) if w == i]
+                if mine:
+                    act[i] = mine[0]
+                    assert mine == list(range(mine[0], len(r)))       # once on its own, a hypothesis stays on its own
+        perm = np.argsort(-ntok, kind="stable")
+        first = act[perm] if share else np.zeros(n, np.int64)
+        end = ntok[perm]
+        row_steps = int(np.maximum(end - first, 0).sum())
+        col_of = np.empty(n, np.int64)
+        col_of[perm] = np.arange(n)
         tok = np.full((L, n), pad, dtype=np.int64)
-        tgt = np.full((L, n), pad, dtype=np.int64)
         for col, i in enumerate(perm):
             h = flat[i]
             k = len(h) + 1
             tok[0, col] = sos
             tok[1:k, col] = h
-            tgt[:k - 1, col] = h
-            tgt[k - 1, col] = eos
-        n_active = (ntok[perm][None, :] > np.arange(L)[:, None]).sum(1)      # (L,), non-increasing
+        forks = None
+        if share:
+            f_t, f_dst, f_src = [], [], []
+            for i in range(n):
+                if 0 < act[i] <= L:
+                    f_t.append(int(act[i]))
+                    f_dst.append(int(col_of[i]))
+                    f_src.append(int(col_of[rep[i][act[i] - 1]]))
+            order = np.argsort(np.asarray(f_t, np.int64), kind="stable")
+            f_t = np.asarray(f_t, np.int64)[order]
+            fork_off = np.searchsorted(f_t, np.arange(L + 1)).astype(np.int32)
+            forks = (fork_off, np.asarray(f_dst, np.int32)[order], np.asarray(f_src, np.int32)[order])
         tok_d = torch.from_numpy(tok).to(dev)
         own = owner[torch.from_numpy(perm).to(owner.device)]
         _tick = _tick or (lambda name: None)
         _tick("host prep")
-        out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, n_active=n_active)
-        _tick("token loop (%d tokens, %d hypotheses, %d pairs)" % (L, n, int(n_active.sum())))
-        # the pairs (t, col) with col < n_active[t], step-major
-        tt = np.repeat(np.arange(L), n_active)
-        cc = np.concatenate([np.arange(k) for k in n_active])
-        rows = out[torch.from_numpy(tt).to(dev), torch.from_numpy(cc).to(dev)]                    # (R, H)
+        out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, spans=(first, end), forks=forks)
+        _tick("token loop (%d tokens, %d hypotheses, %d pairs, %d row steps)" % (L, n, int(ntok.sum()), row_steps))
+        self.last_pass = {"pairs": int(ntok.sum()), "row_steps": row_steps, "shared": bool(share)}
+        # the (step, hypothesis) pairs that exist, and the (step, row) each one reads
+        tt = np.concatenate([np.arange(k) for k in ntok])
+        ii = np.repeat(np.arange(n), ntok)
+        if share:
+            rr = col_of[np.concatenate([np.asarray(r, np.int64) for r in rep])]
+        else:
+            rr = col_of[ii]
+        tgt = np.concatenate([np.asarray(list(h) + [eos], np.int64) for h in flat])
+        key, inv = np.unique(tt * n + rr, return_inverse=True)                  # distinct (step, row) pairs
+        rows = out[torch.from_numpy(key // n).to(dev), torch.from_numpy(key % n).to(dev)]         # (R, H)
         logp = torch.log_softmax(scale * ops.linear(rows, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
-        want = torch.from_numpy(tgt[tt, cc]).to(dev).clamp(max=logp.shape[1] - 1)
-        picked = np.zeros((L, n), dtype=np.float32)
-        picked[tt, cc] = logp.gather(1, want.unsqueeze(1)).squeeze(1).cpu().numpy()
-        _tick("vocabulary projection + log-softmax + gather")
-        res = [None] * n
-        for col, i in enumerate(perm):
-            res[i] = picked[:ntok[i], col].tolist()
+        want = torch.from_numpy(tgt).to(dev).clamp(max=logp.shape[1] - 1)
+        picked = logp[torch.from_numpy(inv).to(dev), want].cpu().numpy()
+        _tick("vocabulary projection + log-softmax + gather (%d distinct rows)" % len(key))
+        res, o = [None] * n, 0
+        for i in range(n):
+            res[i] = picked[o:o + ntok[i]].tolist()
+            o += ntok[i]
         _tick("host lists")
         return res
 

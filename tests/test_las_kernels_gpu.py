@@ -31,7 +31,7 @@ def test_lstm_cell(hip_device, N, H):
     h2 = torch.full((N, 2 * H), -7.0, device=hip_device)
     with torch.cuda.device(hip_device):
         _lib.check(_lib.lib().pika_lstm_cell(gates.data_ptr(), gates.stride(0), c.data_ptr(), c.data_ptr(), h1.data_ptr(),
-                                             h1.stride(0), h2[:, H:].data_ptr(), h2.stride(0), N, H, None,
+                                             h1.stride(0), h2[:, H:].data_ptr(), h2.stride(0), N, H, None, None, None,
                                              torch.cuda.current_stream().cuda_stream), "pika_lstm_cell")
     assert (c.double() - c_ref).abs().max() < 2e-6 * max(1.0, c_ref.abs().max().item())
     assert (h1[:, :H].double() - h_ref).abs().max() < 2e-6 and torch.equal(h1[:, :H], h2[:, H:])
@@ -149,3 +149,43 @@ def test_blstm_encoder_matches_nn_lstm(hip_device, monkeypatch, S, B, D, H, In, 
         assert not enc._fused_ok(x.to(hip_device), lens, None)
         (h2, c2), out2 = enc(x.to(hip_device), lens)
     assert (out2 - out).abs().max().item() < 5e-5 and (h2 - h).abs().max().item() < 5e-5
+
+
+def test_prefix_sharing_gives_the_values_of_scoring_every_entry_from_scratch(hip_device, monkeypatch):
+    """n-best entries that share prefixes share decoder rows (tries per utterance, pika_las_fork_rows at the step an entry
+    leaves the shared prefix).  Lists with common prefixes of every kind -- duplicates, an entry that is a strict prefix of
+    an earlier and of a later one, entries that diverge at the first / last token, an empty entry, an utterance without
+    any sharing -- against the same pass with sharing off (every entry its own rows from step 0): identical values."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from trainer.model import las
+    net = las.Net(LC.opt("mlp"), LC.C_IN, LC.V, LC.PAD)
+    net.load_state_dict(seeded_state_dict(net, 32, scale=0.3))
+    net = net.to(hip_device).eval()
+    g = torch.Generator().manual_seed(6)
+    lens = [17, 23, 9, 12]
+    src = torch.zeros(23, 4, LC.C_IN)
+    for b, n in enumerate(lens):
+        src[:n, b] = torch.randn(n, LC.C_IN, generator=g)
+    src = src.to(hip_device)
+    base = [3, 7, 7, 12, 9, 4, 21, 5]
+    hyps = [[base, base[:5] + [30, 1], base, base[:3], base + [2, 2], [8] + base[1:], base[:7] + [6], []],
+            [[8, 1, 30, 2, 2, 19, 4], [8, 1, 30, 2, 2, 19], [8, 1, 30, 2, 2, 19, 4, 4, 4], [8, 1]],
+            [[11], [12], [13, 11]],
+            [[5, 5, 5, 5], [5, 5, 5, 5], [5, 5, 5], [5, 5, 5, 6]]]
+    res = {}
+    for share in ("1", "0"):
+        monkeypatch.setenv("PIKA_LAS_SHARE_PREFIXES", share)
+        res[share] = net.score_nbest_batch(src, lens, hyps, LC.SOS, LC.EOS)
+        info = dict(net.last_pass)
+        assert info["shared"] == (share == "1") and info["pairs"] == sum(len(h) + 1 for row in hyps for h in row)
+        if share == "1":
+            assert info["row_steps"] == 43          # the distinct prefixes of the lists above (114 pairs)
+    for a, b in zip(res["1"], res["0"]):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert len(x) == len(y) and np.allclose(x, y, rtol=0, atol=1e-6), (x, y)
+    # one utterance through score_nbest
+    monkeypatch.setenv("PIKA_LAS_SHARE_PREFIXES", "1")
+    one = net.score_nbest(src[:17, 0:1], hyps[0], LC.SOS, LC.EOS)
+    for x, y in zip(one, res["0"][0]):
+        assert np.allclose(x, y, rtol=0, atol=2e-5)
