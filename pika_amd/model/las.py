@@ -506,18 +506,26 @@ class Net(nn.Module):
         rep = None
         if share:
             rep, act = [None] * n, np.full(n, L + 1, np.int64)
-            tries = {}
-            for i, h in enumerate(flat):
-                node = tries.setdefault(int(own_h[i]), {"who": i})
-                r = [node["who"]]
-                for tokv in h:
-                    node = node.setdefault(int(tokv), {"who": i})
-                    r.append(node["who"])
+            roots = {}
+            for i, h in enumerate(flat):                    # a trie node: {token: child, -1: the entry that created it}
+                b = int(own_h[i])
+                node = roots.get(b)
+                if node is None:
+                    node = roots[b] = {-1: i}
+                r = [node[-1]]
+                a = 0 if node[-1] == i else None
+                for t, tokv in enumerate(h, 1):
+                    nxt = node.get(tokv)
+                    if nxt is None:
+                        nxt = node[tokv] = {-1: i}
+                    node = nxt
+                    w = node[-1]
+                    r.append(w)
+                    if a is None and w == i:
+                        a = t                               # from here on every node of the path is new: created by i
                 rep[i] = r
-                mine = [t for t, w in enumerate(r) if w == i]
-                if mine:
-                    act[i] = mine[0]
-                    assert mine == list(range(mine[0], len(r)))       # once on its own, a hypothesis stays on its own
+                if a is not None:
+                    act[i] = a
         perm = np.argsort(-ntok, kind="stable")
         first = act[perm] if share else np.zeros(n, np.int64)
         end = ntok[perm]
