@@ -283,6 +283,7 @@ def decode_workload(args, dev, rank):
     las_fw = las_bw = None
     SOS, EOS, PAD = V, V + 1, V + 2
     if args.las:   # forward + backward LAS rescorers, 2-layer BLSTM 1024, mlp attention, random weights
+        os.environ.setdefault("PIKA_LAS_TIMING", "1")       # phase times of a rescoring pass into the line (las_phases_ms)
         from trainer.model import las
         lopt = SimpleNamespace(rnn_size=1024, encoder_type="rnn", rnn_type="LSTM", brnn=True, enc_layers=2,
                                dropout=0.0, use_downsampler=False, embd_dim=100, num_heads=1, sampling_decoder=False,
@@ -751,7 +752,7 @@ def leg_decode(args, R_, with_cpu):
                 d["with_fst_and_las"] = {
                     "value": fd["value"], "unit": "RTF", "ms_per_step": fd["ms_per_step"],
                     "search_s": tm["search_s"], "las_rescoring_s": tm["las_s"], "launches_per_step": tm["launches_per_step"],
-                    "las_row_steps": tm.get("las_row_steps"),
+                    "las_row_steps": tm.get("las_row_steps"), "las_phases_ms": tm.get("las_phases_ms"),
                     "labels_per_utt_top1": fd["config"]["labels_per_utt_top1"],
                     "note": "configs[4] in full: bigram FST shallow fusion inside the launch chain (scale %.2f) + fw/bw LAS "
                             "rescoring of all %d x %d hypotheses as one per-token kernel chain per model; synthetic LM and "

@@ -505,6 +505,11 @@ class Net(nn.Module):
                  and self.decoder._fused_ok(enc_out))
         rep = None
         if share:
+            # (the tries are tens of thousands of small dicts: with the cyclic collector on, their allocation triggers
+            # full collections over whatever heap the host program has -- 80 ms per pass inside a training script)
+            import gc
+            gc_was_on = gc.isenabled()
+            gc.disable()
             rep, act = [None] * n, np.full(n, L + 1, np.int64)
             roots = {}
             for i, h in enumerate(flat):                    # a trie node: {token: child, -1: the entry that created it}
@@ -526,6 +531,9 @@ class Net(nn.Module):
                 rep[i] = r
                 if a is not None:
                     act[i] = a
+            del roots
+            if gc_was_on:
+                gc.enable()
         perm = np.argsort(-ntok, kind="stable")
         first = act[perm] if share else np.zeros(n, np.int64)
         end = ntok[perm]
