@@ -115,9 +115,12 @@ class TransducerDecoder(object):
                 raise ValueError("unknown decode_precision %r" % (self.decode_precision,))
             G.PRECISION = self.decode_precision if self.decode_precision in ("bf16x3", "bf16") else "fp32"
         try:
-            return self._decode_batch(x, x_len, max_len)
+            ret, enc_out = self._decode_batch(x, x_len, max_len)
         finally:
             G.PRECISION = old
+        # what las_rescore / bilas_rescore will be asked about next (batch-ahead scoring, below)
+        self._nbest = {"enc_out": enc_out, "hyps": ret["predictions"], "scores": {}}
+        return ret, enc_out
 
     def _decode_batch(self, x, x_len, max_len=None):
         model, K = self.model, self.beam_size
@@ -306,15 +309,51 @@ def _las_scores(rescorer, x, tgt, scale=1.0):
     return logp[torch.arange(idx.size(0)), idx].tolist()
 
 
+def _batch_ahead(self, which, rescorer, x, tgt, scale):
+    """The reference decode script asks for the rescorer's scores ONE hypothesis at a time, 2 x batch x n_best calls per
+    decode batch (decode_transducer.py:136-156), each a batch-1 encoder pass and a batch-1 token loop.  The n-best lists
+    it will ask about are known since decode_batch returned them: the first call of a batch (per rescorer) scores ALL of
+    them in one batched pass (las.Net.score_nbest_batch: one encoder pass, one token loop whose entries share their
+    common prefixes) and the calls look their answer up -- same values (tests/test_las.py).  Returns None when the call
+    is not about the last decode batch (or PIKA_LAS_BATCH_AHEAD=0): the caller then scores the hypothesis on its own."""
+    import os
+    nb = getattr(self, "_nbest", None)
+    if nb is None or os.environ.get("PIKA_LAS_BATCH_AHEAD", "1") == "0" or not hasattr(rescorer, "score_nbest_batch"):
+        return None
+    enc = nb["enc_out"]
+    if x.dim() != 3 or x.shape[1] != 1 or x.shape[0] != enc.shape[1] or x.device != enc.device or tgt.shape[0] < 2:
+        return None
+    row = enc.stride(0) * enc.element_size()
+    off = x.data_ptr() - enc.data_ptr()
+    if off < 0 or off % row or off // row >= enc.shape[0] or x.stride(0) != enc.stride(1):
+        return None                                        # not a row of the last batch's encoder output
+    i = off // row
+    toks = tgt.view(-1).tolist()
+    sos, eos, hyp = toks[0], toks[-1], tuple(toks[1:-1])
+    key = (which, sos, eos)
+    table = nb["scores"].get(key)
+    if table is None:
+        B = enc.shape[0]
+        lists = [[[int(e) for e in h if int(e) != self.blk] for h in nb["hyps"][b]] for b in range(B)]
+        if which == "bw":
+            lists = [[h[::-1] for h in row_] for row_ in lists]
+        got = rescorer.score_nbest_batch(enc.transpose(0, 1), [enc.shape[1]] * B, lists, sos, eos, scale=scale)
+        table = nb["scores"][key] = {(b, tuple(h)): sc for b in range(B) for h, sc in zip(lists[b], got[b])}
+    return table.get((i, hyp))
+
+
 def las_rescore(self, x, tgt, bw=False):
     """x (T,1,C) encoder output of one utterance, tgt (L,1,1) = [SOS] + hyp + [EOS]."""
     with torch.no_grad():
-        return _las_scores(self.las_rescorer_bw if bw else self.las_rescorer, x, tgt)
+        rescorer = self.las_rescorer_bw if bw else self.las_rescorer
+        got = _batch_ahead(self, "bw" if bw else "fw", rescorer, x, tgt, 1.0)
+        return got if got is not None else _las_scores(rescorer, x, tgt)
 
 
 def bilas_rescore(self, x, tgt):
     with torch.no_grad():
-        return _las_scores(self.bilas_rescorer, x, tgt, scale=0.5)
+        got = _batch_ahead(self, "bi", self.bilas_rescorer, x, tgt, 0.5)
+        return got if got is not None else _las_scores(self.bilas_rescorer, x, tgt, scale=0.5)
 
 
 TransducerDecoder.las_rescore = las_rescore

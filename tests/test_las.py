@@ -122,3 +122,71 @@ def test_gpu_las_training_step_matches_reference(hip_device):
         _las_training_step(hip_device)
     finally:
         G.PRECISION = old
+
+
+def _script_loop(device, batch_ahead, monkeypatch):
+    """The rescoring part of decode_transducer.py:130-156 on a tiny transducer + tiny forward / backward rescorers: decode
+    a batch, then ask for the scores one (utterance, n-best entry, direction) at a time."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    import decode_common as D
+    from test_decode import build
+    from trainer.model import las
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    monkeypatch.setenv("PIKA_LAS_BATCH_AHEAD", "1" if batch_ahead else "0")
+    net = build("transformer", device)
+    x, x_len = D.inputs()
+    x, x_len = x.to(device), x_len.to(device)
+    C_enc = net.hid_dim
+    V = net.output_dim
+    sos, eos, pad = V, V + 1, V + 2
+    rescorers = []
+    for seed in (31, 32):
+        r = las.Net(LC.opt("mlp"), C_enc, V + 2, pad)
+        r.load_state_dict(seeded_state_dict(r, seed, scale=0.3))
+        rescorers.append(r.eval().to(device))
+    args = SimpleNamespace(las_rescorer=rescorers[0], las_rescorer_bw=rescorers[1], bilas_rescorer=None, nonblk_reward=0.0)
+    d = TransducerDecoder(net, batch_size=x.shape[0], beam_size=4, n_best=4, blk=0, global_scorer=GlobalScorer(),
+                          sm_scale=0.8, cuda=(device != "cpu"), beam_prune=True, args=args)
+    ret, enc_out = d.decode_batch(x, x_len, [int(v) + 100 for v in x_len])
+    out = []
+    for i in range(x.shape[0]):
+        for j in range(4):
+            hyp = [e.item() for e in ret["predictions"][i][j] if e != 0]
+            las_in = enc_out[i].unsqueeze(1)
+            tgt = torch.LongTensor([sos] + hyp + [eos]).to(device).unsqueeze(-1).unsqueeze(-1)
+            fw = d.las_rescore(las_in, tgt)
+            tgt = torch.LongTensor([sos] + hyp[::-1] + [eos]).to(device).unsqueeze(-1).unsqueeze(-1)
+            bw = d.las_rescore(las_in, tgt, bw=True)
+            assert len(fw) == len(bw) == len(hyp) + 1
+            out.append((fw, bw))
+    # a question that is not about the last batch falls back to scoring on its own
+    other = torch.randn_like(enc_out[0]).unsqueeze(1)
+    tgt = torch.LongTensor([sos, 3, 4, eos]).to(device).unsqueeze(-1).unsqueeze(-1)
+    assert len(d.las_rescore(other, tgt)) == 3
+    return out, (d._nbest["scores"] if batch_ahead else None)
+
+
+def test_batch_ahead_rescoring_answers_the_script_loop_with_the_per_hypothesis_values(monkeypatch):
+    """The unchanged decode script asks for LAS scores one hypothesis at a time; the decoder answers from ONE batched pass
+    per rescorer over the n-best lists decode_batch returned (transducer_decoder._batch_ahead).  Same values as scoring
+    every hypothesis on its own, on the CPU path."""
+    ahead, tables = _script_loop("cpu", True, monkeypatch)
+    alone, _ = _script_loop("cpu", False, monkeypatch)
+    assert set(k[0] for k in tables) == {"fw", "bw"}            # one batched pass per rescorer, both were used
+    for (f1, b1), (f2, b2) in zip(ahead, alone):
+        assert np.allclose(f1, f2, rtol=1e-5, atol=1e-5) and np.allclose(b1, b2, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_ahead_rescoring_answers_the_script_loop(hip_device, monkeypatch):
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        ahead, tables = _script_loop(hip_device, True, monkeypatch)
+        alone, _ = _script_loop(hip_device, False, monkeypatch)
+    finally:
+        G.PRECISION = old
+    assert set(k[0] for k in tables) == {"fw", "bw"}
+    for (f1, b1), (f2, b2) in zip(ahead, alone):
+        assert np.allclose(f1, f2, rtol=1e-4, atol=1e-4) and np.allclose(b1, b2, rtol=1e-4, atol=1e-4)
