@@ -56,6 +56,21 @@ def test_dgemm_bias_relu_residual_scatter(hip_device, terms, tol, M, N, K):
     got = C[:, :N].double()
     assert (got[crow[:M - 7]] - want[:M - 7]).abs().max().item() <= tol * scale
     assert torch.all(C[crow[M - 7:]][:, :N] == 7.0)
+    # gather lists: launch row e stands for row rowlist[off + e] of A, res and C (LAS token loop: the step's active rows)
+    n_e = max(M // 3, 1)
+    off = 5
+    rl = torch.cat([torch.full((off,), -1, dtype=torch.int32), torch.randperm(M, generator=g)[:n_e].to(torch.int32)])
+    rl_d, off_d = rl.to(hip_device), torch.tensor([off], dtype=torch.int32, device=hip_device)
+    ne_d = torch.tensor([n_e], dtype=torch.int32, device=hip_device)
+    C.fill_(7.0)
+    d.crow, d.m_dev, d.rowlist, d.rowoff_dev = None, ne_d.data_ptr(), rl_d.data_ptr(), off_d.data_ptr()
+    _lib.check(_lib.lib().pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm")
+    rows = rl[off:].long().to(hip_device)
+    got = C[:, :N].double()
+    assert (got[rows] - want[rows]).abs().max().item() <= tol * scale
+    rest = torch.ones(M, dtype=torch.bool, device=hip_device)
+    rest[rows] = False
+    assert torch.all(C[rest][:, :N] == 7.0)
 
 
 def test_dgemm_gate_epilogue(hip_device):

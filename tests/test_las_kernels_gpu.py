@@ -1,6 +1,7 @@
 """Per-token kernels of LAS rescoring (include/pika_las.h) vs the torch formulas of the reference modules
 (modules/global_attention.py:162-248 "mlp" attention; nn.LSTMCell as stacked by modules/stacked_rnn.py:20-34), and
 the fused scoring pass of pika_amd.model.las against its own op-by-op pass on a ragged decode batch."""
+import ctypes
 import os
 import sys
 
@@ -189,3 +190,64 @@ def test_prefix_sharing_gives_the_values_of_scoring_every_entry_from_scratch(hip
     one = net.score_nbest(src[:17, 0:1], hyps[0], LC.SOS, LC.EOS)
     for x, y in zip(one, res["0"][0]):
         assert np.allclose(x, y, rtol=0, atol=2e-5)
+
+
+def test_fork_rows_and_row_lists(hip_device):
+    """pika_las_fork_rows (segments of row dst <- row src for the forks of step t only) and the gather-list forms of
+    pika_lstm_cell / pika_las_embed_rows (launch row e stands for row rowlist[off + e])."""
+    from pika_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    N, W1, W2 = 13, 40, 24
+    a = torch.randn(N, W1, generator=g).to(hip_device)
+    b = torch.randn(N, W2, generator=g).to(hip_device)
+    a0, b0 = a.clone(), b.clone()
+    step = torch.tensor([2, 0, 0, 0], dtype=torch.int32, device=hip_device)
+    fork_off = torch.tensor([0, 0, 1, 4, 4], dtype=torch.int32, device=hip_device)       # step 2: forks 1..3
+    dst = torch.tensor([9, 3, 7, 11], dtype=torch.int32, device=hip_device)
+    src = torch.tensor([0, 1, 1, 5], dtype=torch.int32, device=hip_device)
+    st = torch.cuda.current_stream().cuda_stream
+    base = (ctypes.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+    ld = (ctypes.c_longlong * 2)(W1, W2)
+    col0 = (ctypes.c_int * 2)(8, 0)
+    ncols = (ctypes.c_int * 2)(16, 24)
+    with torch.cuda.device(hip_device):
+        _lib.check(lib.pika_las_fork_rows(step.data_ptr(), fork_off.data_ptr(), dst.data_ptr(), src.data_ptr(), 3, 2,
+                                          base, ld, col0, ncols, st), "pika_las_fork_rows")
+    want_a, want_b = a0.clone(), b0.clone()
+    for d_, s_ in ((3, 1), (7, 1), (11, 5)):
+        want_a[d_, 8:24] = a0[s_, 8:24]
+        want_b[d_] = b0[s_]
+    assert torch.equal(a, want_a) and torch.equal(b, want_b)
+    # LSTM cell on a gather list
+    H = 8
+    gates = torch.randn(N, 4 * H, generator=g).to(hip_device)
+    c = torch.randn(N, H, generator=g).to(hip_device)
+    c_ref = c.clone()
+    h = torch.full((N, H), -7.0, device=hip_device)
+    rl = torch.tensor([-1, -1, 4, 12, 0], dtype=torch.int32, device=hip_device)
+    off = torch.tensor([2], dtype=torch.int32, device=hip_device)
+    n = torch.tensor([3], dtype=torch.int32, device=hip_device)
+    with torch.cuda.device(hip_device):
+        _lib.check(lib.pika_lstm_cell(gates.data_ptr(), 4 * H, c.data_ptr(), c.data_ptr(), h.data_ptr(), H, None, 0, N, H,
+                                      n.data_ptr(), rl.data_ptr(), off.data_ptr(), st), "pika_lstm_cell")
+    i_, f_, g_, o_ = gates.double().chunk(4, dim=1)
+    cn = torch.sigmoid(f_) * c_ref.double() + torch.sigmoid(i_) * torch.tanh(g_)
+    hn = torch.sigmoid(o_) * torch.tanh(cn)
+    rows = [4, 12, 0]
+    others = [r for r in range(N) if r not in rows]
+    assert (c[rows].double() - cn[rows]).abs().max() < 2e-6 and (h[rows].double() - hn[rows]).abs().max() < 2e-6
+    assert torch.equal(c[others], c_ref[others]) and bool((h[others] == -7.0).all())
+    # embedding rows on the step's list
+    E, V = 12, 20
+    emb = torch.randn(V, E, generator=g).to(hip_device)
+    tokens = torch.randint(0, V, (4, N), generator=g).to(hip_device)
+    x0 = torch.full((N, E + 4), -7.0, device=hip_device)
+    crow = torch.full((N,), -1, dtype=torch.long, device=hip_device)
+    step = torch.tensor([2, 3, 2, 0], dtype=torch.int32, device=hip_device)              # t = 2, n = 3, list offset 2
+    with torch.cuda.device(hip_device):
+        _lib.check(lib.pika_las_embed_rows(step.data_ptr(), tokens.data_ptr(), emb.data_ptr(), x0.data_ptr(), E + 4,
+                                           crow.data_ptr(), N, E, rl.data_ptr(), st), "pika_las_embed_rows")
+    for r in rows:
+        assert torch.equal(x0[r, :E], emb[tokens[2, r]]) and int(crow[r]) == 2 * N + r
+    assert bool((x0[others] == -7.0).all()) and bool((crow[others] == -1).all()) and bool((x0[:, E:] == -7.0).all())
