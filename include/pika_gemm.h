@@ -58,6 +58,9 @@ typedef struct {
 #define PIKA_GEMM_FP32SPLIT 4
 #define PIKA_GEMM_OUT_BF16 8   /* C points to a bf16 matrix (pitch ldc elements); only for bf16 x bf16 products the
                                 * direct-to-LDS kernel takes (K % 64 == 0, >= 160 output tiles), else PIKA_EINVAL */
+#define PIKA_GEMM_F16_OPERANDS 16 /* the 16-bit operands (dtype PIKA_BF16 in the descriptors) hold FP16 bit patterns: the
+                                * segments pika_split_bf16_terms(n_terms = 4) writes.  Only the plain product with fp32
+                                * output on the direct-to-LDS kernel (v_mfma_f32_16x16x32_f16), else PIKA_EINVAL */
 
 /* Requirements (16-byte operand loads): K % 4 == 0 unless both operands are `trans` (then the output
  * extents M / N must be multiples of g instead); with g = 4 for f32 / 8 for bf16 operands, C,

@@ -40,6 +40,11 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
  *   n_terms = 3 (fp32-exact):  A [t0 | t0 | t1 | t0 | t2 | t1]   B [t0 | t1 | t0 | t2 | t0 | t1]
  *       -> the six products PIKA_GEMM_FP32SPLIT issues (everything above 2^-24 of the leading one), at a sixth of
  *       the bf16 rate of the direct-to-LDS kernels instead of a sixth of the register-staged kernel's.
+ *   n_terms = 4 (two FP16 terms, PIKA_SPLIT_CONCAT only; the product must be issued with PIKA_GEMM_F16_OPERANDS):
+ *       x = hi + lo, hi = fp16(x), 22 mantissa bits;   A [hi | 32 lo | hi / 64]   B [hi | hi / 32 | 64 lo]
+ *       -> hi.hi + lo.hi + hi.lo in ONE accumulator: the power-of-two factors cancel in every product and keep the
+ *       small terms out of fp16's subnormal range.  An fp32 product to ~2^-22 at a third of the 16-bit rate (the
+ *       three-term bf16 split: exact, a sixth).  Inputs saturate at +-65504.
  * Source: n_batch blocks (batch_stride apart) of t_in rows (pitch ld) x C columns, f32, C % 8 == 0.  S = 3 or 6
  * segments.
  *   PIKA_SPLIT_CONCAT: dst (n_batch, t_in, S*Cp) bf16, segment s of a row at columns [s*Cp, s*Cp + C), the pad

@@ -176,6 +176,7 @@ struct PPArgs {
     float *lse_pm, *lse_ps;
     int lse_np;
     int nx, ntiles;                    // output tiles per row of tiles / in total (filled in by launch_pp_epi)
+    int f16;                           // the 16-bit operands are fp16 (EPI 0 only: PIKA_GEMM_F16_OPERANDS)
 #ifdef PIKA_PP_TRACE
     unsigned long long *trace;         // tools/pp_trace.hip: [wg < 8][group 2][tile < 16][24] time stamps
 #endif
@@ -200,7 +201,7 @@ __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast
 // EPI 2: out16 bf16 = scale * (A B^T) where aux > 0, else 0  (ReLU + dropout backward in one mask).
 // EPI 3: C f32 = dropout(A B^T + bias) + res  (projection + residual dropout + residual add).
 // BOUNDS: A is a padded time-delay view (rows whose source time leaves the signal read the zero page)
-template <int EPI, bool BOUNDS>
+template <int EPI, bool BOUNDS, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int M = P.M, N = P.N;
@@ -342,7 +343,13 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[ia + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j0 + j][kk], fa[i][kk], acc[ia + i][j0 + j], 0, 0, 0);
+                    if constexpr (F16) {       // the operands hold fp16 bit patterns (PIKA_GEMM_F16_OPERANDS)
+                        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                        acc[ia + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                            __builtin_bit_cast(h8, fb[j0 + j][kk]), __builtin_bit_cast(h8, fa[i][kk]), acc[ia + i][j0 + j], 0, 0, 0);
+                    } else {
+                        acc[ia + i][j0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j0 + j][kk], fa[i][kk], acc[ia + i][j0 + j], 0, 0, 0);
+                    }
         __builtin_amdgcn_s_setprio(0);
     };
     int gt = 0, cur_slot = blockIdx.x;   // K-tiles consumed so far (parity = LDS buffer); the tile being accumulated
@@ -937,6 +944,24 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
         return cus & ~7;
     }();
     const int grid = (wgs >= 8 && nt > wgs) ? (wgs & ~7) : (int)nt;
+    if (Q.f16) {
+        if constexpr (EPI == 0) {
+            static bool attr16 = false;
+            if (!attr16) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<0, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp<0, true, true>),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
+                if (e != hipSuccess) return (int)e;
+                attr16 = true;
+            }
+            if (Q.a_bounds) hipLaunchKernelGGL((gemm_pp<0, true, true>), dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
+            else hipLaunchKernelGGL((gemm_pp<0, false, true>), dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
+            return (int)hipGetLastError();
+        } else {
+            return PIKA_EINVAL;
+        }
+    }
     if (Q.a_bounds) {
         if constexpr (EPI <= 1) hipLaunchKernelGGL((gemm_pp<EPI, true>), dim3(grid), dim3(512), 2 * PP_BUF, s, Q);
         else return PIKA_EINVAL;
@@ -1089,9 +1114,10 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
                           int M, int N, int K, const float *bias, int flags, void *ws, size_t ws_bytes,
                           hipStream_t s) {
     if (A->dtype != PIKA_BF16 || B->dtype != PIKA_BF16 || (A->trans != 0) != (B->trans != 0)) return PIKA_NOT_APPLICABLE;
-    const bool out16 = (flags & PIKA_GEMM_OUT_BF16) != 0;
+    const bool out16 = (flags & PIKA_GEMM_OUT_BF16) != 0, f16 = (flags & PIKA_GEMM_F16_OPERANDS) != 0;
+    if (f16 && (A->trans || out16)) return PIKA_NOT_APPLICABLE;     // fp16 operands: the plain product with fp32 output only
     if (A->trans) return out16 ? PIKA_NOT_APPLICABLE : launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, ws, ws_bytes, s);
-    if (flags & ~(PIKA_GEMM_RELU | PIKA_GEMM_OUT_BF16)) return PIKA_NOT_APPLICABLE;
+    if (flags & ~(PIKA_GEMM_RELU | PIKA_GEMM_OUT_BF16 | PIKA_GEMM_F16_OPERANDS)) return PIKA_NOT_APPLICABLE;
     if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & (out16 ? 7 : 15))) return PIKA_NOT_APPLICABLE;
     // B: plain matrix
     if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
@@ -1102,6 +1128,7 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     P.B = static_cast<const __bf16 *>(B->ptr);
     P.C = C; P.bias = bias; P.ldb = B->ld; P.ldc = ldc;
     P.M = M; P.N = N; P.K = K; P.relu = (flags & PIKA_GEMM_RELU) ? 1 : 0;
+    P.f16 = f16 ? 1 : 0;
     if (!pp_offsets_fit(P)) return PIKA_NOT_APPLICABLE;
     if (out16) {   // C is a bf16 matrix with pitch ldc: plain bf16 epilogue (no dropout)
         P.out16 = reinterpret_cast<__bf16 *>(C); P.ldo16 = ldc; P.thr = 0; P.scale = 1.f;

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256) void split_terms_kernel(const float *__restric
                                                           long long batch_stride, long long ld, unsigned pattern,
                                                           long long seg_stride, long long dst_batch,
                                                           long long dst_ld, long long n_gran,
-                                                          __bf16 *__restrict__ dst) {
+                                                          __bf16 *__restrict__ dst, int f16_role) {
     typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_gran) return;
     const int gpr = Cp >> 3;                       // granules per destination row
@@ -173,6 +174,25 @@ __global__ __launch_bounds__(256) void split_terms_kernel(const float *__restric
         const float4 *src = reinterpret_cast<const float4 *>(x + b * batch_stride + (long long)t * ld + c);
         const float4 v0 = src[0], v1 = src[1];
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (f16_role) {
+            // two fp16 terms x = hi + lo (22 mantissa bits) for ONE accumulator: the three segments of the two sides are
+            //   A: [hi | lo * 32 | hi / 64]      B: [hi | hi / 32 | lo * 64]     -> hi.hi + lo_a.hi_b + hi_a.lo_b
+            // the power-of-two factors keep the small terms out of fp16's subnormal range (lo ~ 2^-12 |x|) and cancel in
+            // every product; inputs saturate at +-65504
+            h8 t0, t1, t2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x_ = fminf(fmaxf(v[i], -65504.f), 65504.f);
+                const _Float16 h = (_Float16)x_;
+                const float lo = x_ - (float)h;        // exact in fp32
+                t0[i] = h;
+                t1[i] = f16_role == 1 ? (_Float16)(lo * 32.f) : (_Float16)((float)h * (1.f / 32.f));
+                t2[i] = f16_role == 1 ? (_Float16)((float)h * (1.f / 64.f)) : (_Float16)(lo * 64.f);
+            }
+            term[0] = __builtin_bit_cast(bf8, t0);
+            term[1] = __builtin_bit_cast(bf8, t1);
+            term[2] = __builtin_bit_cast(bf8, t2);
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const __bf16 h = (__bf16)v[i];
@@ -181,6 +201,7 @@ __global__ __launch_bounds__(256) void split_terms_kernel(const float *__restric
             term[0][i] = h;
             term[1][i] = m;
             term[2][i] = (__bf16)(r1 - (float)m);  // exact: what is left fits 8 bits
+        }
         }
     } else {
 #pragma unroll
@@ -249,7 +270,8 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
 int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
                           int role, int n_terms, int layout, int Cp, void *dst, void *stream) {
     if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
-    if (n_terms != 2 && n_terms != 3) return PIKA_EINVAL;
+    if (n_terms != 2 && n_terms != 3 && n_terms != 4) return PIKA_EINVAL;
+    if (n_terms == 4 && layout != PIKA_SPLIT_CONCAT) return PIKA_EINVAL;
     if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK && layout != PIKA_SPLIT_PAIR) return PIKA_EINVAL;
     if (layout == PIKA_SPLIT_PAIR && n_terms != 2) return PIKA_EINVAL;
     if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
@@ -258,7 +280,8 @@ int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long lon
     const long long rows = (long long)n_batch * t_in;
     const long long n_gran = rows * (Cp >> 3);
     if ((n_gran + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
-    const int nseg = layout == PIKA_SPLIT_PAIR ? 2 : (n_terms == 2 ? 3 : 6);
+    const int nseg = layout == PIKA_SPLIT_PAIR ? 2 : (n_terms == 3 ? 6 : 3);
+    const int f16_role = n_terms == 4 ? 1 + role : 0;
     long long seg_stride, dst_batch, dst_ld;
     if (layout == PIKA_SPLIT_PAIR) { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
     else if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
@@ -268,18 +291,19 @@ int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long lon
     static const unsigned pat[2][2] = {{0u | 1u << 2 | 0u << 4, 0u | 0u << 2 | 1u << 4},
                                        {0u | 0u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 1u << 10,
                                         0u | 1u << 2 | 0u << 4 | 2u << 6 | 0u << 8 | 1u << 10}};
-    const unsigned pattern = layout == PIKA_SPLIT_PAIR ? (0u | 1u << 2) : pat[n_terms - 2][role];
+    const unsigned pattern = layout == PIKA_SPLIT_PAIR ? (0u | 1u << 2)
+                             : (n_terms == 4 ? (0u | 1u << 2 | 2u << 4) : pat[n_terms - 2][role]);
     const dim3 grid((unsigned)((n_gran + 255) / 256));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (nseg == 2)
         hipLaunchKernelGGL(split_terms_kernel<2>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
-                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
+                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst), f16_role);
     else if (nseg == 3)
         hipLaunchKernelGGL(split_terms_kernel<3>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
-                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
+                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst), f16_role);
     else
         hipLaunchKernelGGL(split_terms_kernel<6>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
-                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst));
+                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst), f16_role);
     return (int)hipGetLastError();
 }
 

@@ -53,17 +53,22 @@ class TransducerDecoder(object):
         # (3 = fp32-exact products; 2 = hi.hi + hi.lo + lo.hi, an fp32 product to ~2^-17; 1 = plain bf16 operands)
         import os
         self.fused_search = os.environ.get("PIKA_DECODE_FUSED_SEARCH", "1") != "0"
-        # decode_precision "fp32" (default): fp32-grade products everywhere.  The encoder and the joint halves (once per
-        # batch) run on three bf16 terms per operand, six MFMA products: exact fp32 products.  The step products (prediction
-        # network, joint, fc2: 340 steps per batch) run on two fp16 terms per operand (include/pika_decode_step.h, terms = 4:
-        # 22 mantissa bits per operand, hi.hi and the cross products in separate accumulators: an fp32 product to ~2^-22
-        # with three MFMAs).  On the full-width golden every n-best entry separated from its neighbours by > 1e-3 in score
-        # sits at its reference rank and scores agree within 3e-4 -- the same as with exact step products
-        # (decode_precision "fp32-exact": three bf16 terms there too, 17 % more search time).
+        # decode_precision "fp32" (default): fp32-grade products everywhere, on two FP16 terms per operand (22 mantissa bits:
+        # an fp32 product to ~2^-22 with three MFMA products instead of the six of the exact three-term bf16 split).
+        # The step products (prediction network, joint, fc2: 340 steps per batch): include/pika_decode_step.h, terms = 4
+        # (second term kept at the first one's magnitude, cross products in their own accumulator).  The encoder and the
+        # joint halves (once per batch): pika_amd.gemm precision "fp16x2" (three K-concatenated segments with power-of-two
+        # factors, one accumulator) where the direct-to-LDS kernel takes the product, exact products elsewhere
+        # (PIKA_DECODE_ENCODER_PRECISION=fp32: exact everywhere).  On the full-width golden every n-best entry separated
+        # from its neighbours by > 1e-3 in score sits at its reference rank and scores agree within 3e-4 -- the same as
+        # with exact products throughout (decode_precision "fp32-exact": three bf16 terms, 17 % more search time, 16 ms
+        # more encoder time per batch); at bench size the encoder output differs from the exact one by the exact mode's
+        # own accumulation noise (tests/test_decode_full.py).
         # "bf16x3": two bf16 terms per operand everywhere (an fp32 product to ~2^-17; encoder 20 ms faster per batch, top-1
         # and greedy hypotheses identical to the reference's, scores within 2e-3: tools/decode_two_term_check.py).
         # "bf16": plain bf16 operands.
         self.decode_precision = os.environ.get("PIKA_DECODE_PRECISION", "fp32")
+        self.encoder_precision = os.environ.get("PIKA_DECODE_ENCODER_PRECISION", "fp16x2")
         self.replays_per_sync = 4
         self.groups_in_flight = 3       # groups of replays queued ahead of the host's look at the stop flag
 
@@ -113,7 +118,11 @@ class TransducerDecoder(object):
         if x.is_cuda:
             if self.decode_precision not in ("fp32", "fp32-exact", "fp16x2", "bf16x3", "bf16"):
                 raise ValueError("unknown decode_precision %r" % (self.decode_precision,))
-            G.PRECISION = self.decode_precision if self.decode_precision in ("bf16x3", "bf16") else "fp32"
+            # the large products of a decode (encoder, joint halves: once per batch): two bf16 terms / one term in those
+            # modes; otherwise fp32-grade -- PIKA_DECODE_ENCODER_PRECISION = "fp32" (three bf16 terms, exact products, six
+            # segments) or "fp16x2" (two fp16 terms, ~2^-22, three segments; pika_amd.gemm)
+            G.PRECISION = self.decode_precision if self.decode_precision in ("bf16x3", "bf16") else (
+                "fp32" if self.decode_precision == "fp32-exact" else self.encoder_precision)
         try:
             ret, enc_out = self._decode_batch(x, x_len, max_len)
         finally:

@@ -28,7 +28,11 @@ RELU, ACCUMULATE, FP32SPLIT = 1, 2, 4
 # is the arithmetic whose encoder activations and loss are within 1e-3 of the reference's (tests/test_model_full.py);
 # PIKA_GEMM_PRECISION=bf16 buys 15 % of step time at 3e-2.
 PRECISION = os.environ.get("PIKA_GEMM_PRECISION", "mixed")
-PRECISIONS = ("bf16", "bf16x3", "fp32", "mixed")
+PRECISIONS = ("bf16", "bf16x3", "fp32", "mixed", "fp16x2")
+# "fp16x2" (inference products: the decoder's encoder pass, the rescorer): every fp32 operand as two FP16 terms (22 mantissa
+#           bits), hi.hi + lo.hi + hi.lo as ONE fp16 product over a three times longer reduction (pika_split_bf16_terms
+#           n_terms = 4: power-of-two factors keep the small terms normal and cancel in the products) -- an fp32 product to
+#           ~2^-22 at half the cost of the exact six-segment path; products the direct-to-LDS kernel does not take run exact.
 # "bf16x3": the joint's lattice products (fc2 over the (B,T,U) lattice and its two gradient products: half of a training
 # step's FLOPs, on a hidden the gate kernel writes once) stay in the config-2 bf16 arithmetic by default -- the
 # encoder, the prediction network and the joint's projections are what the parity statement (encoder activations,
@@ -44,6 +48,7 @@ def joint_in_bf16():
 def bf16_backward():
     """Modes whose backward products run on one bf16 term (and whose activations between MFMA products are bf16 planes)."""
     return PRECISION in ("bf16", "mixed")
+FP16X2_STATS = {"fast": 0, "exact": 0}     # "fp16x2" products on the three-segment fp16 path / handed to the exact path
 BF16X3_STATS = {"fast": 0, "exact": 0}     # "bf16x3" products taken by the split path / handed to the exact path
 FP32_STATS = {"concat": 0, "staged": 0}    # "fp32" products on the six-segment path / on the register-staged kernel
 
@@ -101,6 +106,7 @@ def _flags(relu, accumulate, precision):
 
 
 OUT_BF16 = 8
+F16_OPERANDS = 16
 # "fp32" products of direct-to-LDS size as ONE bf16 product over six term segments (PIKA_FP32_CONCAT=0: always the
 # register-staged exact kernel)
 FP32_CONCAT = os.environ.get("PIKA_FP32_CONCAT", "1") != "0"
@@ -127,7 +133,7 @@ def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_t
     """bf16 term-segment copy of an f32 source (pika_split_bf16_terms: 3 segments for two terms, 6 for three);
     returns the tensor (flat)."""
     rows = n_batch * t_in
-    nseg = 3 if n_terms == 2 else 6
+    nseg = 6 if n_terms == 3 else 3
     dst = torch.empty(nseg * rows * Cp, dtype=torch.bfloat16, device=device)
     rc = _lib.lib().pika_split_bf16_terms(op.ptr, n_batch, t_in, C, batch_stride, ld, role, n_terms, layout, Cp,
                                           dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -150,9 +156,11 @@ def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):
     """The two operands of a K-concatenated product as bf16 operands over a reduction of S = 3 (two terms) or 6 (three
     terms) segments, or None when the split does not apply (bf16 / batched / mixed-orientation operands, extents the
     16-byte bf16 loads cannot take): the caller then runs the exact path.  Returns (a3, b3, K3, keep-alive tensors)."""
-    S = 3 if n_terms == 2 else 6
+    S = 6 if n_terms == 3 else 3
     if a_op.dtype != PIKA_F32 or b_op.dtype != PIKA_F32 or bool(a_op.trans) != bool(b_op.trans):
         return None
+    if n_terms == 4 and a_op.trans:
+        return None             # two fp16 terms: forward (reduction-contiguous) products only
     if a_op.z_outer or a_op.z_inner or b_op.z_outer or b_op.z_inner:
         return None
     if not a_op.trans:
@@ -217,6 +225,20 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         # one bf16 operand against a reduction-major fp32 one (a weight gradient whose activation was stored in bf16):
         # the exact kernel does not take that pairing; the stored operand already carries the bf16 rounding
         p = precision = "bf16"
+    f16 = False
+    if p == "fp16x2":
+        ok = (batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32 and not accumulate
+              and not a_op.trans and not b_op.trans and _direct_to_lds_size(False, M, N, K))
+        with torch.cuda.device(out.device):
+            sp = _bf16x3_operands(a_op, b_op, M, N, K, out.device, 4) if ok else None
+        if sp is not None:
+            a_op, b_op, K, keep = sp
+            p = precision = "bf16"
+            f16 = True
+            FP16X2_STATS["fast"] += 1
+        else:
+            p = precision = "fp32"      # small / transposed / batched products: exact
+            FP16X2_STATS["exact"] += 1
     if p == "bf16x3" or (p == "fp32" and not accumulate and FP32_CONCAT):
         n_terms = 2 if p == "bf16x3" else 3
         splittable = batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32
@@ -239,7 +261,8 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         rc = _lib.lib().pika_gemm_nt_ws(ctypes.byref(a_op), ctypes.byref(b_op), out.data_ptr(), ldc,
                                         c_z_outer, c_z_inner, M, N, K, batch, z_div,
                                         None if bias is None else bias.data_ptr(),
-                                        _flags(relu, accumulate, precision) | (OUT_BF16 if out.dtype == torch.bfloat16 else 0),
+                                        _flags(relu, accumulate, precision) | (OUT_BF16 if out.dtype == torch.bfloat16 else 0)
+                                        | (F16_OPERANDS if f16 else 0),
                                         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
                                         torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pika_gemm_nt(M=%d,N=%d,K=%d)" % (M, N, K))

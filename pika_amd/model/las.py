@@ -57,7 +57,7 @@ class LASRNNEncoder(nn.Module):
 
     def _forward_fused(self, input, lengths):
         """nn.LSTM over pack_padded_sequence(input, lengths) -> pad_packed_sequence, per layer: the input projections of
-        every position and both directions as ONE GEMM (exact products), then the recurrence of both directions as ONE
+        every position and both directions as ONE GEMM (fp32-grade products), then the recurrence of both directions as ONE
         persistent launch whose workgroups keep their slice of W_hh in registers (pika_amd/csrc/blstm.hip)."""
         import ctypes
         from .. import _lib
@@ -87,7 +87,8 @@ class LASRNNEncoder(nn.Module):
                                   for s in sfx], 0).float().contiguous()
                 packed = torch.empty(int(lib.pika_blstm_packed_bytes(D, H)), dtype=torch.uint8, device=dev)
                 _lib.check(lib.pika_blstm_pack(w_hh.data_ptr(), D, H, packed.data_ptr(), st), "pika_blstm_pack")
-                gx = G.gemm_nt(x.view(S * B, x.shape[2]), w_ih, bias=bias, precision="fp32")       # (S*B, D*4H)
+                # fp32-grade products (two fp16 terms on the direct-to-LDS kernel; exact products for small shapes)
+                gx = G.gemm_nt(x.view(S * B, x.shape[2]), w_ih, bias=bias, precision="fp16x2")     # (S*B, D*4H)
                 out = torch.empty((S, B, D * H), device=dev)
                 h_n, c_n = torch.empty((D, B, H), device=dev), torch.empty((D, B, H), device=dev)
                 rc = lib.pika_blstm_layer(gx.data_ptr(), packed.data_ptr(), lens_d.data_ptr(), out.data_ptr(),
@@ -268,7 +269,7 @@ class InputFeedRNNDecoder(nn.Module):
             h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
             ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
             # "mixed" is a training arithmetic (bf16 backward): a scoring pass under it runs its forward grade, i.e. exact
-            infer = "bf16x3" if G.PRECISION == "mixed" else None
+            infer = "fp16x2" if G.PRECISION in ("mixed", "fp32") else None
             proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous(),
                              precision=infer).view(B, S, H)
             own = owner.to(device=dev, dtype=torch.int32).contiguous()

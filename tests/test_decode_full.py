@@ -154,3 +154,32 @@ def test_gpu_full_width_greedy_is_identical_to_the_reference(hip_device, precisi
     assert np.array_equal(got["hyps"], z["hyps"])
     # scores: 3e-4 with fp32-grade products; the two-term bf16 option moves them by ~2e-3 (sums of ~150 log-probs)
     assert np.abs(got["scores"] - z["scores"]).max() < (5e-3 if precision == "bf16x3" else 1e-3)
+
+
+@pytest.mark.gpu
+def test_decode_encoder_on_two_fp16_terms_matches_the_exact_products(hip_device):
+    """The decoder's encoder pass at batch sizes whose products the direct-to-LDS kernel takes (the B = 4 goldens above are
+    below its size gate and run exact either way): precision "fp16x2" (two fp16 terms per operand, three K-concatenated
+    segments) against "fp32" (three bf16 terms, six segments: exact products) on the full-width model -- the outputs
+    agree to the fp32 accumulation noise of the exact mode itself."""
+    from pika_amd import gemm as G
+    from pika_amd.model import transducer
+    net = F.build(transducer, seeded_state_dict).to(hip_device)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(32, 1000, F.D_IN, generator=g).to(hip_device)
+    out = {}
+    old = G.PRECISION
+    try:
+        for prec in ("fp32", "fp16x2"):
+            G.PRECISION = prec
+            before = G.FP16X2_STATS["fast"]
+            with torch.no_grad():
+                out[prec] = net.encoder(x).float()
+            if prec == "fp16x2":
+                assert G.FP16X2_STATS["fast"] > before + 10        # the encoder's products took the fp16 path
+    finally:
+        G.PRECISION = old
+    # measured 5e-6 after the encoder's 13 product layers: the size of the exact mode's own distance from the reference
+    # encoder on the golden (3.9e-6)
+    rel = ((out["fp16x2"] - out["fp32"]).abs().max() / out["fp32"].abs().max()).item()
+    assert rel < 1.5e-5, rel

@@ -269,3 +269,47 @@ def test_mixed_linear_with_an_output_width_the_two_term_kernel_does_not_take(hip
         assert x.grad is not None and w.grad.shape == w.shape and b.grad.shape == b.shape
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("M,N,K,taps", [(8192, 2048, 1024, 1), (16384, 1024, 3072, 1), (8000, 1536, 768, 3)])
+def test_fp16_two_term_products(hip_device, M, N, K, taps):
+    """precision "fp16x2": two fp16 terms per operand as three K-concatenated segments on the direct-to-LDS kernel
+    (v_mfma_f32_16x16x32_f16): an fp32 product to ~2^-22 -- against float64, beside the exact six-segment mode; operands with
+    a wide dynamic range (small elements whose low terms would be fp16 subnormals without the scaling) and a time-delay view."""
+    from pika_amd import gemm as G
+    g = torch.Generator().manual_seed(M + N + K)
+    if taps == 1:
+        a = torch.randn(M, K, generator=g) * torch.logspace(-3, 1.5, K).unsqueeze(0)
+        a_op_src = a.to(hip_device)
+        a_mat = a.double()
+    else:
+        C = K // taps
+        x = (torch.randn(1, M + taps - 1, C, generator=g) * 3).to(hip_device)
+        a_op_src = x
+        a_mat = torch.cat([x[0, t:t + M].double().cpu() for t in range(taps)], 1)
+    w = torch.randn(N, K, generator=g) * 0.03 * torch.logspace(-2, 0.5, N).unsqueeze(1)
+    bias = torch.randn(N, generator=g)
+    want = a_mat @ w.double().t() + bias.double()
+    scale = want.abs().max().item()
+    got = {}
+    for prec in ("fp16x2", "fp32"):
+        before = dict(G.FP16X2_STATS)
+        if taps == 1:
+            out = G.gemm_nt(a_op_src, w.to(hip_device), bias=bias.to(hip_device), precision=prec)
+        else:
+            a_op, rows, Kk, _ = G.time_delay(a_op_src, taps)
+            w_d, bias_d = w.to(hip_device), bias.to(hip_device)      # descriptors hold raw pointers: keep the tensors
+            b_op, _, _ = G.matrix(w_d)
+            out = torch.empty(M, N, device=hip_device)
+            G.launch(a_op, b_op, out, N, M, N, K, bias=bias_d, precision=prec)
+        if prec == "fp16x2":
+            assert G.FP16X2_STATS["fast"] == before["fast"] + 1            # the three-segment fp16 path took it
+        got[prec] = (out.double().cpu() - want).abs().max().item() / scale
+    # both sit at the fp32 accumulation noise of a K-term sum (measured: 1.5e-6 vs 2.5e-6 at K = 3072)
+    assert got["fp16x2"] < 5e-6 and got["fp32"] < 5e-6 and got["fp16x2"] < 2 * got["fp32"] + 5e-7, got
+    # an operand beyond fp16's range saturates instead of producing inf / nan
+    a = torch.randn(4096, 1024, generator=g)
+    a[3, 5] = 1e6
+    before = G.FP16X2_STATS["fast"]
+    out = G.gemm_nt(a.to(hip_device), torch.randn(2560, 1024, generator=g).to(hip_device) * 0.03, precision="fp16x2")
+    assert G.FP16X2_STATS["fast"] == before + 1 and bool(torch.isfinite(out).all())
