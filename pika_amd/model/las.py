@@ -269,7 +269,7 @@ class InputFeedRNNDecoder(nn.Module):
             h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
             ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
             # "mixed" is a training arithmetic (bf16 backward): a scoring pass under it runs its forward grade, i.e. exact
-            infer = "fp16x2" if G.PRECISION in ("mixed", "fp32") else None
+            infer = "fp16x2" if G.PRECISION == "mixed" else None
             proj = G.gemm_nt(ctx.view(B * S, H), att.linear_context.weight.detach().contiguous(),
                              precision=infer).view(B, S, H)
             own = owner.to(device=dev, dtype=torch.int32).contiguous()
