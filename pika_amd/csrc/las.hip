@@ -77,6 +77,9 @@ __device__ inline float block_reduce(float v, bool is_max, float *red) {
 // softmax is online (running maximum m, running sum l, context sums rescaled when m moves), so the scores never leave
 // the registers; the eight waves' partial (m, l, sums) are merged through LDS at the end.
 constexpr int AW = 8;         // waves per workgroup
+#ifndef PIKA_LAS_ATT_G1_MAX
+#define PIKA_LAS_ATT_G1_MAX 1024   // launches sized for up to this many queries take one query per workgroup
+#endif
 template <int G>
 __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float *__restrict__ wq, long long ldq,
                                                                 const float *__restrict__ proj,
@@ -335,7 +338,7 @@ int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, co
         return PIKA_EINVAL;
     // few queries (a rescoring pass whose n-best entries share their prefixes): one query per workgroup -- a workgroup's
     // time is (positions / 8 waves) x (queries of the group), and the CUs are not all busy anyway
-    if (N <= 512)
+    if (N <= PIKA_LAS_ATT_G1_MAX)
         hipLaunchKernelGGL(las_mlp_attention_kernel<1>, dim3((unsigned)N), dim3(64 * AW), 0,
                            static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
                            align_out, N, S, D, n_dev, qoff_dev);

@@ -40,7 +40,8 @@ def test_lstm_cell(hip_device, N, H):
 
 
 @pytest.mark.parametrize("B,S,D,nper", [(1, 5, 4, [1]), (3, 23, 32, [3, 2, 1]), (4, 240, 1024, [16, 16, 5, 16]),
-                                        (2, 300, 100, [7, 9])])
+                                        (2, 300, 100, [7, 9]),
+                                        (5, 40, 64, [300, 301, 299, 150, 3])])     # > 1024 queries: four per workgroup
 def test_mlp_attention(hip_device, B, S, D, nper):
     """Queries of several utterances (groups of 4 straddle utterance boundaries), ragged source lengths."""
     from pika_amd import _lib
