@@ -5,5 +5,5 @@ PIKA_LAS_TIMING=1 timeout 600 python bench.py --workload decode --batch 64 --fst
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); t=d['config']['timing']; print('pipeline', d['value'], d['ms_per_step'], t['search_s'], t['las_s'], {k:[(a[:10],round(b,1)) for a,b in v] for k,v in t['las_phases_ms'].items()})
+        d=json.loads(l); t=d['config']['timing']; print('pipeline', d['value'], d['ms_per_step'], t['search_s'], t['las_s'], {k:[(a[:10],round(b,1)) for a,b in v] for k,v in t.get('las_phases_ms',{}).items()})
 "
