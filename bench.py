@@ -421,7 +421,9 @@ def mbr_workload(args, dev, rank):
         if isinstance(m, torch.nn.BatchNorm1d):
             m.momentum = 0.0
     dec = decoder(beam)
-    dec.decode_precision = "bf16"      # N-best generation inside a training step: the training arithmetic
+    # N-best generation in the decoder's default arithmetic (fp32-grade products on two fp16 terms: the mode whose N-best is
+    # pinned against the reference script's, tests/test_mbr.py); --mbr-search-precision bf16 = one bf16 term (r1-r3 numbers)
+    dec.decode_precision = getattr(args, "mbr_search_precision", None) or dec.decode_precision
     # the step size is negligible on purpose: the calibrated random model must keep emitting ~U labels per
     # utterance in every timed step (the arithmetic of the update is the same)
     optim = torch.optim.SGD(model.parameters(), 1e-9, momentum=0.9, nesterov=True)
@@ -934,6 +936,8 @@ def main():
     ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
     ap.add_argument("--fst-scale", type=float, default=0.3, help="decode --fst: LM weight (egs/eval_transducer.sh uses 0.3)")
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
+    ap.add_argument("--mbr-search-precision", default=None, choices=["fp32", "fp32-exact", "bf16x3", "bf16"],
+                    help="mbr_step: decode arithmetic of the N-best search (default: the decoder's default, fp32-grade)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the secondary full-train-step measurement of the default run")

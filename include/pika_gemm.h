@@ -112,6 +112,13 @@ int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long lo
 int pika_dropout_keep_mask(unsigned char *mask, int rows, int cols, float p_drop, unsigned seed,
                            void *stream);
 
+/* The direct-to-LDS kernels take a (non-transposed) product only when it fills the chip: at least `min_tiles` 256 x 256
+ * output tiles (default 160); smaller products run on the register-staged kernel.  The gate is a performance choice, not
+ * an arithmetic one -- but the K-concatenated term products (fp16x2 / six-segment exact) exist on the direct-to-LDS kernels
+ * only, so a parity test at a small batch lowers it to put that arithmetic on its path.  Returns the previous value;
+ * min_tiles < 1 only reads.  Process-wide. */
+int pika_gemm_set_min_tiles(int min_tiles);
+
 /* Registers (NULL: clears) a device word that EVERY kernel of this library that takes a dropout seed adds to it when it
  * runs (GEMM epilogues, pika_dropout_mask_cast_bf16, the attention keep bits, the two keep-mask helpers).  A training
  * step captured once into a hipGraph replays the seeds it was captured with; with the caller changing this word between

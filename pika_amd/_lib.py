@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -41,6 +41,7 @@ SIGNATURES = {
                                      ctypes.c_uint, _vp, _ll, ctypes.c_float, _vp]),
     "pika_dropout_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_set_dropout_salt": (_i, [_vp]),
+    "pika_gemm_set_min_tiles": (_i, [_i]),
     "pika_gemm_bf16_dropout_residual": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, ctypes.c_float,
                                              ctypes.c_uint, _vp, _ll, _vp]),
     "pika_dropout_mask_cast_bf16": (_i, [_vp, _ll, _i, _i, ctypes.c_float, ctypes.c_uint, _vp, _ll, _vp]),

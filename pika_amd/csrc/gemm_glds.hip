@@ -1108,6 +1108,14 @@ bool pp_fill_a(const pika_operand_t &A, int K, PPArgs &P) {
 
 }  // namespace
 
+static int g_pp_min_tiles = 160;
+
+extern "C" int pika_gemm_set_min_tiles(int min_tiles) {
+    const int old = g_pp_min_tiles;
+    if (min_tiles >= 1) g_pp_min_tiles = min_tiles;
+    return old;
+}
+
 // Used by pika_gemm_nt (gemm.hip): returns PIKA_NOT_APPLICABLE when the operands do not fit the
 // direct-to-LDS kernels (then the register-staged kernel runs).
 int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
@@ -1122,7 +1130,7 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     // B: plain matrix
     if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
         return PIKA_NOT_APPLICABLE;
-    if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < 160) return PIKA_NOT_APPLICABLE;
+    if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < g_pp_min_tiles) return PIKA_NOT_APPLICABLE;
     PPArgs P{};
     if (!pp_fill_a(*A, K, P)) return PIKA_NOT_APPLICABLE;
     P.B = static_cast<const __bf16 *>(B->ptr);

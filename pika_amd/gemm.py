@@ -145,11 +145,24 @@ def _plain(op, K):
     return op.C >= K and op.pad == 0 and op.stride == 1
 
 
+MIN_TILES = 160
+
+
+def set_min_tiles(n):
+    """The direct-to-LDS kernels' fill-the-chip gate (include/pika_gemm.h: pika_gemm_set_min_tiles), here and in the
+    library.  Returns the previous value.  Tests lower it so that a B = 4 golden runs the K-concatenated term products
+    the benchmarked batch sizes run."""
+    global MIN_TILES
+    old, MIN_TILES = MIN_TILES, int(n)
+    _lib.lib().pika_gemm_set_min_tiles(int(n))
+    return old
+
+
 def _direct_to_lds_size(trans, M, N, K):
     """The size gates of the direct-to-LDS kernels (gemm_glds.hip: pika_internal_gemm_pp / launch_pp_tn)."""
     if trans:
         return M >= 192 and N >= 192 and K >= 512
-    return M >= 256 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= 160
+    return M >= 256 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= MIN_TILES
 
 
 def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):

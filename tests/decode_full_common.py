@@ -14,6 +14,7 @@ V, H, EMB, D_IN = 5000, 1024, 100, 240
 B, BEAM, SM_SCALE = 4, 16, 0.8
 SEED, SCALE = 515, 0.02
 LENS = [260, 248, 236, 252]
+FST_SCALE, FST_REWARD = 0.2, 6.5    # shallow fusion weight / non-blank reward of the FST-fused golden
 
 
 def opt():

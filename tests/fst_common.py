@@ -25,3 +25,31 @@ def bigram_arcs(V, seed=123, n_succ=6):
     finals = {k: float(np.float32(v)) for k, v in finals.items()}
     params = dict(max_num_arcs=V + 4, max_id=V + 3, backoff_id=backoff_id, disambig_ids=[disambig])
     return n_states, arcs, finals, params
+
+
+class DuckFst(object):
+    """What the REFERENCE SortedMatcher asks of an OpenFST object (`arcs(state)` -> iterator with seek/done/value,
+    `final(state).value`; decoder/sorted_matcher.py:28-47,97) over a plain arc list -- golden generators only."""
+
+    def __init__(self, n_states, arcs, finals):
+        from types import SimpleNamespace
+        self._ns = SimpleNamespace
+        self.by = [[] for _ in range(n_states)]
+        for s, i, w, d in arcs:
+            self.by[s].append(SimpleNamespace(ilabel=i, weight=SimpleNamespace(value=w), nextstate=d))
+        for lst in self.by:
+            lst.sort(key=lambda a: a.ilabel)
+        self.finals = finals
+
+    def arcs(self, state):
+        lst = self.by[state]
+
+        class It(object):
+            pos = 0
+            def seek(s, p): s.pos = p
+            def done(s): return s.pos >= len(lst)
+            def value(s): return lst[s.pos]
+        return It()
+
+    def final(self, state):
+        return self._ns(value=self.finals.get(state, float("inf")))

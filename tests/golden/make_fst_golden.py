@@ -25,27 +25,7 @@ import decode_common as D  # noqa: E402
 import fst_common as FC  # noqa: E402
 
 
-class DuckFst(object):
-    def __init__(self, n_states, arcs, finals):
-        self.by = [[] for _ in range(n_states)]
-        for s, i, w, d in arcs:
-            self.by[s].append(SimpleNamespace(ilabel=i, weight=SimpleNamespace(value=w), nextstate=d))
-        for lst in self.by:
-            lst.sort(key=lambda a: a.ilabel)
-        self.finals = finals
-
-    def arcs(self, state):
-        lst = self.by[state]
-
-        class It(object):
-            pos = 0
-            def seek(s, p): s.pos = p
-            def done(s): return s.pos >= len(lst)
-            def value(s): return lst[s.pos]
-        return It()
-
-    def final(self, state):
-        return SimpleNamespace(value=self.finals.get(state, float("inf")))
+DuckFst = FC.DuckFst
 
 
 transducer, encoder, tdec, beam_mod, sm = pika_ref.load_reference(

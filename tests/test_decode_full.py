@@ -19,18 +19,28 @@ import decode_full_common as F  # noqa: E402
 from oracle.pika_ref import seeded_state_dict  # noqa: E402
 
 GOLD = os.path.join(HERE, "golden", "decode_full.npz")
+GOLD_FST = os.path.join(HERE, "golden", "decode_full_fst.npz")   # tests/golden/make_decode_full_fst_golden.py
 
 
-def decode(device, precision=None):
+def fst_matcher():
+    import fst_common as FC
+    from pika_amd.decoder.ngram_fst import NgramFst, SortedMatcher
+    n, arcs, finals, params = FC.bigram_arcs(F.V)
+    return SortedMatcher(NgramFst.from_arcs(n, arcs, finals), **params)
+
+
+def decode(device, precision=None, fst=False):
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
     from pika_amd.model import transducer
     net = F.build(transducer, seeded_state_dict).to(device)
     x, x_len = F.inputs()
-    args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+    args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None,
+                           nonblk_reward=F.FST_REWARD if fst else 0.0)
     d = TransducerDecoder(net, batch_size=F.B, beam_size=F.BEAM, n_best=F.BEAM, blk=0, global_scorer=GlobalScorer(),
-                          sm_scale=F.SM_SCALE, cuda=(device != "cpu"), beam_prune=True, args=args)
+                          sm_scale=F.SM_SCALE, cuda=(device != "cpu"), beam_prune=True, args=args,
+                          **(dict(lm_scorer=fst_matcher(), lm_scorer_scale=F.FST_SCALE) if fst else {}))
     if precision is not None:
         d.decode_precision = precision
     ret, enc = d.decode_batch(x.to(device), x_len.to(device), F.max_len(x_len))
@@ -112,6 +122,77 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
                         np.array_equal(got16["hyps"][b, 0, :z["lens"][b, 0]], z["hyps"][b, 0, :z["lens"][b, 0]]))
                     for b in range(F.B))
     print("bf16 mode: encoder output max rel err %.2e, identical top-1 hypotheses %d / %d" % (rel16, same_top1, F.B))
+
+
+def test_cpu_full_width_fst_fused_decode_matches_reference():
+    """The configs[4] search of bench.py (beam 16, n-best 16, back-off bigram over the 4999 labels fused in) on the host
+    path: n-best lists identical to the reference decoder + reference SortedMatcher."""
+    got, _, _ = decode("cpu", fst=True)
+    z = np.load(GOLD_FST)
+    assert np.array_equal(got["lens"], z["lens"]) and np.array_equal(got["hyps"], z["hyps"])
+    assert np.allclose(got["scores"], z["scores"], rtol=1e-5, atol=1e-3)
+
+
+def check_fst(got, z):
+    """Same criterion as `check` (top-1 identical; every entry separated by > 1e-3 from both neighbours at its reference
+    rank, score within 2e-3), without the encoder sample."""
+    gap, n_same = 1e-3, 0
+    B, nb = z["lens"].shape
+    for b in range(B):
+        assert same_entry(got, z, b, 0), "top-1 hypothesis of utterance %d differs" % b
+        sc = z["scores"][b]
+        for j in range(nb):
+            sep = (j == 0 or sc[j - 1] - sc[j] > gap) and (j == nb - 1 or sc[j] - sc[j + 1] > gap)
+            same = same_entry(got, z, b, j)
+            n_same += int(same)
+            assert same or not sep, "utterance %d rank %d: separated by > %g from its neighbours but differs" % (b, j, gap)
+            if same:
+                assert abs(got["scores"][b, j] - sc[j]) < 2e-3, (b, j, got["scores"][b, j], sc[j])
+    return n_same / float(B * nb)
+
+
+@pytest.mark.gpu
+def test_gpu_full_width_fst_fused_decode_matches_reference(hip_device):
+    """The FST-fused full-width search on the device path bench.py's configs[4] leg times (pika_fst_advance inside the
+    captured launch chain, default decode arithmetic) against the reference decoder + reference SortedMatcher golden."""
+    z = np.load(GOLD_FST)
+    got, _, d = decode(hip_device, fst=True)
+    assert d.decode_precision == "fp32" and "launches_per_step" in d.timing and d.timing["graphs"] == 1
+    frac = check_fst(got, z)
+    print("FST-fused full-width search, default arithmetic: top-1 identical for all %d utterances, %.0f %% of the %d "
+          "n-best entries at the reference rank; max |score diff| over those %.2e" % (
+              F.B, 100 * frac, F.B * F.BEAM, max(abs(got["scores"][b, j] - z["scores"][b, j]) for b in range(F.B)
+                                               for j in range(F.BEAM) if same_entry(got, z, b, j))))
+    assert frac >= 0.85
+
+
+@pytest.mark.gpu
+def test_gpu_full_width_goldens_on_the_two_fp16_term_encoder_products(hip_device):
+    """bench.py decodes B = 64: its encoder / joint-half products pass the direct-to-LDS kernel's fill-the-chip gate and
+    run as two fp16 terms per operand over three K-concatenated segments (pika_amd.gemm "fp16x2").  The B = 4 goldens are
+    below that gate (20 tiles < 160) and would run exact products: lower the gate (pika_gemm_set_min_tiles) so that the
+    reference goldens -- greedy, beam 16 and FST-fused -- are decoded in the arithmetic that is benchmarked."""
+    from pika_amd import gemm as G
+    old = G.set_min_tiles(1)
+    try:
+        before = G.FP16X2_STATS["fast"]
+        zg = np.load(GREEDY)
+        got, d = decode_greedy(hip_device)
+        assert d.decode_precision == "fp32" and d.encoder_precision == "fp16x2"
+        n_fast = G.FP16X2_STATS["fast"] - before
+        assert n_fast >= 13, n_fast                                # the encoder's and the joint halves' products
+        assert np.array_equal(got["lens"], zg["lens"]) and np.array_equal(got["hyps"], zg["hyps"])
+        assert np.abs(got["scores"] - zg["scores"]).max() < 1e-3
+        z = np.load(GOLD)
+        gotb, enc, _ = decode(hip_device)
+        rel, frac = check(gotb, enc, z, 1e-4, exact=False)
+        gotf, _, _ = decode(hip_device, fst=True)
+        fracf = check_fst(gotf, np.load(GOLD_FST))
+        print("two-fp16-term encoder products at B = 4 (%d products): encoder output max rel err %.2e; greedy identical; "
+              "beam 16: %.0f %% of the entries at the reference rank; FST-fused: %.0f %%" % (n_fast, rel, 100 * frac,
+                                                                                           100 * fracf))
+    finally:
+        G.set_min_tiles(old)
 
 
 GREEDY = os.path.join(HERE, "golden", "decode_full_greedy.npz")

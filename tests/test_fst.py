@@ -98,9 +98,14 @@ def test_cpu_fused_decode_matches_reference(dec):
 
 
 @pytest.mark.gpu
-def test_gpu_fused_decode_matches_reference(hip_device):
+@pytest.mark.parametrize("precision", ["fp32", "default"])
+def test_gpu_fused_decode_matches_reference(hip_device, precision):
+    """The tiny-model FST goldens in the exact mode and in the package default (the decoder switches to its own decode
+    arithmetic either way; the full-width FST-fused golden: tests/test_decode_full.py)."""
     from pika_amd import gemm as G
-    old, G.PRECISION = G.PRECISION, "fp32"
+    old = G.PRECISION
+    if precision != "default":
+        G.PRECISION = precision
     try:
         run("transformer", hip_device)
         run("rnn", hip_device)

@@ -69,9 +69,14 @@ def test_cpu_las_rescore_matches_reference():
 
 
 @pytest.mark.gpu
-def test_gpu_las_rescore_matches_reference(hip_device):
+@pytest.mark.parametrize("precision", ["fp32", "default"])
+def test_gpu_las_rescore_matches_reference(hip_device, precision):
+    """In the exact mode and in the package default (what a decode script gets; the full-width scenario with the
+    persistent BLSTM kernel on its path: tests/test_las_full.py)."""
     from pika_amd import gemm as G
-    old, G.PRECISION = G.PRECISION, "fp32"
+    old = G.PRECISION
+    if precision != "default":
+        G.PRECISION = precision
     try:
         run(hip_device)
     finally:
@@ -179,9 +184,12 @@ def test_batch_ahead_rescoring_answers_the_script_loop_with_the_per_hypothesis_v
 
 
 @pytest.mark.gpu
-def test_gpu_batch_ahead_rescoring_answers_the_script_loop(hip_device, monkeypatch):
+@pytest.mark.parametrize("precision", ["fp32", "default"])
+def test_gpu_batch_ahead_rescoring_answers_the_script_loop(hip_device, monkeypatch, precision):
     from pika_amd import gemm as G
-    old, G.PRECISION = G.PRECISION, "fp32"
+    old = G.PRECISION
+    if precision != "default":
+        G.PRECISION = precision
     try:
         ahead, tables = _script_loop(hip_device, True, monkeypatch)
         alone, _ = _script_loop(hip_device, False, monkeypatch)
