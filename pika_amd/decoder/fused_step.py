@@ -13,8 +13,9 @@ is a label (:139-171; conv-transformer prediction net, trainer/model/rnnt_conv_t
 concatenated per step (weights are packed once per `decode_batch`), and because every buffer has a fixed shape the
 host can replay the graph several times per read of the `stop` flag (state-mutating launches are no-ops once it is set).
 
-Arithmetic: `terms` bf16 terms per operand -- 3 (default) reproduces fp32 products exactly (the parity mode: n-best
-lists identical to the reference's fp32 CPU decoder), 1 is plain bf16 operands.
+Arithmetic: `terms` = 4 (default): two fp16 terms per operand, fp32-grade products; 3: three bf16 terms, exact fp32 products;
+2: two bf16 terms; 1: plain bf16 operands.  Against the reference's fp32 CPU decoder (tests/test_decode_full.py): greedy
+hypotheses and every top-1 identical, n-best entries separated by > 1e-3 in score at their reference rank.
 """
 import ctypes
 

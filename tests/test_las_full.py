@@ -4,10 +4,10 @@ the REFERENCE `las.Net` scored one hypothesis at a time (tests/golden/make_las_f
 benchmarked pass uses on the path: the persistent BLSTM kernel (pika_blstm_layer, two bf16 terms of W_hh in registers),
 the captured token loop on two fp16 terms per operand, prefix sharing, the padded ragged batch.
 
-Tolerance on a log-prob (values span -19 .. -1e-3): 2e-3 absolute.  The budget: the BLSTM recurrence keeps W_hh as two
+Tolerance on a log-prob (values span -19 .. -1e-3): 1e-4 absolute.  The budget: the BLSTM recurrence keeps W_hh as two
 bf16 terms (2^-17 per product, 61 dependent steps, two layers: 2e-5 on the encoder outputs, tests/test_las_kernels_gpu.py),
-the token loop's products are fp32-grade (2^-22), and dec_proj -- sharpened 30x in this scenario so that errors of the
-decoder state SHOW -- multiplies a 1e-5 state error into ~3e-4 on a logit.  Measured on MI355X: see the printed line."""
+the token loop's products are fp32-grade (2^-22), and dec_proj is sharpened 30x in this scenario so that errors of the
+decoder state SHOW.  Measured on MI355X: 5.7e-6 (batched pass, fw and bw), 7.6e-6 (one hypothesis at a time)."""
 import os
 import sys
 
@@ -69,7 +69,7 @@ def test_gpu_full_width_las_scores_match_reference_in_the_benchmarked_arithmetic
         out[key] = worst(got, z, key, hyps)
     print("full-width LAS rescoring, default arithmetic: max |log-prob - reference| fw %.2e, bw %.2e "
           "(row steps %d of %d pairs)" % (out["fw"], out["bw"], fw.last_pass["row_steps"], fw.last_pass["pairs"]))
-    assert out["fw"] < 2e-3 and out["bw"] < 2e-3, out
+    assert out["fw"] < 1e-4 and out["bw"] < 1e-4, out
     # the unchanged decode script asks one hypothesis at a time (decode_transducer.py:136-156): the same values through
     # TransducerDecoder.las_rescore on the B = 1 encoder pass (persistent kernel at B = 1, no sharing)
     from types import SimpleNamespace
@@ -84,4 +84,4 @@ def test_gpu_full_width_las_scores_match_reference_in_the_benchmarked_arithmetic
             tgt = torch.LongTensor([LF.SOS] + hyps[b][j][::-1] + [LF.EOS]).to(hip_device).unsqueeze(-1).unsqueeze(-1)
             w1 = max(w1, float(np.abs(np.asarray(d.las_rescore(x, tgt, bw=True)) - z["bw/%d/%d" % (b, j)]).max()))
     print("one hypothesis at a time (las_rescore): max |log-prob - reference| %.2e" % w1)
-    assert w1 < 2e-3, w1
+    assert w1 < 1e-4, w1
