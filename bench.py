@@ -129,8 +129,8 @@ def train_step_workload(args, R_):
     aug = SpecAugment(15, 35)
     def make_optim():
         return torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
-    # PIKA_TRAIN_GRAPH=0: the eager launch sequence of the reference loop; default: the same sequence captured once into a
-    # hipGraph (pika_amd/train_graph.py) -- forward, loss, backward, clip and SGD are one graph launch per step
+    # PIKA_TRAIN_GRAPH=0: the eager launch sequence of the reference loop; default: the same calls, with the model's forward
+    # and backward served by two hipGraph replays behind Net.forward / loss.backward() (pika_amd/train_graph.py)
     graphed = None
     if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0":
         from pika_amd.train_graph import GraphedTrainStep
@@ -218,7 +218,10 @@ def run_train_step(args, R_, steps, warmup):
                                   "fwd, RNN-T loss, bwd, clip, SGD%s" % (", BMUF all-reduce every 5 steps" if world > 1 else ""),
                       "batch_per_gpu": B, "T_in": T, "T_enc": 240, "U": U, "V": V,
                       "global_batch": B * world, "parallelism": "bmuf-dp%d" % world, "loss": loss,
-                      "launch": "one hipGraph per step (forward, loss, backward, clip, SGD)"
+                      "launch": "the reference loop's own calls (forward, loss, backward, clip, step); behind Net.forward / "
+                                "loss.backward() the model's forward and backward are two hipGraph replays, loss + clip + SGD ~10 "
+                                "eager launches (pika_amd/train_graph.py: what the unchanged training script gets through "
+                                "pika_amd.launch)"
                                 if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0" else "eager (~650 launches per step)"},
            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
                         "frac": tf / 2500.0, "traffic": None},

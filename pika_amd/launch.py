@@ -12,6 +12,8 @@ What it absorbs (SURVEY.md 8b "legacy-runtime conventions"), without touching th
   * `torch.load` of whole-module pickles (`weights_only` now defaults to True);
   * the per-batch `clip_grad_norm_(.., norm_type=inf)` + `optim.SGD(.., nesterov=True).step()` of the training
     scripts run as three multi-tensor HIP launches (pika_amd/optim.py; stock torch for everything else);
+  * `model.forward(...)` / `loss.backward()` of a training step on a HIP device replay two hipGraphs captured per batch
+    shape (pika_amd/train_graph.py): ~600 launches of host work per step become two;
   * integer-tensor `/` as integer division (torch <= 1.4 semantics) ONLY on request (`--legacy-int-div`): the one
     reference line that relies on it (decoder/beam_transducer.py:125) lives in a module the drop-in `decoder`
     package replaces, so the process-wide patch is off unless a user script of its own needs it.
@@ -45,6 +47,10 @@ def install_shims(legacy_int_div=False):
     # (pika_amd/optim.py); every other use falls through to torch
     from . import optim as _optim
     _optim.install()
+    # the model's forward / backward of a TRAINING step as two hipGraph replays behind Net.forward (pika_amd/train_graph.py;
+    # PIKA_TRAIN_GRAPH=0: the eager launch sequence)
+    from . import train_graph as _tg
+    _tg.AUTO = True
     if legacy_int_div:
         true_div = torch.Tensor.__truediv__
 

@@ -58,6 +58,20 @@ class Net(nn.Module):
         return self.decoder(y)
 
     def forward(self, x, y, x_len=None, softmax=True):
+        """transducer.py:73-112.  A TRAINING call on a HIP device may be served by a hipGraph replay of this very
+        forward (pika_amd/train_graph.py: enabled by pika_amd.launch for the training scripts and by bench.py); same
+        values, and `_forward_eager` is what gets captured."""
+        from .. import train_graph
+        if train_graph.wanted(self, x, softmax):
+            return train_graph.forward(self, x, y, x_len, softmax)
+        return self._forward_eager(x, y, x_len, softmax)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_step_graphs", None)         # captured graphs are not part of a checkpoint (torch.save(model))
+        return state
+
+    def _forward_eager(self, x, y, x_len=None, softmax=True):
         enc = self.encode(x, x_len)
         sos = torch.zeros(y.shape[0], 1, dtype=torch.long, device=y.device)  # SOS = blank = 0
         pred = self.predict(torch.cat((sos, y), dim=1))

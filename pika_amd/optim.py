@@ -45,25 +45,22 @@ class _Tables(object):
         self.host_np = self.host.numpy()            # element writes through torch cost ~5 us each; numpy: one call
         self.events = [[None] * 3 for _ in range(self.RING)]
         self.gen = [0, 0, 0]
-        # staging rows owned by hipGraph captures (allocated up front: no host allocation while a stream captures); a
-        # captured copy node reads its host source at every replay, so such a row is written once and never again
-        self.cap_host = torch.empty(self.CAPTURES * 3, self.n, dtype=torch.int64).pin_memory()
-        self.cap_np = self.cap_host.numpy()
-        self.n_captured = 0
         self.dev = torch.empty(3, self.n, dtype=torch.int64, device=device)
         self.norm = torch.zeros(1, dtype=torch.float32, device=device)
+        self.last = [None, None, None]              # what each device row holds: an unchanged table is not uploaded again
 
-    RING, CAPTURES = 8, 8
+    RING = 8
 
     def upload(self, row, tensors):
-        ptrs = [t.data_ptr() for t in tensors]
         if torch.cuda.is_current_stream_capturing():
-            if self.n_captured >= self.cap_host.shape[0]:
-                raise RuntimeError("pika_amd.optim: more than %d optimizer captures of one parameter set" % self.CAPTURES)
-            k, self.n_captured = self.n_captured, self.n_captured + 1
-            self.cap_np[k, :] = ptrs
-            self.dev[row].copy_(self.cap_host[k], non_blocking=True)
+            # lr, momentum and the `first` flag are host scalars of the launch and the pointer rows are host memory a
+            # captured copy would re-read at every replay: a captured optimizer step would silently freeze all of them.
+            # The graphed training step (pika_amd/train_graph.py) captures the model's forward / backward only.
+            raise RuntimeError("pika_amd.optim: clip / SGD steps are eager launches (3 per step); do not capture them")
+        ptrs = [t.data_ptr() for t in tensors]
+        if self.last[row] == ptrs:      # parameters and momentum buffers stay put; so do the gradients of a replayed step
             return self.dev[row].data_ptr()
+        self.last[row] = ptrs
         g = self.gen[row] = (self.gen[row] + 1) % self.RING
         ev = self.events[g][row]
         if ev is not None:

@@ -208,6 +208,12 @@ class LazyLogProbs(torch.Tensor):
 class _RNNTLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, labels, frames_lengths, labels_lengths, blank=0):
+        wide = getattr(log_probs, "_pika_labels", None)
+        if wide is not None and labels.dim() == 2 and log_probs.dim() == 4 and labels.shape[1] < log_probs.shape[2] - 1 \
+                and wide.shape == (labels.shape[0], log_probs.shape[2] - 1):
+            # a replayed forward (pika_amd/train_graph.py) padded the label axis to its bucket: its own copy of the labels
+            # over that axis (same values in the caller's columns; nothing beyond labels_lengths is ever read)
+            labels = wide
         _check_inputs(log_probs, labels, frames_lengths, labels_lengths, blank)
         ctx.lazy = bool(getattr(log_probs, "_pika_lazy_grad_ok", False)) and _lazy_enabled()
         lib = _lib.lib()
@@ -224,8 +230,12 @@ class _RNNTLossFn(torch.autograd.Function):
             x = log_probs.buf
             with torch.cuda.device(x.device):
                 costs = torch.empty(B, dtype=torch.float32, device=x.device)
-                lse = torch.empty(B * T * U1, dtype=torch.float32, device=x.device)
-                ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=x.device)
+                # a replayed forward (pika_amd/train_graph.py) names the buffers its captured backward reads
+                ws, lse = getattr(log_probs, "_pika_loss_buffers", None) or (None, None)
+                n_ws = lib.pika_rnnt_workspace_bytes(B, T, U1)
+                if ws is None or ws.numel() != n_ws or lse.numel() != B * T * U1 or ws.device != x.device:
+                    lse = torch.empty(B * T * U1, dtype=torch.float32, device=x.device)
+                    ws = torch.empty(n_ws, dtype=torch.uint8, device=x.device)
                 part = state.partials
                 state.partials = None          # one use: 250 MB at the benchmark shape
                 with _timed("fwd"):

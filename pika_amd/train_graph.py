@@ -1,82 +1,350 @@
-"""One training step -- forward, RNN-T loss, backward, inf-norm clip, Nesterov SGD -- as ONE hipGraph.
+"""The training step of the reference loop as hipGraph replays -- BEHIND `Net.forward`, so that the UNCHANGED training
+script (trainer/train_transducer_bmuf_otfaug.py:95-110) gets it:
 
-The eager step of the reference loop (trainer/train_transducer_bmuf_otfaug.py:95-110) is ~650 kernel launches issued
-from Python: 42 ms of host time for 44 ms of device time on an idle 128-core box (profiles/r2_train_step_host_bound.txt),
-which is exactly where eight ranks on one host lose their scaling.  Captured once, the same launch sequence costs the
-host one graph launch per step and the device no launch gaps.
+    outputs = model.forward(data_batch, target_batch, len_batch, True)     # replay of graph F (everything in forward)
+    loss = transducer_loss(outputs, target_batch.int(), len_batch, ali_lens).sum()   # ~6 eager launches (this package's loss)
+    loss.backward()                                                        # loss backward (1 launch) + replay of graph B
+    torch.nn.utils.clip_grad_norm_(model.parameters(), args.grad_clip, norm_type=inf)   # 2 launches (pika_amd/optim.py)
+    optimizer.step()                                                       # 1 launch; lr / momentum read per call
 
-What makes the sequence replayable:
-  * fixed shapes: the batch lives in static device buffers the caller's tensors are copied into (the bucketed loader of
-    the recipes yields a handful of shapes; one graph per (B, T, U) shape is kept);
-  * dropout: every kernel of libpika_amd.so that takes a dropout seed adds a device word to it
-    (pika_set_dropout_salt); the word is re-drawn on the device before every replay, so each replay has new masks
-    and the forward / backward of one replay agree; torch's own dropout (the few eager-fallback call sites) is
-    graph-safe by itself (philox offsets are graph inputs);
-  * the optimizer: momentum buffers and gradients live at fixed addresses inside the graph's memory pool; the reference
-    re-creates the optimizer after every BMUF block (:121) = momentum buffers restart from zero, which is
-    `reset_momentum()` here (buf = 0.9 * 0 + g equals the first step of a fresh torch.optim.SGD);
-  * nothing on the path reads the device (the loss value stays in a static tensor; the caller decides when to read it).
-The first `warmup` calls run eagerly (they are real training steps: lazy workspaces, kernel attributes and the
-allocator reach their steady state), the next call captures and replays.
+The eager step is ~650 kernel launches issued from Python (22 ms of host CPU for 45 ms of device time); with eight ranks
+on one host that is where scaling goes.  Here the ~600 launches of the model's forward and backward are captured once
+per batch shape, the way torch.cuda.make_graphed_callables splits a callable at its autograd boundary:
+
+  * graph F: `Net.forward` on static copies of (data, labels, lengths), recorded with autograd on;
+  * graph B: `torch.autograd.grad(outputs, parameters, grad_outputs=<the loss' compact gradient>)` of that recording;
+  * `Net.forward` copies the batch into the static inputs, replays F and returns the static output buffer -- a fresh
+    `LazyLogProbs` over the raw logits, whose grad_fn is `_GraphedFn`; this package's loss reads it eagerly (log-sum-exp
+    partials from the GEMM epilogue + two gathered logits per lattice cell) into static workspace / lse buffers;
+  * `_GraphedFn.backward` gets the loss' `LazyDenseGrad` (never written: the non-zeros sit in the workspace), replays B
+    and hands the static gradient tensors to `p.grad` (accumulating if the caller left gradients in place).
+
+What makes the sequence replayable: fixed shapes (one pair of graphs per (data shape, labels shape); the graphs share ONE
+memory pool, so the activations of all shapes occupy the same memory, and an LRU bound caps the static outputs -- the
+logits alone are 7.8 GB at B = 32, T' = 240); dropout through a device-side salt word every seeded kernel of
+libpika_amd.so adds to its seed (`pika_set_dropout_salt`), re-drawn on the device before every forward; nothing on the
+path reads the device.  The optimizer is NOT captured: clip + Nesterov SGD are three eager multi-tensor launches that read
+lr / momentum from the optimizer object the script rebuilds after every BMUF block (:115-123).
+
+Whatever does not fit runs the eager step with the same values: the first `warmup` training calls (lazy workspaces,
+kernel attributes and the allocator reach their steady state), evaluation / no-grad calls, `softmax=False`, packed
+sequences (LSTM encoders), a shape seen fewer than `min_seen` times, a capture that fails (remembered; warned once).
+What cannot be served raises instead of computing something else: a backward that does not belong to the latest forward,
+log-probs that were READ between forward and backward (that normalises the static logits in place; set
+PIKA_TRAIN_GRAPH=0 for such a loop), a gradient that is not this package's loss gradient.
+
+Knobs (environment): PIKA_TRAIN_GRAPH=0 off; PIKA_TRAIN_GRAPH_WARMUP (2); PIKA_TRAIN_GRAPH_MAX (4 shapes kept);
+PIKA_TRAIN_GRAPH_MIN_SEEN (1: capture a shape the first time it appears after the warm-up); PIKA_TRAIN_GRAPH_U_BUCKET (8:
+the label axis is padded to a multiple of it).
 """
+import collections
+import os
+import warnings
+
 import torch
 
 from . import _lib
 
+_SALT = {"word": None, "users": 0}
 
-class GraphedTrainStep(object):
-    def __init__(self, model, loss_fn, make_optimizer, clip=3.0, warmup=2):
-        self.model, self.loss_fn, self.clip = model, loss_fn, float(clip)
-        self.optimizer = make_optimizer()
-        self.warmup, self.calls = int(warmup), 0
-        self.graphs = {}            # (data shape, labels shape) -> (graph, static buffers, static loss)
-        dev = next(model.parameters()).device
-        self.salt = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().pika_set_dropout_salt(self.salt.data_ptr()), "pika_set_dropout_salt")
+
+def _salt_word(device):
+    """The process-wide dropout salt word (one process drives one GPU): allocated once and never freed, so a registered
+    pointer can never dangle; registered while anybody uses it."""
+    w = _SALT["word"]
+    if w is None:
+        w = _SALT["word"] = torch.zeros(1, dtype=torch.int32, device=device)
+    if w.device != torch.device(device):
+        raise RuntimeError("pika_amd.train_graph: one process drives one GPU (salt word lives on %s, asked for %s)"
+                           % (w.device, device))
+    return w
+
+
+def _salt_acquire(device):
+    w = _salt_word(device)
+    if _SALT["users"] == 0:
+        _lib.check(_lib.lib().pika_set_dropout_salt(w.data_ptr()), "pika_set_dropout_salt")
+    _SALT["users"] += 1
+    return w
+
+
+def _salt_release():
+    if _SALT["users"] > 0:
+        _SALT["users"] -= 1
+        if _SALT["users"] == 0:
+            _lib.lib().pika_set_dropout_salt(None)
+
+
+class _Entry(object):
+    __slots__ = ("key", "gf", "gb", "inputs", "labels32", "logits", "partials", "ws", "lse", "dims", "grads", "gen", "scale")
+
+
+class StepGraphs(object):
+    """Per-model state of the graphed step (hangs off the module as `_step_graphs`; not pickled)."""
+
+    def __init__(self, model, warmup=None, max_graphs=None, min_seen=None):
+        env = os.environ.get
+        self.warmup = int(env("PIKA_TRAIN_GRAPH_WARMUP", "2")) if warmup is None else int(warmup)
+        self.max_graphs = max(1, int(env("PIKA_TRAIN_GRAPH_MAX", "4")) if max_graphs is None else int(max_graphs))
+        self.min_seen = max(1, int(env("PIKA_TRAIN_GRAPH_MIN_SEEN", "1")) if min_seen is None else int(min_seen))
+        self.u_bucket = max(1, int(env("PIKA_TRAIN_GRAPH_U_BUCKET", "8")))
+        self.entries = collections.OrderedDict()        # key -> _Entry, least recently used first
+        self.seen = {}
+        self.calls = 0
+        self.pool = None
+        self.param_ptrs = None
+        self.broken = None                              # reason the model's forward cannot be captured
+        self.last = None                                # (entry, generation) of the latest graphed forward
+        self.stats = {"replays": 0, "captures": 0, "eager": 0, "evictions": 0}
+        self.salt = _salt_acquire(next(model.parameters()).device)
+        self._closed = False
+
+    def clear(self):
+        self.entries.clear()
+        self.last = None
 
     def close(self):
-        _lib.lib().pika_set_dropout_salt(None)
+        if not self._closed:
+            self._closed = True
+            self.clear()
+            _salt_release()
 
-    def _body(self, data, labels, len_b, ali):
-        out = self.model(data, labels.long(), len_b, True)
-        loss = self.loss_fn(out, labels.int(), len_b, ali).sum()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, norm_type=float("inf"))
-        self.optimizer.step()
-        return loss
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def enable(model, warmup=None, max_graphs=None, min_seen=None):
+    """Turn the graphed step on for `model` (a pika_amd.model.transducer.Net).  Idempotent; returns the state object."""
+    st = model.__dict__.get("_step_graphs")
+    if st is None or st._closed:
+        st = StepGraphs(model, warmup, max_graphs, min_seen)
+        model.__dict__["_step_graphs"] = st
+    return st
+
+
+def disable(model):
+    st = model.__dict__.pop("_step_graphs", None)
+    if st is not None:
+        st.close()
+
+
+AUTO = False        # pika_amd.launch sets this for training scripts: every Net that trains on a HIP device is enabled
+
+
+def wanted(model, x, softmax):
+    """Does this forward call go through the graphs?  (The cheap checks; `forward` below does the rest.)"""
+    if os.environ.get("PIKA_TRAIN_GRAPH", "1") == "0":
+        return False
+    st = model.__dict__.get("_step_graphs")
+    if st is None:
+        if not AUTO or not (model.training and x.is_cuda and torch.is_grad_enabled()):
+            return False
+        st = enable(model)
+    return (st.broken is None and not st._closed and model.training and softmax and x.is_cuda and torch.is_grad_enabled()
+            and not model.pack_seq and not torch.cuda.is_current_stream_capturing())
+
+
+def _give_up(st, why):
+    st.broken = why
+    st.clear()
+    warnings.warn("pika_amd.train_graph: the training step stays an eager launch sequence (%s)" % why)
+
+
+def _capture(model, st, key, x, y, x_len):
+    from .rnnt import CompactGrad, LazyDenseGrad, LazyLogProbs
+    dev = x.device
+    e = _Entry()
+    e.key, e.gen = key, 0
+    e.inputs = [x.clone(), y.clone(), None if x_len is None else x_len.clone()]
+    e.labels32 = y.to(torch.int32)       # what the loss reads when the label axis was padded to its bucket
+    params = [p for p in model.parameters() if p.requires_grad]
+    if st.pool is None:
+        st.pool = torch.cuda.graph_pool_handle()
+    lib = _lib.lib()
+    e.gf, e.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    # thread_local: the loader thread keeps issuing its own uploads / kernels on its side stream during the capture
+    with torch.cuda.graph(e.gf, pool=st.pool, capture_error_mode="thread_local"):
+        out = model._forward_eager(e.inputs[0], e.inputs[1], e.inputs[2], True)
+    if not isinstance(out, LazyLogProbs):
+        del out
+        return None, "the joint does not hand out lazily normalised log-probs (PIKA_LAZY_LOGPROBS=0, or V > 5120)"
+    if not getattr(out, "_pika_lazy_grad_ok", False) or out.state.scale != 1.0:
+        del out
+        return None, "the loss gradient is not taken in its compact form here (PIKA_RNNT_LAZY_GRAD=0)"
+    B, T, U1, V = out.shape
+    e.logits, e.partials, e.scale = out.buf, out.state.partials, out.state.scale
+    e.dims = (B, T, U1, V, 0)
+    with torch.cuda.device(dev):
+        e.ws = torch.empty(int(lib.pika_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=dev)
+        e.lse = torch.empty(B * T * U1, dtype=torch.float32, device=dev)
+    compact = CompactGrad.__new__(CompactGrad)
+    compact.ws, compact.dims, compact.ptr, compact.version = e.ws, e.dims, 0, 0
+    lazy = LazyDenseGrad(compact, None, None, None)
+    lazy.lse = e.lse
+    with torch.cuda.graph(e.gb, pool=st.pool, capture_error_mode="thread_local"):
+        grads = torch.autograd.grad((out,), params, grad_outputs=(lazy,), allow_unused=True)
+    del out
+    e.grads = [(p, g) for p, g in zip(params, grads) if g is not None]
+    return e, None
+
+
+class _GraphedFn(torch.autograd.Function):
+    """The autograd node of a replayed forward: `forward` wraps the static logits, `backward` replays graph B."""
+
+    @staticmethod
+    def forward(ctx, st, e, *params):
+        from .rnnt import LazyLogProbs, LogitsState
+        state = LogitsState(e.scale)
+        state.partials = e.partials
+        ctx.st, ctx.e, ctx.gen, ctx.state, ctx.n = st, e, e.gen, state, len(params)
+        ctx.set_materialize_grads(False)
+        return LazyLogProbs(state, e.logits)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .rnnt import LazyDenseGrad
+        st, e = ctx.st, ctx.e
+        none = (None,) * (2 + ctx.n)
+        if g is None:
+            return none
+        if st.last is None or st.last[0] is not e or st.last[1] != ctx.gen or e.gen != ctx.gen:
+            raise RuntimeError("pika_amd.train_graph: backward of a forward that is not the model's latest one (its static "
+                               "buffers have been overwritten); PIKA_TRAIN_GRAPH=0 runs such a loop eagerly")
+        if not ctx.state.raw:
+            raise RuntimeError("pika_amd.train_graph: the log-probs were read between forward and backward, which "
+                               "normalised the graph's logits buffer in place; PIKA_TRAIN_GRAPH=0 runs such a loop eagerly")
+        if not (isinstance(g, LazyDenseGrad) and g._dense is None and g.lse is not None
+                and tuple(g.compact.dims) == tuple(e.dims)):
+            raise RuntimeError("pika_amd.train_graph: the gradient of the model's output is not the compact gradient of this "
+                               "package's RNNTLoss(blank=0) on the raw logits (got %r); PIKA_TRAIN_GRAPH=0 runs such a loop "
+                               "eagerly" % (g,))
+        if g.compact.ws.data_ptr() != e.ws.data_ptr():
+            e.ws.copy_(g.compact.ws)
+        if g.lse.data_ptr() != e.lse.data_ptr():
+            e.lse.copy_(g.lse)
+        # a p.grad that IS the static tensor (the caller did not zero its gradients, or backs through a retained graph
+        # twice) holds the earlier values the replay is about to overwrite: accumulate as autograd would
+        kept = {id(gr): gr.clone() for p, gr in e.grads if p.grad is gr}
+        e.gb.replay()
+        for p, gr in e.grads:
+            if p.grad is None:
+                p.grad = gr
+            elif p.grad is gr:
+                p.grad = kept[id(gr)] + gr
+            else:
+                p.grad.add_(gr)
+        return none
+
+
+def forward(model, x, y, x_len, softmax):
+    """`Net.forward` when `wanted(...)`: eager during warm-up / for shapes not (yet) captured, otherwise a replay."""
+    st = model._step_graphs
+    st.calls += 1
+    st.salt.random_()                                    # device-side draw: new dropout masks, no host involvement
+    if st.calls <= st.warmup:
+        st.stats["eager"] += 1
+        return model._forward_eager(x, y, x_len, softmax)
+    params = [p for p in model.parameters() if p.requires_grad]
+    ptrs = tuple(p.data_ptr() for p in params)
+    if st.param_ptrs != ptrs:                            # BMUF re-points parameters into its flat vector; .to(); ...
+        st.clear()
+        st.param_ptrs = ptrs
+    # the label axis is padded to a multiple of `u_bucket` with the embedding's padding index -- what the loader itself
+    # pads the shorter utterances of a batch with (otf_utt_loader.py:262-270): the prediction network masks those
+    # positions as keys and is causal, the loss never reads lattice columns beyond an utterance's label count, so the
+    # values of every lattice cell the loss reads are unchanged (tests/test_train_step_gpu.py) while batches whose
+    # longest label sequences differ by a few labels share one pair of graphs.  (The TIME axis is not padded: BatchNorm
+    # statistics and the encoder's unmasked self-attention run over every frame of the batch, so extra frames would
+    # change the values.)
+    U = y.shape[1]
+    Ub = -(-U // st.u_bucket) * st.u_bucket
+    pad = getattr(model.embed, "padding_idx", None)
+    if Ub != U and (pad is None or y.dim() != 2):
+        Ub = U
+    if Ub != U:
+        yp = torch.full((y.shape[0], Ub), int(pad), dtype=y.dtype, device=y.device)
+        yp[:, :U] = y
+        y = yp
+    key = (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype,
+           None if x_len is None else (tuple(x_len.shape), x_len.dtype))
+    e = st.entries.get(key)
+    if e is None:
+        n = st.seen[key] = st.seen.get(key, 0) + 1
+        if n < st.min_seen:
+            st.stats["eager"] += 1
+            return model._forward_eager(x, y, x_len, softmax)
+        while len(st.entries) >= st.max_graphs:
+            st.entries.popitem(last=False)               # least recently used: its static outputs go back to the pool
+            st.stats["evictions"] += 1
+        try:
+            e, why = _capture(model, st, key, x, y, x_len)
+        except Exception as err:                         # a launch the stream capture refuses, out of memory, ...
+            e, why = None, "%s: %s" % (type(err).__name__, str(err).split("\n")[0])
+        if e is None:
+            _give_up(st, why)
+            st.stats["eager"] += 1
+            return model._forward_eager(x, y, x_len, softmax)
+        st.entries[key] = e
+        st.stats["captures"] += 1
+    else:
+        st.entries.move_to_end(key)
+        for s, t in zip(e.inputs, (x, y, x_len)):
+            if s is not None:
+                s.copy_(t, non_blocking=True)
+        e.labels32.copy_(y, non_blocking=True)
+    e.gen += 1
+    st.last = (e, e.gen)
+    e.gf.replay()
+    st.stats["replays"] += 1
+    out = _GraphedFn.apply(st, e, *params)
+    out._pika_lazy_grad_ok = True
+    out._pika_loss_buffers = (e.ws, e.lse)               # the loss writes its workspace / lse where graph B reads them
+    out._pika_labels = e.labels32                        # the labels over the padded label axis
+    return out
+
+
+class GraphedTrainStep(object):
+    """The reference loop's step, spelled out, on a model with the graphs enabled (bench.py, tests): zero_grad,
+    forward, loss, backward, inf-norm clip, optimizer step.  `optimizer` may be replaced / re-parameterised between
+    calls (the script rebuilds it after every BMUF block, :115-123): nothing of it is captured."""
+
+    def __init__(self, model, loss_fn, make_optimizer, clip=3.0, warmup=2, max_graphs=None, min_seen=None):
+        self.model, self.loss_fn, self.clip = model, loss_fn, float(clip)
+        self.make_optimizer = make_optimizer
+        self.optimizer = make_optimizer()
+        disable(model)
+        self.state = enable(model, warmup=warmup, max_graphs=max_graphs, min_seen=min_seen)
+
+    @property
+    def graphs(self):
+        return self.state.entries
+
+    @property
+    def salt(self):
+        return self.state.salt
+
+    def close(self):
+        disable(self.model)
 
     def reset_momentum(self):
-        """What re-creating the optimizer does to its state (train_transducer_bmuf_otfaug.py:121), at fixed addresses."""
-        bufs = [st["momentum_buffer"] for st in self.optimizer.state.values() if st.get("momentum_buffer") is not None]
-        if bufs:
-            torch._foreach_zero_(bufs)
+        """What re-creating the optimizer does to its state (train_transducer_bmuf_otfaug.py:121)."""
+        self.optimizer = self.make_optimizer()
 
-    def _capture(self, data, labels, len_b, ali):
-        static = [t.clone() for t in (data, labels, len_b, ali)]
-        g = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)      # gradients are (re)allocated inside the graph's pool
-        # thread_local: the loader thread keeps issuing its own uploads / kernels on its side stream during the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            loss = self._body(*static)
-        entry = (g, static, loss.detach())
-        self.graphs[(tuple(data.shape), tuple(labels.shape))] = entry
-        return entry
+    def set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            g["lr"] = float(lr)
 
     def __call__(self, data, labels, len_b, ali):
         """data (B,T,F) f32 after CMVN / SpecAugment, labels (B,U), len_b / ali (B,) int32: one optimisation step;
-        returns the summed loss as a device tensor (static across calls: read or clone it before the next call)."""
-        self.calls += 1
-        self.salt.random_()                              # device-side draw: no host involvement
-        if self.calls <= self.warmup:
-            self.optimizer.zero_grad(set_to_none=True)
-            return self._body(data, labels, len_b, ali).detach()
-        entry = self.graphs.get((tuple(data.shape), tuple(labels.shape)))
-        fresh = entry is None
-        if fresh:
-            entry = self._capture(data, labels, len_b, ali)     # records, does not run: replayed below on this batch
-        g, static, loss = entry
-        if not fresh:
-            for s, t in zip(static, (data, labels, len_b, ali)):
-                s.copy_(t, non_blocking=True)
-        g.replay()
-        return loss
+        returns the summed loss as a device tensor."""
+        self.optimizer.zero_grad(set_to_none=True)
+        out = self.model(data, labels.long(), len_b, True)
+        loss = self.loss_fn(out, labels.int(), len_b, ali).sum()
+        loss.backward()
+        if self.clip > 0:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip, norm_type=float("inf"))
+        self.optimizer.step()
+        return loss.detach()

@@ -244,3 +244,191 @@ def test_graphed_train_step_draws_new_dropout_masks_per_replay(hip_device):
     finally:
         fused_optim.uninstall()
         G.PRECISION = old
+
+
+def _batch(hip_device, g, B, T, U, V, pad_from=None):
+    data = torch.randn(B, T, 240, generator=g).to(hip_device)
+    labels = torch.randint(1, V, (B, U), generator=g)
+    ali = torch.full((B,), U, dtype=torch.int32)
+    if pad_from is not None:            # ragged label counts, padded with padding_idx as the loader does
+        for b in range(B):
+            n = pad_from + (b % (U - pad_from + 1))
+            labels[b, n:] = V
+            ali[b] = n
+    len_b = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.int32, device=hip_device)
+    return data, labels.to(hip_device), len_b, ali.to(hip_device)
+
+
+def _script_loop(model, batches, lr=0.0005, rebuild_every=0):
+    """The body of trainer/train_transducer_bmuf_otfaug.py:76-123 on device tensors, verbatim in what it calls: NOTHING
+    of pika_amd.train_graph is named here -- with train_graph.AUTO set (what pika_amd.launch does) Net.forward itself
+    serves the step from its graphs."""
+    from warp_rnnt import RNNTLoss
+    transducer_loss = RNNTLoss(blank=0, reduction='sum').apply
+    optimizer = torch.optim.SGD(model.parameters(), lr, momentum=0.9, nesterov=True)
+    losses = []
+    for num_done, (data_batch, target_batch, len_batch, ali_lens) in enumerate(batches):
+        optimizer.zero_grad()
+        outputs = model.forward(data_batch, target_batch.long(), len_batch, True)
+        loss = transducer_loss(outputs, target_batch.int(), len_batch, ali_lens)
+        loss = loss.sum()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+        optimizer.step()
+        if rebuild_every and num_done != 0 and num_done % rebuild_every == 0:       # :112-123 after a BMUF block
+            lr *= 0.9
+            optimizer = torch.optim.SGD(model.parameters(), lr, momentum=0.9, nesterov=True)
+        losses.append(loss.item())
+    return losses
+
+
+def test_script_loop_gets_the_graphs_and_the_eager_loss_sequence(hip_device, monkeypatch):
+    """The unchanged script's loop, spelled out: with the launcher's switch (train_graph.AUTO) the model's forward and
+    backward are graph replays from the third step on -- the loss sequence and the parameters after 8 steps (optimizer
+    rebuilt with a new lr every 3 steps, ragged label counts padded to the bucket) equal those of the same loop with
+    PIKA_TRAIN_GRAPH=0."""
+    import copy
+    from pika_amd import gemm as G
+    from pika_amd import train_graph
+    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0)
+    ref = copy.deepcopy(model)
+    init = [p.detach().clone() for p in model.parameters()]
+    g = torch.Generator().manual_seed(21)
+    batches = [_batch(hip_device, g, 4, 300, 11, 500, pad_from=7) for _ in range(8)]
+    old, old_auto = G.PRECISION, train_graph.AUTO
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        monkeypatch.setenv("PIKA_TRAIN_GRAPH", "0")
+        train_graph.AUTO = True
+        want = _script_loop(ref, batches, rebuild_every=3)
+        assert "_step_graphs" not in ref.__dict__
+        monkeypatch.setenv("PIKA_TRAIN_GRAPH", "1")
+        got = _script_loop(model, batches, rebuild_every=3)
+        st = model._step_graphs
+        assert st.broken is None, st.broken
+        assert st.stats["eager"] == 2 and st.stats["captures"] == 1 and st.stats["replays"] == 6, st.stats
+        key = next(iter(st.entries))
+        assert key[2] == (4, 16)                               # 11 labels padded to the bucket of 16
+        train_graph.disable(model)
+    finally:
+        train_graph.AUTO = old_auto
+        fused_optim.uninstall()
+        G.PRECISION = old
+    assert torch.allclose(torch.tensor(got), torch.tensor(want), rtol=5e-4), (got, want)
+    worst = []
+    for (n, p), q, p0 in zip(model.named_parameters(), ref.parameters(), init):
+        moved = (q - p0).norm().item()
+        worst.append(((p - q).norm().item() / max(moved, 1e-12), n, moved))
+    big = max(w[2] for w in worst)
+    worst = sorted((w for w in worst if w[2] > 1e-3 * big), reverse=True)
+    assert worst[0][0] < 0.1, worst[:5]
+
+
+def test_graphed_step_follows_the_optimizer_object(hip_device):
+    """Nothing of the optimizer is captured (a captured step froze lr and the first-step flag): with lr = 0 the
+    replays leave the parameters alone, after set_lr they move, and a rebuilt optimizer (fresh momentum) keeps working."""
+    from pika_amd import gemm as G
+    from pika_amd.train_graph import GraphedTrainStep
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0)
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        gs = GraphedTrainStep(model, loss_fn, lambda: torch.optim.SGD(model.parameters(), 0.0, momentum=0.9, nesterov=True),
+                              clip=3.0, warmup=1)
+        p0 = [p.detach().clone() for p in model.parameters()]
+        for b in batches[:3]:
+            gs(*b)
+        assert gs.state.stats["replays"] == 2
+        assert all(torch.equal(p, q) for p, q in zip(model.parameters(), p0))
+        gs.set_lr(1e-3)
+        gs(*batches[3])
+        moved = sum(int(not torch.equal(p, q)) for p, q in zip(model.parameters(), p0))
+        assert moved > 0.9 * len(p0), moved
+        gs.reset_momentum()             # what the script's rebuild after a BMUF block does
+        gs.set_lr(1e-3)
+        l = gs(*batches[4])
+        assert torch.isfinite(l)
+        assert gs.state.stats["replays"] == 4 and gs.state.stats["captures"] == 1
+        gs.close()
+    finally:
+        fused_optim.uninstall()
+        G.PRECISION = old
+
+
+def test_graph_cache_is_bounded_under_a_six_shape_schedule(hip_device):
+    """Six batch shapes in rotation against a bound of three: never more than three pairs of graphs alive, the least
+    recently used one goes, the device memory the process holds stops growing after the first round (the graphs share
+    one pool), and the losses are those of the eager loop."""
+    import copy
+    from pika_amd import gemm as G
+    from pika_amd.train_graph import GraphedTrainStep
+    model, loss_fn, _, fused_optim = _small_step_harness(hip_device, 0.0)
+    ref = copy.deepcopy(model)
+    g = torch.Generator().manual_seed(31)
+    shapes = [(300, 8), (332, 8), (364, 16), (300, 16), (396, 8), (332, 24)]
+    sched = [_batch(hip_device, g, 4, T, U, 500) for _ in range(3) for (T, U) in shapes]
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        def make(m):
+            return lambda: torch.optim.SGD(m.parameters(), 0.0005, momentum=0.9, nesterov=True)
+        o = make(ref)()
+        want = []
+        for b in sched:
+            o.zero_grad(set_to_none=True)
+            loss = loss_fn(ref(b[0], b[1].long(), b[2], True), b[1].int(), b[2], b[3]).sum()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 3.0, norm_type=float("inf"))
+            o.step()
+            want.append(loss.item())
+        gs = GraphedTrainStep(model, loss_fn, make(model), clip=3.0, warmup=2, max_graphs=3)
+        got, reserved = [], []
+        for i, b in enumerate(sched):
+            got.append(gs(*b).item())
+            assert len(gs.graphs) <= 3
+            if (i + 1) % len(shapes) == 0:
+                torch.cuda.synchronize()
+                reserved.append(torch.cuda.memory_reserved())
+        st = gs.state.stats
+        assert st["evictions"] >= 9 and st["captures"] >= 12, st       # every shape is re-captured in every round
+        assert reserved[2] <= reserved[1] * 1.05 + (64 << 20), reserved
+        gs.close()
+    finally:
+        fused_optim.uninstall()
+        G.PRECISION = old
+    assert torch.allclose(torch.tensor(got), torch.tensor(want), rtol=1e-3), (got, want)
+
+
+def test_graphed_step_refuses_what_it_cannot_serve(hip_device):
+    """Reading the log-probs between forward and backward normalises the static logits in place: the backward raises
+    instead of differentiating something else; a forward without backward followed by another forward is fine."""
+    from pika_amd import gemm as G
+    from pika_amd.train_graph import GraphedTrainStep
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0)
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        gs = GraphedTrainStep(model, loss_fn, lambda: torch.optim.SGD(model.parameters(), 1e-4, momentum=0.9, nesterov=True),
+                              clip=3.0, warmup=1)
+        gs(*batches[0])
+        gs(*batches[1])                                          # captured
+        d, y, lb, ali = batches[2]
+        out = model(d, y.long(), lb, True)                       # replay, no backward
+        out2 = model(d, y.long(), lb, True)
+        s = float(out2.exp().sum(-1).mean())                     # READ: rows of probabilities sum to one
+        assert abs(s - 1.0) < 1e-3
+        loss = loss_fn(out2, y.int(), lb, ali).sum()
+        with pytest.raises(RuntimeError, match="read between forward and backward"):
+            loss.backward()
+        loss = loss_fn(out, y.int(), lb, ali).sum()
+        with pytest.raises(RuntimeError, match="not the model's latest"):
+            loss.backward()
+        assert torch.isfinite(gs(*batches[3]))                   # and the next step is served again
+        gs.close()
+    finally:
+        fused_optim.uninstall()
+        G.PRECISION = old
