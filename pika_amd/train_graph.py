@@ -76,7 +76,8 @@ def _salt_release():
 
 
 class _Entry(object):
-    __slots__ = ("key", "gf", "gb", "inputs", "labels32", "logits", "partials", "ws", "lse", "dims", "grads", "gen", "scale")
+    __slots__ = ("key", "gf", "gb", "inputs", "labels32", "logits", "partials", "ws", "lse", "dims", "grads", "gen", "scale",
+                 "kind", "gout")
 
 
 class StepGraphs(object):
@@ -160,33 +161,75 @@ def _capture(model, st, key, x, y, x_len):
     e.key, e.gen = key, 0
     e.inputs = [x.clone(), y.clone(), None if x_len is None else x_len.clone()]
     e.labels32 = y.to(torch.int32)       # what the loss reads when the label axis was padded to its bucket
-    params = [p for p in model.parameters() if p.requires_grad]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    params = [p for _, p in named]
+    # The recording differentiates fresh leaf ALIASES of the parameters (same storage), not the parameters themselves: the
+    # reference loop keeps `loss` / `outputs` of the previous iteration alive across the next forward, and with them the
+    # parameters' AccumulateGrad nodes, which belong to the stream that step ran on -- the autograd engine would then make
+    # THAT stream wait for the capturing one inside the capture (torch warns "AccumulateGrad node's stream does not match";
+    # hipStreamEndCapture crashes).  The aliases' nodes are born on the capture stream.
+    aliases = {n: p.detach().requires_grad_(True) for n, p in named}
     if st.pool is None:
         st.pool = torch.cuda.graph_pool_handle()
     lib = _lib.lib()
     e.gf, e.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     # thread_local: the loader thread keeps issuing its own uploads / kernels on its side stream during the capture
-    with torch.cuda.graph(e.gf, pool=st.pool, capture_error_mode="thread_local"):
-        out = model._forward_eager(e.inputs[0], e.inputs[1], e.inputs[2], True)
-    if not isinstance(out, LazyLogProbs):
+    # (not torch.func.functional_call: with a module registered under two names -- the embedding the prediction network
+    # shares with the transducer -- it leaves the alias in place of the Parameter when it restores the module)
+    by_id = {id(p): aliases[n] for n, p in named}
+    swapped = []
+    for mod in model.modules():
+        for k, p in list(mod._parameters.items()):
+            if p is not None and id(p) in by_id:
+                swapped.append((mod, k, p))
+                mod._parameters[k] = by_id[id(p)]
+    try:
+        with torch.cuda.graph(e.gf, pool=st.pool, capture_error_mode="thread_local"):
+            out = model._forward_eager(e.inputs[0], e.inputs[1], e.inputs[2], True)
+    finally:
+        for mod, k, p in swapped:
+            mod._parameters[k] = p
+    compact_ok = (isinstance(out, LazyLogProbs) and getattr(out, "_pika_lazy_grad_ok", False) and out.state.scale == 1.0
+                  and out.dim() == 4)
+    if compact_ok:
+        # the fast form: raw logits out, the loss' compact gradient in (neither log-probs nor a dense gradient exist)
+        e.kind = "compact"
+        B, T, U1, V = out.shape
+        e.logits, e.partials, e.scale = out.buf, out.state.partials, out.state.scale
+        e.dims = (B, T, U1, V, 0)
+        with torch.cuda.device(dev):
+            e.ws = torch.empty(int(lib.pika_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=dev)
+            e.lse = torch.empty(B * T * U1, dtype=torch.float32, device=dev)
+        compact = CompactGrad.__new__(CompactGrad)
+        compact.ws, compact.dims, compact.ptr, compact.version = e.ws, e.dims, 0, 0
+        gout = LazyDenseGrad(compact, None, None, None)
+        gout.lse = e.lse
+    elif type(out) is torch.Tensor and out.requires_grad:
+        # the general form (vocabularies the lazy joint does not take, PIKA_LAZY_LOGPROBS=0, ...): a plain output tensor
+        # and a dense gradient copied into a static buffer, as torch.cuda.make_graphed_callables does it
+        e.kind = "dense"
+        e.logits, e.partials, e.scale, e.ws, e.lse, e.dims = out, None, 1.0, None, None, None
+        with torch.cuda.device(dev):
+            gout = e.gout = torch.empty_like(out)
+    else:
         del out
-        return None, "the joint does not hand out lazily normalised log-probs (PIKA_LAZY_LOGPROBS=0, or V > 5120)"
-    if not getattr(out, "_pika_lazy_grad_ok", False) or out.state.scale != 1.0:
-        del out
-        return None, "the loss gradient is not taken in its compact form here (PIKA_RNNT_LAZY_GRAD=0)"
-    B, T, U1, V = out.shape
-    e.logits, e.partials, e.scale = out.buf, out.state.partials, out.state.scale
-    e.dims = (B, T, U1, V, 0)
-    with torch.cuda.device(dev):
-        e.ws = torch.empty(int(lib.pika_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=dev)
-        e.lse = torch.empty(B * T * U1, dtype=torch.float32, device=dev)
-    compact = CompactGrad.__new__(CompactGrad)
-    compact.ws, compact.dims, compact.ptr, compact.version = e.ws, e.dims, 0, 0
-    lazy = LazyDenseGrad(compact, None, None, None)
-    lazy.lse = e.lse
+        return None, "the model's output is neither this package's lazy log-probs nor a plain tensor"
+    err = None
     with torch.cuda.graph(e.gb, pool=st.pool, capture_error_mode="thread_local"):
-        grads = torch.autograd.grad((out,), params, grad_outputs=(lazy,), allow_unused=True)
+        try:
+            grads = torch.autograd.grad((out,), [aliases[n] for n, _ in named], grad_outputs=(gout,), allow_unused=True)
+        except Exception as ex:         # reported below; leaving the context with an exception in flight ends the capture twice
+            err = ex
+            if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG"):
+                import traceback
+                traceback.print_exc()
+    if err is not None:
+        del out
+        return None, "backward capture: %s: %s" % (type(err).__name__, str(err).split("\n")[0])
     del out
+    if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG"):
+        print("train_graph capture: kind %s, no gradient for %s" % (e.kind, [n for (n, _), g in zip(named, grads) if g is None]),
+              flush=True)
     e.grads = [(p, g) for p, g in zip(params, grads) if g is not None]
     return e, None
 
@@ -197,10 +240,13 @@ class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, st, e, *params):
         from .rnnt import LazyLogProbs, LogitsState
+        ctx.set_materialize_grads(False)
+        if e.kind == "dense":
+            ctx.st, ctx.e, ctx.gen, ctx.state, ctx.n = st, e, e.gen, None, len(params)
+            return e.logits.detach()
         state = LogitsState(e.scale)
         state.partials = e.partials
         ctx.st, ctx.e, ctx.gen, ctx.state, ctx.n = st, e, e.gen, state, len(params)
-        ctx.set_materialize_grads(False)
         return LazyLogProbs(state, e.logits)
 
     @staticmethod
@@ -213,18 +259,21 @@ class _GraphedFn(torch.autograd.Function):
         if st.last is None or st.last[0] is not e or st.last[1] != ctx.gen or e.gen != ctx.gen:
             raise RuntimeError("pika_amd.train_graph: backward of a forward that is not the model's latest one (its static "
                                "buffers have been overwritten); PIKA_TRAIN_GRAPH=0 runs such a loop eagerly")
-        if not ctx.state.raw:
+        if e.kind == "dense":
+            e.gout.copy_(g.dense() if isinstance(g, LazyDenseGrad) else g)
+        elif not ctx.state.raw:
             raise RuntimeError("pika_amd.train_graph: the log-probs were read between forward and backward, which "
                                "normalised the graph's logits buffer in place; PIKA_TRAIN_GRAPH=0 runs such a loop eagerly")
-        if not (isinstance(g, LazyDenseGrad) and g._dense is None and g.lse is not None
-                and tuple(g.compact.dims) == tuple(e.dims)):
+        elif not (isinstance(g, LazyDenseGrad) and g._dense is None and g.lse is not None
+                  and tuple(g.compact.dims) == tuple(e.dims)):
             raise RuntimeError("pika_amd.train_graph: the gradient of the model's output is not the compact gradient of this "
                                "package's RNNTLoss(blank=0) on the raw logits (got %r); PIKA_TRAIN_GRAPH=0 runs such a loop "
                                "eagerly" % (g,))
-        if g.compact.ws.data_ptr() != e.ws.data_ptr():
-            e.ws.copy_(g.compact.ws)
-        if g.lse.data_ptr() != e.lse.data_ptr():
-            e.lse.copy_(g.lse)
+        else:
+            if g.compact.ws.data_ptr() != e.ws.data_ptr():
+                e.ws.copy_(g.compact.ws)
+            if g.lse.data_ptr() != e.lse.data_ptr():
+                e.lse.copy_(g.lse)
         # a p.grad that IS the static tensor (the caller did not zero its gradients, or backs through a retained graph
         # twice) holds the earlier values the replay is about to overwrite: accumulate as autograd would
         kept = {id(gr): gr.clone() for p, gr in e.grads if p.grad is gr}
@@ -300,8 +349,9 @@ def forward(model, x, y, x_len, softmax):
     e.gf.replay()
     st.stats["replays"] += 1
     out = _GraphedFn.apply(st, e, *params)
-    out._pika_lazy_grad_ok = True
-    out._pika_loss_buffers = (e.ws, e.lse)               # the loss writes its workspace / lse where graph B reads them
+    if e.kind == "compact":
+        out._pika_lazy_grad_ok = True
+        out._pika_loss_buffers = (e.ws, e.lse)           # the loss writes its workspace / lse where graph B reads them
     out._pika_labels = e.labels32                        # the labels over the padded label axis
     return out
 

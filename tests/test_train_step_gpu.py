@@ -140,12 +140,12 @@ def test_bf16_mode_matches_parity_mode_on_the_full_architecture(hip_device):
     print("worst relative gradient difference:", worst)
 
 
-def _small_step_harness(hip_device, dropout):
+def _small_step_harness(hip_device, dropout, V=500):
     sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
     from pika_amd import optim as fused_optim
     from pika_amd.model.transducer import Net
     from pika_amd.rnnt import RNNTLoss
-    B, T, U, V = 4, 300, 8, 500
+    B, T, U = 4, 300, 8        # V = 500: the joint's general (dense log-prob) form; V = 512: the lazy / compact-gradient form
     opt = SimpleNamespace(rnn_size=256, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn",
                           dropout=dropout, enc_layers=4, dec_layers=1, embd_dim=64, padding_idx=V)
     torch.manual_seed(11)
@@ -282,34 +282,34 @@ def _script_loop(model, batches, lr=0.0005, rebuild_every=0):
     return losses
 
 
-def test_script_loop_gets_the_graphs_and_the_eager_loss_sequence(hip_device, monkeypatch):
+def test_script_loop_gets_the_graphs_and_the_eager_loss_sequence(hip_device):
     """The unchanged script's loop, spelled out: with the launcher's switch (train_graph.AUTO) the model's forward and
     backward are graph replays from the third step on -- the loss sequence and the parameters after 8 steps (optimizer
-    rebuilt with a new lr every 3 steps, ragged label counts padded to the bucket) equal those of the same loop with
-    PIKA_TRAIN_GRAPH=0."""
+    rebuilt with a new lr every 3 steps, ragged label counts padded to the bucket) equal those of the same loop run as an
+    eager launch sequence."""
     import copy
     from pika_amd import gemm as G
     from pika_amd import train_graph
-    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0)
+    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0, V=512)
     ref = copy.deepcopy(model)
     init = [p.detach().clone() for p in model.parameters()]
     g = torch.Generator().manual_seed(21)
-    batches = [_batch(hip_device, g, 4, 300, 11, 500, pad_from=7) for _ in range(8)]
+    batches = [_batch(hip_device, g, 4, 300, 11, 512, pad_from=7) for _ in range(8)]
     old, old_auto = G.PRECISION, train_graph.AUTO
     G.PRECISION = "mixed"
     fused_optim.install()
     try:
-        monkeypatch.setenv("PIKA_TRAIN_GRAPH", "0")
-        train_graph.AUTO = True
+        train_graph.AUTO = False                               # = PIKA_TRAIN_GRAPH=0: the eager launch sequence
         want = _script_loop(ref, batches, rebuild_every=3)
         assert "_step_graphs" not in ref.__dict__
-        monkeypatch.setenv("PIKA_TRAIN_GRAPH", "1")
+        train_graph.AUTO = True                                # what pika_amd.launch sets
         got = _script_loop(model, batches, rebuild_every=3)
         st = model._step_graphs
         assert st.broken is None, st.broken
         assert st.stats["eager"] == 2 and st.stats["captures"] == 1 and st.stats["replays"] == 6, st.stats
         key = next(iter(st.entries))
         assert key[2] == (4, 16)                               # 11 labels padded to the bucket of 16
+        assert st.entries[key].kind == "compact"               # raw logits out, the loss' compact gradient in
         train_graph.disable(model)
     finally:
         train_graph.AUTO = old_auto
@@ -364,11 +364,11 @@ def test_graph_cache_is_bounded_under_a_six_shape_schedule(hip_device):
     import copy
     from pika_amd import gemm as G
     from pika_amd.train_graph import GraphedTrainStep
-    model, loss_fn, _, fused_optim = _small_step_harness(hip_device, 0.0)
+    model, loss_fn, _, fused_optim = _small_step_harness(hip_device, 0.0, V=512)
     ref = copy.deepcopy(model)
     g = torch.Generator().manual_seed(31)
     shapes = [(300, 8), (332, 8), (364, 16), (300, 16), (396, 8), (332, 24)]
-    sched = [_batch(hip_device, g, 4, T, U, 500) for _ in range(3) for (T, U) in shapes]
+    sched = [_batch(hip_device, g, 4, T, U, 512) for _ in range(3) for (T, U) in shapes]
     old = G.PRECISION
     G.PRECISION = "mixed"
     fused_optim.install()
@@ -407,7 +407,7 @@ def test_graphed_step_refuses_what_it_cannot_serve(hip_device):
     instead of differentiating something else; a forward without backward followed by another forward is fine."""
     from pika_amd import gemm as G
     from pika_amd.train_graph import GraphedTrainStep
-    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0)
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0, V=512)
     old = G.PRECISION
     G.PRECISION = "mixed"
     fused_optim.install()
@@ -416,6 +416,7 @@ def test_graphed_step_refuses_what_it_cannot_serve(hip_device):
                               clip=3.0, warmup=1)
         gs(*batches[0])
         gs(*batches[1])                                          # captured
+        assert next(iter(gs.graphs.values())).kind == "compact"
         d, y, lb, ali = batches[2]
         out = model(d, y.long(), lb, True)                       # replay, no backward
         out2 = model(d, y.long(), lb, True)
