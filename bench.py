@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
 
+import pika_amd  # noqa: E402,F401  (first: sets the HIP runtime flag the graphed train step needs, pika_amd/__init__.py)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -914,6 +915,10 @@ def cpu_baseline_mbr(args, blank_bias, B=2):
 
 
 def main():
+    # a benchmark must never hang a GPU box: after PIKA_BENCH_WATCHDOG seconds (default 1500) every thread's stack goes to
+    # stderr and the process exits
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("PIKA_BENCH_WATCHDOG", "1500")), exit=True)
     if os.environ.get("PIKA_BENCH_WATCHDOG"):      # dump every thread's stack if the run exceeds N seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["PIKA_BENCH_WATCHDOG"]), exit=True)

@@ -9,3 +9,29 @@ Nothing in this package imports ``oracle/`` and there is no CPU fallback: ops ra
 HIP library is missing or if they are handed non-GPU tensors.
 """
 __version__ = "0.1.0"
+
+import os as _os
+import sys as _sys
+
+
+def _hip_graph_workaround():
+    """ROCm 7.0 HIP runtime, MI355X: with the runtime's "graph packet capture" fast path (AQL packets pre-built at
+    hipGraphInstantiate; DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) two graph execs replayed ALTERNATELY with ordinary
+    launches in between -- the forward / backward graphs of pika_amd.train_graph around the eager loss, clip and SGD
+    launches -- go wrong from about the tenth replay: a replay's kernels run on stale state (the training loss of a
+    replayed loop leaves the eager loop's, bit-identical for nine steps, at the tenth; any host synchronisation placed
+    between the launches moves the step at which it happens; with the fast path off the two loops agree step for step,
+    tools/graph_dropout_diff.py).  The flag is read once, when the HIP runtime initialises, so it is set here, at import
+    -- before torch makes its first HIP call in the normal order of imports.  Decode (one exec replayed back to back) is
+    not affected either way and costs the same with the flag off (171 vs 173 ms per batch at configs[4])."""
+    if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ:
+        return _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
+    torch = _sys.modules.get("torch")
+    late = torch is not None and torch.cuda.is_initialized()
+    _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    return not late
+
+
+# False: the HIP runtime was initialised before this package could turn the fast path off (or the user turned it on):
+# pika_amd.train_graph then keeps the training step an eager launch sequence
+HIP_GRAPHS_SAFE_TO_ALTERNATE = _hip_graph_workaround()

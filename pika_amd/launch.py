@@ -30,6 +30,7 @@ DROPIN = os.path.join(HERE, "dropin")
 
 
 def install_shims(legacy_int_div=False):
+    import pika_amd  # noqa: F401  (first: turns the HIP runtime's graph packet-capture fast path off before torch touches HIP)
     import torch
     if "torch._six" not in sys.modules:
         six = types.ModuleType("torch._six")
@@ -96,6 +97,9 @@ def main(argv=None):
         if p in sys.path:
             sys.path.remove(p)
         sys.path.insert(0, p)
+    if os.environ.get("PIKA_LAUNCH_WATCHDOG"):      # diagnostics on a GPU box: dump every thread's stack and exit after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PIKA_LAUNCH_WATCHDOG"]), exit=True)
     install_shims(legacy_int_div)
     for m in preload:
         importlib.import_module(m)

@@ -19,7 +19,8 @@ per batch shape, the way torch.cuda.make_graphed_callables splits a callable at 
   * `_GraphedFn.backward` gets the loss' `LazyDenseGrad` (never written: the non-zeros sit in the workspace), replays B
     and hands the static gradient tensors to `p.grad` (accumulating if the caller left gradients in place).
 
-What makes the sequence replayable: fixed shapes (one pair of graphs per (data shape, labels shape); the graphs share ONE
+What makes the sequence replayable: fixed shapes (one pair of graphs per (data shape, label-axis width); a batch whose label
+axis is a few labels narrower than an existing pair's is padded onto it; the time axis is never padded; the graphs share ONE
 memory pool, so the activations of all shapes occupy the same memory, and an LRU bound caps the static outputs -- the
 logits alone are 7.8 GB at B = 32, T' = 240); dropout through a device-side salt word every seeded kernel of
 libpika_amd.so adds to its seed (`pika_set_dropout_salt`), re-drawn on the device before every forward; nothing on the
@@ -34,8 +35,9 @@ log-probs that were READ between forward and backward (that normalises the stati
 PIKA_TRAIN_GRAPH=0 for such a loop), a gradient that is not this package's loss gradient.
 
 Knobs (environment): PIKA_TRAIN_GRAPH=0 off; PIKA_TRAIN_GRAPH_WARMUP (2); PIKA_TRAIN_GRAPH_MAX (4 shapes kept);
-PIKA_TRAIN_GRAPH_MIN_SEEN (1: capture a shape the first time it appears after the warm-up); PIKA_TRAIN_GRAPH_U_BUCKET (8:
-the label axis is padded to a multiple of it).
+PIKA_TRAIN_GRAPH_MIN_SEEN (2: a shape is captured the second time it appears after the warm-up -- a corpus whose batch
+lengths never recur stays eager instead of capturing every step); PIKA_TRAIN_GRAPH_U_BUCKET (8: a batch rides
+on graphs whose label axis is up to 7 labels wider than its own, padded with the embedding's padding index).
 """
 import collections
 import os
@@ -87,7 +89,7 @@ class StepGraphs(object):
         env = os.environ.get
         self.warmup = int(env("PIKA_TRAIN_GRAPH_WARMUP", "2")) if warmup is None else int(warmup)
         self.max_graphs = max(1, int(env("PIKA_TRAIN_GRAPH_MAX", "4")) if max_graphs is None else int(max_graphs))
-        self.min_seen = max(1, int(env("PIKA_TRAIN_GRAPH_MIN_SEEN", "1")) if min_seen is None else int(min_seen))
+        self.min_seen = max(1, int(env("PIKA_TRAIN_GRAPH_MIN_SEEN", "2")) if min_seen is None else int(min_seen))
         self.u_bucket = max(1, int(env("PIKA_TRAIN_GRAPH_U_BUCKET", "8")))
         self.entries = collections.OrderedDict()        # key -> _Entry, least recently used first
         self.seen = {}
@@ -96,7 +98,10 @@ class StepGraphs(object):
         self.param_ptrs = None
         self.broken = None                              # reason the model's forward cannot be captured
         self.last = None                                # (entry, generation) of the latest graphed forward
+        self.freeze_salt = env("PIKA_TRAIN_GRAPH_FREEZE_SALT", "0") == "1"   # tests / debugging: keep the salt word as it is
         self.stats = {"replays": 0, "captures": 0, "eager": 0, "evictions": 0}
+        import weakref
+        self.model_ref = weakref.ref(model)
         self.salt = _salt_acquire(next(model.parameters()).device)
         self._closed = False
 
@@ -123,6 +128,10 @@ def enable(model, warmup=None, max_graphs=None, min_seen=None):
     if st is None or st._closed:
         st = StepGraphs(model, warmup, max_graphs, min_seen)
         model.__dict__["_step_graphs"] = st
+        if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG"):
+            import atexit
+            atexit.register(lambda: print("train_graph stats: %s, shapes kept %d, broken: %s" % (
+                st.stats, len(st.entries), st.broken), flush=True))
     return st
 
 
@@ -144,6 +153,12 @@ def wanted(model, x, softmax):
         if not AUTO or not (model.training and x.is_cuda and torch.is_grad_enabled()):
             return False
         st = enable(model)
+    if st.broken is None:
+        import pika_amd
+        if not pika_amd.HIP_GRAPHS_SAFE_TO_ALTERNATE:
+            _give_up(st, "the HIP runtime was initialised with its graph packet-capture fast path on, under which alternating "
+                         "graph replays go wrong (pika_amd/__init__.py): import pika_amd before the first HIP call, or "
+                         "export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0")
     return (st.broken is None and not st._closed and model.training and softmax and x.is_cuda and torch.is_grad_enabled()
             and not model.pack_seq and not torch.cuda.is_current_stream_capturing())
 
@@ -277,7 +292,18 @@ class _GraphedFn(torch.autograd.Function):
         # a p.grad that IS the static tensor (the caller did not zero its gradients, or backs through a retained graph
         # twice) holds the earlier values the replay is about to overwrite: accumulate as autograd would
         kept = {id(gr): gr.clone() for p, gr in e.grads if p.grad is gr}
+        dbg_sync = int(os.environ.get("PIKA_TRAIN_GRAPH_SYNC", "0"))
+        if dbg_sync & 4:
+            torch.cuda.synchronize()
         e.gb.replay()
+        if dbg_sync & 8:
+            torch.cuda.synchronize()
+        if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG") == "3":     # diagnostics: where does a non-finite value first appear?
+            names = {id(p): n for n, p in st.model_ref().named_parameters()} if st.model_ref() is not None else {}
+            bad = [(names.get(id(p), "?"), float(gr.abs().max())) for p, gr in e.grads if not bool(torch.isfinite(gr).all())]
+            big = max(float(gr.abs().max()) for _, gr in e.grads)
+            print("train_graph call %d: after backward replay: max |grad| %.3e, non-finite in %d tensors %s" % (
+                st.calls, big, len(bad), bad[:6]), flush=True)
         for p, gr in e.grads:
             if p.grad is None:
                 p.grad = gr
@@ -292,7 +318,8 @@ def forward(model, x, y, x_len, softmax):
     """`Net.forward` when `wanted(...)`: eager during warm-up / for shapes not (yet) captured, otherwise a replay."""
     st = model._step_graphs
     st.calls += 1
-    st.salt.random_()                                    # device-side draw: new dropout masks, no host involvement
+    if not st.freeze_salt:
+        st.salt.random_()                                # device-side draw: new dropout masks, no host involvement
     if st.calls <= st.warmup:
         st.stats["eager"] += 1
         return model._forward_eager(x, y, x_len, softmax)
@@ -301,27 +328,33 @@ def forward(model, x, y, x_len, softmax):
     if st.param_ptrs != ptrs:                            # BMUF re-points parameters into its flat vector; .to(); ...
         st.clear()
         st.param_ptrs = ptrs
-    # the label axis is padded to a multiple of `u_bucket` with the embedding's padding index -- what the loader itself
+    # the label axis may be PADDED with the embedding's padding index -- what the loader itself
     # pads the shorter utterances of a batch with (otf_utt_loader.py:262-270): the prediction network masks those
     # positions as keys and is causal, the loss never reads lattice columns beyond an utterance's label count, so the
     # values of every lattice cell the loss reads are unchanged (tests/test_train_step_gpu.py) while batches whose
     # longest label sequences differ by a few labels share one pair of graphs.  (The TIME axis is not padded: BatchNorm
     # statistics and the encoder's unmasked self-attention run over every frame of the batch, so extra frames would
     # change the values.)
+    # ... A batch is served by an existing pair of graphs whose label axis is its own or up to `u_bucket` - 1 labels wider;
+    # a NEW pair is captured at the batch's own width, so a corpus (or benchmark) of one shape pays for no padding.
     U = y.shape[1]
-    Ub = -(-U // st.u_bucket) * st.u_bucket
     pad = getattr(model.embed, "padding_idx", None)
-    if Ub != U and (pad is None or y.dim() != 2):
-        Ub = U
-    if Ub != U:
-        yp = torch.full((y.shape[0], Ub), int(pad), dtype=y.dtype, device=y.device)
-        yp[:, :U] = y
-        y = yp
-    key = (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype,
-           None if x_len is None else (tuple(x_len.shape), x_len.dtype))
-    e = st.entries.get(key)
+
+    def key_for(width):
+        return (tuple(x.shape), x.dtype, (y.shape[0], width), y.dtype,
+                None if x_len is None else (tuple(x_len.shape), x_len.dtype))
+    e, Ub = None, U
+    if y.dim() == 2:
+        for width in range(U, U + (st.u_bucket if pad is not None else 1)):
+            e = st.entries.get(key_for(width))
+            if e is not None:
+                Ub = width
+                break
+    key = key_for(Ub)
     if e is None:
         n = st.seen[key] = st.seen.get(key, 0) + 1
+        if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG") == "2":
+            print("train_graph call %d: %s seen %d" % (st.calls, key[0:3:2], n), flush=True)
         if n < st.min_seen:
             st.stats["eager"] += 1
             return model._forward_eager(x, y, x_len, softmax)
@@ -340,14 +373,30 @@ def forward(model, x, y, x_len, softmax):
         st.stats["captures"] += 1
     else:
         st.entries.move_to_end(key)
-        for s, t in zip(e.inputs, (x, y, x_len)):
-            if s is not None:
-                s.copy_(t, non_blocking=True)
-        e.labels32.copy_(y, non_blocking=True)
+        e.inputs[0].copy_(x, non_blocking=True)
+        if Ub != U:
+            e.inputs[1].fill_(int(pad))
+            e.inputs[1][:, :U].copy_(y, non_blocking=True)
+        else:
+            e.inputs[1].copy_(y, non_blocking=True)
+        if x_len is not None:
+            e.inputs[2].copy_(x_len, non_blocking=True)
+        e.labels32.copy_(e.inputs[1], non_blocking=True)
+    if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG") == "2":
+        print("train_graph call %d: replay of %s for labels %s" % (st.calls, key[0:3:2], tuple(y.shape)), flush=True)
     e.gen += 1
     st.last = (e, e.gen)
+    dbg_sync = int(os.environ.get("PIKA_TRAIN_GRAPH_SYNC", "0"))      # debugging: 1 before F, 2 after F, 4 before B, 8 after B
+    if dbg_sync & 1:
+        torch.cuda.synchronize()
     e.gf.replay()
+    if dbg_sync & 2:
+        torch.cuda.synchronize()
     st.stats["replays"] += 1
+    if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG") == "3":
+        print("train_graph call %d: after forward replay: logits finite %s, max |logit| %.3e, input max %.3e" % (
+            st.calls, bool(torch.isfinite(e.logits).all()), float(e.logits.abs().max()), float(e.inputs[0].abs().max())),
+            flush=True)
     out = _GraphedFn.apply(st, e, *params)
     if e.kind == "compact":
         out._pika_lazy_grad_ok = True
@@ -366,7 +415,7 @@ class GraphedTrainStep(object):
         self.make_optimizer = make_optimizer
         self.optimizer = make_optimizer()
         disable(model)
-        self.state = enable(model, warmup=warmup, max_graphs=max_graphs, min_seen=min_seen)
+        self.state = enable(model, warmup=warmup, max_graphs=max_graphs, min_seen=1 if min_seen is None else min_seen)
 
     @property
     def graphs(self):

@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import pika_amd  # noqa: E402,F401  (before any HIP call: pika_amd/__init__.py sets the runtime flag the graphed train step needs)
 
 
 def pytest_configure(config):

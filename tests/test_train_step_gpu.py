@@ -284,8 +284,8 @@ def _script_loop(model, batches, lr=0.0005, rebuild_every=0):
 
 def test_script_loop_gets_the_graphs_and_the_eager_loss_sequence(hip_device):
     """The unchanged script's loop, spelled out: with the launcher's switch (train_graph.AUTO) the model's forward and
-    backward are graph replays from the third step on -- the loss sequence and the parameters after 8 steps (optimizer
-    rebuilt with a new lr every 3 steps, ragged label counts padded to the bucket) equal those of the same loop run as an
+    backward are graph replays from the fourth step on -- the loss sequence and the parameters after 8 steps (optimizer
+    rebuilt with a new lr every 3 steps, ragged label counts, label-axis widths 9-11 served by one pair of graphs) equal those of the same loop run as an
     eager launch sequence."""
     import copy
     from pika_amd import gemm as G
@@ -294,7 +294,8 @@ def test_script_loop_gets_the_graphs_and_the_eager_loss_sequence(hip_device):
     ref = copy.deepcopy(model)
     init = [p.detach().clone() for p in model.parameters()]
     g = torch.Generator().manual_seed(21)
-    batches = [_batch(hip_device, g, 4, 300, 11, 512, pad_from=7) for _ in range(8)]
+    # label-axis widths 11 11 11 11 9 11 10 9: the graphs are captured at 11, the narrower batches are served by them
+    batches = [_batch(hip_device, g, 4, 300, U, 512, pad_from=7) for U in (11, 11, 11, 11, 9, 11, 10, 9)]
     old, old_auto = G.PRECISION, train_graph.AUTO
     G.PRECISION = "mixed"
     fused_optim.install()
@@ -306,9 +307,10 @@ def test_script_loop_gets_the_graphs_and_the_eager_loss_sequence(hip_device):
         got = _script_loop(model, batches, rebuild_every=3)
         st = model._step_graphs
         assert st.broken is None, st.broken
-        assert st.stats["eager"] == 2 and st.stats["captures"] == 1 and st.stats["replays"] == 6, st.stats
+        # two warm-up steps, the shape's first appearance after them, then captured on its second
+        assert st.stats["eager"] == 3 and st.stats["captures"] == 1 and st.stats["replays"] == 5, st.stats
         key = next(iter(st.entries))
-        assert key[2] == (4, 16)                               # 11 labels padded to the bucket of 16
+        assert key[2] == (4, 11) and len(st.entries) == 1      # captured at the first recurring width; 9 and 10 ride on it
         assert st.entries[key].kind == "compact"               # raw logits out, the loss' compact gradient in
         train_graph.disable(model)
     finally:

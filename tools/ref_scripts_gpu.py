@@ -115,5 +115,103 @@ def run(outdir):
     shutil.rmtree(work, ignore_errors=True)
 
 
+def train_cost(outdir):
+    """Marginal cost of a training step of the UNCHANGED script: the same command on a corpus of 40 and of 120 batches,
+    process CPU time (user + sys, all threads: training loop + loader) and wall time of the child; (run2 - run1) / 80 steps is
+    what a step costs once the graphs exist.  The corpus is length-bucketed the way the recipes' split_by_length.py makes
+    a rank's batches (utterances of 3.5 s, speed perturbation 0.9 / 1.0 / 1.1: the longest utterance of almost every batch
+    is a 0.9 one), so batch shapes recur; PIKA_TRAIN_GRAPH=0 gives the eager launch sequence on the same corpus."""
+    import json
+    import resource
+    import time
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pathlib import Path
+    from test_loader import make_corpus
+    out = Path(outdir).resolve()
+    out.mkdir(parents=True, exist_ok=True)
+    work = out / "work"
+    work.mkdir(exist_ok=True)
+    V = 5000
+    # (an epoch of the script is one pass over its list, whatever --num_batches_per_epoch says: the run length is the corpus)
+    corpora = {}
+    for nb in [int(v) for v in os.environ.get("COST_BATCHES", "40,120").split(",")]:
+        d = work / ("corpus%d" % nb)
+        d.mkdir(exist_ok=True)
+        corpora[nb] = make_corpus(d, n_utts=8 * nb, seed=41, lo=56000, hi=56001)[:2]
+    conf = corpora[min(corpora)][1]
+    (work / "fbank.conf").write_text(Path(conf).read_text().replace("--dither=0", "--dither=1"))
+    rng = np.random.default_rng(0)
+    n, mean = 1000.0, rng.normal(8, 1, 80)
+    (work / "cmvn.stats").write_text(" [\n  " + " ".join("%.10g" % v for v in np.concatenate((mean * n, [n]))) + "\n  " +
+                                     " ".join("%.10g" % v for v in np.concatenate(((mean ** 2 + 4.0) * n, [0.0]))) + " ]\n")
+    res = {}
+    modes = (("graphs", {"PIKA_TRAIN_GRAPH_DEBUG": "1"}), ("eager", {"PIKA_TRAIN_GRAPH": "0"}))
+    if os.environ.get("COST_VARIANTS"):     # debugging: name=ENV=VALUE,... ; e.g. "a=PIKA_TRAIN_GRAPH_U_BUCKET=1;b=COST_DROPOUT=0"
+        modes = []
+        for item in os.environ["COST_VARIANTS"].split(";"):
+            name, _, kv = item.partition("=")
+            e = {"PIKA_TRAIN_GRAPH_DEBUG": "1"}
+            for pair in filter(None, kv.split(",")):
+                k, _, v = pair.partition("=")
+                e[k] = v
+            modes.append((name, e))
+    for mode, genv in modes:
+        rows = []
+        for nb in sorted(corpora):
+            lst = corpora[nb][0]
+            ck = work / ("ckpt_%s_%d" % (mode, nb))
+            ck.mkdir(exist_ok=True)
+            env = dict(os.environ, WORLD_SIZE="1", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
+                       PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", **genv)
+            train = [sys.executable, "-m", "pika_amd.launch", os.path.join(SCRATCH, FILES[0]),
+                     "--verbose", "--optim", "sgd", "--initial_lr", "0.003", "--final_lr", "0.0001", "--grad_clip", "3.0",
+                     "--num_batches_per_epoch", str(nb), "--num_epochs", "1", "--momentum", "0.9", "--block_momentum", "0.9",
+                     "--sync_period", "5", "--feats_dim", "80", "--cuda", "--batch_size", "8", "--encoder_type", "transformer",
+                     "--enc_layers", "4", "--decoder_type", "transformer", "--dec_layers", "2", "--rnn_type", "LSTM",
+                     "--rnn_size", "1024", "--embd_dim", "100", "--dropout", genv.get("COST_DROPOUT", "0.2"), "--padding_idx", str(V),
+                     "--padding_tgt", str(V), "--stride", "1", "--queue_size", "8", "--loader", "otf_utt", "--batch_first",
+                     "--cmn", "--cmvn_stats", str(work / "cmvn.stats"), "--output_dim", str(V), "--num_workers", "1",
+                     "--sample_rate", "16000", "--feat_config", str(work / "fbank.conf"), "--TU_limit", "15000",
+                     "--gain_range", "50,10", "--speed_rate", "0.9,1.0,1.1", "--spec_augment", "--log_per_n_frames", "200",
+                     "--max_len", "1600", "--lctx", "1", "--rctx", "1", "--model_lctx", "21", "--model_rctx", "21",
+                     "--model_stride", "4", "--local-rank=0", "transducer", lst, str(out / ("train_%s_%d.WORKER-ID.log" % (mode, nb))),
+                     str(ck)]
+            for pair in filter(None, genv.get("COST_ARGS", "").split("|")):      # debugging: --flag:value|--flag:value
+                k, _, v = pair.partition(":")
+                if v == "OFF":
+                    train.remove(k)
+                else:
+                    train[train.index(k) + 1] = v
+            r0, t0 = resource.getrusage(resource.RUSAGE_CHILDREN), time.perf_counter()
+            # (a failing reference script does not exit: its loader threads keep the process alive -- bound every run)
+            r = subprocess.run(train, env=env, cwd=str(work), capture_output=True, text=True, timeout=420)
+            wall = time.perf_counter() - t0
+            r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+            cpu = (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
+            assert r.returncode == 0, r.stderr[-6000:]
+            stats = [l for l in r.stdout.splitlines() if l.startswith("train_graph")]
+            if genv.get("PIKA_TRAIN_GRAPH_DEBUG") in ("2", "3"):
+                print("\n".join(stats[:int(os.environ.get("COST_STAT_LINES", "60"))]))
+            log = Path(str(out / ("train_%s_%d.0.log" % (mode, nb))))
+            rows.append({"batches": nb, "wall_s": wall, "cpu_s": cpu, "train_graph": stats[-1:] if stats else None,
+                         "log_tail": log.read_text().splitlines()[-int(os.environ.get("COST_LOG_LINES", "2")):]
+                         if log.exists() else None})
+            shutil.rmtree(ck, ignore_errors=True)
+        if len(rows) < 2:
+            print(mode, rows)
+            continue
+        d = rows[1]["batches"] - rows[0]["batches"]
+        res[mode] = {"runs": rows, "ms_per_step_wall": (rows[1]["wall_s"] - rows[0]["wall_s"]) / d * 1e3,
+                     "ms_per_step_process_cpu": (rows[1]["cpu_s"] - rows[0]["cpu_s"]) / d * 1e3}
+        print(mode, json.dumps(res[mode], indent=1), flush=True)
+    (out / "train_step_cost.json").write_text(json.dumps(res, indent=1))
+    shutil.rmtree(work, ignore_errors=True)
+
+
 if __name__ == "__main__":
-    {"stage": stage, "clean": clean}.get(sys.argv[1], lambda: run(sys.argv[2]))()
+    if sys.argv[1] == "cost":
+        train_cost(sys.argv[2])
+    else:
+        {"stage": stage, "clean": clean}.get(sys.argv[1], lambda: run(sys.argv[2]))()
