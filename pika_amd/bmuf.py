@@ -77,9 +77,11 @@ class BmufTrainer(object):
             self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._flag_event = torch.cuda.Event()
         self._stop_pending = False
-        # True: update_and_sync() returns STOP for the block whose summed delta holds a NaN (one blocking read per
-        # sync, the reference's timing); False (default): at the NEXT call -- the device has already skipped the update
-        self.sync_stop = os.environ.get("PIKA_BMUF_SYNC_STOP", "0") == "1"
+        # True (default): update_and_sync() returns STOP for the block whose summed delta holds a NaN -- the reference's
+        # timing (bmuf.py:89-90), at the price of one blocking 4-byte read per block (the reference loop reads the loss
+        # every step anyway).  PIKA_BMUF_SYNC_STOP=0: the host learns of it at the NEXT call (the device has already
+        # skipped the update); a loop that uses it must ask `pending_stop()` after its last block and before a checkpoint
+        self.sync_stop = os.environ.get("PIKA_BMUF_SYNC_STOP", "1") == "1"
         self.collective_events = None     # set to [] to have every all-reduce bracketed by HIP events
 
     def _rebind_detached_parameters(self):
@@ -99,6 +101,15 @@ class BmufTrainer(object):
             raise RuntimeError("BmufTrainer: the model's parameter count changed since construction "
                                "(%d -> %d elements)" % (self.local.numel(), off))
         return n_fixed
+
+    def pending_stop(self):
+        """Deferred mode (PIKA_BMUF_SYNC_STOP=0) only: did the LAST block hold a NaN?  Blocks until its flag has arrived;
+        clears the pending state (the update kernel left parameters, delta_prev and the local model untouched)."""
+        if self.is_hip and self._stop_pending:
+            self._flag_event.synchronize()
+            self._stop_pending = False
+            return bool(int(self._flag_host[0]))
+        return False
 
     # -- the block update ----------------------------------------------------------------
     def update_and_sync(self):

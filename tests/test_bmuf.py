@@ -172,6 +172,38 @@ def test_trainer_on_hip_single_rank(hip_device, tmp_path):
     dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sync_stop", ["1", "0"])
+def test_nan_guard_on_hip_leaves_every_vector_untouched(hip_device, sync_stop, monkeypatch):
+    """the device-side NaN guard (pika_bmuf_nan_flag -> pika_bmuf_update skips) had no HIP test.  A NaN in the
+    local model: the global model, delta_prev and the local model stay as they were, and STOP comes back from the SAME
+    call by default (the reference's timing, bmuf.py:89-90) or -- with PIKA_BMUF_SYNC_STOP=0 -- from pending_stop() /
+    the next call."""
+    monkeypatch.setenv("PIKA_BMUF_SYNC_STOP", sync_stop)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(C.free_port()), RANK="0", WORLD_SIZE="1")
+    from pika_amd.bmuf import BmufTrainer
+    model = C.make_model(0).to(hip_device)
+    tr = BmufTrainer(0, 0, 1, model, C.BM, C.BLR)
+    try:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01)
+        assert tr.update_and_sync() == 1
+        G0, dp0 = tr.param.clone(), tr.delta_prev.clone()
+        with torch.no_grad():
+            next(model.parameters()).view(-1)[3] = float("nan")
+        L0 = tr.local.clone()
+        rc = tr.update_and_sync()
+        if sync_stop == "1":
+            assert rc == 0
+        else:
+            assert rc == 1 and tr.pending_stop() is True and tr.pending_stop() is False
+        assert torch.equal(tr.param, G0) and torch.equal(tr.delta_prev, dp0)
+        assert torch.equal(torch.nan_to_num(tr.local, nan=7.0), torch.nan_to_num(L0, nan=7.0))
+    finally:
+        dist.destroy_process_group()
+
+
 def _rebind_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))

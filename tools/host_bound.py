@@ -31,9 +31,21 @@ try:
     t2 = time.perf_counter()
     # wall time until the last step is enqueued includes waiting for the loader's back-pressure (its pinned ring is
     # recycled at the device's pace); the CPU time of this thread is what the step costs the host
-    print("launch mode: %s" % ("eager" if os.environ.get("PIKA_TRAIN_GRAPH", "1") == "0" else "one hipGraph per step"))
+    print("launch mode: %s" % ("eager" if os.environ.get("PIKA_TRAIN_GRAPH", "1") == "0" else "forward + backward graph replays behind Net.forward (pika_amd.train_graph)"))
     print("host enqueue (wall) %.2f ms/step, host CPU time of the training thread %.2f ms/step, device done %.2f ms/step"
           % ((t1 - t0) / K * 1e3, (c1 - c0) / K * 1e3, (t2 - t0) / K * 1e3), flush=True)
+    # the same with an EMPTY queue in front of every step (the loop above runs ahead of the device until the hardware queue
+    # is full, and the runtime spins on a full queue: that wait is CPU time but not work)
+    cpu = wall = 0.0
+    for _ in range(K):
+        torch.cuda.synchronize()
+        t0, c0 = time.perf_counter(), time.thread_time()
+        step()
+        cpu += time.thread_time() - c0
+        wall += time.perf_counter() - t0
+    torch.cuda.synchronize()
+    print("one step at a time, queue empty: host enqueue (wall) %.2f ms/step, host CPU of the training thread %.2f ms/step"
+          % (wall / K * 1e3, cpu / K * 1e3), flush=True)
     if "--profile" in sys.argv:
         pr = cProfile.Profile()
         pr.enable()

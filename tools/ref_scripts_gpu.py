@@ -116,8 +116,8 @@ def run(outdir):
 
 
 def train_cost(outdir):
-    """Marginal cost of a training step of the UNCHANGED script: the same command on a corpus of 40 and of 120 batches,
-    process CPU time (user + sys, all threads: training loop + loader) and wall time of the child; (run2 - run1) / 80 steps is
+    """Marginal cost of a training step of the UNCHANGED script: the same command on a corpus of 40 and of 200 batches,
+    process CPU time (user + sys, all threads: training loop + loader) and wall time of the child; (run2 - run1) / 160 steps is
     what a step costs once the graphs exist.  The corpus is length-bucketed the way the recipes' split_by_length.py makes
     a rank's batches (utterances of 3.5 s, speed perturbation 0.9 / 1.0 / 1.1: the longest utterance of almost every batch
     is a 0.9 one), so batch shapes recur; PIKA_TRAIN_GRAPH=0 gives the eager launch sequence on the same corpus."""
@@ -136,7 +136,7 @@ def train_cost(outdir):
     V = 5000
     # (an epoch of the script is one pass over its list, whatever --num_batches_per_epoch says: the run length is the corpus)
     corpora = {}
-    for nb in [int(v) for v in os.environ.get("COST_BATCHES", "40,120").split(",")]:
+    for nb in [int(v) for v in os.environ.get("COST_BATCHES", "40,200").split(",")]:
         d = work / ("corpus%d" % nb)
         d.mkdir(exist_ok=True)
         corpora[nb] = make_corpus(d, n_utts=8 * nb, seed=41, lo=56000, hi=56001)[:2]
@@ -157,6 +157,8 @@ def train_cost(outdir):
                 k, _, v = pair.partition("=")
                 e[k] = v
             modes.append((name, e))
+    if not os.environ.get("COST_VARIANTS"):
+        modes = (("coldstart", {"PIKA_TRAIN_GRAPH": "0"}),) + tuple(modes)      # the first process pages the image in
     for mode, genv in modes:
         rows = []
         for nb in sorted(corpora):
