@@ -92,6 +92,17 @@ int pika_gemm_bf16_nt_lse(const void *A, long long lda, const void *B, long long
                           int M, int N, int K, const float *bias, float *pmax, float *psum, int n_part,
                           void *stream);
 
+/* The joint's logits over the RNN-T lattice in 16 bits (reference trainer/model/transducer.py:107-111, fc2 over (B,T,U1)):
+ * out16 (M = B*T*U1 rows, pitch ldo halves) receives A B^T + bias as IEEE fp16 (saturated at +-65504) -- half the bytes
+ * of the largest tensor of a training step, written once and read once (pika_rnnt_dlogits_compact_bf16_f16in) -- while
+ * everything the LOSS needs leaves in fp32 from the accumulators: the partial log-sum-exp statistics of
+ * pika_gemm_bf16_nt_lse, and gathered[2 m] = C[m][blank], gathered[2 m + 1] = C[m][labels[b (U1-1) + u]] for row
+ * m = (b T + t) U1 + u (u < U1 - 1; unwritten otherwise).  gathered may be NULL (then labels / T / U1 / blank are
+ * ignored). */
+int pika_gemm_bf16_nt_lse_f16(const void *A, long long lda, const void *B, long long ldb, void *out16, long long ldo,
+                              int M, int N, int K, const float *bias, float *pmax, float *psum, int n_part,
+                              const int *labels, int T, int U1, int blank, float *gathered, void *stream);
+
 /* The same product with a fused bf16 epilogue, for chains whose wide intermediate only ever feeds
  * another MFMA product (the transformer feed-forward block, reference trainer/model/position_ffn.py:27-39:
  * w_2(dropout(relu(w_1(x)))) -- the (rows, d_ff) hidden exists only in bf16, ReLU/dropout never run as passes):

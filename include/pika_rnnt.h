@@ -110,6 +110,22 @@ int pika_rnnt_fused_forward_partials(const float *logits, const float *pmax, con
                                      int T, int U1, int V, int blank, float *costs, float *lse, void *workspace,
                                      void *stream);
 
+/* pika_rnnt_fused_forward_partials for the 16-bit logits of pika_gemm_bf16_nt_lse_f16 (pika_gemm.h): logits16 is the
+ * fp16 matrix (row pitch ld16 halves), gathered / g_labels / g_blank what that product's epilogue left in fp32 -- per
+ * lattice row the logits of column g_blank and of the row's label g_labels[b][u].  A lattice cell whose label (blank) is
+ * the gathered one takes the fp32 value, so costs and log-sum-exp are those of the fp32 logits; any other label reads the
+ * fp16 logit.  g_labels may be NULL (nothing gathered for labels). */
+int pika_rnnt_fused_forward_gathered(const void *logits16, long long ld16, const float *gathered, const int *g_labels,
+                                     int g_blank, const float *pmax, const float *psum, int n_part, const int *labels,
+                                     const int *frames_lengths, const int *labels_lengths, int B, int T, int U1, int V,
+                                     int blank, float *costs, float *lse, void *workspace, void *stream);
+
+/* pika_rnnt_dlogits_compact_bf16 reading the RAW logits as fp16 (row pitch ld_in halves; lse = their row log-sum-exp from
+ * the forward call above, required): d(logits) = scale * (g - softmax * sum(g)) as one bf16 matrix + column sums. */
+int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, const float *lse, const void *workspace,
+                                         int B, int T, int U1, int V, int blank, void *out, long long ld_out, float scale,
+                                         float *colsum, void *stream);
+
 /* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces
  * F.log_softmax (trainer/model/transducer.py:111) + the loss + the log-softmax backward for a caller that owns
  * the joint output.  `logits` (B,T,U1,V) f32 are the RAW fc2 outputs, V % 4 == 0, V <= 5120; lse (B*T*U1) f32

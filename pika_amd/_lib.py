@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -23,6 +23,9 @@ SIGNATURES = {
     "pika_rnnt_fused_forward_partials": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_rnnt_fused_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _ll, _vp]),
     "pika_rnnt_dlogits_compact_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
+    "pika_rnnt_fused_forward_gathered": (_i, [_vp, _ll, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp,
+                                               _vp, _vp]),
+    "pika_rnnt_dlogits_compact_bf16_f16in": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
     "pika_rnnt_export_lattice": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     # include/pika_bmuf.h
     "pika_bmuf_delta": (_i, [_vp, _vp, _vp, _sz, _vp]),
@@ -37,6 +40,7 @@ SIGNATURES = {
     "pika_gemm_nt_ws": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _i, _i, _i, _i, _i, _vp, _i, _vp, ctypes.c_size_t, _vp]),
     "pika_gemm_bf16_nt": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp]),
     "pika_gemm_bf16_nt_lse": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "pika_gemm_bf16_nt_lse_f16": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "pika_gemm_bf16_epilogue": (_i, [_vp, _ll, _vp, _ll, _vp, _ll, _i, _i, _i, _vp, _i, _i, ctypes.c_float,
                                      ctypes.c_uint, _vp, _ll, ctypes.c_float, _vp]),
     "pika_dropout_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),

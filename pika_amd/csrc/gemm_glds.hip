@@ -175,6 +175,13 @@ struct PPArgs {
     // log-sum-exp statistics of the row: lse_pm[m * lse_np + b] = max over the block, lse_ps[...] = sum exp(x - max)
     float *lse_pm, *lse_ps;
     int lse_np;
+    // EPI 4 (the joint's logits over the RNN-T lattice, 16-bit): out16 receives the tile as IEEE fp16 (pitch ldo16), the
+    // lse statistics above come from the fp32 accumulators as in EPI 0, and the TWO columns of a lattice row the loss reads
+    // -- blank and the row's label -- also leave as fp32: g_out[2 m] = C[m][g_blank], g_out[2 m + 1] = C[m][label(m)] with
+    // label(m) = g_labels[b (g_U1 - 1) + u] for row m = (b g_T + t) g_U1 + u, u < g_U1 - 1 (no label in the last column)
+    const int *g_labels;
+    float *g_out;
+    int g_T, g_U1, g_blank;
     int nx, ntiles;                    // output tiles per row of tiles / in total (filled in by launch_pp_epi)
     int f16;                           // the 16-bit operands are fp16 (EPI 0 only: PIKA_GEMM_F16_OPERANDS)
 #ifdef PIKA_PP_TRACE
@@ -200,6 +207,7 @@ __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast
 // EPI 0: C f32 = act(A B^T + bias).   EPI 1: out16 bf16 = dropout(act(A B^T + bias)).
 // EPI 2: out16 bf16 = scale * (A B^T) where aux > 0, else 0  (ReLU + dropout backward in one mask).
 // EPI 3: C f32 = dropout(A B^T + bias) + res  (projection + residual dropout + residual add).
+// EPI 4: out16 FP16 = A B^T + bias, with the lse statistics of EPI 0 and two gathered fp32 columns per row (see PPArgs).
 // BOUNDS: A is a padded time-delay view (rows whose source time leaves the signal read the zero page)
 template <int EPI, bool BOUNDS, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
@@ -504,9 +512,16 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         const int m = em0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= M) continue;
         [[maybe_unused]] f32x4 lv[4];
-        if constexpr (EPI == 0) {
+        if constexpr (EPI == 0 || EPI == 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) lv[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        [[maybe_unused]] int g_lab = -1;
+        if constexpr (EPI == 4) {
+            if (P.g_out) {
+                const int u = m % P.g_U1;
+                if (u < P.g_U1 - 1) g_lab = P.g_labels[(long long)(m / (P.g_U1 * P.g_T)) * (P.g_U1 - 1) + u];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -532,11 +547,24 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 else if (n + 3 < N) v += *reinterpret_cast<const f32x4 *>(rp);
                 else for (int e = 0; e < 4; ++e) if (n + e < N) v[e] += rp[e];
             }
-            if constexpr (EPI == 0) {
+            if constexpr (EPI == 0 || EPI == 4) {
                 if (n + 3 < N) lv[j] = v;
                 else for (int e = 0; e < 4; ++e) if (n + e < N) lv[j][e] = v[e];
             }
-            if constexpr (EPI == 0 || EPI == 3) {
+            if constexpr (EPI == 4) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                if (P.g_out) {      // the lane that holds a gathered column hands its fp32 value over
+                    if ((unsigned)(P.g_blank - n) < 4u && P.g_blank < N) P.g_out[2LL * m] = v[P.g_blank - n];
+                    if ((unsigned)(g_lab - n) < 4u && g_lab < N) P.g_out[2LL * m + 1] = v[g_lab - n];
+                }
+                f32x4 c = v;        // fp16 saturates at +-65504: never an infinity in the stored logits
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = fminf(fmaxf(c[e], -65504.f), 65504.f);
+                const f16x4 h4 = __builtin_convertvector(c, f16x4);
+                _Float16 *op = reinterpret_cast<_Float16 *>(P.out16) + (long long)m * P.ldo16 + n;
+                if (n + 3 < N) *reinterpret_cast<f16x4 *>(op) = h4;
+                else for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = h4[e];
+            } else if constexpr (EPI == 0 || EPI == 3) {
                 if (n + 3 < N) {
                     *reinterpret_cast<f32x4 *>(C + (long long)m * P.ldc + n) = v;
                 } else {
@@ -577,7 +605,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 }
             }
         }
-        if constexpr (EPI == 0) {
+        if constexpr (EPI == 0 || EPI == 4) {
             if (P.lse_pm) {
                 // the 64 columns this wave holds of row m sit in the 4 lanes {l, l+16, l+32, l+48}, 16 values each
                 float mx = -INFINITY;
@@ -1185,6 +1213,27 @@ extern "C" int pika_gemm_bf16_nt_lse(const void *A, long long lda, const void *B
     P.M = M; P.N = N; P.K = K; P.relu = 0;
     P.lse_pm = pmax; P.lse_ps = psum; P.lse_np = n_part;
     return launch_pp(P, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pika_gemm_bf16_nt_lse_f16(const void *A, long long lda, const void *B, long long ldb, void *out16,
+                                         long long ldo, int M, int N, int K, const float *bias, float *pmax, float *psum,
+                                         int n_part, const int *labels, int T, int U1, int blank, float *gathered,
+                                         void *stream) {
+    if (!A || !B || !out16 || !pmax || !psum || M <= 0 || N <= 256 || K <= 0 || n_part != ((N + 255) / 256) * 4) return PIKA_EINVAL;
+    if ((K % BK) || (lda & 7) || (ldb & 7) || (ldo & 3) || ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) ||
+        (reinterpret_cast<uintptr_t>(out16) & 7))
+        return PIKA_EINVAL;
+    if (gathered && (T <= 0 || U1 <= 0 || blank < 0 || blank >= N || (long long)T * U1 > 0x7fffffffLL || M % (T * U1) ||
+                     (U1 > 1 && !labels)))
+        return PIKA_EINVAL;
+    PPArgs P{};
+    P.A = static_cast<const __bf16 *>(A); P.B = static_cast<const __bf16 *>(B); P.bias = bias;
+    P.ldb = ldb; P.a_rpb = M; P.a_batch = 0; P.a_row = lda; P.a_tap = 0; P.a_C = K;
+    P.M = M; P.N = N; P.K = K; P.relu = 0;
+    P.out16 = static_cast<__bf16 *>(out16); P.ldo16 = ldo;
+    P.lse_pm = pmax; P.lse_ps = psum; P.lse_np = n_part;
+    P.g_labels = labels; P.g_out = gathered; P.g_T = T; P.g_U1 = U1; P.g_blank = blank;
+    return launch_pp_epi<4>(P, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pika_gemm_bf16_epilogue(const void *A, long long lda, const void *B, long long ldb, void *out,

@@ -497,14 +497,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // COLSUM: every wave walks RPW consecutive rows and keeps the column sums of what it writes in registers
 // (d(bias) of the layer that produced the logits); the four waves of a workgroup combine through LDS and issue one
 // atomicAdd per column.
-template <bool COLSUM>
-__global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *__restrict__ lp,
+// The logits arrive as fp32 (TI = float) or as the fp16 matrix of pika_gemm_bf16_nt_lse_f16 (TI = _Float16, row pitch
+// ld_in): half the bytes of the pass's input.
+typedef _Float16 ch16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
+__device__ inline f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ inline f32x4 ld4(const _Float16 *p) { return __builtin_convertvector(*reinterpret_cast<const ch16x4 *>(p), f32x4); }
+
+template <bool COLSUM, typename TI = float>
+__global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const TI *__restrict__ lp,
                                                                    const RowMeta *__restrict__ meta,
                                                                    __bf16 *__restrict__ out, long long rows,
                                                                    int V, long long ld_out, int blank,
                                                                    float scale, int rpw,
                                                                    float *__restrict__ colsum,
-                                                                   const float *__restrict__ lse) {
+                                                                   const float *__restrict__ lse,
+                                                                   long long ld_in = 0) {
+    if (ld_in == 0) ld_in = V;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = V >> 2, o4 = (int)(ld_out >> 2);
     const long long r0 = ((long long)blockIdx.x * 4 + wave) * rpw;
     f32x4 cs[COLSUM ? CQ : 1];
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
         const RowMeta m = meta[r];
         const float s = m.gb + m.ge;
         const float l = lse ? lse[r] : 0.f;   // `lp` holds raw logits: log-prob = logit - log-sum-exp of its row
-        const f32x4 *lrow = reinterpret_cast<const f32x4 *>(lp + r * V);
+        const TI *lrow = lp + r * ld_in;
         cbf16x4 *orow = reinterpret_cast<cbf16x4 *>(out + r * ld_out);
         // rows outside an utterance's sub-lattice carry no gradient and, when `lp` holds raw logits, no defined
         // log-sum-exp: their exp() must not reach the output (inf * 0).  The row is fetched regardless -- making
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
         f32x4 v[CQ];
 #pragma unroll
         for (int q = 0; q < CQ; ++q)
-            if (lane + q * 64 < c4) v[q] = lrow[lane + q * 64];
+            if (lane + q * 64 < c4) v[q] = ld4(lrow + 4 * (lane + q * 64));
 #pragma unroll
         for (int q = 0; q < CQ; ++q) {
             const int i = lane + q * 64;
@@ -572,14 +581,16 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const float *
 // wave-uniform tests instead of two compares per element -- a third of the instructions of the kernel above, 120
 // registers instead of 289 (one wave per SIMD before), so the loads of several rows are in flight per CU.
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
-template <int NIT>
-__global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const float *__restrict__ lp,
+template <int NIT, typename TI = float>
+__global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const TI *__restrict__ lp,
                                                                     const RowMeta *__restrict__ meta,
                                                                     __bf16 *__restrict__ out, long long rows,
                                                                     int V, long long ld_out, int blank,
                                                                     float scale, int rpw,
                                                                     float *__restrict__ colsum,
-                                                                    const float *__restrict__ lse) {
+                                                                    const float *__restrict__ lse,
+                                                                    long long ld_in = 0) {
+    if (ld_in == 0) ld_in = V;
     constexpr float LOG2E = 1.4426950408889634f;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const float 
         const bool live = (m.gb != 0.f) || (m.ge != 0.f);       // wave-uniform; dead rows are zeros (see above)
         const float nl2 = lse ? -lse[r] * LOG2E : 0.f;
         const float k = -scale * ssum;
-        const float *lrow = lp + r * V;
+        const TI *lrow = lp + r * ld_in;
         __bf16 *orow = out + r * ld_out;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -606,9 +617,16 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const float 
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.f;
             if (live) {
-                const float *src = lrow + (c < V ? c : 0);       // always a valid address; the store is guarded
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(src);
-                const f32x4 b2 = *reinterpret_cast<const f32x4 *>(src + 4);
+                const TI *src = lrow + (c < V ? c : 0);          // always a valid address; the store is guarded
+                f32x4 a, b2;
+                if constexpr (sizeof(TI) == 2) {                 // one 16-byte load carries the eight columns
+                    const ch16x8 h = *reinterpret_cast<const ch16x8 *>(src);
+                    a = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                    b2 = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+                } else {
+                    a = ld4(src);
+                    b2 = ld4(src + 4);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     o[e] = k * __builtin_amdgcn_exp2f(__builtin_fmaf(a[e], LOG2E, nl2));
@@ -633,13 +651,13 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const float 
         // again (same thread, same address: program order), their share of the column sums goes in separately
         if (live) {
             if (lane == gb_lane && m.gb != 0.f) {
-                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf(lrow[blank], LOG2E, nl2));
+                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf((float)lrow[blank], LOG2E, nl2));
                 orow[blank] = (__bf16)(v + scale * m.gb);
                 cs_blank += scale * m.gb;
             }
             const int ye = m.ye;
             if (ye >= 0 && m.ge != 0.f && lane == ((ye >> 3) & 63)) {
-                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf(lrow[ye], LOG2E, nl2));
+                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf((float)lrow[ye], LOG2E, nl2));
                 float add = scale * m.ge;
                 if (ye == blank && m.gb != 0.f) add += scale * m.gb;         // never in practice (labels > blank)
                 orow[ye] = (__bf16)(v + add);
@@ -749,10 +767,16 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather_kernel(
 // The same outputs from the per-row partial (max, sum exp) pairs the joint's output GEMM emitted in its epilogue
 // (pika_gemm_bf16_nt_lse): 16 lanes per row merge n_part pairs, then the row's two needed logits are fetched (two
 // 64-byte sectors per lattice cell instead of the whole 20 KB row).
+// GATHERED: the logits are the fp16 matrix `logits16` (pitch ld16) of pika_gemm_bf16_nt_lse_f16, whose epilogue left
+// the blank column g_blank and the column of g_labels[b][u] of every row in fp32 (gathered[2 r], gathered[2 r + 1]): a
+// cell whose label / blank IS that one takes the fp32 value, any other one the fp16 logit.
+template <bool GATHERED = false>
 __global__ __launch_bounds__(256) void rnnt_lse_merge_gather_kernel(
     const float *__restrict__ logits, const float *__restrict__ pmax, const float *__restrict__ psum, int n_part,
     const int *__restrict__ labels, const int *__restrict__ Tn_, const int *__restrict__ Un_, long long rows, int T,
-    int U1, int V, int blank, float *__restrict__ lse, float *__restrict__ lpb, float *__restrict__ lpe, int Wp, int D) {
+    int U1, int V, int blank, float *__restrict__ lse, float *__restrict__ lpb, float *__restrict__ lpe, int Wp, int D,
+    const _Float16 *__restrict__ logits16 = nullptr, long long ld16 = 0, const float *__restrict__ gathered = nullptr,
+    const int *__restrict__ g_labels = nullptr, int g_blank = 0) {
     const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     const bool in = r < rows;
@@ -780,14 +804,27 @@ __global__ __launch_bounds__(256) void rnnt_lse_merge_gather_kernel(
     if (!live) { lse[r] = 0.f; return; }
     const float l = m + __logf(s);
     lse[r] = l;
-    const float *row = logits + r * V;
-    float ve = NEG;
-    if (u < Un) {
-        const int y = labels[(size_t)b * (U1 - 1) + u];
-        if (y >= 0 && y < V) ve = fmaxf(row[y] - l, NEG);
+    float ve = NEG, vb;
+    if constexpr (GATHERED) {
+        const _Float16 *row = logits16 + r * ld16;
+        if (u < Un) {
+            const int y = labels[(size_t)b * (U1 - 1) + u];
+            if (y >= 0 && y < V) {
+                const float x = (g_labels && g_labels[(size_t)b * (U1 - 1) + u] == y) ? gathered[2 * r + 1] : (float)row[y];
+                ve = fmaxf(x - l, NEG);
+            }
+        }
+        vb = (blank == g_blank ? gathered[2 * r] : (float)row[blank]) - l;
+    } else {
+        const float *row = logits + r * V;
+        if (u < Un) {
+            const int y = labels[(size_t)b * (U1 - 1) + u];
+            if (y >= 0 && y < V) ve = fmaxf(row[y] - l, NEG);
+        }
+        vb = row[blank] - l;
     }
     const size_t o = ((size_t)b * D + (t + u)) * Wp + u;
-    lpb[o] = fmaxf(row[blank] - l, NEG);
+    lpb[o] = fmaxf(vb, NEG);
     lpe[o] = ve;
 }
 
@@ -833,7 +870,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__
 
 extern "C" {
 
-int pika_amd_abi_version(void) { return 14; }
+int pika_amd_abi_version(void) { return 15; }
 
 size_t pika_rnnt_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024) return 0;
@@ -955,18 +992,18 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
         static const bool wide_off = getenv("PIKA_DLOGITS_NARROW") != nullptr;     // A/B: the 4-column kernel
         if (!wide_off && !(V & 7) && !(ld_out & 7) && V > 512 * 9 && ld_out <= 512 * 10 &&
             !(reinterpret_cast<uintptr_t>(out) & 15)) {
-            hipLaunchKernelGGL(rnnt_dlogits_compact8_kernel<10>, dim3((unsigned)((rows + per_block - 1) / per_block)),
+            hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<10, float>), dim3((unsigned)((rows + per_block - 1) / per_block)),
                                dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
-                               scale, rpw, colsum, lse);
+                               scale, rpw, colsum, lse, 0LL);
             return (int)hipGetLastError();
         }
-        hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<true>, dim3((unsigned)((rows + per_block - 1) / per_block)),
+        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, float>), dim3((unsigned)((rows + per_block - 1) / per_block)),
                            dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
-                           scale, rpw, colsum, lse);
+                           scale, rpw, colsum, lse, 0LL);
     } else {
-        hipLaunchKernelGGL(rnnt_dlogits_compact_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                            log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
-                           static_cast<float *>(nullptr), lse);
+                           static_cast<float *>(nullptr), lse, 0LL);
     }
     return (int)hipGetLastError();
 }
@@ -999,10 +1036,68 @@ int pika_rnnt_fused_forward_partials(const float *logits, const float *pmax, con
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Lattice L = carve(workspace, B, T, U1);
-    hipLaunchKernelGGL(rnnt_lse_merge_gather_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, logits, pmax,
-                       psum, n_part, labels, frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe,
-                       L.Wp, L.D);
+    hipLaunchKernelGGL(rnnt_lse_merge_gather_kernel<false>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, logits,
+                       pmax, psum, n_part, labels, frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe,
+                       L.Wp, L.D, static_cast<const _Float16 *>(nullptr), 0LL, static_cast<const float *>(nullptr),
+                       static_cast<const int *>(nullptr), 0);
     return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
+}
+
+int pika_rnnt_fused_forward_gathered(const void *logits16, long long ld16, const float *gathered, const int *g_labels,
+                                     int g_blank, const float *pmax, const float *psum, int n_part, const int *labels,
+                                     const int *frames_lengths, const int *labels_lengths, int B, int T, int U1, int V,
+                                     int blank, float *costs, float *lse, void *workspace, void *stream) {
+    if (int rc = check_dims(B, T, U1, V, blank)) return rc;
+    if (!logits16 || ld16 < V || !gathered || !pmax || !psum || n_part <= 0 || !frames_lengths || !labels_lengths || !costs ||
+        !lse || !workspace)
+        return PIKA_EINVAL;
+    if (U1 > 1 && !labels) return PIKA_EINVAL;
+    const long long rows = (long long)B * T * U1;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Lattice L = carve(workspace, B, T, U1);
+    hipLaunchKernelGGL(rnnt_lse_merge_gather_kernel<true>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s,
+                       static_cast<const float *>(nullptr), pmax, psum, n_part, labels, frames_lengths, labels_lengths, rows,
+                       T, U1, V, blank, lse, L.lpb, L.lpe, L.Wp, L.D, static_cast<const _Float16 *>(logits16), ld16, gathered,
+                       g_labels, g_blank);
+    return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
+}
+
+int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, const float *lse, const void *workspace,
+                                         int B, int T, int U1, int V, int blank, void *out, long long ld_out, float scale,
+                                         float *colsum, void *stream) {
+    if (!logits16 || !lse || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
+        blank >= V)
+        return PIKA_EINVAL;
+    if ((V & 3) || V > 64 * 4 * CQ || ld_out < V || (ld_out & 3) || ld_out > 64 * 4 * CQ || ld_in < V || (ld_in & 3) ||
+        (reinterpret_cast<uintptr_t>(logits16) & 7) || (reinterpret_cast<uintptr_t>(out) & 7))
+        return PIKA_EINVAL;
+    const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
+    const long long rows = (long long)B * T * U1;
+    if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const _Float16 *x = static_cast<const _Float16 *>(logits16);
+    if (colsum) {
+        hipError_t e = hipMemsetAsync(colsum, 0, (size_t)V * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        const int rpw = rows >= (1 << 18) ? 64 : 4;
+        const long long per_block = 4LL * rpw;
+        if (!(V & 7) && !(ld_out & 7) && !(ld_in & 7) && V > 512 * 9 && ld_out <= 512 * 10 &&
+            !(reinterpret_cast<uintptr_t>(out) & 15) && !(reinterpret_cast<uintptr_t>(logits16) & 15)) {
+            hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<10, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)),
+                               dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw,
+                               colsum, lse, ld_in);
+            return (int)hipGetLastError();
+        }
+        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)),
+                           dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw, colsum,
+                           lse, ld_in);
+    } else {
+        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, _Float16>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
+                           x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
+                           static_cast<float *>(nullptr), lse, ld_in);
+    }
+    return (int)hipGetLastError();
 }
 
 int pika_rnnt_fused_backward(const float *logits, const float *lse, const int *labels,

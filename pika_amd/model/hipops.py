@@ -493,13 +493,50 @@ class JointOutFn(torch.autograd.Function):
     compact_hits = 0   # times the backward used the loss' compact gradient (tests / diagnostics)
 
     @staticmethod
-    def forward(ctx, h, weight, bias, scale, lazy=False):
+    def forward(ctx, h, weight, bias, scale, lazy=False, labels=None):
         N, K = weight.shape
         h2 = h.reshape(-1, K)
-        out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
         ctx.scale = float(scale)
         ctx.has_bias = bias is not None
         ctx.state = None
+        if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and N > 256 and N % 8 == 0
+                and labels.dim() == 2 and labels.shape == (h.shape[0], h.shape[2] - 1)
+                and os.environ.get("PIKA_JOINT_LSE_EPILOGUE", "1") != "0" and os.environ.get("PIKA_JOINT_F16_LOGITS", "1") != "0"):
+            # 16-bit logits: the (B,T,U1,V) lattice -- the largest tensor of a training step -- is written ONCE as fp16
+            # and read once (by the d(logits) pass of the backward); everything the LOSS reads leaves the product's
+            # epilogue in fp32: the row log-sum-exp partials and the logits of the blank and of the row's label, so costs
+            # are those of fp32 logits.  Any other reader gets log-probabilities from a re-run of the product in fp32
+            # (LogitsState.recompute): values never come from the fp16 copy except in the backward's softmax, whose result
+            # is rounded to bf16 anyway (include/pika_gemm.h: pika_gemm_bf16_nt_lse_f16)
+            from ..rnnt import LazyLogProbs, LogitsState
+            B_, T_, U1_ = h.shape[0], h.shape[1], h.shape[2]
+            M = h2.shape[0]
+            out16 = torch.empty(h.shape[:-1] + (N,), dtype=torch.float16, device=h.device)
+            n_part = (N + 255) // 256 * 4
+            part = torch.empty((2, M, n_part), dtype=torch.float32, device=h.device)
+            gath = torch.empty((M, 2), dtype=torch.float32, device=h.device)
+            lab32 = labels.detach().to(torch.int32).contiguous()
+            wb = weight.detach().to(torch.bfloat16)
+            with torch.cuda.device(h.device):
+                _lib.check(_lib.lib().pika_gemm_bf16_nt_lse_f16(
+                    h2.data_ptr(), h2.stride(0), wb.data_ptr(), wb.stride(0), out16.data_ptr(), N, M, N, K,
+                    None if bias is None else bias.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), n_part,
+                    lab32.data_ptr(), T_, U1_, 0, gath.data_ptr(), _stream()), "pika_gemm_bf16_nt_lse_f16")
+            st = ctx.state = LogitsState(scale)
+            st.partials, st.gathered = part, (gath, lab32, 0)
+            h2d, wd, bd = h2.detach(), weight.detach(), None if bias is None else bias.detach()
+
+            def recompute():
+                full = torch.empty((B_, T_, U1_, N), dtype=torch.float32, device=h2d.device)
+                G.gemm_bf16_nt(h2d, wd.to(torch.bfloat16), bias=bd, out=full.view(-1, N))
+                with torch.cuda.device(h2d.device):
+                    _lib.check(_lib.lib().pika_log_softmax_rows(full.data_ptr(), M, N, N, 1.0, _stream()),
+                               "pika_log_softmax_rows")
+                return full
+            st.recompute = recompute
+            ctx.save_for_backward(h2, weight, out16)
+            return LazyLogProbs(st, out16)
+        out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
         if lazy and out.dim() == 4:
             # the log-softmax pass is deferred until something needs the values (pika_amd.rnnt.LazyLogProbs);
             # `out` is normalised in place by a raw kernel call, which autograd's version counter does not see.
@@ -547,7 +584,14 @@ class JointOutFn(torch.autograd.Function):
                     lse = g.lse     # the loss read the raw logits `lp` still holds: log-prob = logit - lse
             else:
                 g = g.dense()
-        if lse is None and ctx.state is not None:
+        lp16 = None
+        if lp.dtype == torch.float16:      # 16-bit logits: only the compact gradient on the raw logits reads them ...
+            if compact is not None and lse is not None:
+                lp16 = lp
+            else:                          # ... anything else works on fp32 log-probabilities (the product runs again)
+                lp = ctx.state.to_log_probs(lp)
+                lse = None
+        elif lse is None and ctx.state is not None:
             ctx.state.to_log_probs(lp)     # every other path below needs the log-probabilities in `lp`
         if compact is None:
             if not g.is_contiguous():
@@ -565,10 +609,16 @@ class JointOutFn(torch.autograd.Function):
                 B_, T_, U1_, V_, blank = compact.dims
                 want_db = ctx.has_bias and ctx.needs_input_grad[2]
                 db_fused = torch.empty(N, dtype=torch.float32, device=dl.device) if want_db else None
-                _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16(
-                    lp.data_ptr(), None if lse is None else lse.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_,
-                    blank, dl.data_ptr(), Np, ctx.scale,
-                    None if db_fused is None else db_fused.data_ptr(), _stream()), "pika_rnnt_dlogits_compact_bf16")
+                if lp16 is not None:
+                    _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16_f16in(
+                        lp16.data_ptr(), lp16.stride(-2), lse.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_,
+                        blank, dl.data_ptr(), Np, ctx.scale,
+                        None if db_fused is None else db_fused.data_ptr(), _stream()), "pika_rnnt_dlogits_compact_bf16_f16in")
+                else:
+                    _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16(
+                        lp.data_ptr(), None if lse is None else lse.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_,
+                        blank, dl.data_ptr(), Np, ctx.scale,
+                        None if db_fused is None else db_fused.data_ptr(), _stream()), "pika_rnnt_dlogits_compact_bf16")
                 JointOutFn.compact_hits += 1
             else:
                 _lib.check(_lib.lib().pika_log_softmax_bwd_rows_bf16(
@@ -589,7 +639,7 @@ class JointOutFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=dl.device)
                 _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
                            "pika_colsum_bf16")
-        return dh, dw, db, None, None
+        return dh, dw, db, None, None, None
 
 
 def attention_ok(q, k, v, heads, mask):

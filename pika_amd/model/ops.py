@@ -254,7 +254,7 @@ def self_attention_packed(x, wq, bq, wk, bk, wv, bv, heads, p_drop, training, ma
     return _pair(PackedAttentionFn.apply(qkv, heads, drop, seed, qkv_lo, mask))
 
 
-def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
+def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0, labels=None):
     """Gated joint network over the full (T,U) lattice.
 
     enc (B,T,H), pred (B,U,H) -> (B,T,U,V).  Reference (transducer.py:98-111) concatenates the
@@ -277,7 +277,10 @@ def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0):
             # the log-softmax pass runs only if something other than this package's RNN-T loss needs the values
             # (pika_amd.rnnt.LazyLogProbs), and the loss may hand back its gradient as a tensor that is only written
             # if something other than JointOutFn looks at it (pika_amd.rnnt.LazyDenseGrad)
-            lp = JointOutFn.apply(h, fc2.weight, fc2.bias, scale, _lazy_enabled() and os.environ.get("PIKA_LAZY_LOGPROBS", "1") != "0")
+            # labels (B,U), optional: the label of every lattice column, which lets the product keep the lattice in 16 bits
+            # (the two logits per row the RNN-T loss reads leave its epilogue in fp32; JointOutFn.forward)
+            lp = JointOutFn.apply(h, fc2.weight, fc2.bias, scale,
+                                  _lazy_enabled() and os.environ.get("PIKA_LAZY_LOGPROBS", "1") != "0", labels)
             lp._pika_lazy_grad_ok = True
             return lp
         out = linear(h, fc2.weight, fc2.bias)

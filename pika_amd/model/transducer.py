@@ -75,7 +75,7 @@ class Net(nn.Module):
         enc = self.encode(x, x_len)
         sos = torch.zeros(y.shape[0], 1, dtype=torch.long, device=y.device)  # SOS = blank = 0
         pred = self.predict(torch.cat((sos, y), dim=1))
-        return ops.joint(enc, pred, self.fc1, self.fc_gate, self.fc2, log_softmax=softmax)
+        return ops.joint(enc, pred, self.fc1, self.fc_gate, self.fc2, log_softmax=softmax, labels=y)
 
     def clean_hidden(self):
         """interface kept for the training scripts"""

@@ -153,14 +153,27 @@ class LogitsState(object):
     hangs off them may keep the 7.8 GB buffer alive -- the buffer itself lives in autograd's saved tensors and in the
     LazyLogProbs the caller holds.)"""
 
-    __slots__ = ("scale", "raw", "partials")
+    __slots__ = ("scale", "raw", "partials", "gathered", "recompute", "dense_lp")
 
     def __init__(self, scale):
         self.scale, self.raw = float(scale), True
         self.partials = None      # (2, rows, n_part) per-row partial (max, sum exp) pairs from the GEMM epilogue
+        # 16-bit logits (pika_gemm_bf16_nt_lse_f16): the buffer is an fp16 matrix; `gathered` = (values (rows, 2) f32,
+        # labels (B, U) i32, blank column) holds what the loss reads in fp32; `recompute()` runs the product again with an
+        # fp32 output and returns log_softmax of it -- what ANY reader other than this package's loss gets (`dense_lp`)
+        self.gathered = None
+        self.recompute = None
+        self.dense_lp = None
 
     def to_log_probs(self, buf):
-        """In place: buf <- log_softmax(scale * buf), once."""
+        """The log-probabilities: in place in an fp32 buffer (buf <- log_softmax(scale * buf), once), or -- 16-bit logits --
+        a separate fp32 tensor made by running the product again."""
+        if self.recompute is not None:
+            if self.dense_lp is None:
+                self.dense_lp = self.recompute()
+                self.raw = False
+                self.partials = None
+            return self.dense_lp
         if self.raw:
             B, T, U1, V = buf.shape
             with torch.cuda.device(buf.device):
@@ -181,6 +194,7 @@ class LazyLogProbs(torch.Tensor):
 
     @staticmethod
     def __new__(cls, state, buf):
+        # (buf: the fp32 logits, or the fp16 matrix of a 16-bit joint; the tensor this object stands for is fp32 either way)
         r = torch.Tensor._make_wrapper_subclass(cls, tuple(buf.shape), dtype=torch.float32, device=buf.device,
                                                 requires_grad=False)
         r.state, r.buf = state, buf
@@ -223,7 +237,8 @@ class _RNNTLossFn(torch.autograd.Function):
         B, T, U1, V = log_probs.shape
         lse = None
         state = log_probs.state if isinstance(log_probs, LazyLogProbs) else None
-        if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= 5120):
+        if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= 5120
+                                      and (state.gathered is None or state.partials is not None)):
             state = None
         if state is not None:
             # raw logits of this package's joint: log-sum-exp + gather in one read, no log-prob tensor
@@ -239,7 +254,14 @@ class _RNNTLossFn(torch.autograd.Function):
                 part = state.partials
                 state.partials = None          # one use: 250 MB at the benchmark shape
                 with _timed("fwd"):
-                    if part is not None:
+                    if state.gathered is not None:
+                        gath, g_labels, g_blank = state.gathered
+                        _lib.check(lib.pika_rnnt_fused_forward_gathered(
+                            _ptr(x), x.stride(-2), _ptr(gath), _ptr(g_labels), int(g_blank), part[0].data_ptr(),
+                            part[1].data_ptr(), part.shape[2], _ptr(labels), _ptr(frames_lengths), _ptr(labels_lengths),
+                            B, T, U1, V, blank, _ptr(costs), _ptr(lse), _ptr(ws), _stream()),
+                            "pika_rnnt_fused_forward_gathered")
+                    elif part is not None:
                         _lib.check(lib.pika_rnnt_fused_forward_partials(
                             _ptr(x), part[0].data_ptr(), part[1].data_ptr(), part.shape[2], _ptr(labels),
                             _ptr(frames_lengths), _ptr(labels_lengths), B, T, U1, V, blank, _ptr(costs), _ptr(lse),

@@ -79,7 +79,7 @@ def _salt_release():
 
 class _Entry(object):
     __slots__ = ("key", "gf", "gb", "inputs", "labels32", "logits", "partials", "ws", "lse", "dims", "grads", "gen", "scale",
-                 "kind", "gout")
+                 "kind", "gout", "gathered", "recompute")
 
 
 class StepGraphs(object):
@@ -212,6 +212,7 @@ def _capture(model, st, key, x, y, x_len):
         e.kind = "compact"
         B, T, U1, V = out.shape
         e.logits, e.partials, e.scale = out.buf, out.state.partials, out.state.scale
+        e.gathered, e.recompute = out.state.gathered, out.state.recompute      # 16-bit logits (JointOutFn.forward)
         e.dims = (B, T, U1, V, 0)
         with torch.cuda.device(dev):
             e.ws = torch.empty(int(lib.pika_rnnt_workspace_bytes(B, T, U1)), dtype=torch.uint8, device=dev)
@@ -225,6 +226,7 @@ def _capture(model, st, key, x, y, x_len):
         # and a dense gradient copied into a static buffer, as torch.cuda.make_graphed_callables does it
         e.kind = "dense"
         e.logits, e.partials, e.scale, e.ws, e.lse, e.dims = out, None, 1.0, None, None, None
+        e.gathered = e.recompute = None
         with torch.cuda.device(dev):
             gout = e.gout = torch.empty_like(out)
     else:
@@ -265,7 +267,7 @@ class _GraphedFn(torch.autograd.Function):
             ctx.st, ctx.e, ctx.gen, ctx.state, ctx.n = st, e, e.gen, None, len(params)
             return e.logits.detach()
         state = LogitsState(e.scale)
-        state.partials = e.partials
+        state.partials, state.gathered, state.recompute = e.partials, e.gathered, e.recompute
         ctx.st, ctx.e, ctx.gen, ctx.state, ctx.n = st, e, e.gen, state, len(params)
         return LazyLogProbs(state, e.logits)
 
@@ -282,8 +284,9 @@ class _GraphedFn(torch.autograd.Function):
         if e.kind == "dense":
             e.gout.copy_(g.dense() if isinstance(g, LazyDenseGrad) else g)
         elif not ctx.state.raw:
-            raise RuntimeError("pika_amd.train_graph: the log-probs were read between forward and backward, which "
-                               "normalised the graph's logits buffer in place; PIKA_TRAIN_GRAPH=0 runs such a loop eagerly")
+            raise RuntimeError("pika_amd.train_graph: the log-probs were read between forward and backward; the captured "
+                               "backward differentiates the raw logits this package's loss reads (and a read normalises an "
+                               "fp32 logits buffer in place); PIKA_TRAIN_GRAPH=0 runs such a loop eagerly")
         elif not (isinstance(g, LazyDenseGrad) and g._dense is None and g.lse is not None
                   and tuple(g.compact.dims) == tuple(e.dims)):
             raise RuntimeError("pika_amd.train_graph: the gradient of the model's output is not the compact gradient of this "

@@ -299,3 +299,57 @@ def test_log_sum_exp_from_the_output_gemm_epilogue(hip_device, monkeypatch, V):
         assert torch.allclose(a[4], r[4], atol=1e-5)          # reading the values normalises both the same way
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.parametrize("V", [5000, 1000, 264])
+def test_sixteen_bit_logits_keep_the_loss_in_fp32(hip_device, V):
+    """JointOutFn with the lattice's labels (pika_gemm_bf16_nt_lse_f16): the (B,T,U1,V) logits exist only as fp16, yet
+    * costs equal those of the fp32-logits path to fp32 rounding: log-sum-exp partials and the two logits per row the loss
+      reads leave the product's epilogue in fp32 (rows beyond an utterance's lattice included);
+    * d(hidden), d(weight), d(bias) agree with the fp32-logits path at the level of the bf16 rounding of d(logits) (the
+      softmax of the backward is taken from the fp16 copy);
+    * a loss given OTHER labels than the joint (or another blank) still gets the right cells -- from the fp16 copy;
+    * reading the values returns the fp32 log-probabilities (the product runs again), and the backward still works."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
+    from pika_amd.rnnt import RNNTLoss, LazyLogProbs
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        g = torch.Generator().manual_seed(V + 1)
+        B, T, U, H = 3, 37, 6, 128
+        h = (torch.randn(B, T, U + 1, H, generator=g) * 0.5).bfloat16().to(hip_device)
+        w = (torch.randn(V, H, generator=g) * 0.3).to(hip_device)
+        b = (torch.randn(V, generator=g) * 2.0).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        other = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        tl = torch.tensor([T, T - 5, T - 11], dtype=torch.int32, device=hip_device)
+        ul = torch.tensor([U, U - 1, U - 4], dtype=torch.int32, device=hip_device)
+
+        def run(joint_labels, loss_labels=labels, blank=0, read=False):
+            hh, ww, bb = (t.clone().requires_grad_(True) for t in (h, w, b))
+            lp = JointOutFn.apply(hh, ww, bb, 1.0, True, joint_labels)
+            lp._pika_lazy_grad_ok = True
+            assert isinstance(lp, LazyLogProbs) and (lp.buf.dtype == torch.float16) == (joint_labels is not None)
+            vals = lp.detach().clone() if read else None
+            costs = RNNTLoss(blank=blank).apply(lp, loss_labels, tl, ul)
+            costs.sum().backward()
+            return costs.detach(), hh.grad.float(), ww.grad, bb.grad, vals
+        ref, got = run(None), run(labels.long())
+        assert torch.allclose(got[0], ref[0], rtol=2e-6, atol=1e-5), (got[0], ref[0])
+        worst = [float((x - y).abs().max() / y.abs().max()) for x, y in zip(got[1:4], ref[1:4])]
+        print("V=%d: 16-bit logits: cost difference %.1e, d(hidden) / d(weight) / d(bias) %.1e / %.1e / %.1e of the largest "
+              "entry" % (V, float((got[0] - ref[0]).abs().max()), *worst))
+        assert worst[0] < 1.5e-2 and worst[1] < 2e-3 and worst[2] < 2e-3, worst
+        # other labels / another blank: the cells come from the fp16 copy (|logit| < 8 here: 2^-11 * 8 = 4e-3 each,
+        # ~40 cells on a path)
+        for kw in (dict(loss_labels=other), dict(blank=3)):
+            r2, g2 = run(None, **kw), run(labels.long(), **kw)
+            assert torch.allclose(g2[0], r2[0], rtol=2e-4, atol=5e-2), (kw.keys(), g2[0], r2[0])
+        # a reader gets fp32 log-probabilities; loss and backward still work (dense path)
+        rr, gr = run(None, read=True), run(labels.long(), read=True)
+        assert torch.allclose(gr[4], rr[4], atol=1e-5)
+        assert torch.allclose(gr[0], rr[0], rtol=2e-6, atol=1e-5)
+        for x, y in zip(gr[1:4], rr[1:4]):
+            assert (x - y).abs().max().item() <= 1e-2 * y.abs().max().item() + 1e-12
+    finally:
+        G.PRECISION = old
