@@ -26,6 +26,22 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# The REFERENCE's own Python modules timed on CPU ("the reference's own Python modules ... on PyTorch-CPU fp32").
+# /root/reference does not exist on the GPU box, so these are constants measured by tools/time_reference_cpu.py in the
+# build container (8 cores, fp32, warm) and carried beside the port each leg times live on the GPU box's host cores.
+CPU_REFERENCE = {
+    "source": "tools/time_reference_cpu.py, build container, 8 cores, round 4",
+    "train_step": {"value": 0.1505, "unit": "utterances/s", "cores": 8, "kind": "reference",
+                   "sample": "reference transducer.Net fwd (as written: (B,T,U,2H) concat, dense log-softmax) + oracle C RNN-T "
+                             "loss + bwd + clip + SGD, B=2, T_in=1000, U=50, V=5000, warm, 2 steps of 13.3 s"},
+    "decode": {"value": 2.84, "unit": "RTF", "cores": 8, "kind": "reference",
+               "sample": "reference TransducerDecoder.decode_batch, B=4, beam 16, n-best 16, 10.0 s of audio, full-width model "
+                         "(tests/decode_full_common.py), 28.3 s of wall time"},
+    "mbr_step": {"value": 1.094, "unit": "utterances/s", "cores": 8, "kind": "reference",
+                 "sample": "UNCHANGED train_transducer_mbr_bmuf_otfaug.py on the reference's own modules, full-width model, "
+                           "B=2 utterances of 1.5 s (not 10 s), beam 4: decode -> optimizer step 1.8 s (second batch)"},
+}
+
 
 def make_inputs(B, T, U, V, dev, seed):
     """SURVEY 8d M1 inputs: log_softmax(randn) built utterance by utterance (no 2x temp)."""
@@ -454,6 +470,7 @@ def mbr_workload(args, dev, rank):
         info["risk"] = float((prob * dist).sum())
         info["hyp_labels"] = float(np.mean([len(h) for row in nonblk for h in row]))
         return rnnt
+    step.decoder = dec
     return step, info
 
 
@@ -499,8 +516,15 @@ class Ranks(object):
             backend = os.environ.get("PIKA_BENCH_BACKEND", "gloo" if dry_run else "nccl")   # "nccl" is RCCL on ROCm
             dist.init_process_group(backend=backend, init_method="env://")
             self.backend = backend
+            self.selfcheck = None
+            if not dry_run and backend == "nccl" and os.environ.get("PIKA_BENCH_SELFCHECK", "1") != "0":
+                # first contact with RCCL on this node: a diagnosis instead of a hang (tools/rccl_selfcheck.py)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import rccl_selfcheck
+                self.selfcheck = rccl_selfcheck.selfcheck(self.dev)
         else:
             self.backend = None
+            self.selfcheck = None
 
     def sync(self):
         if not self.dry_run:
@@ -671,6 +695,7 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
                                             f32["config"]["loss"], ts["config"]["loss"])}
         if with_cpu and R_.rank == 0:
             ts["cpu_baseline"] = cpu_baseline_train_step(args)
+        ts["cpu_baseline_reference"] = CPU_REFERENCE["train_step"]
     except Exception as e:  # the headline line must survive a failure of a secondary leg
         import traceback
         ts = {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-800:]}
@@ -700,17 +725,23 @@ def cpu_baseline_train_step(args, B=2):
     len_b = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.int32)
     ali = torch.full((B,), U, dtype=torch.int32)
     optim = torch.optim.SGD(model.parameters(), 0.003, momentum=0.9, nesterov=True)
+
+    def one():
+        optim.zero_grad(set_to_none=True)
+        out = model(data, labels, len_b, True)
+        costs, grads = O.rnnt_loss(out.detach().numpy(), labels.int().numpy(), len_b.numpy(), ali.numpy(), dtype=np.float32)
+        out.backward(torch.from_numpy(grads))
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
+        optim.step()
+    one()                       # warm: allocator, thread pools, oneDNN primitives
+    n = 3
     t0 = time.perf_counter()
-    optim.zero_grad(set_to_none=True)
-    out = model(data, labels, len_b, True)
-    costs, grads = O.rnnt_loss(out.detach().numpy(), labels.int().numpy(), len_b.numpy(), ali.numpy(), dtype=np.float32)
-    out.backward(torch.from_numpy(grads))
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
-    optim.step()
-    el = time.perf_counter() - t0
+    for _ in range(n):
+        one()
+    el = (time.perf_counter() - t0) / n
     return {"value": B / el, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 step, B=%d, T_in=%d, U=%d, V=%d: same module tree on PyTorch-CPU fp32 stock ops + oracle "
-                      "C/OpenMP RNN-T loss + clip + SGD, %.1f s (features given, no audio front end)" % (B, T, U, V, el)}
+            "sample": "%d warm steps, B=%d, T_in=%d, U=%d, V=%d: same module tree on PyTorch-CPU fp32 stock ops + oracle "
+                      "C/OpenMP RNN-T loss + clip + SGD, %.1f s per step (features given, no audio front end)" % (n, B, T, U, V, el)}
 
 
 def leg_decode(args, R_, with_cpu):
@@ -725,6 +756,7 @@ def leg_decode(args, R_, with_cpu):
         audio_s = a.batch * a.frames / 100.0
         d = decode_report(a, step, ret, el, audio_s, R_.world, cal_labels)
         d = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")}
+        d["cpu_baseline_reference"] = CPU_REFERENCE["decode"]
         if with_cpu and R_.rank == 0:
             d["cpu_baseline"] = cpu_baseline_decode(a, decode_workload.blank_bias)
         if step.decoder.decode_precision == "fp32":
@@ -852,12 +884,13 @@ def cpu_baseline_decode(a, blank_bias, B=4):
     dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
     dec = TransducerDecoder(model, batch_size=B, beam_size=a.beam, n_best=a.beam, blk=0, global_scorer=GlobalScorer(),
                             sm_scale=0.8, cuda=False, beam_prune=True, args=dargs)
+    dec.decode_batch(feats[:1, :300], x_len[:1] * 0 + (300 - 42 + 3) // 4, [170])      # warm (a short utterance)
     t0 = time.perf_counter()
     dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
     el = time.perf_counter() - t0
     return {"value": el / (B * T / 100.0), "unit": "RTF", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "B=%d utterances of %d frames, beam %d: same search on PyTorch-CPU fp32 stock ops, %.1f s, %d steps"
-                      % (B, T, a.beam, el, dec.timing["steps"])}
+            "sample": "B=%d utterances of %d frames, beam %d, after a warm-up decode: same search on PyTorch-CPU fp32 stock "
+                      "ops, %.1f s, %d steps" % (B, T, a.beam, el, dec.timing["steps"])}
 
 
 def cpu_baseline_mbr(args, blank_bias, B=2):
@@ -914,14 +947,62 @@ def cpu_baseline_mbr(args, blank_bias, B=2):
                       "+ oracle C/OpenMP RNN-T loss, %.1f s" % (B, beam, T, el)}
 
 
+def leg_mbr(args, R_, with_cpu, steps=3, warmup=1):
+    """BASELINE configs[3] / SURVEY 8d M4 in the default line: the MBR training step at B = 8 per GPU, beam 4, full config-2
+    model, N-best search in the decoder's default (fp32-grade) arithmetic, training part in the package default."""
+    from types import SimpleNamespace
+    from pika_amd import gemm as G
+    try:
+        a = SimpleNamespace(**vars(args))
+        a.batch, a.beam, a.frames, a.labels = 8, 4, 1000, 50
+        step, info = mbr_workload(a, R_.dev, R_.rank)
+        search = []
+        dec = step.decoder
+
+        def timed_step():
+            r = step()
+            search.append(dec.timing.get("search_s", 0.0))
+            return r
+        el, _ = R_.timed(timed_step, steps, warmup)
+        el /= steps
+        search_ms = float(np.mean(search[-steps:])) * 1e3
+        flops = 730e9 * a.batch            # SURVEY 8d M2 per utterance: the step trains on the full (T',U) lattice as well (:124-159)
+        tf = flops / el / 1e12
+        d = {"metric": "utterances/sec MBR train step (T_in=%d,U=%d,V=%d)" % (a.frames, a.labels, a.vocab),
+             "value": a.batch * R_.world / el, "unit": "utterances/s", "ms_per_step": el * 1e3,
+             "dtype": "N-best search: %s; training part: %s" % (dec.decode_precision, G.PRECISION),
+             "config": {"workload": "mbr_step (BASELINE configs[3] / SURVEY 8d M4): N-best decode (beam %d) + encoder fwd + "
+                                    "RNN-T loss bwd + risk terms + trajectory joint with the HIP risk-gradient kernel + clip + "
+                                    "SGD, full config-2 model" % a.beam,
+                        "batch_per_gpu": a.batch, "beam": a.beam, "steps": steps, "warmup": warmup,
+                        "expected_risk": info.get("risk"), "hyp_labels": info.get("hyp_labels"),
+                        "nbest_search_ms": search_ms, "training_part_ms": el * 1e3 - search_ms},
+             "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                          "traffic": None,
+                          "note": "730 GF per utterance (the step's full-lattice RNN-T part, SURVEY 8d M2) over the WHOLE step; "
+                                  "%.0f of its %.0f ms are the N-best search, a chain of ~%d dependent launches per step at 32 rows "
+                                  "that is bound by launch latency, not by MFMA or HBM (decode.roofline)" % (
+                                      search_ms, el * 1e3, dec.timing.get("launches_per_step", 0))},
+             "parity": "N-best identical to the unchanged reference script's and gradients within the bf16-backward budget in "
+                       "this arithmetic (tests/test_mbr.py::test_gpu_native_mbr_step_in_the_benchmarked_arithmetic)",
+             "cpu_baseline_reference": CPU_REFERENCE["mbr_step"]}
+        step.close() if hasattr(step, "close") else None
+        del step
+        torch.cuda.empty_cache()
+        if with_cpu and R_.rank == 0:
+            d["cpu_baseline"] = cpu_baseline_mbr(a, float(info.get("blank_bias", 1.0)))
+    except Exception as e:
+        import traceback
+        d = {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-800:]}
+    torch.cuda.empty_cache()
+    return d
+
+
 def main():
     # a benchmark must never hang a GPU box: after PIKA_BENCH_WATCHDOG seconds (default 1500) every thread's stack goes to
     # stderr and the process exits
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("PIKA_BENCH_WATCHDOG", "1500")), exit=True)
-    if os.environ.get("PIKA_BENCH_WATCHDOG"):      # dump every thread's stack if the run exceeds N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["PIKA_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="rnnt_loss_M1", choices=["rnnt_loss_M1", "rnnt_loss_M1p", "train_step", "decode", "mbr_step"])
     ap.add_argument("--beam", type=int, default=16)
@@ -946,6 +1027,7 @@ def main():
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
     ap.add_argument("--mbr-search-precision", default=None, choices=["fp32", "fp32-exact", "bf16x3", "bf16"],
                     help="mbr_step: decode arithmetic of the N-best search (default: the decoder's default, fp32-grade)")
+    ap.add_argument("--no-mbr", action="store_true", help="default run: skip the MBR-step leg (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the secondary full-train-step measurement of the default run")
@@ -1076,7 +1158,9 @@ def main():
                 "metric": "utterances/sec MBR train step (T_in=%d,U=%d,V=%d)" % (T, U, V), "value": B * world / el,
                 "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "N-best search: bf16 operands; training part: %s" % __import__("pika_amd.gemm", fromlist=["x"]).PRECISION,
+                "dtype": "N-best search: %s; training part: %s" % (step.decoder.decode_precision,
+                                                                 __import__("pika_amd.gemm", fromlist=["x"]).PRECISION),
+                "cpu_baseline_reference": CPU_REFERENCE["mbr_step"],
                 "data": "synthetic",
                 "config": {"workload": "mbr_step (BASELINE configs[3] / SURVEY 8d M4): N-best decode (beam %d) + encoder "
                                        "fwd + RNN-T loss bwd + risk terms + trajectory joint with the HIP risk-gradient "
@@ -1092,10 +1176,13 @@ def main():
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_train_step(args)
+            out["cpu_baseline_reference"] = CPU_REFERENCE["train_step"]
             print(json.dumps(out), flush=True)
         R_.finish()
         return
     out = leg_rnnt_loss_m1(args, R_, ragged=args.ragged)
+    if rank == 0 and R_.selfcheck is not None:
+        out["rccl_selfcheck"] = R_.selfcheck
     if not args.no_train_step:
         ts = leg_train_step(args, R_, max(5, min(args.steps, 10)), 2, world == 1 and not args.no_cpu_baseline)
         if rank == 0:
@@ -1104,6 +1191,10 @@ def main():
         d = leg_decode(args, R_, world == 1 and not args.no_cpu_baseline)
         if rank == 0:
             out["decode"] = d
+    if not args.no_mbr:
+        m = leg_mbr(args, R_, world == 1 and not args.no_cpu_baseline)
+        if rank == 0:
+            out["mbr_step"] = m
     if rank == 0:
         print(json.dumps(out), flush=True)
     R_.finish()

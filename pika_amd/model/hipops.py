@@ -709,6 +709,38 @@ def _attn_bwd(q, k, v, out, dout, lse, bits, dq, dk, dv, B, T, heads, D, ld, p_d
             p_drop, seed, _stream()), "pika_attention_bwd")
 
 
+def attention_infer_ok(q, k, v, heads, mask):
+    """Inference (no autograd) in one of the two-term arithmetic modes -- the decoder's encoder pass
+    (decoder/transducer_decoder.py: "fp16x2" by default, "bf16x3"; the exact mode "fp32" keeps the exact torch chain): the
+    fused two-term attention takes the fp32 projections.  PIKA_INFER_ATTN=0 keeps the torch chain (hipBLASLt batched
+    products + softmax) in every mode."""
+    D = q.shape[-1] // heads
+    if mask is not None and (mask.dim() != 3 or mask.shape[1] != q.shape[1] or mask.shape[2] != k.shape[1]):
+        return False
+    return (not torch.is_grad_enabled() and G.PRECISION in ("fp16x2", "bf16x3") and _fused() and q.is_cuda
+            and q.dtype == torch.float32 and q.dim() == 3 and q.shape == k.shape == v.shape and D in (64, 128)
+            and D * heads == q.shape[-1] and os.environ.get("PIKA_INFER_ATTN", "1") != "0")
+
+
+def attention_infer_two_term(q, k, v, heads, mask=None):
+    """softmax(q k^T / sqrt(D)) v on fp32 projections through pika_attention_fwd_two_term: q, k, v are split into two
+    bf16 planes each (x = hi + lo, 16 mantissa bits), Q K^T and P V run as hi.hi + lo.hi + hi.lo on the MFMA pipe with the
+    softmax in fp32, and the context comes back as hi + lo.  The (B,H,T,T) score tensor -- 8 GB at B = 64, T = 994 -- is
+    never materialised (reference multi_headed_attn.py:199-231 builds it three times over)."""
+    B, T, HD = q.shape
+    planes = torch.empty((2, B, T, 3 * HD), dtype=torch.bfloat16, device=q.device)
+    hi, lo = planes[0], planes[1]
+    for i, x in enumerate((q, k, v)):
+        h = hi[..., i * HD:(i + 1) * HD]
+        h.copy_(x)
+        lo[..., i * HD:(i + 1) * HD].copy_(x - h.float())
+    out = Pair.empty((B, T, HD), q.device)
+    lse = torch.empty(B * heads * T, dtype=torch.float32, device=q.device)
+    _attn_fwd(hi[..., :HD], hi[..., HD:2 * HD], hi[..., 2 * HD:], out.hi, lse, B, T, heads, HD // heads, 3 * HD, 0.0, 0,
+              _mask_bytes(mask), lo_off=hi.numel(), out_lo_off=out.hi.numel())
+    return out.hi.float().add_(out.lo)
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(D)) [dropout] v per head on (B,T,H*D) projections
     (multi_headed_attn.py:199-231) without materialising the (B,H,T,T) tensors: include/pika_attn.h."""

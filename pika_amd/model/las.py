@@ -119,11 +119,44 @@ class LASRNNEncoder(nn.Module):
             if int(word[0]):
                 raise RuntimeError("pika_blstm_layer: workgroups gave up waiting for their peers (grid not resident)")
 
+    def _forward_fused_blocks(self, input, lengths):
+        """The persistent kernel needs its whole grid resident -- D x (H/16) x (rows/16) workgroups, i.e. 64 rows on the 256
+        CUs of an MI355X at 512 units per direction: larger batches run as consecutive row blocks of that size (rows are
+        independent), each block one launch per layer."""
+        r = self.rnn
+        D, H = (2 if r.bidirectional else 1), r.hidden_size
+        cus = torch.cuda.get_device_properties(input.device).multi_processor_count
+        rows = 16 * max(1, cus // (D * (H // 16)))
+        S, B, _ = input.shape
+        if B <= rows:
+            return self._forward_fused(input, lengths)
+        lens = torch.as_tensor(lengths).view(-1).to(torch.int64).cpu()
+        s_out = int(lens.max())
+        hs, cs, outs = [], [], []
+        for b0 in range(0, B, rows):
+            res = self._forward_fused(input[:, b0:b0 + rows].contiguous(), lens[b0:b0 + rows])
+            if res is None:
+                return None
+            (h, c), out = res
+            if out.shape[0] < s_out:        # a block whose longest row is shorter than the batch's: zero rows behind it
+                out = torch.cat([out, out.new_zeros((s_out - out.shape[0],) + tuple(out.shape[1:]))], 0)
+            hs.append(h)
+            cs.append(c)
+            outs.append(out)
+        return (torch.cat(hs, 1), torch.cat(cs, 1)), torch.cat(outs, 1)
+
+    _warned_fallback = False
+
     def forward(self, input, lengths=None, hidden=None):
         if self._fused_ok(input, lengths, hidden):
-            res = self._forward_fused(input, lengths)
+            res = self._forward_fused_blocks(input, lengths)
             if res is not None:
                 return res
+            if not LASRNNEncoder._warned_fallback:
+                LASRNNEncoder._warned_fallback = True
+                import warnings
+                warnings.warn("pika_amd LAS encoder: the persistent BLSTM kernel did not take this pass (grid larger than the "
+                              "device); running nn.LSTM (MIOpen: ~6x slower per pass)")
         packed = input
         if lengths is not None:
             packed = pack_padded_sequence(input, lengths.view(-1).tolist(), enforce_sorted=False)

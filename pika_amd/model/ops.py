@@ -179,7 +179,9 @@ def attention(q, k, v, heads, mask, p_drop, training):
     Tk = k.shape[1]
     D = HD // heads
     if _hip(q):
-        from .hipops import AttentionFn, attention_ok
+        from .hipops import AttentionFn, attention_ok, attention_infer_ok, attention_infer_two_term
+        if attention_infer_ok(q, k, v, heads, mask):
+            return attention_infer_two_term(q, k, v, heads, mask)
         if attention_ok(q, k, v, heads, mask) and not _mixed():
             drop = p_drop if training else 0.0
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if drop > 0 else 0  # CPU generator

@@ -11,6 +11,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
 def _run(argv, extra_env=None):
     env = dict(os.environ, PIKA_BENCH_DRYRUN="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -37,3 +46,18 @@ def test_single_rank_default_and_world_mismatch_is_loud():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_rccl_selfcheck_runs_under_gloo_with_two_ranks():
+    """tools/rccl_selfcheck.py (what `bench.py --gpus N` runs first when N > 1): environment check, checksummed all-reduce
+    against its bounds -- here on CPU tensors over gloo, world_size 2."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+                        os.path.join(ROOT, "tools", "rccl_selfcheck.py"), "--cpu"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world"] == 2 and d["checksum_ok"] and d["all_reduce_ms"] > 0 and len(d["devices"]) == 2

@@ -117,7 +117,8 @@ def test_fused_scoring_pass_equals_the_op_by_op_pass(hip_device, monkeypatch):
 
 
 @pytest.mark.parametrize("S,B,D,H,In,layers", [(9, 5, 2, 128, 64, 1), (40, 37, 2, 512, 256, 2), (25, 16, 1, 256, 128, 2),
-                                               (12, 64, 2, 384, 64, 1)])
+                                               (12, 64, 2, 384, 64, 1),
+                                               (14, 150, 2, 512, 128, 2)])     # > 64 rows: three row blocks of the kernel
 def test_blstm_encoder_matches_nn_lstm(hip_device, monkeypatch, S, B, D, H, In, layers):
     """The persistent-kernel encoder (pika_blstm_layer: recurrent weights in registers, hidden states exchanged between
     workgroups inside the launch) against torch's nn.LSTM over the same packed sequences in float64 on the CPU:
