@@ -279,6 +279,91 @@ def trained_like_bn_statistics(model, feats):
             m.p = p
 
 
+def speech_like(model, B, T, V, dev, seed, n_colors=50):
+    """A synthetic model + input that DECODE like speech -- without training.  (A random transducer emits either nothing or
+    falls into label cycles at a frame: half of a batch with 2 labels, a quarter with 250+, which made search time, rescoring
+    time and labels-per-utterance of the round-3 decode legs meaningless.)
+
+    Input: low-level noise with a 5-frame burst every 18-22 frames (jittered per utterance), each burst one of `n_colors`
+    fixed random patterns: 45-55 bursts per 1000-frame utterance.  The encoder and the prediction network keep their random
+    weights; two ridge regressions find (i) E_c(b,t): a linear read-out of the ENCODER output that is 1 at the encoder frame
+    under a burst of colour c, 0 elsewhere, (ii) P_c(u): a read-out of the PREDICTION network output that is 1 when the last
+    label of the prefix is 1 + c.  The joint gets n_colors hand-set hidden units tanh(4 (E_c - 1/2)) * sigmoid(12 (1/2 - P_c))
+    -- "colour c is under this frame AND it has not just been emitted" -- that fc2 turns into the logit of label 1 + c; blank
+    carries a constant bias, the other ~970 hidden units and 4950 labels keep (scaled) random weights as confusion noise.
+    The search then does what it does on a trained model: blank between bursts, one label per burst, n-best entries that
+    differ in a few positions, T' + U ~ 290 steps, with or without the LM."""
+    C, H = n_colors, model.hid_dim
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pats = (torch.randn(C, 240, generator=g) * 3.0).to(dev)
+    feats = (torch.randn(B, T, 240, generator=g) * 0.5).to(dev)
+    Tp = (T - 42 + 3) // 4
+    Y = torch.zeros(B, Tp, C, device=dev)
+    want = []
+    for b in range(B):
+        period, f, last, seq = int(rng.integers(18, 23)), int(rng.integers(30, 40)), -1, []
+        while f + 5 < T - 30:
+            c = int(rng.integers(0, C))
+            while c == last:
+                c = int(rng.integers(0, C))
+            feats[b, f:f + 5] += pats[c]
+            t = min(max(int(round((f + 2 - 21) / 4.0)), 0), Tp - 1)
+            Y[b, t, c] = 1.0
+            seq.append(1 + c)
+            last = c
+            f += period + int(rng.integers(-2, 3))
+        want.append(seq)
+    feats = feats.contiguous()
+
+    def ridge(X, Yt):
+        X1 = torch.cat([X, torch.ones(X.shape[0], 1, device=X.device)], 1).double()
+        A = X1.t() @ X1
+        A += torch.eye(A.shape[0], device=A.device, dtype=A.dtype) * (1e-4 * float(A.diagonal().mean()))
+        W = torch.linalg.solve(A, X1.t() @ Yt.double())
+        return W[:-1].float(), W[-1].float()
+    with torch.no_grad():
+        trained_like_bn_statistics(model, feats[:min(B, 4)])
+        model.eval()
+        enc = torch.cat([model.encoder(feats[i:i + 8]).float() for i in range(0, B, 8)], 0)
+        WE, bE = ridge(enc.reshape(-1, H), Y.reshape(-1, C))
+        E = enc.reshape(-1, H) @ WE + bE
+        hit = float(((E > 0.5) == (Y.reshape(-1, C) > 0.5)).float().mean())
+        # the prediction network's state is dominated by the LAST label (older taps of the causal convolutions and the
+        # attention's contribution scaled down): what a trained transducer's prediction network mostly encodes too
+        for conv in model.decoder.conv:
+            conv.weight[:, :, :-1] *= 0.1
+        for layer in model.decoder.transformer:
+            layer.self_attn.final_linear.weight *= 0.1
+            layer.self_attn.final_linear.bias *= 0.1
+        seqs = torch.from_numpy(rng.integers(1, C + 1, (4096, 12))).to(dev)
+        seqs[:, 0] = 0
+        pout = torch.cat([model.decoder(seqs[i:i + 512]).float()[:, 1:] for i in range(0, seqs.shape[0], 512)], 0)
+        last = torch.nn.functional.one_hot(seqs[:, 1:] - 1, C).float()
+        WP, bP = ridge(pout.reshape(-1, H), last.reshape(-1, C))
+        P = pout.reshape(-1, H) @ WP + bP
+        hit_p = float((P.argmax(1) == last.reshape(-1, C).argmax(1)).float().mean())
+        hit = float((E.reshape(B * Tp, C)[Y.reshape(-1, C).sum(1) > 0].argmax(1) ==
+                     Y.reshape(-1, C)[Y.reshape(-1, C).sum(1) > 0].argmax(1)).float().mean())
+        a, K, G_, blank_bias = 4.0, 12.0, 24.0, 14.0      # blank above the log-sum-exp of the 4950 noise labels (8.7)
+        w1, wg, w2 = model.fc1, model.fc_gate, model.fc2
+        w1.weight[:C].zero_()
+        wg.weight[:C].zero_()
+        w1.weight[:C, :H] = a * WE.t()
+        w1.bias[:C] = a * (bE - 0.5)
+        wg.weight[:C, H:] = -K * WP.t()
+        wg.bias[:C] = K * (0.5 - bP)
+        w2.weight *= 4.0                       # confusion noise from the random hidden units (max over 4950 labels ~ 2)
+        w2.weight[:, :C] = 0.0
+        w2.weight[0].zero_()
+        w2.bias.zero_()
+        w2.bias[0] = blank_bias
+        for c in range(C):
+            w2.weight[1 + c, c] = G_
+    return feats, {"bursts_per_utt": [len(s_) for s_ in want], "encoder_readout_accuracy": hit,
+                   "prediction_readout_accuracy": hit_p, "labels": want}
+
+
 def decode_workload(args, dev, rank):
     """batch beam decode, B utterances x beam 16, 10 s of synthetic fbank each,
     full-size model with random weights.  Random weights never emit blank, so fc2 is sharpened
@@ -319,17 +404,27 @@ def decode_workload(args, dev, rank):
                                  lm_scorer=lm, lm_scorer_scale=args.fst_scale,
                                  beam_prune=True, args=dargs)
 
-    trained_like_bn_statistics(model, feats[:min(B, 4)])
+    speech = None
+    if getattr(args, "decode_model", "speechlike") == "speechlike" and args.pred_net == "transformer":
+        feats, speech = speech_like(model, B, T, V, dev, 3000 + rank)
+        decode_workload.blank_bias = 14.0
+        decode_workload.speech = speech
+        labels = float(np.median(speech["bursts_per_utt"]))
+    else:
+        decode_workload.speech = None
+        trained_like_bn_statistics(model, feats[:min(B, 4)])
     with torch.no_grad():
-        model.fc2.weight *= 8.0
+        if speech is None:
+            model.fc2.weight *= 8.0
         lo, hi = 0.0, 40.0
-        labels = float("nan")
-        if args.blank_bias is not None:      # profiling runs: skip the calibration decodes
-            lo = hi = args.blank_bias
+        if speech is None:
+            labels = float("nan")
+        if args.blank_bias is not None or speech is not None:      # profiling runs / the constructed model: no calibration decodes
+            lo = hi = args.blank_bias if speech is None else 14.0
         # bisection on the blank bias WITH the search that is timed (beam width, n-best, FST fusion): the top-1
         # hypothesis of the benchmarked configuration then carries ~args.labels labels (a greedy calibration left
         # the beam-16 / LM-fused searches at 29 / 5 labels per utterance in round 1)
-        for _ in range(9 if args.blank_bias is None else 0):
+        for _ in range(9 if (args.blank_bias is None and speech is None) else 0):
             mid = 0.5 * (lo + hi)
             model.fc2.bias[0] = mid
             nc = min(B, 16)
@@ -353,7 +448,7 @@ def decode_workload(args, dev, rank):
             # the random model's n-best lists hold "runaway" entries of up to max_len labels (a search stuck in a label
             # cycle at one frame: DESIGN 6); a trained model emits ~U per utterance.  Rescoring cost is tokens x
             # hypotheses, so entries are cut to 2U labels for this leg -- stated in the line (las_max_labels)
-            cap = 2 * args.labels
+            cap = 2 * args.labels if decode_workload.speech is None else 10 ** 9     # the constructed model needs no cut
             dec.timing["las_truncated"] = sum(1 for row in hyps for h in row if len(h) > cap)
             hyps = [[h[:cap] for h in row] for row in hyps]
             dec.timing["las_max_labels"] = cap
@@ -425,18 +520,30 @@ def mbr_workload(args, dev, rank):
         return TransducerDecoder(model, batch_size=B, beam_size=k, n_best=k, blk=0, global_scorer=GlobalScorer(),
                                  sm_scale=0.8, cuda=True, beam_prune=False, args=dargs)
     max_len = [int(v) + U + 3 for v in x_len]                                 # :114
-    trained_like_bn_statistics(model, feats[:min(B, 4)])
-    model.eval()
-    with torch.no_grad():
-        model.fc2.weight *= 8.0
-        lo, hi = 0.0, 40.0
-        for _ in range(9):      # calibrated with the N-best search that is timed: ~U labels per hypothesis
-            mid = 0.5 * (lo + hi)
-            model.fc2.bias[0] = mid
-            ret, _ = decoder(beam).decode_batch(feats, x_len, max_len)
-            nlab = np.mean([sum(1 for e in h if int(e) != 0) for row in ret["predictions"] for h in row])
-            lo, hi = (mid, hi) if nlab > U else (lo, mid)
-        model.fc2.bias[0] = 0.5 * (lo + hi)
+    if getattr(args, "decode_model", "speechlike") == "speechlike":
+        # the constructed model of the decode leg (speech_like): one label per input burst; the burst sequence of an
+        # utterance IS its transcript, so the N-best lists are the transcript and its near-misses, as in MBR training
+        feats, speech = speech_like(model, B, T, V, dev, 4000 + rank)
+        U = max(len(w) for w in speech["labels"])
+        labels = torch.full((B, U), V, dtype=torch.long, device=dev)
+        for b, w in enumerate(speech["labels"]):
+            labels[b, :len(w)] = torch.tensor(w, device=dev)
+        ali = torch.tensor([len(w) for w in speech["labels"]], dtype=torch.int32, device=dev)
+        max_len = [int(v) + int(n) + 3 for v, n in zip(x_len, ali)]
+        model.eval()
+    else:
+        trained_like_bn_statistics(model, feats[:min(B, 4)])
+        model.eval()
+        with torch.no_grad():
+            model.fc2.weight *= 8.0
+            lo, hi = 0.0, 40.0
+            for _ in range(9):      # calibrated with the N-best search that is timed: ~U labels per hypothesis
+                mid = 0.5 * (lo + hi)
+                model.fc2.bias[0] = mid
+                ret, _ = decoder(beam).decode_batch(feats, x_len, max_len)
+                nlab = np.mean([sum(1 for e in h if int(e) != 0) for row in ret["predictions"] for h in row])
+                lo, hi = (mid, hi) if nlab > U else (lo, mid)
+            model.fc2.bias[0] = 0.5 * (lo + hi)
     for m in model.modules():   # keep the eval-mode model (running statistics) at its calibration point
         if isinstance(m, torch.nn.BatchNorm1d):
             m.momentum = 0.0
@@ -850,6 +957,16 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
                        counts[0], counts[len(counts) // 4], counts[len(counts) // 2], counts[(3 * len(counts)) // 4], counts[-1]],
                    "search_steps_top1": nsteps,
                    "calibration_labels": cal_labels, "blank_bias": decode_workload.blank_bias,
+                   "synthetic_model": None if decode_workload.speech is None else {
+                       "kind": "speech-like construction (bench.py::speech_like): one label per input burst, no training",
+                       "bursts_per_utt_min_median_max": [int(np.min(decode_workload.speech["bursts_per_utt"])),
+                                                         int(np.median(decode_workload.speech["bursts_per_utt"])),
+                                                         int(np.max(decode_workload.speech["bursts_per_utt"]))],
+                       "encoder_readout_accuracy": decode_workload.speech["encoder_readout_accuracy"],
+                       "prediction_readout_accuracy": decode_workload.speech["prediction_readout_accuracy"],
+                       "top1_equals_the_burst_sequence": "%d of %d utterances" % (
+                           sum(1 for h, w in zip(hyps, decode_workload.speech["labels"])
+                               if [int(e) for e in h[0] if int(e) != 0] == w), len(hyps))},
                    "timing": tm},
         "roofline": {"bound": "hbm", "kernel": "one beam-search step (all of its kernels; the search is "
                                                "launch/latency-bound at %d rows)" % (a.batch * a.beam),
@@ -874,12 +991,15 @@ def cpu_baseline_decode(a, blank_bias, B=4):
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2, embd_dim=100, padding_idx=V)
     torch.manual_seed(777)
     model = Net(opt, 240, V).eval()
-    with torch.no_grad():
-        model.fc2.weight *= 8.0
-        model.fc2.bias[0] = blank_bias
-    g = torch.Generator().manual_seed(3000)
-    feats = torch.randn(B, T, 240, generator=g)
-    trained_like_bn_statistics(model, feats[:min(B, 4)])
+    if decode_workload.speech is not None:      # the same constructed model / input as the GPU leg
+        feats, _ = speech_like(model, B, T, V, torch.device("cpu"), 3000)
+    else:
+        with torch.no_grad():
+            model.fc2.weight *= 8.0
+            model.fc2.bias[0] = blank_bias
+        g = torch.Generator().manual_seed(3000)
+        feats = torch.randn(B, T, 240, generator=g)
+        trained_like_bn_statistics(model, feats[:min(B, 4)])
     x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long)
     dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
     dec = TransducerDecoder(model, batch_size=B, beam_size=a.beam, n_best=a.beam, blk=0, global_scorer=GlobalScorer(),
@@ -1028,6 +1148,9 @@ def main():
     ap.add_argument("--mbr-search-precision", default=None, choices=["fp32", "fp32-exact", "bf16x3", "bf16"],
                     help="mbr_step: decode arithmetic of the N-best search (default: the decoder's default, fp32-grade)")
     ap.add_argument("--no-mbr", action="store_true", help="default run: skip the MBR-step leg (configs[3])")
+    ap.add_argument("--decode-model", default="speechlike", choices=["speechlike", "calibrated"],
+                    help="decode: the constructed model that emits one label per input burst (default), or the round-1..3 "
+                         "random model with a calibrated blank bias")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the secondary full-train-step measurement of the default run")
