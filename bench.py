@@ -345,14 +345,22 @@ def speech_like(model, B, T, V, dev, seed, n_colors=50):
         hit_p = float((P.argmax(1) == last.reshape(-1, C).argmax(1)).float().mean())
         hit = float((E.reshape(B * Tp, C)[Y.reshape(-1, C).sum(1) > 0].argmax(1) ==
                      Y.reshape(-1, C)[Y.reshape(-1, C).sum(1) > 0].argmax(1)).float().mean())
-        a, K, G_, blank_bias = 4.0, 12.0, 24.0, 14.0      # blank above the log-sum-exp of the 4950 noise labels (8.7)
+        # a ridge read-out of an over-determined system shrinks: the units threshold half-way between what the read-out
+        # gives ON a burst (the label's own position) and the largest values it gives elsewhere, with a gain that puts
+        # both ends at tanh(+-2) / sigmoid(-+6)
+        Yf, Lf = Y.reshape(-1, C) > 0.5, last.reshape(-1, C) > 0.5
+        e_on, e_off = float(E[Yf].quantile(0.02)), float(E[~Yf].float().quantile(0.9999))
+        p_on, p_off = float(P[Lf].quantile(0.02)), float(P[~Lf].float().quantile(0.9999))
+        th_e, th_p = 0.5 * (e_on + e_off), 0.5 * (p_on + p_off)
+        a, K = 2.0 / max(e_on - th_e, 1e-3), 6.0 / max(p_on - th_p, 1e-3)
+        G_, blank_bias = 24.0, 14.0             # blank above the log-sum-exp of the 4950 noise labels (8.7)
         w1, wg, w2 = model.fc1, model.fc_gate, model.fc2
         w1.weight[:C].zero_()
         wg.weight[:C].zero_()
         w1.weight[:C, :H] = a * WE.t()
-        w1.bias[:C] = a * (bE - 0.5)
+        w1.bias[:C] = a * (bE - th_e)
         wg.weight[:C, H:] = -K * WP.t()
-        wg.bias[:C] = K * (0.5 - bP)
+        wg.bias[:C] = K * (th_p - bP)
         w2.weight *= 4.0                       # confusion noise from the random hidden units (max over 4950 labels ~ 2)
         w2.weight[:, :C] = 0.0
         w2.weight[0].zero_()
@@ -361,7 +369,9 @@ def speech_like(model, B, T, V, dev, seed, n_colors=50):
         for c in range(C):
             w2.weight[1 + c, c] = G_
     return feats, {"bursts_per_utt": [len(s_) for s_ in want], "encoder_readout_accuracy": hit,
-                   "prediction_readout_accuracy": hit_p, "labels": want}
+                   "prediction_readout_accuracy": hit_p, "labels": want,
+                   "readout_levels": {"encoder_on_burst_p02": e_on, "encoder_elsewhere_p9999": e_off,
+                                      "prediction_on_label_p02": p_on, "prediction_elsewhere_p9999": p_off}}
 
 
 def decode_workload(args, dev, rank):
@@ -964,6 +974,7 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
                                                          int(np.max(decode_workload.speech["bursts_per_utt"]))],
                        "encoder_readout_accuracy": decode_workload.speech["encoder_readout_accuracy"],
                        "prediction_readout_accuracy": decode_workload.speech["prediction_readout_accuracy"],
+                       "readout_levels": decode_workload.speech["readout_levels"],
                        "top1_equals_the_burst_sequence": "%d of %d utterances" % (
                            sum(1 for h, w in zip(hyps, decode_workload.speech["labels"])
                                if [int(e) for e in h[0] if int(e) != 0] == w), len(hyps))},
