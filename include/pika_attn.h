@@ -51,6 +51,14 @@ int pika_attention_fwd_two_term(const void *q, const void *k, const void *v, lon
                                 long long out_lo_off, float *lse, void *keep_bits, const void *mask, int B, int T,
                                 int H, int D, long long ld, long long ldo, float p_drop, unsigned seed, void *stream);
 
+/* INFERENCE forward with fp32-grade products on two FP16 terms per operand (the decoder's encoder pass, reference
+ * multi_headed_attn.py:199-231 at T ~ 1000): q, k, v are the fp16 "hi" planes of x = hi + 2^-11 lo' (hi = fp16(x),
+ * lo' = fp16((x - hi) 2^11): the second term at the first one's magnitude), the "lo'" planes lo_off elements behind;
+ * both products keep hi.hi in one accumulator and lo'.hi + hi.lo' in a second one (joined scaled by 2^-11): ~2^-22 per
+ * product at three MFMAs; softmax in fp32, no dropout, context out as fp32 (pitch ldo).  mask as in pika_attention_fwd. */
+int pika_attention_infer_f16x2(const void *q, const void *k, const void *v, long long lo_off, float *out, const void *mask,
+                               int B, int T, int H, int D, long long ld, long long ldo, void *stream);
+
 /* delta (B*H*T,) f32 is scratch (sum_d out*dout per query row). */
 int pika_attention_bwd(const void *q, const void *k, const void *v, const void *out, const void *dout,
                        int io_dtype, const float *lse, const void *keep_bits, const void *mask, float *delta, void *dq,

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "pika_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_attention_fwd_two_term": (_i, [_vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
                                          ctypes.c_float, ctypes.c_uint, _vp]),
+    "pika_attention_infer_f16x2": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _vp]),
     "pika_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll,
                                 ctypes.c_float, ctypes.c_uint, _vp]),
     "pika_attention_keep_mask": (_i, [_vp, _i, _i, ctypes.c_float, ctypes.c_uint, _vp]),

@@ -416,6 +416,144 @@ __global__ __launch_bounds__(THREADS) void attn_fwd2_kernel(Args A) {
     }
 }
 
+// INFERENCE forward on two FP16 terms per operand (the decoder's encoder pass: fp32-grade products, ~2^-22):
+// x = hi + 2^-11 lo' with hi = fp16(x), lo' = fp16((x - hi) 2^11) -- the second term is kept at the magnitude of the first
+// (never subnormal where hi is not), the leading products hi.hi accumulate in one accumulator and the cross products
+// lo'.hi + hi.lo' in a second one that joins scaled by 2^-11:
+//   S^T = Kh.qh + 2^-11 (Kl'.qh + Kh.ql')        O^T = Vh^T.ph + 2^-11 (Vl'^T.ph + Vh^T.pl')
+// Softmax in fp32; no dropout; the context leaves as fp32.  Same tiling / LDS budget as attn_fwd2_kernel.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_LO = 2048.f, F16_LO_INV = 1.f / 2048.f;
+__device__ inline f32x4 mfma_h(bf16x8 a, bf16x8 b, f32x4 c) {      // the operands carry fp16 bit patterns
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ inline uint32_t pack2h(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ inline float half_of(uint32_t w, int half) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(half ? (w >> 16) : (w & 0xffffu)));
+}
+
+template <int D>
+__global__ __launch_bounds__(THREADS) void attn_infer_f16x2_kernel(Args A) {
+    const _Float16 *Aq = static_cast<const _Float16 *>(A.q);
+    const __bf16 *Ak = static_cast<const __bf16 *>(A.k), *Av = static_cast<const __bf16 *>(A.v);   // 16-bit patterns
+    constexpr int P = D + 8, KS = D / 32, DT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    __bf16 *Kh = reinterpret_cast<__bf16 *>(smem2), *Kl = Kh + TILE * P, *Vh = Kl + TILE * P, *Vl = Vh + TILE * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int T = A.T, h = blockIdx.y, b = blockIdx.z;
+    const int qrow = blockIdx.x * TILE + wave * 16 + (lane & 15);
+    const long long boff = (long long)b * T * A.ld + (long long)h * D;
+    bf16x8 qh[KS], ql[KS];
+    {
+        const _Float16 *qp = Aq + boff + (long long)min(qrow, T - 1) * A.ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 a = *reinterpret_cast<const f16x8 *>(qp + ks * 32 + g * 8);
+            const f16x8 c = *reinterpret_cast<const f16x8 *>(qp + A.lo_off + ks * 32 + g * 8);
+            f16x8 fh, fl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = ((float)a[e] + (float)c[e] * F16_LO_INV) * A.qscale;
+                const _Float16 hh = (_Float16)x;
+                fh[e] = hh;
+                fl[e] = (_Float16)((x - (float)hh) * F16_LO);
+            }
+            qh[ks] = __builtin_bit_cast(bf16x8, fh);
+            ql[ks] = __builtin_bit_cast(bf16x8, fl);
+        }
+    }
+    const uint64_t *mrow = A.mask ? A.mask + ((long long)b * T + min(qrow, T - 1)) * A.nkb : nullptr;
+    f32x4 oacc[DT], oaccx[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = oaccx[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lpart = 0.f;
+    for (int kb = 0; kb < T; kb += TILE) {
+        __syncthreads();
+        load_tile<D>(Kh, Ak + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Kl, Ak + A.lo_off + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vh, Av + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        load_tile<D>(Vl, Av + A.lo_off + boff + (long long)kb * A.ld, A.ld, T - kb, 1.f);
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 sx = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kh = frag_n<P>(Kh, kt * 16, ks * 32, lane);
+                sx = mfma_h(frag_n<P>(Kl, kt * 16, ks * 32, lane), qh[ks], sx);
+                sx = mfma_h(kh, ql[ks], sx);
+                s[kt] = mfma_h(kh, qh[ks], s[kt]);
+            }
+            s[kt] += sx * F16_LO_INV;
+        }
+        if (mrow) {
+            const uint64_t mw = mrow[kb >> 6] >> (g * 4);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((mw >> (kt * 16 + r)) & 1ull) s[kt][r] = MASKED;
+        }
+        if (kb + TILE > T) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb + kt * 16 + g * 4 + r >= T) s[kt][r] = -INFINITY;
+        }
+        float mb = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) mb = fmaxf(mb, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+        mb = fmaxf(mb, __shfl_xor(mb, 16));
+        mb = fmaxf(mb, __shfl_xor(mb, 32));
+        const float mn = fmaxf(m, mb), alpha = ex2(m - mn);
+        m = mn;
+        lpart *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            oacc[dt] *= alpha;
+            oaccx[dt] *= alpha;
+        }
+        uint32_t wh[8], wl[8];      // word 2*kt + j = keys (kt*16 + g*4 + 2j, +1): the k-slots of MFMA s2 = kt / 2
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float p0 = ex2(s[kt][2 * j] - mn), p1 = ex2(s[kt][2 * j + 1] - mn);
+                lpart += p0 + p1;
+                const uint32_t w = pack2h(p0, p1);
+                wh[2 * kt + j] = w;
+                wl[2 * kt + j] = pack2h((p0 - half_of(w, 0)) * F16_LO, (p1 - half_of(w, 1)) * F16_LO);
+            }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 ph = __builtin_bit_cast(bf16x8, u32x4{wh[4 * s2], wh[4 * s2 + 1], wh[4 * s2 + 2], wh[4 * s2 + 3]});
+            const bf16x8 pl = __builtin_bit_cast(bf16x8, u32x4{wl[4 * s2], wl[4 * s2 + 1], wl[4 * s2 + 2], wl[4 * s2 + 3]});
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vh = frag_t<P>(Vh, dt * 16, s2 * 32, lane);
+                oaccx[dt] = mfma_h(frag_t<P>(Vl, dt * 16, s2 * 32, lane), ph, oaccx[dt]);
+                oaccx[dt] = mfma_h(vh, pl, oaccx[dt]);
+                oacc[dt] = mfma_h(vh, ph, oacc[dt]);
+            }
+        }
+    }
+    float l = lpart;
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qrow < T) {
+        const float sc = 1.f / l;
+        float *o = static_cast<float *>(A.o) + (long long)b * T * A.ldo + (long long)h * D + (long long)qrow * A.ldo + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4 *>(o + dt * 16) = (oacc[dt] + oaccx[dt] * F16_LO_INV) * sc;
+    }
+}
+
 // delta[bh*T + q] = sum_d out[b,q,h,d] * dout[b,q,h,d]; one workgroup per (b,q) row.
 template <typename T_>
 __device__ inline f32x4 load4(const T_ *p) {
@@ -717,6 +855,33 @@ static int attention_fwd_impl(const void *q, const void *k, const void *v, void 
     } else {
         if (D == 64) launch_fwd<64, __bf16>(A, grid, s); else launch_fwd<128, __bf16>(A, grid, s);
     }
+    return (int)hipGetLastError();
+}
+
+int pika_attention_infer_f16x2(const void *q, const void *k, const void *v, long long lo_off, float *out, const void *mask,
+                               int B, int T, int H, int D, long long ld, long long ldo, void *stream) {
+    if (!q || !k || !v || !out || B <= 0 || T <= 0 || H <= 0 || (D != 64 && D != 128)) return PIKA_EINVAL;
+    if ((ld & 7) || (ldo & 3) || (lo_off & 7) || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                                                   reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(out)) & 15) ||
+        (mask && (reinterpret_cast<uintptr_t>(mask) & 7)))
+        return PIKA_EINVAL;
+    if (B > 65535 || H > 65535 || (long long)B * H * T > 0x7fffffffLL) return PIKA_ETOOBIG;
+    Args A{};
+    A.q = q; A.k = k; A.v = v; A.o = out; A.T = T; A.H = H; A.ld = ld; A.ldo = ldo;
+    A.qscale = 1.4426950408889634f / sqrtf((float)D);
+    A.mask = static_cast<const uint64_t *>(mask); A.lo_off = lo_off; A.nkb = (T + 63) / 64;
+    const dim3 grid((T + TILE - 1) / TILE, H, B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)4 * TILE * (D + 8) * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_infer_f16x2_kernel<128>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE * 136 * 2);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (D == 64) hipLaunchKernelGGL(attn_infer_f16x2_kernel<64>, grid, dim3(THREADS), lds, s, A);
+    else hipLaunchKernelGGL(attn_infer_f16x2_kernel<128>, grid, dim3(THREADS), lds, s, A);
     return (int)hipGetLastError();
 }
 

@@ -710,27 +710,40 @@ def _attn_bwd(q, k, v, out, dout, lse, bits, dq, dk, dv, B, T, heads, D, ld, p_d
 
 
 def attention_infer_ok(q, k, v, heads, mask):
-    """Inference (no autograd) in the two-bf16-term arithmetic mode ("bf16x3": decoder/transducer_decoder.py with
-    PIKA_DECODE_PRECISION=bf16x3): the fused two-term attention takes the fp32 projections.  NOT in the decoder's default
-    mode ("fp16x2", fp32-grade 2^-22 products): with 2^-17 attention products in the encoder pass ONE separated n-best entry
-    of the full-width golden left its reference rank (tests/test_decode_full.py, round 4), so the default keeps the exact
-    torch chain (hipBLASLt batched products + softmax) until the kernel has an fp16 two-term form; PIKA_INFER_ATTN=2 turns
-    the fused kernel on there as well (3.7 ms less per 64-utterance batch), PIKA_INFER_ATTN=0 off everywhere."""
+    """Inference (no autograd) in one of the two-term arithmetic modes -- the decoder's encoder pass
+    (decoder/transducer_decoder.py: "fp16x2" by default, "bf16x3" on request; the exact mode "fp32" keeps the exact torch
+    chain): the fused two-term attention takes the fp32 projections, so no decode mode materialises the (B,H,T,T) scores
+    or touches hipBLASLt.  PIKA_INFER_ATTN=0 keeps the torch chain everywhere."""
     D = q.shape[-1] // heads
     if mask is not None and (mask.dim() != 3 or mask.shape[1] != q.shape[1] or mask.shape[2] != k.shape[1]):
         return False
-    modes = ("fp16x2", "bf16x3") if os.environ.get("PIKA_INFER_ATTN") == "2" else ("bf16x3",)
-    return (not torch.is_grad_enabled() and G.PRECISION in modes and _fused() and q.is_cuda
+    return (not torch.is_grad_enabled() and G.PRECISION in ("fp16x2", "bf16x3") and _fused() and q.is_cuda
             and q.dtype == torch.float32 and q.dim() == 3 and q.shape == k.shape == v.shape and D in (64, 128)
             and D * heads == q.shape[-1] and os.environ.get("PIKA_INFER_ATTN", "1") != "0")
 
 
 def attention_infer_two_term(q, k, v, heads, mask=None):
-    """softmax(q k^T / sqrt(D)) v on fp32 projections through pika_attention_fwd_two_term: q, k, v are split into two
-    bf16 planes each (x = hi + lo, 16 mantissa bits), Q K^T and P V run as hi.hi + lo.hi + hi.lo on the MFMA pipe with the
-    softmax in fp32, and the context comes back as hi + lo.  The (B,H,T,T) score tensor -- 8 GB at B = 64, T = 994 -- is
-    never materialised (reference multi_headed_attn.py:199-231 builds it three times over)."""
+    """softmax(q k^T / sqrt(D)) v on fp32 projections with two 16-bit terms per operand on the MFMA pipe, softmax in
+    fp32; the (B,H,T,T) score tensor -- 8 GB at B = 64, T = 994 -- is never materialised (reference
+    multi_headed_attn.py:199-231 builds it three times over).
+      "fp16x2": x = hi + 2^-11 lo' (fp16 terms, 22 mantissa bits; pika_attention_infer_f16x2): the decoder's default grade;
+      "bf16x3": x = hi + lo (bf16 terms, 16 bits; pika_attention_fwd_two_term, the training forward's kernel)."""
     B, T, HD = q.shape
+    if G.PRECISION == "fp16x2":
+        planes = torch.empty((2, B, T, 3 * HD), dtype=torch.float16, device=q.device)
+        hi, lo = planes[0], planes[1]
+        for i, x in enumerate((q, k, v)):
+            h = hi[..., i * HD:(i + 1) * HD]
+            h.copy_(x.clamp(-65504.0, 65504.0))
+            lo[..., i * HD:(i + 1) * HD].copy_((x - h.float()) * 2048.0)
+        out = torch.empty((B, T, HD), dtype=torch.float32, device=q.device)
+        mb = _mask_bytes(mask)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib().pika_attention_infer_f16x2(
+                hi[..., :HD].data_ptr(), hi[..., HD:2 * HD].data_ptr(), hi[..., 2 * HD:].data_ptr(), hi.numel(),
+                out.data_ptr(), None if mb is None else mb.data_ptr(), B, T, heads, HD // heads, 3 * HD, HD, _stream()),
+                "pika_attention_infer_f16x2")
+        return out
     planes = torch.empty((2, B, T, 3 * HD), dtype=torch.bfloat16, device=q.device)
     hi, lo = planes[0], planes[1]
     for i, x in enumerate((q, k, v)):

@@ -113,3 +113,38 @@ def test_packed_attention_matches_separate(hip_device):
     (out_s * w).sum().backward()
     assert torch.equal(out_p, out_s)
     assert torch.equal(a.grad, torch.cat([p.grad for p in parts], -1))
+
+
+@pytest.mark.parametrize("B,T,H,D,masked", [(2, 300, 4, 64, False), (1, 130, 2, 128, False), (2, 77, 2, 64, True)])
+def test_inference_attention_on_two_fp16_terms(hip_device, B, T, H, D, masked):
+    """pika_attention_infer_f16x2 (the decoder's encoder pass): softmax(q k^T / sqrt(D)) v with q, k, v as two fp16 terms
+    (22 mantissa bits) against float64 -- fp32-grade: an order of magnitude inside what two bf16 terms give."""
+    from pika_amd import gemm as G
+    from pika_amd.model import hipops
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    q, k, v = (torch.randn(B, T, H * D, generator=g) * s for s in (2.0, 2.0, 1.0))
+    mask = None
+    if masked:
+        mask = torch.triu(torch.ones(T, T, dtype=torch.bool), 1).unsqueeze(0).expand(B, T, T).clone()
+        mask[:, :, T - 9:] = True
+        mask[:, :, 0] = False
+    qh = (q.double() / D ** 0.5).view(B, T, H, D).transpose(1, 2)
+    sc = qh @ k.double().view(B, T, H, D).transpose(1, 2).transpose(2, 3)
+    if mask is not None:
+        sc = sc.masked_fill(mask.unsqueeze(1), -1e18)
+    want = (torch.softmax(sc, -1) @ v.double().view(B, T, H, D).transpose(1, 2)).transpose(1, 2).reshape(B, T, H * D)
+    out = {}
+    old = G.PRECISION
+    try:
+        for mode in ("fp16x2", "bf16x3"):
+            G.PRECISION = mode
+            with torch.no_grad():
+                assert hipops.attention_infer_ok(q.to(hip_device), k.to(hip_device), v.to(hip_device), H,
+                                                 None if mask is None else mask.to(hip_device))
+                got = hipops.attention_infer_two_term(q.to(hip_device), k.to(hip_device), v.to(hip_device), H,
+                                                      None if mask is None else mask.to(hip_device))
+            out[mode] = float((got.double().cpu() - want).abs().max() / want.abs().max())
+    finally:
+        G.PRECISION = old
+    print("inference attention vs float64: two fp16 terms %.1e, two bf16 terms %.1e" % (out["fp16x2"], out["bf16x3"]))
+    assert out["fp16x2"] < 2e-6 and out["bf16x3"] < 1e-4, out
