@@ -57,7 +57,7 @@ def check(got, enc, z, enc_tol, exact, ranks=True):
     """exact: every list identical (CPU: same fp32 library arithmetic as the reference run).  Otherwise (GPU): scores
     are sums of ~150 log-probs of |logit| ~ 30 taken from K = 1024 fp32 accumulations in a different order than the
     CPU GEMM -- 1e-4-level noise per score -- so entries whose reference score is closer than `gap` to a neighbour
-    may swap; every entry that is separated from both neighbours by more than `gap` must sit at its reference rank,
+    may swap; every entry that is separated from both neighbours by more than `gap` (1.5e-3) must sit at its reference rank,
     and the top-1 hypothesis must be the reference's."""
     es = enc[:, ::7, ::37].float().cpu().numpy()
     rel = np.abs(es - z["enc_sample"]).max() / np.abs(z["enc_sample"]).max()
@@ -66,7 +66,11 @@ def check(got, enc, z, enc_tol, exact, ranks=True):
         assert np.array_equal(got["lens"], z["lens"]) and np.array_equal(got["hyps"], z["hyps"])
         assert np.allclose(got["scores"], z["scores"], rtol=1e-5, atol=1e-3)
         return rel, 1.0
-    gap, n_same, n_sep = 1e-3, 0, 0
+    # gap: the separation above which an entry must sit at its reference rank = the score noise itself.  Measured on
+    # MI355X (tools/diag_decode_attn.py): max |score - reference| 1.3e-3 .. 1.5e-3 in the fp32-grade modes, whatever the
+    # encoder's attention runs on (exact torch chain: 1.46e-3, encoder output 3.9e-6 off; fused two-fp16-term kernel:
+    # 1.29e-3, 4.4e-6 off): two entries 1.05e-3 apart in the reference list can and do trade places.
+    gap, n_same, n_sep = 1.5e-3, 0, 0
     B, nb = z["lens"].shape
     for b in range(B):
         assert same_entry(got, z, b, 0), "top-1 hypothesis of utterance %d differs" % b
@@ -96,7 +100,7 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
     assert "launches_per_step" in d.timing            # the fused launch-chain search ran
     rel, frac = check(got, enc, z, 1e-4, exact=False)
     print("fp32 mode: encoder output max rel err %.2e; top-1 identical for all %d utterances; %.0f %% of the %d "
-          "n-best entries at the reference rank, the rest are swaps among entries < 1e-3 apart in score; max |score "
+          "n-best entries at the reference rank, the rest are swaps among entries < 1.5e-3 apart in score; max |score "
           "diff| %.2e" % (rel, F.B, 100 * frac, F.B * F.BEAM, float(np.abs(got["scores"] - z["scores"]).max())))
     # the mode is deterministic from run to run (no float atomics on its path: its forward products never split their
     # reduction): same lists, same bits in the scores
@@ -136,7 +140,7 @@ def test_cpu_full_width_fst_fused_decode_matches_reference():
 def check_fst(got, z):
     """Same criterion as `check` (top-1 identical; every entry separated by > 1e-3 from both neighbours at its reference
     rank, score within 2e-3), without the encoder sample."""
-    gap, n_same = 1e-3, 0
+    gap, n_same = 1.5e-3, 0      # as in `check`
     B, nb = z["lens"].shape
     for b in range(B):
         assert same_entry(got, z, b, 0), "top-1 hypothesis of utterance %d differs" % b
