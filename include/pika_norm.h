@@ -12,9 +12,21 @@
 extern "C" {
 #endif
 
+/* Rows that count (optional, NULL = all): the matrix is B blocks of rows_per_batch rows (one utterance each, row = frame)
+ * of which the first (*t_valid - sub) / div hold data and the rest is padding up to a fixed shape -- statistics, the row
+ * count of the mean / variance, and the backward then run over the data rows only, padding rows come out as zeros and
+ * receive no gradient.  *t_valid is read ON THE DEVICE when the kernels run (a launch sequence captured into a hipGraph for
+ * a padded shape serves every batch length that fits it: pika_amd/train_graph.py); sub / div map the valid length of the
+ * network input to this layer's (time-delay layers shorten it, the last one strides by 4). */
+typedef struct {
+    const int *t_valid;      /* device word: valid frames of the network input */
+    int rows_per_batch;      /* rows per utterance in THIS matrix (padded); rows % rows_per_batch == 0 */
+    int sub, div;            /* valid rows per utterance here = max(0, (*t_valid - sub)) / div, capped at rows_per_batch */
+} pika_bn_valid_t;
+
 /* Per-channel sums: stats[0..C) = sum_r x[r][c], stats[C..2C) = sum_r x[r][c]^2 (fp64, zeroed by
  * the call).  x (rows, C) f32 contiguous. */
-int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *stream);
+int pika_bn_stats(const float *x, long long rows, int C, double *stats, const pika_bn_valid_t *valid, void *stream);
 
 /* y = (x - mean) * rstd * gamma + beta with mean/var from `stats` (biased variance, eps inside the
  * sqrt); writes save_mean / save_rstd (C each, for the backward) and, when running_mean != NULL,
@@ -25,7 +37,7 @@ int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *st
 int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
                   const float *beta, float eps, float momentum, float *running_mean,
                   float *running_var, float *save_mean, float *save_rstd, void *y, int y_dtype,
-                  void *y_lo, void *stream);
+                  void *y_lo, const pika_bn_valid_t *valid, void *stream);
 
 /* Backward, two launches: sums[0..C) = sum dy, sums[C..2C) = sum dy*xhat (fp64); then
  * dx = gamma*rstd*(dy - sum_dy/rows - xhat*sum_dy_xhat/rows), dgamma = sum dy*xhat, dbeta = sum dy.
@@ -35,7 +47,7 @@ int pika_bn_apply(const float *x, long long rows, int C, const double *stats, co
  * produced x). */
 int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
                      const float *save_mean, const float *save_rstd, double *sums, void *dx, int dx_dtype,
-                     float *dgamma, float *dbeta, int relu_mask, void *stream);
+                     float *dgamma, float *dbeta, int relu_mask, const pika_bn_valid_t *valid, void *stream);
 
 /* nn.LayerNorm over the last dimension of x (rows, C) f32 contiguous (pre-LN transformer layers,
  * /root/reference/trainer/model/transformer.py:85-100, position_ffn.py:36): C % 4 == 0, C <= 2048.

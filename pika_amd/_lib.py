@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -87,10 +87,10 @@ SIGNATURES = {
     # include/pika_norm.h
     "pika_layer_norm_fwd": (_i, [_vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp]),
+    "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     "pika_bn_apply": (_i, [_vp, _ll, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp,
-                           _vp, _i, _vp, _vp]),
-    "pika_bn_backward": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+                           _vp, _i, _vp, _vp, _vp]),
+    "pika_bn_backward": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     # include/pika_decode.h
     "pika_incremental_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pika_beam_advance": (_i, [_vp, ctypes.c_float, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp,

@@ -40,6 +40,20 @@ __device__ inline void st4(T *p, f32x4 v) {
     else *reinterpret_cast<bf16x4_t *>(p) = __builtin_convertvector(v, bf16x4_t);
 }
 
+// Rows that count (pika_bn_valid_t, include/pika_norm.h): row r = b * rpb + t is valid iff t < (*t_valid - sub) / div.
+// rpb == 0: every row is valid.  Passed by value to the kernels; the valid length is read from the device word, so a
+// launch sequence captured once serves every length that fits its padded shape.
+struct BnValid {
+    const int *t_valid;
+    int rpb, sub, div;
+    __device__ inline int len() const {
+        if (!rpb) return 0x7fffffff;
+        const int v = (*t_valid - sub) / div;
+        return v < 0 ? 0 : (v > rpb ? rpb : v);
+    }
+    __device__ inline bool ok(long long r, int vlen) const { return !rpb || (int)(r % rpb) < vlen; }
+};
+
 // MODE 0: (x, x^2).  MODE 1: (dy, dy*xhat).  Every lane owns 4 consecutive channels (16-byte loads), a wave
 // covers 256 channels of a row, the 4 waves of a block take rows r, r+1, r+2, r+3; four row-steps in flight.
 // `a` is f32 or bf16 (an incoming gradient may be bf16), x always f32.
@@ -49,9 +63,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TA *__restrict__ a
                                                         const float *__restrict__ mean,
                                                         const float *__restrict__ rstd,
                                                         long long rows, int C, int rows_per_block,
-                                                        double *__restrict__ out) {
+                                                        double *__restrict__ out, BnValid V) {
     __shared__ f32x4 p0[4][64], p1[4][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int vlen = V.len();
     const int c = (blockIdx.x * 64 + lane) * 4;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
@@ -69,11 +84,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TA *__restrict__ a
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if (!V.ok(r + 4 * q, vlen)) continue;       // rows beyond the valid length do not count
                 s0 += v[q];
                 s1 += MODE ? v[q] * ((w[q] - mu) * rs) : v[q] * v[q];
             }
         }
         for (; r < r1; r += 4) {
+            if (!V.ok(r, vlen)) continue;
             const f32x4 v = ld4(a + r * C + c);
             s0 += v;
             if (MODE) s1 += v * ((*reinterpret_cast<const f32x4 *>(x + r * C + c) - mu) * rs);
@@ -96,9 +113,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restri
                                                           long long rows, int C, float eps,
                                                           float momentum, float *running_mean,
                                                           float *running_var, float *save_mean,
-                                                          float *save_rstd) {
+                                                          float *save_rstd, BnValid V) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    if (V.rpb) rows = (rows / V.rpb) * (long long)V.len();      // the rows that were summed
+    if (rows < 1) rows = 1;
     const double mean = stats[c] / (double)rows;
     double var = stats[C + c] / (double)rows - mean * mean;
     if (var < 0) var = 0;
@@ -117,14 +136,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
                                                        const float *__restrict__ rstd,
                                                        const float *__restrict__ gamma,
                                                        const float *__restrict__ beta,
-                                                       TO *__restrict__ y, TO *__restrict__ y_lo) {
+                                                       TO *__restrict__ y, TO *__restrict__ y_lo, BnValid V) {
     const long long stride = (long long)gridDim.x * 256;
+    const int vlen = V.len();
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int c = (int)(i % C4);
         const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
         const f32x4 m = reinterpret_cast<const f32x4 *>(mean)[c], r = reinterpret_cast<const f32x4 *>(rstd)[c];
         const f32x4 g = reinterpret_cast<const f32x4 *>(gamma)[c], b = reinterpret_cast<const f32x4 *>(beta)[c];
-        const f32x4 o = (v - m) * r * g + b;
+        f32x4 o = (v - m) * r * g + b;
+        if (!V.ok(i / C4, vlen)) o = f32x4{0.f, 0.f, 0.f, 0.f};      // padding rows: zeros (finite, and the same every time)
         st4(y + 4 * i, o);
         if constexpr (sizeof(TO) == 2) {     // two-term output: the second plane holds what the bf16 rounding dropped
             if (y_lo) st4(y_lo + 4 * i, o - __builtin_convertvector(__builtin_convertvector(o, bf16x4_t), f32x4));
@@ -140,9 +161,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TD *__restrict_
                                                            const float *__restrict__ rstd,
                                                            const float *__restrict__ gamma,
                                                            const double *__restrict__ sums,
-                                                           TX *__restrict__ dx, int relu_mask) {
+                                                           TX *__restrict__ dx, int relu_mask, BnValid V) {
     const long long stride = (long long)gridDim.x * 256;
-    const float inv = 1.0f / (float)rows;
+    const int vlen = V.len();
+    if (V.rpb) rows = (rows / V.rpb) * (long long)vlen;
+    const float inv = 1.0f / (float)(rows < 1 ? 1 : rows);
     const int C = C4 * 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int c = (int)(i % C4);
@@ -158,6 +181,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TD *__restrict_
             o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f;
             o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
         }
+        if (!V.ok(i / C4, vlen)) o = f32x4{0.f, 0.f, 0.f, 0.f};      // no gradient into padding rows
         st4(dx + 4 * i, o);
     }
 }
@@ -307,17 +331,25 @@ inline dim3 red_grid(long long rows, int C, int mode) {
 }
 inline int ew_grid(long long n4) { return (int)((n4 + 1023) / 1024 < 4096 ? (n4 + 1023) / 1024 : 4096); }
 
+inline bool bn_valid(const pika_bn_valid_t *v, long long rows, BnValid &V) {
+    V = BnValid{nullptr, 0, 0, 1};
+    if (!v) return true;
+    if (!v->t_valid || v->rows_per_batch <= 0 || v->div <= 0 || rows % v->rows_per_batch) return false;
+    V = BnValid{v->t_valid, v->rows_per_batch, v->sub, v->div};
+    return true;
+}
+
 template <typename TD, typename TX>
 int bn_backward_impl(const TD *dy, const float *x, long long rows, int C, const float *gamma,
                             const float *save_mean, const float *save_rstd, double *sums, TX *dx,
-                            float *dgamma, float *dbeta, int relu_mask, hipStream_t s) {
+                            float *dgamma, float *dbeta, int relu_mask, hipStream_t s, BnValid V) {
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((bn_reduce_kernel<1, TD>), red_grid(rows, C, 1), dim3(256), 0, s, dy, x, save_mean,
-                       save_rstd, rows, C, bn_rows_per_block(1), sums);
+                       save_rstd, rows, C, bn_rows_per_block(1), sums, V);
     const long long n4 = rows * C / 4;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TD, TX>), dim3(ew_grid(n4)), dim3(256), 0, s, dy, x, n4, C / 4, rows,
-                       save_mean, save_rstd, gamma, sums, dx, relu_mask);
+                       save_mean, save_rstd, gamma, sums, dx, relu_mask, V);
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, C, dgamma,
                        dbeta);
     return (int)hipGetLastError();
@@ -327,49 +359,55 @@ int bn_backward_impl(const TD *dy, const float *x, long long rows, int C, const 
 
 extern "C" {
 
-int pika_bn_stats(const float *x, long long rows, int C, double *stats, void *stream) {
+int pika_bn_stats(const float *x, long long rows, int C, double *stats, const pika_bn_valid_t *valid, void *stream) {
     if (!x || !stats || rows <= 0 || C <= 0 || (C & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return PIKA_EINVAL;
+    BnValid V;
+    if (!bn_valid(valid, rows, V)) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((bn_reduce_kernel<0, float>), red_grid(rows, C, 0), dim3(256), 0, s, x, x, nullptr, nullptr,
-                       rows, C, bn_rows_per_block(0), stats);
+                       rows, C, bn_rows_per_block(0), stats, V);
     return (int)hipGetLastError();
 }
 
 int pika_bn_apply(const float *x, long long rows, int C, const double *stats, const float *gamma,
                   const float *beta, float eps, float momentum, float *running_mean,
                   float *running_var, float *save_mean, float *save_rstd, void *y, int y_dtype,
-                  void *y_lo, void *stream) {
+                  void *y_lo, const pika_bn_valid_t *valid, void *stream) {
     if (!x || !stats || !gamma || !beta || !save_mean || !save_rstd || !y || rows <= 0 || C <= 0 || (C & 3))
         return PIKA_EINVAL;
+    BnValid V;
+    if (!bn_valid(valid, rows, V)) return PIKA_EINVAL;
     if (y_dtype != PIKA_F32 && y_dtype != PIKA_BF16) return PIKA_EINVAL;
     if (y_lo && (y_dtype != PIKA_BF16 || (reinterpret_cast<uintptr_t>(y_lo) & 7))) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, rows, C, eps,
-                       momentum, running_mean, running_var, save_mean, save_rstd);
+                       momentum, running_mean, running_var, save_mean, save_rstd, V);
     const long long n4 = rows * C / 4;
     if (y_dtype == PIKA_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
-                           save_rstd, gamma, beta, static_cast<float *>(y), static_cast<float *>(nullptr));
+                           save_rstd, gamma, beta, static_cast<float *>(y), static_cast<float *>(nullptr), V);
     else
         hipLaunchKernelGGL(bn_apply_kernel<__bf16>, dim3(ew_grid(n4)), dim3(256), 0, s, x, n4, C / 4, save_mean,
-                           save_rstd, gamma, beta, static_cast<__bf16 *>(y), static_cast<__bf16 *>(y_lo));
+                           save_rstd, gamma, beta, static_cast<__bf16 *>(y), static_cast<__bf16 *>(y_lo), V);
     return (int)hipGetLastError();
 }
 
 int pika_bn_backward(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
                      const float *save_mean, const float *save_rstd, double *sums, void *dx, int dx_dtype,
-                     float *dgamma, float *dbeta, int relu_mask, void *stream) {
+                     float *dgamma, float *dbeta, int relu_mask, const pika_bn_valid_t *valid, void *stream) {
     if (!dy || !x || !gamma || !save_mean || !save_rstd || !sums || !dx || !dgamma || !dbeta ||
         rows <= 0 || C <= 0 || (C & 3))
         return PIKA_EINVAL;
+    BnValid V;
+    if (!bn_valid(valid, rows, V)) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float *dyf = static_cast<const float *>(dy);
     const __bf16 *dyb = static_cast<const __bf16 *>(dy);
     float *dxf = static_cast<float *>(dx);
     __bf16 *dxb = static_cast<__bf16 *>(dx);
-#define BNB(DY, DX) return bn_backward_impl(DY, x, rows, C, gamma, save_mean, save_rstd, sums, DX, dgamma, dbeta, relu_mask, s)
+#define BNB(DY, DX) return bn_backward_impl(DY, x, rows, C, gamma, save_mean, save_rstd, sums, DX, dgamma, dbeta, relu_mask, s, V)
     if (dy_dtype == PIKA_F32 && dx_dtype == PIKA_F32) BNB(dyf, dxf);
     if (dy_dtype == PIKA_F32 && dx_dtype == PIKA_BF16) BNB(dyf, dxb);
     if (dy_dtype == PIKA_BF16 && dx_dtype == PIKA_F32) BNB(dyb, dxf);

@@ -1010,7 +1010,41 @@ def _dt(t):
     return G.PIKA_F32 if t.dtype == torch.float32 else G.PIKA_BF16
 
 
-def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16, out_pair=False):
+class BnValid(ctypes.Structure):
+    """include/pika_norm.h: pika_bn_valid_t."""
+    _fields_ = [("t_valid", ctypes.c_void_p), ("rows_per_batch", ctypes.c_int), ("sub", ctypes.c_int),
+                ("div", ctypes.c_int)]
+
+
+_VALID_ROWS = None      # (t_valid (1,) int32 device tensor, rows_per_batch, sub, div) while an encoder layer runs on a batch
+#                         whose time axis is padded beyond its data (pika_amd/train_graph.py); None: every row counts
+
+
+class valid_rows(object):
+    """Context: the BatchNorm launches issued inside count only the first (*t_valid - sub) // div rows of every block of
+    rows_per_batch rows (statistics, row count, backward), write zeros to the rest and send no gradient there."""
+
+    def __init__(self, t_valid, rows_per_batch, sub, div):
+        self.v = None if t_valid is None else (t_valid, int(rows_per_batch), int(sub), int(div))
+
+    def __enter__(self):
+        global _VALID_ROWS
+        self.old, _VALID_ROWS = _VALID_ROWS, self.v
+
+    def __exit__(self, *exc):
+        global _VALID_ROWS
+        _VALID_ROWS = self.old
+
+
+def _valid_arg(valid, rows):
+    if valid is None:
+        return None
+    t, rpb, sub, div = valid
+    assert rows % rpb == 0 and t.dtype == torch.int32 and t.is_cuda, (rows, rpb)
+    return ctypes.byref(BnValid(t.data_ptr(), rpb, sub, div))
+
+
+def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16, out_pair=False, valid=None):
     """Training-mode statistics + apply; returns (y, mean, rstd); with out_pair y is a Pair (two bf16 planes)."""
     M, C = x.shape
     lib = _lib.lib()
@@ -1019,16 +1053,16 @@ def _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_b
     rstd = torch.empty_like(mean)
     pair = Pair.empty(x.shape, x.device) if out_pair else None
     y = pair.hi if out_pair else torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), _stream()), "pika_bn_stats")
+    _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), _valid_arg(valid, M), _stream()), "pika_bn_stats")
     _lib.check(lib.pika_bn_apply(
         x.data_ptr(), M, C, stats.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps),
         float(momentum), None if running_mean is None else running_mean.data_ptr(),
         None if running_var is None else running_var.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-        y.data_ptr(), _dt(y), pair.lo.data_ptr() if out_pair else None, _stream()), "pika_bn_apply")
+        y.data_ptr(), _dt(y), pair.lo.data_ptr() if out_pair else None, _valid_arg(valid, M), _stream()), "pika_bn_apply")
     return (pair if out_pair else y), mean, rstd
 
 
-def _bn_backward(dy, x, weight, mean, rstd, relu_mask, dx_bf16):
+def _bn_backward(dy, x, weight, mean, rstd, relu_mask, dx_bf16, valid=None):
     """Returns (dx, dgamma, dbeta); dy f32 | bf16, dx f32 | bf16."""
     M, C = x.shape
     if dy.dtype not in (torch.float32, torch.bfloat16):
@@ -1041,7 +1075,7 @@ def _bn_backward(dy, x, weight, mean, rstd, relu_mask, dx_bf16):
     _lib.check(_lib.lib().pika_bn_backward(dy.data_ptr(), _dt(dy), x.data_ptr(), M, C, weight.data_ptr(),
                                            mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
                                            dx.data_ptr(), _dt(dx), dg.data_ptr(), db.data_ptr(),
-                                           int(relu_mask), _stream()), "pika_bn_backward")
+                                           int(relu_mask), _valid_arg(valid, M), _stream()), "pika_bn_backward")
     return dx, dg, db
 
 
@@ -1055,9 +1089,11 @@ class BatchNormFn(torch.autograd.Function):
                 out_pair=False):
         x = x.contiguous()
         ctx.relu_input = bool(relu_input)
+        ctx.valid = _VALID_ROWS
         ctx.set_materialize_grads(False)
         with torch.cuda.device(x.device):
-            y, mean, rstd = _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16, out_pair)
+            y, mean, rstd = _bn_forward(x, weight, bias, running_mean, running_var, eps, momentum, out_bf16, out_pair,
+                                        valid=ctx.valid)
         ctx.save_for_backward(x, weight, mean, rstd)
         if out_pair:
             ctx.mark_non_differentiable(y.lo)
@@ -1068,7 +1104,7 @@ class BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy, *_):
         x, weight, mean, rstd = ctx.saved_tensors
         with torch.cuda.device(x.device):
-            dx, dg, db = _bn_backward(dy, x, weight, mean, rstd, ctx.relu_input, False)
+            dx, dg, db = _bn_backward(dy, x, weight, mean, rstd, ctx.relu_input, False, valid=ctx.valid)
         return dx, dg, db, None, None, None, None, None, None, None
 
 
@@ -1082,6 +1118,7 @@ class TdnnBnFn(torch.autograd.Function):
     def forward(ctx, x, w2d, bias, taps, dil, stride, pad, bn_w, bn_b, running_mean, running_var, eps, momentum,
                 out_bf16, x_lo=None, out_pair=False):
         ctx.x_bf16 = x.dtype == torch.bfloat16
+        ctx.valid = _VALID_ROWS
         ctx.set_materialize_grads(False)
         Bn, T, C = x.shape
         N = w2d.shape[0]
@@ -1095,7 +1132,8 @@ class TdnnBnFn(torch.autograd.Function):
                                       batch_stride=T * Cp)
                 y = torch.empty((M, N), dtype=torch.float32, device=x.device)
                 G.gemm_ex(a_op, G.split_weight(w2d, taps), M, N, taps * 3 * Cp, G.EPI_F32, y, bias=bias, relu=True)
-                out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16, out_pair)
+                out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16, out_pair,
+                                              valid=ctx.valid)
             xb = hi.view(Bn, T, Cp)
         else:
             xb = x.contiguous() if ctx.x_bf16 else x.contiguous().to(torch.bfloat16)
@@ -1103,7 +1141,8 @@ class TdnnBnFn(torch.autograd.Function):
                 a_op, M, K, t_out = G.time_delay(xb, taps, dil, stride, pad)
                 y = torch.empty((M, N), dtype=torch.float32, device=x.device)
                 G.launch(a_op, G.matrix(_weight_for(xb, w2d))[0], y, N, M, N, K, bias=bias, relu=True)
-                out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16)
+                out, mean, rstd = _bn_forward(y, bn_w, bn_b, running_mean, running_var, eps, momentum, out_bf16,
+                                              valid=ctx.valid)
         ctx.cfg = (taps, dil, stride, pad, t_out)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(xb, w2d, y, bn_w, mean, rstd)
@@ -1122,7 +1161,7 @@ class TdnnBnFn(torch.autograd.Function):
         M = y.shape[0]
         dx = dw = db = None
         with torch.cuda.device(dout.device):
-            dyb, dg, dbeta = _bn_backward(dout.reshape(M, N), y, bn_w, mean, rstd, True, True)
+            dyb, dg, dbeta = _bn_backward(dout.reshape(M, N), y, bn_w, mean, rstd, True, True, valid=ctx.valid)
             if ctx.needs_input_grad[0]:
                 # bf16 dx straight from the epilogue when the direct-to-LDS kernel takes the product (its own gate)
                 direct = (ctx.x_bf16 and stride == 1 and N % 64 == 0 and C >= 192 and C % 4 == 0

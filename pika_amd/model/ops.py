@@ -93,6 +93,12 @@ def fused_relu_bn_ok(x, bn):
         torch.is_grad_enabled()
 
 
+def valid_rows(t_valid, rows_per_batch, sub, div):
+    """Context for the BatchNorm launches of a layer whose time axis is padded (hipops.valid_rows)."""
+    from .hipops import valid_rows as ctx
+    return ctx(t_valid, rows_per_batch, sub, div)
+
+
 def batch_norm(x2d, bn, relu_input=False, mfma_only=False):
     """BatchNorm1d over rows of a (M,C) matrix with the module's buffers (train: batch stats).
     relu_input: x2d is a ReLU output whose backward mask this op's backward must apply.

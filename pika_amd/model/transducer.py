@@ -44,11 +44,13 @@ class Net(nn.Module):
         self.fc_gate = nn.Linear(2 * self.hid_dim, self.hid_dim)
         self.fc2 = nn.Linear(self.hid_dim, output_dim)
 
-    def encode(self, x, x_len=None):
+    def encode(self, x, x_len=None, valid_frames=None):
         if self.pack_seq and x_len is not None:
             packed = pack_padded_sequence(x, x_len, batch_first=True, enforce_sorted=True)
             packed, _ = self.encoder(packed)
             return pad_packed_sequence(packed, batch_first=True)[0]
+        if valid_frames is not None:        # the time axis is padded beyond its data (pika_amd/train_graph.py)
+            return self.encoder(x, valid_frames=valid_frames)
         return self.encoder(x)
 
     def predict(self, y):
@@ -71,8 +73,8 @@ class Net(nn.Module):
         state.pop("_step_graphs", None)         # captured graphs are not part of a checkpoint (torch.save(model))
         return state
 
-    def _forward_eager(self, x, y, x_len=None, softmax=True):
-        enc = self.encode(x, x_len)
+    def _forward_eager(self, x, y, x_len=None, softmax=True, valid_frames=None):
+        enc = self.encode(x, x_len, valid_frames)
         sos = torch.zeros(y.shape[0], 1, dtype=torch.long, device=y.device)  # SOS = blank = 0
         pred = self.predict(torch.cat((sos, y), dim=1))
         return ops.joint(enc, pred, self.fc1, self.fc_gate, self.fc2, log_softmax=softmax, labels=y)

@@ -20,7 +20,8 @@ per batch shape, the way torch.cuda.make_graphed_callables splits a callable at 
     and hands the static gradient tensors to `p.grad` (accumulating if the caller left gradients in place).
 
 What makes the sequence replayable: fixed shapes (one pair of graphs per (data shape, label-axis width); a batch whose label
-axis is a few labels narrower than an existing pair's is padded onto it; the time axis is never padded; the graphs share ONE
+axis is a few labels narrower, or whose time axis a few frames shorter, than an existing pair's is padded onto it -- the
+encoder then counts the data frames only (BatchNorm statistics, attention keys: model/encoder.py); the graphs share ONE
 memory pool, so the activations of all shapes occupy the same memory, and an LRU bound caps the static outputs -- the
 logits alone are 7.8 GB at B = 32, T' = 240); dropout through a device-side salt word every seeded kernel of
 libpika_amd.so adds to its seed (`pika_set_dropout_salt`), re-drawn on the device before every forward; nothing on the
@@ -37,7 +38,8 @@ PIKA_TRAIN_GRAPH=0 for such a loop), a gradient that is not this package's loss 
 Knobs (environment): PIKA_TRAIN_GRAPH=0 off; PIKA_TRAIN_GRAPH_WARMUP (2); PIKA_TRAIN_GRAPH_MAX (4 shapes kept);
 PIKA_TRAIN_GRAPH_MIN_SEEN (2: a shape is captured the second time it appears after the warm-up -- a corpus whose batch
 lengths never recur stays eager instead of capturing every step); PIKA_TRAIN_GRAPH_U_BUCKET (8: a batch rides
-on graphs whose label axis is up to 7 labels wider than its own, padded with the embedding's padding index).
+on graphs whose label axis is up to 7 labels wider than its own, padded with the embedding's padding index);
+PIKA_TRAIN_GRAPH_T_BUCKET (64: ... and whose time axis is up to 63 frames longer; 0: exact frame counts only).
 """
 import collections
 import os
@@ -79,18 +81,20 @@ def _salt_release():
 
 class _Entry(object):
     __slots__ = ("key", "gf", "gb", "inputs", "labels32", "logits", "partials", "ws", "lse", "dims", "grads", "gen", "scale",
-                 "kind", "gout", "gathered", "recompute")
+                 "kind", "gout", "gathered", "recompute", "t_valid")
 
 
 class StepGraphs(object):
     """Per-model state of the graphed step (hangs off the module as `_step_graphs`; not pickled)."""
 
-    def __init__(self, model, warmup=None, max_graphs=None, min_seen=None):
+    def __init__(self, model, warmup=None, max_graphs=None, min_seen=None, t_bucket=None):
         env = os.environ.get
         self.warmup = int(env("PIKA_TRAIN_GRAPH_WARMUP", "2")) if warmup is None else int(warmup)
         self.max_graphs = max(1, int(env("PIKA_TRAIN_GRAPH_MAX", "4")) if max_graphs is None else int(max_graphs))
         self.min_seen = max(1, int(env("PIKA_TRAIN_GRAPH_MIN_SEEN", "2")) if min_seen is None else int(min_seen))
         self.u_bucket = max(1, int(env("PIKA_TRAIN_GRAPH_U_BUCKET", "8")))
+        # time axis: a batch of T frames rides on graphs captured for up to t_bucket - 1 more frames (0: exact T only)
+        self.t_bucket = max(0, int(env("PIKA_TRAIN_GRAPH_T_BUCKET", "64")) if t_bucket is None else int(t_bucket))
         self.entries = collections.OrderedDict()        # key -> _Entry, least recently used first
         self.seen = {}
         self.calls = 0
@@ -123,11 +127,11 @@ class StepGraphs(object):
             pass
 
 
-def enable(model, warmup=None, max_graphs=None, min_seen=None):
+def enable(model, warmup=None, max_graphs=None, min_seen=None, t_bucket=None):
     """Turn the graphed step on for `model` (a pika_amd.model.transducer.Net).  Idempotent; returns the state object."""
     st = model.__dict__.get("_step_graphs")
     if st is None or st._closed:
-        st = StepGraphs(model, warmup, max_graphs, min_seen)
+        st = StepGraphs(model, warmup, max_graphs, min_seen, t_bucket)
         model.__dict__["_step_graphs"] = st
         if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG"):
             import atexit
@@ -170,13 +174,14 @@ def _give_up(st, why):
     warnings.warn("pika_amd.train_graph: the training step stays an eager launch sequence (%s)" % why)
 
 
-def _capture(model, st, key, x, y, x_len):
+def _capture(model, st, key, x, y, x_len, t_valid=None):
     from .rnnt import CompactGrad, LazyDenseGrad, LazyLogProbs
     dev = x.device
     e = _Entry()
     e.key, e.gen = key, 0
     e.inputs = [x.clone(), y.clone(), None if x_len is None else x_len.clone()]
     e.labels32 = y.to(torch.int32)       # what the loss reads when the label axis was padded to its bucket
+    e.t_valid = None if t_valid is None else torch.tensor([int(t_valid)], dtype=torch.int32, device=dev)
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     params = [p for _, p in named]
     # The recording differentiates fresh leaf ALIASES of the parameters (same storage), not the parameters themselves: the
@@ -201,7 +206,7 @@ def _capture(model, st, key, x, y, x_len):
                 mod._parameters[k] = by_id[id(p)]
     try:
         with torch.cuda.graph(e.gf, pool=st.pool, capture_error_mode="thread_local"):
-            out = model._forward_eager(e.inputs[0], e.inputs[1], e.inputs[2], True)
+            out = model._forward_eager(e.inputs[0], e.inputs[1], e.inputs[2], True, valid_frames=e.t_valid)
     finally:
         for mod, k, p in swapped:
             mod._parameters[k] = p
@@ -341,29 +346,30 @@ def forward(model, x, y, x_len, softmax):
     if st.param_ptrs != ptrs:
         st.clear()
         st.param_ptrs = ptrs
-    # the label axis may be PADDED with the embedding's padding index -- what the loader itself
-    # pads the shorter utterances of a batch with (otf_utt_loader.py:262-270): the prediction network masks those
-    # positions as keys and is causal, the loss never reads lattice columns beyond an utterance's label count, so the
-    # values of every lattice cell the loss reads are unchanged (tests/test_train_step_gpu.py) while batches whose
-    # longest label sequences differ by a few labels share one pair of graphs.  (The TIME axis is not padded: BatchNorm
-    # statistics and the encoder's unmasked self-attention run over every frame of the batch, so extra frames would
-    # change the values.)
-    # ... A batch is served by an existing pair of graphs whose label axis is its own or up to `u_bucket` - 1 labels wider;
-    # a NEW pair is captured at the batch's own width, so a corpus (or benchmark) of one shape pays for no padding.
-    U = y.shape[1]
+    # Shapes.  The LABEL axis may be padded with the embedding's padding index -- what the loader itself pads the shorter
+    # utterances of a batch with (otf_utt_loader.py:262-270): the prediction network masks those positions as keys and is
+    # causal, the loss never reads lattice columns beyond an utterance's label count.  The TIME axis may be padded when
+    # the model's encoder takes `valid_frames` (st.t_bucket > 0): BatchNorm statistics / counts / gradients then run over
+    # the data frames only and padding frames are no attention keys (model/encoder.py), so the values of every lattice cell
+    # the loss reads and every parameter gradient are those of the unpadded batch (tests/test_train_step_gpu.py).
+    # A batch is served by an existing pair of graphs whose label axis is up to u_bucket - 1 labels and whose time axis is
+    # up to t_bucket - 1 frames longer than its own; a NEW pair is captured at the batch's own shape, so a corpus (or a
+    # benchmark) of one shape pays for no padding.
+    T, U = x.shape[1], y.shape[1]
     pad = getattr(model.embed, "padding_idx", None)
+    timed = st.t_bucket > 0 and x.dim() == 3 and hasattr(model.encoder, "hidden_conv")     # the TDNN-Transformer encoder
 
-    def key_for(width):
-        return (tuple(x.shape), x.dtype, (y.shape[0], width), y.dtype,
-                None if x_len is None else (tuple(x_len.shape), x_len.dtype))
-    e, Ub = None, U
-    if y.dim() == 2:
-        for width in range(U, U + (st.u_bucket if pad is not None else 1)):
-            e = st.entries.get(key_for(width))
-            if e is not None:
-                Ub = width
-                break
-    key = key_for(Ub)
+    def key_for(frames, width):
+        return ((x.shape[0], frames) + tuple(x.shape[2:]), x.dtype, (y.shape[0], width), y.dtype,
+                None if x_len is None else (tuple(x_len.shape), x_len.dtype), timed)
+    e, Tb, Ub = None, T, U
+    widths = range(U, U + (st.u_bucket if (pad is not None and y.dim() == 2) else 1))
+    for k_, cand in st.entries.items():      # (at most max_graphs entries)
+        if k_[5] == timed and k_[0][0] == x.shape[0] and k_[0][2:] == tuple(x.shape[2:]) and k_[2][1] in widths \
+                and T <= k_[0][1] < T + max(st.t_bucket, 1) and k_ == key_for(k_[0][1], k_[2][1]):
+            if e is None or (k_[0][1], k_[2][1]) < (Tb, Ub):
+                e, Tb, Ub = cand, k_[0][1], k_[2][1]
+    key = key_for(Tb, Ub)
     if e is None:
         n = st.seen[key] = st.seen.get(key, 0) + 1
         if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG") == "2":
@@ -375,7 +381,7 @@ def forward(model, x, y, x_len, softmax):
             st.entries.popitem(last=False)               # least recently used: its static outputs go back to the pool
             st.stats["evictions"] += 1
         try:
-            e, why = _capture(model, st, key, x, y, x_len)
+            e, why = _capture(model, st, key, x, y, x_len, t_valid=T if timed else None)
         except Exception as err:                         # a launch the stream capture refuses, out of memory, ...
             e, why = None, "%s: %s" % (type(err).__name__, str(err).split("\n")[0])
         if e is None:
@@ -386,7 +392,13 @@ def forward(model, x, y, x_len, softmax):
         st.stats["captures"] += 1
     else:
         st.entries.move_to_end(key)
-        e.inputs[0].copy_(x, non_blocking=True)
+        if Tb != T:
+            e.inputs[0][:, :T].copy_(x, non_blocking=True)      # frames beyond T keep what they held: finite, and masked
+            st.stats["padded"] = st.stats.get("padded", 0) + 1
+        else:
+            e.inputs[0].copy_(x, non_blocking=True)
+        if e.t_valid is not None:
+            e.t_valid.fill_(T)
         if Ub != U:
             e.inputs[1].fill_(int(pad))
             e.inputs[1][:, :U].copy_(y, non_blocking=True)
@@ -423,12 +435,13 @@ class GraphedTrainStep(object):
     forward, loss, backward, inf-norm clip, optimizer step.  `optimizer` may be replaced / re-parameterised between
     calls (the script rebuilds it after every BMUF block, :115-123): nothing of it is captured."""
 
-    def __init__(self, model, loss_fn, make_optimizer, clip=3.0, warmup=2, max_graphs=None, min_seen=None):
+    def __init__(self, model, loss_fn, make_optimizer, clip=3.0, warmup=2, max_graphs=None, min_seen=None, t_bucket=0):
         self.model, self.loss_fn, self.clip = model, loss_fn, float(clip)
         self.make_optimizer = make_optimizer
         self.optimizer = make_optimizer()
         disable(model)
-        self.state = enable(model, warmup=warmup, max_graphs=max_graphs, min_seen=1 if min_seen is None else min_seen)
+        self.state = enable(model, warmup=warmup, max_graphs=max_graphs, min_seen=1 if min_seen is None else min_seen,
+                            t_bucket=t_bucket)
 
     @property
     def graphs(self):

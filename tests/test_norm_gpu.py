@@ -62,3 +62,50 @@ def test_layer_norm_forward_backward(hip_device, rows, C, bf16):
     for a, r in zip(dev, ref):
         s = r.grad.abs().max().item()
         assert (a.grad.double().cpu() - r.grad).abs().max() < 2e-5 * max(s, 1.0) * (rows ** 0.5 if a.dim() == 1 else 1.0)
+
+
+@pytest.mark.parametrize("B,Tp,C,V,sub,div", [(3, 40, 64, 31, 0, 1), (2, 25, 128, 140, 39, 4), (4, 16, 8, 16, 0, 1)])
+def test_batch_norm_over_the_data_rows_of_a_padded_time_axis(hip_device, B, Tp, C, V, sub, div):
+    """pika_bn_valid_t: the matrix is B blocks of Tp rows of which the first (V - sub) // div hold data (V read on the
+    device).  Statistics, running statistics, outputs and all three gradients equal those of BatchNorm1d (float64) over
+    the data rows alone; padding rows come out as zeros and receive no gradient -- whatever they hold."""
+    from pika_amd.model import ops
+    vl = min(max((V - sub) // div, 0), Tp)
+    g = torch.Generator().manual_seed(B * 100 + Tp)
+    x = torch.relu(torch.randn(B, Tp, C, generator=g, dtype=torch.float64) * 2 + 0.5)
+    x[:, vl:] = torch.randn(B, Tp - vl, C, generator=g, dtype=torch.float64) * 50        # garbage in the padding
+    w = torch.randn(B, Tp, C, generator=g, dtype=torch.float64)
+    w[:, vl:] = 0                               # nothing downstream sends gradient into padding rows
+    ref = torch.nn.BatchNorm1d(C).double().train()
+    ours = torch.nn.BatchNorm1d(C).to(hip_device).train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(C, generator=g) * 0.3 + 1)
+        ref.bias.copy_(torch.randn(C, generator=g))
+        ours.weight.copy_(ref.weight.float()); ours.bias.copy_(ref.bias.float())
+    xr = x[:, :vl].reshape(-1, C).clone().requires_grad_(True)
+    yr = ref(xr)
+    (yr * w[:, :vl].reshape(-1, C)).sum().backward()
+    t_valid = torch.tensor([V], dtype=torch.int32, device=hip_device)
+    xd = x.float().to(hip_device).reshape(-1, C).requires_grad_(True)
+    with ops.valid_rows(t_valid, Tp, sub, div):
+        y = ops.batch_norm(xd, ours)
+    (y * w.float().to(hip_device).reshape(-1, C)).sum().backward()
+    y3 = y.double().cpu().view(B, Tp, C)
+    assert (y3[:, :vl].reshape(-1, C) - yr.detach()).abs().max() < 1e-4
+    assert bool((y3[:, vl:] == 0).all())
+    gx = xd.grad.double().cpu().view(B, Tp, C)
+    assert (gx[:, :vl].reshape(-1, C) - xr.grad).abs().max() < 2e-4 * max(1.0, xr.grad.abs().max().item())
+    assert bool((gx[:, vl:] == 0).all())
+    assert (ours.weight.grad.double().cpu() - ref.weight.grad).abs().max() < 1e-3 * max(1, ref.weight.grad.abs().max().item())
+    assert (ours.bias.grad.double().cpu() - ref.bias.grad).abs().max() < 1e-3 * max(1, ref.bias.grad.abs().max().item())
+    assert torch.allclose(ours.running_mean.double().cpu(), ref.running_mean, atol=1e-5)
+    assert torch.allclose(ours.running_var.double().cpu(), ref.running_var, rtol=1e-4, atol=1e-5)
+    # the SAME launches with another valid length on the device word: nothing of the length is a host value
+    t_valid.fill_(sub + div * (vl - 1) if vl > 1 else V)
+    vl2 = min(max((int(t_valid.item()) - sub) // div, 0), Tp)
+    with ops.valid_rows(t_valid, Tp, sub, div):
+        y2 = ops.batch_norm(xd.detach(), ours).double().cpu().view(B, Tp, C)
+    ref3 = torch.nn.BatchNorm1d(C).double().train()
+    with torch.no_grad():
+        ref3.weight.copy_(ref.weight); ref3.bias.copy_(ref.bias)
+    assert (y2[:, :vl2].reshape(-1, C) - ref3(x[:, :vl2].reshape(-1, C)).detach()).abs().max() < 1e-4

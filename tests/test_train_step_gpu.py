@@ -435,3 +435,69 @@ def test_graphed_step_refuses_what_it_cannot_serve(hip_device):
     finally:
         fused_optim.uninstall()
         G.PRECISION = old
+
+
+def test_padded_time_axis_gives_the_values_of_the_unpadded_batch(hip_device):
+    """The encoder on a batch whose time axis is padded beyond its V frames of data (`valid_frames`, a device word):
+    BatchNorm over the data rows of every layer, padding frames masked as attention keys.  Loss and EVERY parameter
+    gradient of the full model equal those of the unpadded batch (mixed arithmetic; dropout off), with garbage in the
+    padding frames."""
+    from pika_amd import gemm as G
+    model, loss_fn, _, _ = _small_step_harness(hip_device, 0.0, V=512)
+    g = torch.Generator().manual_seed(41)
+    B, T, Tb, U = 4, 283, 320, 9
+    data, labels, len_b, ali = _batch(hip_device, g, B, T, U, 512, pad_from=6)
+    len_b = torch.tensor([(T - 42 + 3) // 4, 50, 44, 57], dtype=torch.int32, device=hip_device)    # ragged utterance lengths
+    padded = torch.randn(B, Tb, 240, generator=g).to(hip_device) * 30
+    padded[:, :T] = data
+    tv = torch.tensor([T], dtype=torch.int32, device=hip_device)
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    try:
+        res = []
+        for x, kw in ((data, {}), (padded, {"valid_frames": tv})):
+            model.zero_grad(set_to_none=True)
+            out = model._forward_eager(x, labels.long(), len_b, True, **kw)
+            loss = loss_fn(out, labels.int(), len_b, ali).sum()
+            loss.backward()
+            res.append((float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()}, tuple(out.shape)))
+    finally:
+        G.PRECISION = old
+    (l0, g0, s0), (l1, g1, s1) = res
+    assert s1[1] == (Tb - 39) // 4 and s0[1] == (T - 39) // 4
+    assert abs(l0 - l1) < 2e-5 * abs(l0), (l0, l1)
+    worst = max(((g1[n] - g0[n]).abs().max().item() / (g0[n].abs().max().item() + 1e-12), n) for n in g0
+                if g0[n].abs().max().item() > 1e-6)
+    print("padded vs unpadded batch: loss %.6f / %.6f, worst parameter-gradient difference %.1e (%s)" % (l0, l1, *worst))
+    assert worst[0] < 2e-3, worst
+
+
+def test_script_loop_with_varying_lengths_rides_on_padded_graphs(hip_device):
+    """Batches whose frame counts differ by a few frames (a length-sorted corpus) share one pair of graphs through the
+    padded time axis: the loss sequence equals the eager loop's."""
+    import copy
+    from pika_amd import gemm as G
+    from pika_amd import train_graph
+    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0, V=512)
+    ref = copy.deepcopy(model)
+    g = torch.Generator().manual_seed(43)
+    frames = (300, 300, 300, 300, 292, 300, 277, 289, 300, 271)
+    batches = [_batch(hip_device, g, 4, T, 9, 512, pad_from=6) for T in frames]
+    old, old_auto = G.PRECISION, train_graph.AUTO
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        train_graph.AUTO = False
+        want = _script_loop(ref, batches, rebuild_every=4)
+        train_graph.AUTO = True
+        got = _script_loop(model, batches, rebuild_every=4)
+        st = model._step_graphs
+        assert st.broken is None, st.broken
+        assert st.t_bucket == 64 and len(st.entries) == 1 and st.stats["captures"] == 1, (st.stats, list(st.entries))
+        assert st.stats["replays"] == 7 and st.stats.get("padded") == 4, st.stats
+        train_graph.disable(model)
+    finally:
+        train_graph.AUTO = old_auto
+        fused_optim.uninstall()
+        G.PRECISION = old
+    assert torch.allclose(torch.tensor(got), torch.tensor(want), rtol=5e-4), (got, want)

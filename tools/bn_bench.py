@@ -12,9 +12,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
     mean = torch.zeros(C, device=dev); rstd = torch.ones(C, device=dev); g = torch.ones(C, device=dev)
     dx = torch.empty(M, C, dtype=torch.bfloat16, device=dev); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
     lib = _lib.lib(); st = torch.cuda.current_stream().cuda_stream
-    def fwd(): _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), st), "stats")
+    def fwd(): _lib.check(lib.pika_bn_stats(x.data_ptr(), M, C, stats.data_ptr(), None, st), "stats")
     def bwd(): _lib.check(lib.pika_bn_backward(dy.data_ptr(), 1, x.data_ptr(), M, C, g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                               sums.data_ptr(), dx.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), 1, st), "bwd")
+                                               sums.data_ptr(), dx.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), 1, None, st), "bwd")
     for name, fn in (("stats", fwd), ("backward (reduce + apply + param grads)", bwd)):
         for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
