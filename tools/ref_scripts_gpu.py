@@ -119,8 +119,8 @@ def train_cost(outdir):
     """Marginal cost of a training step of the UNCHANGED script: the same command on a corpus of 40 and of 200 batches,
     process CPU time (user + sys, all threads: training loop + loader) and wall time of the child; (run2 - run1) / 160 steps is
     what a step costs once the graphs exist.  The corpus is length-bucketed the way the recipes' split_by_length.py makes
-    a rank's batches (utterances of 3.5 s, speed perturbation 0.9 / 1.0 / 1.1: the longest utterance of almost every batch
-    is a 0.9 one), so batch shapes recur; PIKA_TRAIN_GRAPH=0 gives the eager launch sequence on the same corpus."""
+    a rank's batches (utterances of 3.25-3.6 s, speed perturbation 0.9 / 1.0 / 1.1: batch frame counts within a few tens of
+    frames of each other), which the graphs' padded time / label axes absorb; PIKA_TRAIN_GRAPH=0 gives the eager launch sequence on the same corpus."""
     import json
     import resource
     import time
@@ -139,7 +139,9 @@ def train_cost(outdir):
     for nb in [int(v) for v in os.environ.get("COST_BATCHES", "40,200").split(",")]:
         d = work / ("corpus%d" % nb)
         d.mkdir(exist_ok=True)
-        corpora[nb] = make_corpus(d, n_utts=8 * nb, seed=41, lo=56000, hi=56001)[:2]
+        # utterances of 3.25-3.6 s (x 0.9 / 1.0 / 1.1 speed perturbation): the longest utterance of a batch of 8 -- the
+        # batch's frame count -- varies over ~20 frames, which the padded time axis of the graphs absorbs
+        corpora[nb] = make_corpus(d, n_utts=8 * nb, seed=41, lo=52000, hi=57600)[:2]
     conf = corpora[min(corpora)][1]
     (work / "fbank.conf").write_text(Path(conf).read_text().replace("--dither=0", "--dither=1"))
     rng = np.random.default_rng(0)
