@@ -4,7 +4,7 @@
   num_bytes`, `.seq` = concatenated raw int16 PCM;
 * Kaldi int-vector archives (labels): text `uttid i1 i2 ...` or binary (`uttid \\0B` + int32 count
   with 1-byte size markers), read specifiers `ark:path`, `ark,t:path` or a plain path;
-* Kaldi float-matrix archives / scp (offline features for loader/utt_loader.py);
+* Kaldi float-matrix archives / scp (offline features for loader/utt_loader.py), plain and compressed (CM / CM2 / CM3);
 * Kaldi text matrices (the CMVN statistics file, train_transducer_bmuf_otfaug.py:341-346).
 """
 import struct
@@ -72,12 +72,50 @@ def read_int_vectors(rspec):
                 yield parts[0], np.array([int(v) for v in parts[1:]], np.int32)
 
 
+def _read_compressed_matrix(f, tok):
+    """Kaldi's CompressedMatrix on disk (what `copy-feats --compress=true` writes; the archives loader/utt_loader.py:163-164
+    reads through PyKaldi).  After the token -- "CM" (format 1), "CM2", "CM3" -- come the remaining 16 bytes of the global
+    header as one raw struct {float min_value, float range, int32 rows, int32 cols} (no size markers), then
+      CM : per column four uint16 percentiles (0, 25, 75, 100 %; value = min + range * q / 65535), then one byte per
+           element COLUMN by column: three linear pieces  0..64 -> [p0, p25], 64..192 -> [p25, p75], 192..255 -> [p75, p100];
+      CM2: uint16 per element, row-major: min + range * q / 65535;
+      CM3: one byte per element, row-major: min + range * q / 255.
+    Arithmetic in float32 in Kaldi's order of operations, so the floats are the ones its reader produces."""
+    lo, rng, rows, cols = struct.unpack("<ffii", f.read(16))
+    lo, rng = np.float32(lo), np.float32(rng)
+    if rows < 0 or cols < 0:
+        raise ValueError("corrupt compressed Kaldi matrix header (%d x %d)" % (rows, cols))
+    if tok == "CM":
+        heads = np.frombuffer(f.read(8 * cols), dtype="<u2").reshape(cols, 4).astype(np.float32)
+        q = np.frombuffer(f.read(rows * cols), dtype=np.uint8)
+        if q.size != rows * cols:
+            raise ValueError("truncated compressed Kaldi matrix")
+        q = q.reshape(cols, rows).astype(np.float32)
+        pc = lo + rng * np.float32(1.0 / 65535.0) * heads                         # (cols, 4)
+        p0, p25, p75, p100 = (pc[:, i:i + 1] for i in range(4))
+        out = np.where(q <= 64, p0 + (p25 - p0) * q * np.float32(1 / 64.0),
+                       np.where(q <= 192, p25 + (p75 - p25) * (q - 64) * np.float32(1 / 128.0),
+                                p75 + (p100 - p75) * (q - 192) * np.float32(1 / 63.0)))
+        return np.ascontiguousarray(out.T.astype(np.float32))
+    if tok == "CM2":
+        q = np.frombuffer(f.read(2 * rows * cols), dtype="<u2")
+        inc = rng * np.float32(1.0 / 65535.0)
+    else:
+        q = np.frombuffer(f.read(rows * cols), dtype=np.uint8)
+        inc = rng * np.float32(1.0 / 255.0)
+    if q.size != rows * cols:
+        raise ValueError("truncated compressed Kaldi matrix")
+    return (lo + q.reshape(rows, cols).astype(np.float32) * inc).astype(np.float32)
+
+
 def _read_binary_matrix(f):
     head = f.read(2)
     assert head == b"\0B", "expected a binary Kaldi matrix"
     tok = _read_token(f)
+    if tok in ("CM", "CM2", "CM3"):
+        return _read_compressed_matrix(f, tok)
     if tok not in ("FM", "DM"):
-        raise NotImplementedError("Kaldi matrix type %r (compressed matrices unsupported)" % tok)
+        raise NotImplementedError("Kaldi matrix type %r" % tok)
     assert f.read(1) == b"\x04"
     rows = struct.unpack("<i", f.read(4))[0]
     assert f.read(1) == b"\x04"

@@ -75,6 +75,86 @@ def test_kaldi_io_formats(tmp_path):
     assert np.allclose(off, np.tile([-2, -4], 3)) and np.allclose(sc, np.tile(1 / np.sqrt([2.0, 2.0]), 3))
 
 
+def _kaldi_compress(mat, fmt):
+    """Test-side writer of Kaldi's CompressedMatrix (the published algorithm of compressed-matrix.cc: global min / range,
+    per-column 0 / 25 / 75 / 100 % points on a 16-bit grid kept strictly increasing, three linear byte pieces)."""
+    rows, cols = mat.shape
+    lo, hi = float(mat.min()), float(mat.max())
+    rng = hi - lo if hi > lo else 1.0
+    tok = {1: b"CM ", 2: b"CM2 ", 3: b"CM3 "}[fmt]
+    out = b"\0B" + tok + struct.pack("<ffii", lo, rng, rows, cols)
+    if fmt == 2:
+        return out + np.floor((mat - lo) / rng * 65535 + 0.499).astype("<u2").tobytes(), rng / 65535 * 0.51
+    if fmt == 3:
+        return out + np.floor((mat - lo) / rng * 255 + 0.5).clip(0, 255).astype(np.uint8).tobytes(), rng / 255 * 0.51
+    heads, data, err = b"", b"", 0.0
+    for c in range(cols):
+        col = np.sort(mat[:, c])
+        q = [int((float(col[i]) - lo) / rng * 65535 + 0.499) for i in (0, rows // 4, 3 * (rows // 4), rows - 1)]
+        q[0] = min(q[0], 65532)
+        q[1] = min(max(q[1], q[0] + 1), 65533)
+        q[2] = min(max(q[2], q[1] + 1), 65534)
+        q[3] = max(q[3], q[2] + 1)
+        heads += struct.pack("<4H", *q)
+        p0, p25, p75, p100 = (lo + rng * v / 65535.0 for v in q)
+        v = mat[:, c].astype(np.float64)
+        b = np.where(v < p25, np.clip(np.floor((v - p0) / (p25 - p0) * 64 + 0.5), 0, 64),
+                     np.where(v < p75, np.clip(np.floor(64 + (v - p25) / (p75 - p25) * 128 + 0.5), 64, 192),
+                              np.clip(np.floor(192 + (v - p75) / (p100 - p75) * 63 + 0.5), 192, 255)))
+        data += b.astype(np.uint8).tobytes()
+        err = max(err, (p25 - p0) / 64, (p75 - p25) / 128, (p100 - p75) / 63)
+    return out + heads + data, 0.51 * err + rng / 65535
+
+
+def test_compressed_kaldi_matrices(tmp_path):
+    """`copy-feats --compress=true` archives (loader/utt_loader.py:163-164 reads them through PyKaldi): known answers built
+    by hand from the format's definition, then a round trip through a test-side compressor for all three formats, mixed
+    with plain matrices in one archive and addressed through an scp."""
+    from pika_amd.loader import kaldi_io as K
+    # format 1 with min 0, range 65535 and column percentiles (0, 64, 192, 255) / (1000, 1064, 1320, 1383): a byte q
+    # decodes to q itself in column 0; in column 1 to 1000 + q (first piece), 1064 + 2 (q - 64), 1320 + (q - 192)
+    qs = [0, 1, 64, 65, 128, 192, 193, 255]
+    raw = (b"\0BCM " + struct.pack("<ffii", 0.0, 65535.0, len(qs), 2) + struct.pack("<4H", 0, 64, 192, 255)
+           + struct.pack("<4H", 1000, 1064, 1320, 1383) + bytes(qs) + bytes(qs))
+    kat = tmp_path / "kat.ark"
+    kat.write_bytes(b"k1 " + raw
+                    + b"k2 \0BCM2 " + struct.pack("<ffii", -1.0, 2.0, 1, 3) + struct.pack("<3H", 0, 65535, 13107)
+                    + b"k3 \0BCM3 " + struct.pack("<ffii", 10.0, 255.0, 2, 2) + bytes([0, 255, 7, 100]))
+    (k1, m1), (k2, m2), (k3, m3) = list(K.read_matrices("ark:%s" % kat))
+    assert (k1, k2, k3) == ("k1", "k2", "k3") and m1.dtype == np.float32 and m1.shape == (8, 2)
+    assert np.array_equal(m1[:, 0], np.array(qs, np.float32))
+    assert np.array_equal(m1[:, 1], np.array([1000, 1001, 1064, 1066, 1192, 1320, 1321, 1383], np.float32))
+    assert np.allclose(m2, [[-1.0, 1.0, -0.6]], atol=1e-6) and np.array_equal(m3, [[10, 265], [17, 110]])
+    # round trip: features-like data, every format, next to an uncompressed matrix; scp offsets into the archive
+    rng = np.random.default_rng(3)
+    feats = (rng.standard_normal((57, 40)) * np.linspace(0.5, 4, 40) + np.linspace(-3, 8, 40)).astype(np.float32)
+    ark = tmp_path / "c.ark"
+    offs, bounds = {}, {}
+    with open(ark, "wb") as f:
+        for fmt in (1, 2, 3):
+            f.write(b"u%d " % fmt)
+            offs[fmt] = f.tell()
+            blob, bounds[fmt] = _kaldi_compress(feats, fmt)
+            f.write(blob)
+        f.write(b"plain \0BFM \x04" + struct.pack("<i", 2) + b"\x04" + struct.pack("<i", 2)
+                + np.array([[1, 2], [3, 4]], "<f4").tobytes())
+    got = dict(K.read_matrices("ark:%s" % ark))
+    assert list(got) == ["u1", "u2", "u3", "plain"] and np.array_equal(got["plain"], [[1, 2], [3, 4]])
+    for fmt in (1, 2, 3):
+        assert got["u%d" % fmt].shape == feats.shape
+        assert np.abs(got["u%d" % fmt] - feats).max() <= bounds[fmt], (fmt, np.abs(got["u%d" % fmt] - feats).max())
+    assert bounds[2] < 1e-3 and bounds[1] < 0.2
+    scp = tmp_path / "c.scp"
+    scp.write_text("u3 %s:%d\nu1 %s:%d\n" % (ark, offs[3], ark, offs[1]))
+    back = list(K.read_matrices("scp:%s" % scp))
+    assert [k for k, _ in back] == ["u3", "u1"] and np.array_equal(back[1][1], got["u1"])
+    # a truncated payload is an error, not a short matrix
+    bad = tmp_path / "bad.ark"
+    bad.write_bytes(b"k1 " + raw[:-3])
+    with pytest.raises(ValueError):
+        list(K.read_matrices("ark:%s" % bad))
+
+
 def test_host_batching_protocol_and_rng_order(tmp_path):
     """Same draws, in the same order, as loader/otf_utt_loader.py:221-223; T*U filter :247;
     empty-batch sentinel :288; label padding :270."""
