@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "pika_decode_step.h"
 #include "pika_rnnt.h"  // PIKA_EINVAL
@@ -76,6 +77,20 @@ __global__ void dpack_kernel(const float *__restrict__ W, long long ldw, int N, 
 // (double buffered, one barrier per step); W fragments global -> registers.  Everything of step k+1 is requested
 // before the MFMAs of step k: these launches are latency-bound (one or two workgroups per CU, weights coming from
 // L2 / Infinity Cache), so what counts is bytes in flight per wave -- KS*32 columns per request round.
+#ifdef PIKA_CORE_TRACE
+// tools/core_trace.hip: time stamps of wave 0 of workgroups 0, 8, .., 56: [wg 8][step 40][stamp 8]
+__device__ unsigned long long g_core_trace[8 * 40 * 8];
+#define CORE_STAMP(step, k) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0 && (step) < 40) \
+    g_core_trace[((blockIdx.x >> 3) * 40 + (step)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CORE_STAMP(step, k) do { } while (0)
+#endif
+#ifdef PIKA_CORE_TRACE_FINE     // stamps between the operand requests and the MFMAs (they split the block the two share)
+#define CORE_STAMP_IN(step, k) CORE_STAMP(step, k)
+#else
+#define CORE_STAMP_IN(step, k) do { } while (0)
+#endif
+
 template <int BM, int WN, int NSM, int KS>
 struct Core {
     static constexpr bool F16 = NSM == TERMS_F16X2;     // two fp16 terms (see TERMS_F16X2); else NSM bf16 terms
@@ -100,12 +115,14 @@ struct Core {
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // A loader: float4 index f = tid + 256*i -> row f / (BK/4), column group f % (BK/4)
-        const float *arow[APT];
+        const float *abase[APT];
+        bool aok[APT];
         int aoff[APT], acol[APT];
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int f = tid + 256 * i, r = f / (BK / 4), c4 = f % (BK / 4);
-            arow[i] = (m0 + r < M) ? A + (long long)(rows ? rows[m0 + r] : m0 + r) * lda + c4 * 4 : nullptr;
+            aok[i] = m0 + r < M;
+            abase[i] = A + (aok[i] ? (long long)(rows ? rows[m0 + r] : m0 + r) * lda : 0LL);
             aoff[i] = r * PITCH + c4 * 4;
             acol[i] = c4 * 4;
         }
@@ -114,13 +131,17 @@ struct Core {
         for (int j = 0; j < WN; ++j) wbase[j] = W + ((long long)(nt0 + j < NT ? nt0 + j : 0) * KT) * 512 + lane * 8;
         const long long term_stride = (long long)NT * KT * 512;
         const int Kcols = Kvalid < KT * 32 ? Kvalid : KT * 32, steps = (KT + KS - 1) / KS;
-        f32x4 araw[APT];
+        f32x4 araw[2][APT];           // the A pieces of step s wait in araw[s & 1]: requested TWO steps ahead (see the loop)
         bf16x8 wreg[WN][KS][NS], wnext[WN][KS][NS];
-        auto load_a = [&](int st) {
+        // branch-free (the loads of the coming steps sit in ONE basic block with the MFMAs of step k, so that the scheduler
+        // can spread them over the MFMAs): rows beyond M read row 0, columns beyond Kcols the last valid group; both are zeroed
+        auto load_a = [&](int st, f32x4 (&dst)[APT]) {
 #pragma unroll
-            for (int i = 0; i < APT; ++i)
-                araw[i] = (arow[i] && st * BK + acol[i] < Kcols) ? *reinterpret_cast<const f32x4 *>(arow[i] + st * BK)
-                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < APT; ++i) {
+                const int k = st * BK + acol[i];
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(abase[i] + (k < Kcols ? k : Kcols - 4));
+                dst[i] = (aok[i] && k < Kcols) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         };
         auto load_w = [&](int st, bf16x8 (&dst)[WN][KS][NS]) {
 #pragma unroll
@@ -133,11 +154,11 @@ struct Core {
                         dst[j][q][s] = *reinterpret_cast<const bf16x8 *>(wbase[j] + s * term_stride + (long long)kt * 512);
                 }
         };
-        auto stage_a = [&](int buf) {
+        auto stage_a = [&](int buf, const f32x4 (&from)[APT]) {
             __bf16 *dst = lds + buf * (NS * BM * PITCH);
 #pragma unroll
             for (int i = 0; i < APT; ++i) {
-                f32x4 r = araw[i];
+                f32x4 r = from[i];
                 if constexpr (F16) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) r[e] = fminf(fmaxf(r[e], -65504.f), 65504.f);   // saturate, never inf
@@ -162,17 +183,25 @@ struct Core {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        load_a(0);
+        CORE_STAMP(39, 0);
+        load_a(0, araw[0]);
         load_w(0, wreg);
-        stage_a(0);
+        stage_a(0, araw[0]);
+        load_a(steps > 1 ? 1 : 0, araw[1]);
+        CORE_STAMP(39, 1);
         __syncthreads();
-        for (int st = 0; st < steps; ++st) {
-            const bool more = st + 1 < steps;
-            if (more) {
-                load_a(st + 1);
-                load_w(st + 1, wnext);
-            }
-            const __bf16 *src = lds + (st & 1) * (NS * BM * PITCH);
+        CORE_STAMP(39, 2);
+        // Step st (parity P): request the A pieces of step st + 2 and the W fragments of step st + 1, run the MFMAs of step st
+        // on LDS buffer P, convert the A pieces of step st + 1 (requested during step st - 1: a whole step ago, so the
+        // conversion does not wait for memory -- one step ahead, every step ended with ~0.3-0.5 us of exactly that wait) into
+        // buffer P ^ 1, barrier.  The tail requests clamp to the last step (never used) instead of branching.
+        auto step = [&](int st, auto parity) {
+            constexpr int P = decltype(parity)::value;
+            CORE_STAMP(st, 0);
+            load_a(st + 2 < steps ? st + 2 : steps - 1, araw[P]);
+            load_w(st + 1 < steps ? st + 1 : steps - 1, wnext);
+            CORE_STAMP_IN(st, 1);
+            const __bf16 *src = lds + P * (NS * BM * PITCH);
             // products of one kind across all accumulators before the next kind (consecutive MFMAs never share an
             // accumulator); smallest products first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
             constexpr int NP = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
@@ -213,16 +242,34 @@ struct Core {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][q][PW[p]], a[i][PA[p]], acc[i][j], 0, 0, 0);
                 }
             }
-            if (more) {
-                stage_a((st + 1) & 1);
+#ifndef PIKA_CORE_NO_INTERLEAVE
+            {
+                // one operand request per few MFMAs: all four waves issuing their 12-14 loads of 1 KB at once right after the
+                // barrier is 0.3-0.45 us of queueing at the CU's address unit (64 B / clk) in front of every step's products
+                constexpr int NLOADS = APT + WN * KS * NS, NMFMA = MT * WN * KS * (NS == 3 ? 6 : (NS == 2 ? 3 : 1));
+                constexpr int PER = NMFMA / NLOADS > 0 ? NMFMA / NLOADS : 1;
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-#pragma unroll
-                    for (int q = 0; q < KS; ++q)
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) wreg[j][q][s] = wnext[j][q][s];
+                for (int i = 0; i < NLOADS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                }
             }
+#endif
+            CORE_STAMP_IN(st, 2);
+            stage_a(P ^ 1, araw[P ^ 1]);
+            CORE_STAMP_IN(st, 3);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < KS; ++q)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) wreg[j][q][s] = wnext[j][q][s];
             __syncthreads();
+            CORE_STAMP(st, 4);
+        };
+        for (int st = 0; st < steps; st += 2) {
+            step(st, std::integral_constant<int, 0>());
+            if (st + 1 < steps) step(st + 1, std::integral_constant<int, 1>());
         }
         if constexpr (F16) {
 #pragma unroll
@@ -569,7 +616,7 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
 }
 
 // ---- fc2 + log-sum-exp partials + top-K partials --------------------------------------------------------------
-constexpr int FC2_BM = 32, FC2_WN = 3, FC2_KS = 2, FC2_COLS = 4 * FC2_WN * 16;   // 192 columns per split
+constexpr int FC2_WN = 3, FC2_KS = 2, FC2_COLS = 4 * FC2_WN * 16;   // 192 columns per split
 struct Cand { float v; int idx; };
 
 __device__ inline bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -580,8 +627,17 @@ __device__ inline unsigned fkey(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict__ h, long long ldh,
+template <int NS, int BM>
+__host__ __device__ constexpr size_t FC2_LDS_MAIN() {      // operand staging buffers, overlaid by the logits slab
+    constexpr size_t a = Core<BM, FC2_WN, NS, FC2_KS>::LDS_BYTES, b = (size_t)BM * FC2_COLS * 4;
+    return a > b ? a : b;
+}
+
+// FC2_BM rows per workgroup: 32, or 64 when the launch has more than 512 rows -- at B * beam = 1024 rows that is 16 x 27 =
+// 432 workgroups, all resident at once (two per CU), instead of 864 in two rounds, and every slab of W is read by half as
+// many workgroups.  The logits slab overlays the operand staging buffers (dead after the product loop's last barrier).
+template <int NS, int FC2_BM>
+__global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_topk_kernel(const float *__restrict__ h, long long ldh,
                                                         const __bf16 *__restrict__ W, const float *__restrict__ bias,
                                                         int rows, int V, int NT, int KT, float sm_scale, int topk,
                                                         int splits, float *__restrict__ pmax,
@@ -590,13 +646,21 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
     typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
     core_t core;
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
-    float *slab = reinterpret_cast<float *>(smem + core_t::LDS_BYTES);   // [32][FC2_COLS]
+    float *slab = reinterpret_cast<float *>(smem);                       // [FC2_BM][FC2_COLS], after the product
     int mb, sp;
     if (!xcd_tile_rows(splits, (rows + FC2_BM - 1) / FC2_BM, mb, sp)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mb * FC2_BM, nt0 = (sp * 4 + wave) * FC2_WN;
     if (m0 >= rows) return;
+    // this split's bias: one value per thread, requested now, parked in ONE register across the product loop and handed
+    // round through LDS afterwards (12 dependent global loads per lane after the loop were 2.5 us of every workgroup)
+    float *bias_s = reinterpret_cast<float *>(smem + FC2_LDS_MAIN<NS, FC2_BM>());
+    const int bc = sp * FC2_COLS + threadIdx.x;
+    const float bv = (bias && threadIdx.x < FC2_COLS && bc < V) ? bias[bc] : 0.f;
     core.run(h, ldh, rows, m0, W, NT, KT, nt0, lds, Kvalid);
+    CORE_STAMP(38, 0);
+    if (threadIdx.x < FC2_COLS) bias_s[threadIdx.x] = bv;
+    __syncthreads();
     // logits of this split -> slab (sm_scale * (acc + bias); columns >= V masked)
 #pragma unroll
     for (int i = 0; i < FC2_BM / 16; ++i)
@@ -605,64 +669,110 @@ __global__ __launch_bounds__(256) void dfc2_topk_kernel(const float *__restrict_
             const int lc = (wave * FC2_WN + j) * 16 + (lane >> 4) * 4;      // column inside the split
             const int c = sp * FC2_COLS + lc;
             f32x4 v = core.acc[i][j];
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_s + lc);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = c + u < V ? sm_scale * (v[u] + (bias ? bias[c + u] : 0.f)) : -INFINITY;
+            for (int u = 0; u < 4; ++u) v[u] = c + u < V ? sm_scale * (v[u] + b4[u]) : -INFINITY;
             *reinterpret_cast<f32x4 *>(slab + (i * 16 + (lane & 15)) * FC2_COLS + lc) = v;
         }
     __syncthreads();
-    // 8 rows per wave: max, sum of exponentials, the topk largest (value desc, column asc)
+    CORE_STAMP(38, 1);
+    // FC2_BM / 4 rows per wave: max, sum of exponentials, the topk largest (value desc, column asc).  RG rows at a time:
+    // every stage below is a chain of dependent cross-lane steps (6 + 6 butterfly exchanges; 32 bisection rounds of
+    // compare -> ballot -> scalar popcount -> scalar select -> compare, ~80 cycles each) that leaves the wave idle --
+    // 2.3 us per row one row at a time (tools/core_trace.hip); the RG independent chains fill each other's bubbles.
     constexpr int PL = FC2_COLS / 64;     // values per lane
-    for (int rr = 0; rr < FC2_BM / 4; ++rr) {
-        const int lr = wave * (FC2_BM / 4) + rr, r = m0 + lr;
-        if (r >= rows) break;
-        float x[PL];
+    constexpr int RG = 4;
+    static_assert((FC2_BM / 4) % RG == 0, "row groups");
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int rr = 0; rr < FC2_BM / 4; rr += RG) {
+        const int lr0 = wave * (FC2_BM / 4) + rr;
+        if (m0 + lr0 >= rows) break;
+        float x[RG][PL], m[RG], s[RG];
 #pragma unroll
-        for (int q = 0; q < PL; ++q) x[q] = slab[lr * FC2_COLS + lane + 64 * q];
-        float m = x[0];
+        for (int g = 0; g < RG; ++g) {
 #pragma unroll
-        for (int q = 1; q < PL; ++q) m = fmaxf(m, x[q]);
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float s = 0.f;
+            for (int q = 0; q < PL; ++q) x[g][q] = slab[(lr0 + g) * FC2_COLS + lane + 64 * q];
+            m[g] = x[g][0];
 #pragma unroll
-        for (int q = 0; q < PL; ++q) s += x[q] > -INFINITY ? expf(x[q] - m) : 0.f;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const long long pi = (long long)r * splits + sp;
-        if (lane == 0) { pmax[pi] = m; psum[pi] = s; }
+            for (int q = 1; q < PL; ++q) m[g] = fmaxf(m[g], x[g][q]);
+        }
+        if (rr == 0) CORE_STAMP(37, 0);
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int g = 0; g < RG; ++g) m[g] = fmaxf(m[g], __shfl_xor(m[g], o));
+        if (rr == 0) CORE_STAMP(37, 1);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            s[g] = 0.f;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) s[g] += x[g][q] > -INFINITY ? expf(x[g][q] - m[g]) : 0.f;
+        }
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int g = 0; g < RG; ++g) s[g] += __shfl_xor(s[g], o);
+        if (rr == 0) CORE_STAMP(37, 2);
         // The topk largest WITHOUT cross-lane shuffles (a wave arg-max is 12 dependent LDS-crossbar permutes, and
         // topk of them per row made this epilogue 4x longer than the product itself): bisect the order-preserving
         // integer image of the values for the topk-th largest key with ballots + popcounts (scalar unit), then every
         // lane stores its own survivors at ranks taken from the ballot prefix.  Output order within a range is
         // arbitrary (the advance re-selects anyway); ties at the threshold go to the lowest columns.
-        unsigned key[PL];
+        unsigned key[RG][PL], T[RG];
 #pragma unroll
-        for (int q = 0; q < PL; ++q) key[q] = fkey(x[q]);
-        unsigned T = 0;
+        for (int g = 0; g < RG; ++g) {
+            T[g] = 0;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) key[g][q] = fkey(x[g][q]);
+        }
         for (int bit = 31; bit >= 0; --bit) {
-            const unsigned mid = T | (1u << bit);
-            int cnt = 0;
+            unsigned mid[RG];
+            unsigned long long bal[RG][PL];
 #pragma unroll
-            for (int q = 0; q < PL; ++q) cnt += __popcll(__ballot(key[q] >= mid));
-            if (cnt >= topk) T = mid;
-        }
-        Cand *out = pcand + pi * topk;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int base = 0;
+            for (int g = 0; g < RG; ++g) mid[g] = T[g] | (1u << bit);
 #pragma unroll
-        for (int q = 0; q < PL; ++q) {
-            const bool gsel = key[q] > T;
-            const unsigned long long mk = __ballot(gsel);
-            if (gsel) out[base + __popcll(mk & lt)] = Cand{x[q], x[q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
-            base += __popcll(mk);
-        }
+            for (int g = 0; g < RG; ++g)
 #pragma unroll
-        for (int q = 0; q < PL; ++q) {
-            const bool e = key[q] == T;
-            const unsigned long long mk = __ballot(e);
-            const int rk = base + __popcll(mk & lt);
-            if (e && rk < topk) out[rk] = Cand{x[q], x[q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
-            base += __popcll(mk);
+                for (int q = 0; q < PL; ++q) bal[g][q] = __ballot(key[g][q] >= mid[g]);
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                int cnt = 0;
+#pragma unroll
+                for (int q = 0; q < PL; ++q) cnt += __popcll(bal[g][q]);
+                if (cnt >= topk) T[g] = mid[g];
+            }
+            // the RG * PL compares back to back, then the scalar counting: a compare -> popcount -> add -> select chain per
+            // row, one after the other, is ~145 cycles of dependent-instruction latency per row and round
+            __builtin_amdgcn_sched_group_barrier(0x004, RG, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, RG * PL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, RG * (2 * PL + 1), 0);
         }
+        if (rr == 0) CORE_STAMP(37, 3);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const int r = m0 + lr0 + g;
+            if (r >= rows) break;                 // (wave-uniform)
+            const long long pi = (long long)r * splits + sp;
+            if (lane == 0) { pmax[pi] = m[g]; psum[pi] = s[g]; }
+            Cand *out = pcand + pi * topk;
+            int base = 0;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) {
+                const bool gsel = key[g][q] > T[g];
+                const unsigned long long mk = __ballot(gsel);
+                if (gsel) out[base + __popcll(mk & lt)] = Cand{x[g][q], x[g][q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
+                base += __popcll(mk);
+            }
+#pragma unroll
+            for (int q = 0; q < PL; ++q) {
+                const bool e = key[g][q] == T[g];
+                const unsigned long long mk = __ballot(e);
+                const int rk = base + __popcll(mk & lt);
+                if (e && rk < topk) out[rk] = Cand{x[g][q], x[g][q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
+                base += __popcll(mk);
+            }
+        }
+        if (rr == 0) CORE_STAMP(37, 4);
     }
+    CORE_STAMP(38, 2);
 }
 
 int check(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -673,12 +783,29 @@ void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
     dgemm_kernel<BM, NS><<<dim3(grid), dim3(256), lds, st>>>(p);
 }
 
+template <int NS, int BM>
+void launch_fc2_bm(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
+                   int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K) {
+    constexpr size_t lds = FC2_LDS_MAIN<NS, BM>() + FC2_COLS * 4;
+    dfc2_topk_kernel<NS, BM><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits,
+                                                                 pmax, psum, pc, (K & 3) ? KT * 32 : K);
+}
+
+int fc2_bm(int rows) {
+    // 64-row tiles once the 32-row form would need a second round of workgroups (rows / 32 * 27 splits > 768 resident ones at
+    // V = 5000): 74 vs 81 us at 1024 rows, but 50 vs 34 us at 32 rows (tools/dfc2_bench.py)
+    static const int forced = [] { const char *e = getenv("PIKA_DFC2_BM"); return e ? atoi(e) : 0; }();
+    if (forced == 32 || forced == 64) return forced;
+    return rows > 768 ? 64 : 32;
+}
+
 template <int NS>
-void launch_fc2(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
+void launch_fc2(hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
                 int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K) {
-    constexpr size_t lds = Core<FC2_BM, FC2_WN, NS, FC2_KS>::LDS_BYTES + FC2_BM * FC2_COLS * 4;
-    dfc2_topk_kernel<NS><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax,
-                                                             psum, pc, (K & 3) ? KT * 32 : K);
+    const int bm = fc2_bm(rows);
+    const unsigned grid = (unsigned)((((rows + bm - 1) / bm + 7) / 8) * 8 * splits);
+    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
 }
 
 }  // namespace
@@ -782,14 +909,13 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
         terms > 4 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
         return PIKA_EINVAL;
     const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
-    const unsigned grid = (unsigned)((((rows + FC2_BM - 1) / FC2_BM + 7) / 8) * 8 * splits);
     hipStream_t st = (hipStream_t)stream;
     const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
     Cand *pc = reinterpret_cast<Cand *>(pcand);
-    if (terms == 1) launch_fc2<1>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else if (terms == 2) launch_fc2<2>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else if (terms == 3) launch_fc2<3>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else launch_fc2<4>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    if (terms == 1) launch_fc2<1>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else if (terms == 2) launch_fc2<2>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else if (terms == 3) launch_fc2<3>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    else launch_fc2<4>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
     return check(hipGetLastError());
 }
 
