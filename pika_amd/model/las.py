@@ -35,6 +35,76 @@ def _phase_timer(net, dev):
     return tick
 
 
+def scoring_plan(flat, own_h, sos, eos, pad, share):
+    """Host-side plan of one scoring pass over the hypotheses `flat` (lists of labels; hypothesis i belongs to utterance
+    own_h[i]) -- everything `Net._score_flat` hands to the token loop, as whole-array numpy (the per-hypothesis Python loops
+    and dict tries this replaces were 5 of the 7 ms of host work per pass at 64 x 16 hypotheses):
+
+    ntok (n,)     decoder steps of a hypothesis = len + 1 (its tokens after <sos>, then <eos>); L = max
+    perm, tok     rows of the token loop = hypotheses by descending ntok (stable); tok (L, n): row `col` feeds
+                  [sos, h_0, h_1, ...] (padded with `pad`)
+    first, end    row `col` takes part in steps first <= t < end.  With `share`: rep[i][t] = the FIRST hypothesis of the
+                  utterance whose first t labels are flat[i][:t] (a trie per utterance, built level by level: the class of a
+                  prefix of length t+1 = (class of its first t labels, label t)); act[i] = the first t at which rep[i][t] is
+                  i itself = the step at which i leaves every earlier entry's prefix and needs a row of its own (L + 1:
+                  never -- a duplicate or a prefix of an earlier entry); first = act.  Without: first = 0
+    forks         (fork_off (L+1,), dst, src) ordered by step: row dst starts at step t > 0 from the recurrent state of row src
+                  = the row that computed its prefix so far; None without `share`
+    pair_*        the (step, hypothesis) pairs that exist, hypothesis-major: step, the ROW that computes that step for the
+                  hypothesis, and the token it predicts there (h_t, then eos)"""
+    import numpy as np
+    n = len(flat)
+    lens = np.fromiter((len(h) for h in flat), np.int64, n)
+    ntok = lens + 1
+    L = int(ntok.max())
+    labels = np.full((n, L), pad, np.int64)                 # labels[i, t] = h_t; column L - 1 only ever holds padding / eos
+    for i, h in enumerate(flat):
+        labels[i, :lens[i]] = h
+    ar = np.arange(n)
+    steps = np.arange(L)[None, :]
+    rep = act = None
+    if share:
+        own_h = np.asarray(own_h, np.int64)
+        rep = np.empty((n, L), np.int64)
+        _, first_idx, inv = np.unique(own_h, return_index=True, return_inverse=True)
+        cls = first_idx[inv.reshape(-1)]                    # class of a prefix = index of its first member
+        rep[:, 0] = cls
+        width = int(max(int(labels.max()), 0)) + 2
+        for t in range(L - 1):
+            key = cls * width + (labels[:, t] + 1)
+            done = lens <= t                                # ended before label t: a class of its own, never looked at
+            key[done] = -1 - ar[done]
+            _, first_idx, inv = np.unique(key, return_index=True, return_inverse=True)
+            cls = first_idx[inv.reshape(-1)]
+            rep[:, t + 1] = cls
+        own = (rep == ar[:, None]) & (steps <= lens[:, None])
+        act = np.where(own.any(1), own.argmax(1), L + 1).astype(np.int64)
+    perm = np.argsort(-ntok, kind="stable")
+    first = act[perm] if share else np.zeros(n, np.int64)
+    end = ntok[perm]
+    col_of = np.empty(n, np.int64)
+    col_of[perm] = ar
+    tok = np.full((L, n), pad, np.int64)
+    tok[0, :] = sos
+    if L > 1:
+        body = labels[perm, :L - 1].T                       # step t + 1 feeds label t ...
+        tok[1:, :] = np.where(np.arange(1, L)[:, None] < end[None, :], body, pad)        # ... while the row has steps left
+    forks = None
+    if share:
+        f_i = np.nonzero((act > 0) & (act <= L))[0]
+        f_t = act[f_i]
+        order = np.argsort(f_t, kind="stable")
+        fork_off = np.searchsorted(f_t[order], np.arange(L + 1)).astype(np.int32)
+        forks = (fork_off, col_of[f_i].astype(np.int32)[order], col_of[rep[f_i, f_t - 1]].astype(np.int32)[order])
+    ii, tt = np.nonzero(steps < ntok[:, None])              # hypothesis-major, steps ascending
+    rr = col_of[rep[ii, tt]] if share else col_of[ii]
+    target = labels.copy()
+    target[ar, lens] = eos
+    return {"L": L, "ntok": ntok, "perm": perm, "tok": tok, "first": first, "end": end, "forks": forks,
+            "row_steps": int(np.maximum(end - first, 0).sum()), "pair_step": tt, "pair_row": rr, "pair_target": target[ii, tt],
+            "rep": rep, "act": act}
+
+
 class LASRNNEncoder(nn.Module):
     def __init__(self, rnn_type, bidirectional, num_layers, hidden_size, dropout, input_dim):
         super().__init__()
@@ -530,68 +600,12 @@ class Net(nn.Module):
         import numpy as np
         dev = enc_out.device
         n = len(flat)
-        ntok = np.array([len(h) + 1 for h in flat], dtype=np.int64)           # decoder steps of a hypothesis
-        L = int(ntok.max())
         pad = self.tgt_embeddings.padding_idx
-        own_h = owner.cpu().numpy()
-        # ---- the prefix tries: rep[i][t] = the first hypothesis of the utterance with the prefix flat[i][:t] ----
         share = (os.environ.get("PIKA_LAS_SHARE_PREFIXES", "1") != "0" and owner is not None
                  and self.decoder._fused_ok(enc_out))
-        rep = None
-        if share:
-            # (the tries are tens of thousands of small dicts: with the cyclic collector on, their allocation triggers
-            # full collections over whatever heap the host program has -- 80 ms per pass inside a training script)
-            import gc
-            gc_was_on = gc.isenabled()
-            gc.disable()
-            rep, act = [None] * n, np.full(n, L + 1, np.int64)
-            roots = {}
-            for i, h in enumerate(flat):                    # a trie node: {token: child, -1: the entry that created it}
-                b = int(own_h[i])
-                node = roots.get(b)
-                if node is None:
-                    node = roots[b] = {-1: i}
-                r = [node[-1]]
-                a = 0 if node[-1] == i else None
-                for t, tokv in enumerate(h, 1):
-                    nxt = node.get(tokv)
-                    if nxt is None:
-                        nxt = node[tokv] = {-1: i}
-                    node = nxt
-                    w = node[-1]
-                    r.append(w)
-                    if a is None and w == i:
-                        a = t                               # from here on every node of the path is new: created by i
-                rep[i] = r
-                if a is not None:
-                    act[i] = a
-            del roots
-            if gc_was_on:
-                gc.enable()
-        perm = np.argsort(-ntok, kind="stable")
-        first = act[perm] if share else np.zeros(n, np.int64)
-        end = ntok[perm]
-        row_steps = int(np.maximum(end - first, 0).sum())
-        col_of = np.empty(n, np.int64)
-        col_of[perm] = np.arange(n)
-        tok = np.full((L, n), pad, dtype=np.int64)
-        for col, i in enumerate(perm):
-            h = flat[i]
-            k = len(h) + 1
-            tok[0, col] = sos
-            tok[1:k, col] = h
-        forks = None
-        if share:
-            f_t, f_dst, f_src = [], [], []
-            for i in range(n):
-                if 0 < act[i] <= L:
-                    f_t.append(int(act[i]))
-                    f_dst.append(int(col_of[i]))
-                    f_src.append(int(col_of[rep[i][act[i] - 1]]))
-            order = np.argsort(np.asarray(f_t, np.int64), kind="stable")
-            f_t = np.asarray(f_t, np.int64)[order]
-            fork_off = np.searchsorted(f_t, np.arange(L + 1)).astype(np.int32)
-            forks = (fork_off, np.asarray(f_dst, np.int32)[order], np.asarray(f_src, np.int32)[order])
+        plan = scoring_plan(flat, owner.cpu().numpy() if owner is not None else np.zeros(n, np.int64), sos, eos, pad, share)
+        L, ntok, perm, tok, first, end, forks, row_steps = (plan[k] for k in
+                                                            ("L", "ntok", "perm", "tok", "first", "end", "forks", "row_steps"))
         tok_d = torch.from_numpy(tok).to(dev)
         own = owner[torch.from_numpy(perm).to(owner.device)]
         _tick = _tick or (lambda name: None)
@@ -599,14 +613,8 @@ class Net(nn.Module):
         out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, spans=(first, end), forks=forks)
         _tick("token loop (%d tokens, %d hypotheses, %d pairs, %d row steps)" % (L, n, int(ntok.sum()), row_steps))
         self.last_pass = {"pairs": int(ntok.sum()), "row_steps": row_steps, "shared": bool(share)}
-        # the (step, hypothesis) pairs that exist, and the (step, row) each one reads
-        tt = np.concatenate([np.arange(k) for k in ntok])
-        ii = np.repeat(np.arange(n), ntok)
-        if share:
-            rr = col_of[np.concatenate([np.asarray(r, np.int64) for r in rep])]
-        else:
-            rr = col_of[ii]
-        tgt = np.concatenate([np.asarray(list(h) + [eos], np.int64) for h in flat])
+        # the (step, hypothesis) pairs that exist, the (step, row) each one reads, the token each one predicts
+        tt, rr, tgt = plan["pair_step"], plan["pair_row"], plan["pair_target"]
         key, inv = np.unique(tt * n + rr, return_inverse=True)                  # distinct (step, row) pairs
         rows = out[torch.from_numpy(key // n).to(dev), torch.from_numpy(key % n).to(dev)]         # (R, H)
         logp = torch.log_softmax(scale * ops.linear(rows, self.dec_proj.weight, self.dec_proj.bias), dim=-1)

@@ -149,3 +149,84 @@ def test_incremental_attention_kernel(hip_device, rows, L, d, heads):
     sc = torch.matmul(qh, Kp.permute(0, 2, 3, 1)).masked_fill(~valid.view(rows, 1, 1, L), -1e18)
     want = torch.matmul(torch.softmax(sc, dim=-1), Vp.permute(0, 2, 1, 3)).reshape(rows, d)
     assert (out.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def _results_loop_form(self):
+    """The extraction spelled out per utterance as beam_transducer.py:196-243 / transducer_decoder.py:204-217 do it (what
+    BeamState.results was before it went to whole-array form): sort_finished(minimum=n_best) + get_hyp for every utterance
+    (beam_transducer.py:196-243, transducer_decoder.py:204-217).  Host side: the search is
+    over, only K-sized lists remain."""
+    import numpy as np
+    S = self.steps
+    ys = self.ys_hist[:S + 1].cpu().numpy()
+    ks = self.ks_hist[:S].cpu().numpy()
+    fin_n = self.fin_n.cpu().clamp(max=self.fin_cap - 1).numpy()
+    nmax = int(fin_n.max()) if self.B else 0
+    fin_score, fin_step, fin_k = (t[:, :nmax].cpu().numpy() for t in
+                                  (self.fin_score, self.fin_step, self.fin_k))
+    scores = self.scores.cpu().numpy()
+    B, nb = self.B, self.n_best
+    sel_score = np.zeros((B, nb), np.float32)
+    sel_step = np.zeros((B, nb), np.int64)
+    sel_k = np.zeros((B, nb), np.int64)
+    for b in range(B):
+        n = int(fin_n[b])
+        fin = [(fin_score[b, i], int(fin_step[b, i]), int(fin_k[b, i])) for i in range(n)]
+        while len(fin) < nb:                                              # :202-210 (i stays 0)
+            fin.append((scores[b, 0], S, 0))
+        fin.sort(key=lambda a: -float(a[0]))                              # :212 (stable)
+        for j, (s, t, k) in enumerate(fin[:nb]):
+            sel_score[b, j], sel_step[b, j], sel_k[b, j] = s, t, k
+    # get_hyp (:234-243) for all B*n_best entries at once: walk the back-pointers from each
+    # entry's own finishing step down to 0
+    smax = int(sel_step.max()) if B else 0
+    out = np.full((B, nb, max(smax, 1)), self.blk, np.int64)
+    kcur = sel_k.copy()
+    brow = np.arange(B)[:, None]
+    for j in range(smax - 1, -1, -1):
+        act = j < sel_step
+        out[:, :, j] = np.where(act, ys[j + 1][brow, kcur], out[:, :, j])
+        kcur = np.where(act, ks[j][brow, kcur], kcur)
+    preds, out_scores = [], []
+    for b in range(B):
+        # hyp[:-1]: strip the trailing eos (:214); elements expose .item() like the
+        # reference's 0-dim tensors (decode_transducer.py:139)
+        preds.append([list(out[b, j, :max(int(sel_step[b, j]) - 1, 0)]) for j in range(nb)])
+        out_scores.append([torch.tensor(float(sel_score[b, j])) for j in range(nb)])
+    return preds, out_scores
+
+
+def _fake_search_state(seed, B=9, K=6, nb=6, S=57, V=40):
+    """A finished search's device state with everything the extraction has to cope with: utterances with fewer finished
+    entries than n_best (none at all, too), tied scores, entries that finished at the last step."""
+    g = torch.Generator().manual_seed(seed)
+    o = SimpleNamespace(steps=S, B=B, n_best=nb, blk=0, fin_cap=K * S + 1)
+    o.ys_hist = torch.randint(0, V, (S + 3, B, K), generator=g)
+    o.ks_hist = torch.randint(0, K, (S + 3, B, K), generator=g)
+    o.fin_n = torch.randint(0, 4 * nb, (B,), generator=g)
+    o.fin_n[0], o.fin_n[1], o.fin_n[2] = 0, 2, nb
+    o.fin_score = -torch.rand(B, o.fin_cap, generator=g) * 30
+    o.fin_score[3, 4] = o.fin_score[3, 1]
+    o.fin_score[1, 0] = o.fin_score[1, 1]
+    o.fin_step = torch.randint(1, S + 1, (B, o.fin_cap), generator=g)
+    o.fin_step[4, :3] = S
+    o.fin_k = torch.randint(0, K, (B, o.fin_cap), generator=g)
+    o.scores = -torch.rand(B, K, generator=g) * 30
+    o.scores[1, 0] = o.fin_score[1, 0]                          # a fill-up entry tied with a finished one
+    return o
+
+
+def test_results_extraction_equals_the_per_utterance_form():
+    """BeamState.results (sorting, fill-ups and back-pointer walks on whole arrays) returns what the per-utterance loops
+    return: same hypotheses (blanks included), same scores in the same order, elements with .item()."""
+    from pika_amd.decoder.beam_search import BeamState
+    for seed in range(6):
+        o = _fake_search_state(seed)
+        want_p, want_s = _results_loop_form(o)
+        got_p, got_s = BeamState.results(o)
+        assert len(got_p) == o.B and all(len(r) == o.n_best for r in got_p)
+        for wr, gr in zip(want_p, got_p):
+            for wh, gh in zip(wr, gr):
+                assert isinstance(gh, list) and [int(e) for e in wh] == [e.item() for e in gh]
+        for wr, gr in zip(want_s, got_s):
+            assert [float(e) for e in wr] == [e.item() for e in gr]
