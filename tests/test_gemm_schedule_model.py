@@ -142,3 +142,40 @@ def test_persistent_tile_walk_covers_every_tile_once():
             assert len(seen) == ntiles and len(set(seen)) == ntiles, (nx, ny, wgs)
             # all tiles of one workgroup stay on its XCD's run (slots share v % 8)
             assert grid % 8 == 0 or grid == ntiles
+
+
+# ---- the register-staged product loop of the search step (csrc/decode_step.hip, Core<>::run) ------------------------
+# A pieces: global -> registers araw[s & 1] (requested TWO steps ahead) -> converted into LDS buffer s & 1 at the end of step
+# s - 1; W fragments: requested at the start of step s - 1 into `wnext`, moved into `wreg` at its end.  The tail requests
+# clamp to the last step instead of branching.  The model replays the statement order of the loop with tagged buffers.
+def _core_loop(steps, a_ahead=2):
+    log = []
+    araw, lds, wreg, wnext = [None, None], [None, None], None, None
+    clamp = lambda s: min(s, steps - 1)
+    araw[0] = ("A", 0)
+    wreg = ("W", 0)
+    lds[0] = araw[0]                                    # stage_a(0, araw[0])
+    araw[1] = ("A", clamp(1))
+    for st in range(steps):                             # (barrier in front of every step)
+        P = st & 1
+        if a_ahead == 2:
+            assert lds[P ^ 1] is None or lds[P ^ 1][1] <= st, "a request must not clobber registers still to be staged"
+            staged_from = araw[P ^ 1]                   # what the end of this step converts: requested during step st - 1
+            araw[P] = ("A", clamp(st + 2))
+        else:                                           # the one-step-ahead form (same registers requested and staged in a step)
+            araw[P ^ 1] = ("A", clamp(st + 1))
+            staged_from = araw[P ^ 1]
+        wnext = ("W", clamp(st + 1))
+        log.append((st, lds[P], wreg))                  # the MFMAs of step st read LDS buffer P and wreg
+        lds[P ^ 1] = staged_from                        # buffer P ^ 1: last read in step st - 1, behind a barrier
+        wreg = wnext
+    return log
+
+
+def test_search_step_product_loop_feeds_every_step_its_own_operands():
+    for steps in range(1, 12):
+        for ahead in (1, 2):
+            log = _core_loop(steps, ahead)
+            assert [st for st, _, _ in log] == list(range(steps))
+            for st, a, w in log:
+                assert a == ("A", st) and w == ("W", st), (steps, ahead, st, a, w)
