@@ -583,7 +583,7 @@ class Net(nn.Module):
             out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
         return out, None, None, enc_out
 
-    def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None):
+    def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None):
         """log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
         owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).
 
@@ -603,7 +603,9 @@ class Net(nn.Module):
         pad = self.tgt_embeddings.padding_idx
         share = (os.environ.get("PIKA_LAS_SHARE_PREFIXES", "1") != "0" and owner is not None
                  and self.decoder._fused_ok(enc_out))
-        plan = scoring_plan(flat, owner.cpu().numpy() if owner is not None else np.zeros(n, np.int64), sos, eos, pad, share)
+        if owner_host is None:                              # (the batch entry hands over the host copy it built the tensor from)
+            owner_host = owner.cpu().numpy() if owner is not None else np.zeros(n, np.int64)
+        plan = scoring_plan(flat, owner_host, sos, eos, pad, share)
         L, ntok, perm, tok, first, end, forks, row_steps = (plan[k] for k in
                                                             ("L", "ntok", "perm", "tok", "first", "end", "forks", "row_steps"))
         tok_d = torch.from_numpy(tok).to(dev)
@@ -655,9 +657,12 @@ class Net(nn.Module):
         _tick = _phase_timer(self, dev)
         enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
         _tick("encoder")
-        owner = torch.tensor([inv[b].item() for b in range(B) for _ in hyps[b]], dtype=torch.long, device=dev)
+        import numpy as np
+        owner_h = np.repeat(inv.numpy(), [len(hyps[b]) for b in range(B)]).astype(np.int64)
+        owner = torch.from_numpy(owner_h).to(dev)
         flat = [list(h) for b in range(B) for h in hyps[b]]
-        scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick)
+        scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick,
+                                  owner_host=owner_h)
         self.encoder.check_status()
         res, i = [], 0
         for b in range(B):
