@@ -104,7 +104,7 @@ def train_step_workload(args, R_):
     if os.environ.get("PIKA_FUSED_OPTIM", "1") != "0":
         fused_optim.install()   # what `python -m pika_amd.launch <training script>` installs: the script's own
     #                             clip_grad_norm_(inf) / optim.SGD(nesterov) calls below then run as 3 HIP launches
-    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
+    opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type=getattr(args, "pred_net", "transformer"), brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,
                           embd_dim=100, padding_idx=V)
     torch.manual_seed(777)      # identical initial replicas; BMUF broadcasts rank 0's anyway
