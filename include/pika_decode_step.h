@@ -74,6 +74,13 @@ typedef struct {
                                 r = rowlist[*rowoff_dev + e] of A, res, node, crow, t_idx and C (the rows of a launch are
                                 then any subset of the buffers' rows; buffers stay where they are)          */
     const int *rowoff_dev;   /* device int32 offset into rowlist, or NULL (0)                               */
+    const float *ln_gamma;   /* NULL, or: the rows of A are layer-normalised over their K columns on the way in
+                                (reference onmt LayerNorm in front of every projection of the prediction net,
+                                trainer/model/rnnt_conv_transformer_lm.py:59-80): A' = (A - mean) * rsqrt(var + ln_eps) *
+                                ln_gamma + ln_beta, biased variance, two passes.  Needs K % 32 == 0, K <= 1024,
+                                16-byte aligned ln_gamma / ln_beta (K floats each); PIKA_EINVAL otherwise           */
+    const float *ln_beta;
+    float ln_eps;
 } pika_dgemm_t;
 int pika_dgemm(const pika_dgemm_t *p, void *stream);
 
@@ -156,10 +163,18 @@ int pika_dstep_lstm_cell(const float *gates, long long ldg, float *state, long l
  *   pmax[r*splits+s] = max_c x,  psum[...] = sum_c exp(x - pmax),  x = sm_scale * (h.W^T + bias)[r, c]
  *   pcand[(r*splits+s)*topk + j] = {x, c} of the j-th largest x of the range (ties: lowest c), j < topk <= 64;
  *   ranges with fewer than topk columns are filled with {-inf, 0x7fffffff}. */
+#define PIKA_DFC2_COLS 192        /* columns per range (= pika_dfc2_cols_per_split()) */
 int pika_dfc2_splits(int V);
 int pika_dfc2_cols_per_split(void);
 int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K,
                    int terms, float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream);
+
+/* The same product with the row statistics only: pmax / psum as above, and the scaled values x themselves go to
+ * logits (rows, ldl) f32, ldl >= splits * cols (columns [V, splits*cols) are written as -inf).  pika_beam_advance_logits
+ * then finds a row's K best with one thresholded pass over the row (below): cheaper than selecting K per range here
+ * (27 ranges x 16 candidates per row for 16 winners at V = 5000, and more than half of this launch's time). */
+int pika_dfc2_logits(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K,
+                     int terms, float sm_scale, float *pmax, float *psum, float *logits, long long ldl, void *stream);
 
 /* ---- advance from partials ---------------------------------------------------------------------------------
  * As pika_beam_advance (pika_decode.h) with the row log-softmax / top-K taken from the partials above, plus:
@@ -179,6 +194,21 @@ int pika_beam_advance_partials(const float *pmax, const float *psum, const void 
                                int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
                                int blk, int beam_prune, int n_best, int *stop, long long *max_hyp, int *sync,
                                void *stream);
+
+/* As pika_beam_advance_partials with the candidates taken from the scaled logits of pika_dfc2_logits: per row, the K-th
+ * largest of the row's `splits` range maxima bounds the row's K-th largest value from below; one pass over the row keeps
+ * the values at or above the bound (a few dozen of V), and the K best of those are the row's K best (same tie rule: lowest
+ * column first).  Rows whose survivors outnumber the 256-entry pool (many near-equal values; splits < K) have the bound
+ * raised by bisection with counting passes.  Results identical to pika_beam_advance_partials / pika_beam_advance. */
+int pika_beam_advance_logits(const float *pmax, const float *psum, const float *logits, long long ldl, int splits,
+                             float *scores, const float *lm_scores, float lm_scale, long long *y,
+                             long long *t_idx, const long long *num_frames, const long long *max_len,
+                             long long *hyp, long long *hyp_len, int L, long long *ks_hist,
+                             long long *ys_hist, long long *step_t, unsigned char *eos_top,
+                             float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
+                             int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
+                             int blk, int beam_prune, int n_best, int *stop, long long *max_hyp, int *sync,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -113,6 +113,10 @@ SIGNATURES = {
     "pika_beam_advance_partials": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                         _vp, _vp, _vp, _vp]),
+    "pika_dfc2_logits": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _vp, _ll, _vp]),
+    "pika_beam_advance_logits": (_i, [_vp, _vp, _vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                      _vp, _vp, _vp, _vp]),
     # include/pika_optim.h
     "pika_multi_absmax": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "pika_multi_scale_by_clip": (_i, [_vp, _vp, _vp, _vp, _i, _vp, ctypes.c_float, _vp]),

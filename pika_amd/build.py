@@ -15,6 +15,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libpika_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+FLAGS += os.environ.get("PIKA_HIPCC_EXTRA", "").split()      # profiling builds (-DPIKA_ADV_TRACE ...): build with --force
 # Per-file code-generation options.  attn.hip: MFMA results in VGPRs instead of AGPRs -- the online softmax reads every
 # score and rescales every context accumulator each key tile, so the AGPR form costs ~80 v_accvgpr_read/write per tile
 # per wave in kernels that are bound by VALU issue (419 -> 343 instructions in the forward loop, same arithmetic).

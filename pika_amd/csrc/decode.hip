@@ -31,6 +31,10 @@ __device__ inline bool better(float va, int ia, float vb, int ib) {
     return va > vb || (va == vb && ia < ib);
 }
 
+// Workgroup barrier for hand-offs through LDS only: __syncthreads() also waits for the wave's outstanding global STORES
+// (vmcnt counts them on gfx9), a ~2 us write round trip in kernels that publish results as they go.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- kernel A: one wavefront per beam row -> the row's K best candidates -----------------------
 __global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
     const float *__restrict__ logits, float sm_scale, int first, const float *__restrict__ scores,
@@ -139,6 +143,19 @@ __global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
     }
 }
 
+#ifdef PIKA_ADV_TRACE     // profiling builds only (tools/adv_trace.py): time stamps of utterance 0's wave PIKA_ADV_TRACE, summed over launches
+__device__ unsigned long long g_adv_trace[16];
+__device__ inline unsigned long long *adv_slots() { __shared__ unsigned long long s_[16]; return s_; }
+// stamps go to LDS and reach memory once, at the end (a global read-modify-write per stamp is a ~2 us round trip of its own)
+#define ADV_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (PIKA_ADV_TRACE)) { adv_slots()[k] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 9) { for (int i_ = 1; i_ < 16; ++i_) g_adv_trace[i_] += adv_slots()[i_] - adv_slots()[0]; g_adv_trace[0] += 1; } } } while (0)
+extern "C" int pika_debug_adv_trace(unsigned long long *out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_adv_trace), sizeof(g_adv_trace));
+}
+#else
+#define ADV_STAMP(k) do { } while (0)
+#endif
+
 // ---- kernel B: one workgroup per utterance: merge + the bookkeeping of `advance` -------------
 struct BeamState {
     float *scores; const float *lm_scores; float lm_scale; long long *y; long long *t_idx;
@@ -150,9 +167,13 @@ struct BeamState {
 
 // Shared scratch of one utterance (static part; hyp_l [K][L] ints and cand [K][K] live in dynamic LDS)
 struct BeamShared {
-    float lm_old[MAXK], best_v[MAXK];
-    long long t_old[MAXK], len_old[MAXK], y_old[MAXK];
+    float lm_old[MAXK], best_v[MAXK], new_score[MAXK];
+    long long t_old[MAXK], len_old[MAXK], y_old[MAXK], new_len[MAXK];
     int best_i[MAXK], fin_flag[MAXK];
+    int rank[MAXK * MAXK];
+    // per-utterance scalars, read ONCE with the slot state (every later use would be a dependent ~2 us round trip of its own)
+    long long nf, ml, fin_n, s_now;
+    int eos;
 };
 
 // Everything in this kernel is a handful of dependent memory round trips (~2 us each at this occupancy), so loops
@@ -165,6 +186,12 @@ __device__ inline void beam_load_state(const BeamState &a, BeamShared &sh, int *
         sh.t_old[tid] = a.t_idx[bk + tid];
         sh.len_old[tid] = a.hyp_len[bk + tid];
         sh.y_old[tid] = a.y[bk + tid];
+    } else if (tid == 64) {
+        sh.nf = a.num_frames[b];
+        sh.ml = a.max_len[b];
+        sh.fin_n = a.fin_n[b];
+        sh.s_now = a.step_t[0];
+        sh.eos = a.eos_top[b];
     }
     __syncthreads();
     long long ml = 0;
@@ -194,24 +221,49 @@ __device__ inline void beam_merge_and_book(const BeamState &a, BeamShared &sh, c
     const int tid = threadIdx.x, K = a.K, L = a.L, V = a.V, B = a.B;
     const long long bk = (long long)b * K;
     const int nc = K * K;
-    // rank sort of the K*K row winners, value desc / flat index asc (:119-121)
-    for (int c = tid; c < nc; c += blockDim.x) {
-        const Cand me = cand[c];
-        int rank = 0;
-        for (int j = 0; j < nc; ++j) rank += better(cand[j].v, cand[j].idx, me.v, me.idx) ? 1 : 0;
-        if (rank < K) { sh.best_v[rank] = me.v; sh.best_i[rank] = me.idx; }
+    // rank sort of the K*K row winners, value desc / flat index asc (:119-121).  The comparisons of a candidate are
+    // split over blockDim / nc threads (partial ranks meet in LDS): one thread walking all K*K candidates was a chain of
+    // 256 dependent LDS reads, the longest single item of this kernel.
+    // Every candidate against every other: 64 x 64 blocks, one per wave and turn -- the wave keeps its 64 "others" in
+    // registers and broadcasts them lane by lane through the scalar unit (v_readlane); partial ranks meet in LDS.
+    // (Reading the others from LDS, 16 waves at once, was 4 us of LDS traffic for K = 16.)
+    {
+        const int lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+        const int chunks = (nc + 63) >> 6;
+        for (int c = tid; c < nc; c += blockDim.x) sh.rank[c] = 0;
+        lds_barrier();
+        for (int task = wave; task < chunks * chunks; task += nwaves) {
+            const int cm = task % chunks, co = task / chunks;
+            const int ci = cm * 64 + lane, oi = co * 64 + lane;
+            const Cand me = cand[ci < nc ? ci : nc - 1];
+            const Cand ot = oi < nc ? cand[oi] : Cand{-INFINITY, 0x7fffffff};     // (padding: better than nothing)
+            const int no = min(64, nc - co * 64);
+            int rank = 0;
+            for (int j = 0; j < no; ++j) {
+                const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ot.v), j));
+                const int ox = __builtin_amdgcn_readlane(ot.idx, j);
+                rank += better(ov, ox, me.v, me.idx) ? 1 : 0;
+            }
+            if (rank && ci < nc) atomicAdd(&sh.rank[ci], rank);
+        }
+        lds_barrier();
+        for (int c2 = tid; c2 < nc; c2 += blockDim.x)
+            if (sh.rank[c2] < K) { sh.best_v[sh.rank[c2]] = cand[c2].v; sh.best_i[sh.rank[c2]] = cand[c2].idx; }
     }
-    __syncthreads();
+    lds_barrier();
+    ADV_STAMP(10);
 
     // ---- bookkeeping on K lanes (:125-187) ---------------------------------------------------
-    const long long s = a.step_t[0];                // steps taken before this one
+    const long long s = sh.s_now;                   // steps taken before this one
     const long long n_ys = s + 2;                   // len(next_ys) after the append
     if (tid < K) {
         const int id = sh.best_i[tid];
         const int pk = id / V, ysym = id - pk * V;
         const float ns = sh.best_v[tid] - a.lm_scale * sh.lm_old[pk];
-        const bool fin = (ysym == a.blk && sh.t_old[pk] == a.num_frames[b] - 1) || (n_ys > a.max_len[b]);
+        const bool fin = (ysym == a.blk && sh.t_old[pk] == sh.nf - 1) || (n_ys > sh.ml);
         sh.fin_flag[tid] = fin ? 1 : 0;
+        sh.new_score[tid] = ns;
+        sh.new_len[tid] = fin ? sh.len_old[tid] : sh.len_old[pk] + ((ysym != a.blk) ? 1 : 0);
         a.scores[bk + tid] = ns;
         a.prev_k_out[bk + tid] = pk;
         a.ks_hist[(s * B + b) * K + tid] = pk;
@@ -220,30 +272,35 @@ __device__ inline void beam_merge_and_book(const BeamState &a, BeamShared &sh, c
         a.y[bk + tid] = yn;
         a.ys_hist[((s + 1) * B + b) * K + tid] = yn;
         a.t_idx[bk + tid] = sh.t_old[pk];           // transducer_decoder.py:201-202
-        if (tid == 0 && yn == EOS) a.eos_top[b] = 1;
-        if (!fin) a.hyp_len[bk + tid] = sh.len_old[pk] + ((ysym != a.blk) ? 1 : 0);
+        if (tid == 0 && yn == EOS) { a.eos_top[b] = 1; sh.eos = 1; }
+        if (!fin) a.hyp_len[bk + tid] = sh.new_len[tid];
     }
-    __syncthreads();
+    lds_barrier();
+    ADV_STAMP(11);
     if (tid == 0) {                                  // finished list, slot order (:165-181)
-        long long n = a.fin_n[b];
+        long long n = sh.fin_n;
         for (int i = 0; i < K; ++i) {
             if (!sh.fin_flag[i]) continue;
             const long long pos = n < a.fin_cap - 2 ? n : a.fin_cap - 2;
-            a.fin_score[(long long)b * a.fin_cap + pos] = a.scores[bk + i];
+            a.fin_score[(long long)b * a.fin_cap + pos] = sh.new_score[i];
             a.fin_step[(long long)b * a.fin_cap + pos] = n_ys - 1;
             a.fin_k[(long long)b * a.fin_cap + pos] = i;
             ++n;
         }
         a.fin_n[b] = n;
+        sh.fin_n = n;
     }
+    ADV_STAMP(12);
     // partial hypotheses: slot i <- parent's labels (+ y), finished slots keep their own (:217-226)
-    for (int i = 0; i < K; ++i) {
+    // (a wave per slot: the slots one after the other were K dependent LDS-read chains for the whole workgroup)
+    const int lane = tid & 63, nwaves = (int)blockDim.x >> 6;
+    for (int i = tid >> 6; i < K; i += nwaves) {
         if (sh.fin_flag[i]) continue;
         const int p = sh.best_i[i] / V, ys_ = sh.best_i[i] - p * V;
         const int plen = (int)sh.len_old[p];
         long long *dst = a.hyp + (bk + i) * L;
         const int ncopy = min(L, plen + 1);          // the parent's labels + the new one; the rest is never read
-        for (int q = tid; q < ncopy; q += blockDim.x) {
+        for (int q = lane; q < ncopy; q += 64) {
             long long v = hyp_l[p * L + q];
             if (q == plen && ys_ != a.blk) v = ys_;
             dst[q] = v;
@@ -332,12 +389,93 @@ __device__ inline void select_row(const Cand *pool, int n, int K, int lane, floa
 // longest partial hypothesis and the step counter (last workgroup to arrive).
 // Launched with min(16, K) waves per utterance: every beam row gets a wave of its own for phase 1 (the four rows a wave
 // took in turn at 256 threads were four dependent chains of row-sized round trips: 70 us of a 600 us step).
+
+// logits != NULL (pika_beam_advance_logits): the partials are the row statistics only and the candidates come from the
+// scaled logits themselves -- see row_survivors.
+constexpr int POOL_CAP = 256;     // candidates a row's wave holds in LDS for the selection (select_row<4>)
+
+// The row's candidates for its K best logits WITHOUT looking at most of them twice: the K-th largest of the row's split
+// maxima (one per lane, bisected like select_row's keys) is a lower bound on the row's K-th largest logit, so ONE pass
+// over the row keeps the few dozen values at or above it (ballot prefix -> dense LDS pool, scan order = index order).
+// More than POOL_CAP survivors (rows of near-equal logits, tiny S): the bound is raised by bisection with counting passes
+// until they fit; values tied at a bound that cannot be raised any more are taken lowest index first after everything
+// above them -- what the selection would have done with them.  Returns the pool size.
+__device__ inline int row_survivors(const float *__restrict__ row, int V, int K, int S, float split_max, int lane,
+                                    Cand *pool) {
+    constexpr int COLS = PIKA_DFC2_COLS, PL = COLS / 64, SB = 16;    // SB ranges per batch of requests
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned km = lane < S ? fkey_h(split_max) : 0u;
+    unsigned lo = 0;                                            // keys >= lo: at least K of them
+    if (S >= K) {
+        // (any bound with at least K maxima at or above it will do: the first that has exactly K ends the bisection)
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned mid = lo | (1u << bit);
+            const int cnt = __popcll(__ballot(km >= mid));
+            if (cnt >= K) lo = mid;
+            if (cnt == K) break;
+        }
+    }
+    // Only the ranges whose maximum reaches the bound can hold a survivor (K of 27 as a rule): their columns in ascending
+    // order, SB ranges' requests in flight together.
+    // mode 0: collect key >= lo_; 1: count key >= lo_; 2: collect key > lo_; 3: append key == lo_ (from pool[c0])
+    auto pass = [&](unsigned lo_, int mode, int c0) {
+        int c = c0;
+        unsigned long long todo = __ballot(lane < S && km >= lo_);
+        while (todo) {
+            float t[SB][PL];
+            int sp[SB];
+            unsigned long long td = todo;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                sp[u] = td ? (int)__builtin_ctzll(td) : -1;
+                td &= td - 1;
+#pragma unroll
+                for (int q = 0; q < PL; ++q) {
+                    const int v = sp[u] * COLS + 64 * q + lane;
+                    t[u][q] = (sp[u] >= 0 && v < V) ? row[v] : -INFINITY;
+                }
+            }
+            todo = td;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                if (sp[u] < 0) break;
+#pragma unroll
+                for (int q = 0; q < PL; ++q) {
+                    const int v = sp[u] * COLS + 64 * q + lane;
+                    const unsigned key = fkey_h(t[u][q]);
+                    const bool sel = v < V && (mode == 2 ? key > lo_ : (mode == 3 ? key == lo_ : key >= lo_));
+                    const unsigned long long mk = __ballot(sel);
+                    const int pos = c + __popcll(mk & lt);
+                    if (mode != 1 && sel && pos < POOL_CAP) pool[pos] = Cand{t[u][q], v};
+                    c += __popcll(mk);
+                }
+            }
+        }
+        return c;
+    };
+    int c = pass(lo, 0, 0);
+    if (c <= POOL_CAP) return c;
+    unsigned hi = 0xffffffffu;                                  // keys >= hi: fewer than K (no key is all ones: NaN-free rows)
+    while (hi - lo > 1u) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        const int cm = pass(mid, 1, 0);
+        if (cm >= K) { lo = mid; c = cm; if (c <= POOL_CAP) break; } else hi = mid;
+    }
+    if (c <= POOL_CAP) return pass(lo, 0, 0);
+    // more than POOL_CAP values tie at key lo and fewer than K lie above it
+    const int above = pass(lo, 2, 0);
+    const int all = pass(lo, 3, above);
+    return all < POOL_CAP ? all : POOL_CAP;
+}
+
 __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__restrict__ pmax,
                                                             const float *__restrict__ psum,
                                                             const Cand *__restrict__ pcand, int S, BeamState a,
                                                             int beam_prune, int n_best, int *__restrict__ stop,
                                                             long long *__restrict__ max_hyp, int *__restrict__ sync,
-                                                            long long *__restrict__ step_rw) {
+                                                            long long *__restrict__ step_rw,
+                                                            const float *__restrict__ logits, long long ldl) {
+    ADV_STAMP(0);
     if (*stop) {                                      // a replay after the search has ended: nothing happens, and the
         if (blockIdx.x == 0 && threadIdx.x == 0) {    // FST advance of this (skipped) step must not run either
             sync[4] = 1;
@@ -356,10 +494,21 @@ __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__rest
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, L = a.L, V = a.V;
     const long long bk = (long long)b * K;
-    const long long s_now = a.step_t[0];
-    const int first = s_now == 0;
+    ADV_STAMP(1);
+    // the row statistics of this wave's (first) row: requested before the slot state, they do not depend on it
+    float pm_first = -INFINITY, ps_first = 0.f;
+    {
+        const int k0 = threadIdx.x >> 6, l0 = threadIdx.x & 63;
+        if (k0 < a.K && l0 < S) {
+            pm_first = pmax[((long long)blockIdx.x * a.K + k0) * S + l0];
+            ps_first = psum[((long long)blockIdx.x * a.K + k0) * S + l0];
+        }
+    }
     beam_load_state(a, sh, hyp_l, b);
     __syncthreads();
+    ADV_STAMP(2);
+    const long long s_now = sh.s_now;
+    const int first = s_now == 0;
     const int nwaves = blockDim.x >> 6;
     for (int k = wave; k < K; k += nwaves) {
         bool d;
@@ -369,12 +518,12 @@ __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__rest
             d = sh.y_old[k] == EOS;           // (from LDS: a global load per candidate slot here was a chain of
             const long long len = sh.len_old[k];   //  up to K dependent ~2 us round trips per row)
             if (!d && beam_prune && len > 0) {
-                for (int j = 0; j < k && !d; ++j) {
-                    if (sh.y_old[j] == EOS || sh.len_old[j] != len) continue;
-                    bool same = true;
-                    for (long long p = lane; p < len; p += 64) same &= hyp_l[j * L + p] == hyp_l[k * L + p];
-                    d = __all(same);
-                }
+                // lane j < k compares slot j with slot k, last label first (the hypotheses of a beam share their beginnings):
+                // 15 slots one after the other, each a wave-wide compare + vote, were 6 us of the last row's wave
+                bool same = lane < k && sh.y_old[lane] != EOS && sh.len_old[lane] == len;
+                for (long long p = len - 1; p >= 0 && __any(same); --p)
+                    if (same) same = hyp_l[lane * L + p] == hyp_l[k * L + p];
+                d = __any(same);
             }
         }
         Cand *out = cand + k * K;
@@ -382,16 +531,29 @@ __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__rest
             if (lane < K) out[lane] = Cand{first ? -3.0e38f : DEAD, k * V + lane};
             continue;
         }
+        ADV_STAMP(3);
         const long long pi = (bk + k) * S;
-        float m = lane < S ? pmax[pi + lane] : -INFINITY;
+        float m = k == wave ? pm_first : (lane < S ? pmax[pi + lane] : -INFINITY);
         const float mine = m;
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float s = lane < S ? psum[pi + lane] * expf(mine - m) : 0.f;
+        float s = lane < S ? (k == wave ? ps_first : psum[pi + lane]) * expf(mine - m) : 0.f;
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float logsum = logf(s);
         const float add_s = a.scores[bk + k], add_l = a.lm_scale * sh.lm_old[k];
         // all S*K partial candidates of the row into this wave's LDS slab with ONE round of loads, then K rounds of
         // "lane-local best over its strided share + wave arg-max" (no load sits on the selection's critical path)
+        if (logits) {
+            ADV_STAMP(4);
+            Cand *pool = pool_all + wave * POOL_CAP;
+            const int n = row_survivors(logits + (bk + k) * ldl, V, K, S, mine, lane, pool);
+            __builtin_amdgcn_wave_barrier();
+            ADV_STAMP(5);
+            if (n <= 64) select_row<1>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+            else if (n <= 128) select_row<2>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+            else select_row<4>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+            ADV_STAMP(6);
+            continue;
+        }
         const int n = S * K;
         Cand *pool = pool_all + wave * n;
         const Cand *src = pcand + pi * K;
@@ -409,14 +571,16 @@ __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__rest
         else if (n <= 512) select_row<8>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
         else select_row<16>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
     }
-    __syncthreads();
+    lds_barrier();
+    ADV_STAMP(7);
     beam_merge_and_book(a, sh, hyp_l, cand, b);
-    __syncthreads();
+    lds_barrier();
+    ADV_STAMP(8);
     if (tid == 0) {
         long long mh = 0;
-        for (int i = 0; i < K; ++i) mh = max(mh, a.hyp_len[bk + i]);
+        for (int i = 0; i < K; ++i) mh = max(mh, sh.new_len[i]);
         atomicMax(reinterpret_cast<unsigned long long *>(max_hyp), (unsigned long long)mh);
-        const int done = (a.eos_top[b] && a.fin_n[b] >= n_best) ? 1 : 0;   // beam_transducer.py:189-194
+        const int done = (sh.eos && sh.fin_n >= n_best) ? 1 : 0;   // beam_transducer.py:189-194
         const int par = (int)(s_now & 1);
         // ONE device-scope atomic carries both the arrival and the done count (high half): no fence, no second
         // atomic whose order would matter; the last arriver sees everybody's contribution in the value it gets back
@@ -436,6 +600,7 @@ __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__rest
             step_rw[0] = s_now + 1;
         }
     }
+    ADV_STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -742,26 +907,28 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
     return (int)hipGetLastError();
 }
 
-extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
-                                          float *scores, const float *lm_scores, float lm_scale, long long *y,
-                                          long long *t_idx, const long long *num_frames, const long long *max_len,
-                                          long long *hyp, long long *hyp_len, int L, long long *ks_hist,
-                                          long long *ys_hist, long long *step_t, unsigned char *eos_top,
-                                          float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
-                                          int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
-                                          int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
-                                          int *sync, void *stream) {
-    if (!pmax || !psum || !pcand || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
+static int advance_partials_launch(const float *pmax, const float *psum, const void *pcand, const float *logits,
+                                   long long ldl, int splits,
+                                   float *scores, const float *lm_scores, float lm_scale, long long *y,
+                                   long long *t_idx, const long long *num_frames, const long long *max_len,
+                                   long long *hyp, long long *hyp_len, int L, long long *ks_hist,
+                                   long long *ys_hist, long long *step_t, unsigned char *eos_top,
+                                   float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
+                                   int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
+                                   int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
+                                   int *sync, void *stream) {
+    if (!pmax || !psum || (!pcand && !logits) || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
         !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step || !fin_k || !fin_n ||
         !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
         return PIKA_EINVAL;
     // a wave per beam row (at most 16), fewer when their candidate pools would not fit the LDS budget
     int waves = K < 16 ? K : 16;
-    auto lds_for = [&](int w) { return (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)w * splits * K * sizeof(Cand); };
+    const int pool = logits ? POOL_CAP : splits * K;
+    auto lds_for = [&](int w) { return (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)w * pool * sizeof(Cand); };
     while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
     if (waves < 4) waves = 4;
     const size_t lds_bytes = lds_for(waves);
-    if (K > MAXK || splits > 64 || splits * K > 1024 || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
+    if (K > MAXK || splits > 64 || (!logits && splits * K > 1024) || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_partials_kernel),
@@ -772,8 +939,41 @@ extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, 
     BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
                 eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
     hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(64 * waves), lds_bytes, static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
-                       beam_prune, n_best, stop, max_hyp, sync, step_t);
+                       beam_prune, n_best, stop, max_hyp, sync, step_t, logits, ldl);
     return (int)hipGetLastError();
+}
+
+extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
+                                          float *scores, const float *lm_scores, float lm_scale, long long *y,
+                                          long long *t_idx, const long long *num_frames, const long long *max_len,
+                                          long long *hyp, long long *hyp_len, int L, long long *ks_hist,
+                                          long long *ys_hist, long long *step_t, unsigned char *eos_top,
+                                          float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
+                                          int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
+                                          int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
+                                          int *sync, void *stream) {
+    if (!pcand) return PIKA_EINVAL;
+    return advance_partials_launch(pmax, psum, pcand, nullptr, 0, splits, scores, lm_scores, lm_scale, y, t_idx, num_frames,
+                                   max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t, eos_top, fin_score, fin_step, fin_k,
+                                   fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk, beam_prune, n_best, stop, max_hyp, sync,
+                                   stream);
+}
+
+extern "C" int pika_beam_advance_logits(const float *pmax, const float *psum, const float *logits, long long ldl,
+                                        int splits,
+                                        float *scores, const float *lm_scores, float lm_scale, long long *y,
+                                        long long *t_idx, const long long *num_frames, const long long *max_len,
+                                        long long *hyp, long long *hyp_len, int L, long long *ks_hist,
+                                        long long *ys_hist, long long *step_t, unsigned char *eos_top,
+                                        float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
+                                        int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
+                                        int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
+                                        int *sync, void *stream) {
+    if (!logits || ldl < V) return PIKA_EINVAL;
+    return advance_partials_launch(pmax, psum, nullptr, logits, ldl, splits, scores, lm_scores, lm_scale, y, t_idx,
+                                   num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t, eos_top, fin_score,
+                                   fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk, beam_prune, n_best,
+                                   stop, max_hyp, sync, stream);
 }
 
 extern "C" int pika_incremental_attention(const float *q, const float *k_cache, const float *v_cache,

@@ -287,6 +287,7 @@ struct DG {   // device copy of pika_dgemm_t
     const int *m_dev; const long long *crow;
     const int *rowlist; const int *rowoff_dev;
     int Kvalid;   // K when K % 4 == 0 (columns beyond are never read), else ceil32(K) (the caller zero-pads, as the header says)
+    const float *ln_g, *ln_b; float ln_eps;     // LayerNorm of the A rows on the way in (dgemm_sk_kernel only)
 };
 
 // blockIdx -> (row tile, column group) so that a column group always lands on the same XCD (block b runs on XCD
@@ -310,6 +311,72 @@ __device__ inline bool xcd_tile_rows(int n_groups, int m_tiles, int &mg, int &ng
     mg = xcd * band + i % band;
     ng = i / band;
     return mg < m_tiles && ng < n_groups;
+}
+
+// One lane's 4 consecutive result columns [c0, c0 + 4) of buffer row r: bias, ReLU, residual, the gate, the stores.
+// pre: the additive terms were requested ahead of the product (pb = bias, or the gate's encoder halves in the order of v;
+// pr = residual) -- only for whole aligned groups of 4 columns.
+__device__ inline f32x4 dg_gate_terms(const DG &p, int r, int c0) {
+    const int H = p.N >> 1, j0 = c0 >> 1;
+    long long t = p.t_idx[r];
+    t = t < 0 ? 0 : (t > p.T - 1 ? p.T - 1 : t);
+    const float *e = p.e_all + ((long long)(r / p.beam) * p.T + t) * p.N;
+    return f32x4{e[j0], e[H + j0], j0 + 1 < H ? e[j0 + 1] : 0.f, j0 + 1 < H ? e[H + j0 + 1] : 0.f};
+}
+
+__device__ inline void dg_finish(const DG &p, int r, int c0, f32x4 v, bool pre, f32x4 pb, f32x4 pr) {
+    if (c0 >= p.N) return;
+    if (p.flags & PIKA_DG_GATE) {
+        // columns (2j, 2j+1) = (fc1, fc_gate) of joint unit j; this lane holds units c0/2 and c0/2 + 1
+        const int H = p.N >> 1, j0 = c0 >> 1;
+        const f32x4 e = pre ? pb : dg_gate_terms(p, r, c0);
+        float o[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float z1 = v[2 * u] + e[2 * u], zg = v[2 * u + 1] + e[2 * u + 1];
+            o[u] = tanhf(z1) * (1.f / (1.f + expf(-zg)));
+        }
+        float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + j0;
+        dst[0] = o[0];
+        if (j0 + 1 < H) dst[1] = o[1];
+        return;
+    }
+    const bool full = c0 + 3 < p.N;
+    if (pre) {
+        v += pb;
+    } else if (p.bias) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u < p.N) v[u] += p.bias[c0 + u];
+    }
+    if (p.flags & PIKA_DG_RELU) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+    }
+    if (pre) {
+        v += pr;
+    } else if (p.res) {
+        const float *rp = p.res + (long long)r * p.ldr + c0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u < p.N) v[u] += rp[u];
+    }
+    const long long nd = p.node ? p.node[r] : 0;
+    if ((p.flags & PIKA_DG_ROWMASK) && nd == p.skip_node) return;
+    float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + c0;
+    if (full && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u < p.N) dst[u] = v[u];
+    }
+    if (p.C2) {
+        float *d2 = p.C2 + nd * p.ldc2 + c0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u < p.N) d2[u] = v[u];
+    }
 }
 
 template <int BM, int NS>
@@ -337,57 +404,304 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
     for (int i = 0; i < BM / 16; ++i) {
         const int e_ = m0 + i * 16 + (lane & 15);
         if (e_ >= M) continue;
-        const int r = rows ? rows[e_] : e_;
-        f32x4 v = core.acc[i][0];
-        if (p.flags & PIKA_DG_GATE) {
-            // columns (2j, 2j+1) = (fc1, fc_gate) of joint unit j; this lane holds units c0/2 and c0/2 + 1
-            const int H = p.N >> 1, j0 = c0 >> 1;
-            long long t = p.t_idx[r];
-            t = t < 0 ? 0 : (t > p.T - 1 ? p.T - 1 : t);
-            const float *e = p.e_all + ((long long)(r / p.beam) * p.T + t) * p.N;
-            float o[2];
+        dg_finish(p, rows ? rows[e_] : e_, c0, core.acc[i][0], false, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+}
+
+// ---- products on few rows: one 16-column tile per workgroup, the reduction split over its waves --------------------
+// The prediction-network products of a search step run on the ~B*beam/6 rows that emitted a label: a handful of row
+// tiles.  dgemm_kernel (a wave owns 16 columns and walks the WHOLE reduction in steps of 64-128 columns) is then a chain
+// of dependent memory round trips -- m_dev, first tiles, one per step, bias, residual: 13.7 us for 170 x 512 x 512 where
+// the MFMAs need 0.2 us -- on 48 of 256 CUs.  Here a workgroup owns ONE 16-column tile of 16 MT rows and its KW waves
+// split the reduction, at most CH k-tiles of 32 each: every operand byte of a tile (the wave's W fragments straight from
+// L2 / Infinity Cache, its A pieces in MFMA fragment order straight from global memory -- 8 consecutive fp32 of one row
+// per lane, no LDS staging: nothing is shared between the waves) is requested in ONE round before the first MFMA,
+// together with the bias / residual / gate terms of the epilogue; the waves' partial tiles meet in LDS (summed in wave
+// order: the result does not depend on timing).  Many small workgroups, each with a sliver of the weight bytes, one
+// memory round trip per tile, several workgroups per CU covering each other's latency.
+// Workgroups walk the tiles of their XCD's column tiles (column tile nt lives on XCD nt % 8: the row tiles sharing a
+// slab of W find it in that XCD's L2).  LN: the rows of A are layer-normalised on the way in (the statistics need the
+// whole row: partial sums of the waves meet in LDS, two passes like ln_fwd_kernel) -- one launch instead of two.
+template <int NSM, int KW, int MT, int WN, int CH, bool LN, bool PIPE>
+__global__ __launch_bounds__(64 * KW, KW == 16 ? 4 : 2) void dgemm_sk_kernel(DG p) {
+    constexpr bool F16 = NSM == TERMS_F16X2;
+    constexpr int NS = planes_of(NSM);
+    constexpr int BMR = 16 * MT, TN = 16 * WN;              // rows / columns of a tile
+    constexpr int CQ = TN / 4, ETH = BMR * CQ;              // epilogue threads: row tid / CQ, columns [4 (tid % CQ), +4)
+    static_assert(ETH <= 64 * KW, "epilogue threads");
+    __shared__ __attribute__((aligned(16))) float red[KW][BMR][TN];
+    __shared__ float ln_part[LN ? KW : 1][BMR];
+    __shared__ __attribute__((aligned(16))) float ln_gb[LN ? 2 : 1][LN ? 1024 : 4];      // gamma | beta (K <= 1024)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the wave's k-tile range is uniform)
+    int M = p.M;
+    if (p.m_dev) M = min(M, *p.m_dev);
+    if (M <= 0) return;
+    const int m_tiles = (M + BMR - 1) / BMR;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jstride = gridDim.x >> 3;
+    const int NG = (p.NT + WN - 1) / WN;                    // column groups of WN tiles; group g lives on XCD g % 8
+    const int total = ((NG - xcd + 7) >> 3) * m_tiles;      // tiles of this XCD
+    if (j0 >= total) return;
+    const int *rows = p.rowlist ? p.rowlist + (p.rowoff_dev ? *p.rowoff_dev : 0) : nullptr;
+    const int per = (p.KT + KW - 1) / KW;                   // k-tiles per wave, taken CH at a time
+    const int kt_lo = min(wave * per, p.KT);
+    const int nk = min(p.KT, kt_lo + per) - kt_lo;          // (scalar) this wave's k-tiles: [kt_lo, kt_lo + nk)
+    const long long term_stride = (long long)p.NT * p.KT * 512;
+    const int Kcols = p.Kvalid < p.KT * 32 ? p.Kvalid : p.KT * 32;
+    const int kq = (lane >> 4) * 8;                         // this lane's 8 consecutive reduction indices inside a k-tile
+    if constexpr (LN) {
+        for (int i = tid * 4; i < p.KT * 32; i += 256 * KW) {
+            *reinterpret_cast<f32x4 *>(&ln_gb[0][i]) = *reinterpret_cast<const f32x4 *>(p.ln_g + i);
+            *reinterpret_cast<f32x4 *>(&ln_gb[1][i]) = *reinterpret_cast<const f32x4 *>(p.ln_b + i);
+        }
+    }
+
+    for (int q = j0; q < total; q += jstride) {
+        const int ti = q / m_tiles, mg = q - ti * m_tiles;
+        const int grp = xcd + 8 * ti, m0 = mg * BMR;
+        // (1) the loads other loads depend on: gather list, frame index of the gate rows -- oldest in the queue, so
+        // waiting for them later does not wait for the operands
+        const int e_row = m0 + tid / CQ, e_c0 = grp * TN + (tid % CQ) * 4;
+        const bool e_on = tid < ETH && e_row < M && e_c0 < p.N;
+        int e_r = e_on ? e_row : m0;
+        int a_r[MT];
+        bool aok[MT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float z1 = v[2 * u] + e[j0 + u], zg = v[2 * u + 1] + e[H + j0 + u];
-                o[u] = tanhf(z1) * (1.f / (1.f + expf(-zg)));
+        for (int t = 0; t < MT; ++t) {
+            const int e = m0 + t * 16 + (lane & 15);
+            aok[t] = e < M;
+            a_r[t] = aok[t] ? e : m0;                       // rows beyond M read the tile's first row (zeroed below)
+        }
+        if (rows) {
+            e_r = rows[e_r];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a_r[t] = rows[a_r[t]];
+        }
+        const bool gate = p.flags & PIKA_DG_GATE;
+        long long e_t = 0;
+        if (gate && e_on) e_t = p.t_idx[e_r];
+        const __bf16 *wb[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int nt = grp * WN + j < p.NT ? grp * WN + j : p.NT - 1;       // (a group's tail tile: computed, not stored)
+            wb[j] = p.W + ((long long)nt * p.KT + kt_lo) * 512 + lane * 8;
+        }
+        const float *ab[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) ab[t] = p.A + (long long)a_r[t] * p.lda + kt_lo * 32 + kq;
+        f32x4 acc[MT][WN], accx[MT][WN];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[t][j] = accx[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool pre = false;
+        f32x4 pb = {0.f, 0.f, 0.f, 0.f}, pr = {0.f, 0.f, 0.f, 0.f};
+        struct Req { f32x4 a[MT][CH][2]; bf16x8 w[WN][CH][NS]; };
+        // every operand of a round, at constant offsets from one base per row tile / plane (k-tiles beyond the wave's range
+        // are skipped by scalar branches; columns [Kvalid, ceil32(K)) are readable by contract, zeroed in `compute`)
+        auto issue = [&](int r0, Req &r) {
+            const int nr = nk - r0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < nr) {
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int s_ = 0; s_ < NS; ++s_)
+                            r.w[j][c][s_] = *reinterpret_cast<const bf16x8 *>(wb[j] + s_ * term_stride + (long long)(r0 + c) * 512);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        r.a[t][c][0] = *reinterpret_cast<const f32x4 *>(ab[t] + (r0 + c) * 32);
+                        r.a[t][c][1] = *reinterpret_cast<const f32x4 *>(ab[t] + (r0 + c) * 32 + 4);
+                    }
+                }
+        };
+        Req q0;
+        [[maybe_unused]] Req q1;
+        issue(0, q0);
+        {
+            // (3) the epilogue's additive terms (whole aligned groups of 4 columns; others are read in dg_finish)
+            if (e_on) {
+                if (gate) {
+                    pre = true;
+                    const int H = p.N >> 1, jj = e_c0 >> 1;
+                    const long long t = e_t < 0 ? 0 : (e_t > p.T - 1 ? p.T - 1 : e_t);
+                    const float *e = p.e_all + ((long long)(e_r / p.beam) * p.T + t) * p.N;
+                    pb = f32x4{e[jj], e[H + jj], e[jj + 1], e[H + jj + 1]};     // (N % 4 == 0: both units exist)
+                } else if (e_c0 + 3 < p.N && !(p.ldr & 3) && !(reinterpret_cast<uintptr_t>(p.res) & 15) &&
+                           !(reinterpret_cast<uintptr_t>(p.bias) & 15)) {
+                    pre = true;
+                    if (p.bias) pb = *reinterpret_cast<const f32x4 *>(p.bias + e_c0);
+                    if (p.res) pr = *reinterpret_cast<const f32x4 *>(p.res + (long long)e_r * p.ldr + e_c0);
+                }
             }
-            float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + j0;
-            dst[0] = o[0];
-            if (j0 + 1 < H) dst[1] = o[1];
-            continue;
         }
-        const bool full = c0 + 3 < p.N;
-        if (p.bias) {
+        [[maybe_unused]] float mu[MT], rs[MT];
+        {
+            if constexpr (LN) {
+                // (the host entry admits LN only when K is a multiple of 32 -- no partial k-tiles -- and one round covers it)
+                float s_[MT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (c0 + u < p.N) v[u] += p.bias[c0 + u];
-        }
-        if (p.flags & PIKA_DG_RELU) {
+                for (int t = 0; t < MT; ++t) s_[t] = 0.f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
-        }
-        if (p.res) {
-            const float *rp = p.res + (long long)r * p.ldr + c0;
+                for (int c = 0; c < CH; ++c)
+                    if (c < nk) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (c0 + u < p.N) v[u] += rp[u];
+                        for (int t = 0; t < MT; ++t)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x4 x = q0.a[t][c][h];
+                                s_[t] += (x[0] + x[1]) + (x[2] + x[3]);
+                            }
+                    }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    s_[t] += __shfl_xor(s_[t], 16);
+                    s_[t] += __shfl_xor(s_[t], 32);
+                    if (lane < 16) ln_part[wave][t * 16 + lane] = s_[t];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w_ = 0; w_ < KW; ++w_) v += ln_part[w_][t * 16 + (lane & 15)];
+                    mu[t] = v / (float)p.Kvalid;
+                    s_[t] = 0.f;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c < nk) {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const f32x4 d = q0.a[t][c][h] - mu[t];
+                                s_[t] += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                            }
+                    }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    s_[t] += __shfl_xor(s_[t], 16);
+                    s_[t] += __shfl_xor(s_[t], 32);
+                    if (lane < 16) ln_part[wave][t * 16 + lane] = s_[t];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w_ = 0; w_ < KW; ++w_) v += ln_part[w_][t * 16 + (lane & 15)];
+                    rs[t] = rsqrtf(v / (float)p.Kvalid + p.ln_eps);
+                }
+            }
         }
-        const long long nd = p.node ? p.node[r] : 0;
-        if ((p.flags & PIKA_DG_ROWMASK) && nd == p.skip_node) continue;
-        float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + c0;
-        if (full && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-            *reinterpret_cast<f32x4 *>(dst) = v;
+        auto compute = [&](int r0, const Req &r) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (c >= nk - r0) break;
+                const int k = (kt_lo + r0 + c) * 32 + kq;
+                bf16x8 afr[MT][NS];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    f32x4 x[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        x[h] = r.a[t][c][h];
+                        if constexpr (LN)
+                            x[h] = (x[h] - mu[t]) * rs[t] * *reinterpret_cast<const f32x4 *>(&ln_gb[0][k + 4 * h]) +
+                                   *reinterpret_cast<const f32x4 *>(&ln_gb[1][k + 4 * h]);
+                        if (!(aok[t] && k + 4 * h < Kcols)) x[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if constexpr (F16) {
+                        f16x8 hi, lo;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 v = x[h];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], -65504.f), 65504.f);   // saturate, never inf
+                            const f16x4 h4 = __builtin_convertvector(v, f16x4);
+                            const f16x4 l4 = __builtin_convertvector((v - __builtin_convertvector(h4, f32x4)) * LO_SCALE, f16x4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hi[4 * h + e] = h4[e]; lo[4 * h + e] = l4[e]; }
+                        }
+                        afr[t][0] = __builtin_bit_cast(bf16x8, hi);
+                        afr[t][1] = __builtin_bit_cast(bf16x8, lo);
+                    } else {
+#pragma unroll
+                        for (int s_ = 0; s_ < NS; ++s_) {
+                            bf16x8 o;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const bf16x4 b4 = __builtin_convertvector(x[h], bf16x4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[4 * h + e] = b4[e];
+                                if (s_ + 1 < NS) x[h] = x[h] - __builtin_convertvector(b4, f32x4);
+                            }
+                            afr[t][s_] = o;
+                        }
+                    }
+                }
+                if constexpr (F16) {
+                    auto f16 = [](const bf16x8 &v) { return __builtin_bit_cast(f16x8, v); };
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            accx[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f16(r.w[j][c][1]), f16(afr[t][0]), accx[t][j], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            accx[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f16(r.w[j][c][0]), f16(afr[t][1]), accx[t][j], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f16(r.w[j][c][0]), f16(afr[t][0]), acc[t][j], 0, 0, 0);
+                } else {
+                    // smallest products first, as in Core: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                    constexpr int NP = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
+                    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PA[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int pp = 6 - NP; pp < 6; ++pp)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r.w[j][c][PW[pp]], afr[t][PA[pp]], acc[t][j], 0, 0, 0);
+                }
+            }
+        };
+        if constexpr (PIPE) {
+            // rounds of CH k-tiles, the next round's requests in flight while this one multiplies
+            for (int r0 = 0; r0 < nk; r0 += 2 * CH) {
+                if (r0 + CH < nk) issue(r0 + CH, q1);
+                compute(r0, q0);
+                if (r0 + CH < nk) {
+                    if (r0 + 2 * CH < nk) issue(r0 + 2 * CH, q0);
+                    compute(r0 + CH, q1);
+                }
+            }
         } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (c0 + u < p.N) dst[u] = v[u];
+            compute(0, q0);             // (the host entry chose KW such that one round covers the reduction)
         }
-        if (p.C2) {
-            float *d2 = p.C2 + nd * p.ldc2 + c0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (c0 + u < p.N) d2[u] = v[u];
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (F16) acc[t][j] += accx[t][j] * LO_UNSCALE;
+                *reinterpret_cast<f32x4 *>(&red[wave][t * 16 + (lane & 15)][j * 16 + (lane >> 4) * 4]) = acc[t][j];
+            }
+        __syncthreads();
+        if (e_on) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(&red[0][tid / CQ][(tid % CQ) * 4]);
+#pragma unroll
+            for (int w_ = 1; w_ < KW; ++w_) v += *reinterpret_cast<const f32x4 *>(&red[w_][tid / CQ][(tid % CQ) * 4]);
+            dg_finish(p, e_r, e_c0, v, pre, pb, pr);
         }
+        if (q + jstride < total) __syncthreads();           // `red` is rewritten by the next tile
     }
 }
 
@@ -617,6 +931,7 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
 
 // ---- fc2 + log-sum-exp partials + top-K partials --------------------------------------------------------------
 constexpr int FC2_WN = 3, FC2_KS = 2, FC2_COLS = 4 * FC2_WN * 16;   // 192 columns per split
+static_assert(FC2_COLS == PIKA_DFC2_COLS, "pika_decode_step.h");
 struct Cand { float v; int idx; };
 
 __device__ inline bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -636,12 +951,18 @@ __host__ __device__ constexpr size_t FC2_LDS_MAIN() {      // operand staging bu
 // FC2_BM rows per workgroup: 32, or 64 when the launch has more than 512 rows -- at B * beam = 1024 rows that is 16 x 27 =
 // 432 workgroups, all resident at once (two per CU), instead of 864 in two rounds, and every slab of W is read by half as
 // many workgroups.  The logits slab overlays the operand staging buffers (dead after the product loop's last barrier).
-template <int NS, int FC2_BM>
+// CANDS = false: the row statistics only, and the scaled logits themselves go to `logits` (row pitch ldl >= splits *
+// FC2_COLS, columns >= V hold -inf): the advance then picks a row's K best with ONE thresholded pass over the row (the
+// K-th largest of the row's split maxima bounds its K-th largest logit from below: a few dozen survivors of 5000) instead
+// of this kernel bisecting every (row, split) pair for its own K best -- 27 x 16 candidates per row for 16 winners, and
+// more than half of this kernel's time.
+template <int NS, int FC2_BM, bool CANDS>
 __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_topk_kernel(const float *__restrict__ h, long long ldh,
                                                         const __bf16 *__restrict__ W, const float *__restrict__ bias,
                                                         int rows, int V, int NT, int KT, float sm_scale, int topk,
                                                         int splits, float *__restrict__ pmax,
-                                                        float *__restrict__ psum, Cand *__restrict__ pcand, int Kvalid) {
+                                                        float *__restrict__ psum, Cand *__restrict__ pcand, int Kvalid,
+                                                        float *__restrict__ logits, long long ldl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
     core_t core;
@@ -711,6 +1032,17 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
 #pragma unroll
             for (int g = 0; g < RG; ++g) s[g] += __shfl_xor(s[g], o);
         if (rr == 0) CORE_STAMP(37, 2);
+        if constexpr (!CANDS) {
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                const int r = m0 + lr0 + g;
+                if (r >= rows) break;                 // (wave-uniform)
+                if (lane == 0) { pmax[(long long)r * splits + sp] = m[g]; psum[(long long)r * splits + sp] = s[g]; }
+#pragma unroll
+                for (int q = 0; q < PL; ++q) logits[(long long)r * ldl + sp * FC2_COLS + lane + 64 * q] = x[g][q];
+            }
+            continue;
+        }
         // The topk largest WITHOUT cross-lane shuffles (a wave arg-max is 12 dependent LDS-crossbar permutes, and
         // topk of them per row made this epilogue 4x longer than the product itself): bisect the order-preserving
         // integer image of the values for the topk-th largest key with ballots + popcounts (scalar unit), then every
@@ -785,10 +1117,17 @@ void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
 
 template <int NS, int BM>
 void launch_fc2_bm(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
-                   int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K) {
+                   int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K,
+                   float *logits, long long ldl) {
     constexpr size_t lds = FC2_LDS_MAIN<NS, BM>() + FC2_COLS * 4;
-    dfc2_topk_kernel<NS, BM><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits,
-                                                                 pmax, psum, pc, (K & 3) ? KT * 32 : K);
+    if (logits)
+        dfc2_topk_kernel<NS, BM, false><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk,
+                                                                            splits, pmax, psum, pc, (K & 3) ? KT * 32 : K,
+                                                                            logits, ldl);
+    else
+        dfc2_topk_kernel<NS, BM, true><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk,
+                                                                           splits, pmax, psum, pc, (K & 3) ? KT * 32 : K,
+                                                                           nullptr, 0);
 }
 
 int fc2_bm(int rows) {
@@ -801,11 +1140,12 @@ int fc2_bm(int rows) {
 
 template <int NS>
 void launch_fc2(hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
-                int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K) {
+                int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K,
+                float *logits, long long ldl) {
     const int bm = fc2_bm(rows);
     const unsigned grid = (unsigned)((((rows + bm - 1) / bm + 7) / 8) * 8 * splits);
-    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
+    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
+    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
 }
 
 }  // namespace
@@ -832,10 +1172,41 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     if ((q->lda & 3) || (reinterpret_cast<uintptr_t>(q->A) & 15)) return PIKA_EINVAL;
     if ((q->flags & PIKA_DG_GATE) && (!q->e_all || !q->t_idx || q->T <= 0 || q->beam <= 0 || (q->N & 3))) return PIKA_EINVAL;
     if (((q->flags & PIKA_DG_ROWMASK) || q->C2) && !q->node) return PIKA_EINVAL;
+    const bool ln = q->ln_gamma != nullptr;
+    if (ln && (!q->ln_beta || (q->K & 31) || q->K > 1024 || ((reinterpret_cast<uintptr_t>(q->ln_gamma) |
+                                                               reinterpret_cast<uintptr_t>(q->ln_beta)) & 15)))
+        return PIKA_EINVAL;
     DG p{q->A, q->lda, reinterpret_cast<const __bf16 *>(q->W), q->bias, q->res, q->ldr, q->C, q->ldc, q->C2, q->ldc2,
          q->node, q->skip_node, q->e_all, q->t_idx, q->T, q->beam, q->M, q->N, (q->N + 15) / 16, (q->K + 31) / 32, q->flags,
-         q->m_dev, q->crow, q->rowlist, q->rowoff_dev, (q->K & 3) ? ((q->K + 31) / 32) * 32 : q->K};
+         q->m_dev, q->crow, q->rowlist, q->rowoff_dev, (q->K & 3) ? ((q->K + 31) / 32) * 32 : q->K,
+         q->ln_gamma, q->ln_beta, q->ln_eps};
     hipStream_t st = (hipStream_t)stream;
+    // Few rows expected (a compact row list: m_dev / rowlist; or M itself small): the split-reduction kernel, one
+    // 16-column tile of 32 rows per workgroup.  PIKA_DGEMM_SK=0 / 1 forces the choice (A/B runs).
+    static const int sk_env = [] { const char *e = getenv("PIKA_DGEMM_SK"); return e ? atoi(e) : -1; }();
+    const bool sk = ln || (sk_env >= 0 ? sk_env != 0 : (q->m_dev != nullptr || q->rowlist != nullptr || q->M <= 256));
+    // 4 waves per workgroup take K <= 512 in ONE request round, 8 waves K <= 1024; beyond (K up to 4096) 8 waves in
+    // rounds of 4 k-tiles.  Wide products (N >= 1024) take 32-column tiles: all tiles of a ~170-row launch resident at once.
+    const bool sk_fits = p.KT <= 128 && !(ln && p.KT > 32);
+    if (ln && !sk_fits) return PIKA_EINVAL;
+    if (sk && sk_fits) {
+        const int kw = p.KT <= 16 ? 4 : 8, wn = q->N >= 1024 ? 2 : 1;
+        const long long tiles = (long long)((q->M + 31) / 32) * ((p.NT + wn - 1) / wn);
+        // workgroups resident at once per XCD (32 CUs): 2 per CU of 256 threads, 1 of 512
+        const long long cap8 = kw == 4 ? 64 : 32;
+        const unsigned grid = (unsigned)(8 * (tiles / 8 + 1 < cap8 ? tiles / 8 + 1 : cap8));
+#define PIKA_SK(NS, KW, WN, LN) do { if (p.KT <= 4 * KW) dgemm_sk_kernel<NS, KW, 2, WN, 4, LN, false><<<dim3(grid), dim3(64 * KW), 0, st>>>(p); \
+                                     else dgemm_sk_kernel<NS, KW, 2, WN, 2, false, true><<<dim3(grid), dim3(64 * KW), 0, st>>>(p); } while (0)
+#define PIKA_SK_T(KW, WN, LN) do { if (q->terms == 1) PIKA_SK(1, KW, WN, LN); else if (q->terms == 2) PIKA_SK(2, KW, WN, LN); \
+                                   else if (q->terms == 3) PIKA_SK(3, KW, WN, LN); else PIKA_SK(4, KW, WN, LN); } while (0)
+#define PIKA_SK_W(KW, LN) do { if (wn == 2) PIKA_SK_T(KW, 2, LN); else PIKA_SK_T(KW, 1, LN); } while (0)
+        if (ln) { if (kw == 4) PIKA_SK_W(4, true); else PIKA_SK_W(8, true); }
+        else { if (kw == 4) PIKA_SK_W(4, false); else PIKA_SK_W(8, false); }
+#undef PIKA_SK_W
+#undef PIKA_SK_T
+#undef PIKA_SK
+        return check(hipGetLastError());
+    }
     const int n_groups = (p.NT + 3) / 4;
     // enough workgroups to cover the chip: 32-row tiles unless 64-row tiles already give > 256 of them
     const bool big = (long long)((q->M + 63) / 64) * n_groups >= 512;
@@ -903,20 +1274,34 @@ int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, floa
 int pika_dfc2_splits(int V) { return (V + FC2_COLS - 1) / FC2_COLS; }
 int pika_dfc2_cols_per_split(void) { return FC2_COLS; }
 
+static int dfc2_launch(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
+                       float sm_scale, int topk, float *pmax, float *psum, void *pcand, float *logits, long long ldl,
+                       void *stream) {
+    const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
+    Cand *pc = reinterpret_cast<Cand *>(pcand);
+    if (terms == 1) launch_fc2<1>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
+    else if (terms == 2) launch_fc2<2>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
+    else if (terms == 3) launch_fc2<3>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
+    else launch_fc2<4>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
+    return check(hipGetLastError());
+}
+
 int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
                    float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream) {
     if (!h || !W || !pmax || !psum || !pcand || rows <= 0 || V <= 0 || K <= 0 || topk < 1 || topk > 64 || terms < 1 ||
         terms > 4 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
         return PIKA_EINVAL;
-    const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
-    hipStream_t st = (hipStream_t)stream;
-    const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
-    Cand *pc = reinterpret_cast<Cand *>(pcand);
-    if (terms == 1) launch_fc2<1>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else if (terms == 2) launch_fc2<2>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else if (terms == 3) launch_fc2<3>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    else launch_fc2<4>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K);
-    return check(hipGetLastError());
+    return dfc2_launch(h, ldh, W, bias, rows, V, K, terms, sm_scale, topk, pmax, psum, pcand, nullptr, 0, stream);
+}
+
+int pika_dfc2_logits(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
+                     float sm_scale, float *pmax, float *psum, float *logits, long long ldl, void *stream) {
+    if (!h || !W || !pmax || !psum || !logits || rows <= 0 || V <= 0 || K <= 0 || terms < 1 || terms > 4 || (ldh & 3) ||
+        (reinterpret_cast<uintptr_t>(h) & 15) || ldl < (long long)pika_dfc2_splits(V) * FC2_COLS)
+        return PIKA_EINVAL;
+    return dfc2_launch(h, ldh, W, bias, rows, V, K, terms, sm_scale, 1, pmax, psum, nullptr, logits, ldl, stream);
 }
 
 }  // extern "C"

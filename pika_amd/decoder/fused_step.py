@@ -32,7 +32,8 @@ class DGemm(ctypes.Structure):
     _fields_ = [("A", _vp), ("lda", _ll), ("W", _vp), ("bias", _vp), ("res", _vp), ("ldr", _ll), ("C", _vp), ("ldc", _ll),
                 ("C2", _vp), ("ldc2", _ll), ("node", _vp), ("skip_node", _ll), ("e_all", _vp), ("t_idx", _vp),
                 ("T", _i), ("beam", _i), ("M", _i), ("N", _i), ("K", _i), ("terms", _i), ("flags", _i),
-                ("m_dev", _vp), ("crow", _vp), ("rowlist", _vp), ("rowoff_dev", _vp)]
+                ("m_dev", _vp), ("crow", _vp), ("rowlist", _vp), ("rowoff_dev", _vp),
+                ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", ctypes.c_float)]
 
 
 class DPrep(ctypes.Structure):
@@ -77,7 +78,7 @@ def supported(model, beam, K):
     heads = dec.transformer[0].self_attn.head_count
     dh = d // heads
     g = dh // 4
-    return (len(dec.conv) <= MAX_LAYERS and d % 4 == 0 and d <= 1024 and 256 % (d // 4) == 0 and dh % 4 == 0
+    return (len(dec.conv) <= MAX_LAYERS and d % 32 == 0 and d <= 1024 and 256 % (d // 4) == 0 and dh % 4 == 0
             and 1 <= g <= 64 and (g & (g - 1)) == 0)
 
 
@@ -132,7 +133,9 @@ class FusedSearch(object):
         self.splits = lib.pika_dfc2_splits(self.V)
         self.pmax = torch.empty(R * self.splits, **f32)
         self.psum = torch.empty(R * self.splits, **f32)
-        self.pcand = torch.empty(R * self.splits * K * 8, dtype=torch.uint8, device=dev)
+        # the scaled logits of a step, (rows, splits * columns per split): the advance reads each row once, thresholded
+        self.ldl = self.splits * lib.pika_dfc2_cols_per_split()
+        self.logits = torch.empty(R, self.ldl, **f32)
         H = self.H
         wp = torch.cat((model.fc1.weight[:, H:], model.fc_gate.weight[:, H:]), dim=0)   # (2H, H) prediction halves
         self.wp = PackedWeight(wp, self.terms, interleave2=True)
@@ -166,15 +169,12 @@ class FusedSearch(object):
         self.pos = torch.zeros(R, **i64)
         # activations of one step
         self.y_conv = torch.empty(R, d, **f32)
-        self.ln = torch.empty(R, d, **f32)
         self.kvq = torch.empty(R, 3 * d, **f32)
         self.ctx = torch.empty(R, d, **f32)
         self.o = torch.empty(R, d, **f32)
         dff = net.transformer[0].feed_forward.w_1.weight.shape[0]
         self.hmid = torch.empty(R, dff, **f32)
         self.xfin = torch.empty(R, d, **f32)
-        self.mean = torch.empty(R, **f32)
-        self.rstd = torch.empty(R, **f32)
         # weights, packed once
         t = self.terms
         self.layers = []
@@ -197,9 +197,11 @@ class FusedSearch(object):
 
     # ---- launches ------------------------------------------------------------------------------------------
     def _gemm(self, A, lda, W, bias, C, ldc, M, relu=False, res=None, ldr=0, C2=None, ldc2=0, rowmask=False, gate=False,
-              m_dev=None, crow=None):
+              m_dev=None, crow=None, ln=None):
         g = DGemm()
         g.m_dev, g.crow = _ptr(m_dev), _ptr(crow)
+        if ln is not None:      # LayerNorm of the A rows inside the launch
+            g.ln_gamma, g.ln_beta, g.ln_eps = ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)
         g.A, g.lda, g.W, g.bias = _ptr(A), lda, W.buf.data_ptr(), _ptr(bias)
         g.res, g.ldr, g.C, g.ldc = _ptr(res), ldr, _ptr(C), ldc
         g.C2, g.ldc2 = _ptr(C2), ldc2
@@ -209,28 +211,21 @@ class FusedSearch(object):
         g.flags = (DG_RELU if relu else 0) | (DG_GATE if gate else 0) | (DG_ROWMASK if rowmask else 0)
         _lib.check(_lib.lib().pika_dgemm(ctypes.byref(g), _stream()), "pika_dgemm(M=%d,N=%d,K=%d)" % (M, W.N, W.K))
 
-    def _layer_norm(self, x, ln, y):
-        rows, C = x.shape
-        _lib.check(_lib.lib().pika_layer_norm_fwd(x.data_ptr(), rows, C, ln.weight.data_ptr(), ln.bias.data_ptr(),
-                                                  float(ln.eps), y.data_ptr(), 0, None, self.mean.data_ptr(),
-                                                  self.rstd.data_ptr(), _stream()), "pika_layer_norm_fwd")
-
     def _prednet(self, anc_dst, state_dst, count):
         """All layers at the new position of the `count` (device int32) rows of the compact list; `rowmap` / `node` /
         `pos` / A[l] were prepared (slot order).  Only these rows' states change (:139-171)."""
         lib = _lib.lib()
         R, d = self.rows, self.d
         for l, w in enumerate(self.layers):
+            # every LayerNorm rides in the A-load of the product that consumes it (pika_dgemm ln_gamma / ln_beta)
             self._gemm(self.A[l], self.lda[l], w["conv"], w["bconv"], self.y_conv, d, R, relu=True, m_dev=count)
-            self._layer_norm(self.y_conv, w["ln1"], self.ln)
-            self._gemm(self.ln, d, w["qkv"], w["bqkv"], self.kvq, 3 * d, R, m_dev=count)
+            self._gemm(self.y_conv, d, w["qkv"], w["bqkv"], self.kvq, 3 * d, R, m_dev=count, ln=w["ln1"])
             _lib.check(lib.pika_dstep_attention(self.kvq.data_ptr(), 3 * d, self.Kc[l].data_ptr(), self.Vc[l].data_ptr(),
                                                 anc_dst.data_ptr(), self.L, self.pos.data_ptr(), self.node.data_ptr(),
                                                 self.rowmap.data_ptr(), count.data_ptr(), R, self.L, d, self.heads,
                                                 self.ctx.data_ptr(), _stream()), "pika_dstep_attention")
             self._gemm(self.ctx, d, w["fin"], w["bfin"], self.o, d, R, res=self.y_conv, ldr=d, m_dev=count)
-            self._layer_norm(self.o, w["ln2"], self.ln)
-            self._gemm(self.ln, d, w["w1"], w["b1"], self.hmid, self.hmid.shape[1], R, relu=True, m_dev=count)
+            self._gemm(self.o, d, w["w1"], w["b1"], self.hmid, self.hmid.shape[1], R, relu=True, m_dev=count, ln=w["ln2"])
             if l + 1 < self.nl:
                 # the next layer's input: fifth tap block of its conv matrix + its cache row
                 nxt = self.A[l + 1][:, 4 * self.Cin[l + 1]:]
@@ -238,8 +233,8 @@ class FusedSearch(object):
                            C2=self.X[l + 1], ldc2=self.Cin[l + 1], m_dev=count)
             else:
                 self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], self.xfin, d, R, res=self.o, ldr=d, m_dev=count)
-        self._layer_norm(self.xfin, self.model.decoder.layer_norm, self.ln)
-        self._gemm(self.ln, d, self.wout, self.bout, state_dst, self.H, R, m_dev=count, crow=self.rowmap)
+        self._gemm(self.xfin, d, self.wout, self.bout, state_dst, self.H, R, m_dev=count, crow=self.rowmap,
+                   ln=self.model.decoder.layer_norm)
 
     def _prep(self, parity):
         p = DPrep()
@@ -289,24 +284,24 @@ class FusedSearch(object):
         lib = _lib.lib()
         b = self.beam
         self._gemm(dec_hid, lda, self.wp, None, self.h, self.H, self.rows, gate=True)
-        _lib.check(lib.pika_dfc2_topk(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
-                                      self.V, self.H, self.terms, self.sm_scale, self.K, self.pmax.data_ptr(),
-                                      self.psum.data_ptr(), self.pcand.data_ptr(), _stream()), "pika_dfc2_topk")
+        _lib.check(lib.pika_dfc2_logits(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
+                                        self.V, self.H, self.terms, self.sm_scale, self.pmax.data_ptr(),
+                                        self.psum.data_ptr(), self.logits.data_ptr(), self.ldl, _stream()), "pika_dfc2_logits")
         fst = b.fst_dev
-        _lib.check(lib.pika_beam_advance_partials(
-            self.pmax.data_ptr(), self.psum.data_ptr(), self.pcand.data_ptr(), self.splits, b.scores.data_ptr(),
+        _lib.check(lib.pika_beam_advance_logits(
+            self.pmax.data_ptr(), self.psum.data_ptr(), self.logits.data_ptr(), self.ldl, self.splits, b.scores.data_ptr(),
             b.lm_scores.data_ptr(), self.lm_scale, b.y.data_ptr(), self.t_idx.data_ptr(), self.num_frames.data_ptr(),
             b.max_len.data_ptr(), b.hyp.data_ptr(), b.hyp_len.data_ptr(), b.hyp.shape[2], b.ks_hist.data_ptr(),
             b.ys_hist.data_ptr(), b.step_t.data_ptr(), self.eos_u8.data_ptr(), b.fin_score.data_ptr(),
             b.fin_step.data_ptr(), b.fin_k.data_ptr(), b.fin_n.data_ptr(), b.fin_cap, self.prev_k.data_ptr(),
             None if fst is None else fst["y_raw"].data_ptr(), self.B, self.K, self.V, b.blk, int(b.beam_prune),
             b.n_best, self.stop.data_ptr(), self.max_hyp.data_ptr(), self.sync.data_ptr(), _stream()),
-            "pika_beam_advance_partials")
+            "pika_beam_advance_logits")
         if fst is not None:
             b._fst_advance_device(self.prev_k.view(self.B, self.K), self.lm_scale, skip=self.sync[4:5])
 
     def launches_per_step(self):
-        return 1 + 8 * self.nl + 2 + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
+        return 1 + 6 * self.nl + 1 + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
 
     def final_state(self, steps):
         """Prediction-net states / frame indices in beam order after the last step (the attributes the reference

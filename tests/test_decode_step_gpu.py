@@ -73,6 +73,39 @@ def test_dgemm_bias_relu_residual_scatter(hip_device, terms, tol, M, N, K):
     assert torch.all(C[rest][:, :N] == 7.0)
 
 
+@pytest.mark.parametrize("terms,tol", [(1, 2e-2), (3, 3e-6), (4, 5e-6)])
+@pytest.mark.parametrize("M,N,K", [(170, 1536, 512), (1024, 512, 512), (37, 100, 96), (300, 1024, 1024)])
+def test_dgemm_layer_norm_on_the_way_in(hip_device, terms, tol, M, N, K):
+    """pika_dgemm with ln_gamma / ln_beta == LayerNorm (onmt LayerNorm, eps 1e-6, biased variance) followed by the product:
+    the rows are normalised inside the launch (row statistics over the waves of a workgroup)."""
+    from pika_amd.decoder.fused_step import DGemm, PackedWeight, DG_RELU
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K + terms)
+    A = (torch.randn(M, K, generator=g) * 3 + 0.7).to(hip_device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(hip_device)
+    bias = torch.randn(N, generator=g).to(hip_device)
+    gamma = (1 + 0.2 * torch.randn(K, generator=g)).to(hip_device)
+    beta = (0.1 * torch.randn(K, generator=g)).to(hip_device)
+    res = torch.randn(M, N, generator=g).to(hip_device)
+    C = torch.full((M, N), 7.0, device=hip_device)
+    md = torch.tensor([M - 3], dtype=torch.int32, device=hip_device)
+    pw = PackedWeight(W, terms)
+    d = DGemm()
+    d.A, d.lda, d.W, d.bias, d.res, d.ldr = A.data_ptr(), K, pw.buf.data_ptr(), bias.data_ptr(), res.data_ptr(), N
+    d.C, d.ldc, d.M, d.N, d.K, d.terms, d.flags = C.data_ptr(), N, M, N, K, terms, DG_RELU
+    d.m_dev = md.data_ptr()
+    d.ln_gamma, d.ln_beta, d.ln_eps = gamma.data_ptr(), beta.data_ptr(), 1e-6
+    _lib.check(_lib.lib().pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm ln")
+    x = A.double()
+    xn = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-6) * gamma.double() + beta.double()
+    want = torch.relu(xn @ W.double().t() + bias.double()) + res.double()
+    scale = want.abs().max().item()
+    assert (C[:M - 3].double() - want[:M - 3]).abs().max().item() <= tol * scale
+    assert torch.all(C[M - 3:] == 7.0)
+    d.K = K - 4                                           # not a whole number of k-tiles: refused, not mis-computed
+    assert _lib.lib().pika_dgemm(ctypes.byref(d), _st()) < 0
+
+
 def test_dgemm_gate_epilogue(hip_device):
     """Prediction halves of fc1 / fc_gate + gathered encoder halves + tanh * sigmoid (transducer.py:107-109)."""
     from pika_amd.decoder.fused_step import DGemm, PackedWeight, DG_GATE
@@ -115,11 +148,14 @@ def _beam_inputs(B, K, V, L, g, dev, first):
     return {k: v.to(dev) for k, v in s.items()}
 
 
-@pytest.mark.parametrize("V,K,Hd,first", [(100, 4, 64, False), (5000, 16, 128, False), (333, 8, 64, True)])
+@pytest.mark.parametrize("V,K,Hd,first,ties", [(100, 4, 64, False, 0), (5000, 16, 128, False, 0), (333, 8, 64, True, 0),
+                                                (5000, 16, 64, False, 3), (5000, 16, 64, False, 1), (700, 8, 64, False, 40)])
 @pytest.mark.parametrize("terms", [3, 1, 4])
-def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, first, terms):
-    """fc2 + partial log-sum-exp / top-K + pika_beam_advance_partials == materialised logits -> pika_beam_advance:
-    same parents, symbols, finished lists; scores to fp32 rounding of the log-sum-exp."""
+def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, first, terms, ties):
+    """fc2 + partial log-sum-exp / top-K + pika_beam_advance_partials == fc2 + row statistics + scaled logits +
+    pika_beam_advance_logits (the thresholded row pass) == materialised logits -> pika_beam_advance: same parents, symbols,
+    finished lists; scores to fp32 rounding of the log-sum-exp.  ties > 0: logits take only that many distinct values
+    (more candidates at the bound than the selection pool holds: the bound is raised / ties go by lowest column)."""
     from pika_amd.decoder.fused_step import PackedWeight
     from pika_amd import _lib
     lib = _lib.lib()
@@ -129,9 +165,18 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
     h = torch.randn(R, Hd, generator=g).to(hip_device)
     W = (torch.randn(V, Hd, generator=g) * 0.5).to(hip_device)
     bias = torch.randn(V, generator=g).to(hip_device)
+    if ties:
+        W.zero_()
+        bias = torch.randint(0, ties, (V,), generator=g).float().to(hip_device)
     pw = PackedWeight(W, terms)
     sm = 0.8
     splits = lib.pika_dfc2_splits(V)
+    ldl = splits * lib.pika_dfc2_cols_per_split()
+    pmax2 = torch.empty(R * splits, device=hip_device)
+    psum2 = torch.empty(R * splits, device=hip_device)
+    slog = torch.full((R, ldl), 7.0, device=hip_device)
+    _lib.check(lib.pika_dfc2_logits(h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), R, V, Hd, terms, sm,
+                                    pmax2.data_ptr(), psum2.data_ptr(), slog.data_ptr(), ldl, _st()), "pika_dfc2_logits")
     pmax = torch.empty(R * splits, device=hip_device)
     psum = torch.empty(R * splits, device=hip_device)
     pcand = torch.empty(R * splits * K * 8, dtype=torch.uint8, device=hip_device)
@@ -146,13 +191,17 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
     _lib.check(lib.pika_dgemm(ctypes.byref(d), _st()), "pika_dgemm")
     if terms == 3:
         want = h.double() @ W.double().t() + bias.double()
-        assert (logits.double() - want).abs().max().item() < 3e-6 * want.abs().max().item()
+        assert (logits.double() - want).abs().max().item() <= 3e-6 * want.abs().max().item()
     # partial statistics
     x = (sm * logits).double()
     lse = torch.logsumexp(x, dim=1)
     pm = pmax.view(R, splits).double()
     got_lse = (psum.view(R, splits).double() * torch.exp(pm - pm.max(1, keepdim=True).values)).sum(1).log() + pm.max(1).values
     assert (got_lse - lse).abs().max().item() < 1e-5
+    assert torch.equal(pmax2, pmax) and torch.equal(psum2, psum)
+    # (the plain product sums its reduction in another order than the vocabulary product)
+    assert torch.allclose(slog[:, :V], sm * logits, rtol=0, atol=1e-5 * float(logits.abs().max()) + (2e-2 if terms == 1 else 0))
+    assert bool(torch.all(slog[:, V:] == -float("inf")))
 
     def run(use_partials):
         st = _beam_inputs(B, K, V, L, torch.Generator().manual_seed(9), hip_device, first)
@@ -173,7 +222,12 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
                   st["num_frames"].data_ptr(), st["max_len"].data_ptr(), st["hyp"].data_ptr(), st["hyp_len"].data_ptr(), L,
                   ks_hist.data_ptr(), ys_hist.data_ptr(), step_t.data_ptr(), st["eos"].data_ptr(), fin_score.data_ptr(),
                   fin_step.data_ptr(), fin_k.data_ptr(), fin_n.data_ptr(), fin_cap, prev_k.data_ptr(), y_raw.data_ptr()]
-        if use_partials:
+        if use_partials == 2:
+            _lib.check(lib.pika_beam_advance_logits(pmax2.data_ptr(), psum2.data_ptr(), slog.data_ptr(), ldl, splits, *common,
+                                                    B, K, V, blk, 1, K, stop.data_ptr(), max_hyp.data_ptr(),
+                                                    sync.data_ptr(), _st()), "pika_beam_advance_logits")
+            assert int(step_t) == (1 if first else 4) and int(max_hyp) == int(st["hyp_len"].max())
+        elif use_partials:
             _lib.check(lib.pika_beam_advance_partials(pmax.data_ptr(), psum.data_ptr(), pcand.data_ptr(), splits, *common,
                                                       B, K, V, blk, 1, K, stop.data_ptr(), max_hyp.data_ptr(),
                                                       sync.data_ptr(), _st()), "pika_beam_advance_partials")
@@ -184,11 +238,13 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
                                              _st()), "pika_beam_advance")
         torch.cuda.synchronize()
         return dict(st, prev_k=prev_k, y_raw=y_raw, fin_n=fin_n, fin_score=fin_score, fin_k=fin_k, fin_step=fin_step)
-    a, b = run(True), run(False)
+    a, b, c = run(True), run(False), run(2)
     for k in ("prev_k", "y_raw", "y", "t_idx", "hyp", "hyp_len", "fin_n", "fin_k", "fin_step", "eos"):
         assert torch.equal(a[k], b[k]), k
+        assert torch.equal(c[k], b[k]), k
     assert torch.allclose(a["scores"], b["scores"], rtol=0, atol=2e-5)
     assert torch.allclose(a["fin_score"], b["fin_score"], rtol=0, atol=2e-5)
+    assert torch.equal(c["scores"], a["scores"]) and torch.equal(c["fin_score"], a["fin_score"])
 
 
 @pytest.mark.parametrize("pred_net", ["transformer", "rnn"])
@@ -205,7 +261,7 @@ def test_fused_search_equals_stepwise_search(hip_device, dec_terms, pred_net):
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
     net = build(pred_net, hip_device)
-    want_launches = 22 if pred_net == "transformer" else 4 + 2 * net.decoder.num_layers
+    want_launches = 17 if pred_net == "transformer" else 4 + 2 * net.decoder.num_layers
     x, x_len = D.inputs()
     x, x_len_d = x.to(hip_device), x_len.to(hip_device)
     args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
