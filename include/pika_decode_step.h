@@ -49,7 +49,8 @@ int pika_dpack_weight(const float *W, long long ldw, int N, int K, int terms, in
 /* ---- C = epilogue(A . W^T) --------------------------------------------------------------------------------- */
 #define PIKA_DG_RELU 1      /* max(.,0) after bias                                                   */
 #define PIKA_DG_GATE 2      /* packed W is interleave2: C[r,j] = tanh(acc[2j] + e[g,j]) * sigmoid(acc[2j+1] + e[g,N/2+j]),
-                               g = (r / beam) * T + clamp(t_idx[r], 0, T-1); N counts the 2H interleaved columns */
+                               g = (r / beam) * T + clamp(t_idx[r], 0, T-1); N counts the 2H interleaved columns;
+                               C2 (optional, no node needed): the raw acc, (M, N) at the row C is written to       */
 #define PIKA_DG_ROWMASK 4   /* rows r with node[r] == skip_node are not stored                        */
 typedef struct {
     const float *A;          /* (M, Kp) f32, Kp = ceil32(K) columns readable (caller zero-pads)      */
@@ -95,6 +96,20 @@ int pika_dgemm(const pika_dgemm_t *p, void *stream);
  * layer l>0: A[l][slot, :4*C[l]] = [X[l][anc[p-4]] .. X[l][anc[p-1]]]  (the fifth block is written by the layer below)
  * s = *step_t (steps taken so far).  The prediction-net launches of the step then run on count[s&1] rows. */
 #define PIKA_DSTEP_MAX_LAYERS 4
+/* The joint's prediction half travels with the rows (optional; pj[0] == NULL: off).  A row's prediction-net state only
+ * changes when it emits a label, so its product with the prediction halves of fc1 / fc_gate (transducer.py:107-109) is
+ * computed once, when the state is, and kept: pj[(s+1)&1][r] = pj[s&1][parent] for every row (the same double buffering as
+ * the state); rows that did NOT emit a label get their joint hidden for this step right here,
+ *   h[r, j] = tanh(pj[2j] + e[j]) * sigmoid(pj[2j+1] + e[JH + j]),  e = e_all[(r / beam) * T + clamp(t_idx[r], 0, T-1)]
+ * (t_idx after this step's increment); the rows of the compact list get pj and h from the PIKA_DG_GATE product of their
+ * new state (pika_dgemm with rowlist = rowmap32, C = h, C2 = pj[(s+1)&1]) -- count rows instead of all of them. */
+typedef struct {
+    float *pj[2];            /* (rows, 2*JH) f32: columns (2j, 2j+1) = (fc1, fc_gate) prediction halves of unit j  */
+    float *h;                /* (rows, JH) f32 out                                                                 */
+    const float *e_all;      /* (B*T, 2*JH) f32 = [fc1 encoder half + bias | fc_gate encoder half + bias]          */
+    int *rowmap32;           /* (rows) int32 out: slot -> row, the gather list of the compact rows' joint product  */
+    int T, JH;
+} pika_dstep_joint_t;
 typedef struct {
     const long long *prev_k, *y, *hyp_len, *step_t;
     long long *t_idx;
@@ -112,6 +127,7 @@ typedef struct {
     long long dump_node, zero_node;
     int layers, rows, beam, H, L, blk;
     const int *stop;
+    pika_dstep_joint_t joint;
 } pika_dstep_prep_t;
 int pika_dstep_prep(const pika_dstep_prep_t *p, void *stream);
 
@@ -146,6 +162,7 @@ typedef struct {
     int *count;              /* int32[2], as in pika_dstep_prep_t                                    */
     int layers, rows, beam, H, E, blk;
     const int *stop;
+    pika_dstep_joint_t joint;        /* (JH = H: the joint reads h of the last layer)                   */
 } pika_dstep_prep_lstm_t;
 int pika_dstep_prep_lstm(const pika_dstep_prep_lstm_t *p, void *stream);
 

@@ -336,9 +336,11 @@ __device__ inline void dg_finish(const DG &p, int r, int c0, f32x4 v, bool pre, 
             const float z1 = v[2 * u] + e[2 * u], zg = v[2 * u + 1] + e[2 * u + 1];
             o[u] = tanhf(z1) * (1.f / (1.f + expf(-zg)));
         }
-        float *dst = p.C + (p.crow ? p.crow[r] : (long long)r) * p.ldc + j0;
+        const long long row = p.crow ? p.crow[r] : (long long)r;
+        float *dst = p.C + row * p.ldc + j0;
         dst[0] = o[0];
         if (j0 + 1 < H) dst[1] = o[1];
+        if (p.C2) *reinterpret_cast<f32x4 *>(p.C2 + row * p.ldc2 + c0) = v;      // (N % 4 == 0, ldc2 % 4 == 0)
         return;
     }
     const bool full = c0 + 3 < p.N;
@@ -710,6 +712,31 @@ struct PrepDev {
     pika_dstep_prep_t p;
 };
 
+// The joint's prediction half follows the row's parent; rows that did not emit a label get this step's joint hidden
+// (pika_dstep_joint_t).  t_new: the row's frame index after this step's increment.
+__device__ inline void joint_carry(const pika_dstep_joint_t &j, int src, long long pr, int r, int beam, bool commit,
+                                   long long t_new) {
+    if (!j.pj[0]) return;
+    const int tid = threadIdx.x, JH = j.JH;
+    const float *ps = j.pj[src] + pr * 2 * JH;
+    float *pd = j.pj[src ^ 1] + (long long)r * 2 * JH;
+    const long long t = t_new < 0 ? 0 : (t_new > j.T - 1 ? j.T - 1 : t_new);
+    const float *e = j.e_all + ((long long)(r / beam) * j.T + t) * 2 * JH;
+    for (int c = tid * 4; c < JH; c += 1024) {          // units [c, c + 4): pj columns [2c, 2c + 8)
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(ps + 2 * c), p1 = *reinterpret_cast<const f32x4 *>(ps + 2 * c + 4);
+        *reinterpret_cast<f32x4 *>(pd + 2 * c) = p0;
+        *reinterpret_cast<f32x4 *>(pd + 2 * c + 4) = p1;
+        if (commit) continue;
+        const f32x4 e1 = *reinterpret_cast<const f32x4 *>(e + c), eg = *reinterpret_cast<const f32x4 *>(e + JH + c);
+        const float z1[4] = {p0[0] + e1[0], p0[2] + e1[1], p1[0] + e1[2], p1[2] + e1[3]};
+        const float zg[4] = {p0[1] + eg[0], p0[3] + eg[1], p1[1] + eg[2], p1[3] + eg[3]};
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = tanhf(z1[u]) * (1.f / (1.f + expf(-zg[u])));
+        *reinterpret_cast<f32x4 *>(j.h + (long long)r * JH + c) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     const pika_dstep_prep_t &p = a.p;
     if (p.stop && *p.stop) return;
@@ -731,6 +758,7 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
         if (c + 3 < p.H) *reinterpret_cast<f32x4 *>(sd + c) = *reinterpret_cast<const f32x4 *>(ss + c);
         else for (int u = 0; c + u < p.H; ++u) sd[c + u] = ss[c + u];
     }
+    joint_carry(p.joint, src, pr, r, p.beam, commit, p.t_idx[r] + (tok == p.blk ? 1 : 0));
     const long long *as = p.anc[src] + pr * p.L;
     long long *ad = p.anc[dst] + (long long)r * p.L;
     const long long ncopy = pos + 1 < p.L ? pos + 1 : p.L;      // positions > pos are never read
@@ -739,6 +767,7 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
         if (commit && j == pos) v = node;
         ad[j] = v;
     }
+    __syncthreads();            // (every thread has read t_idx[r] in joint_carry)
     if (tid == 0) {
         if (tok == p.blk) p.t_idx[r] += 1;                       // :129
         // rows that emitted a label get a slot in the compact row list the prediction-net launches work on
@@ -749,6 +778,7 @@ __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     const int slot = slot_s;
     if (tid == 0) {
         p.rowmap[slot] = r;
+        if (p.joint.rowmap32) p.joint.rowmap32[slot] = r;
         p.node[slot] = node;
         p.pos[slot] = pos;
     }
@@ -796,6 +826,8 @@ __global__ __launch_bounds__(256) void dstep_prep_lstm_kernel(pika_dstep_prep_ls
     const float *ss = p.state[src] + pr * SP;
     float *sd = p.state[dst] + (long long)r * SP;
     for (long long c = tid * 4; c < SP; c += 1024) *reinterpret_cast<f32x4 *>(sd + c) = *reinterpret_cast<const f32x4 *>(ss + c);
+    joint_carry(p.joint, src, pr, r, p.beam, commit, p.t_idx[r] + (tok == p.blk ? 1 : 0));
+    __syncthreads();            // (every thread has read t_idx[r])
     if (tid == 0) {
         if (tok == p.blk) p.t_idx[r] += 1;                       // :129
         slot_s = commit ? atomicAdd(p.count + src, 1) : -1;
@@ -803,7 +835,7 @@ __global__ __launch_bounds__(256) void dstep_prep_lstm_kernel(pika_dstep_prep_ls
     __syncthreads();
     if (!commit) return;
     const int slot = slot_s;
-    if (tid == 0) p.rowmap[slot] = r;
+    if (tid == 0) { p.rowmap[slot] = r; if (p.joint.rowmap32) p.joint.rowmap32[slot] = r; }
     float *a0 = p.A[0] + (long long)slot * p.lda[0];
     for (int c = tid; c < p.E; c += 256) a0[c] = p.emb[tok * p.E + c];
     for (int c = tid; c < p.H; c += 256) a0[p.E + c] = ss[c];
@@ -932,6 +964,9 @@ __global__ __launch_bounds__(256) void dstep_attn_kernel(const float *__restrict
 // ---- fc2 + log-sum-exp partials + top-K partials --------------------------------------------------------------
 constexpr int FC2_WN = 3, FC2_KS = 2, FC2_COLS = 4 * FC2_WN * 16;   // 192 columns per split
 static_assert(FC2_COLS == PIKA_DFC2_COLS, "pika_decode_step.h");
+// floats per slab row: 4 more than the columns, so that 16 rows read at the same column sit in 16 different LDS banks
+// (the row statistics of the logits mode: four lanes per row, all rows of a wave at once)
+constexpr int FC2_PITCH = FC2_COLS + 4;
 struct Cand { float v; int idx; };
 
 __device__ inline bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -944,7 +979,7 @@ __device__ inline unsigned fkey(float f) {
 
 template <int NS, int BM>
 __host__ __device__ constexpr size_t FC2_LDS_MAIN() {      // operand staging buffers, overlaid by the logits slab
-    constexpr size_t a = Core<BM, FC2_WN, NS, FC2_KS>::LDS_BYTES, b = (size_t)BM * FC2_COLS * 4;
+    constexpr size_t a = Core<BM, FC2_WN, NS, FC2_KS>::LDS_BYTES, b = (size_t)BM * FC2_PITCH * 4;
     return a > b ? a : b;
 }
 
@@ -967,7 +1002,7 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
     typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
     core_t core;
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
-    float *slab = reinterpret_cast<float *>(smem);                       // [FC2_BM][FC2_COLS], after the product
+    float *slab = reinterpret_cast<float *>(smem);                       // [FC2_BM][FC2_PITCH], after the product
     int mb, sp;
     if (!xcd_tile_rows(splits, (rows + FC2_BM - 1) / FC2_BM, mb, sp)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -993,10 +1028,38 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
             const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_s + lc);
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = c + u < V ? sm_scale * (v[u] + b4[u]) : -INFINITY;
-            *reinterpret_cast<f32x4 *>(slab + (i * 16 + (lane & 15)) * FC2_COLS + lc) = v;
+            *reinterpret_cast<f32x4 *>(slab + (i * 16 + (lane & 15)) * FC2_PITCH + lc) = v;
         }
     __syncthreads();
     CORE_STAMP(38, 1);
+    if constexpr (!CANDS) {
+        // Row statistics with FOUR lanes per row -- a lane walks every fourth column of its row (no cross-lane step until
+        // the 4-lane merge; the row pitch keeps the 16 rows of a wave in different banks) -- and the slab goes to `logits`
+        // in whole 16-byte pieces.  (One row per wave pass: 12 butterfly steps per row, 16 rows per wave.)
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+        if (row < FC2_BM && m0 + row < rows) {
+            const float *sr = slab + row * FC2_PITCH + part;
+            float xv[FC2_COLS / 4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < FC2_COLS / 4; ++i) { xv[i] = sr[4 * i]; m = fmaxf(m, xv[i]); }
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < FC2_COLS / 4; ++i) sum += xv[i] > -INFINITY ? expf(xv[i] - m) : 0.f;
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            if (part == 0) { pmax[(long long)(m0 + row) * splits + sp] = m; psum[(long long)(m0 + row) * splits + sp] = sum; }
+        }
+        for (int idx = threadIdx.x; idx < FC2_BM * (FC2_COLS / 4); idx += 256) {
+            const int r = idx / (FC2_COLS / 4), c4 = idx - r * (FC2_COLS / 4);
+            if (m0 + r < rows)
+                *reinterpret_cast<f32x4 *>(logits + (long long)(m0 + r) * ldl + sp * FC2_COLS + 4 * c4) =
+                    *reinterpret_cast<const f32x4 *>(slab + r * FC2_PITCH + 4 * c4);
+        }
+        return;
+    }
     // FC2_BM / 4 rows per wave: max, sum of exponentials, the topk largest (value desc, column asc).  RG rows at a time:
     // every stage below is a chain of dependent cross-lane steps (6 + 6 butterfly exchanges; 32 bisection rounds of
     // compare -> ballot -> scalar popcount -> scalar select -> compare, ~80 cycles each) that leaves the wave idle --
@@ -1012,7 +1075,7 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
 #pragma unroll
-            for (int q = 0; q < PL; ++q) x[g][q] = slab[(lr0 + g) * FC2_COLS + lane + 64 * q];
+            for (int q = 0; q < PL; ++q) x[g][q] = slab[(lr0 + g) * FC2_PITCH + lane + 64 * q];
             m[g] = x[g][0];
 #pragma unroll
             for (int q = 1; q < PL; ++q) m[g] = fmaxf(m[g], x[g][q]);
@@ -1032,17 +1095,6 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
 #pragma unroll
             for (int g = 0; g < RG; ++g) s[g] += __shfl_xor(s[g], o);
         if (rr == 0) CORE_STAMP(37, 2);
-        if constexpr (!CANDS) {
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                const int r = m0 + lr0 + g;
-                if (r >= rows) break;                 // (wave-uniform)
-                if (lane == 0) { pmax[(long long)r * splits + sp] = m[g]; psum[(long long)r * splits + sp] = s[g]; }
-#pragma unroll
-                for (int q = 0; q < PL; ++q) logits[(long long)r * ldl + sp * FC2_COLS + lane + 64 * q] = x[g][q];
-            }
-            continue;
-        }
         // The topk largest WITHOUT cross-lane shuffles (a wave arg-max is 12 dependent LDS-crossbar permutes, and
         // topk of them per row made this epilogue 4x longer than the product itself): bisect the order-preserving
         // integer image of the values for the topk-th largest key with ballots + popcounts (scalar unit), then every
@@ -1171,7 +1223,8 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
         return PIKA_EINVAL;
     if ((q->lda & 3) || (reinterpret_cast<uintptr_t>(q->A) & 15)) return PIKA_EINVAL;
     if ((q->flags & PIKA_DG_GATE) && (!q->e_all || !q->t_idx || q->T <= 0 || q->beam <= 0 || (q->N & 3))) return PIKA_EINVAL;
-    if (((q->flags & PIKA_DG_ROWMASK) || q->C2) && !q->node) return PIKA_EINVAL;
+    if (((q->flags & PIKA_DG_ROWMASK) || (q->C2 && !(q->flags & PIKA_DG_GATE))) && !q->node) return PIKA_EINVAL;
+    if ((q->flags & PIKA_DG_GATE) && q->C2 && ((q->ldc2 & 3) || (reinterpret_cast<uintptr_t>(q->C2) & 15))) return PIKA_EINVAL;
     const bool ln = q->ln_gamma != nullptr;
     if (ln && (!q->ln_beta || (q->K & 31) || q->K > 1024 || ((reinterpret_cast<uintptr_t>(q->ln_gamma) |
                                                                reinterpret_cast<uintptr_t>(q->ln_beta)) & 15)))
@@ -1299,7 +1352,8 @@ int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bi
 int pika_dfc2_logits(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
                      float sm_scale, float *pmax, float *psum, float *logits, long long ldl, void *stream) {
     if (!h || !W || !pmax || !psum || !logits || rows <= 0 || V <= 0 || K <= 0 || terms < 1 || terms > 4 || (ldh & 3) ||
-        (reinterpret_cast<uintptr_t>(h) & 15) || ldl < (long long)pika_dfc2_splits(V) * FC2_COLS)
+        (reinterpret_cast<uintptr_t>(h) & 15) || ldl < (long long)pika_dfc2_splits(V) * FC2_COLS || (ldl & 3) ||
+        (reinterpret_cast<uintptr_t>(logits) & 15))
         return PIKA_EINVAL;
     return dfc2_launch(h, ldh, W, bias, rows, V, K, terms, sm_scale, 1, pmax, psum, nullptr, logits, ldl, stream);
 }

@@ -36,19 +36,24 @@ class DGemm(ctypes.Structure):
                 ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", ctypes.c_float)]
 
 
+class DJoint(ctypes.Structure):
+    _fields_ = [("pj", _vp * 2), ("h", _vp), ("e_all", _vp), ("rowmap32", _vp), ("T", _i), ("JH", _i)]
+
+
 class DPrep(ctypes.Structure):
     _fields_ = [("prev_k", _vp), ("y", _vp), ("hyp_len", _vp), ("step_t", _vp), ("t_idx", _vp),
                 ("state", _vp * 2), ("anc", _vp * 2), ("emb", _vp), ("X", _vp * MAX_LAYERS), ("A", _vp * MAX_LAYERS),
                 ("C", _i * MAX_LAYERS), ("lda", _ll * MAX_LAYERS), ("node", _vp), ("pos", _vp), ("rowmap", _vp),
                 ("count", _vp), ("dump_node", _ll),
                 ("zero_node", _ll), ("layers", _i), ("rows", _i), ("beam", _i), ("H", _i), ("L", _i), ("blk", _i),
-                ("stop", _vp)]
+                ("stop", _vp), ("joint", DJoint)]
 
 
 class DPrepLSTM(ctypes.Structure):
     _fields_ = [("prev_k", _vp), ("y", _vp), ("step_t", _vp), ("t_idx", _vp), ("state", _vp * 2), ("emb", _vp),
                 ("A", _vp * MAX_LAYERS), ("lda", _ll * MAX_LAYERS), ("rowmap", _vp), ("count", _vp),
-                ("layers", _i), ("rows", _i), ("beam", _i), ("H", _i), ("E", _i), ("blk", _i), ("stop", _vp)]
+                ("layers", _i), ("rows", _i), ("beam", _i), ("H", _i), ("E", _i), ("blk", _i), ("stop", _vp),
+                ("joint", DJoint)]
 
 
 def _ptr(t):
@@ -129,6 +134,10 @@ class FusedSearch(object):
         self.max_hyp = torch.zeros(1, **i64)
         self.eos_u8 = torch.zeros(B, dtype=torch.uint8, device=dev)
         self.h = torch.empty(R, self.H, **f32)
+        # the joint's prediction half of every row (raw, fc1 / fc_gate interleaved), double-buffered like the state: computed
+        # when a row's state is, carried along by `prep` otherwise (pika_dstep_joint_t)
+        self.pj = [torch.zeros(R, 2 * self.H, **f32) for _ in range(2)]
+        self.rowmap32 = torch.arange(R, dtype=torch.int32, device=dev)
         lib = _lib.lib()
         self.splits = lib.pika_dfc2_splits(self.V)
         self.pmax = torch.empty(R * self.splits, **f32)
@@ -137,8 +146,6 @@ class FusedSearch(object):
         self.ldl = self.splits * lib.pika_dfc2_cols_per_split()
         self.logits = torch.empty(R, self.ldl, **f32)
         H = self.H
-        wp = torch.cat((model.fc1.weight[:, H:], model.fc_gate.weight[:, H:]), dim=0)   # (2H, H) prediction halves
-        self.wp = PackedWeight(wp, self.terms, interleave2=True)
         self.w2 = PackedWeight(model.fc2.weight, self.terms)
         self.b2 = model.fc2.bias.detach().float().contiguous()
         self.dump_node = 0
@@ -164,7 +171,10 @@ class FusedSearch(object):
         self.Kc = [torch.zeros(cap, d, **f32) for _ in range(self.nl)]
         self.Vc = [torch.zeros(cap, d, **f32) for _ in range(self.nl)]
         self.A = [torch.zeros(R, w, **f32) for w in self.lda]
-        self.state = [torch.zeros(R, self.H, **f32) for _ in range(2)]
+        # A row's carried "state" is the last transformer layer's output at its last position (d wide, before the final
+        # LayerNorm): linear_out and the prediction halves of fc1 / fc_gate are ONE product per step (folded below), and the
+        # decoder's own state -- linear_out(LayerNorm(.)) -- is only formed for the rows that are left at the end
+        self.state = [torch.zeros(R, d, **f32) for _ in range(2)]
         self.anc = [torch.full((R, self.L), self.dump_node, **i64) for _ in range(2)]
         self.pos = torch.zeros(R, **i64)
         # activations of one step
@@ -174,7 +184,6 @@ class FusedSearch(object):
         self.o = torch.empty(R, d, **f32)
         dff = net.transformer[0].feed_forward.w_1.weight.shape[0]
         self.hmid = torch.empty(R, dff, **f32)
-        self.xfin = torch.empty(R, d, **f32)
         # weights, packed once
         t = self.terms
         self.layers = []
@@ -192,14 +201,21 @@ class FusedSearch(object):
                 w2=PackedWeight(ff.w_2.weight, t), b2=ff.w_2.bias.detach().float().contiguous()))
         self.wout = PackedWeight(net.linear_out.weight, t)
         self.bout = net.linear_out.bias.detach().float().contiguous()
+        # No nonlinearity sits between linear_out (rnnt_conv_transformer_lm.py:80) and the prediction halves of fc1 / fc_gate
+        # (transducer.py:107-109): per step the two products are one, W' = [fc1_p; fc_gate_p] . W_out (2H x d, formed in
+        # float64, rounded once), and the constant [fc1_p; fc_gate_p] . b_out joins the encoder halves (which already hold
+        # the biases of fc1 / fc_gate).  One K = d product instead of a K = d and a K = H one, one launch less per step.
+        wp64 = torch.cat((model.fc1.weight[:, self.H:], model.fc_gate.weight[:, self.H:]), dim=0).detach().double()
+        self.wp = PackedWeight((wp64 @ net.linear_out.weight.detach().double()).float(), t, interleave2=True)
+        self.e_all = (self.e_all + (wp64 @ net.linear_out.bias.detach().double()).float().unsqueeze(0)).contiguous()
         self.emb = net.embeddings.weight.detach().float().contiguous()
         self._init_sos()
 
     # ---- launches ------------------------------------------------------------------------------------------
     def _gemm(self, A, lda, W, bias, C, ldc, M, relu=False, res=None, ldr=0, C2=None, ldc2=0, rowmask=False, gate=False,
-              m_dev=None, crow=None, ln=None):
+              m_dev=None, crow=None, ln=None, rowlist=None):
         g = DGemm()
-        g.m_dev, g.crow = _ptr(m_dev), _ptr(crow)
+        g.m_dev, g.crow, g.rowlist = _ptr(m_dev), _ptr(crow), _ptr(rowlist)
         if ln is not None:      # LayerNorm of the A rows inside the launch
             g.ln_gamma, g.ln_beta, g.ln_eps = ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps)
         g.A, g.lda, g.W, g.bias = _ptr(A), lda, W.buf.data_ptr(), _ptr(bias)
@@ -232,9 +248,8 @@ class FusedSearch(object):
                 self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], nxt, self.lda[l + 1], R, res=self.o, ldr=d,
                            C2=self.X[l + 1], ldc2=self.Cin[l + 1], m_dev=count)
             else:
-                self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], self.xfin, d, R, res=self.o, ldr=d, m_dev=count)
-        self._gemm(self.xfin, d, self.wout, self.bout, state_dst, self.H, R, m_dev=count, crow=self.rowmap,
-                   ln=self.model.decoder.layer_norm)
+                self._gemm(self.hmid, self.hmid.shape[1], w["w2"], w["b2"], state_dst, d, R, res=self.o, ldr=d, m_dev=count,
+                           crow=self.rowmap)
 
     def _prep(self, parity):
         p = DPrep()
@@ -249,8 +264,9 @@ class FusedSearch(object):
         p.node, p.pos, p.rowmap = self.node.data_ptr(), self.pos.data_ptr(), self.rowmap.data_ptr()
         p.count = self.sync[5:7].data_ptr()
         p.dump_node, p.zero_node = self.dump_node, self.zero_node
-        p.layers, p.rows, p.beam, p.H, p.L, p.blk = self.nl, self.rows, self.K, self.H, self.L, b.blk
+        p.layers, p.rows, p.beam, p.H, p.L, p.blk = self.nl, self.rows, self.K, self.d, self.L, b.blk     # (H: state width)
         p.stop = self.stop.data_ptr()
+        self._fill_joint(p.joint)
         _lib.check(_lib.lib().pika_dstep_prep(ctypes.byref(p), _stream()), "pika_dstep_prep")
 
     def _init_sos(self):
@@ -268,6 +284,7 @@ class FusedSearch(object):
             self.anc[0][:, 0] = 0
             self.sync[5] = R                # every row is in the compact list (identity rowmap) for this one pass
             self._prednet(self.anc[0], self.state[0], self.sync[5:6])
+            self._joint_rows(self.state[0], self.d, self.pj[0], self.sync[5:6], ln=self.model.decoder.layer_norm)
             self.sync[5] = 0
 
     def step_launches(self, parity):
@@ -276,14 +293,26 @@ class FusedSearch(object):
         with torch.cuda.device(self.dev):
             self._prep(parity)
             self._prednet(self.anc[dst], self.state[dst], self.sync[5 + parity:6 + parity])
-            self._joint_and_advance(self.state[dst], self.H)
+            self._joint_rows(self.state[dst], self.d, self.pj[dst], self.sync[5 + parity:6 + parity],
+                             ln=self.model.decoder.layer_norm)
+            self._joint_and_advance()
 
-    def _joint_and_advance(self, dec_hid, lda):
-        """dec_hid (rows, H) with pitch lda: prediction halves of fc1 / fc_gate with the gate in the epilogue -> fc2
-        with log-sum-exp + top-K partials -> advance from the partials (+ device FST advance)."""
+    def _fill_joint(self, j):
+        for i in range(2):
+            j.pj[i] = self.pj[i].data_ptr()
+        j.h, j.e_all, j.rowmap32 = self.h.data_ptr(), self.e_all.data_ptr(), self.rowmap32.data_ptr()
+        j.T, j.JH = self.T, self.H
+
+    def _joint_rows(self, dec_hid, lda, pj_dst, count, ln=None):
+        """The joint's prediction half + this step's joint hidden for the rows of the compact list (their state is new):
+        dec_hid (rows, .) with pitch lda, gathered through rowmap32; the other rows got theirs in `prep`."""
+        self._gemm(dec_hid, lda, self.wp, None, self.h, self.H, self.rows, gate=True, m_dev=count, rowlist=self.rowmap32,
+                   C2=pj_dst, ldc2=2 * self.H, ln=ln)
+
+    def _joint_and_advance(self):
+        """fc2 with the row statistics + scaled logits -> advance (+ device FST advance)."""
         lib = _lib.lib()
         b = self.beam
-        self._gemm(dec_hid, lda, self.wp, None, self.h, self.H, self.rows, gate=True)
         _lib.check(lib.pika_dfc2_logits(self.h.data_ptr(), self.H, self.w2.buf.data_ptr(), self.b2.data_ptr(), self.rows,
                                         self.V, self.H, self.terms, self.sm_scale, self.pmax.data_ptr(),
                                         self.psum.data_ptr(), self.logits.data_ptr(), self.ldl, _stream()), "pika_dfc2_logits")
@@ -301,14 +330,17 @@ class FusedSearch(object):
             b._fst_advance_device(self.prev_k.view(self.B, self.K), self.lm_scale, skip=self.sync[4:5])
 
     def launches_per_step(self):
-        return 1 + 6 * self.nl + 1 + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
+        return 1 + 6 * self.nl + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)
 
     def final_state(self, steps):
         """Prediction-net states / frame indices in beam order after the last step (the attributes the reference
         decoder leaves behind, transducer_decoder.py:107,121,188-202)."""
-        src = self.state[steps & 1]
         flat = (torch.arange(self.B, device=self.dev).unsqueeze(1) * self.K + self.prev_k.view(self.B, self.K)).reshape(-1)
-        return src.index_select(0, flat), self.t_idx
+        src = self.state[steps & 1].index_select(0, flat)
+        out = torch.empty(self.rows, self.H, dtype=torch.float32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            self._gemm(src, self.d, self.wout, self.bout, out, self.H, self.rows, ln=self.model.decoder.layer_norm)
+        return out, self.t_idx
 
 
 class FusedSearchLSTM(FusedSearch):
@@ -336,6 +368,8 @@ class FusedSearchLSTM(FusedSearch):
         self.A = [torch.zeros(R, w, **f32) for w in self.lda]          # pad columns stay zero
         self.gates = torch.empty(R, 4 * H, **f32)
         self.emb = model.embed.weight.detach().float().contiguous()
+        wp = torch.cat((model.fc1.weight[:, H:], model.fc_gate.weight[:, H:]), dim=0)   # (2H, H) prediction halves
+        self.wp = PackedWeight(wp, self.terms, interleave2=True)
         self.Wl, self.bl = [], []
         for l in range(self.nl):
             w = torch.cat([getattr(rnn, "weight_ih_l%d" % l), getattr(rnn, "weight_hh_l%d" % l)], 1)
@@ -362,6 +396,7 @@ class FusedSearchLSTM(FusedSearch):
             self.A[0][:, :self.E] = self.emb[self.beam.blk].unsqueeze(0)
             self.sync[5] = R                # every row is in the compact list (identity rowmap) for this one pass
             self._layers(self.state[0], self.sync[5:6])
+            self._joint_rows(self.state[0][:, (self.nl - 1) * 2 * self.H:], self.SP, self.pj[0], self.sync[5:6])
             self.sync[5] = 0
 
     def _prep(self, parity):
@@ -378,6 +413,7 @@ class FusedSearchLSTM(FusedSearch):
         p.count = self.sync[5:7].data_ptr()
         p.layers, p.rows, p.beam, p.H, p.E, p.blk = self.nl, self.rows, self.K, self.H, self.E, b.blk
         p.stop = self.stop.data_ptr()
+        self._fill_joint(p.joint)
         _lib.check(_lib.lib().pika_dstep_prep_lstm(ctypes.byref(p), _stream()), "pika_dstep_prep_lstm")
 
     def step_launches(self, parity):
@@ -386,7 +422,8 @@ class FusedSearchLSTM(FusedSearch):
             self._prep(parity)
             self._layers(self.state[dst], self.sync[5 + parity:6 + parity])
             top = self.state[dst][:, (self.nl - 1) * 2 * self.H:]                 # h of the last layer, in place
-            self._joint_and_advance(top, self.SP)
+            self._joint_rows(top, self.SP, self.pj[dst], self.sync[5 + parity:6 + parity])
+            self._joint_and_advance()
 
     def launches_per_step(self):
         return 1 + 2 * self.nl + 1 + 1 + 1 + (1 if self.beam.fst_dev is not None else 0)

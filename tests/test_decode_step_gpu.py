@@ -198,7 +198,7 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
     pm = pmax.view(R, splits).double()
     got_lse = (psum.view(R, splits).double() * torch.exp(pm - pm.max(1, keepdim=True).values)).sum(1).log() + pm.max(1).values
     assert (got_lse - lse).abs().max().item() < 1e-5
-    assert torch.equal(pmax2, pmax) and torch.equal(psum2, psum)
+    assert torch.equal(pmax2, pmax) and torch.allclose(psum2, psum, rtol=2e-6, atol=0)      # (another summation order)
     # (the plain product sums its reduction in another order than the vocabulary product)
     assert torch.allclose(slog[:, :V], sm * logits, rtol=0, atol=1e-5 * float(logits.abs().max()) + (2e-2 if terms == 1 else 0))
     assert bool(torch.all(slog[:, V:] == -float("inf")))
@@ -244,7 +244,7 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
         assert torch.equal(c[k], b[k]), k
     assert torch.allclose(a["scores"], b["scores"], rtol=0, atol=2e-5)
     assert torch.allclose(a["fin_score"], b["fin_score"], rtol=0, atol=2e-5)
-    assert torch.equal(c["scores"], a["scores"]) and torch.equal(c["fin_score"], a["fin_score"])
+    assert torch.allclose(c["scores"], a["scores"], rtol=0, atol=2e-6) and torch.allclose(c["fin_score"], a["fin_score"], rtol=0, atol=2e-6)
 
 
 @pytest.mark.parametrize("pred_net", ["transformer", "rnn"])
@@ -261,7 +261,7 @@ def test_fused_search_equals_stepwise_search(hip_device, dec_terms, pred_net):
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
     net = build(pred_net, hip_device)
-    want_launches = 17 if pred_net == "transformer" else 4 + 2 * net.decoder.num_layers
+    want_launches = 16 if pred_net == "transformer" else 4 + 2 * net.decoder.num_layers
     x, x_len = D.inputs()
     x, x_len_d = x.to(hip_device), x_len.to(hip_device)
     args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)

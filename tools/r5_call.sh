@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out/c3
 mkdir -p $O
 
-timeout 600 python -m pytest tests/test_decode_step_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_decode_step_gpu.py tests/test_decode_full.py tests/test_fst.py tests/test_mbr.py -x -q -m gpu 2>&1 | tail -5
 timeout 300 python bench.py --workload decode --batch 64 --steps 3 --warmup 1 --no-cpu-baseline > $O/dec.json 2> $O/dec.err
 python - <<PY
 import json
