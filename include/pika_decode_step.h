@@ -52,6 +52,8 @@ int pika_dpack_weight(const float *W, long long ldw, int N, int K, int terms, in
                                g = (r / beam) * T + clamp(t_idx[r], 0, T-1); N counts the 2H interleaved columns;
                                C2 (optional, no node needed): the raw acc, (M, N) at the row C is written to       */
 #define PIKA_DG_ROWMASK 4   /* rows r with node[r] == skip_node are not stored                        */
+#define PIKA_DG_FEW_ROWS 8  /* hint: *m_dev is expected to be a small fraction of M (the rows of a search step that emitted
+                               a label, ~M/6): many small workgroups with ONE request round each instead of M-sized tiling */
 typedef struct {
     const float *A;          /* (M, Kp) f32, Kp = ceil32(K) columns readable (caller zero-pads)      */
     long long lda;

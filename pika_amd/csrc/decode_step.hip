@@ -1234,10 +1234,11 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
          q->m_dev, q->crow, q->rowlist, q->rowoff_dev, (q->K & 3) ? ((q->K + 31) / 32) * 32 : q->K,
          q->ln_gamma, q->ln_beta, q->ln_eps};
     hipStream_t st = (hipStream_t)stream;
-    // Few rows expected (a compact row list: m_dev / rowlist; or M itself small): the split-reduction kernel, one
-    // 16-column tile of 32 rows per workgroup.  PIKA_DGEMM_SK=0 / 1 forces the choice (A/B runs).
+    // Few rows (the caller says so for a compact row list whose count lives on the device: PIKA_DG_FEW_ROWS; or M itself
+    // is small): the split-reduction kernel, one 16/32-column tile of 32 rows per workgroup.  PIKA_DGEMM_SK=0 / 1 forces the
+    // choice (A/B runs).
     static const int sk_env = [] { const char *e = getenv("PIKA_DGEMM_SK"); return e ? atoi(e) : -1; }();
-    const bool sk = ln || (sk_env >= 0 ? sk_env != 0 : (q->m_dev != nullptr || q->rowlist != nullptr || q->M <= 256));
+    const bool sk = ln || (sk_env >= 0 ? sk_env != 0 : ((q->flags & PIKA_DG_FEW_ROWS) || q->M <= 256));
     // 4 waves per workgroup take K <= 512 in ONE request round, 8 waves K <= 1024; beyond (K up to 4096) 8 waves in
     // rounds of 4 k-tiles.  Wide products (N >= 1024) take 32-column tiles: all tiles of a ~170-row launch resident at once.
     const bool sk_fits = p.KT <= 128 && !(ln && p.KT > 32);

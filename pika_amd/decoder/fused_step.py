@@ -24,7 +24,7 @@ import torch
 from .. import _lib
 
 _vp, _ll, _i = ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int
-DG_RELU, DG_GATE, DG_ROWMASK = 1, 2, 4
+DG_RELU, DG_GATE, DG_ROWMASK, DG_FEW_ROWS = 1, 2, 4, 8
 MAX_LAYERS = 4
 
 
@@ -224,7 +224,8 @@ class FusedSearch(object):
         g.node, g.skip_node = self.node.data_ptr(), self.dump_node
         g.e_all, g.t_idx, g.T, g.beam = self.e_all.data_ptr(), self.t_idx.data_ptr(), self.T, self.K
         g.M, g.N, g.K, g.terms = M, W.N, W.K, W.terms
-        g.flags = (DG_RELU if relu else 0) | (DG_GATE if gate else 0) | (DG_ROWMASK if rowmask else 0)
+        g.flags = ((DG_RELU if relu else 0) | (DG_GATE if gate else 0) | (DG_ROWMASK if rowmask else 0) |
+                   (DG_FEW_ROWS if m_dev is not None else 0))      # compact rows: ~1/6 of the beam rows emit a label in a step
         _lib.check(_lib.lib().pika_dgemm(ctypes.byref(g), _stream()), "pika_dgemm(M=%d,N=%d,K=%d)" % (M, W.N, W.K))
 
     def _prednet(self, anc_dst, state_dst, count):
