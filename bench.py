@@ -798,6 +798,25 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
         ts["parity"] = ("encoder activations and RNN-T loss within 1e-3 of the reference model's fp32 golden on the full "
                         "architecture in this arithmetic (tests/test_model_full.py::test_gpu_modes_against_reference_full_golden"
                         "[mixed])" if args.precision in (None, "mixed") else "see the mode's row in tests/test_model_full.py")
+        if args.precision is None and getattr(args, "pred_net", "transformer") == "transformer":
+            # the configuration every shipped recipe trains (egs/train_transducer_bmuf_otfaug.sh:32, dec_type=rnn): the same
+            # step with the 2-layer LSTM prediction network (trainer/model/transducer.py:55-61), same arithmetic, same graphs
+            from types import SimpleNamespace
+            a2 = SimpleNamespace(**vars(args))
+            a2.pred_net = "rnn"
+            old, G.PRECISION = G.PRECISION, "mixed"
+            try:
+                rn = run_train_step(a2, R_, max(5, steps // 2), 3)
+                ts["lstm_prediction_net"] = {
+                    "ms_per_step": rn["ms_per_step"], "value": rn["value"], "unit": rn["unit"], "loss": rn["config"]["loss"],
+                    "note": "dec_type=rnn as in the recipes: nn.LSTM (MIOpen recurrence, fp32) inside the captured step, layer by "
+                            "layer with torch's dropout between the layers (the library's own inter-layer dropout keeps the mask of "
+                            "the capture); parity at full width: tests/test_model_full.py::test_gpu_lstm_prediction_net_against_"
+                            "reference_full_golden[mixed]"}
+            except Exception as e:
+                ts["lstm_prediction_net"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                G.PRECISION = old
         if args.precision is None:
             old, G.PRECISION = G.PRECISION, "bf16"
             try:

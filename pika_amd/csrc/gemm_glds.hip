@@ -183,6 +183,7 @@ struct PPArgs {
     float *g_out;
     int g_T, g_U1, g_blank;
     int nx, ntiles;                    // output tiles per row of tiles / in total (filled in by launch_pp_epi)
+    int gm;                            // tile rows per band of the XCD-aware walk (filled in by launch_pp_epi)
     int f16;                           // the 16-bit operands are fp16 (EPI 0 only: PIKA_GEMM_F16_OPERANDS)
 #ifdef PIKA_PP_TRACE
     unsigned long long *trace;         // tools/pp_trace.hip: [wg < 8][group 2][tile < 16][24] time stamps
@@ -226,11 +227,12 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     // ... and the run is walked in bands of PP_GM tile rows, column by column inside a band: the ~32 tiles an XCD
     // works on at any moment form a PP_GM x (32 / PP_GM) block that shares PP_GM + 32 / PP_GM operand panels in its
     // L2 instead of the 1 + 32 of a row-major walk (fewer L2 misses = shorter load latency = faster LDS fill)
+    const int gm = P.gm;                // rows of a band (PP_GM; PIKA_GEMM_PP_GM for A/B runs)
     auto tile_mn = [&](int tile, int &tm, int &tn) {
-        const int band = tile / (PP_GM * nx), in = tile - band * (PP_GM * nx);
-        const int rows = min(PP_GM, ntiles / nx - band * PP_GM);
+        const int band = tile / (gm * nx), in = tile - band * (gm * nx);
+        const int rows = min(gm, ntiles / nx - band * gm);
         tn = in / rows;
-        tm = band * PP_GM + (in - tn * rows);
+        tm = band * gm + (in - tn * rows);
     };
 
     // Sources: a scalar 64-bit base per operand and tile plus a 32-bit byte offset per lane and piece (the host
@@ -960,6 +962,8 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
     if (nt > 0x7fffffffLL - 65536) return PIKA_ETOOBIG;
     PPArgs Q = P;
     Q.nx = (P.N + 255) / 256; Q.ntiles = (int)nt;
+    static const int gm_env = [] { const char *e = getenv("PIKA_GEMM_PP_GM"); return e ? atoi(e) : 0; }();
+    Q.gm = gm_env > 0 ? gm_env : PP_GM;
     Q.salt = pika_internal_dropout_salt();
     // persistent: one workgroup per CU (128 KB of LDS each) walks its share of the output tiles.
     // PIKA_GEMM_PP_WGS=0 launches one workgroup per tile instead (for A/B timing).

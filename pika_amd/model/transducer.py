@@ -9,6 +9,26 @@ from .encoder import Net as TdnnTransformerEncoder
 from .prednet import Net as ConvTransformerPredNet
 
 
+def _lstm_forward(rnn, x):
+    """nn.LSTM(x)[0] (trainer/model/transducer.py:93-96).  Training on a HIP device with dropout between the layers: the
+    layers are run one at a time with torch's own dropout in between -- same function, same parameters -- because the
+    dropout INSIDE the library's multi-layer call keeps the mask it drew when a hipGraph was captured: every replay of
+    the graphed training step (pika_amd/train_graph.py) would drop the same units for the rest of the run
+    (tests/test_train_step_gpu.py::test_graphed_lstm_prediction_net_draws_new_dropout_masks_per_replay).  torch's dropout
+    takes its Philox offset from the graph-registered generator state and draws a new mask per replay."""
+    if not (rnn.training and rnn.dropout > 0.0 and rnn.num_layers > 1 and x.is_cuda and rnn.batch_first
+            and not rnn.bidirectional and getattr(rnn, "proj_size", 0) == 0 and rnn.bias):
+        return rnn(x)[0]
+    out = x
+    zeros = x.new_zeros(1, x.shape[0], rnn.hidden_size)
+    for l in range(rnn.num_layers):
+        w = [getattr(rnn, n % l) for n in ("weight_ih_l%d", "weight_hh_l%d", "bias_ih_l%d", "bias_hh_l%d")]
+        out = torch._VF.lstm(out, (zeros, zeros), w, True, 1, 0.0, True, False, True)[0]
+        if l + 1 < rnn.num_layers:
+            out = torch.nn.functional.dropout(out, rnn.dropout, True)
+    return out
+
+
 class Net(nn.Module):
     """`opt` supplies rnn_size, local_rank, decoder_type, brnn, encoder_type, dropout,
     enc_layers, dec_layers, embd_dim, padding_idx (transducer.py:27-68)."""
@@ -56,7 +76,7 @@ class Net(nn.Module):
     def predict(self, y):
         """Prediction network on label sequences that already start with SOS (= blank = 0)."""
         if self.decoder_type == 'rnn':
-            return self.decoder(self.embed(y))[0]
+            return _lstm_forward(self.decoder, self.embed(y))
         return self.decoder(y)
 
     def forward(self, x, y, x_len=None, softmax=True):

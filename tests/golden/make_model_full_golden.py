@@ -5,7 +5,8 @@ strided sample of the log-probs, the RNN-T costs of the reference's log-probs (f
 reference's own loss is the absent third-party warp_rnnt), and of EVERY parameter gradient of `costs.sum()` the
 compact form of tests/golden/mbr_hooks.py (512 strided entries + L2 norm, sum, max, numel), plus the BatchNorm
 running statistics after the step.  About a minute of CPU.
-    python tests/golden/make_model_full_golden.py
+    python tests/golden/make_model_full_golden.py          # conv-transformer prediction net -> model_full_train.npz
+    python tests/golden/make_model_full_golden.py rnn      # the recipes' 2-layer LSTM prediction net -> model_full_train_rnn.npz
 """
 import os
 import sys
@@ -26,11 +27,13 @@ from mbr_hooks import compact  # noqa: E402
 
 transducer = pika_ref.load_reference("trainer.model.transducer")
 torch.set_num_threads(8)
-net = F.build(transducer, pika_ref.seeded_state_dict)
+DEC = sys.argv[1] if len(sys.argv) > 1 else "transformer"
+assert DEC in ("transformer", "rnn")
+net = F.build(transducer, pika_ref.seeded_state_dict, DEC)
 x, y, x_len, y_len = F.inputs()
 seen = {}
 net.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("enc", o.detach()))
-net.decoder.register_forward_hook(lambda m, i, o: seen.__setitem__("pred", o.detach()))
+net.decoder.register_forward_hook(lambda m, i, o: seen.__setitem__("pred", (o[0] if isinstance(o, tuple) else o).detach()))
 t0 = time.time()
 lp = net(x, y, x_len, True)
 costs, g = O.rnnt_loss(lp.detach().numpy(), y.numpy(), x_len.numpy(), y_len.numpy())      # fp64
@@ -47,6 +50,6 @@ out["costs"] = costs
 out["enc_absmax"] = np.array(float(seen["enc"].abs().max()))
 for k in ("encoder.bn_in.running_mean", "encoder.hidden_bn.8.running_var", "encoder.bn_final.running_var"):
     out["buf:" + k] = net.state_dict()[k].numpy()
-path = os.path.join(HERE, "model_full_train.npz")
+path = os.path.join(HERE, "model_full_train.npz" if DEC == "transformer" else "model_full_train_rnn.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -16,14 +16,16 @@ U_LENS = [12, 9, 11]
 SEED, SCALE = 929, 0.02
 
 
-def opt():
-    return SimpleNamespace(rnn_size=H, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn",
+def opt(decoder_type="transformer"):
+    """decoder_type "rnn": the 2-layer LSTM prediction network every shipped recipe trains (egs/train_transducer_bmuf_otfaug.sh:32,
+    trainer/model/transducer.py:55-61)."""
+    return SimpleNamespace(rnn_size=H, local_rank=0, decoder_type=decoder_type, brnn=False, encoder_type="tdnn",
                            dropout=0.0, enc_layers=4, dec_layers=2, embd_dim=EMB, padding_idx=V)
 
 
-def build(transducer_mod, seeded_state_dict):
+def build(transducer_mod, seeded_state_dict, decoder_type="transformer"):
     torch.manual_seed(0)
-    net = transducer_mod.Net(opt(), D_IN, V)
+    net = transducer_mod.Net(opt(decoder_type), D_IN, V)
     net.load_state_dict(seeded_state_dict(net, SEED, scale=SCALE))
     with torch.no_grad():
         net.fc2.weight *= 25.0

@@ -54,13 +54,13 @@ def grad_report(got, z):
     return rows
 
 
-def run(device, loss):
+def run(device, loss, decoder_type="transformer"):
     from pika_amd.model import transducer
-    net = F.build(transducer, seeded_state_dict).to(device)
+    net = F.build(transducer, seeded_state_dict, decoder_type).to(device)
     x, y, x_len, y_len = [t.to(device) for t in F.inputs()]
     seen = {}
     net.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("enc", o.detach()))
-    net.decoder.register_forward_hook(lambda m, i, o: seen.__setitem__("pred", o.detach()))
+    net.decoder.register_forward_hook(lambda m, i, o: seen.__setitem__("pred", (o[0] if isinstance(o, tuple) else o).detach()))
     lp = net(x, y, x_len, True)
     costs = loss(lp, y.int(), x_len, y_len)
     costs.sum().backward()
@@ -83,7 +83,7 @@ def summarize(tag, net, seen, lp, costs, got, z):
     rest = [r for r in rows if not r[0].startswith("encoder.")]
     w_enc = max(enc, key=lambda r: r[1])
     w_rest = max(rest, key=lambda r: r[1])
-    w_rest2 = max((r for r in rest if "linear_keys" not in r[0]), key=lambda r: r[1])
+    w_rest2 = max((r for r in rest if "linear_keys" not in r[0]), key=lambda r: r[1])      # (an LSTM net has none)
     med_enc = float(np.median([r[1] for r in enc]))
     print("\n[%s] encoder act %.2e  pred-net act %.2e  log-probs %.2e  costs %.2e | gradients: encoder median %.2e worst "
           "%.2e (%s); prediction net + joint worst %.2e (%s), without key projections %.2e (%s)" % (
@@ -112,6 +112,53 @@ def test_cpu_module_tree_matches_reference_full_golden():
     r = summarize("cpu", *run("cpu", _Loss.apply), z)
     assert r["enc"] < 1e-4 and r["pred"] < 1e-4 and r["lp"] < 1e-4 and r["cost"] < 1e-5 and r["bn"] < 1e-4, r
     assert r["g_rest"] < 1e-3 and r["g_enc"] < 2e-2, r
+
+
+GOLD_RNN = os.path.join(HERE, "golden", "model_full_train_rnn.npz")
+
+
+def test_cpu_module_tree_matches_reference_full_golden_lstm_prediction_net():
+    """The recipes' configuration (dec_type=rnn, egs/train_transducer_bmuf_otfaug.sh:32): our module tree with the 2-layer
+    LSTM prediction network on stock torch CPU ops is the reference's computation (golden: make_model_full_golden.py rnn)."""
+    from oracle import rnnt as O
+
+    class _Loss(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, lp, y, tl, ul):
+            c, g = O.rnnt_loss(lp.detach().numpy(), y.numpy(), tl.numpy(), ul.numpy())
+            ctx.save_for_backward(torch.from_numpy(g.astype(np.float32)))
+            return torch.from_numpy(c.astype(np.float32))
+
+        @staticmethod
+        def backward(ctx, go):
+            return ctx.saved_tensors[0] * go.view(-1, 1, 1, 1), None, None, None
+    torch.set_num_threads(8)
+    z = np.load(GOLD_RNN)
+    r = summarize("cpu, LSTM prediction net", *run("cpu", _Loss.apply, "rnn"), z)
+    assert r["enc"] < 1e-4 and r["pred"] < 1e-4 and r["lp"] < 1e-4 and r["cost"] < 1e-5 and r["bn"] < 1e-4, r
+    assert r["g_rest"] < 1e-3 and r["g_enc"] < 2e-2, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["mixed", "fp32"])
+def test_gpu_lstm_prediction_net_against_reference_full_golden(hip_device, mode):
+    """The configuration every shipped recipe trains -- TDNN-Transformer encoder + 2-layer LSTM prediction network
+    (trainer/model/transducer.py:55-61,93-96) -- at full width in TRAIN mode against the reference's golden: the benchmarked
+    "mixed" arithmetic and the exact mode, the tolerances of the conv-transformer rows above (the LSTM itself runs in fp32:
+    MIOpen's recurrence; encoder, joint and loss are the HIP path)."""
+    from pika_amd import gemm as G
+    from pika_amd.rnnt import RNNTLoss
+    z = np.load(GOLD_RNN)
+    old = G.PRECISION
+    G.PRECISION = mode
+    try:
+        r = summarize(mode + ", LSTM prediction net", *run(hip_device, RNNTLoss(blank=0).apply, "rnn"), z)
+    finally:
+        G.PRECISION = old
+    t_enc, t_cost, t_genc, t_grest, t_grest2 = TOL[mode]
+    assert r["enc"] < t_enc and r["pred"] < max(t_enc, 1e-3) and r["cost"] < t_cost, (mode, r)
+    assert r["g_enc"] < t_genc and r["g_rest"] < min(t_grest, 8e-2) and r["g_rest_nokeys"] < t_grest2, (mode, r)
+    assert r["bn"] < max(t_enc, 1e-3), (mode, r)
 
 
 TOL = {  # mode: (encoder act, costs, encoder gradients (worst), prediction net + joint gradients: worst, worst without

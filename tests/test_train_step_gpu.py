@@ -140,14 +140,15 @@ def test_bf16_mode_matches_parity_mode_on_the_full_architecture(hip_device):
     print("worst relative gradient difference:", worst)
 
 
-def _small_step_harness(hip_device, dropout, V=500):
+def _small_step_harness(hip_device, dropout, V=500, decoder_type="transformer"):
     sys.path.insert(0, os.path.join(ROOT, "pika_amd", "dropin"))
     from pika_amd import optim as fused_optim
     from pika_amd.model.transducer import Net
     from pika_amd.rnnt import RNNTLoss
     B, T, U = 4, 300, 8        # V = 500: the joint's general (dense log-prob) form; V = 512: the lazy / compact-gradient form
-    opt = SimpleNamespace(rnn_size=256, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn",
-                          dropout=dropout, enc_layers=4, dec_layers=1, embd_dim=64, padding_idx=V)
+    opt = SimpleNamespace(rnn_size=256, local_rank=0, decoder_type=decoder_type, brnn=False, encoder_type="tdnn",
+                          dropout=dropout, enc_layers=4, dec_layers=1 if decoder_type == "transformer" else 2, embd_dim=64,
+                          padding_idx=V)
     torch.manual_seed(11)
     model = Net(opt, 240, V).to(hip_device).train()
     for m in model.modules():
@@ -164,15 +165,15 @@ def _small_step_harness(hip_device, dropout, V=500):
     return model, RNNTLoss(blank=0).apply, batches, fused_optim
 
 
-@pytest.mark.parametrize("mode", ["mixed", "bf16"])
-def test_graphed_train_step_equals_the_eager_step(hip_device, mode):
+@pytest.mark.parametrize("mode,pred_net", [("mixed", "transformer"), ("bf16", "transformer"), ("mixed", "rnn")])
+def test_graphed_train_step_equals_the_eager_step(hip_device, mode, pred_net):
     """pika_amd.train_graph.GraphedTrainStep: the captured launch sequence is the eager one -- the losses of two eager +
     three replayed steps equal those of five eager steps, and so do the parameter updates (dropout off; up to the order
     of the float atomics in the BatchNorm / split-K reductions, which a ReLU network amplifies: in the L2 norm)."""
     import copy
     from pika_amd import gemm as G
     from pika_amd.train_graph import GraphedTrainStep
-    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0)
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.0, decoder_type=pred_net)
     ref = copy.deepcopy(model)
     init = [p.detach().clone() for p in model.parameters()]
     old = G.PRECISION
@@ -211,6 +212,32 @@ def test_graphed_train_step_equals_the_eager_step(hip_device, mode):
     for k, v in model.state_dict().items():
         if "running" in k:
             assert torch.allclose(v, ref.state_dict()[k], rtol=1e-2, atol=1e-3), k
+
+
+def test_graphed_lstm_prediction_net_draws_new_dropout_masks_per_replay(hip_device):
+    """The recipes' LSTM prediction network inside the captured step: nn.LSTM's inter-layer dropout (MIOpen) must not freeze
+    to the mask of the capture -- replays of the SAME batch with a zero learning rate give different losses."""
+    from pika_amd import gemm as G
+    from pika_amd.train_graph import GraphedTrainStep
+    model, loss_fn, batches, fused_optim = _small_step_harness(hip_device, 0.3, decoder_type="rnn")
+    for m in model.modules():           # only the LSTM's own dropout is on
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float) and not isinstance(m, torch.nn.LSTM):
+            m.dropout = 0.0
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        gs = GraphedTrainStep(model, loss_fn, lambda: torch.optim.SGD(model.parameters(), 0.0, momentum=0.9, nesterov=True),
+                              clip=3.0, warmup=1)
+        losses = [gs(*batches[0]).item() for _ in range(6)]
+        assert len(gs.graphs) == 1
+        assert len(set(round(v, 3) for v in losses[2:])) >= 3, losses      # replays differ from each other
+        gs.close()
+    finally:
+        fused_optim.uninstall()
+        G.PRECISION = old
 
 
 def test_graphed_train_step_draws_new_dropout_masks_per_replay(hip_device):
