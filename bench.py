@@ -43,6 +43,35 @@ CPU_REFERENCE = {
 }
 
 
+def cpu_reference(leg, live):
+    """The `cpu_baseline_reference` entry of a leg.  live (rank 0 of a 1-GPU run with CPU baselines on): the REFERENCE's own
+    modules are timed here and now, on this host's cores, by tools/time_reference_cpu.py in a child process (its shims
+    replace torch.Tensor.cuda: never in this process) -- from /root/reference, or on the GPU box from the copy that
+    tools/stage_reference.py staged under the git-ignored _ref_scratch/ ("timed on the same box's host
+    cores").  Otherwise, or if that fails: the round-4 figures of the 8-core build container, labelled as such."""
+    import subprocess
+    const = dict(CPU_REFERENCE[leg], measured="constants: " + CPU_REFERENCE["source"])
+    name = {"train_step": "train", "decode": "decode", "mbr_step": "mbr"}[leg]
+    staged = os.path.isfile(os.path.join(ROOT, "_ref_scratch", "reference", "trainer", "model", "transducer.py"))
+    if not live or not (os.path.isdir("/root/reference") or staged) or os.environ.get("PIKA_BENCH_REF_LIVE", "1") == "0":
+        return const
+    threads = min(os.cpu_count() or 8, 32)
+    try:
+        env = dict(os.environ, PIKA_REF_THREADS=str(threads), PIKA_REF_TRAIN_STEPS="1", HIP_VISIBLE_DEVICES="",
+                   CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+        t0 = time.perf_counter()
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference_cpu.py"), name], env=env,
+                             capture_output=True, text=True, timeout=900)
+        res = json.loads(out.stdout.strip().splitlines()[-1])[name]
+        res["measured"] = "live on this host (%d of %d cores), %.0f s in all; reference from %s" % (
+            threads, os.cpu_count() or 0, time.perf_counter() - t0,
+            "/root/reference" if os.path.isdir("/root/reference") else "_ref_scratch/reference (tools/stage_reference.py)")
+        return res
+    except Exception as e:
+        const["live_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        return const
+
+
 def make_inputs(B, T, U, V, dev, seed):
     """SURVEY 8d M1 inputs: log_softmax(randn) built utterance by utterance (no 2x temp)."""
     g = torch.Generator(device=dev)
@@ -78,8 +107,9 @@ def cpu_baseline(lp, labels, tl, ul, n_utts, min_seconds=10.0):
             break
     return {"value": done / el, "unit": "utterances/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%d utterances of the same (T=%d,U=%d,V=%d) batch, oracle fp32 C/OpenMP port "
-                      "(costs + dense grads), %.1f s" % (done, x.shape[1], x.shape[2] - 1,
-                                                       x.shape[3], el)}, costs
+                      "(costs + dense grads), %.1f s.  A PORT, not a reference timing: the reference has no CPU loss (its "
+                      "loss is the third-party CUDA binding warp_rnnt, absent here); the legs that have a reference CPU "
+                      "path carry it as cpu_baseline_reference" % (done, x.shape[1], x.shape[2] - 1, x.shape[3], el)}, costs
 
 
 def train_step_workload(args, R_):
@@ -855,7 +885,7 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
                                             f32["config"]["loss"], ts["config"]["loss"])}
         if with_cpu and R_.rank == 0:
             ts["cpu_baseline"] = cpu_baseline_train_step(args)
-        ts["cpu_baseline_reference"] = CPU_REFERENCE["train_step"]
+        ts["cpu_baseline_reference"] = cpu_reference("train_step", with_cpu and R_.rank == 0)
     except Exception as e:  # the headline line must survive a failure of a secondary leg
         import traceback
         ts = {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-800:]}
@@ -916,7 +946,7 @@ def leg_decode(args, R_, with_cpu):
         audio_s = a.batch * a.frames / 100.0
         d = decode_report(a, step, ret, el, audio_s, R_.world, cal_labels)
         d = {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")}
-        d["cpu_baseline_reference"] = CPU_REFERENCE["decode"]
+        d["cpu_baseline_reference"] = cpu_reference("decode", with_cpu and R_.rank == 0)
         if with_cpu and R_.rank == 0:
             d["cpu_baseline"] = cpu_baseline_decode(a, decode_workload.blank_bias)
         if step.decoder.decode_precision == "fp32":
@@ -1159,17 +1189,105 @@ def leg_mbr(args, R_, with_cpu, steps=3, warmup=1):
                                       search_ms, el * 1e3, dec.timing.get("launches_per_step", 0))},
              "parity": "N-best identical to the unchanged reference script's and gradients within the bf16-backward budget in "
                        "this arithmetic (tests/test_mbr.py::test_gpu_native_mbr_step_in_the_benchmarked_arithmetic)",
-             "cpu_baseline_reference": CPU_REFERENCE["mbr_step"]}
+             "cpu_baseline_reference": None}
         step.close() if hasattr(step, "close") else None
         del step
         torch.cuda.empty_cache()
         if with_cpu and R_.rank == 0:
             d["cpu_baseline"] = cpu_baseline_mbr(a, float(info.get("blank_bias", 1.0)))
+        d["cpu_baseline_reference"] = cpu_reference("mbr_step", with_cpu and R_.rank == 0)
     except Exception as e:
         import traceback
         d = {"error": "%s: %s" % (type(e).__name__, e), "trace": traceback.format_exc()[-800:]}
     torch.cuda.empty_cache()
     return d
+
+
+def run_m1p(args, R_, steps, warmup):
+    """SURVEY 8d M1': fused boundary logits -> (costs, d/dlogits); no log-prob tensor, no dense lp gradient.  Returns the
+    JSON object of the workload on rank 0 (None elsewhere)."""
+    from warp_rnnt import RNNTLoss
+    from pika_amd import rnnt as R
+    from pika_amd.rnnt import rnnt_loss_from_logits
+    dev, rank, world = R_.dev, R_.rank, R_.world
+    B, T, U, V = args.batch, args.frames, args.labels, args.vocab
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + 100 * rank)
+    logits = torch.randn(B, T, U + 1, V, generator=g, device=dev).requires_grad_(True)
+    g.manual_seed(1235 + 100 * rank)
+    labels = torch.randint(1, V, (B, U), generator=g, device=dev, dtype=torch.int32)
+    tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+    ul = torch.full((B,), U, dtype=torch.int32, device=dev)
+
+    def step():
+        logits.grad = None
+        c = rnnt_loss_from_logits(logits, labels, tl, ul)
+        c.sum().backward()
+        return c
+    for _ in range(warmup):
+        step()
+    R.KERNEL_EVENTS = {"fwd": [], "bwd": []}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        costs = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    ev, R.KERNEL_EVENTS = R.KERNEL_EVENTS, None
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item()) / steps
+    if rank != 0:
+        return None
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
+    bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]]))
+    bytes_per_launch = 3.0 * B * T * (U + 1) * V * 4          # SURVEY 8d M1': 3X
+    achieved = bytes_per_launch / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
+    # the composition it replaces, on the same logits
+    lp = torch.log_softmax(logits.detach(), dim=-1)
+    c_ref = RNNTLoss(blank=0).apply(lp, labels, tl, ul)
+    return {
+        "metric": "utterances/sec fused log-softmax + RNNT loss fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
+        "value": B * world / el, "unit": "utterances/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "rnnt_loss_M1p (SURVEY 8d M1'): rnnt_loss_from_logits(randn logits (B,T,U+1,V))"
+                               ".sum().backward(), fp32 d/dlogits out", "batch_per_gpu": B, "T": T, "U": U, "V": V,
+                   "max_rel_cost_diff_vs_log_softmax_plus_loss": float(((costs - c_ref).abs() / c_ref.abs()).max())},
+        "roofline": {"bound": "hbm", "kernel": "rnnt_lse_gather_kernel + rnnt_dlogits_fused_kernel",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                     "forward_ms": fwd_ms, "backward_ms": bwd_ms}}
+
+
+def leg_m1_variants(args, R_):
+    """Cheap extras of the default line, so that neither path goes unobserved: the ragged variant of M1 (T_n ~
+    U{0.6 T..T}, U_n ~ U{0.4 U..U}) and M1' (logits -> costs and d/dlogits in one pass over the lattice)."""
+    from types import SimpleNamespace
+    out = {}
+    a = SimpleNamespace(**vars(args))
+    a.steps, a.warmup, a.no_cpu_baseline = 5, 2, True
+    try:
+        r = leg_rnnt_loss_m1(a, R_, ragged=True)
+        if R_.rank == 0:
+            out["rnnt_loss_M1_ragged"] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                          "roofline_frac": r["roofline"]["frac"], "config": r["config"]}
+    except Exception as e:
+        out["rnnt_loss_M1_ragged"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+    try:
+        r = run_m1p(args, R_, 5, 2)
+        if R_.rank == 0:
+            out["rnnt_loss_M1p"] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                    "roofline": r["roofline"], "config": r["config"]}
+    except Exception as e:
+        out["rnnt_loss_M1p"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -1206,6 +1324,7 @@ def main():
                     help="decode: the constructed model that emits one label per input burst (default), or the round-1..3 "
                          "random model with a calibrated blank bias")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-m1-variants", action="store_true", help="default run: skip the ragged-M1 and M1' extras")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the secondary full-train-step measurement of the default run")
     ap.add_argument("--no-decode", action="store_true", help="skip the secondary decode-RTF measurement of the default run")
@@ -1253,58 +1372,9 @@ def main():
         R_.finish()
         return
     if args.workload == "rnnt_loss_M1p":
-        # SURVEY 8d M1': fused boundary logits -> (costs, d/dlogits); no log-prob tensor, no dense lp gradient
-        from pika_amd.rnnt import rnnt_loss_from_logits
-        g = torch.Generator(device=dev)
-        g.manual_seed(1234 + 100 * rank)
-        logits = torch.randn(B, T, U + 1, V, generator=g, device=dev).requires_grad_(True)
-        g.manual_seed(1235 + 100 * rank)
-        labels = torch.randint(1, V, (B, U), generator=g, device=dev, dtype=torch.int32)
-        tl = torch.full((B,), T, dtype=torch.int32, device=dev)
-        ul = torch.full((B,), U, dtype=torch.int32, device=dev)
-
-        def step():
-            logits.grad = None
-            c = rnnt_loss_from_logits(logits, labels, tl, ul)
-            c.sum().backward()
-            return c
-        for _ in range(args.warmup):
-            step()
-        R.KERNEL_EVENTS = {"fwd": [], "bwd": []}
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            costs = step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        ev, R.KERNEL_EVENTS = R.KERNEL_EVENTS, None
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item()) / args.steps
+        d = run_m1p(args, R_, args.steps, args.warmup)
         if rank == 0:
-            fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
-            bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]]))
-            bytes_per_launch = 3.0 * B * T * (U + 1) * V * 4          # SURVEY 8d M1': 3X
-            achieved = bytes_per_launch / ((fwd_ms + bwd_ms) * 1e-3) / 1e9
-            # the composition it replaces, on the same logits
-            lp = torch.log_softmax(logits.detach(), dim=-1)
-            c_ref = RNNTLoss(blank=0).apply(lp, labels, tl, ul)
-            print(json.dumps({
-                "metric": "utterances/sec fused log-softmax + RNNT loss fwd+bwd (T=%d,U=%d,V=%d)" % (T, U, V),
-                "value": B * world / el, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "rnnt_loss_M1p (SURVEY 8d M1'): rnnt_loss_from_logits(randn logits (B,T,U+1,V))"
-                                       ".sum().backward(), fp32 d/dlogits out", "batch_per_gpu": B, "T": T, "U": U, "V": V,
-                           "max_rel_cost_diff_vs_log_softmax_plus_loss": float(((costs - c_ref).abs() / c_ref.abs()).max())},
-                "roofline": {"bound": "hbm", "kernel": "rnnt_lse_gather_kernel + rnnt_dlogits_fused_kernel",
-                             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
-                             "forward_ms": fwd_ms, "backward_ms": bwd_ms}}), flush=True)
+            print(json.dumps(d), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -1337,7 +1407,7 @@ def main():
                 "ms_per_step": el * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "N-best search: %s; training part: %s" % (step.decoder.decode_precision,
                                                                  __import__("pika_amd.gemm", fromlist=["x"]).PRECISION),
-                "cpu_baseline_reference": CPU_REFERENCE["mbr_step"],
+                "cpu_baseline_reference": cpu_reference("mbr_step", world == 1 and not args.no_cpu_baseline),
                 "data": "synthetic",
                 "config": {"workload": "mbr_step (BASELINE configs[3] / SURVEY 8d M4): N-best decode (beam %d) + encoder "
                                        "fwd + RNN-T loss bwd + risk terms + trajectory joint with the HIP risk-gradient "
@@ -1353,13 +1423,17 @@ def main():
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_train_step(args)
-            out["cpu_baseline_reference"] = CPU_REFERENCE["train_step"]
+            out["cpu_baseline_reference"] = cpu_reference("train_step", world == 1 and not args.no_cpu_baseline)
             print(json.dumps(out), flush=True)
         R_.finish()
         return
     out = leg_rnnt_loss_m1(args, R_, ragged=args.ragged)
     if rank == 0 and R_.selfcheck is not None:
         out["rccl_selfcheck"] = R_.selfcheck
+    if not args.no_m1_variants and not args.ragged:
+        extra = leg_m1_variants(args, R_)
+        if rank == 0:
+            out.update(extra)
     if not args.no_train_step:
         ts = leg_train_step(args, R_, max(5, min(args.steps, 10)), 2, world == 1 and not args.no_cpu_baseline)
         if rank == 0:

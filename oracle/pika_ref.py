@@ -13,7 +13,26 @@ import sys
 
 import torch
 
-REF = "/root/reference"
+import os
+
+
+def _reference_root():
+    """/root/reference in the build container; on the GPU box (where it does not exist) the staged copy of the hot-path
+    modules that tools/stage_reference.py puts under the git-ignored _ref_scratch/ -- it travels with the snapshot like a
+    built .so -- so that bench.py's cpu_baseline legs can time the REFERENCE itself on that host.  PIKA_REF_ROOT overrides."""
+    env = os.environ.get("PIKA_REF_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference"):
+        return "/root/reference"
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_ref_scratch", "reference")
+
+
+REF = _reference_root()
+
+
+def available():
+    return os.path.isfile(os.path.join(REF, "trainer", "model", "transducer.py"))
 
 
 def seeded_state_dict(module, seed, scale=0.1):

@@ -23,7 +23,10 @@ def _lstm_forward(rnn, x):
     zeros = x.new_zeros(1, x.shape[0], rnn.hidden_size)
     for l in range(rnn.num_layers):
         w = [getattr(rnn, n % l) for n in ("weight_ih_l%d", "weight_hh_l%d", "bias_ih_l%d", "bias_hh_l%d")]
-        out = torch._VF.lstm(out, (zeros, zeros), w, True, 1, 0.0, True, False, True)[0]
+        # (the dropout argument of a ONE-layer call drops nothing -- there is no layer below the output -- but it selects the
+        # library's step-wise recurrence; without it the call takes a hipBLASLt path that cannot be captured at all:
+        # "operation would make the legacy stream depend on a capturing blocking stream", tools/lstm_capture_probe.py)
+        out = torch._VF.lstm(out, (zeros, zeros), w, True, 1, rnn.dropout, True, False, True)[0]
         if l + 1 < rnn.num_layers:
             out = torch.nn.functional.dropout(out, rnn.dropout, True)
     return out

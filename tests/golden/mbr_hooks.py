@@ -16,7 +16,8 @@ import types
 HERE = os.path.dirname(os.path.abspath(__file__))
 TESTS = os.path.dirname(HERE)
 ROOT = os.path.dirname(TESTS)
-REF = os.environ.get("PIKA_REF_ROOT", "/root/reference")
+REF = os.environ.get("PIKA_REF_ROOT") or ("/root/reference" if os.path.isdir("/root/reference") else os.path.join(
+    os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "_ref_scratch", "reference"))
 SCRIPT = os.path.join(REF, "trainer", "train_transducer_mbr_bmuf_otfaug.py")
 V = 40
 MODEL_ARGS = ["--encoder_type", "transformer", "--enc_layers", "2", "--decoder_type", "transformer", "--dec_layers", "1",

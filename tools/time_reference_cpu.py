@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Times the REFERENCE's own Python modules (imported from /root/reference under the shims of oracle/pika_ref.py) on the
-CPU cores of the build container -- the CPU baseline SURVEY 8(d) asks for ("the reference's own Python modules ... on
-PyTorch-CPU fp32").  /root/reference does not exist on the GPU box, so bench.py cannot run this there: it carries the
-figures below as `cpu_baseline_reference` constants (bench.py: CPU_REFERENCE) next to the port it times live.
+CPU cores of THIS host -- the CPU baseline SURVEY 8(d) asks for ("the reference's own Python modules ... on PyTorch-CPU
+fp32").  bench.py runs it as a child process for its `cpu_baseline_reference` entries: in the build container from
+/root/reference, on the GPU box from the staged copy under _ref_scratch/ (tools/stage_reference.py; oracle/pika_ref.py
+resolves the root); only where neither exists does bench.py fall back to the round-4 constants (bench.py: CPU_REFERENCE).
+PIKA_REF_THREADS / PIKA_REF_TRAIN_STEPS bound the sample.
 
     python tools/time_reference_cpu.py [train|decode|mbr ...]      # prints one JSON object; ~10 minutes for all three
 
@@ -58,7 +60,7 @@ def time_train(threads):
         return float(costs.sum())
     step()
     t0 = time.perf_counter()
-    n = 2
+    n = int(os.environ.get("PIKA_REF_TRAIN_STEPS", "2"))
     for _ in range(n):
         loss = step()
     el = (time.perf_counter() - t0) / n
@@ -184,8 +186,8 @@ if __name__ == "__main__":
         _mbr_child(int(sys.argv[2]))
         sys.exit(0)
     which = sys.argv[1:] or ["train", "decode", "mbr"]
-    threads = os.cpu_count() or 8
-    res = {"host": "build container, %d cores" % threads}
+    threads = int(os.environ.get("PIKA_REF_THREADS", os.cpu_count() or 8))
+    res = {"host": "%d of %d cores" % (threads, os.cpu_count() or 0)}
     for name in which:
         res[name] = {"train": time_train, "decode": time_decode, "mbr": time_mbr}[name](threads)
         print(name, json.dumps(res[name]), flush=True)
