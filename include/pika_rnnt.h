@@ -121,10 +121,14 @@ int pika_rnnt_fused_forward_gathered(const void *logits16, long long ld16, const
                                      int blank, float *costs, float *lse, void *workspace, void *stream);
 
 /* pika_rnnt_dlogits_compact_bf16 reading the RAW logits as fp16 (row pitch ld_in halves; lse = their row log-sum-exp from
- * the forward call above, required): d(logits) = scale * (g - softmax * sum(g)) as one bf16 matrix + column sums. */
+ * the forward call above, required): d(logits) = scale * (g - softmax * sum(g)) as one bf16 matrix + column sums.
+ * gathered (optional; with g_labels / g_blank as in pika_rnnt_fused_forward_gathered: the (rows, 2) f32 blank and label
+ * logits of every row): the softmax of those two columns -- the only entries that also carry the loss' own gradient terms -- is then taken from
+ * the fp32 values instead of the fp16 copy. */
 int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, const float *lse, const void *workspace,
                                          int B, int T, int U1, int V, int blank, void *out, long long ld_out, float scale,
-                                         float *colsum, void *stream);
+                                         float *colsum, const float *gathered, const int *g_labels, int g_blank,
+                                         void *stream);
 
 /* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces
  * F.log_softmax (trainer/model/transducer.py:111) + the loss + the log-softmax backward for a caller that owns

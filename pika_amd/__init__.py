@@ -22,12 +22,28 @@ def _hip_graph_workaround():
     replayed loop leaves the eager loop's, bit-identical for nine steps, at the tenth; any host synchronisation placed
     between the launches moves the step at which it happens; with the fast path off the two loops agree step for step,
     tools/graph_dropout_diff.py).  The flag is read once, when the HIP runtime initialises, so it is set here, at import
-    -- before torch makes its first HIP call in the normal order of imports.  Decode (one exec replayed back to back) is
+    -- before torch makes its first HIP call in the normal order of imports (`pika_amd.launch`, bench.py and tests/conftest.py
+    import this package first; a script that has already called torch.cuda.is_available() gets the eager step).  Decode (one exec replayed back to back) is
     not affected either way and costs the same with the flag off (171 vs 173 ms per batch at configs[4])."""
     if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ:
         return _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
-    torch = _sys.modules.get("torch")
-    late = torch is not None and torch.cuda.is_initialized()
+    # Has the HIP runtime already read its flags?  torch.cuda.is_initialized() only knows about torch's own lazy init --
+    # torch.cuda.is_available() / device_count() call hipGetDeviceCount without setting it -- so the question is put to the
+    # process itself: the runtime opens /dev/kfd when it starts.  Unknown (no /proc) counts as "already started" when torch
+    # is imported: the training step then stays eager, which is slower, never wrong.
+    started = None
+    try:
+        started = False
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    started = True
+                    break
+            except OSError:
+                pass
+    except OSError:
+        started = None
+    late = started if started is not None else ("torch" in _sys.modules)
     _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
     return not late
 

@@ -25,7 +25,8 @@ SIGNATURES = {
     "pika_rnnt_dlogits_compact_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
     "pika_rnnt_fused_forward_gathered": (_i, [_vp, _ll, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp,
                                                _vp, _vp]),
-    "pika_rnnt_dlogits_compact_bf16_f16in": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp]),
+    "pika_rnnt_dlogits_compact_bf16_f16in": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, _i, _vp, _ll, ctypes.c_float, _vp, _vp, _vp,
+                                                   _i, _vp]),
     "pika_rnnt_export_lattice": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     # include/pika_bmuf.h
     "pika_bmuf_delta": (_i, [_vp, _vp, _vp, _sz, _vp]),

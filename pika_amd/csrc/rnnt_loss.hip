@@ -512,7 +512,10 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const TI *__r
                                                                    float scale, int rpw,
                                                                    float *__restrict__ colsum,
                                                                    const float *__restrict__ lse,
-                                                                   long long ld_in = 0) {
+                                                                   long long ld_in = 0,
+                                                                   const float *__restrict__ gathered = nullptr,
+                                                                   const int *__restrict__ g_labels = nullptr,
+                                                                   int g_blank = 0, int T = 1, int U1 = 1) {
     if (ld_in == 0) ld_in = V;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = V >> 2, o4 = (int)(ld_out >> 2);
     const long long r0 = ((long long)blockIdx.x * 4 + wave) * rpw;
@@ -531,6 +534,15 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const TI *__r
         // log-sum-exp: their exp() must not reach the output (inf * 0).  The row is fetched regardless -- making
         // the loads wait for the metadata would serialise two memory latencies per row.
         const bool live = (m.gb != 0.f) || (m.ge != 0.f);
+        // (the gathered pair of a row belongs to column g_blank and to the label the PRODUCT was given for it: used where they
+        // are the loss' blank and label)
+        const bool use_gb = gathered && g_blank == blank;
+        bool use_ge = false;
+        if (gathered && m.ye >= 0) {
+            const int u = (int)(r % U1);
+            const long long b_ = r / ((long long)T * U1);
+            use_ge = u < U1 - 1 && g_labels[b_ * (U1 - 1) + u] == m.ye;
+        }
         f32x4 v[CQ];
 #pragma unroll
         for (int q = 0; q < CQ; ++q)
@@ -546,7 +558,12 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const TI *__r
                         const int col = 4 * i + e;
                         float g = col == blank ? m.gb : 0.f;
                         if (col == m.ye) g += m.ge;
-                        o[e] = scale * (g - __expf(v[q][e] - l) * s);
+                        float x = v[q][e];
+                        // the two columns whose gradient carries the loss' own terms: their logits in fp32 (the forward
+                        // product's epilogue kept them) instead of the fp16 copy -- 2^-11 of |logit| is percents of a softmax
+                        if (use_gb && col == blank) x = gathered[2 * r];
+                        if (use_ge && col == m.ye) x = gathered[2 * r + 1];
+                        o[e] = scale * (g - __expf(x - l) * s);
                     }
                 }
                 orow[i] = __builtin_convertvector(o, cbf16x4);
@@ -589,7 +606,10 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const TI *__
                                                                     float scale, int rpw,
                                                                     float *__restrict__ colsum,
                                                                     const float *__restrict__ lse,
-                                                                    long long ld_in = 0) {
+                                                                    long long ld_in = 0,
+                                                                    const float *__restrict__ gathered = nullptr,
+                                                                    const int *__restrict__ g_labels = nullptr,
+                                                                    int g_blank = 0, int T = 1, int U1 = 1) {
     if (ld_in == 0) ld_in = V;
     constexpr float LOG2E = 1.4426950408889634f;
     const int lane = threadIdx.x & 63;
@@ -650,18 +670,26 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const TI *__
         // the (at most two) columns that carry an extra term: the lane that stored their granule stores the element
         // again (same thread, same address: program order), their share of the column sums goes in separately
         if (live) {
+            // (their logits in fp32 where the forward product's epilogue kept them: `gathered`; the fp16 copy is 2^-11 of
+            // |logit| off, percents of a softmax value at |logit| ~ 30 -- and these two entries carry the gradient's own terms.
+            // The column sums took the bulk value above: they get the difference.)
             if (lane == gb_lane && m.gb != 0.f) {
-                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf((float)lrow[blank], LOG2E, nl2));
+                const float vb = k * __builtin_amdgcn_exp2f(__builtin_fmaf((float)lrow[blank], LOG2E, nl2));
+                const float v = (gathered && g_blank == blank) ? k * __builtin_amdgcn_exp2f(__builtin_fmaf(gathered[2 * r], LOG2E, nl2)) : vb;
                 orow[blank] = (__bf16)(v + scale * m.gb);
-                cs_blank += scale * m.gb;
+                cs_blank += scale * m.gb + (v - vb);
             }
             const int ye = m.ye;
             if (ye >= 0 && m.ge != 0.f && lane == ((ye >> 3) & 63)) {
-                const float v = k * __builtin_amdgcn_exp2f(__builtin_fmaf((float)lrow[ye], LOG2E, nl2));
+                const float vb = k * __builtin_amdgcn_exp2f(__builtin_fmaf((float)lrow[ye], LOG2E, nl2));
+                // (the gathered label logit belongs to the label the PRODUCT was given for this row: used where it is the loss')
+                const int u = (int)(r % U1);
+                const bool mine = gathered && u < U1 - 1 && g_labels[(r / ((long long)T * U1)) * (U1 - 1) + u] == ye;
+                const float v = mine ? k * __builtin_amdgcn_exp2f(__builtin_fmaf(gathered[2 * r + 1], LOG2E, nl2)) : vb;
                 float add = scale * m.ge;
                 if (ye == blank && m.gb != 0.f) add += scale * m.gb;         // never in practice (labels > blank)
                 orow[ye] = (__bf16)(v + add);
-                atomicAdd(colsum + ye, scale * m.ge);
+                atomicAdd(colsum + ye, scale * m.ge + (v - vb));
             }
         }
     }
@@ -1065,7 +1093,9 @@ int pika_rnnt_fused_forward_gathered(const void *logits16, long long ld16, const
 
 int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, const float *lse, const void *workspace,
                                          int B, int T, int U1, int V, int blank, void *out, long long ld_out, float scale,
-                                         float *colsum, void *stream) {
+                                         float *colsum, const float *gathered, const int *g_labels, int g_blank,
+                                         void *stream) {
+    if (gathered && !g_labels) return PIKA_EINVAL;
     if (!logits16 || !lse || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
         blank >= V)
         return PIKA_EINVAL;
@@ -1086,16 +1116,16 @@ int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, 
             !(reinterpret_cast<uintptr_t>(out) & 15) && !(reinterpret_cast<uintptr_t>(logits16) & 15)) {
             hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<10, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)),
                                dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw,
-                               colsum, lse, ld_in);
+                               colsum, lse, ld_in, gathered, g_labels, g_blank, T, U1);
             return (int)hipGetLastError();
         }
         hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)),
                            dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw, colsum,
-                           lse, ld_in);
+                           lse, ld_in, gathered, g_labels, g_blank, T, U1);
     } else {
         hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, _Float16>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                            x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
-                           static_cast<float *>(nullptr), lse, ld_in);
+                           static_cast<float *>(nullptr), lse, ld_in, gathered, g_labels, g_blank, T, U1);
     }
     return (int)hipGetLastError();
 }

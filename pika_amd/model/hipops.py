@@ -499,7 +499,9 @@ class JointOutFn(torch.autograd.Function):
         ctx.scale = float(scale)
         ctx.has_bias = bias is not None
         ctx.state = None
-        if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and N > 256 and N % 8 == 0
+        # (N <= 5120: what the loss' fused path and the compact d(logits) kernels take; beyond, the fp16 copy would only be
+        # followed by a second, fp32 run of the product for the loss -- ADVICE r4)
+        if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and 256 < N <= 5120 and N % 8 == 0
                 and labels.dim() == 2 and labels.shape == (h.shape[0], h.shape[2] - 1)
                 and os.environ.get("PIKA_JOINT_LSE_EPILOGUE", "1") != "0" and os.environ.get("PIKA_JOINT_F16_LOGITS", "1") != "0"):
             # 16-bit logits: the (B,T,U1,V) lattice -- the largest tensor of a training step -- is written ONCE as fp16
@@ -610,10 +612,15 @@ class JointOutFn(torch.autograd.Function):
                 want_db = ctx.has_bias and ctx.needs_input_grad[2]
                 db_fused = torch.empty(N, dtype=torch.float32, device=dl.device) if want_db else None
                 if lp16 is not None:
+                    # the blank / label logits of every row in fp32, where the forward product kept them (the fp16
+                    # copy is 2^-11 of |logit| off -- percents of a softmax value -- on the two entries that matter most)
+                    gath = ctx.state.gathered if ctx.state is not None else None
                     _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16_f16in(
                         lp16.data_ptr(), lp16.stride(-2), lse.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_,
                         blank, dl.data_ptr(), Np, ctx.scale,
-                        None if db_fused is None else db_fused.data_ptr(), _stream()), "pika_rnnt_dlogits_compact_bf16_f16in")
+                        None if db_fused is None else db_fused.data_ptr(),
+                        None if gath is None else gath[0].data_ptr(), None if gath is None else gath[1].data_ptr(),
+                        0 if gath is None else int(gath[2]), _stream()), "pika_rnnt_dlogits_compact_bf16_f16in")
                 else:
                     _lib.check(_lib.lib().pika_rnnt_dlogits_compact_bf16(
                         lp.data_ptr(), None if lse is None else lse.data_ptr(), compact.ws.data_ptr(), B_, T_, U1_, V_,

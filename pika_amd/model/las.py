@@ -170,24 +170,40 @@ class LASRNNEncoder(nn.Module):
                 cs.append(c_n)
                 x = out
                 failed = work[:4].view(torch.int32).clone() if k == 0 else failed | work[:4].view(torch.int32)
-            # the launch's error word (a workgroup gave up waiting for its peers: the grid was not resident) travels to
-            # a pinned word behind the last layer; check_status() -- called where the caller synchronises anyway -- reads it
-            if self._status is None:
-                self._status = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-            word, ev = self._status
-            word.copy_(failed, non_blocking=True)
-            ev.record()
-        return (torch.cat(hs, 0), torch.cat(cs, 0)), x
+        # `failed`: the launches' error word (a workgroup gave up waiting for its peers: the grid was not resident), still
+        # on the device -- _publish_status() sends the OR over all row blocks of a pass to a pinned word
+        return (torch.cat(hs, 0), torch.cat(cs, 0)), x, failed
 
     _status = None
+    _no_fused = False        # set once a pass did not complete: nn.LSTM from then on (status_ok)
 
-    def check_status(self):
-        """Raises if the last persistent-kernel pass did not complete (blocks until that pass has finished)."""
-        if self._status is not None:
-            word, ev = self._status
-            ev.synchronize()
-            if int(word[0]):
-                raise RuntimeError("pika_blstm_layer: workgroups gave up waiting for their peers (grid not resident)")
+    def _publish_status(self, failed):
+        """The pass' error word travels to a pinned word behind its last launch; status_ok() -- called where the caller
+        synchronises anyway -- reads it."""
+        if self._status is None:
+            self._status = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        word, ev = self._status
+        with torch.cuda.device(failed.device):
+            word.copy_(failed, non_blocking=True)
+            ev.record()
+
+    def status_ok(self):
+        """False if the last persistent-kernel pass did not complete (blocks until that pass has finished): some workgroup
+        of the grid was not resident -- another process or stream held CUs -- and its peers gave up waiting.  The caller
+        repeats the pass; this encoder then runs nn.LSTM (warned once) instead of spinning again."""
+        if self._status is None:
+            return True
+        word, ev = self._status
+        ev.synchronize()
+        if int(word[0]):
+            word.zero_()
+            if not self._no_fused:
+                import warnings
+                warnings.warn("pika_amd LAS encoder: the persistent BLSTM launch was not resident as a whole (CUs held by another "
+                              "stream or process); the pass is repeated with nn.LSTM, which this encoder uses from now on")
+            self._no_fused = True
+            return False
+        return True
 
     def _forward_fused_blocks(self, input, lengths):
         """The persistent kernel needs its whole grid resident -- D x (H/16) x (rows/16) workgroups, i.e. 64 rows on the 256
@@ -199,26 +215,33 @@ class LASRNNEncoder(nn.Module):
         rows = 16 * max(1, cus // (D * (H // 16)))
         S, B, _ = input.shape
         if B <= rows:
-            return self._forward_fused(input, lengths)
+            res = self._forward_fused(input, lengths)
+            if res is None:
+                return None
+            self._publish_status(res[2])
+            return res[0], res[1]
         lens = torch.as_tensor(lengths).view(-1).to(torch.int64).cpu()
         s_out = int(lens.max())
         hs, cs, outs = [], [], []
+        failed = None
         for b0 in range(0, B, rows):
             res = self._forward_fused(input[:, b0:b0 + rows].contiguous(), lens[b0:b0 + rows])
             if res is None:
                 return None
-            (h, c), out = res
+            (h, c), out, f = res
+            failed = f if failed is None else failed | f        # every block's error word counts
             if out.shape[0] < s_out:        # a block whose longest row is shorter than the batch's: zero rows behind it
                 out = torch.cat([out, out.new_zeros((s_out - out.shape[0],) + tuple(out.shape[1:]))], 0)
             hs.append(h)
             cs.append(c)
             outs.append(out)
+        self._publish_status(failed)
         return (torch.cat(hs, 1), torch.cat(cs, 1)), torch.cat(outs, 1)
 
     _warned_fallback = False
 
     def forward(self, input, lengths=None, hidden=None):
-        if self._fused_ok(input, lengths, hidden):
+        if not self._no_fused and self._fused_ok(input, lengths, hidden):
             res = self._forward_fused_blocks(input, lengths)
             if res is not None:
                 return res
@@ -635,11 +658,13 @@ class Net(nn.Module):
         """src (T,1,C) one utterance; hyps: list of label lists.  Returns, per hypothesis, the list
         of log P(token_t | prefix) over `hyp + [eos]` -- what `las_rescore` returns one by one."""
         lens = torch.tensor([src.shape[0]], dtype=torch.int32)
-        enc_hidden, enc_out = self.encoder(src, lens)
-        owner = torch.zeros(len(hyps), dtype=torch.long, device=src.device)
-        res = self._score_flat(enc_out, enc_hidden, owner, torch.tensor([enc_out.shape[0]], device=src.device),
-                               [list(h) for h in hyps], sos, eos, scale)
-        self.encoder.check_status()
+        for _ in range(2):      # (a second pass only if the persistent encoder launch was not resident: status_ok)
+            enc_hidden, enc_out = self.encoder(src, lens)
+            owner = torch.zeros(len(hyps), dtype=torch.long, device=src.device)
+            res = self._score_flat(enc_out, enc_hidden, owner, torch.tensor([enc_out.shape[0]], device=src.device),
+                                   [list(h) for h in hyps], sos, eos, scale)
+            if self.encoder.status_ok():
+                break
         return res
 
     @torch.no_grad()
@@ -654,16 +679,18 @@ class Net(nn.Module):
         order = torch.argsort(lens, descending=True, stable=True)          # packed sequences want sorted lengths
         inv = torch.empty_like(order)
         inv[order] = torch.arange(B)
-        _tick = _phase_timer(self, dev)
-        enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
-        _tick("encoder")
         import numpy as np
         owner_h = np.repeat(inv.numpy(), [len(hyps[b]) for b in range(B)]).astype(np.int64)
         owner = torch.from_numpy(owner_h).to(dev)
         flat = [list(h) for b in range(B) for h in hyps[b]]
-        scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick,
-                                  owner_host=owner_h)
-        self.encoder.check_status()
+        for _ in range(2):      # (a second pass only if the persistent encoder launch was not resident: status_ok)
+            _tick = _phase_timer(self, dev)
+            enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
+            _tick("encoder")
+            scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick,
+                                      owner_host=owner_h)
+            if self.encoder.status_ok():
+                break
         res, i = [], 0
         for b in range(B):
             res.append(scores[i:i + len(hyps[b])])

@@ -353,3 +353,43 @@ def test_sixteen_bit_logits_keep_the_loss_in_fp32(hip_device, V):
             assert (x - y).abs().max().item() <= 1e-2 * y.abs().max().item() + 1e-12
     finally:
         G.PRECISION = old
+
+
+@pytest.mark.gpu
+def test_sixteen_bit_logits_backward_takes_blank_and_label_logits_in_fp32(hip_device):
+    """with |logit| ~ 30-60 the fp16 copy of the lattice is 2^-11 |logit| = 1.5-3e-2 off, i.e. percents of a
+    softmax value -- and the blank / label entries of a row carry the loss' own gradient terms.  Their softmax comes from
+    the fp32 pair the forward product kept (`gathered`): d(bias) of the blank column -- the sum of that entry over all
+    lattice rows -- agrees with the fp32-logits path several times closer than with the fp16 values alone (measured with
+    the fix-up switched off through a loss that is handed another blank, for which the pair does not apply)."""
+    from pika_amd import gemm as G
+    from pika_amd.model.hipops import JointOutFn
+    from pika_amd.rnnt import RNNTLoss
+    old, G.PRECISION = G.PRECISION, "bf16"
+    try:
+        V = 5000
+        g = torch.Generator().manual_seed(77)
+        B, T, U, H = 3, 37, 6, 128
+        h = (torch.randn(B, T, U + 1, H, generator=g) * 1.5).bfloat16().to(hip_device)
+        w = (torch.randn(V, H, generator=g) * 0.6).to(hip_device)          # |logit| up to ~60
+        b = (torch.randn(V, generator=g) * 2.0).to(hip_device)
+        b[0] += 30.0                                                         # a blank that takes a share of every row
+        labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
+        tl = torch.tensor([T, T - 5, T - 11], dtype=torch.int32, device=hip_device)
+        ul = torch.tensor([U, U - 1, U - 4], dtype=torch.int32, device=hip_device)
+
+        def run(joint_labels):
+            hh, ww, bb = (t.clone().requires_grad_(True) for t in (h, w, b))
+            lp = JointOutFn.apply(hh, ww, bb, 1.0, True, joint_labels)
+            lp._pika_lazy_grad_ok = True
+            RNNTLoss(blank=0).apply(lp, labels, tl, ul).sum().backward()
+            return bb.grad, float(lp.buf.float().abs().max())
+        ref, _ = run(None)
+        got, big = run(labels.long())
+        assert big > 25.0, big
+        cols = torch.cat([torch.zeros(1, dtype=torch.long, device=hip_device), labels.long().unique()])
+        err = ((got - ref)[cols].abs() / ref[cols].abs().clamp(min=1e-3)).max().item()
+        print("largest |logit| %.0f: d(bias) of the blank / label columns, 16-bit logits vs fp32 logits: %.2e" % (big, err))
+        assert err < 1e-2, err      # (bf16 rounding of the entries themselves is 4e-3; the fp16 softmax alone 1-3e-2)
+    finally:
+        G.PRECISION = old

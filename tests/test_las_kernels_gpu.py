@@ -139,7 +139,7 @@ def test_blstm_encoder_matches_nn_lstm(hip_device, monkeypatch, S, B, D, H, In, 
     with torch.no_grad():
         assert enc._fused_ok(x.to(hip_device), lens, None)
         (h, c), out = enc(x.to(hip_device), lens)
-    enc.check_status()
+    assert enc.status_ok() and not enc._no_fused
     assert out.shape == out_ref.shape and h.shape == h_ref.shape
     for got, want, name in ((out, out_ref, "out"), (h, h_ref, "h_n"), (c, c_ref, "c_n")):
         err = (got.double().cpu() - want).abs().max().item()

@@ -632,3 +632,19 @@ def test_mixed_arithmetic_trains_like_fp32(hip_device):
           % (((mix - f32).abs() / f32).max(), ((b16 - f32).abs() / f32).max()))
     assert pf[-1] < 0.2 * pf[0], pf.tolist()                            # the loop learns: the check means something
     assert dev_m[:6].max() < 2e-3 and dev_m.max() < 1e-2, dev_m.tolist()   # measured: <= 1e-3 on all eight passes
+
+
+def test_graph_safety_flag_sees_a_hip_runtime_that_started_before_the_import(hip_device):
+    """torch.cuda.is_available() starts the HIP runtime (which then has read its graph fast-path flag) without
+    setting torch's own `is_initialized()`: pika_amd must notice -- it asks the process (an open /dev/kfd) -- and keep the
+    training step eager; imported before any HIP call it may alternate graphs."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None); import torch; %s"
+            "import pika_amd; print('SAFE', pika_amd.HIP_GRAPHS_SAFE_TO_ALTERNATE)")
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    late = subprocess.run([sys.executable, "-c", code % (ROOT, "torch.cuda.is_available(); ")], env=env, capture_output=True,
+                          text=True, timeout=300).stdout
+    early = subprocess.run([sys.executable, "-c", code % (ROOT, "")], env=env, capture_output=True, text=True,
+                           timeout=300).stdout
+    assert "SAFE False" in late, late
+    assert "SAFE True" in early, early
