@@ -1055,9 +1055,27 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
         "roofline": {"bound": "hbm", "kernel": "one beam-search step (all of its kernels; the search is "
                                                "launch/latency-bound at %d rows)" % (a.batch * a.beam),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "bytes_per_launch": bps, "search_steps": tm["steps"],
+                     "bytes_per_launch": bps, "search_steps": tm["steps"],
                      "us_per_search_step": tm["search_s"] / max(tm["steps"], 1) * 1e6,
-                     "search_s": tm["search_s"]}}
+                     "search_s": tm["search_s"], **decode_step_traffic(a)}}
+
+
+def decode_step_traffic(a):
+    """Counter-level traffic of ONE search step: PMC counters need their own rocprofv3 passes, so this is the committed
+    measurement of the same kernels at the same shape (tools/gpu_pmc_decode.sh), not this run."""
+    path = os.path.join(ROOT, "profiles", "r5_decode_step_pmc.json")
+    try:
+        if (a.batch, a.beam, a.vocab, a.pred_net, bool(a.fst)) != (64, 16, 5000, "transformer", False):
+            return {"traffic": None}
+        d = json.load(open(path))
+        return {"traffic": d["hbm_bytes_per_step"], "traffic_unit": "bytes per search step beyond L2 (FETCH_SIZE + WRITE_SIZE; "
+                                                                      "Infinity-Cache hits included)",
+                "traffic_source": "profiles/r5_decode_step_pmc.json (separate --pmc passes of the same kernels, eager launches; "
+                                  "not this run)",
+                "traffic_note": "7.5 x the algorithmic bytes: every XCD pulls the weights through its own L2 (the vocabulary "
+                                "product alone fetches 169 MB = 8 x its 20 MB of two-term weights); the step stays latency-bound"}
+    except Exception:
+        return {"traffic": None}
 
 
 def cpu_baseline_decode(a, blank_bias, B=4):

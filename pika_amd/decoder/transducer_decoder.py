@@ -45,7 +45,8 @@ class TransducerDecoder(object):
         self.args = args
         self.t_idx = None
         self.dec_states = None
-        self.use_graph = True   # capture the steady-state step in a hipGraph on the GPU
+        # capture the steady-state step in a hipGraph on the GPU (PIKA_DECODE_GRAPH=0: eager launches, for counter passes)
+        self.use_graph = __import__("os").environ.get("PIKA_DECODE_GRAPH", "1") != "0"
         self.fused_step = True   # fused HIP advance kernel on the GPU (include/pika_decode.h)
         self.incremental = True  # transformer prediction net: one new position per step (cached)
         # GPU, transformer prediction net: the whole step as a fixed launch chain (fused_step.py), replayed
