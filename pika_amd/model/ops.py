@@ -47,6 +47,77 @@ def _bf16_fast():
     return _bf16_mode() and _fused()
 
 
+# ---- a sub-network in another arithmetic than the rest of the step ---------------------------------------------------
+# "mixed" runs every backward product on one bf16 term.  For the encoder and the joint that is the benchmarked trade (their
+# gradients stay within 2-4e-2 of the reference's); the conv-transformer prediction network is 1632 rows -- a few per cent of
+# a step -- and its query / key gradients are the small remainder of a nearly shift-invariant softmax: on one bf16 term they
+# were 0.11 off.  It therefore runs as an island of the two-term mode ("bf16x3": fp32 tensors between products, two-term
+# products forward AND backward).  The mode is a process global that kernels are picked by at call time, so the island is
+# entered / left by two identity autograd nodes: autograd runs nodes in reverse order of creation, every node of the
+# prediction network was created after every node of the encoder, so between `island_enter`'s backward (the first node of
+# the island to run) and `island_leave`'s (the last) no node from outside the island runs.
+_ISLAND_STACK = []
+
+
+class _IslandEnter(torch.autograd.Function):
+    """Identity on the island's OUTPUT: its backward runs first and switches the arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        ctx.mode = mode
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import gemm as G
+        _ISLAND_STACK.append(G.PRECISION)
+        G.PRECISION = ctx.mode
+        return g, None
+
+
+class _IslandLeave(torch.autograd.Function):
+    """Identity on the island's INPUT: its backward runs last and restores the arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import gemm as G
+        if _ISLAND_STACK:
+            G.PRECISION = _ISLAND_STACK.pop()
+        return g
+
+
+class precision_island(object):
+    """with precision_island(x) as isl:  h = isl.inp(first differentiable tensor);  ...;  y = isl.out(result)
+    Active (mode "bf16x3") only for a training call on a HIP device under the "mixed" arithmetic; otherwise a no-op."""
+
+    def __init__(self, probe):
+        from .. import gemm as G
+        self.mode = "bf16x3" if (G.PRECISION == "mixed" and probe.is_cuda and torch.is_grad_enabled()) else None
+        self.old = None
+
+    def __enter__(self):
+        if self.mode is not None:
+            from .. import gemm as G
+            self.old, G.PRECISION = G.PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode is not None:
+            from .. import gemm as G
+            G.PRECISION = self.old
+        return False
+
+    def inp(self, x):
+        return _IslandLeave.apply(x) if (self.mode is not None and x.requires_grad) else x
+
+    def out(self, y):
+        return _IslandEnter.apply(y, self.mode) if (self.mode is not None and y.requires_grad) else y
+
+
 def tdnn_bn_ok(x, conv_weight, bn):
     """bn(relu(tdnn(x))) can run as ONE node (hipops.TdnnBnFn): bf16 fast mode, training statistics, widths
     the direct-to-LDS kernels take, enough rows to be worth a bf16 copy."""

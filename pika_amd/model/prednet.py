@@ -27,14 +27,18 @@ class Net(nn.Module):
 
     def forward(self, src, softmax=False):
         B, L = src.shape
-        out = self.embeddings(src)
         pad = src.eq(self.embeddings.padding_idx).unsqueeze(1).expand(B, L, L)
         mask = pad | self.mask[:, :L, :L].bool()  # key j hidden from query i if j>i or src[j] is padding
-        for conv, layer in zip(self.conv, self.transformer):
-            out = ops.relu(ops.causal_conv1d(out, conv.weight, conv.bias))
-            out = layer(out, mask=mask)
-        out = ops.linear(ops.layer_norm(out, self.layer_norm), self.linear_out.weight,
-                         self.linear_out.bias)
+        # (under the train step's "mixed" arithmetic this network is an island of the two-term mode, backward included:
+        # ops.precision_island)
+        with ops.precision_island(self.linear_out.weight) as isl:
+            out = isl.inp(self.embeddings(src))
+            for conv, layer in zip(self.conv, self.transformer):
+                out = ops.relu(ops.causal_conv1d(out, conv.weight, conv.bias))
+                out = layer(out, mask=mask)
+            out = ops.linear(ops.layer_norm(out, self.layer_norm), self.linear_out.weight,
+                             self.linear_out.bias)
+            out = isl.out(out)
         if softmax:
             out = torch.log_softmax(out, dim=-1)
         return out

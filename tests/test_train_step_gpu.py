@@ -613,8 +613,8 @@ CURVE_LR, CURVE_STEPS = 0.0005, 48
 def test_mixed_arithmetic_trains_like_fp32(hip_device):
     """Convergence-level check of the benchmarked arithmetic: 48 steps of the script's loop (inf-norm clip 3, Nesterov
     SGD, lr 5e-4) over six recurring batches from the same initial weights in "fp32" (exact products) and in "mixed" (two
-    bf16 terms per operand forward, ONE term in the lattice products and in every backward product -- single parameter
-    gradients differ from fp32's by up to 1e-1, tests/test_model_full.py).  The summed loss falls from 1712 to ~204 per
+    bf16 terms per operand forward, ONE term in the lattice products and in the backward products of encoder and joint --
+    single parameter gradients differ from fp32's by up to 2e-2, tests/test_model_full.py).  The summed loss falls from 1712 to ~204 per
     pass over the batches in those 48 steps, and the per-pass means of the two curves agree to 1e-3 -- which is also what
     two fp32 runs do (float atomics in the BatchNorm / split-K reductions; tools/curve_modes.py prints all modes next to
     a repeated fp32 run: beyond ~50 steps, or at 4x the learning rate, two fp32 runs part by 1-10 % themselves, and the
@@ -632,6 +632,30 @@ def test_mixed_arithmetic_trains_like_fp32(hip_device):
           % (((mix - f32).abs() / f32).max(), ((b16 - f32).abs() / f32).max()))
     assert pf[-1] < 0.2 * pf[0], pf.tolist()                            # the loop learns: the check means something
     assert dev_m[:6].max() < 2e-3 and dev_m.max() < 1e-2, dev_m.tolist()   # measured: <= 1e-3 on all eight passes
+
+
+def test_mixed_arithmetic_tracks_fp32_over_300_steps(hip_device):
+    """The longer leash (VERDICT r4 #4b): 312 optimisation steps -- 13 passes over 24 recurring batches -- in "mixed" next to
+    TWO runs in "fp32".  A ReLU network trained by SGD is chaotic at this horizon: the two fp32 runs differ in nothing but
+    the order of float atomics (BatchNorm / split-K reductions) and still part ways -- 1e-2 of the per-pass loss by pass 5,
+    1e-1 by pass 13 (measured); their distance so far is the band any arithmetic can be held to.  "mixed" stays within 5 x
+    the running maximum of that band (and 2 % where the band is tighter), learns as far (last pass within 10 %; measured
+    5.7e-2 against the fp32 pair's own 1.0e-1), and never leaves the curve by more than 15 % on a single pass."""
+    steps, nb = 312, 24
+    f32a = torch.tensor(_loss_curve(hip_device, "fp32", CURVE_LR, steps, n_batches=nb), dtype=torch.float64)
+    f32b = torch.tensor(_loss_curve(hip_device, "fp32", CURVE_LR, steps, n_batches=nb), dtype=torch.float64)
+    mix = torch.tensor(_loss_curve(hip_device, "mixed", CURVE_LR, steps, n_batches=nb), dtype=torch.float64)
+    assert torch.isfinite(mix).all() and torch.isfinite(f32a).all()
+    pa, pb, pm = (c.view(-1, nb).mean(1) for c in (f32a, f32b, mix))
+    band = (pb / pa - 1).abs()
+    dev = (pm / pa - 1).abs()
+    print("fp32 per pass:", [round(v, 1) for v in pa.tolist()])
+    print("fp32 vs fp32 :", ["%.1e" % v for v in band.tolist()])
+    print("mixed vs fp32:", ["%.1e" % v for v in dev.tolist()])
+    assert pa[-1] < 0.5 * pa[0], pa.tolist()
+    env = torch.cummax(band, 0).values
+    assert bool((dev <= torch.maximum(5 * env, torch.full_like(env, 2e-2))).all()), (dev.tolist(), band.tolist())
+    assert dev[-1] < 0.1 and dev.max() < 0.15
 
 
 def test_graph_safety_flag_sees_a_hip_runtime_that_started_before_the_import(hip_device):
