@@ -38,6 +38,16 @@ int pika_bmuf_nan_flag(const float *delta, size_t n, int *flag, void *stream);
 int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float *local, size_t n,
                      float inv_world, float block_momentum, float block_lr, const int *skip_flag, void *stream);
 
+/* BMUF-Adam (/root/reference/trainer/bmuf.py:191-333: the block update of Adam's first / second moments, :291-313).
+ * sum_* (n) IN: the moments summed over the ranks (the all-reduced optimizer state itself); OUT: the block moments, which
+ * the optimizer continues from.  blk_* (n): the block moments kept from block to block.  Per element, every product rounded:
+ *   blk = (c1 * blk + c2 * (sum * inv_world)) / c3
+ * with c1 = beta^tau (beta^(rho bm) - 1), c2 = 1 - beta^tau beta^(rho bm), c3 = 1 - beta^tau formed by the caller in
+ * float64 (tau = sync period, rho as in the reference).  skip_flag as in pika_bmuf_update. */
+int pika_bmuf_adam_moments(float *sum_avg, float *blk_avg, float *sum_sq, float *blk_sq, size_t n, float inv_world,
+                           float c1_avg, float c2_avg, float c3_avg, float c1_sq, float c2_sq, float c3_sq,
+                           const int *skip_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

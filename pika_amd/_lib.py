@@ -33,6 +33,7 @@ SIGNATURES = {
     "pika_bmuf_nan_flag": (_i, [_vp, _sz, _vp, _vp]),
     "pika_bmuf_update": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float,
                               ctypes.c_float, _vp, _vp]),
+    "pika_bmuf_adam_moments": (_i, [_vp, _vp, _vp, _vp, _sz, ctypes.c_float] + [ctypes.c_float] * 6 + [_vp, _vp]),
     # include/pika_feat.h
     "pika_cmvn_apply": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "pika_specaug_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

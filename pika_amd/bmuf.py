@@ -180,86 +180,141 @@ class BmufTrainer(object):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
 
 
+def _flatten_parameters(params, dev):
+    """Re-points the parameters to views of ONE flat fp32 vector (order = model.parameters()) and returns it."""
+    n = sum(p.numel() for p in params)
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    off = 0
+    for p in params:
+        if p.dtype != torch.float32:
+            raise TypeError("BMUF expects fp32 master parameters, got %s" % p.dtype)
+        k = p.numel()
+        flat[off:off + k].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + k].view(p.shape)
+        off += k
+    return flat
+
+
 class BmufAdamTrainer(object):
     """BMUF-Adam (Chen et al. 2020), drop-in for trainer.bmuf.BmufAdamTrainer (/root/reference/trainer/bmuf.py:191-333):
     same constructor (`..., block_momentum, block_lr, sync_period, optim`), `update_and_sync()`, `broadcast`,
-    `sum_reduce`, and the same block update of the parameters AND of Adam's first / second moments, whose
-    averaged, bias-compensated values are written back into the optimizer state (`state['step']` advanced by
-    rho * block_momentum).
+    `sum_reduce`; the block update of the parameters AND of Adam's first / second moments, whose averaged,
+    bias-compensated values are what the optimizer continues from (`state['step']` advanced by rho * block_momentum).
 
-    As in BmufTrainer above, the reference's reduce-to-master + master-only update + broadcast of one long vector
-    [delta | exp_avg | exp_avg_sq] becomes ONE all-reduce after which every rank applies the identical update
-    (every rank keeps delta_prev and the block moments); the NaN guard therefore stops all ranks together.
-    The elementwise math is written with the reference's expressions in the reference's order (flat fp32
-    vectors, a handful of streaming torch kernels per block -- the LAS training script that uses this class is
-    outside the RNN-T hot path)."""
+    Laid out for one node of MI355Xs like BmufTrainer above, not like the reference (which concatenates three freshly
+    gathered vectors per block, reduces them to the master, updates there and broadcasts three vectors back):
+
+    * ONE exchange buffer `xch` = [delta | exp_avg | exp_avg_sq] lives for the whole run.  The parameters are views of a
+      flat local vector; the optimizer's moment tensors are re-pointed (at the first block, when they exist) to views of
+      the second and third segment of `xch` -- Adam updates them in place, so at a block boundary the buffer already
+      holds what has to travel: nothing is gathered, nothing is scattered back;
+    * ONE in-place all-reduce(SUM) of `xch`, after which every rank applies the identical update (every rank keeps
+      delta_prev and the block moments; replicas stay bitwise identical);
+    * on a HIP device the update is two single-pass kernels (include/pika_bmuf.h: pika_bmuf_update for the parameters,
+      pika_bmuf_adam_moments for both moments -- the summed state goes in, the block moments come out in the same
+      memory) behind the device-side NaN flag of BmufTrainer; on the CPU (gloo tests) the same arithmetic as in-place
+      torch ops on the segments.
+    A NaN in the summed buffer returns STOP on every rank at the same block (the optimizer state is then the sum, not a
+    usable state: STOP ends the run, as in the reference)."""
 
     def __init__(self, master_node, rank, world_size, model, block_momentum, block_lr, sync_period, optim,
                  backend=None):
         self.master_node, self.rank, self.world_size = master_node, rank, world_size
         self.model, self.optim = model, optim
-        self.block_momentum, self.block_lr, self.sync_period = block_momentum, block_lr, sync_period
+        self.block_momentum, self.block_lr, self.sync_period = float(block_momentum), float(block_lr), sync_period
         params = [p for p in model.parameters()]
         dev = params[0].device
+        self.is_hip = dev.type == "cuda"
         if not dist.is_initialized():
-            dist.init_process_group(backend=backend or ("nccl" if dev.type == "cuda" else "gloo"),
-                                    init_method="env://")
+            dist.init_process_group(backend=backend or ("nccl" if self.is_hip else "gloo"), init_method="env://")
+        if self.is_hip:
+            _lib.lib()
         self.rho = 0.0
         self.betas = (0.9, 0.999)
-        self.param = torch.nn.utils.parameters_to_vector(model.parameters()).data.clone()
-        dist.broadcast(tensor=self.param, src=master_node, async_op=False)
-        self.num_param = self.param.numel()
-        torch.nn.utils.vector_to_parameters(self.param.clone(), model.parameters())
-        self.delta_prev = torch.zeros_like(self.param)
-        dim = 0
+        self._opt_params = []
         for group in optim.param_groups:
             self.betas = group['betas']
-            for p in group['params']:
-                dim += p.numel()
-        self.exp_avg = torch.zeros(dim, dtype=torch.float32, device=dev)
+            self._opt_params += list(group['params'])
+        self.local = _flatten_parameters(params, dev)
+        self.param = self.local.clone()                      # the global model
+        dist.broadcast(tensor=self.param, src=master_node, async_op=False)
+        self.local.copy_(self.param)
+        self.num_param = n = self.param.numel()
+        self.dim = dim = sum(p.numel() for p in self._opt_params)
+        self.xch = torch.zeros(n + 2 * dim, dtype=torch.float32, device=dev)       # [delta | exp_avg | exp_avg_sq]
+        self.delta_prev = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(dim, dtype=torch.float32, device=dev)           # the block moments
         self.exp_avg_sq = torch.zeros(dim, dtype=torch.float32, device=dev)
+        self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._adopted = False
 
-    def _moment_params(self):
-        for group in self.optim.param_groups:
-            for p in group['params']:
-                if p.grad is not None:
-                    yield p
+    def _adopt_optimizer_state(self):
+        """The optimizer's moment tensors become views of the exchange buffer (once: Adam creates them at its first step
+        and updates them in place from then on).  Re-done when something re-bound them (load_state_dict)."""
+        n, dim, off = self.num_param, self.dim, 0
+        base1, base2 = self.xch[n:n + dim], self.xch[n + dim:]
+        for p in self._opt_params:
+            k = p.numel()
+            st = self.optim.state.get(p)
+            if st and 'exp_avg' in st:
+                for name, seg in (('exp_avg', base1), ('exp_avg_sq', base2)):
+                    t = st[name]
+                    view = seg[off:off + k]
+                    if t.data_ptr() != view.data_ptr():
+                        view.copy_(t.reshape(-1))
+                        st[name] = view.view(t.shape)
+            else:       # no optimizer step has touched this parameter yet: zero moments travel for it
+                base1[off:off + k].zero_()
+                base2[off:off + k].zero_()
+            off += k
+        self._adopted = True
 
     def update_and_sync(self):
-        delta = self.param - torch.nn.utils.parameters_to_vector(self.model.parameters()).data
-        ps = list(self._moment_params())
-        exp_avg = torch.cat([self.optim.state[p]['exp_avg'].view(-1) for p in ps])
-        exp_avg_sq = torch.cat([self.optim.state[p]['exp_avg_sq'].view(-1) for p in ps])
-        vec = torch.cat([delta, exp_avg, exp_avg_sq])
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        if torch.isnan(vec).sum().item():
-            return STOP
-        self.rho = self.block_momentum * self.rho + self.sync_period
-        n = self.num_param
-        vec = vec / float(self.world_size)
-        self.delta_prev = self.block_momentum * self.delta_prev + \
-            (self.block_lr * (1 - self.block_momentum) * vec[:n])
-        self.param -= (1 + self.block_momentum) * self.delta_prev
-        dim = (vec.numel() - n) // 2
-        beta1_tau = self.betas[0] ** self.sync_period
-        beta2_tau = self.betas[1] ** self.sync_period
-        beta1_rho = self.betas[0] ** (self.rho * self.block_momentum)
-        beta2_rho = self.betas[1] ** (self.rho * self.block_momentum)
-        self.exp_avg = beta1_tau * (beta1_rho - 1) * self.exp_avg
-        self.exp_avg += (1 - beta1_tau * beta1_rho) * vec[n:n + dim]
-        self.exp_avg = self.exp_avg / (1 - beta1_tau)
-        self.exp_avg_sq = beta2_tau * (beta2_rho - 1) * self.exp_avg_sq
-        self.exp_avg_sq += (1 - beta2_tau * beta2_rho) * vec[n + dim:]
-        self.exp_avg_sq = self.exp_avg_sq / (1 - beta2_tau)
-        torch.nn.utils.vector_to_parameters(self.param.clone(), self.model.parameters())
-        ptr = 0
-        for p in ps:                                    # flattened block moments back into the optimizer
-            state = self.optim.state[p]
-            state['step'] += self.rho * self.block_momentum
-            k = state['exp_avg'].numel()
-            state['exp_avg'].copy_(self.exp_avg[ptr:ptr + k].view_as(state['exp_avg']))
-            state['exp_avg_sq'].copy_(self.exp_avg_sq[ptr:ptr + k].view_as(state['exp_avg_sq']))
-            ptr += k
+        n, dim, W, bm = self.num_param, self.dim, float(self.world_size), self.block_momentum
+        self._adopt_optimizer_state()
+        delta, m_sum, v_sum = self.xch[:n], self.xch[n:n + dim], self.xch[n + dim:]
+        lib = _lib.lib() if self.is_hip else None
+        if self.is_hip:
+            with torch.cuda.device(self.xch.device):
+                _lib.check(lib.pika_bmuf_delta(self.param.data_ptr(), self.local.data_ptr(), delta.data_ptr(), n, _stream()),
+                           "pika_bmuf_delta")
+        else:
+            torch.sub(self.param, self.local, out=delta)
+        dist.all_reduce(self.xch, op=dist.ReduceOp.SUM)
+        # the coefficients of this block (float64 on the host, like the reference's Python floats)
+        rho = bm * self.rho + self.sync_period
+        b1t, b2t = self.betas[0] ** self.sync_period, self.betas[1] ** self.sync_period
+        b1r, b2r = self.betas[0] ** (rho * bm), self.betas[1] ** (rho * bm)
+        c_avg = (b1t * (b1r - 1), 1 - b1t * b1r, 1 - b1t)
+        c_sq = (b2t * (b2r - 1), 1 - b2t * b2r, 1 - b2t)
+        if self.is_hip:
+            with torch.cuda.device(self.xch.device):
+                self._flag.zero_()
+                _lib.check(lib.pika_bmuf_nan_flag(self.xch.data_ptr(), self.xch.numel(), self._flag.data_ptr(), _stream()),
+                           "pika_bmuf_nan_flag")
+                _lib.check(lib.pika_bmuf_update(delta.data_ptr(), self.delta_prev.data_ptr(), self.param.data_ptr(),
+                                                self.local.data_ptr(), n, 1.0 / W, bm, self.block_lr,
+                                                self._flag.data_ptr(), _stream()), "pika_bmuf_update")
+                _lib.check(lib.pika_bmuf_adam_moments(m_sum.data_ptr(), self.exp_avg.data_ptr(), v_sum.data_ptr(),
+                                                      self.exp_avg_sq.data_ptr(), dim, 1.0 / W, *c_avg, *c_sq,
+                                                      self._flag.data_ptr(), _stream()), "pika_bmuf_adam_moments")
+            if int(self._flag.item()):
+                return STOP
+        else:
+            if bool(torch.isnan(self.xch).any().item()):
+                return STOP
+            self.xch.div_(W)
+            self.delta_prev.mul_(bm).add_(delta * (self.block_lr * (1 - bm)))
+            self.param.sub_(self.delta_prev * (1 + bm))
+            self.local.copy_(self.param)
+            for blk, x, c in ((self.exp_avg, m_sum, c_avg), (self.exp_avg_sq, v_sum, c_sq)):
+                blk.mul_(c[0]).add_(x * c[1]).div_(c[2])
+                x.copy_(blk)                  # the optimizer's own tensors: it continues from the block moments
+        self.rho = rho
+        for p in self._opt_params:
+            st = self.optim.state.get(p)
+            if st and 'step' in st:
+                st['step'] += self.rho * bm
         return SUCCESS
 
     def broadcast(self, tensor):

@@ -81,6 +81,31 @@ __global__ __launch_bounds__(256) void bmuf_update_kernel(const float *__restric
     }
 }
 
+// ---- BMUF-Adam: the block update of Adam's two moments (Chen et al. 2020; /root/reference/trainer/bmuf.py:291-313) ------
+// x = the summed moment of all ranks (IN: the all-reduced optimizer state; OUT: the block moment, i.e. what the optimizer
+// continues from), blk = the block moment kept across blocks:
+//   blk = (c1 * blk + c2 * (x / world)) / c3,   c1 = beta^tau (beta^(rho bm) - 1), c2 = 1 - beta^tau beta^(rho bm), c3 = 1 - beta^tau
+// every product rounded before it is added (the reference's sequence of separate torch ops).
+__global__ __launch_bounds__(256) void bmuf_adam_moments_kernel(float *__restrict__ x1, float *__restrict__ b1,
+                                                                float *__restrict__ x2, float *__restrict__ b2, size_t n,
+                                                                float inv_world, float c1a, float c2a, float c3a, float c1b,
+                                                                float c2b, float c3b, const int *__restrict__ skip_flag) {
+#pragma clang fp contract(off)
+    if (skip_flag && *skip_flag) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float m = x1[i] * inv_world, v = x2[i] * inv_world;
+        float a = c1a * b1[i];
+        a = a + c2a * m;
+        a = a / c3a;
+        float q = c1b * b2[i];
+        q = q + c2b * v;
+        q = q / c3b;
+        b1[i] = a; x1[i] = a;
+        b2[i] = q; x2[i] = q;
+    }
+}
+
 inline int grid_for(size_t n) {
     const size_t want = (n + 1023) / 1024;
     return (int)(want < 1 ? 1 : (want > BLOCKS ? BLOCKS : want));
@@ -120,6 +145,16 @@ int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float
     else
         hipLaunchKernelGGL(bmuf_update_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, delta,
                            delta_prev, global, local, n, inv_world, block_momentum, block_lr, skip_flag);
+    return (int)hipGetLastError();
+}
+
+int pika_bmuf_adam_moments(float *sum_avg, float *blk_avg, float *sum_sq, float *blk_sq, size_t n, float inv_world,
+                           float c1_avg, float c2_avg, float c3_avg, float c1_sq, float c2_sq, float c3_sq,
+                           const int *skip_flag, void *stream) {
+    if (!sum_avg || !blk_avg || !sum_sq || !blk_sq || c3_avg == 0.f || c3_sq == 0.f) return PIKA_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bmuf_adam_moments_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), sum_avg,
+                       blk_avg, sum_sq, blk_sq, n, inv_world, c1_avg, c2_avg, c3_avg, c1_sq, c2_sq, c3_sq, skip_flag);
     return (int)hipGetLastError();
 }
 

@@ -517,7 +517,8 @@ class InputFeedRNNDecoder(nn.Module):
                         token_step()
         return outs, None
 
-    def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, spans=None, forks=None):
+    def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, spans=None, forks=None, feed=None,
+            hidden_is_decoder_state=False):
         """tokens (L,N) decoder inputs, context (S,N,H).  Returns outputs (L,N,H).
         With `owner` (N,) and `lens` (B,): context / enc_hidden are per UTTERANCE ((S,B,H), (layers,B,H)) and hypothesis
         n reads utterance owner[n], whose valid source positions are [0, lens[owner[n]])."""
@@ -530,11 +531,13 @@ class InputFeedRNNDecoder(nn.Module):
             enc_hidden = tuple(e[:, owner].contiguous() for e in enc_hidden)
             mask = torch.arange(S, device=context.device).unsqueeze(0) < lens.to(context.device)[owner].unsqueeze(1)
             mask = None if bool(mask.all()) else mask
-        hidden = tuple(self._fix_enc_hidden(e) for e in enc_hidden)
+        # (a DecoderState's hidden is already in the decoder's layout; an encoder's final state is folded into it)
+        hidden = tuple(enc_hidden) if hidden_is_decoder_state else tuple(self._fix_enc_hidden(e) for e in enc_hidden)
         ctx = context.transpose(0, 1).contiguous()
         proj = self.attn.project_context(ctx)
         emb = self.embeddings.embeddings(tokens)
-        feed = ctx.new_zeros(ctx.shape[0], self.hidden_size)
+        if feed is None:
+            feed = ctx.new_zeros(ctx.shape[0], self.hidden_size)
         outs = []
         for t in range(tokens.shape[0]):
             rnn_out, hidden = self.rnn(torch.cat([emb[t], feed], 1), hidden)
@@ -542,6 +545,18 @@ class InputFeedRNNDecoder(nn.Module):
             feed = self.dropout(attn_h)
             outs.append(feed)
         return torch.stack(outs), hidden
+
+
+class DecoderState(object):
+    """What `Net.forward` hands back as its third value (the reference's RNNDecoderState, trainer/model/las.py:560-600):
+    the stacked LSTM's (h, c) after the last token and the input-feed vector."""
+
+    def __init__(self, hidden, input_feed):
+        self.hidden, self.input_feed = tuple(hidden), input_feed
+
+    def detach(self):
+        self.hidden = tuple(h.detach() for h in self.hidden)
+        self.input_feed = self.input_feed.detach()
 
 
 class Net(nn.Module):
@@ -570,10 +585,35 @@ class Net(nn.Module):
         state["_enc_cache"] = None          # the memo of the last scoring call is not part of a checkpoint
         return state
 
+    def _pretrain_inputfeed_decoder(self, tgt):
+        """Decoder pre-training as a language model (trainer/model/las.py:92-116, `--pretrain_decoder`): the stacked LSTM
+        of the input-feed decoder on [emb_t | previous output], zero initial state, no encoder and no attention."""
+        emb = self.decoder.embeddings.embeddings(tgt.squeeze(2) if tgt.dim() == 3 else tgt)          # (L, B, E)
+        B = emb.shape[1]
+        zeros = emb.new_zeros(self.decoder.num_layers, B, self.hid_dim)
+        hidden = (zeros, zeros.clone())
+        output = emb.new_zeros(B, self.hid_dim)
+        outs = []
+        for t in range(emb.shape[0]):
+            output, hidden = self.decoder.rnn(torch.cat([emb[t], output], 1), hidden)
+            outs.append(output)
+        return torch.stack(outs)
+
     def forward(self, src, tgt, lengths, dec_state=None, enable_dec=True, enable_enc=True):
-        if not enable_enc or not enable_dec or dec_state is not None:
-            raise NotImplementedError("LAS training/pre-training paths are out of scope (SURVEY 2.1)")
+        """trainer/model/las.py:51-90.  enable_enc False: decoder pre-training (outputs, None, None, None); enable_dec False:
+        encoder-only training, e.g. on the CTC branch of the script's loss (None, None, None, enc_out); dec_state: the
+        `DecoderState` a previous call returned, to continue from instead of the encoder's final state
+        (train_las_bmuf_otfaug.py:227-239 always hands None)."""
         tgt = tgt[:-1]                                               # las.py:66 (exclude EOS)
+        if not enable_enc:
+            return self._pretrain_inputfeed_decoder(tgt), None, None, None
+        if not enable_dec:
+            return None, None, None, self.encoder(src, lengths)[1]
+        if dec_state is not None:
+            enc_hidden, enc_out = self.encoder(src, lengths)
+            out, hidden = self.decoder.run(tgt.squeeze(2), enc_out, dec_state.hidden, feed=dec_state.input_feed,
+                                           hidden_is_decoder_state=True)
+            return out, None, DecoderState(hidden, out[-1]), enc_out
         if not torch.is_grad_enabled():
             # the rescoring loop of decode_transducer.py:136-156 calls this for every n-best entry and direction of the
             # SAME utterance: keep the last encoder pass.  The entry HOLDS `src` (its storage cannot be freed and handed to
@@ -602,9 +642,9 @@ class Net(nn.Module):
             ln = torch.as_tensor(lengths).to(device=enc_out.device, dtype=torch.long).view(-1)
             out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden,
                                       owner=torch.arange(n, device=enc_out.device), lens=ln)
-        else:
-            out, _ = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
-        return out, None, None, enc_out
+            return out, None, None, enc_out
+        out, hidden = self.decoder.run(tgt.squeeze(2), enc_out, enc_hidden)
+        return out, None, DecoderState(hidden, out[-1]), enc_out
 
     def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None):
         """log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance

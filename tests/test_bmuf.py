@@ -247,3 +247,41 @@ def test_parameters_rebound_behind_the_trainer_are_adopted(tmp_path):
     out = str(tmp_path / "rebind.npy")
     mp.spawn(_rebind_worker, args=(1, C.free_port(), out), nprocs=1, join=True)
     assert np.isfinite(np.load(out)).all()
+
+
+@pytest.mark.gpu
+def test_adam_moments_kernel_matches_the_torch_op_sequence(hip_device):
+    """pika_bmuf_adam_moments == the reference's three statements per moment (bmuf.py:297-313) run as separate fp32 torch ops
+    on the summed state: bit for bit (every product rounded before it is added), the block moments land in the optimizer's
+    own memory, and a set skip flag leaves everything untouched."""
+    import ctypes
+    from pika_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    n, W = 100003, 8.0
+    x1, x2 = (torch.randn(n, generator=g) * 3).to(hip_device), (torch.rand(n, generator=g) * 5).to(hip_device)
+    b1, b2 = torch.randn(n, generator=g).to(hip_device), torch.rand(n, generator=g).to(hip_device)
+    betas, tau, rho, bm = (0.9, 0.999), 5, 7.3, 0.9
+    c = []
+    for beta in betas:
+        bt, br = beta ** tau, beta ** (rho * bm)
+        c.append((bt * (br - 1), 1 - bt * br, 1 - bt))
+    want = []
+    for x, b, cc in ((x1, b1, c[0]), (x2, b2, c[1])):
+        v = x / W
+        a = cc[0] * b
+        a += cc[1] * v
+        want.append(a / cc[2])
+    flag = torch.zeros(1, dtype=torch.int32, device=hip_device)
+    keep = [t.clone() for t in (x1, b1, x2, b2)]
+    st = torch.cuda.current_stream().cuda_stream
+    flag.fill_(1)
+    _lib.check(lib.pika_bmuf_adam_moments(x1.data_ptr(), b1.data_ptr(), x2.data_ptr(), b2.data_ptr(), n, 1.0 / W, *c[0], *c[1],
+                                          flag.data_ptr(), st), "pika_bmuf_adam_moments")
+    assert all(torch.equal(a, b) for a, b in zip((x1, b1, x2, b2), keep))
+    flag.zero_()
+    _lib.check(lib.pika_bmuf_adam_moments(x1.data_ptr(), b1.data_ptr(), x2.data_ptr(), b2.data_ptr(), n, 1.0 / W, *c[0], *c[1],
+                                          flag.data_ptr(), st), "pika_bmuf_adam_moments")
+    for got_x, got_b, w in ((x1, b1, want[0]), (x2, b2, want[1])):
+        assert torch.equal(got_x, got_b)
+        assert torch.allclose(got_b, w, rtol=2e-7, atol=0), float((got_b - w).abs().max())

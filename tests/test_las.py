@@ -113,6 +113,78 @@ def _las_training_step(device):
         assert n == len([k for k in z.files if k.startswith(attn + "/grad/")])
 
 
+def _las_training_modes(device):
+    """The calls trainer/train_las_bmuf_otfaug.py makes besides the default one (:193-239): decoder pre-training
+    (--pretrain_decoder: enable_enc False), encoder-only training on the script's CTC branch (dec_loss_scale 0: enable_dec
+    False; :98-131), and a call that continues from the decoder state a previous call returned -- outputs, loss and every
+    parameter gradient against the reference's (tests/golden/make_las_train_golden.py)."""
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from model import las                     # what importlib.import_module("model." + nnet_proto) resolves to
+    z = np.load(os.path.join(HERE, "golden", "las_train.npz"))
+
+    def fresh():
+        net = las.Net(LC.opt("mlp"), LC.C_IN, LC.V, LC.PAD)
+        net.load_state_dict(seeded_state_dict(net, 31, scale=0.3))
+        return net.to(device).train()
+
+    def check(tag, net, loss, extra):
+        loss.backward()
+        want = float(z["%s/loss" % tag])
+        assert abs(loss.item() - want) < 1e-4 * max(1.0, abs(want)), (tag, loss.item(), want)
+        for k, v in extra.items():
+            assert np.allclose(v.detach().cpu().numpy(), z["%s/%s" % (tag, k)], rtol=1e-4, atol=1e-5), (tag, k)
+        n = 0
+        for k, p in net.named_parameters():
+            w = z["%s/grad/%s" % (tag, k)]
+            got = (p.grad if p.grad is not None else torch.zeros_like(p)).cpu().numpy()
+            assert np.allclose(got, w, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(w).max())), (tag, k)
+            n += 1
+        assert n == len([k for k in z.files if k.startswith(tag + "/grad/")])
+    src, tgt, lens = LC.train_batch()
+    src, tgt = src.to(device), tgt.to(device)
+    net = fresh()
+    outputs, a, b, c = net.forward(src, tgt, lens, None, True, False)
+    assert a is None and b is None and c is None
+    logp = F.log_softmax(net.dec_proj(outputs.view(-1, outputs.size(2))), dim=1)
+    check("pretrain_dec", net, F.nll_loss(logp, tgt[1:].contiguous().view(-1), ignore_index=LC.PAD, reduction="sum"),
+          {"outputs": outputs})
+    net = fresh()
+    o, a, b, enc_out = net.forward(src, tgt, lens, None, False, True)
+    assert o is None and a is None and b is None
+    L, B_, _ = enc_out.shape
+    pout = net.enc_proj(enc_out.view(-1, enc_out.size(2))).view(L, B_, -1)
+    t2 = tgt.view(tgt.size(0), -1).transpose(0, 1)
+    mask = torch.lt(t2, LC.PAD) & torch.gt(t2, 1)
+    ctc = torch.nn.CTCLoss()(pout.cpu() if device == "cpu" else pout, t2[mask].int().cpu(), torch.as_tensor(lens).int(),
+                             mask.int().sum(1).cpu())
+    check("enc_only_ctc", net, ctc, {"enc_out": enc_out})
+    net = fresh()
+    half = (tgt.size(0) - 1) // 2
+    tgt_a, tgt_b = tgt[:half + 1], tgt[half:]
+    out_a, _, st, _ = net.forward(src, tgt_a, lens, None, True, True)
+    out_b, _, _, _ = net.forward(src, tgt_b, lens, st, True, True)
+    outputs = torch.cat([out_a, out_b], 0)
+    logp = F.log_softmax(net.dec_proj(outputs.view(-1, outputs.size(2))), dim=1)
+    tg = torch.cat([tgt_a[1:], tgt_b[1:]], 0)
+    check("carried_state", net, F.nll_loss(logp, tg.contiguous().view(-1), ignore_index=LC.PAD, reduction="sum"),
+          {"outputs": outputs})
+
+
+def test_las_training_modes_match_reference():
+    _las_training_modes("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_las_training_modes_match_reference(hip_device):
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        _las_training_modes(hip_device)
+    finally:
+        G.PRECISION = old
+
+
 def test_las_training_step_matches_reference():
     _las_training_step("cpu")
 
