@@ -184,7 +184,7 @@ def train_step_workload(args, R_):
         graphed = GraphedTrainStep(model, loss_fn, make_optim, clip=3.0, warmup=2)
     state = {"optim": graphed.optimizer if graphed is not None else make_optim(), "n": 0}
     bmuf = None
-    if world > 1:
+    if world > 1 and getattr(R_, "rccl_ok", True):
         from trainer.bmuf import BmufTrainer
         bmuf = BmufTrainer(0, rank, world, model, 0.9, 1.0)
         bmuf.collective_events = []
@@ -307,6 +307,19 @@ def run_train_step(args, R_, steps, warmup):
                        "bound_direct_ms": 2.0 * (nbytes / world) / 153e9 * 1e3,
                        "bound_ring_ms": 2.0 * (world - 1) / world * nbytes / 153e9 * 1e3,
                        "amortised_ms_per_step": (float(np.mean(ms)) / 5.0) if ms else None}
+    elif world > 1:
+        out["bmuf"] = {"error": "skipped: rccl_selfcheck failed on some rank (see rccl_selfcheck in the line); the step above "
+                                "ran WITHOUT the block exchange"}
+    if world > 1:
+        # every rank's own view: its step time, the host time of its loader thread, its exchange time -- eight ranks share
+        # one host, and a straggler shows here, not in the max
+        import resource
+        mine = {"rank": R_.rank, "ms_per_step_local": None, "loader_host_ms_per_batch": out["loader"]["host_ms_per_batch"],
+                "all_reduce_ms": (out.get("bmuf") or {}).get("all_reduce_ms"),
+                "process_cpu_s": resource.getrusage(resource.RUSAGE_SELF).ru_utime +
+                resource.getrusage(resource.RUSAGE_SELF).ru_stime,
+                "cpu_affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+        out["per_rank"] = R_.gather(mine)
     return out
 
 
@@ -682,26 +695,46 @@ class Ranks(object):
                 self.local_rank = int(os.environ["PIKA_BENCH_DEVICE"])
             torch.cuda.set_device(self.local_rank)
             self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1 and hasattr(os, "sched_setaffinity") and os.environ.get("PIKA_BENCH_PIN", "1") != "0":
+            # N ranks (training thread + loader thread + RCCL proxy each) on one host: every rank keeps to its own
+            # contiguous slice of the cores it was given -- on a two-socket 8-GPU node that is also the socket of its GPU
+            # (GPUs 0-3 / 4-7) -- instead of all ranks' threads migrating over all cores
+            cores = sorted(os.sched_getaffinity(0))
+            per = len(cores) // self.world
+            if per >= 2:
+                lr = self.local_rank % self.world
+                os.sched_setaffinity(0, cores[lr * per:(lr + 1) * per])
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = os.environ.get("PIKA_BENCH_BACKEND", "gloo" if dry_run else "nccl")   # "nccl" is RCCL on ROCm
             dist.init_process_group(backend=backend, init_method="env://")
             self.backend = backend
-            self.selfcheck = None
+            # The CONTROL plane of the benchmark -- barriers, the max-over-ranks of the timed region, per-rank reports --
+            # runs over a gloo group of its own: the first RCCL run of this code is the driver's, and a broken RCCL must
+            # cost the BMUF leg its numbers, not the whole line (the headline path has no data-path collective).
+            self.ctl = dist.new_group(backend="gloo") if backend != "gloo" else None
+            self.selfcheck, self.rccl_ok = None, True
             if not dry_run and backend == "nccl" and os.environ.get("PIKA_BENCH_SELFCHECK", "1") != "0":
                 # first contact with RCCL on this node: a diagnosis instead of a hang (tools/rccl_selfcheck.py)
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import rccl_selfcheck
-                self.selfcheck = rccl_selfcheck.selfcheck(self.dev)
+                try:
+                    self.selfcheck = rccl_selfcheck.selfcheck(self.dev)
+                except Exception as e:          # diagnosed, reported in the line, the BMUF leg is skipped on EVERY rank
+                    self.selfcheck = {"error": "%s: %s" % (type(e).__name__, str(e)[:600])}
+                ok = torch.tensor([0 if "error" in (self.selfcheck or {}) else 1])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.ctl)
+                self.rccl_ok = bool(int(ok[0]))
         else:
             self.backend = None
             self.selfcheck = None
+            self.ctl, self.rccl_ok = None, True
 
     def sync(self):
         if not self.dry_run:
             torch.cuda.synchronize()
         if self.world > 1:
-            dist.barrier()
+            dist.barrier(group=self.ctl)
         if not self.dry_run:
             torch.cuda.synchronize()
 
@@ -717,14 +750,22 @@ class Ranks(object):
         self.sync()
         el = time.perf_counter() - t0
         if self.world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.ctl)
             el = float(t.item())
         return el, last
 
+    def gather(self, obj):
+        """One object per rank -> list on every rank (control plane)."""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.ctl)
+        return out
+
     def finish(self):
         if self.world > 1:
-            dist.barrier()
+            dist.barrier(group=self.ctl)
             dist.destroy_process_group()
 
 
@@ -823,7 +864,7 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
             ts = run_train_step(args, R_, steps, warmup)
         finally:
             G.PRECISION = old_mode
-        keep = ("value", "unit", "ms_per_step", "dtype", "config", "roofline", "bmuf", "loader")
+        keep = ("value", "unit", "ms_per_step", "dtype", "config", "roofline", "bmuf", "loader", "per_rank")
         ts = {k: ts[k] for k in keep if k in ts}
         ts["parity"] = ("encoder activations and RNN-T loss within 1e-3 of the reference model's fp32 golden on the full "
                         "architecture in this arithmetic (tests/test_model_full.py::test_gpu_modes_against_reference_full_golden"
@@ -1247,17 +1288,17 @@ def run_m1p(args, R_, steps, warmup):
     R.KERNEL_EVENTS = {"fwd": [], "bwd": []}
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=R_.ctl)
     t0 = time.perf_counter()
     for _ in range(steps):
         costs = step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.barrier(group=R_.ctl)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     ev, R.KERNEL_EVENTS = R.KERNEL_EVENTS, None
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=R_.ctl)
     el = float(t.item()) / steps
     if rank != 0:
         return None
@@ -1394,7 +1435,7 @@ def main():
         if rank == 0:
             print(json.dumps(d), flush=True)
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=R_.ctl)
             dist.destroy_process_group()
         return
     if args.workload == "mbr_step":
@@ -1403,16 +1444,16 @@ def main():
             step()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=R_.ctl)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.barrier(group=R_.ctl)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=R_.ctl)
         el = float(t.item()) / args.steps
         if rank == 0:
             cb = None
@@ -1433,7 +1474,7 @@ def main():
                            "batch_per_gpu": B, "beam": args.beam, "expected_risk": info.get("risk"),
                            "hyp_labels": info.get("hyp_labels")}}), flush=True)
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=R_.ctl)
             dist.destroy_process_group()
         return
     if args.workload == "train_step":
