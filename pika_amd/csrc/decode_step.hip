@@ -424,6 +424,19 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
 // Workgroups walk the tiles of their XCD's column tiles (column tile nt lives on XCD nt % 8: the row tiles sharing a
 // slab of W find it in that XCD's L2).  LN: the rows of A are layer-normalised on the way in (the statistics need the
 // whole row: partial sums of the waves meet in LDS, two passes like ln_fwd_kernel) -- one launch instead of two.
+#ifdef PIKA_SK_TRACE      // profiling builds only (tools/sk_trace.py): time stamps of workgroup 0's first wave, summed over launches
+__device__ unsigned long long g_sk_trace[8][8];
+__device__ inline unsigned long long *sk_slots() { __shared__ unsigned long long s_[8]; return s_; }
+#define SK_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { sk_slots()[k] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 6) { const int v_ = (LN ? 4 : 0) + (KW == 8 ? 2 : 0) + (PIPE ? 1 : 0); \
+        for (int i_ = 1; i_ < 7; ++i_) g_sk_trace[v_][i_] += sk_slots()[i_] - sk_slots()[0]; g_sk_trace[v_][0] += 1; } } } while (0)
+extern "C" int pika_debug_sk_trace(unsigned long long *out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sk_trace), sizeof(g_sk_trace));
+}
+#else
+#define SK_STAMP(k) do { } while (0)
+#endif
+
 template <int NSM, int KW, int MT, int WN, int CH, bool LN, bool PIPE>
 __global__ __launch_bounds__(64 * KW, KW == 16 ? 4 : 2) void dgemm_sk_kernel(DG p) {
     constexpr bool F16 = NSM == TERMS_F16X2;
@@ -436,9 +449,11 @@ __global__ __launch_bounds__(64 * KW, KW == 16 ? 4 : 2) void dgemm_sk_kernel(DG 
     __shared__ __attribute__((aligned(16))) float ln_gb[LN ? 2 : 1][LN ? 1024 : 4];      // gamma | beta (K <= 1024)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the wave's k-tile range is uniform)
+    SK_STAMP(0);
     int M = p.M;
     if (p.m_dev) M = min(M, *p.m_dev);
     if (M <= 0) return;
+    SK_STAMP(1);
     const int m_tiles = (M + BMR - 1) / BMR;
     const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jstride = gridDim.x >> 3;
     const int NG = (p.NT + WN - 1) / WN;                    // column groups of WN tiles; group g lives on XCD g % 8
@@ -520,7 +535,9 @@ __global__ __launch_bounds__(64 * KW, KW == 16 ? 4 : 2) void dgemm_sk_kernel(DG 
         };
         Req q0;
         [[maybe_unused]] Req q1;
+        SK_STAMP(2);
         issue(0, q0);
+        SK_STAMP(3);
         {
             // (3) the epilogue's additive terms (whole aligned groups of 4 columns; others are read in dg_finish)
             if (e_on) {
@@ -689,6 +706,7 @@ __global__ __launch_bounds__(64 * KW, KW == 16 ? 4 : 2) void dgemm_sk_kernel(DG 
         } else {
             compute(0, q0);             // (the host entry chose KW such that one round covers the reduction)
         }
+        SK_STAMP(4);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -697,12 +715,14 @@ __global__ __launch_bounds__(64 * KW, KW == 16 ? 4 : 2) void dgemm_sk_kernel(DG 
                 *reinterpret_cast<f32x4 *>(&red[wave][t * 16 + (lane & 15)][j * 16 + (lane >> 4) * 4]) = acc[t][j];
             }
         __syncthreads();
+        SK_STAMP(5);
         if (e_on) {
             f32x4 v = *reinterpret_cast<const f32x4 *>(&red[0][tid / CQ][(tid % CQ) * 4]);
 #pragma unroll
             for (int w_ = 1; w_ < KW; ++w_) v += *reinterpret_cast<const f32x4 *>(&red[w_][tid / CQ][(tid % CQ) * 4]);
             dg_finish(p, e_r, e_c0, v, pre, pb, pr);
         }
+        SK_STAMP(6);
         if (q + jstride < total) __syncthreads();           // `red` is rewritten by the next tile
     }
 }
