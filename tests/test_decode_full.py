@@ -119,8 +119,8 @@ def against_f64(lst, f, b):
 def check_against_f64(lst, f, tag, eps):
     """Which order is RIGHT is a float64 question: the fp32 reference list holds runs of entries 1e-4
     apart.  Against the reference decoder run in float64: the top-1 is the float64 top-1; every score is within `eps` of
-    its float64 value; an entry that is not at its float64 rank has moved by less than 2 eps in float64 score (its
-    displacement IS the score noise); entries that the float64 search did not finish at all (the searches part ways on a
+    its float64 value; two entries in the other order than in the float64 list are less than 2 eps apart in float64 score
+    (the swap IS the score noise); entries that the float64 search did not finish at all (the searches part ways on a
     beam-boundary tie) are counted and bounded."""
     B, nb = lst["lens"].shape
     found = at_rank = 0
@@ -130,14 +130,17 @@ def check_against_f64(lst, f, tag, eps):
         worst = max(worst, err)
         assert ranks[0] == 0, "%s: top-1 of utterance %d is not the float64 top-1" % (tag, b)
         assert err < eps, (tag, b, err)
-        for j, k in enumerate(ranks):
-            if k < 0:
-                continue
-            found += 1
-            at_rank += int(k == j)
-            if k != j and j < int(f["count"][b]):
-                moved = abs(float(f["scores"][b, k]) - float(f["scores"][b, j]))
-                assert moved < 2 * eps, "%s: utterance %d rank %d sits at float64 rank %d, %.2e away" % (tag, b, j, k, moved)
+        ks = [k for k in ranks if k >= 0]
+        found += len(ks)
+        # order among the entries both searches finished (an entry only one of them finished shifts every later rank by
+        # one, which is not a displacement): in place = the same position in both lists' common subsequence
+        at_rank += sum(int(k == o) for k, o in zip(ks, sorted(ks)))
+        for i1 in range(len(ks)):
+            for i2 in range(i1 + 1, len(ks)):
+                if ks[i1] > ks[i2]:     # an inversion: the two are closer than the score noise in float64
+                    moved = abs(float(f["scores"][b, ks[i1]]) - float(f["scores"][b, ks[i2]]))
+                    assert moved < 2 * eps, "%s: utterance %d: float64 ranks %d and %d swapped, %.2e apart" % (
+                        tag, b, ks[i1], ks[i2], moved)
         assert sum(1 for k in ranks if k >= 0) >= nb - 2, (tag, b, ranks)
     print("%s against the float64 reference run: %d of %d entries finished by the float64 search too, %d at their float64 "
           "rank, max |score - float64 score| %.2e" % (tag, found, B * nb, at_rank, worst))
@@ -174,11 +177,11 @@ def test_gpu_full_width_decode_matches_reference(hip_device):
           "n-best entries at the reference rank, the rest are swaps among entries < 1.5e-3 apart in score; max |score "
           "diff| %.2e" % (rel, F.B, 100 * frac, F.B * F.BEAM, float(np.abs(got["scores"] - z["scores"]).max())))
     # and against the TRUTH -- the reference decoder run in float64: the GPU's scores are as close to it as the fp32
-    # reference's own (measured 3.7e-4 vs 2.9e-4), and wherever an entry is not at its float64 rank it has moved by less than
-    # twice that noise.  (The fp32 reference's ranks are all float64 ranks: the swaps between the GPU's list and the fp32
+    # reference's own (measured 3.7e-4 vs 2.9e-4), and the entries both searches finish come in the float64 order (measured:
+    # 61 found, 61 in order; an inversion would have to be closer than twice that noise).  (The fp32 reference's ranks are all float64 ranks: the swaps between the GPU's list and the fp32
     # golden above are the GPU's noise, not the golden's.)
     found, at_rank, worst = check_against_f64(got, np.load(GOLD_F64), "GPU fp32-grade search", 5e-4)
-    assert found >= 60 and at_rank >= found - 6, (found, at_rank)
+    assert found >= 60 and at_rank >= found - 2, (found, at_rank)
     # the mode is deterministic from run to run (no float atomics on its path: its forward products never split their
     # reduction): same lists, same bits in the scores
     again, _, _ = decode(hip_device, "fp32")
