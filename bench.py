@@ -462,11 +462,11 @@ def decode_workload(args, dev, rank):
     x_len = torch.full((B,), (T - 42 + 3) // 4, dtype=torch.long, device=dev)
     dargs = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
     lm_scorer = synthetic_bigram_matcher(V) if args.fst else None
-    las_fw = las_bw = None
+    las_fw = las_bw = las_mod = None
     SOS, EOS, PAD = V, V + 1, V + 2
     if args.las:   # forward + backward LAS rescorers, 2-layer BLSTM 1024, mlp attention, random weights
-        os.environ.setdefault("PIKA_LAS_TIMING", "1")       # phase times of a rescoring pass into the line (las_phases_ms)
         from trainer.model import las
+        las_mod = las
         lopt = SimpleNamespace(rnn_size=1024, encoder_type="rnn", rnn_type="LSTM", brnn=True, enc_layers=2,
                                dropout=0.0, use_downsampler=False, embd_dim=100, num_heads=1, sampling_decoder=False,
                                input_feed=1, dec_layers=2, global_attention="mlp", coverage_attn=False,
@@ -516,6 +516,7 @@ def decode_workload(args, dev, rank):
         model.fc2.bias[0] = 0.5 * (lo + hi)
         decode_workload.blank_bias = 0.5 * (lo + hi)
     dec = decoder(args.beam, args.beam, lm_scorer)
+    x_len_host = [int(v) for v in x_len]     # (the decode script holds the lengths on the host: decode_transducer.py:100-110)
 
     def step():
         ret, enc_out = dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
@@ -531,10 +532,15 @@ def decode_workload(args, dev, rank):
             dec.timing["las_max_labels"] = cap
             dec.timing["las_pairs"] = sum(len(h) + 1 for row in hyps for h in row)
             src = enc_out.transpose(0, 1)                                   # (T', B, H)
-            fw = las_fw.score_nbest_batch(src, x_len, hyps, SOS, EOS)
-            bw = las_bw.score_nbest_batch(src, x_len, [[h[::-1] for h in row] for row in hyps], SOS, EOS)
-            ret["las"] = (fw, bw)
+            # both rescorers as one call (las.score_nbest_batch_many).  Phase times (device-synchronised at every phase) only in
+            # the first call.
+            os.environ["PIKA_LAS_TIMING"] = "1" if step.calls == 0 else "0"
+            step.calls += 1
+            ret["las"] = tuple(las_mod.score_nbest_batch_many(
+                [(las_fw, src, x_len_host, hyps, SOS, EOS, 1.0),
+                 (las_bw, src, x_len_host, [[h[::-1] for h in row] for row in hyps], SOS, EOS, 1.0)]))
             torch.cuda.synchronize()
+            step.las_calls.append(round(time.perf_counter() - t0, 4))
             # decoder row steps actually computed: entries of an utterance that share a prefix share its rows
             dec.timing["las_row_steps"] = {"fw": getattr(las_fw, "last_pass", None), "bw": getattr(las_bw, "last_pass", None)}
             if getattr(las_fw, "phase_times", None):
@@ -542,6 +548,8 @@ def decode_workload(args, dev, rank):
         dec.timing["las_s"] = time.perf_counter() - t0
         return ret, enc_out
     step.decoder = dec
+    step.calls = 0
+    step.las_calls = []
     return step, float(labels)
 
 
@@ -680,6 +688,18 @@ def self_launch(n, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+HARNESS_NOTE = ("gc.collect() + gc.freeze() after the warm-up steps of a leg: the interpreter's full collections walk the ~1e6 live "
+                "objects of the models and tables (a 45 ms stall every fourth decode batch, profiles/r5_las_pass_overlap.txt); "
+                "frozen, collections still run over the objects made afterwards.  PIKA_BENCH_GC_FREEZE=0: off")
+
+
+def freeze_gc():
+    if os.environ.get("PIKA_BENCH_GC_FREEZE", "1") != "0":
+        import gc
+        gc.collect()
+        gc.freeze()
+
+
 class Ranks(object):
     """Rank bookkeeping + the timing contract: barrier + synchronize on both sides, MAX over ranks."""
 
@@ -743,6 +763,7 @@ class Ranks(object):
         last = None
         for _ in range(warmup):
             last = step()
+        freeze_gc()
         self.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -1427,6 +1448,7 @@ def main():
         if rank == 0:
             d = decode_report(args, step, ret, el, B * T / 100.0, world, cal_labels)
             d["steps"], d["warmup"] = args.steps, args.warmup
+            d["harness"] = HARNESS_NOTE
             print(json.dumps(d), flush=True)
         R_.finish()
         return
@@ -1506,6 +1528,7 @@ def main():
         if rank == 0:
             out["mbr_step"] = m
     if rank == 0:
+        out["harness"] = HARNESS_NOTE
         print(json.dumps(out), flush=True)
     R_.finish()
 

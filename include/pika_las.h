@@ -15,6 +15,7 @@
 #ifndef PIKA_LAS_H
 #define PIKA_LAS_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -48,6 +49,19 @@ int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, co
                            float *align_out, int N, int B, int S, int D, const int *n_dev, const int *qoff_dev,
                            void *stream);
 
+/* The same attention for a query list ORDERED BY UTTERANCE, utterance by utterance (two launches): a workgroup takes all
+ * the queries of one utterance and a chunk of 32 of its positions -- the utterance's U_a h_s and h_s rows are read once
+ * per workgroup instead of once per query (111 -> ~40 us at 470 queries, S = 240, D = 1024) -- and a second launch merges
+ * the chunks' partial (max, sum, context sums) into ctx_out.  Same values to rounding (another summation order).
+ * uoff int32 (B + 1): the queries of utterance b are entries [uoff[b], uoff[b + 1]) of the list (qidx + *qoff_dev, of
+ * min(N, *n_dev) entries); with step_dev the table of the current step, uoff + *step_dev * (B + 1) (step[0] of
+ * pika_las_step_advance).  work: f32 scratch of pika_las_attention_work_floats(N, S, D) floats, 16-byte aligned. */
+size_t pika_las_attention_work_floats(int N, int S, int D);
+int pika_las_mlp_attention_by_utterance(const float *wq, long long ldq, const float *proj, const float *context,
+                                        const int *owner, const int *lens, const int *qidx, const int *uoff, const float *v,
+                                        float *ctx_out, long long ldo, float *work, int N, int B, int S, int D,
+                                        const int *n_dev, const int *qoff_dev, const int *step_dev, void *stream);
+
 /* The token loop of a rescoring pass as ONE captured launch sequence replayed once per token: every per-token quantity
  * lives on the device.  step int32[4] = {t, n, qoff, -} (the caller starts it at {-1, 0, 0, 0});
  * pika_las_step_advance: t += 1, n = n_active[t], qoff = qoffs[t] (0 beyond L) -- n is what the m_dev / n_dev
@@ -63,7 +77,8 @@ int pika_las_step_advance(int *step, const int *n_active, const int *qoffs, int 
  * k in [fork_off[t], fork_off[t+1]) and every segment i < nseg (<= PIKA_LAS_FORK_SEGS):
  *   base[i][fork_dst[k], col0[i] : col0[i] + ncols[i]] = base[i][fork_src[k], same columns]   (row pitch ld[i], floats)
  * t = step[0] (after pika_las_step_advance); fork_off int32[L + 1]; max_forks = the largest number of forks of a step
- * (sizes the grid).  Source and destination rows of a step are disjoint.  Columns / pitches multiples of 4. */
+ * (sizes the grid).  Source and destination rows of a step are disjoint.  Columns / pitches multiples of 4.   A step without active rows (step[1] == 0: beyond the pass, when a longer pass shares the
+ * replayed launch sequence) copies nothing. */
 #define PIKA_LAS_FORK_SEGS 8
 int pika_las_fork_rows(const int *step, const int *fork_off, const int *fork_dst, const int *fork_src, int max_forks,
                        int nseg, float *const *base, const long long *ld, const int *col0, const int *ncols, void *stream);

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -70,6 +70,9 @@ SIGNATURES = {
     # include/pika_las.h
     "pika_lstm_cell": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_las_mlp_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pika_las_attention_work_floats": (ctypes.c_size_t, [_i, _i, _i]),
+    "pika_las_mlp_attention_by_utterance": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i,
+                                                 _vp, _vp, _vp, _vp]),
     "pika_las_step_advance": (_i, [_vp, _vp, _vp, _i, _vp]),
     "pika_las_embed_rows": (_i, [_vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _vp, _vp]),
     "pika_las_fork_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -410,6 +410,51 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DG p) {
     }
 }
 
+// ---- wide products on some hundred rows (the LSTM gate products of a LAS scoring pass: 64..1000 rows x 4096 x 2560) --
+// What bounds these launches is the rate at which ONE CU pulls operand bytes that are not in its XCD's L2 -- ~50 GB/s,
+// a third of its L1 rate, with two steps of requests in flight: W (33-44 MB) streams from the Infinity Cache, and the row
+// tiles that share a slab of it run in lockstep, so each of them waits for the same fills.  A tile of BM x BN needs
+// 4 (BM + BN) K bytes: dgemm_kernel's 64 x 64 tiles on 2 workgroups per CU took 80 us at 470 rows (57 us at 64 rows: 40
+// dependent steps); 64 x 128 tiles, one per CU: 1.5 MB per CU, 42 us at 470 rows, 37 us at 64 (tools/las_gemm_bench.py).
+// Measured no better: 128-row tiles on eight waves (fewer CUs), 32-row tiles on two workgroups per CU (25 us up to 256
+// rows, 80 us at 960), W fragments two or three steps ahead in registers (43 -> 34 us while one workgroup per CU
+// suffices, two rounds beyond), the conversion of the next A pieces scheduled under the MFMAs (tools/core_trace.hip).
+// XCD x owns the column groups x, x + 8, ..: their slabs of W are fetched into ONE L2.
+template <int NS>
+__global__ __launch_bounds__(256) void dgemm_wide_kernel(DG p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 64;
+    Core<BM, 2, NS, 2> core;
+    const int n_groups = (p.NT + 7) / 8;
+    int mg, ng;
+    {   // XCD x owns the column groups x, x + 8, ..; its workgroups walk them ROW TILE BY ROW TILE: the launch is sized for
+        // the largest step of a scoring pass, and the row tiles beyond this step's rows (idle workgroups: ~0.3 us of
+        // dispatch each, 20 us in front of a 64-row step when they are interleaved with the live ones) come last
+        const int g = blockIdx.x, xcd = g & 7, i = g >> 3, gpx = (n_groups + 7) >> 3;
+        ng = xcd + 8 * (i % gpx);
+        mg = i / gpx;
+        if (ng >= n_groups) return;
+    }
+    int M = p.M;
+    if (p.m_dev) M = min(M, *p.m_dev);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = mg * BM, nt0 = ng * 8 + wave * 2;
+    if (m0 >= M) return;
+    const int *rows = p.rowlist ? p.rowlist + (p.rowoff_dev ? *p.rowoff_dev : 0) : nullptr;
+    core.run(p.A, p.lda, M, m0, p.W, p.NT, p.KT, nt0, reinterpret_cast<__bf16 *>(smem), p.Kvalid, rows);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c0 = (nt0 + j) * 16 + (lane >> 4) * 4;
+        if (nt0 + j >= p.NT || c0 >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < BM / 16; ++i) {
+            const int e_ = m0 + i * 16 + (lane & 15);
+            if (e_ >= M) continue;
+            dg_finish(p, rows ? rows[e_] : e_, c0, core.acc[i][j], false, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+    }
+}
+
 // ---- products on few rows: one 16-column tile per workgroup, the reduction split over its waves --------------------
 // The prediction-network products of a search step run on the ~B*beam/6 rows that emitted a label: a handful of row
 // tiles.  dgemm_kernel (a wave owns 16 columns and walks the WHOLE reduction in steps of 64-128 columns) is then a chain
@@ -1279,6 +1324,15 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
 #undef PIKA_SK_W
 #undef PIKA_SK_T
 #undef PIKA_SK
+        return check(hipGetLastError());
+    }
+    // wide products (N >= 2048) beyond the few-rows kernel: 64 x 128 tiles (PIKA_DGEMM_WIDE=0: the 64 x 64 tiles, A/B runs)
+    static const bool wide_on = [] { const char *e = getenv("PIKA_DGEMM_WIDE"); return !e || atoi(e) != 0; }();
+    if (q->N >= 2048 && wide_on && !(q->flags & PIKA_DG_GATE)) {
+        const unsigned grid = (unsigned)(8 * ((((p.NT + 7) / 8) + 7) / 8) * ((q->M + 63) / 64));
+#define PIKA_WIDE(NS) dgemm_wide_kernel<NS><<<dim3(grid), dim3(256), Core<64, 2, NS, 2>::LDS_BYTES, st>>>(p)
+        if (q->terms == 1) PIKA_WIDE(1); else if (q->terms == 2) PIKA_WIDE(2); else if (q->terms == 3) PIKA_WIDE(3); else PIKA_WIDE(4);
+#undef PIKA_WIDE
         return check(hipGetLastError());
     }
     const int n_groups = (p.NT + 3) / 4;

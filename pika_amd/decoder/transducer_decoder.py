@@ -344,11 +344,29 @@ def _batch_ahead(self, which, rescorer, x, tgt, scale):
     table = nb["scores"].get(key)
     if table is None:
         B = enc.shape[0]
-        lists = [[[int(e) for e in h if int(e) != self.blk] for h in nb["hyps"][b]] for b in range(B)]
-        if which == "bw":
-            lists = [[h[::-1] for h in row_] for row_ in lists]
-        got = rescorer.score_nbest_batch(enc.transpose(0, 1), [enc.shape[1]] * B, lists, sos, eos, scale=scale)
-        table = nb["scores"][key] = {(b, tuple(h)): sc for b in range(B) for h, sc in zip(lists[b], got[b])}
+
+        def lists_of(which_):
+            lists = [[[int(e) for e in h if int(e) != self.blk] for h in nb["hyps"][b]] for b in range(B)]
+            return [[h[::-1] for h in row_] for row_ in lists] if which_ == "bw" else lists
+        # The script asks the forward and the backward rescorer about the same batch one after the other
+        # (decode_transducer.py:136-156, same SOS / EOS): both passes are run at the first request
+        # (las.score_nbest_batch_many; PIKA_LAS_PAIR=0: each at its own first request)
+        jobs = [(which, rescorer)]
+        other = {"fw": "bw", "bw": "fw"}.get(which)
+        r2 = {"fw": getattr(self, "las_rescorer", None), "bw": getattr(self, "las_rescorer_bw", None)}.get(other)
+        if (r2 is not None and hasattr(r2, "score_nbest_batch") and (other, sos, eos) not in nb["scores"]
+                and os.environ.get("PIKA_LAS_PAIR", "1") != "0"):
+            jobs.append((other, r2))
+        lists = [lists_of(w) for w, _ in jobs]
+        src = enc.transpose(0, 1)
+        if all(hasattr(r, "_batch_stages") for _, r in jobs):
+            from ..model.las import score_nbest_batch_many
+            got = score_nbest_batch_many([(r, src, [enc.shape[1]] * B, ls, sos, eos, scale) for (_, r), ls in zip(jobs, lists)])
+        else:       # (a rescorer of another class that offers the batched call)
+            got = [r.score_nbest_batch(src, [enc.shape[1]] * B, ls, sos, eos, scale=scale) for (_, r), ls in zip(jobs, lists)]
+        for (w, _), ls, g in zip(jobs, lists, got):
+            nb["scores"][(w, sos, eos)] = {(b, tuple(h)): sc for b in range(B) for h, sc in zip(ls[b], g[b])}
+        table = nb["scores"][key]
     return table.get((i, hyp))
 
 

@@ -18,6 +18,17 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 from . import ops
 
 
+def _h2d(x, dev, dtype=None):
+    """Small host array -> device.  (Measured on this runtime, ROCm 7.2: staging these arrays through pinned memory and
+    non-blocking copies -- so that a second scoring pass' host work could run under the first one's kernels -- made the
+    kernels that followed slower, 58 -> 76 ms for the two passes of a decode batch; profiles/r5_las_pass_overlap.txt.  The
+    plain copy from pageable memory waits for the stream, which paces the host to the device.)"""
+    t = torch.from_numpy(x) if not torch.is_tensor(x) else x
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
 def _phase_timer(net, dev):
     """PIKA_LAS_TIMING=1: wall time of the phases of a scoring pass (device-synchronised) into net.phase_times."""
     if os.environ.get("PIKA_LAS_TIMING") != "1" or dev.type != "cuda":
@@ -105,6 +116,87 @@ def scoring_plan(flat, own_h, sos, eos, pad, share):
             "rep": rep, "act": act}
 
 
+def _run_stages(gens):
+    """Scoring passes (Net._batch_stages generators), one after the other, each in its stages: encoder queued; host plan and
+    loop preparation (under the encoder's kernels); the token loop; the tail queued; the wait and the lists.
+    Tried on this runtime (ROCm 7.2, graph packet capture off) and measured worse -- profiles/r5_las_pass_overlap.txt:
+    the second pass' host work under the first pass' kernels (its replays, launched into a busy stream, cost 0.4-1.3 ms of
+    host time each); both passes' token loops as one replayed graph (a pass' weights and projected encoder outputs,
+    ~215 MB at B = 64, stay in the Infinity Cache from token to token; two passes' do not: 1.3 x the kernel time); the
+    loops launched from Python without a graph (twice the device time)."""
+    out = []
+    for g in gens:
+        next(g)
+        drive_token_loops([next(g)])
+        next(g)
+        out.append(next(g))
+    return out
+
+
+def score_nbest_batch_many(jobs):
+    """Several rescorers on one decode batch (the forward and the backward LAS of decode_transducer.py:136-156):
+    jobs = [(net, src, lengths, hyps, sos, eos, scale), ..] -> [net.score_nbest_batch(src, lengths, hyps, sos, eos, scale), ..].
+    The passes run one after the other (_run_stages says what else was tried)."""
+    with torch.no_grad():
+        preps = [net._batch_prep(src, lengths, hyps) for net, src, lengths, hyps, _, _, _ in jobs]
+        for _ in range(2):      # (a second round only if a persistent encoder launch was not resident: status_ok)
+            gens = [net._batch_stages(prep, sos, eos, scale) for (net, _, _, _, sos, eos, scale), prep in zip(jobs, preps)]
+            scores = _run_stages(gens)
+            if all(net.encoder.status_ok() for net, _, _, _, _, _, _ in jobs):
+                break
+        out = []
+        for (net, _, _, hyps, _, _, _), sc in zip(jobs, scores):
+            res, i = [], 0
+            for h in hyps:
+                res.append(sc[i:i + len(h)])
+                i += len(h)
+            out.append(res)
+        return out
+
+
+class TokenLoop(object):
+    """A prepared token loop of the fused decoder (InputFeedRNNDecoder._prepare_fused): step() queues one token's launches
+    -- every per-token quantity is a device word the step's first launch advances, past the loop's L tokens the launches
+    find zero active rows -- and outs (L, N, H) receives the outputs."""
+
+    def __init__(self, step, L, outs, dev):
+        self.step, self.L, self.outs, self.dev = step, L, outs, dev
+
+
+def drive_token_loops(loops):
+    """Run prepared token loops: token 0 of each eagerly (lazy kernel attributes reach their state), then ONE captured
+    launch sequence -- a token of every loop -- replayed max(L) - 1 times (PIKA_LAS_GRAPH=0: the same launches from
+    Python)."""
+    loops = [lp for lp in loops if lp is not None]
+    if not loops:
+        return
+    dev = loops[0].dev
+    with torch.cuda.device(dev):
+        for lp in loops:
+            lp.step()
+        n_more = max(lp.L for lp in loops) - 1
+        if n_more <= 0:
+            return
+        if os.environ.get("PIKA_LAS_GRAPH", "1") != "0":
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(cur)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                graph.capture_begin(capture_error_mode="thread_local")
+                for lp in loops:
+                    if lp.L > 1:
+                        lp.step()
+                graph.capture_end()
+            cur.wait_stream(side)
+            for _ in range(n_more):
+                graph.replay()
+        else:
+            for _ in range(n_more):
+                for lp in loops:
+                    lp.step()
+
+
 class LASRNNEncoder(nn.Module):
     def __init__(self, rnn_type, bidirectional, num_layers, hidden_size, dropout, input_dim):
         super().__init__()
@@ -139,7 +231,7 @@ class LASRNNEncoder(nn.Module):
         S, B, _ = input.shape
         lens_h = torch.as_tensor(lengths).view(-1).to(torch.int64).cpu()
         s_out = int(lens_h.max())
-        lens_d = lens_h.to(device=dev, dtype=torch.int32)
+        lens_d = _h2d(lens_h, dev, torch.int32)
         x = input[:s_out].contiguous()
         S = s_out
         hs, cs = [], []
@@ -353,6 +445,11 @@ class InputFeedRNNDecoder(nn.Module):
         self.attn = GlobalAttention(hidden_size, coverage=False, attn_type=attn_type)
         self._copy = False
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_packed", None)          # the packed copies of the weights (a scoring pass' cache) are not part of a checkpoint
+        return state
+
     def _fix_enc_hidden(self, h):
         if self.bidirectional_encoder:
             h = torch.cat([h[0:h.size(0):2], h[1:h.size(0):2]], 2)
@@ -367,13 +464,14 @@ class InputFeedRNNDecoder(nn.Module):
                 and H == self.hidden_size and H % 4 == 0 and H <= 1024 and E % 4 == 0 and S <= 2048
                 and context.dtype == torch.float32 and os.environ.get("PIKA_LAS_FUSED", "1") != "0")
 
-    def _run_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None):
+    def _prepare_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None):
         """The token loop of `run` for N hypotheses of B utterances (owner (N,) -> utterance, lens (B,) valid source
         positions) on un-expanded encoder outputs: per token 2 x (one GEMM over [input | h] with [W_ih | W_hh] + one
-        LSTM-cell kernel), the query projection, ONE attention kernel (scores, softmax and context sum of a hypothesis
-        never leave the workgroup; the (N,S,H) tanh tensor of global_attention.py:218-221 does not exist) and the
+        LSTM-cell kernel), the query projection, the attention (a chunk launch + a merge launch, utterance by utterance:
+        the (N,S,H) tanh tensor of global_attention.py:218-221 does not exist, an utterance's rows are read once per
+        workgroup, not once per hypothesis) and the
         output projection written straight into the result and fed back (input feeding, las.py:649-668).
-        The nine launches of a token are captured ONCE into a hipGraph and replayed per token: the step index, the
+        The ten launches of a token are captured ONCE into a hipGraph and replayed per token: the step index, the
         number of active hypotheses and the query-list offset are device words a one-thread kernel advances
         (PIKA_LAS_GRAPH=0: the same launches issued from Python per token).
         spans = (first, end) host int arrays (N,): hypothesis row r takes part in steps first[r] <= t < end[r] (None:
@@ -406,10 +504,17 @@ class InputFeedRNNDecoder(nn.Module):
             # PIKA_LAS_TERMS=3: three bf16 terms, exact fp32 products, six MFMAs
             from ..decoder.fused_step import DGemm, PackedWeight
             terms = 1 if G.PRECISION == "bf16" else int(os.environ.get("PIKA_LAS_TERMS", "4"))
-            Wl = [PackedWeight(torch.cat([c.weight_ih, c.weight_hh], 1), terms) for c in self.rnn.layers]
-            bl = [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.rnn.layers]
-            Wq, bq = PackedWeight(att.linear_query.weight, terms), att.linear_query.bias.detach().float().contiguous()
-            Wo, bo = PackedWeight(att.linear_out.weight, terms), att.linear_out.bias.detach().float().contiguous()
+            # (packed once per set of weights: the pack is four kernels over ~90 MB, the weights of a scoring model do not change)
+            srcs = [w for c in self.rnn.layers for w in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)] + \
+                   [att.linear_query.weight, att.linear_query.bias, att.linear_out.weight, att.linear_out.bias]
+            pkey = (terms, str(dev)) + tuple((w.data_ptr(), w._version) for w in srcs)
+            if getattr(self, "_packed", (None,))[0] != pkey:
+                self._packed = (pkey,
+                                [PackedWeight(torch.cat([c.weight_ih, c.weight_hh], 1), terms) for c in self.rnn.layers],
+                                [(c.bias_ih + c.bias_hh).detach().float().contiguous() for c in self.rnn.layers],
+                                PackedWeight(att.linear_query.weight, terms), att.linear_query.bias.detach().float().contiguous(),
+                                PackedWeight(att.linear_out.weight, terms), att.linear_out.bias.detach().float().contiguous())
+            _, Wl, bl, Wq, bq, Wo, bo = self._packed
             v = att.v.weight.detach().reshape(-1).contiguous()
             # X[0] = [emb_t | feed | h_0], X[l] = [h_{l-1} | h_l]: a layer's input rows, updated in place
             X = [torch.zeros((N, E + 2 * H), device=dev)] + [torch.zeros((N, 2 * H), device=dev) for _ in range(1, nl)]
@@ -425,7 +530,7 @@ class InputFeedRNNDecoder(nn.Module):
             # (include/pika_las.h): step = {t, n, qoff}; the active hypotheses [0, n) of a step re-ordered by utterance,
             # so that the four queries of an attention workgroup share the utterance's rows
             import numpy as np
-            own_h = owner.cpu().numpy()
+            own_h = owner.cpu().numpy() if owner_host is None else np.asarray(owner_host)
             by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
             first = np.zeros(N, np.int64) if spans is None else np.asarray(spans[0], np.int64)
             end = np.full(N, L, np.int64) if spans is None else np.asarray(spans[1], np.int64)
@@ -433,10 +538,17 @@ class InputFeedRNNDecoder(nn.Module):
             lists = [by_owner[(f_o <= t) & (t < e_o)] for t in range(L)]
             n_act = np.asarray([len(x) for x in lists], np.int32)
             qoff = np.concatenate([[0], np.cumsum(n_act)]).astype(np.int32)
-            qlist = torch.from_numpy(np.concatenate(lists).astype(np.int32) if N else np.zeros(0, np.int32)).to(dev)
-            n_act_d = torch.from_numpy(n_act).to(dev)
-            qoff_d = torch.from_numpy(qoff[:L].copy()).to(dev)
-            step = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=dev)
+            qlist = _h2d(np.concatenate(lists).astype(np.int32) if N else np.zeros(0, np.int32), dev)
+            # per step, where each utterance's queries sit in the step's list (the lists are ordered by utterance): the
+            # attention runs utterance by utterance (pika_las_mlp_attention_by_utterance; PIKA_LAS_ATT=query: per query)
+            by_utt = os.environ.get("PIKA_LAS_ATT", "utterance") != "query" and N > 0
+            if by_utt:
+                uoff = np.stack([np.searchsorted(own_h[x], np.arange(B + 1)) for x in lists]).astype(np.int32)
+                uoff_d = _h2d(uoff, dev)
+                att_work = torch.empty(int(lib.pika_las_attention_work_floats(max(int(n_act.max()), 1), S, H)), device=dev)
+            n_act_d = _h2d(n_act, dev)
+            qoff_d = _h2d(qoff[:L].copy(), dev)
+            step = _h2d(np.array([-1, 0, 0, 0], np.int32), dev)
             n_dev = step[1:2]
             crow = torch.zeros(N, dtype=torch.long, device=dev)
             iden = torch.arange(N, dtype=torch.long, device=dev)
@@ -462,7 +574,7 @@ class InputFeedRNNDecoder(nn.Module):
             fork = None
             if forks is not None and len(forks[1]):
                 # rows that leave a shared prefix at step t inherit [feed | h_0], h_l and c_l of the row that computed it
-                f_off, f_dst, f_src = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in forks)
+                f_off, f_dst, f_src = (_h2d(np.ascontiguousarray(x), dev) for x in forks)
                 segs = [(X[0], E, 2 * H)] + [(X[l], H, H) for l in range(1, nl)] + [(c[l], 0, H) for l in range(nl)]
                 ns = len(segs)
                 fork = (f_off, f_dst, f_src, int(np.diff(forks[0]).max()), ns,
@@ -490,41 +602,36 @@ class InputFeedRNNDecoder(nn.Module):
                                                   nxt.stride(0), n_max, H, n_dev.data_ptr(), qlist.data_ptr(),
                                                   step[2:3].data_ptr(), st), "pika_lstm_cell")
                 dgemm(CQ[:, H:], 2 * H, Wq, bq, wq, H)
-                _lib.check(lib.pika_las_mlp_attention(wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(),
-                                                      ln.data_ptr(), qlist.data_ptr(), v.data_ptr(), CQ.data_ptr(), 2 * H,
-                                                      None, n_max, B, S, H, n_dev.data_ptr(), step[2:3].data_ptr(), st),
-                           "pika_las_mlp_attention")
+                if by_utt:
+                    _lib.check(lib.pika_las_mlp_attention_by_utterance(
+                        wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(), ln.data_ptr(), qlist.data_ptr(),
+                        uoff_d.data_ptr(), v.data_ptr(), CQ.data_ptr(), 2 * H, att_work.data_ptr(), n_max, B, S, H,
+                        n_dev.data_ptr(), step[2:3].data_ptr(), step[0:1].data_ptr(), st),
+                        "pika_las_mlp_attention_by_utterance")
+                else:
+                    _lib.check(lib.pika_las_mlp_attention(wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(),
+                                                          ln.data_ptr(), qlist.data_ptr(), v.data_ptr(), CQ.data_ptr(),
+                                                          2 * H, None, n_max, B, S, H, n_dev.data_ptr(),
+                                                          step[2:3].data_ptr(), st), "pika_las_mlp_attention")
                 # output projection of [context | h_t]: into row (t, r) of the result AND into the feed block of the
                 # layer-0 input rows (input feeding, las.py:649-668)
                 dgemm(CQ, 2 * H, Wo, bo, outs.view(L * N, H), H, crow_=crow, C2=X[0][:, E:], ldc2=X[0].stride(0))
 
-            token_step()                                      # token 0, eagerly (lazy kernel attributes reach their state)
-            if L > 1:
-                if os.environ.get("PIKA_LAS_GRAPH", "1") != "0":
-                    cur = torch.cuda.current_stream()
-                    side = torch.cuda.Stream(dev)
-                    side.wait_stream(cur)
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.stream(side):
-                        graph.capture_begin(capture_error_mode="thread_local")
-                        token_step()
-                        graph.capture_end()
-                    cur.wait_stream(side)
-                    for _ in range(L - 1):
-                        graph.replay()
-                else:
-                    for _ in range(L - 1):
-                        token_step()
-        return outs, None
+        return TokenLoop(token_step, L, outs, dev)
+
+    def _run_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None):
+        loop = self._prepare_fused(tokens, context, enc_hidden, owner, lens, spans, forks, owner_host)
+        drive_token_loops([loop])
+        return loop.outs, None
 
     def run(self, tokens, context, enc_hidden, mask=None, owner=None, lens=None, spans=None, forks=None, feed=None,
-            hidden_is_decoder_state=False):
+            hidden_is_decoder_state=False, owner_host=None):
         """tokens (L,N) decoder inputs, context (S,N,H).  Returns outputs (L,N,H).
         With `owner` (N,) and `lens` (B,): context / enc_hidden are per UTTERANCE ((S,B,H), (layers,B,H)) and hypothesis
         n reads utterance owner[n], whose valid source positions are [0, lens[owner[n]])."""
         if owner is not None:
             if self._fused_ok(context):
-                return self._run_fused(tokens, context, enc_hidden, owner, lens, spans, forks)
+                return self._run_fused(tokens, context, enc_hidden, owner, lens, spans, forks, owner_host)
             assert forks is None, "prefix sharing needs the fused token loop"
             S = context.shape[0]
             context = context[:, owner].contiguous()
@@ -647,7 +754,18 @@ class Net(nn.Module):
         return out, None, DecoderState(hidden, out[-1]), enc_out
 
     def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None):
-        """log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
+        """One pass of _score_stages on its own."""
+        def stages():
+            yield None
+            for item in self._score_stages(enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick, owner_host):
+                yield item
+        return _run_stages([stages()])[0]
+
+    def _score_stages(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None):
+        """A generator in three stages (_run_stages drives several passes stage by stage): (1) the host plan and the
+        prepared token loop, yielded for the caller to drive -- together with the other passes' loops; (2) the vocabulary
+        projection of the distinct rows, queued; (3) the wait and the lists.
+        log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
         owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).
 
         Decoder step t of a hypothesis is a function of its first t tokens only, and the n-best entries of an utterance
@@ -671,27 +789,48 @@ class Net(nn.Module):
         plan = scoring_plan(flat, owner_host, sos, eos, pad, share)
         L, ntok, perm, tok, first, end, forks, row_steps = (plan[k] for k in
                                                             ("L", "ntok", "perm", "tok", "first", "end", "forks", "row_steps"))
-        tok_d = torch.from_numpy(tok).to(dev)
-        own = owner[torch.from_numpy(perm).to(owner.device)]
+        tok_d = _h2d(tok, dev)
+        own = owner[_h2d(perm, owner.device)]
         _tick = _tick or (lambda name: None)
         _tick("host prep")
-        out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, spans=(first, end), forks=forks)
+        fused = owner is not None and self.decoder._fused_ok(enc_out)
+        if fused:
+            loop = self.decoder._prepare_fused(tok_d, enc_out, enc_hidden, own, lens, (first, end), forks, owner_host[perm])
+            yield loop
+            out = loop.outs
+        else:
+            yield None
+            out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, spans=(first, end), forks=forks)
         _tick("token loop (%d tokens, %d hypotheses, %d pairs, %d row steps)" % (L, n, int(ntok.sum()), row_steps))
         self.last_pass = {"pairs": int(ntok.sum()), "row_steps": row_steps, "shared": bool(share)}
         # the (step, hypothesis) pairs that exist, the (step, row) each one reads, the token each one predicts
         tt, rr, tgt = plan["pair_step"], plan["pair_row"], plan["pair_target"]
         key, inv = np.unique(tt * n + rr, return_inverse=True)                  # distinct (step, row) pairs
-        rows = out[torch.from_numpy(key // n).to(dev), torch.from_numpy(key % n).to(dev)]         # (R, H)
+        rows = out[_h2d(key // n, dev), _h2d(key % n, dev)]         # (R, H)
         logp = torch.log_softmax(scale * ops.linear(rows, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
-        want = torch.from_numpy(tgt).to(dev).clamp(max=logp.shape[1] - 1)
-        picked = logp[torch.from_numpy(inv).to(dev), want].cpu().numpy()
+        want = _h2d(tgt, dev).clamp(max=logp.shape[1] - 1)
+        picked_d = logp[_h2d(inv, dev), want]
+        # everything up to here is queued on the device; _run_stages queues the other passes' tails before the last stage --
+        # the only one that waits -- of any pass
+        if dev.type == "cuda":
+            host = torch.empty(picked_d.shape, dtype=picked_d.dtype, pin_memory=True)
+            host.copy_(picked_d, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+        else:
+            host, done = picked_d, None
+
+        yield None
+        if done is not None:
+            done.synchronize()
+        picked = host.numpy()
         _tick("vocabulary projection + log-softmax + gather (%d distinct rows)" % len(key))
         res, o = [None] * n, 0
         for i in range(n):
             res[i] = picked[o:o + ntok[i]].tolist()
             o += ntok[i]
         _tick("host lists")
-        return res
+        yield res
 
     @torch.no_grad()
     def score_nbest(self, src, hyps, sos, eos, scale=1.0):
@@ -707,12 +846,15 @@ class Net(nn.Module):
                 break
         return res
 
-    @torch.no_grad()
     def score_nbest_batch(self, src, lengths, hyps, sos, eos, scale=1.0):
         """All utterances of a decode batch at once: src (S,B,C) padded encoder outputs, lengths (B,), hyps[b] =
         list of label lists.  Returns out[b][j] = what score_nbest(src[:len_b, b:b+1], hyps[b])[j] returns.
         One batched encoder pass and ONE pass of the input-feed decoder over all sum_b len(hyps[b]) hypotheses
-        (decode_transducer.py:136-156 scores them one by one, re-encoding the utterance every time)."""
+        (decode_transducer.py:136-156 scores them one by one, re-encoding the utterance every time).
+        Two rescorers on the same batch: score_nbest_batch_many."""
+        return score_nbest_batch_many([(self, src, lengths, hyps, sos, eos, scale)])[0]
+
+    def _batch_prep(self, src, lengths, hyps):
         dev = src.device
         B = src.shape[1]
         lens = torch.as_tensor(lengths).to(torch.int64).cpu()
@@ -721,19 +863,15 @@ class Net(nn.Module):
         inv[order] = torch.arange(B)
         import numpy as np
         owner_h = np.repeat(inv.numpy(), [len(hyps[b]) for b in range(B)]).astype(np.int64)
-        owner = torch.from_numpy(owner_h).to(dev)
-        flat = [list(h) for b in range(B) for h in hyps[b]]
-        for _ in range(2):      # (a second pass only if the persistent encoder launch was not resident: status_ok)
-            _tick = _phase_timer(self, dev)
-            enc_hidden, enc_out = self.encoder(src[:, order.to(dev)], lens[order].to(torch.int32))
-            _tick("encoder")
-            scores = self._score_flat(enc_out, enc_hidden, owner, lens[order].to(dev), flat, sos, eos, scale, _tick,
-                                      owner_host=owner_h)
-            if self.encoder.status_ok():
-                break
-        res, i = [], 0
-        for b in range(B):
-            res.append(scores[i:i + len(hyps[b])])
-            i += len(hyps[b])
-        return res
+        return {"src": src, "dev": dev, "lens": lens, "order": order, "owner_h": owner_h, "owner": _h2d(owner_h, dev),
+                "flat": [list(h) for b in range(B) for h in hyps[b]]}
 
+    def _batch_stages(self, prep, sos, eos, scale):
+        dev, lens, order = prep["dev"], prep["lens"], prep["order"]
+        _tick = _phase_timer(self, dev)
+        enc_hidden, enc_out = self.encoder(prep["src"][:, _h2d(order, dev)], lens[order].to(torch.int32))
+        _tick("encoder")
+        yield None
+        for item in self._score_stages(enc_out, enc_hidden, prep["owner"], _h2d(lens[order], dev), prep["flat"], sos, eos,
+                                       scale, _tick, owner_host=prep["owner_h"]):
+            yield item

@@ -18,7 +18,8 @@ def _st():
 
 
 @pytest.mark.parametrize("terms,tol", [(1, 2e-2), (2, 2e-4), (3, 2e-6), (4, 4e-6)])
-@pytest.mark.parametrize("M,N,K", [(70, 100, 64), (1024, 512, 2560), (33, 1536, 96), (1024, 2048, 512)])
+@pytest.mark.parametrize("M,N,K", [(70, 100, 64), (1024, 512, 2560), (33, 1536, 96), (1024, 2048, 512), (300, 4100, 160),
+                                   (600, 2056, 96)])      # (the last three: the wide-tile kernel, 128 / 128 / 64 + 64 rows)
 def test_dgemm_bias_relu_residual_scatter(hip_device, terms, tol, M, N, K):
     from pika_amd.decoder.fused_step import DGemm, PackedWeight, DG_RELU, DG_ROWMASK
     from pika_amd import _lib

@@ -82,6 +82,33 @@ def test_mlp_attention(hip_device, B, S, D, nper):
     rest = torch.ones(N, dtype=torch.bool)
     rest[sel] = False
     assert bool((out2[rest] == -7.0).all())
+    # utterance by utterance (pika_las_mlp_attention_by_utterance): the list ordered by utterance (a subset: utterance 0
+    # loses a query, the last utterance all of them), behind an offset, with the step's table of utterance ranges
+    lib = _lib.lib()
+    keep = [i for i in range(N) if not (owner[i] == B - 1 and B > 1)]
+    if nper[0] > 1:
+        keep.remove(0)
+    off, step_t = 3, 2
+    qlist = torch.cat([torch.full((off,), -1, dtype=torch.int32), torch.tensor(keep, dtype=torch.int32)])
+    own_list = owner[keep].numpy()
+    uoff = np.zeros((step_t + 1, B + 1), np.int32)
+    uoff[step_t] = np.searchsorted(own_list, np.arange(B + 1))
+    out3 = torch.full((N, 2 * D), -7.0, device=hip_device)
+    with torch.cuda.device(hip_device):
+        work = torch.empty(int(lib.pika_las_attention_work_floats(N + 4, S, D)), device=hip_device)
+        ql_d, uo_d = qlist.to(hip_device), torch.from_numpy(uoff).to(hip_device)
+        n_d = torch.tensor([len(keep)], dtype=torch.int32, device=hip_device)
+        off_d = torch.tensor([off], dtype=torch.int32, device=hip_device)
+        st_d = torch.tensor([step_t], dtype=torch.int32, device=hip_device)
+        _lib.check(lib.pika_las_mlp_attention_by_utterance(
+            dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(), dev[4].data_ptr(), ql_d.data_ptr(),
+            uo_d.data_ptr(), dev[5].data_ptr(), out3.data_ptr(), 2 * D, work.data_ptr(), N + 4, B, S, D, n_d.data_ptr(),
+            off_d.data_ptr(), st_d.data_ptr(), torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention_by_utterance")
+    assert (out3[keep][:, :D].double().cpu() - c_ref[keep]).abs().max() < 1e-5
+    assert bool((out3[:, D:] == -7.0).all())
+    rest = torch.ones(N, dtype=torch.bool)
+    rest[keep] = False
+    assert bool((out3[rest] == -7.0).all())
 
 
 def test_fused_scoring_pass_equals_the_op_by_op_pass(hip_device, monkeypatch):
@@ -204,7 +231,7 @@ def test_fork_rows_and_row_lists(hip_device):
     a = torch.randn(N, W1, generator=g).to(hip_device)
     b = torch.randn(N, W2, generator=g).to(hip_device)
     a0, b0 = a.clone(), b.clone()
-    step = torch.tensor([2, 0, 0, 0], dtype=torch.int32, device=hip_device)
+    step = torch.tensor([2, 5, 0, 0], dtype=torch.int32, device=hip_device)        # (n = 0 would make the launch a no-op)
     fork_off = torch.tensor([0, 0, 1, 4, 4], dtype=torch.int32, device=hip_device)       # step 2: forks 1..3
     dst = torch.tensor([9, 3, 7, 11], dtype=torch.int32, device=hip_device)
     src = torch.tensor([0, 1, 1, 5], dtype=torch.int32, device=hip_device)

@@ -39,7 +39,7 @@ static void dump(const char *what, int steps) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_core_trace), z.data(), z.size() * 8);
 }
 int main(int argc, char **argv) {
-    const int rows = argc > 1 ? atoi(argv[1]) : 1024, V = 5000, K = 1024, topk = 16;
+    int rows = argc > 1 ? atoi(argv[1]) : 1024; const int V = 5000, K = 1024, topk = 16;
     float *h, *W, *bias, *pmax, *psum, *C; void *packed4, *pcand;
     CK(hipMalloc(&h, (size_t)rows * K * 4)); CK(hipMalloc(&W, (size_t)V * K * 4)); CK(hipMalloc(&bias, V * 4));
     CK(hipMalloc(&C, (size_t)rows * K * 4));
@@ -71,5 +71,30 @@ int main(int argc, char **argv) {
         printf("dgemm %d x 1024 x 1024: rc %d  %.1f us\n", rows, rc, ms * 1e3);
     }
     dump("dgemm", rows > 256 ? 16 : 8);
+    // a gate product of the LAS scoring pass: N = 4096, K = 2048 (dgemm_wide_kernel; PIKA_DGEMM_WIDE / _WD pick the variant)
+    {
+        const int N2 = 4096, K2 = 2048;
+        float *A2, *W2, *C2; void *p2;
+        CK(hipMalloc(&A2, (size_t)rows * K2 * 4)); CK(hipMalloc(&W2, (size_t)N2 * K2 * 4)); CK(hipMalloc(&C2, (size_t)rows * N2 * 4));
+        hipLaunchKernelGGL(fill_f32, dim3(1024), dim3(256), 0, 0, A2, (long long)rows * K2, 5u, 1.f);
+        hipLaunchKernelGGL(fill_f32, dim3(1024), dim3(256), 0, 0, W2, (long long)N2 * K2, 6u, 0.03f);
+        CK(hipMalloc(&p2, pika_dpack_bytes(N2, K2, 4)));
+        if (pika_dpack_weight(W2, K2, N2, K2, 4, 0, p2, nullptr)) return 2;
+        pika_dgemm_t w{};
+        w.A = A2; w.lda = K2; w.W = p2; w.C = C2; w.ldc = N2; w.M = rows; w.N = N2; w.K = K2; w.terms = 4;
+        if (argc > 2) {      // launch sized for n_max rows, `rows` of them in use (a device word, as in the LAS token loop)
+            int *md; CK(hipMalloc(&md, 4)); CK(hipMemcpy(md, &rows, 4, hipMemcpyHostToDevice));
+            w.M = atoi(argv[2]); w.m_dev = md;
+            CK(hipFree(C2)); CK(hipMalloc(&C2, (size_t)w.M * N2 * 4)); w.C = C2;
+        }
+        for (int it = 0; it < 4; ++it) {
+            CK(hipEventRecord(e0));
+            int rc = pika_dgemm(&w, nullptr);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("dgemm %d x 4096 x 2048: rc %d  %.1f us\n", rows, rc, ms * 1e3);
+        }
+        dump("dgemm wide", 32);
+    }
     return 0;
 }
