@@ -541,6 +541,7 @@ def decode_workload(args, dev, rank):
                  (las_bw, src, x_len_host, [[h[::-1] for h in row] for row in hyps], SOS, EOS, 1.0)]))
             torch.cuda.synchronize()
             step.las_calls.append(round(time.perf_counter() - t0, 4))
+            dec.timing["las_s_per_call"] = list(step.las_calls)
             # decoder row steps actually computed: entries of an utterance that share a prefix share its rows
             dec.timing["las_row_steps"] = {"fw": getattr(las_fw, "last_pass", None), "bw": getattr(las_bw, "last_pass", None)}
             if getattr(las_fw, "phase_times", None):

@@ -117,19 +117,23 @@ def scoring_plan(flat, own_h, sos, eos, pad, share):
 
 
 def _run_stages(gens):
-    """Scoring passes (Net._batch_stages generators), one after the other, each in its stages: encoder queued; host plan and
-    loop preparation (under the encoder's kernels); the token loop; the tail queued; the wait and the lists.
+    """Scoring passes (Net._score_stages generators), one after the other, each in its stages: (A) host plan; (B) encoder,
+    uploads, loop preparation, then the token loop; (C) the tail queued; (D) the wait and the lists -- the next pass' plan
+    (pure host work, ~3 ms) runs under this pass' token loop.
     Tried on this runtime (ROCm 7.2, graph packet capture off) and measured worse -- profiles/r5_las_pass_overlap.txt:
     the second pass' host work under the first pass' kernels (its replays, launched into a busy stream, cost 0.4-1.3 ms of
     host time each); both passes' token loops as one replayed graph (a pass' weights and projected encoder outputs,
     ~215 MB at B = 64, stay in the Infinity Cache from token to token; two passes' do not: 1.3 x the kernel time); the
     loops launched from Python without a graph (twice the device time)."""
     out = []
-    for g in gens:
-        next(g)
-        drive_token_loops([next(g)])
-        next(g)
-        out.append(next(g))
+    if gens:
+        next(gens[0])                               # (A) of the first pass
+    for k, g in enumerate(gens):
+        drive_token_loops([next(g)])                # (B), then its token loop queued
+        if k + 1 < len(gens):
+            next(gens[k + 1])                       # (A) of the next pass under this pass' token loop
+        next(g)                                     # (C)
+        out.append(next(g))                         # (D)
     return out
 
 
@@ -140,7 +144,8 @@ def score_nbest_batch_many(jobs):
     with torch.no_grad():
         preps = [net._batch_prep(src, lengths, hyps) for net, src, lengths, hyps, _, _, _ in jobs]
         for _ in range(2):      # (a second round only if a persistent encoder launch was not resident: status_ok)
-            gens = [net._batch_stages(prep, sos, eos, scale) for (net, _, _, _, sos, eos, scale), prep in zip(jobs, preps)]
+            gens = [net._batch_stages(prep, sos, eos, scale, first=(k == 0))
+                    for k, ((net, _, _, _, sos, eos, scale), prep) in enumerate(zip(jobs, preps))]
             scores = _run_stages(gens)
             if all(net.encoder.status_ok() for net, _, _, _, _, _, _ in jobs):
                 break
@@ -159,22 +164,29 @@ class TokenLoop(object):
     -- every per-token quantity is a device word the step's first launch advances, past the loop's L tokens the launches
     find zero active rows -- and outs (L, N, H) receives the outputs."""
 
-    def __init__(self, step, L, outs, dev):
-        self.step, self.L, self.outs, self.dev = step, L, outs, dev
+    def __init__(self, step, L, outs, dev, sig=None):
+        self.step, self.L, self.outs, self.dev, self.sig = step, L, outs, dev, sig
+
+
+_warmed = set()     # launch configurations (TokenLoop.sig) whose kernels have run once in this process
 
 
 def drive_token_loops(loops):
-    """Run prepared token loops: token 0 of each eagerly (lazy kernel attributes reach their state), then ONE captured
-    launch sequence -- a token of every loop -- replayed max(L) - 1 times (PIKA_LAS_GRAPH=0: the same launches from
-    Python)."""
+    """Run prepared token loops: ONE captured launch sequence -- a token of every loop -- replayed max(L) times
+    (PIKA_LAS_GRAPH=0: the same launches from Python).  The first time a launch configuration is seen its token 0 runs
+    eagerly, outside the capture (kernel attributes are set at a kernel's first launch), and the graph takes the rest."""
     loops = [lp for lp in loops if lp is not None]
     if not loops:
         return
     dev = loops[0].dev
     with torch.cuda.device(dev):
-        for lp in loops:
-            lp.step()
-        n_more = max(lp.L for lp in loops) - 1
+        n_more = max(lp.L for lp in loops)
+        cold = any(lp.sig is None or lp.sig not in _warmed for lp in loops)
+        if cold or n_more <= 1 or os.environ.get("PIKA_LAS_GRAPH", "1") == "0":
+            for lp in loops:
+                lp.step()
+                _warmed.add(lp.sig)
+            n_more -= 1
         if n_more <= 0:
             return
         if os.environ.get("PIKA_LAS_GRAPH", "1") != "0":
@@ -185,8 +197,7 @@ def drive_token_loops(loops):
             with torch.cuda.stream(side):
                 graph.capture_begin(capture_error_mode="thread_local")
                 for lp in loops:
-                    if lp.L > 1:
-                        lp.step()
+                    lp.step()
                 graph.capture_end()
             cur.wait_stream(side)
             for _ in range(n_more):
@@ -464,7 +475,26 @@ class InputFeedRNNDecoder(nn.Module):
                 and H == self.hidden_size and H % 4 == 0 and H <= 1024 and E % 4 == 0 and S <= 2048
                 and context.dtype == torch.float32 and os.environ.get("PIKA_LAS_FUSED", "1") != "0")
 
-    def _prepare_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None):
+    @staticmethod
+    def step_lists(own_h, spans, L, N, B):
+        """Host side of the token loop's row lists (pure numpy: a scoring pass computes it ahead, Net._score_stages (A)):
+        per step t the active rows first[r] <= t < end[r] ordered by utterance, concatenated (qlist) with their counts
+        (n_act) and offsets (qoff), and per step where each utterance's rows sit in the step's list (uoff (L, B + 1))."""
+        import numpy as np
+        by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
+        first = np.zeros(N, np.int64) if spans is None else np.asarray(spans[0], np.int64)
+        end = np.full(N, L, np.int64) if spans is None else np.asarray(spans[1], np.int64)
+        f_o, e_o = first[by_owner], end[by_owner]
+        lists = [by_owner[(f_o <= t) & (t < e_o)] for t in range(L)]
+        n_act = np.asarray([len(x) for x in lists], np.int32)
+        qoff = np.concatenate([[0], np.cumsum(n_act)]).astype(np.int32)
+        qlist = np.concatenate(lists).astype(np.int32) if N and L else np.zeros(0, np.int32)
+        uoff = (np.stack([np.searchsorted(own_h[x], np.arange(B + 1)) for x in lists]).astype(np.int32) if L
+                else np.zeros((0, B + 1), np.int32))
+        return {"n_act": n_act, "qoff": qoff, "qlist": qlist, "uoff": uoff}
+
+    def _prepare_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None,
+                       host_lists=None):
         """The token loop of `run` for N hypotheses of B utterances (owner (N,) -> utterance, lens (B,) valid source
         positions) on un-expanded encoder outputs: per token 2 x (one GEMM over [input | h] with [W_ih | W_hh] + one
         LSTM-cell kernel), the query projection, the attention (a chunk launch + a merge launch, utterance by utterance:
@@ -530,20 +560,13 @@ class InputFeedRNNDecoder(nn.Module):
             # (include/pika_las.h): step = {t, n, qoff}; the active hypotheses [0, n) of a step re-ordered by utterance,
             # so that the four queries of an attention workgroup share the utterance's rows
             import numpy as np
-            own_h = owner.cpu().numpy() if owner_host is None else np.asarray(owner_host)
-            by_owner = np.argsort(own_h, kind="stable").astype(np.int32)
-            first = np.zeros(N, np.int64) if spans is None else np.asarray(spans[0], np.int64)
-            end = np.full(N, L, np.int64) if spans is None else np.asarray(spans[1], np.int64)
-            f_o, e_o = first[by_owner], end[by_owner]
-            lists = [by_owner[(f_o <= t) & (t < e_o)] for t in range(L)]
-            n_act = np.asarray([len(x) for x in lists], np.int32)
-            qoff = np.concatenate([[0], np.cumsum(n_act)]).astype(np.int32)
-            qlist = _h2d(np.concatenate(lists).astype(np.int32) if N else np.zeros(0, np.int32), dev)
-            # per step, where each utterance's queries sit in the step's list (the lists are ordered by utterance): the
-            # attention runs utterance by utterance (pika_las_mlp_attention_by_utterance; PIKA_LAS_ATT=query: per query)
+            hl = host_lists if host_lists is not None else self.step_lists(
+                owner.cpu().numpy() if owner_host is None else np.asarray(owner_host), spans, L, N, B)
+            n_act, qoff, uoff = hl["n_act"], hl["qoff"], hl["uoff"]
+            qlist = _h2d(hl["qlist"], dev)
+            # the attention runs utterance by utterance (pika_las_mlp_attention_by_utterance; PIKA_LAS_ATT=query: per query)
             by_utt = os.environ.get("PIKA_LAS_ATT", "utterance") != "query" and N > 0
             if by_utt:
-                uoff = np.stack([np.searchsorted(own_h[x], np.arange(B + 1)) for x in lists]).astype(np.int32)
                 uoff_d = _h2d(uoff, dev)
                 att_work = torch.empty(int(lib.pika_las_attention_work_floats(max(int(n_act.max()), 1), S, H)), device=dev)
             n_act_d = _h2d(n_act, dev)
@@ -617,7 +640,7 @@ class InputFeedRNNDecoder(nn.Module):
                 # layer-0 input rows (input feeding, las.py:649-668)
                 dgemm(CQ, 2 * H, Wo, bo, outs.view(L * N, H), H, crow_=crow, C2=X[0][:, E:], ldc2=X[0].stride(0))
 
-        return TokenLoop(token_step, L, outs, dev)
+        return TokenLoop(token_step, L, outs, dev, sig=(str(dev), n_max > 256, terms, H, E, nl, by_utt, fork is not None))
 
     def _run_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None):
         loop = self._prepare_fused(tokens, context, enc_hidden, owner, lens, spans, forks, owner_host)
@@ -754,17 +777,15 @@ class Net(nn.Module):
         return out, None, DecoderState(hidden, out[-1]), enc_out
 
     def _score_flat(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None):
-        """One pass of _score_stages on its own."""
-        def stages():
-            yield None
-            for item in self._score_stages(enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick, owner_host):
-                yield item
-        return _run_stages([stages()])[0]
+        """One pass of _score_stages on its own (the encoder has run)."""
+        return _run_stages([self._score_stages(lambda: (enc_hidden, enc_out), enc_out.device, enc_out.is_cuda, owner, lens,
+                                               flat, sos, eos, scale, _tick, owner_host)])[0]
 
-    def _score_stages(self, enc_out, enc_hidden, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None):
-        """A generator in three stages (_run_stages drives several passes stage by stage): (1) the host plan and the
-        prepared token loop, yielded for the caller to drive -- together with the other passes' loops; (2) the vocabulary
-        projection of the distinct rows, queued; (3) the wait and the lists.
+    def _score_stages(self, encode, dev, fused_hint, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None,
+                      encode_first=False):
+        """A generator in four stages (_run_stages): (A) the host plan -- pure host work; (B) encode() -> (enc_hidden,
+        enc_out), the uploads and the prepared token loop, yielded for the caller to drive; (C) the vocabulary projection of
+        the distinct rows, queued; (D) the wait and the lists.  encode_first: encode() is queued in front of (A).
         log P(token_t | prefix) over `hyp + [eos]` for every hypothesis of `flat` (hypothesis i reads utterance
         owner[i] of enc_out (S,B,H), valid positions lens[owner[i]]).
 
@@ -779,39 +800,55 @@ class Net(nn.Module):
         path: training mode, CPU) step t runs on the hypotheses that still have a token.  Only the distinct (step, row)
         pairs are projected onto the vocabulary."""
         import numpy as np
-        dev = enc_out.device
         n = len(flat)
         pad = self.tgt_embeddings.padding_idx
-        share = (os.environ.get("PIKA_LAS_SHARE_PREFIXES", "1") != "0" and owner is not None
-                 and self.decoder._fused_ok(enc_out))
+        _tick = _tick or (lambda name: None)
         if owner_host is None:                              # (the batch entry hands over the host copy it built the tensor from)
             owner_host = owner.cpu().numpy() if owner is not None else np.zeros(n, np.int64)
-        plan = scoring_plan(flat, owner_host, sos, eos, pad, share)
+        n_utt = int(lens.numel()) if (owner is not None and torch.is_tensor(lens)) else None
+
+        def make_plan(share):
+            plan = scoring_plan(flat, owner_host, sos, eos, pad, share)
+            # the (step, hypothesis) pairs that exist, the (step, row) each one reads, the token each one predicts; the
+            # distinct (step, row) pairs are what the tail projects onto the vocabulary
+            plan["key"], plan["inv"] = np.unique(plan["pair_step"] * n + plan["pair_row"], return_inverse=True)
+            if n_utt is not None:                           # the token loop's row lists (the fused loop takes them)
+                plan["lists"] = InputFeedRNNDecoder.step_lists(owner_host[plan["perm"]], (plan["first"], plan["end"]),
+                                                               plan["L"], n, n_utt)
+            return plan
+        # (whether the fused token loop takes the pass is known for sure once the encoder has run: fused_hint says what to plan for)
+        share = os.environ.get("PIKA_LAS_SHARE_PREFIXES", "1") != "0" and owner is not None and bool(fused_hint)
+        if encode_first:                                    # (the first pass of a call: its plan runs under its encoder's kernels)
+            enc_hidden, enc_out = encode()
+        plan = make_plan(share)
+        yield None                                          # ---- (A) done
+        if not encode_first:
+            enc_hidden, enc_out = encode()
+        _tick("encoder + host plan" if encode_first else "encoder")
+        fused = owner is not None and self.decoder._fused_ok(enc_out)
+        if share and not fused:
+            plan, share = make_plan(False), False
         L, ntok, perm, tok, first, end, forks, row_steps = (plan[k] for k in
                                                             ("L", "ntok", "perm", "tok", "first", "end", "forks", "row_steps"))
+        key, inv, tgt = plan["key"], plan["inv"], plan["pair_target"]
         tok_d = _h2d(tok, dev)
         own = owner[_h2d(perm, owner.device)]
-        _tick = _tick or (lambda name: None)
-        _tick("host prep")
-        fused = owner is not None and self.decoder._fused_ok(enc_out)
+        # (the tail's index arrays travel now: once the token loop is queued, a copy waits for all of it)
+        key_t, key_r, inv_d, tgt_d = _h2d(key // n, dev), _h2d(key % n, dev), _h2d(inv, dev), _h2d(tgt, dev)
+        _tick("host prep + uploads")
         if fused:
-            loop = self.decoder._prepare_fused(tok_d, enc_out, enc_hidden, own, lens, (first, end), forks, owner_host[perm])
-            yield loop
+            loop = self.decoder._prepare_fused(tok_d, enc_out, enc_hidden, own, lens, (first, end), forks, owner_host[perm],
+                                               host_lists=plan.get("lists") if enc_out.shape[1] == n_utt else None)
+            yield loop                                      # ---- (B) done: the caller drives the loop
             out = loop.outs
         else:
             yield None
             out, _ = self.decoder.run(tok_d, enc_out, enc_hidden, owner=own, lens=lens, spans=(first, end), forks=forks)
         _tick("token loop (%d tokens, %d hypotheses, %d pairs, %d row steps)" % (L, n, int(ntok.sum()), row_steps))
         self.last_pass = {"pairs": int(ntok.sum()), "row_steps": row_steps, "shared": bool(share)}
-        # the (step, hypothesis) pairs that exist, the (step, row) each one reads, the token each one predicts
-        tt, rr, tgt = plan["pair_step"], plan["pair_row"], plan["pair_target"]
-        key, inv = np.unique(tt * n + rr, return_inverse=True)                  # distinct (step, row) pairs
-        rows = out[_h2d(key // n, dev), _h2d(key % n, dev)]         # (R, H)
+        rows = out[key_t, key_r]                            # (R, H)
         logp = torch.log_softmax(scale * ops.linear(rows, self.dec_proj.weight, self.dec_proj.bias), dim=-1)
-        want = _h2d(tgt, dev).clamp(max=logp.shape[1] - 1)
-        picked_d = logp[_h2d(inv, dev), want]
-        # everything up to here is queued on the device; _run_stages queues the other passes' tails before the last stage --
-        # the only one that waits -- of any pass
+        picked_d = logp[inv_d, tgt_d.clamp(max=logp.shape[1] - 1)]
         if dev.type == "cuda":
             host = torch.empty(picked_d.shape, dtype=picked_d.dtype, pin_memory=True)
             host.copy_(picked_d, non_blocking=True)
@@ -819,8 +856,7 @@ class Net(nn.Module):
             done.record(torch.cuda.current_stream(dev))
         else:
             host, done = picked_d, None
-
-        yield None
+        yield None                                          # ---- (C) done: everything is queued
         if done is not None:
             done.synchronize()
         picked = host.numpy()
@@ -866,12 +902,12 @@ class Net(nn.Module):
         return {"src": src, "dev": dev, "lens": lens, "order": order, "owner_h": owner_h, "owner": _h2d(owner_h, dev),
                 "flat": [list(h) for b in range(B) for h in hyps[b]]}
 
-    def _batch_stages(self, prep, sos, eos, scale):
+    def _batch_stages(self, prep, sos, eos, scale, first=False):
         dev, lens, order = prep["dev"], prep["lens"], prep["order"]
         _tick = _phase_timer(self, dev)
-        enc_hidden, enc_out = self.encoder(prep["src"][:, _h2d(order, dev)], lens[order].to(torch.int32))
-        _tick("encoder")
-        yield None
-        for item in self._score_stages(enc_out, enc_hidden, prep["owner"], _h2d(lens[order], dev), prep["flat"], sos, eos,
-                                       scale, _tick, owner_host=prep["owner_h"]):
-            yield item
+
+        def encode():
+            return self.encoder(prep["src"][:, _h2d(order, dev)], lens[order].to(torch.int32))
+        fused_hint = prep["src"].is_cuda and not self.training and not torch.is_grad_enabled()
+        return self._score_stages(encode, dev, fused_hint, prep["owner"], _h2d(lens[order], dev), prep["flat"], sos, eos, scale,
+                                  _tick, owner_host=prep["owner_h"], encode_first=first)
