@@ -1086,8 +1086,9 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
         "metric": "decode RTF (wall / audio seconds), batch beam search", "value": el / audio_s,
         "unit": "RTF", "n_gpus": world, "steps": 2, "warmup": 1,
         "ms_per_step": el * 1e3, "higher_is_better": False, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"fp32": "f32 (fp32-grade products on MFMA: encoder / joint halves as 3 bf16 terms per operand "
-                                               "(exact), step products as 2 fp16 terms per operand (22 mantissa bits, ~2^-22))",
+        "vs_baseline": None, "dtype": {"fp32": "f32 (fp32-grade products on MFMA: two fp16 terms per operand, 22 mantissa bits, ~2^-22 "
+                                               "per product -- encoder / joint halves (%s) and step products)" % (
+                                                   "PIKA_DECODE_ENCODER_PRECISION=" + step.decoder.encoder_precision),
                                        "fp32-exact": "f32 (3-term bf16 split on MFMA everywhere: exact fp32 products)",
                                        "bf16x3": "f32 (2 bf16 terms per operand, hi.hi + hi.lo + lo.hi on MFMA, fp32 "
                                                  "accumulation; PIKA_DECODE_PRECISION=fp32: exact 3-term products)"}.get(

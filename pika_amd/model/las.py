@@ -29,6 +29,25 @@ def _h2d(x, dev, dtype=None):
     return t.to(dev)
 
 
+def _h2d_many(arrays, dev):
+    """Several small host arrays -> device as ONE copy (each copy from pageable memory is a staged transfer and a wait of its
+    own: ~0.2 ms, 14 of them per scoring pass): {name: ndarray} -> {name: tensor}, views into one uploaded byte buffer."""
+    import numpy as np
+    arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    if torch.device(dev).type != "cuda":
+        return {k: torch.from_numpy(v) for k, v in arrays.items()}
+    offs, total = {}, 0
+    for k, v in arrays.items():
+        offs[k] = total
+        total += (v.nbytes + 15) & ~15
+    blob = np.zeros(max(total, 16), np.uint8)
+    for k, v in arrays.items():
+        blob[offs[k]:offs[k] + v.nbytes] = v.view(np.uint8).reshape(-1)
+    d = torch.from_numpy(blob).to(dev)
+    return {k: d[offs[k]:offs[k] + v.nbytes].view(torch.from_numpy(v[:0].reshape(-1)).dtype).view(v.shape)
+            for k, v in arrays.items()}
+
+
 def _phase_timer(net, dev):
     """PIKA_LAS_TIMING=1: wall time of the phases of a scoring pass (device-synchronised) into net.phase_times."""
     if os.environ.get("PIKA_LAS_TIMING") != "1" or dev.type != "cuda":
@@ -493,8 +512,19 @@ class InputFeedRNNDecoder(nn.Module):
                 else np.zeros((0, B + 1), np.int32))
         return {"n_act": n_act, "qoff": qoff, "qlist": qlist, "uoff": uoff}
 
+    @staticmethod
+    def loop_arrays(hl, forks):
+        """The host arrays a token loop reads on the device (step_lists + the fork lists + the step word's initial value)."""
+        import numpy as np
+        out = {"qlist": hl["qlist"], "uoff": hl["uoff"], "n_act": hl["n_act"], "qoff": hl["qoff"][:len(hl["n_act"])].copy(),
+               "step": np.array([-1, 0, 0, 0], np.int32)}
+        if forks is not None and len(forks[1]):
+            out.update({"f_off": np.asarray(forks[0], np.int32), "f_dst": np.asarray(forks[1], np.int32),
+                        "f_src": np.asarray(forks[2], np.int32)})
+        return out
+
     def _prepare_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None,
-                       host_lists=None):
+                       host_lists=None, uploaded=None):
         """The token loop of `run` for N hypotheses of B utterances (owner (N,) -> utterance, lens (B,) valid source
         positions) on un-expanded encoder outputs: per token 2 x (one GEMM over [input | h] with [W_ih | W_hh] + one
         LSTM-cell kernel), the query projection, the attention (a chunk launch + a merge launch, utterance by utterance:
@@ -562,16 +592,13 @@ class InputFeedRNNDecoder(nn.Module):
             import numpy as np
             hl = host_lists if host_lists is not None else self.step_lists(
                 owner.cpu().numpy() if owner_host is None else np.asarray(owner_host), spans, L, N, B)
-            n_act, qoff, uoff = hl["n_act"], hl["qoff"], hl["uoff"]
-            qlist = _h2d(hl["qlist"], dev)
+            n_act = hl["n_act"]
+            up = uploaded if uploaded is not None else _h2d_many(self.loop_arrays(hl, forks), dev)
+            qlist, uoff_d, n_act_d, qoff_d, step = up["qlist"], up["uoff"], up["n_act"], up["qoff"], up["step"]
             # the attention runs utterance by utterance (pika_las_mlp_attention_by_utterance; PIKA_LAS_ATT=query: per query)
             by_utt = os.environ.get("PIKA_LAS_ATT", "utterance") != "query" and N > 0
             if by_utt:
-                uoff_d = _h2d(uoff, dev)
                 att_work = torch.empty(int(lib.pika_las_attention_work_floats(max(int(n_act.max()), 1), S, H)), device=dev)
-            n_act_d = _h2d(n_act, dev)
-            qoff_d = _h2d(qoff[:L].copy(), dev)
-            step = _h2d(np.array([-1, 0, 0, 0], np.int32), dev)
             n_dev = step[1:2]
             crow = torch.zeros(N, dtype=torch.long, device=dev)
             iden = torch.arange(N, dtype=torch.long, device=dev)
@@ -597,7 +624,7 @@ class InputFeedRNNDecoder(nn.Module):
             fork = None
             if forks is not None and len(forks[1]):
                 # rows that leave a shared prefix at step t inherit [feed | h_0], h_l and c_l of the row that computed it
-                f_off, f_dst, f_src = (_h2d(np.ascontiguousarray(x), dev) for x in forks)
+                f_off, f_dst, f_src = up["f_off"], up["f_dst"], up["f_src"]
                 segs = [(X[0], E, 2 * H)] + [(X[l], H, H) for l in range(1, nl)] + [(c[l], 0, H) for l in range(nl)]
                 ns = len(segs)
                 fork = (f_off, f_dst, f_src, int(np.diff(forks[0]).max()), ns,
@@ -831,14 +858,19 @@ class Net(nn.Module):
         L, ntok, perm, tok, first, end, forks, row_steps = (plan[k] for k in
                                                             ("L", "ntok", "perm", "tok", "first", "end", "forks", "row_steps"))
         key, inv, tgt = plan["key"], plan["inv"], plan["pair_target"]
-        tok_d = _h2d(tok, dev)
-        own = owner[_h2d(perm, owner.device)]
-        # (the tail's index arrays travel now: once the token loop is queued, a copy waits for all of it)
-        key_t, key_r, inv_d, tgt_d = _h2d(key // n, dev), _h2d(key % n, dev), _h2d(inv, dev), _h2d(tgt, dev)
+        # ONE upload: the tokens, the permutation, the tail's index arrays (once the token loop is queued a copy waits for all
+        # of it) and the token loop's row lists
+        arrays = {"tok": tok, "perm": perm, "key_t": key // n, "key_r": key % n, "inv": inv, "tgt": tgt}
+        lists = plan.get("lists") if (fused and enc_out.shape[1] == n_utt) else None
+        if lists is not None:
+            arrays.update(InputFeedRNNDecoder.loop_arrays(lists, forks))
+        up = _h2d_many(arrays, dev)
+        tok_d, key_t, key_r, inv_d, tgt_d = up["tok"], up["key_t"], up["key_r"], up["inv"], up["tgt"]
+        own = owner[up["perm"].to(owner.device)]
         _tick("host prep + uploads")
         if fused:
             loop = self.decoder._prepare_fused(tok_d, enc_out, enc_hidden, own, lens, (first, end), forks, owner_host[perm],
-                                               host_lists=plan.get("lists") if enc_out.shape[1] == n_utt else None)
+                                               host_lists=lists, uploaded=up if lists is not None else None)
             yield loop                                      # ---- (B) done: the caller drives the loop
             out = loop.outs
         else:

@@ -10,7 +10,7 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n=r['Name']
-    if any(k in n for k in ('las_','lstm_cell_kernel','dgemm_kernel','dgemm_sk','blstm','gemm_pp','gemm_nt','softmax','SoftMax','index','split_terms','copyBuffer')):
+    if any(k in n for k in ('las_','lstm_cell_kernel','dgemm_kernel','dgemm_wide','dgemm_sk','blstm','gemm_pp','gemm_nt','softmax','SoftMax','index','split_terms','copyBuffer')):
         print(n[:90].ljust(90), r['Calls'].rjust(6), '%8.1f us avg'%(float(r['AverageNs'])/1e3), '%7.1f ms'%(float(r['TotalDurationNs'])/1e6), 'min %.1f max %.1f'%(float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
 PY
 tail -c 600 gpurun_out/prof_las.log
