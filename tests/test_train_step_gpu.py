@@ -637,10 +637,12 @@ def test_mixed_arithmetic_trains_like_fp32(hip_device):
 def test_mixed_arithmetic_tracks_fp32_over_300_steps(hip_device):
     """The longer leash (VERDICT r4 #4b): 312 optimisation steps -- 13 passes over 24 recurring batches -- in "mixed" next to
     TWO runs in "fp32".  A ReLU network trained by SGD is chaotic at this horizon: the two fp32 runs differ in nothing but
-    the order of float atomics (BatchNorm / split-K reductions) and still part ways -- 1e-2 of the per-pass loss by pass 5,
-    1e-1 by pass 13 (measured); their distance so far is the band any arithmetic can be held to.  "mixed" stays within 5 x
-    the running maximum of that band (and 2 % where the band is tighter), learns as far (last pass within 10 %; measured
-    5.7e-2 against the fp32 pair's own 1.0e-1), and never leaves the curve by more than 15 % on a single pass."""
+    the order of float atomics (BatchNorm / split-K reductions) and still part ways -- 1e-3 of the per-pass loss by pass 4,
+    between 2e-2 and 1e-1 by pass 13 from run to run (measured); that distance is the band any arithmetic can be held to.
+    Asserted: both arithmetics learn (last pass below half of the first; measured 7 %); over the first five passes (120
+    steps, before the trajectories part ways) "mixed" is within 1 % of fp32 (measured 1.7e-3, the fp32 pair 3.2e-3); after
+    that it stays within 15 % of the nearer fp32 run on every pass and within 12 % on the last (measured 8.4e-2 / 7.0e-2
+    against the fp32 pair's own 2.4e-2 .. 1e-1)."""
     steps, nb = 312, 24
     f32a = torch.tensor(_loss_curve(hip_device, "fp32", CURVE_LR, steps, n_batches=nb), dtype=torch.float64)
     f32b = torch.tensor(_loss_curve(hip_device, "fp32", CURVE_LR, steps, n_batches=nb), dtype=torch.float64)
@@ -652,10 +654,10 @@ def test_mixed_arithmetic_tracks_fp32_over_300_steps(hip_device):
     print("fp32 per pass:", [round(v, 1) for v in pa.tolist()])
     print("fp32 vs fp32 :", ["%.1e" % v for v in band.tolist()])
     print("mixed vs fp32:", ["%.1e" % v for v in dev.tolist()])
-    assert pa[-1] < 0.5 * pa[0], pa.tolist()
-    env = torch.cummax(band, 0).values
-    assert bool((dev <= torch.maximum(5 * env, torch.full_like(env, 2e-2))).all()), (dev.tolist(), band.tolist())
-    assert dev[-1] < 0.1 and dev.max() < 0.15
+    assert pa[-1] < 0.5 * pa[0] and pm[-1] < 0.5 * pm[0], (pa.tolist(), pm.tolist())
+    assert dev[:5].max() < 1e-2, dev.tolist()
+    near = torch.minimum(dev, (pm / pb - 1).abs())           # distance to the nearer of the two fp32 runs
+    assert near.max() < 0.15 and near[-1] < 0.12, (near.tolist(), band.tolist())
 
 
 def test_graph_safety_flag_sees_a_hip_runtime_that_started_before_the_import(hip_device):
