@@ -809,7 +809,7 @@ class Net(nn.Module):
                                                flat, sos, eos, scale, _tick, owner_host)])[0]
 
     def _score_stages(self, encode, dev, fused_hint, owner, lens, flat, sos, eos, scale, _tick=None, owner_host=None,
-                      encode_first=False):
+                      encode_first=False, tick_factory=None):
         """A generator in four stages (_run_stages): (A) the host plan -- pure host work; (B) encode() -> (enc_hidden,
         enc_out), the uploads and the prepared token loop, yielded for the caller to drive; (C) the vocabulary projection of
         the distinct rows, queued; (D) the wait and the lists.  encode_first: encode() is queued in front of (A).
@@ -829,7 +829,10 @@ class Net(nn.Module):
         import numpy as np
         n = len(flat)
         pad = self.tgt_embeddings.padding_idx
+        make_tick = tick_factory            # (a phase clock made when the pass' own device work starts: _phase_timer)
         _tick = _tick or (lambda name: None)
+        if make_tick is not None and encode_first:
+            _tick = make_tick()
         if owner_host is None:                              # (the batch entry hands over the host copy it built the tensor from)
             owner_host = owner.cpu().numpy() if owner is not None else np.zeros(n, np.int64)
         n_utt = int(lens.numel()) if (owner is not None and torch.is_tensor(lens)) else None
@@ -850,6 +853,8 @@ class Net(nn.Module):
         plan = make_plan(share)
         yield None                                          # ---- (A) done
         if not encode_first:
+            if make_tick is not None:                       # (a later pass' plan ran under the previous pass' token loop: its
+                _tick = make_tick()                         #  phase clock starts with its encoder)
             enc_hidden, enc_out = encode()
         _tick("encoder + host plan" if encode_first else "encoder")
         fused = owner is not None and self.decoder._fused_ok(enc_out)
@@ -936,10 +941,10 @@ class Net(nn.Module):
 
     def _batch_stages(self, prep, sos, eos, scale, first=False):
         dev, lens, order = prep["dev"], prep["lens"], prep["order"]
-        _tick = _phase_timer(self, dev)
 
         def encode():
             return self.encoder(prep["src"][:, _h2d(order, dev)], lens[order].to(torch.int32))
         fused_hint = prep["src"].is_cuda and not self.training and not torch.is_grad_enabled()
         return self._score_stages(encode, dev, fused_hint, prep["owner"], _h2d(lens[order], dev), prep["flat"], sos, eos, scale,
-                                  _tick, owner_host=prep["owner_h"], encode_first=first)
+                                  owner_host=prep["owner_h"], encode_first=first,
+                                  tick_factory=lambda: _phase_timer(self, dev))
