@@ -34,8 +34,6 @@ def _h2d_many(arrays, dev):
     own: ~0.2 ms, 14 of them per scoring pass): {name: ndarray} -> {name: tensor}, views into one uploaded byte buffer."""
     import numpy as np
     arrays = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
-    if torch.device(dev).type != "cuda":
-        return {k: torch.from_numpy(v) for k, v in arrays.items()}
     offs, total = {}, 0
     for k, v in arrays.items():
         offs[k] = total

@@ -270,3 +270,31 @@ def test_gpu_batch_ahead_rescoring_answers_the_script_loop(hip_device, monkeypat
     assert set(k[0] for k in tables) == {"fw", "bw"}
     for (f1, b1), (f2, b2) in zip(ahead, alone):
         assert np.allclose(f1, f2, rtol=1e-4, atol=1e-4) and np.allclose(b1, b2, rtol=1e-4, atol=1e-4)
+
+
+def test_step_lists_and_one_blob_upload():
+    """Host side of the fused token loop (InputFeedRNNDecoder.step_lists): per step the active rows, ordered by utterance,
+    with each utterance's range in the step's list; and _h2d_many (one upload for many arrays) hands every array back
+    unchanged."""
+    from pika_amd.model.las import InputFeedRNNDecoder, _h2d_many
+    rng = np.random.default_rng(5)
+    B, N, L = 5, 37, 9
+    own = np.sort(rng.integers(0, B, N))
+    own[own == 3] = 2                                   # an utterance without rows
+    own = own[rng.permutation(N)]
+    first = rng.integers(0, 4, N)
+    end = first + rng.integers(0, L - 3, N)
+    hl = InputFeedRNNDecoder.step_lists(own, (first, end), L, N, B)
+    assert hl["uoff"].shape == (L, B + 1) and hl["n_act"].shape == (L,)
+    for t in range(L):
+        rows = hl["qlist"][hl["qoff"][t]:hl["qoff"][t + 1]]
+        assert sorted(rows.tolist()) == sorted(np.nonzero((first <= t) & (t < end))[0].tolist())
+        assert len(rows) == hl["n_act"][t] and np.all(np.diff(own[rows]) >= 0)          # ordered by utterance
+        for b in range(B):
+            seg = rows[hl["uoff"][t, b]:hl["uoff"][t, b + 1]]
+            assert np.all(own[seg] == b) and len(seg) == int((own[rows] == b).sum())
+    arrays = {"a": rng.integers(0, 9, (3, 5)).astype(np.int64), "b": np.arange(7, dtype=np.int32), "c": np.zeros(0, np.int32),
+              "d": rng.standard_normal(11).astype(np.float32)}
+    up = _h2d_many(arrays, "cpu")
+    for k, v in arrays.items():
+        assert up[k].shape == v.shape and np.array_equal(up[k].numpy(), v)
