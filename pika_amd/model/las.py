@@ -529,7 +529,7 @@ class InputFeedRNNDecoder(nn.Module):
         the (N,S,H) tanh tensor of global_attention.py:218-221 does not exist, an utterance's rows are read once per
         workgroup, not once per hypothesis) and the
         output projection written straight into the result and fed back (input feeding, las.py:649-668).
-        The ten launches of a token are captured ONCE into a hipGraph and replayed per token: the step index, the
+        The eleven launches of a token are captured ONCE into a hipGraph (drive_token_loops) and replayed per token: the step index, the
         number of active hypotheses and the query-list offset are device words a one-thread kernel advances
         (PIKA_LAS_GRAPH=0: the same launches issued from Python per token).
         spans = (first, end) host int arrays (N,): hypothesis row r takes part in steps first[r] <= t < end[r] (None:
@@ -547,7 +547,6 @@ class InputFeedRNNDecoder(nn.Module):
         nl = self.num_layers
         att = self.attn
         with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream().cuda_stream
             h0, c0 = (self._fix_enc_hidden(e) for e in enc_hidden)                 # (layers, B, H)
             ctx = context.transpose(0, 1).contiguous()                              # (B, S, H)
             # "mixed" is a training arithmetic (bf16 backward): a scoring pass under it runs its forward grade, i.e. exact
@@ -585,8 +584,8 @@ class InputFeedRNNDecoder(nn.Module):
             wq = torch.empty((N, H), device=dev)
             outs = torch.empty((L, N, H), device=dev)
             # Every per-token quantity lives on the device, so ONE captured launch sequence serves all tokens
-            # (include/pika_las.h): step = {t, n, qoff}; the active hypotheses [0, n) of a step re-ordered by utterance,
-            # so that the four queries of an attention workgroup share the utterance's rows
+            # (include/pika_las.h): step = {t, n, qoff}; the active hypotheses [0, n) of a step ordered by utterance: an
+            # attention workgroup takes the queries of one utterance (step_lists)
             import numpy as np
             hl = host_lists if host_lists is not None else self.step_lists(
                 owner.cpu().numpy() if owner_host is None else np.asarray(owner_host), spans, L, N, B)
