@@ -51,7 +51,7 @@ int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, co
 
 /* The same attention for a query list ORDERED BY UTTERANCE, utterance by utterance (two launches): a workgroup takes all
  * the queries of one utterance and a chunk of 32 of its positions -- the utterance's U_a h_s and h_s rows are read once
- * per workgroup instead of once per query (111 -> ~40 us at 470 queries, S = 240, D = 1024) -- and a second launch merges
+ * per workgroup instead of once per query (130 -> 73 us at 470 queries of 64 utterances, S = 240, D = 1024) -- and a second launch merges
  * the chunks' partial (max, sum, context sums) into ctx_out.  Same values to rounding (another summation order).
  * uoff int32 (B + 1): the queries of utterance b are entries [uoff[b], uoff[b + 1]) of the list (qidx + *qoff_dev, of
  * min(N, *n_dev) entries); with step_dev the table of the current step, uoff + *step_dev * (B + 1) (step[0] of

@@ -228,7 +228,10 @@ __global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float 
 // D = 1024, and a CU pulls bytes from beyond its L1 at ~50 GB/s -- 111 us for the ~470 queries of an average step of a
 // rescoring pass, three times what its exp2 / rcp need.  Here a workgroup takes ALL the queries of one utterance (the
 // query list is ordered by utterance) and a chunk of ACS positions: every row is read once per workgroup; a second launch
-// merges the chunks' partial (max, sum, context sums).
+// merges the chunks' partial (max, sum, context sums).  Measured (tools/las_gemm_bench.py): 130 -> 73 us at 470 queries,
+// 158 -> 99 at 960, 36 -> 39 at 64 (one query per utterance: the workgroup's chain of dependent round trips -- row count,
+// ranges, query rows, position rows, two barriers, the chunk's h_s rows -- is ~20 us, the merge launch the rest).
+// Batching the loads of phases 1 and 3 further cost registers (> 128: one workgroup per CU) and measured worse.
 //   phase 1  wave w walks positions w, w + 8, .. of the chunk: the position's U_a h_s row in registers, the queries from
 //            LDS (staged scaled by 2 log2 e), one score per (query, position) into LDS;
 //   phase 2  thread (query, position): the chunk's max, the weights exp(score - max) (into LDS, [position][query]), their sum;
