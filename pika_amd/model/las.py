@@ -164,8 +164,14 @@ def score_nbest_batch_many(jobs):
             gens = [net._batch_stages(prep, sos, eos, scale, first=(k == 0))
                     for k, ((net, _, _, _, sos, eos, scale), prep) in enumerate(zip(jobs, preps))]
             scores = _run_stages(gens)
-            if all(net.encoder.status_ok() for net, _, _, _, _, _, _ in jobs):
+            # EVERY rescorer's status word is read (no short-circuit): each encoder whose launch was not resident
+            # switches to nn.LSTM for the repeat, so the repeat cannot fail the same way
+            ok = [net.encoder.status_ok() for net, _, _, _, _, _, _ in jobs]
+            if all(ok):
                 break
+        else:
+            raise RuntimeError("pika_amd LAS rescoring: the BLSTM encoder pass did not complete twice in a row "
+                               "(persistent launch not resident, then the repeat); no scores are returned")
         out = []
         for (net, _, _, hyps, _, _, _), sc in zip(jobs, scores):
             res, i = [], 0
@@ -914,6 +920,8 @@ class Net(nn.Module):
                                    [list(h) for h in hyps], sos, eos, scale)
             if self.encoder.status_ok():
                 break
+        else:
+            raise RuntimeError("pika_amd LAS rescoring: the BLSTM encoder pass did not complete twice in a row")
         return res
 
     def score_nbest_batch(self, src, lengths, hyps, sos, eos, scale=1.0):

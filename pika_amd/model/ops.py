@@ -96,6 +96,8 @@ class precision_island(object):
 
     def __init__(self, probe):
         from .. import gemm as G
+        precision_island.recover()
+        self.left = False
         self.mode = "bf16x3" if (G.PRECISION == "mixed" and probe.is_cuda and torch.is_grad_enabled()) else None
         self.old = None
 
@@ -105,6 +107,16 @@ class precision_island(object):
             self.old, G.PRECISION = G.PRECISION, self.mode
         return self
 
+    @staticmethod
+    def recover():
+        """A backward pass that entered an island and never left it (an exception inside it, a pass cut short by
+        autograd.grad(inputs=...)) leaves the process in the island's arithmetic: the next forward puts the outermost
+        saved mode back.  Called at the start of every island forward and of every graphed / eager training forward."""
+        if _ISLAND_STACK:
+            from .. import gemm as G
+            G.PRECISION = _ISLAND_STACK[0]
+            del _ISLAND_STACK[:]
+
     def __exit__(self, *exc):
         if self.mode is not None:
             from .. import gemm as G
@@ -112,10 +124,18 @@ class precision_island(object):
         return False
 
     def inp(self, x):
-        return _IslandLeave.apply(x) if (self.mode is not None and x.requires_grad) else x
+        if self.mode is None:
+            return x
+        if not x.requires_grad:
+            # frozen embeddings: the Leave node must still exist (and run last), or Enter's switch is never undone --
+            # a throw-away leaf gives it a gradient edge
+            x = x.detach().requires_grad_(True)
+        self.left = True
+        return _IslandLeave.apply(x)
 
     def out(self, y):
-        return _IslandEnter.apply(y, self.mode) if (self.mode is not None and y.requires_grad) else y
+        # Enter only ever together with Leave
+        return _IslandEnter.apply(y, self.mode) if (self.mode is not None and self.left and y.requires_grad) else y
 
 
 def tdnn_bn_ok(x, conv_weight, bn):

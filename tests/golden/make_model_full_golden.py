@@ -7,6 +7,8 @@ compact form of tests/golden/mbr_hooks.py (512 strided entries + L2 norm, sum, m
 running statistics after the step.  About a minute of CPU.
     python tests/golden/make_model_full_golden.py          # conv-transformer prediction net -> model_full_train.npz
     python tests/golden/make_model_full_golden.py rnn      # the recipes' 2-layer LSTM prediction net -> model_full_train_rnn.npz
+    python tests/golden/make_model_full_golden.py long     # the BENCHMARKED length: B = 4, T_in = 1000 (T' = 240), U = 50 ->
+                                                           # model_full_train_long.npz (same recorded quantities; ~2 min)
 """
 import os
 import sys
@@ -27,10 +29,11 @@ from mbr_hooks import compact  # noqa: E402
 
 transducer = pika_ref.load_reference("trainer.model.transducer")
 torch.set_num_threads(8)
-DEC = sys.argv[1] if len(sys.argv) > 1 else "transformer"
-assert DEC in ("transformer", "rnn")
+ARG = sys.argv[1] if len(sys.argv) > 1 else "transformer"
+assert ARG in ("transformer", "rnn", "long")
+DEC = "rnn" if ARG == "rnn" else "transformer"
 net = F.build(transducer, pika_ref.seeded_state_dict, DEC)
-x, y, x_len, y_len = F.inputs()
+x, y, x_len, y_len = F.inputs(F.LONG if ARG == "long" else F.SHORT)
 seen = {}
 net.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("enc", o.detach()))
 net.decoder.register_forward_hook(lambda m, i, o: seen.__setitem__("pred", (o[0] if isinstance(o, tuple) else o).detach()))
@@ -45,11 +48,12 @@ out["n"] = np.array(len(grads))
 out["names"] = np.array([n for n, _ in net.named_parameters()])
 out["enc"] = F.enc_slice(seen["enc"]).numpy()
 out["pred"] = seen["pred"][:, :, ::17].numpy()
-out["lp"] = F.lp_slice(lp.detach()).numpy()
+out["lp"] = (F.lp_slice_long if ARG == "long" else F.lp_slice)(lp.detach()).numpy()
 out["costs"] = costs
 out["enc_absmax"] = np.array(float(seen["enc"].abs().max()))
 for k in ("encoder.bn_in.running_mean", "encoder.hidden_bn.8.running_var", "encoder.bn_final.running_var"):
     out["buf:" + k] = net.state_dict()[k].numpy()
-path = os.path.join(HERE, "model_full_train.npz" if DEC == "transformer" else "model_full_train_rnn.npz")
+path = os.path.join(HERE, {"transformer": "model_full_train.npz", "rnn": "model_full_train_rnn.npz",
+                          "long": "model_full_train_long.npz"}[ARG])
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path) // 1024, "KiB")

@@ -36,17 +36,24 @@ def build(transducer_mod, seeded_state_dict, decoder_type="transformer"):
     return net.train()
 
 
-def inputs():
-    g = torch.Generator().manual_seed(SEED + 1)
-    x = torch.randn(B, T_IN, D_IN, generator=g)
-    lens = torch.tensor(LENS)
-    for n in range(B):          # the loader pads with the last frame (otf_utt_loader.py:267-268)
-        x[n, LENS[n]:] = x[n, LENS[n] - 1]
+# The benchmarked LENGTH (BASELINE.json configs[1]: T ~ 1000 input frames -> T' = 240 lattice frames, U = 50 labels) at a
+# batch the reference finishes in a minute on CPU: the encoder's attention over 994 / 976 frames, lattice products over
+# B * 240 * 51 rows -- the tile shapes `bench.py` runs, B = 4 instead of 32.
+LONG = SimpleNamespace(B=4, T_IN=1000, U=50, LENS=[1000, 987, 951, 1000], U_LENS=[50, 47, 50, 41], SEED=SEED + 7)
+SHORT = SimpleNamespace(B=B, T_IN=T_IN, U=U, LENS=LENS, U_LENS=U_LENS, SEED=SEED + 1)
+
+
+def inputs(sc=SHORT):
+    g = torch.Generator().manual_seed(sc.SEED)
+    x = torch.randn(sc.B, sc.T_IN, D_IN, generator=g)
+    lens = torch.tensor(sc.LENS)
+    for n in range(sc.B):          # the loader pads with the last frame (otf_utt_loader.py:267-268)
+        x[n, sc.LENS[n]:] = x[n, sc.LENS[n] - 1]
     x_len = ((lens - 42) // 4 + ((lens - 42) % 4 != 0).long()).int()      # train_transducer_bmuf_otfaug.py:80-82
-    y = torch.randint(1, V, (B, U), generator=g)
-    y_len = torch.tensor(U_LENS, dtype=torch.int32)
-    for n in range(B):
-        y[n, U_LENS[n]:] = V    # padding label
+    y = torch.randint(1, V, (sc.B, sc.U), generator=g)
+    y_len = torch.tensor(sc.U_LENS, dtype=torch.int32)
+    for n in range(sc.B):
+        y[n, sc.U_LENS[n]:] = V    # padding label
     return x, y, x_len, y_len
 
 
@@ -56,3 +63,7 @@ def enc_slice(enc):
 
 def lp_slice(lp):
     return lp[:, ::6, ::4, ::61]
+
+
+def lp_slice_long(lp):
+    return lp[:, ::13, ::7, ::61]

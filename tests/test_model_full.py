@@ -186,3 +186,86 @@ def test_gpu_modes_against_reference_full_golden(hip_device, mode):
     assert r["enc"] < t_enc and r["pred"] < max(t_enc, 1e-3) and r["cost"] < t_cost, (mode, r)
     assert r["g_enc"] < t_genc and r["g_rest"] < t_grest and r["g_rest_nokeys"] < t_grest2, (mode, r)
     assert r["bn"] < max(t_enc, 1e-3), (mode, r)
+
+
+GOLD_LONG = os.path.join(HERE, "golden", "model_full_train_long.npz")
+
+
+def test_long_golden_is_the_benchmarked_length():
+    """The fixture itself: B = 4 utterances of T_in = 1000 frames -> T' = 240 lattice frames, U = 50 (configs[1]'s length)."""
+    z = np.load(GOLD_LONG)
+    assert z["enc"].shape[0] == F.LONG.B and z["costs"].shape == (F.LONG.B,)
+    assert z["lp"].shape == (F.LONG.B, len(range(0, 240, 13)), len(range(0, 51, 7)), len(range(0, F.V, 61)))
+    assert np.isfinite(z["costs"]).all() and (z["costs"] > 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["graph", "eager"])
+def test_gpu_mixed_at_the_benchmarked_length_against_reference_golden(hip_device, path):
+    """configs[1] at its OWN length: the reference model (trainer/model/transducer.py:74-112,
+    rnnt_tdnn_transformer.py:73-89) at T_in = 1000 -- attention over 994 / 976 frames, lattice products over B * 240 * 51
+    rows, the tile shapes bench.py runs -- against the benchmarked "mixed" arithmetic, once as the eager launch sequence and
+    once through the hipGraph pair behind Net.forward (pass 3 and 4 are REPLAYS; the graph's costs / log-probs / gradients
+    are compared, the activations come from the eager pass of the same arithmetic since a replay runs no module hooks).
+    Tolerances: TOL["mixed"] -- the ones of the T_in = 420 golden."""
+    from pika_amd import gemm as G
+    from pika_amd import train_graph
+    from pika_amd.model import transducer
+    from pika_amd.rnnt import RNNTLoss
+    z = np.load(GOLD_LONG)
+    old, old_auto = G.PRECISION, train_graph.AUTO
+    G.PRECISION = "mixed"
+    loss = RNNTLoss(blank=0).apply
+    try:
+        net = F.build(transducer, seeded_state_dict).to(hip_device)
+        x, y, x_len, y_len = [t.to(hip_device) for t in F.inputs(F.LONG)]
+        seen = {}
+        hooks = [net.encoder.register_forward_hook(lambda m, i, o: seen.__setitem__("enc", o.detach().clone())),
+                 net.decoder.register_forward_hook(
+                     lambda m, i, o: seen.__setitem__("pred", (o[0] if isinstance(o, tuple) else o).detach().clone()))]
+        bn0 = None
+        n_pass = 4 if path == "graph" else 1
+        if path == "graph":
+            st = train_graph.enable(net, warmup=1, min_seen=1)
+        for k in range(n_pass):
+            net.zero_grad(set_to_none=True)
+            lp = net.forward(x, y, x_len, True)
+            costs = loss(lp, y.int(), x_len, y_len)
+            costs.sum().backward()
+            if k == 0:          # (no hooks inside the capture) the golden's BatchNorm statistics are those after ONE step
+                for h in hooks:
+                    h.remove()
+                bn0 = {k2: net.state_dict()[k2[4:]].detach().clone() for k2 in z.files if k2.startswith("buf:")}
+        if path == "graph":
+            assert st.broken is None, st.broken
+            assert st.stats["captures"] == 1 and st.stats["replays"] >= 2, st.stats
+            assert next(iter(st.entries.values())).kind == "compact"
+        lp = lp.detach()
+        if hasattr(lp, "dense"):
+            lp = lp.dense()
+        grads = {"g%03d" % i: p.grad.detach().float().cpu().numpy() for i, (n, p) in enumerate(net.named_parameters())}
+        got = compact(grads)
+        got["n"] = np.array(len(grads))
+        costs = costs.detach().double().cpu().numpy()
+        if path == "graph":
+            train_graph.disable(net)
+    finally:
+        G.PRECISION = old
+        train_graph.AUTO = old_auto
+    e_enc = rel_max(F.enc_slice(seen["enc"]), z["enc"])
+    e_pred = rel_max(seen["pred"][:, :, ::17], z["pred"])
+    e_lp = rel_max(F.lp_slice_long(lp), z["lp"])
+    e_cost = float(np.abs(costs - z["costs"]).max() / np.abs(z["costs"]).max())
+    rows = grad_report(got, z)
+    enc = [r for r in rows if r[0].startswith("encoder.")]
+    rest = [r for r in rows if not r[0].startswith("encoder.")]
+    w_enc, w_rest = max(enc, key=lambda r: r[1]), max(rest, key=lambda r: r[1])
+    e_bn = max(rel_max(bn0[k2], z[k2]) for k2 in bn0)
+    print("\n[mixed, T_in = 1000, %s] encoder act %.2e  pred-net act %.2e  log-probs %.2e  costs %.2e | gradients: encoder "
+          "median %.2e worst %.2e (%s); prediction net + joint worst %.2e (%s); BatchNorm statistics %.2e" % (
+              path, e_enc, e_pred, e_lp, e_cost, float(np.median([r[1] for r in enc])), w_enc[1], w_enc[0], w_rest[1],
+              w_rest[0], e_bn))
+    t_enc, t_cost, t_genc, t_grest, _ = TOL["mixed"]
+    assert e_enc < t_enc and e_pred < max(t_enc, 1e-3) and e_cost < t_cost and e_lp < 1e-3, (e_enc, e_pred, e_cost, e_lp)
+    assert w_enc[1] < t_genc and w_rest[1] < t_grest, (w_enc, w_rest)
+    assert e_bn < max(t_enc, 1e-3), e_bn
