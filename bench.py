@@ -358,11 +358,13 @@ def speech_like(model, B, T, V, dev, seed, n_colors=50):
     C, H = n_colors, model.hid_dim
     rng = np.random.default_rng(seed)
     g = torch.Generator(device="cpu").manual_seed(seed)
-    pats = (torch.randn(C, 240, generator=g) * 6.0).to(dev)
-    feats = (torch.randn(B, T, 240, generator=g) * 0.5).to(dev)
+    # (built on the HOST and uploaded once: element-wise writes into device tensors were ~9000 blit copies + kernels of
+    # start-up that every kernel trace of a decode leg carried -- profiles/r6_copy_census.txt)
+    pats = torch.randn(C, 240, generator=g) * 6.0
+    feats = torch.randn(B, T, 240, generator=g) * 0.5
     Tp = (T - 42 + 3) // 4
-    Y = torch.zeros(B, Tp, C, device=dev)
-    care = torch.ones(B, Tp, dtype=torch.bool, device=dev)      # the encoder frames next to a burst's own are left out of the fit
+    Y = torch.zeros(B, Tp, C)
+    care = torch.ones(B, Tp, dtype=torch.bool)      # the encoder frames next to a burst's own are left out of the fit
     want = []
     for b in range(B):
         period, f, last, seq = int(rng.integers(18, 23)), int(rng.integers(30, 40)), -1, []
@@ -378,7 +380,7 @@ def speech_like(model, B, T, V, dev, seed, n_colors=50):
             last = c
             f += period + int(rng.integers(-2, 3))
         want.append(seq)
-    feats = feats.contiguous()
+    feats, Y, care = feats.contiguous().to(dev), Y.to(dev), care.to(dev)
 
     def ridge(X, Yt):
         X1 = torch.cat([X, torch.ones(X.shape[0], 1, device=X.device)], 1).double()
@@ -433,8 +435,7 @@ def speech_like(model, B, T, V, dev, seed, n_colors=50):
         w2.weight[0].zero_()
         w2.bias.zero_()
         w2.bias[0] = blank_bias
-        for c in range(C):
-            w2.weight[1 + c, c] = G_
+        w2.weight[1:1 + C, :C] += G_ * torch.eye(C, device=w2.weight.device)     # (columns [0, C) were zeroed above)
     return feats, {"bursts_per_utt": [len(s_) for s_ in want], "encoder_readout_accuracy": hit,
                    "prediction_readout_accuracy": hit_p, "labels": want,
                    "readout_levels": {"encoder_on_burst_p02": e_on, "encoder_elsewhere_p9999": e_off,
@@ -644,6 +645,11 @@ def mbr_workload(args, dev, rank):
     loss_fn = RNNTLoss(blank=0, reduction="sum").apply
     info = {"blank_bias": float(model.fc2.bias[0])}
 
+    # the training half (:120-235) as ONE hipGraph per batch shape (pika_amd.mbr.GraphedMbrStep; PIKA_TRAIN_GRAPH=0: the
+    # eager launch sequence with the script's two backward passes): rnnt_scale 0.1 (:152-158), sm_scale 0.8
+    train_half = mbr.GraphedMbrStep(model, rnnt_scale=0.1, sm_scale=0.8, blk=0, min_seen=1, warmup=1)
+    x_len32 = x_len.int()
+
     def step():
         model.eval()
         with torch.no_grad():
@@ -651,20 +657,18 @@ def mbr_workload(args, dev, rank):
         hyps, scores = ret["predictions"], ret["scores"]
         model.train()
         optim.zero_grad(set_to_none=True)
-        enc = model.encode(feats, None)                                       # :124-138
-        sos = torch.zeros(B, 1, dtype=torch.long, device=dev)
-        pred = model.predict(torch.cat((sos, labels), dim=1))
-        lp = ops.joint(enc, pred, model.fc1, model.fc_gate, model.fc2, log_softmax=True)
-        rnnt = 0.1 * loss_fn(lp, labels.int(), x_len.int(), ali).sum()       # rnnt_scale :152-158
-        rnnt.backward(retain_graph=True)
-        prob, dist, seq_grad, nonblk = mbr.risk_terms(hyps, scores, labels, ali, 0, dev)   # :163-195
-        mbr.mbr_backward(model, enc, hyps, seq_grad, nonblk, 0, 0.8)          # :197-235
+        rnnt = train_half(feats, labels, x_len32, ali, hyps, scores)          # :120-235
         torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0, norm_type=float("inf"))
         optim.step()
-        info["risk"] = float((prob * dist).sum())
-        info["hyp_labels"] = float(np.mean([len(h) for row in nonblk for h in row]))
+        info["_last"] = (train_half.last_risk, hyps)
         return rnnt
-    step.decoder = dec
+
+    def finish():       # read-outs of the last step, after the timed region (no host read of the device inside a step)
+        (prob, dist), hyps = info.pop("_last")
+        info["risk"] = float((prob * dist).sum())
+        info["hyp_labels"] = float(np.mean([sum(1 for e in mbr._ints(h) if e != 0) for row in hyps for h in row]))
+        info["train_half"] = dict(train_half.stats, broken=train_half.broken, graphs=len(train_half.entries))
+    step.decoder, step.finish, step.close = dec, finish, train_half.close
     return step, info
 
 
@@ -1258,6 +1262,7 @@ def leg_mbr(args, R_, with_cpu, steps=3, warmup=1):
             return r
         el, _ = R_.timed(timed_step, steps, warmup)
         el /= steps
+        step.finish()
         search_ms = float(np.mean(search[-steps:])) * 1e3
         flops = 730e9 * a.batch            # SURVEY 8d M2 per utterance: the step trains on the full (T',U) lattice as well (:124-159)
         tf = flops / el / 1e12
@@ -1269,7 +1274,9 @@ def leg_mbr(args, R_, with_cpu, steps=3, warmup=1):
                                     "SGD, full config-2 model" % a.beam,
                         "batch_per_gpu": a.batch, "beam": a.beam, "steps": steps, "warmup": warmup,
                         "expected_risk": info.get("risk"), "hyp_labels": info.get("hyp_labels"),
-                        "nbest_search_ms": search_ms, "training_part_ms": el * 1e3 - search_ms},
+                        "nbest_search_ms": search_ms, "training_part_ms": el * 1e3 - search_ms,
+                        "training_part": "one hipGraph replay per step (pika_amd.mbr.GraphedMbrStep: %s)" % (
+                            info.get("train_half"),)},
              "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
                           "traffic": None,
                           "note": "730 GF per utterance (the step's full-lattice RNN-T part, SURVEY 8d M2) over the WHOLE step; "
@@ -1490,6 +1497,7 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=R_.ctl)
         el = float(t.item()) / args.steps
+        step.finish()
         if rank == 0:
             cb = None
             if world == 1 and not args.no_cpu_baseline:
@@ -1507,7 +1515,8 @@ def main():
                                        "fwd + RNN-T loss bwd + risk terms + trajectory joint with the HIP risk-gradient "
                                        "kernel + clip + SGD, full config-2 model" % args.beam,
                            "batch_per_gpu": B, "beam": args.beam, "expected_risk": info.get("risk"),
-                           "hyp_labels": info.get("hyp_labels")}}), flush=True)
+                           "hyp_labels": info.get("hyp_labels"), "train_half": info.get("train_half"),
+                           "nbest_search_ms": 1e3 * step.decoder.timing.get("search_s", 0.0)}}), flush=True)
         if world > 1:
             dist.barrier(group=R_.ctl)
             dist.destroy_process_group()

@@ -106,16 +106,17 @@ def risk_terms(hyps, scores, targets, target_lens, blk, device):
     return prob, dist, prob * (dist - avg), nonblk
 
 
-def mbr_backward(model, enc, hyps, seq_grad, nonblk, blk, sm_scale):
-    """:197-235 -- accumulates the risk gradient into the model's .grad through `enc` (B,T,H, part
-    of the live graph) and the prediction net.  Returns the surrogate value (for tests)."""
+def hyp_arrays(hyps, nonblk, pad, blk, S=None, Umax=None):
+    """The N-best of a batch as three host arrays (ONE upload each): y (B*beam, Umax) blank-free labels padded with the
+    embedding's padding index, sym (B*beam, S) symbols incl. blanks padded with blank, slen (B*beam,) symbol counts.
+    S / Umax may be given larger than the batch needs (the graphed step pads them to its buckets)."""
     B, beam = len(hyps), len(hyps[0])
-    dev = enc.device
-    T, H = enc.shape[1], enc.shape[2]
-    pad = model.embed.padding_idx
-    Umax = max(len(h) for row in nonblk for h in row)
-    S = max(max(len(h) for row in hyps for h in row), 1)
-    y_h = np.full((B * beam, max(Umax, 0)), pad, dtype=np.int64)       # built on the host, ONE upload each
+    u_need = max(len(h) for row in nonblk for h in row)
+    s_need = max(max(len(h) for row in hyps for h in row), 1)
+    Umax = u_need if Umax is None else Umax
+    S = s_need if S is None else S
+    assert Umax >= u_need and S >= s_need
+    y_h = np.full((B * beam, max(Umax, 0)), pad, dtype=np.int64)
     sym_h = np.full((B * beam, S), blk, dtype=np.int64)
     slen_h = np.zeros(B * beam, dtype=np.int64)
     for b in range(B):
@@ -127,17 +128,27 @@ def mbr_backward(model, enc, hyps, seq_grad, nonblk, blk, sm_scale):
             if h:
                 sym_h[r, :len(h)] = h
             slen_h[r] = len(h)
-    y, sym, slen = (torch.from_numpy(a).to(dev) for a in (y_h, sym_h, slen_h))
-    sos = torch.zeros(B * beam, 1, dtype=torch.long, device=dev)
+    return y_h, sym_h, slen_h
+
+
+def risk_surrogate(model, enc, y, sym, slen, seq_grad, blk, sm_scale):
+    """:197-235 as a differentiable scalar: sum over the live trajectory rows of val * log_softmax(sm_scale * logits)[sym]
+    with val = seq_grad of the row's hypothesis (blank rows / T).  Its gradient IS what `out.backward(mbr_grad)` of the
+    reference back-propagates.  Device tensors in, no host reads: capturable (GraphedMbrStep)."""
+    bb, S = sym.shape
+    B = enc.shape[0]
+    beam = bb // B
+    dev = enc.device
+    T, H = enc.shape[1], enc.shape[2]
+    sos = torch.zeros(bb, 1, dtype=torch.long, device=dev)
     pred = model.predict(torch.cat((sos, y), dim=1))                          # (bb, U, H)   :198-206
-    # trajectory: before step s the path has consumed t = #blanks, u = #labels of steps < s  (:212-217)
     is_blk = sym.eq(blk)
     steps = torch.arange(S, device=dev).unsqueeze(0)
     live = steps < slen.unsqueeze(1)
     t_idx = (torch.cumsum(is_blk & live, 1) - (is_blk & live).long()).clamp(max=T - 1)
     u_idx = torch.cumsum(~is_blk & live, 1) - (~is_blk & live).long()
     rows_b = torch.arange(B, device=dev).repeat_interleave(beam).unsqueeze(1).expand(-1, S)
-    rows_r = torch.arange(B * beam, device=dev).unsqueeze(1).expand(-1, S)
+    rows_r = torch.arange(bb, device=dev).unsqueeze(1).expand(-1, S)
     w1, wg = model.fc1, model.fc_gate
     e1 = ops.linear(enc, w1.weight[:, :H].contiguous(), w1.bias)
     eg = ops.linear(enc, wg.weight[:, :H].contiguous(), wg.bias)
@@ -147,9 +158,217 @@ def mbr_backward(model, enc, hyps, seq_grad, nonblk, blk, sm_scale):
     zg = eg[rows_b, t_idx] + pg[rows_r, u_idx]
     h = torch.tanh(z1) * torch.sigmoid(zg)
     logits = ops.linear(h.reshape(-1, H), model.fc2.weight, model.fc2.bias)
-    # one non-zero per live row: seq_grad at the emitted symbol, blank entries scaled by 1/T (:225-233)
     val = seq_grad.reshape(-1, 1).expand(-1, S) * live
     val = torch.where(is_blk, val / float(T), val)
-    surrogate = RiskFn.apply(logits, sym.reshape(-1).int(), val.reshape(-1).float().contiguous(), sm_scale)
+    return RiskFn.apply(logits, sym.reshape(-1).int(), val.reshape(-1).float().contiguous(), sm_scale)
+
+
+def mbr_backward(model, enc, hyps, seq_grad, nonblk, blk, sm_scale):
+    """:197-235 -- accumulates the risk gradient into the model's .grad through `enc` (B,T,H, part
+    of the live graph) and the prediction net.  Returns the surrogate value (for tests)."""
+    dev = enc.device
+    y_h, sym_h, slen_h = hyp_arrays(hyps, nonblk, model.embed.padding_idx, blk)
+    y, sym, slen = (torch.from_numpy(a).to(dev) for a in (y_h, sym_h, slen_h))
+    # trajectory: before step s the path has consumed t = #blanks, u = #labels of steps < s  (:212-217); one non-zero per
+    # live row: seq_grad at the emitted symbol, blank entries scaled by 1/T (:225-233) -- risk_surrogate
+    surrogate = risk_surrogate(model, enc, y, sym, slen, seq_grad, blk, sm_scale)
     surrogate.backward()
     return float(surrogate.detach())
+
+
+class _MbrEntry(object):
+    __slots__ = ("graph", "x", "labels", "labels32", "x_len", "ali", "y", "sym", "slen", "seq_grad", "rnnt", "grads", "key")
+
+
+class GraphedMbrStep(object):
+    """The TRAINING half of the MBR step (train_transducer_mbr_bmuf_otfaug.py:120-235: encoder forward, RNN-T loss on the
+    reference labels, risk terms, prediction net on the N-best, trajectory joint, both backward passes) as ONE hipGraph per
+    batch shape.  The script's loop calls model.encoder / .decoder / .fc1 ... inline and back-propagates twice through the
+    encoder (`rnnt_loss.backward(retain_graph=True)`, then `out.backward(mbr_grad)`); here both losses hang off one recorded
+    forward and ONE backward pass differentiates `rnnt_scale * rnnt + surrogate` -- the same gradients (the encoder's
+    backward sees the sum of the two d(enc) instead of accumulating two passes), ~half the encoder backward work, and no
+    launch is issued from Python in the steady state: eager, the ~1300 launches of this half take 46 ms of host time for
+    ~14 ms of device work at B = 8.
+
+        step = GraphedMbrStep(model, rnnt_scale=0.1, sm_scale=0.8, blk=0)
+        rnnt = step(feats, labels, x_len, ali, hyps, scores)      # p.grad of every parameter holds the step's gradient
+        clip_grad_norm_(...); optimizer.step()                    # eager, three launches (pika_amd/optim.py)
+
+    Shapes: a graph is keyed by (feats shape, label-axis width, beam, S bucket, U bucket) -- S = the longest hypothesis
+    incl. blanks, padded up to a multiple of `s_bucket` with dead rows (val = 0), U = the longest blank-free hypothesis,
+    padded to a multiple of `u_bucket` with the embedding's padding index (masked as keys by the prediction network).  A key
+    is captured the `min_seen`-th time it appears (LRU bound `max_graphs`, ONE memory pool); until then, and whenever a
+    capture fails, the step runs as the eager launch sequence (`eager_step`: the two backward passes of the script).
+    Dropout: the device-side salt word of pika_amd.train_graph, re-drawn before every replay."""
+
+    def __init__(self, model, rnnt_scale=1.0, sm_scale=1.0, blk=0, max_graphs=4, min_seen=2, s_bucket=32, u_bucket=8,
+                 warmup=1):
+        from . import train_graph
+        from .rnnt import RNNTLoss
+        self.model, self.rnnt_scale, self.sm_scale, self.blk = model, float(rnnt_scale), float(sm_scale), int(blk)
+        self.max_graphs, self.min_seen = max(1, int(max_graphs)), max(1, int(min_seen))
+        self.s_bucket, self.u_bucket, self.warmup = max(1, int(s_bucket)), max(1, int(u_bucket)), int(warmup)
+        self.loss = RNNTLoss(blank=self.blk).apply
+        import collections
+        self.entries = collections.OrderedDict()
+        self.seen, self.calls, self.pool, self.broken = {}, 0, None, None
+        self.param_ptrs = None
+        self.stats = {"replays": 0, "captures": 0, "eager": 0, "evictions": 0}
+        self.salt = train_graph._salt_acquire(next(model.parameters()).device)
+        self._closed = False
+        self.last_risk = None        # (prob, dist) of the latest call, device tensors: expected risk = (prob * dist).sum()
+
+    def close(self):
+        if not self._closed:
+            from . import train_graph
+            self._closed = True
+            self.entries.clear()
+            train_graph._salt_release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the step as the script runs it (two backward passes), also the fallback -------------------------------------------
+    def eager_step(self, feats, labels, x_len, ali, hyps, scores, terms=None):
+        model = self.model
+        B = feats.shape[0]
+        enc = model.encode(feats, None)                                       # :124-138
+        sos = torch.zeros(B, 1, dtype=torch.long, device=feats.device)
+        pred = model.predict(torch.cat((sos, labels.long()), dim=1))
+        lp = ops.joint(enc, pred, model.fc1, model.fc_gate, model.fc2, log_softmax=True)
+        rnnt = self.rnnt_scale * self.loss(lp, labels.int(), x_len.int(), ali.int()).sum()      # :152-158
+        rnnt.backward(retain_graph=True)
+        prob, dist, seq_grad, nonblk = terms if terms is not None else risk_terms(hyps, scores, labels, ali, self.blk,
+                                                                                  feats.device)
+        self.last_risk = (prob, dist)
+        mbr_backward(model, enc, hyps, seq_grad, nonblk, self.blk, self.sm_scale)                # :197-235
+        return rnnt.detach()
+
+    def _capture(self, key, feats, labels, x_len, ali, y, sym, slen, seq_grad):
+        model = self.model
+        dev = feats.device
+        e = _MbrEntry()
+        e.key = key
+        e.x, e.labels, e.x_len, e.ali = feats.clone(), labels.long().clone(), x_len.int().clone(), ali.int().clone()
+        e.labels32 = e.labels.int()
+        e.y, e.sym, e.slen, e.seq_grad = y.clone(), sym.clone(), slen.clone(), seq_grad.float().clone()
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        # fresh leaf aliases of the parameters, for the reason pika_amd/train_graph.py::_capture gives (AccumulateGrad
+        # nodes of an earlier eager step belong to another stream)
+        aliases = {n: p.detach().requires_grad_(True) for n, p in named}
+        by_id = {id(p): aliases[n] for n, p in named}
+        swapped = []
+        for mod in model.modules():
+            for k, p in list(mod._parameters.items()):
+                if p is not None and id(p) in by_id:
+                    swapped.append((mod, k, p))
+                    mod._parameters[k] = by_id[id(p)]
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        e.graph = torch.cuda.CUDAGraph()
+        err = None
+        try:
+            with torch.cuda.graph(e.graph, pool=self.pool, capture_error_mode="thread_local"):
+                try:
+                    B = e.x.shape[0]
+                    enc = model.encode(e.x, None)
+                    sos = torch.zeros(B, 1, dtype=torch.long, device=dev)
+                    pred = model.predict(torch.cat((sos, e.labels), dim=1))
+                    lp = ops.joint(enc, pred, model.fc1, model.fc_gate, model.fc2, log_softmax=True, labels=e.labels)
+                    rnnt = self.rnnt_scale * self.loss(lp, e.labels32, e.x_len, e.ali).sum()
+                    surrogate = risk_surrogate(model, enc, e.y, e.sym, e.slen, e.seq_grad, self.blk, self.sm_scale)
+                    grads = torch.autograd.grad((rnnt + surrogate,), [aliases[n] for n, _ in named], allow_unused=True)
+                    grads = [g if g is None or (g.dtype == p.dtype and g.is_contiguous() and g.shape == p.shape)
+                             else g.to(p.dtype).expand_as(p).contiguous() for g, (_, p) in zip(grads, named)]
+                    e.rnnt = rnnt.detach()
+                except Exception as ex:     # leaving the context with an exception in flight ends the capture twice
+                    err = ex
+        finally:
+            for mod, k, p in swapped:
+                mod._parameters[k] = p
+        if err is not None:
+            return None, "%s: %s" % (type(err).__name__, str(err).split("\n")[0])
+        e.grads = [(p, g) for (_, p), g in zip(named, grads) if g is not None]
+        return e, None
+
+    def __call__(self, feats, labels, x_len, ali, hyps, scores):
+        """feats (B,T,F) f32, labels (B,U) with the padding index beyond ali, x_len / ali (B,), hyps / scores = the N-best of
+        TransducerDecoder.decode_batch.  Leaves the step's gradient in p.grad (accumulating into gradients the caller left
+        in place) and returns rnnt_scale * sum of the RNN-T costs (device tensor)."""
+        import os
+        import warnings
+        model = self.model
+        dev = feats.device
+        self.calls += 1
+        terms = risk_terms(hyps, scores, labels, ali, self.blk, dev)          # :163-195
+        prob, dist, seq_grad, nonblk = terms
+        self.last_risk = (prob, dist)
+        if (self.broken is not None or self.calls <= self.warmup or not feats.is_cuda or self._closed
+                or os.environ.get("PIKA_TRAIN_GRAPH", "1") == "0" or getattr(model, "pack_seq", False)
+                or torch.cuda.is_current_stream_capturing()):
+            self.stats["eager"] += 1
+            return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)
+        import pika_amd
+        if not pika_amd.HIP_GRAPHS_SAFE_TO_ALTERNATE:
+            self.broken = "HIP graph packet capture is on (pika_amd/__init__.py)"
+            self.stats["eager"] += 1
+            return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)
+        ptrs = tuple(p.data_ptr() for p in model.parameters() if p.requires_grad)
+        if self.param_ptrs != ptrs:           # BMUF re-pointed the parameters into its flat vector, .to(), ...
+            self.entries.clear()
+            self.param_ptrs = ptrs
+        B, beam = len(hyps), len(hyps[0])
+        u_need = max(len(h) for row in nonblk for h in row)
+        s_need = max(max(len(h) for row in hyps for h in row), 1)
+        Sb = -(-s_need // self.s_bucket) * self.s_bucket
+        Ub = -(-max(u_need, 1) // self.u_bucket) * self.u_bucket
+        pad = model.embed.padding_idx
+        y_h, sym_h, slen_h = hyp_arrays(hyps, nonblk, pad, self.blk, S=Sb, Umax=Ub)
+        key = (tuple(feats.shape), feats.dtype, tuple(labels.shape), beam, Sb, Ub)
+        e = self.entries.get(key)
+        if e is None:
+            n = self.seen[key] = self.seen.get(key, 0) + 1
+            if n < self.min_seen:
+                self.stats["eager"] += 1
+                return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)
+            while len(self.entries) >= self.max_graphs:
+                self.entries.popitem(last=False)
+                self.stats["evictions"] += 1
+            y, sym, slen = (torch.from_numpy(a).to(dev) for a in (y_h, sym_h, slen_h))
+            self.salt.random_()
+            try:
+                e, why = self._capture(key, feats, labels, x_len, ali, y, sym, slen, seq_grad)
+            except Exception as err:
+                e, why = None, "%s: %s" % (type(err).__name__, str(err).split("\n")[0])
+            if e is None:
+                self.broken = why
+                warnings.warn("pika_amd.mbr.GraphedMbrStep: the step stays an eager launch sequence (%s)" % why)
+                self.stats["eager"] += 1
+                return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)
+            self.entries[key] = e
+            self.stats["captures"] += 1
+        else:
+            self.entries.move_to_end(key)
+            e.x.copy_(feats, non_blocking=True)
+            e.labels.copy_(labels, non_blocking=True)
+            e.labels32.copy_(labels, non_blocking=True)
+            e.x_len.copy_(x_len, non_blocking=True)
+            e.ali.copy_(ali, non_blocking=True)
+            for dst, a in ((e.y, y_h), (e.sym, sym_h), (e.slen, slen_h)):
+                dst.copy_(torch.from_numpy(a), non_blocking=False)      # (pageable source: the copy returns when staged)
+            e.seq_grad.copy_(seq_grad, non_blocking=True)
+        self.salt.random_()                              # device-side draw: new dropout masks per replay
+        kept = {id(g): g.clone() for p, g in e.grads if p.grad is g}
+        e.graph.replay()
+        self.stats["replays"] += 1
+        for p, g in e.grads:
+            if p.grad is None:
+                p.grad = g
+            elif p.grad is g:
+                p.grad = kept[id(g)] + g
+            else:
+                p.grad.add_(g)
+        return e.rnnt

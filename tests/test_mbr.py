@@ -157,7 +157,7 @@ def test_unchanged_mbr_script_on_the_dropins_reproduces_the_reference_gradients(
     M.compare(got, want, rel=1e-3)
 
 
-def _native_step_vs_script_golden(device, search_precision=None, _raw=False):
+def _native_step_vs_script_golden(device, search_precision=None, _raw=False, graphed=False):
     """pika_amd.mbr (device trajectories, split joint, sparse risk surrogate / HIP risk-gradient kernel) fed with
     the same seeded model and fixture batch as the golden run of the reference script: same N-best out of the
     drop-in decoder, and RNN-T + risk gradients equal to what the script's inline code produced."""
@@ -233,6 +233,21 @@ def _native_step_vs_script_golden(device, search_precision=None, _raw=False):
         assert score_err < 2e-3, score_err
     net.train()
     net.zero_grad()
+    if graphed:
+        # the training half as ONE hipGraph (pika_amd.mbr.GraphedMbrStep): an eager warm-up call, the capture, two replays;
+        # dropout is off, so every call leaves the same gradients -- the LAST replay's are compared
+        step = mbr.GraphedMbrStep(net, rnnt_scale=rnnt_scale, sm_scale=sm, blk=blk, min_seen=1, warmup=1)
+        for _ in range(4):
+            net.zero_grad(set_to_none=True)
+            step(data, target, len_b.int(), ali.int(), hyps, scores)
+        assert step.broken is None, step.broken
+        assert step.stats == {"replays": 3, "captures": 1, "eager": 1, "evictions": 0}, step.stats
+        grads = {"g%03d" % i: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy()
+                 for i, p in enumerate(net.parameters())}
+        step.close()
+        if _raw == "names":
+            return M, dict(M.compact(grads), n=np.array(len(grads)), names=[k for k, _ in net.named_parameters()]), want
+        return M, dict(M.compact(grads), n=np.array(len(grads))), want
     enc = net.encoder(data)                                                       # :124-138
     sos = torch.zeros(3, 1, dtype=torch.long, device=device)
     pred = net.predict(torch.cat((sos, target), dim=1))
@@ -272,6 +287,20 @@ def test_gpu_native_mbr_step_matches_the_reference_script_golden(hip_device):
     old, G.PRECISION = G.PRECISION, "fp32"
     try:
         M, got, want = _native_step_vs_script_golden(hip_device)
+    finally:
+        G.PRECISION = old
+    M.compare(got, want, rel=2e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_graphed_mbr_training_half_matches_the_reference_script_golden(hip_device):
+    """The training half of the step as ONE replayed hipGraph (GraphedMbrStep: one backward pass over rnnt + surrogate
+    instead of the script's two) in the exact arithmetic: the gradients the unchanged reference script left in .grad
+    (train_transducer_mbr_bmuf_otfaug.py:120-235), to the same 2e-3 as the eager native step."""
+    from pika_amd import gemm as G
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        M, got, want = _native_step_vs_script_golden(hip_device, graphed=True)
     finally:
         G.PRECISION = old
     M.compare(got, want, rel=2e-3)
@@ -318,6 +347,12 @@ def test_gpu_native_mbr_step_in_the_benchmarked_arithmetic(hip_device):
           "(%s), worst parameter-norm difference %.2e" % (ws, who, wn))
     assert ws < 0.15 and wn < 0.15, (ws, wn, who)
     _native_step_vs_script_golden(hip_device, search_precision="bf16")   # asserts the N-best inside
+    # ... and as bench.py's MBR leg runs the training half: ONE replayed hipGraph (pika_amd.mbr.GraphedMbrStep)
+    M, got, want = _native_step_vs_script_golden(hip_device, _raw="names", graphed=True)
+    ws, wn, who = _worst(got, want, got["names"])
+    print("MBR step, default arithmetic, graphed training half: worst gradient sample error %.2e of the parameter's scale "
+          "(%s), worst parameter-norm difference %.2e" % (ws, who, wn))
+    assert ws < 0.15 and wn < 0.15, (ws, wn, who)
 
 
 def test_edit_distances_library_call_equals_the_python_dp():
