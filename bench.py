@@ -589,7 +589,10 @@ def mbr_workload(args, dev, rank):
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
     from pika_amd import mbr
-    from pika_amd.model import ops
+    from pika_amd import optim as fused_optim
+    if os.environ.get("PIKA_FUSED_OPTIM", "1") != "0":
+        fused_optim.install()   # as `python -m pika_amd.launch <training script>` does: the script's clip_grad_norm_(inf) /
+    #                             optim.SGD(nesterov) calls run as 3 HIP launches (stock torch: ~40 launches, 8 ms of span)
     B, T, U, V, beam = args.batch, args.frames, args.labels, args.vocab, args.beam
     opt = SimpleNamespace(rnn_size=1024, local_rank=0, decoder_type="transformer", brnn=False,
                           encoder_type="tdnn", dropout=0.2, enc_layers=4, dec_layers=2,

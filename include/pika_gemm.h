@@ -62,6 +62,13 @@ typedef struct {
                                 * segments pika_split_bf16_terms(n_terms = 4) writes.  Only the plain product with fp32
                                 * output on the direct-to-LDS kernel (v_mfma_f32_16x16x32_f16), else PIKA_EINVAL */
 
+#define PIKA_GEMM_TERM_PRODUCT 32 /* the operands are term-segment copies (a K-concatenated product of pika_split_bf16_terms:
+                                * 3 or 6 times the reduction of the plain product): the direct-to-LDS kernel takes the
+                                * product from 24 output tiles on instead of 160 -- its alternative is not the bf16
+                                * register-staged kernel but the EXACT one at six MFMA products per tile (round 6: the
+                                * decoder's encoder pass at B = 8, 128 tiles, spent 6.9 of its 9 ms there).  Changes which
+                                * kernel runs, never the values of a product. */
+
 /* Requirements (16-byte operand loads): K % 4 == 0 unless both operands are `trans` (then the output
  * extents M / N must be multiples of g instead); with g = 4 for f32 / 8 for bf16 operands, C,
  * ld and the batch strides must be multiples of g and the base pointer 16-byte aligned; the rows

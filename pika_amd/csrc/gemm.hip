@@ -513,6 +513,7 @@ extern "C" int pika_gemm_nt_ws(const pika_operand_t *A, const pika_operand_t *B,
         const int rc = off ? -100 : pika_internal_gemm_pp(A, B, C, ldc, M, N, K, bias, flags, workspace, workspace_bytes, s);
         if (rc != -100) return rc;
     }
+    flags &= ~PIKA_GEMM_TERM_PRODUCT;                                                 // (a gate of the direct-to-LDS kernel only)
     if (flags & (PIKA_GEMM_OUT_BF16 | PIKA_GEMM_F16_OPERANDS)) return PIKA_EINVAL;   // only the direct-to-LDS kernel writes bf16 / reads fp16
     const int key = (A->dtype == PIKA_BF16 ? 2 : 0) | (B->dtype == PIKA_BF16 ? 1 : 0);
 #define ARGS A, B, C, ldc, c_z_outer, c_z_inner, M, N, K, batch, z_div, bias, flags, s

@@ -205,6 +205,20 @@ __device__ inline void pp_keep4(unsigned seed, unsigned m, unsigned n, unsigned 
 
 __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
+// 16-bit epilogues, column-interior tiles: a lane holds, per 16-column block j of its row, the 4 consecutive columns
+// (lane >> 4) * 4.. -- an 8-byte store per block, 32-byte runs per row and instruction, and the store tail of a tile is
+// bound by the NUMBER of store instructions (MI355X guide T21).  For a pair of blocks (j, j + 1) one
+// v_permlane16_swap per dword (odd 16-lane rows of the first operand <-> even rows of the second) leaves every lane with 8
+// consecutive columns: lane group g = lane >> 4 holds columns (g >> 1) * 8.. of block j + (g & 1) -- one 16-byte store
+// per pair instead of two 8-byte ones.  x, y: the lane's packed 4 x 16 bit of blocks j and j + 1.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline u32x4 pp_pair16(u32x2 x, u32x2 y) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+    return u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
 // EPI 0: C f32 = act(A B^T + bias).   EPI 1: out16 bf16 = dropout(act(A B^T + bias)).
 // EPI 2: out16 bf16 = scale * (A B^T) where aux > 0, else 0  (ReLU + dropout backward in one mask).
 // EPI 3: C f32 = dropout(A B^T + bias) + res  (projection + residual dropout + residual add).
@@ -341,6 +355,13 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         issue_b(1, smem + PP_BUF);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PP_ABL     // tools/r6_pp_ablate.sh: timing-only builds (results are wrong): bit 0 = fragment reads only in the first
+    //               K-tile, bit 1 = no LDS-DMA piece behind the prologue
+    if (PP_ABL & 2) x_ok = false;
+#define PP_RD ((PP_ABL & 1) == 0 || gt == 0)
+#else
+#define PP_RD true
+#endif
     PP_BAR();
     if (wr == 1) PP_BAR();   // group 1 runs one segment behind group 0
 
@@ -394,6 +415,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         if (tr_on && t == 8) tr_k8 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- phase 0: quadrant (m-half 0, n-half 0)
+        if (PP_RD) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             fb[j][0] = ldsv(cur + boff + j * 2048 + sw0);
@@ -403,6 +425,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = ldsv(cur + aoff + i * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + i * 2048 + sw1);
+        }
         }
         if (x_ok) {
             issue_b(2, nxt);
@@ -414,10 +437,12 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         PP_BAR();
         PP_STAMP(1);
         // ---- phase 1: (m-half 0, n-half 1)
+        if (PP_RD) {
 #pragma unroll
         for (int j = 2; j < 4; ++j) {
             fb[j][0] = ldsv(cur + boff + j * 2048 + sw0);
             fb[j][1] = ldsv(cur + boff + j * 2048 + sw1);
+        }
         }
         if (x_ok) {
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -438,10 +463,12 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         PP_BAR();
         PP_STAMP(3);
         // ---- phase 2: (m-half 1, n-half 1)
+        if (PP_RD) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             fa[i][0] = ldsv(cur + aoff + (4 + i) * 2048 + sw0);
             fa[i][1] = ldsv(cur + aoff + (4 + i) * 2048 + sw1);
+        }
         }
         if (x_ok) {
             issue_a(0, nn);
@@ -489,6 +516,9 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     // residual / mask operands of a column-interior tile are fetched one or two 16-row blocks at a time, ahead
     // of the arithmetic and the stores: one at a time, every load pays its full latency behind the previous store
     const bool wide = en0 + 256 <= N;
+    // ... and a 16-bit epilogue on such a tile stores 16 bytes per lane and block pair (pp_pair16) when rows are 16-byte aligned
+    [[maybe_unused]] const bool wide16 = wide && !(P.ldo16 & 7) && !(reinterpret_cast<uintptr_t>(P.out16) & 15) &&
+                                         !(reinterpret_cast<uintptr_t>(P.out16_lo) & 15);
     constexpr int EB = EPI == 3 ? 1 : 2;   // 16-row blocks fetched ahead (sixteen registers either way)
 #pragma unroll
     for (int ip = 0; ip < 8; ip += EB) {
@@ -514,6 +544,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         const int m = em0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= M) continue;
         [[maybe_unused]] f32x4 lv[4];
+        [[maybe_unused]] u32x2 pk[4], pk_lo[4];      // 16-bit epilogues on a column-interior tile: packed values per block
         if constexpr (EPI == 0 || EPI == 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) lv[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -564,7 +595,8 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 for (int e = 0; e < 4; ++e) c[e] = fminf(fmaxf(c[e], -65504.f), 65504.f);
                 const f16x4 h4 = __builtin_convertvector(c, f16x4);
                 _Float16 *op = reinterpret_cast<_Float16 *>(P.out16) + (long long)m * P.ldo16 + n;
-                if (n + 3 < N) *reinterpret_cast<f16x4 *>(op) = h4;
+                if (wide16) pk[j] = __builtin_bit_cast(u32x2, h4);          // stored pairwise behind the j loop
+                else if (n + 3 < N) *reinterpret_cast<f16x4 *>(op) = h4;
                 else for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = h4[e];
             } else if constexpr (EPI == 0 || EPI == 3) {
                 if (n + 3 < N) {
@@ -592,7 +624,9 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 }
                 __bf16 *op = P.out16 + (long long)m * P.ldo16 + n;
                 const bf16x4 hi4 = __builtin_convertvector(v, bf16x4);
-                if (n + 3 < N) {
+                if (wide16) {
+                    pk[j] = __builtin_bit_cast(u32x2, hi4);                // stored pairwise behind the j loop
+                } else if (n + 3 < N) {
                     *reinterpret_cast<bf16x4 *>(op) = hi4;
                 } else {
                     for (int e = 0; e < 4; ++e) if (n + e < N) op[e] = hi4[e];
@@ -601,8 +635,30 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                     if (P.out16_lo) {      // the second term of the value: what the bf16 rounding above dropped
                         const bf16x4 lo4 = __builtin_convertvector(v - __builtin_convertvector(hi4, f32x4), bf16x4);
                         __bf16 *lp = P.out16_lo + (long long)m * P.ldo16 + n;
-                        if (n + 3 < N) *reinterpret_cast<bf16x4 *>(lp) = lo4;
+                        if (wide16) pk_lo[j] = __builtin_bit_cast(u32x2, lo4);
+                        else if (n + 3 < N) *reinterpret_cast<bf16x4 *>(lp) = lo4;
                         else for (int e = 0; e < 4; ++e) if (n + e < N) lp[e] = lo4[e];
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == 1 || EPI == 2 || EPI == 4) {
+            if (wide16) {    // (wave-uniform; every lane of the wave takes part in the swaps: rows m >= M only skip the store)
+                const int g = lane >> 4;
+                unsigned short *orow = reinterpret_cast<unsigned short *>(P.out16) + (long long)m * P.ldo16 + en0 + wc * 64 + (g >> 1) * 8 + (g & 1) * 16;
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const u32x4 q = pp_pair16(pk[j], pk[j + 1]);
+                    *reinterpret_cast<u32x4 *>(orow + j * 16) = q;
+                }
+                if constexpr (EPI == 1) {
+                    if (P.out16_lo) {
+                        unsigned short *lrow = reinterpret_cast<unsigned short *>(P.out16_lo) + (long long)m * P.ldo16 + en0 + wc * 64 + (g >> 1) * 8 + (g & 1) * 16;
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const u32x4 q = pp_pair16(pk_lo[j], pk_lo[j + 1]);
+                            *reinterpret_cast<u32x4 *>(lrow + j * 16) = q;
+                        }
                     }
                 }
             }
@@ -1157,12 +1213,16 @@ int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, floa
     const bool out16 = (flags & PIKA_GEMM_OUT_BF16) != 0, f16 = (flags & PIKA_GEMM_F16_OPERANDS) != 0;
     if (f16 && (A->trans || out16)) return PIKA_NOT_APPLICABLE;     // fp16 operands: the plain product with fp32 output only
     if (A->trans) return out16 ? PIKA_NOT_APPLICABLE : launch_pp_tn(A, B, C, ldc, M, N, K, bias, flags, ws, ws_bytes, s);
-    if (flags & ~(PIKA_GEMM_RELU | PIKA_GEMM_OUT_BF16 | PIKA_GEMM_F16_OPERANDS)) return PIKA_NOT_APPLICABLE;
+    if (flags & ~(PIKA_GEMM_RELU | PIKA_GEMM_OUT_BF16 | PIKA_GEMM_F16_OPERANDS | PIKA_GEMM_TERM_PRODUCT)) return PIKA_NOT_APPLICABLE;
     if ((K & 63) || (ldc & 3) || (reinterpret_cast<uintptr_t>(C) & (out16 ? 7 : 15))) return PIKA_NOT_APPLICABLE;
     // B: plain matrix
     if (B->C < K || B->pad || (B->ld & 7) || B->rows_per_batch < N || (reinterpret_cast<uintptr_t>(B->ptr) & 15))
         return PIKA_NOT_APPLICABLE;
-    if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < g_pp_min_tiles) return PIKA_NOT_APPLICABLE;
+    // fill-the-chip gate: 160 tiles for a plain product (below it the register-staged bf16 kernel's smaller tiles win), 24
+    // for a K-concatenated term product (3-6 x the K-tiles per output tile amortise the fixed costs, and what it falls back
+    // to is the exact kernel)
+    const int min_tiles = (flags & PIKA_GEMM_TERM_PRODUCT) ? (g_pp_min_tiles < 24 ? g_pp_min_tiles : 24) : g_pp_min_tiles;
+    if (M < 256 || N < 192 || (long long)((M + 255) / 256) * ((N + 255) / 256) < min_tiles) return PIKA_NOT_APPLICABLE;
     PPArgs P{};
     if (!pp_fill_a(*A, K, P)) return PIKA_NOT_APPLICABLE;
     P.B = static_cast<const __bf16 *>(B->ptr);

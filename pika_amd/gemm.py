@@ -107,6 +107,7 @@ def _flags(relu, accumulate, precision):
 
 OUT_BF16 = 8
 F16_OPERANDS = 16
+TERM_PRODUCT = 32
 # "fp32" products of direct-to-LDS size as ONE bf16 product over six term segments (PIKA_FP32_CONCAT=0: always the
 # register-staged exact kernel)
 FP32_CONCAT = os.environ.get("PIKA_FP32_CONCAT", "1") != "0"
@@ -146,6 +147,7 @@ def _plain(op, K):
 
 
 MIN_TILES = 160
+TERM_MIN_TILES = 24      # ... of a K-concatenated term product (include/pika_gemm.h: PIKA_GEMM_TERM_PRODUCT)
 
 
 def set_min_tiles(n):
@@ -158,11 +160,13 @@ def set_min_tiles(n):
     return old
 
 
-def _direct_to_lds_size(trans, M, N, K):
-    """The size gates of the direct-to-LDS kernels (gemm_glds.hip: pika_internal_gemm_pp / launch_pp_tn)."""
+def _direct_to_lds_size(trans, M, N, K, terms=False):
+    """The size gates of the direct-to-LDS kernels (gemm_glds.hip: pika_internal_gemm_pp / launch_pp_tn); terms: of a
+    K-concatenated term product (launched with TERM_PRODUCT)."""
     if trans:
         return M >= 192 and N >= 192 and K >= 512
-    return M >= 256 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= MIN_TILES
+    return M >= 256 and N >= 192 and ((M + 255) // 256) * ((N + 255) // 256) >= (min(MIN_TILES, TERM_MIN_TILES) if terms
+                                                                                 else MIN_TILES)
 
 
 def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):
@@ -238,16 +242,16 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         # one bf16 operand against a reduction-major fp32 one (a weight gradient whose activation was stored in bf16):
         # the exact kernel does not take that pairing; the stored operand already carries the bf16 rounding
         p = precision = "bf16"
-    f16 = False
+    f16 = term = False
     if p == "fp16x2":
         ok = (batch == 1 and not c_z_outer and not c_z_inner and out.dtype == torch.float32 and not accumulate
-              and not a_op.trans and not b_op.trans and _direct_to_lds_size(False, M, N, K))
+              and not a_op.trans and not b_op.trans and _direct_to_lds_size(False, M, N, K, terms=True))
         with torch.cuda.device(out.device):
             sp = _bf16x3_operands(a_op, b_op, M, N, K, out.device, 4) if ok else None
         if sp is not None:
             a_op, b_op, K, keep = sp
             p = precision = "bf16"
-            f16 = True
+            f16 = term = True
             FP16X2_STATS["fast"] += 1
         else:
             p = precision = "fp32"      # small / transposed / batched products: exact
@@ -258,7 +262,7 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         if n_terms == 3:    # only where the direct-to-LDS kernels will take the product (6x their time beats 6 MFMAs
             #                 per tile on the register-staged kernel) and the six-segment copies stay moderate (the
             #                 joint's lattice-sized operands would need 2 x 24 GB of temporaries per product)
-            splittable = (splittable and bool(a_op.trans) == bool(b_op.trans) and _direct_to_lds_size(a_op.trans, M, N, K)
+            splittable = (splittable and bool(a_op.trans) == bool(b_op.trans) and _direct_to_lds_size(a_op.trans, M, N, K, terms=True)
                           and 12 * max(M, N) * K <= FP32_CONCAT_MAX_BYTES)
         with torch.cuda.device(out.device):
             sp = _bf16x3_operands(a_op, b_op, M, N, K, out.device, n_terms) if splittable else None
@@ -266,6 +270,7 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
         if sp is not None:
             a_op, b_op, K, keep = sp        # `keep` holds the split copies until the launch below is enqueued
             precision = "bf16"
+            term = True
             stats[hit] += 1
         else:
             stats[miss] += 1
@@ -275,7 +280,7 @@ def launch(a_op, b_op, out, ldc, M, N, K, bias=None, relu=False, accumulate=Fals
                                         c_z_outer, c_z_inner, M, N, K, batch, z_div,
                                         None if bias is None else bias.data_ptr(),
                                         _flags(relu, accumulate, precision) | (OUT_BF16 if out.dtype == torch.bfloat16 else 0)
-                                        | (F16_OPERANDS if f16 else 0),
+                                        | (F16_OPERANDS if f16 else 0) | (TERM_PRODUCT if term else 0),
                                         None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
                                         torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pika_gemm_nt(M=%d,N=%d,K=%d)" % (M, N, K))

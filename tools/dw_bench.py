@@ -14,7 +14,10 @@ def worker():
     sys.path.insert(0, ROOT)
     from pika_amd import gemm as G
     dev = torch.device("cuda:0")
+    only = os.environ.get("DW_BENCH_ONLY")          # e.g. joint_dW2: one shape (for --pmc passes)
     for name, N, Ka, M in SHAPES:
+        if only and name != only:
+            continue
         dy = torch.randn(M, N, device=dev).bfloat16()
         x = torch.randn(M, Ka, device=dev).bfloat16()
         out = torch.empty(N, Ka, device=dev)

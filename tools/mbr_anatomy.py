@@ -40,19 +40,31 @@ def main():
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = con.execute("select %s, start, end from kernels order by start" % name).fetchall()
-    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[0]]
-    assert len(sgd) >= 2, "need two optimizer steps in the trace"
-    step = rows[sgd[-2] + 1: sgd[-1] + 1]
-    prep = [i for i, r in enumerate(step) if "dstep_prep" in r[0]]
-    beam = [i for i, r in enumerate(step) if "beam_" in r[0] or "dstep_" in r[0] or "dfc2" in r[0]]
-    a, b = prep[0], beam[-1]
-    print("last MBR step: %d launches, %.2f ms from the first launch after the previous optimizer step to the end of sgd_kernel"
-          % (len(step), (step[-1][2] - step[0][1]) / 1e6))
-    part(step[:a], "(a) decoder's encoder pass + joint halves")
-    part(step[a:b + 1], "(b) N-best search loop")
-    print("    host time between the search's last kernel and the training half's first: %.2f ms" % (
-        (step[b + 1][1] - step[b][2]) / 1e6))
-    part(step[b + 1:], "(c) training half (incl. clip + SGD)")
+    is_search = lambda n: ("dstep_" in n or "beam_" in n or "dfc2" in n or "dgemm_sk" in n or "fst_advance" in n)
+    prep = [i for i, r in enumerate(rows) if "dstep_prep" in r[0]]
+    # search loops = runs of dstep_prep launches less than 3 ms apart
+    runs, cur = [], [prep[0]]
+    for i in prep[1:]:
+        if rows[i][1] - rows[cur[-1]][1] > 3e6:
+            runs.append(cur)
+            cur = [i]
+        else:
+            cur.append(i)
+    runs.append(cur)
+    assert len(runs) >= 2, "need two N-best searches in the trace"
+    a0 = runs[-2][0]
+    a1 = max(i for i in range(runs[-2][-1], runs[-1][0]) if is_search(rows[i][0]) and rows[i][1] - rows[runs[-2][-1]][1] < 3e6)
+    b0 = runs[-1][0]
+    print("one MBR step = N-best search k, then training half k, then the decoder's encoder pass of step k + 1: %.2f ms from the "
+          "first launch of search k to the first launch of search k + 1" % ((rows[b0][1] - rows[a0][1]) / 1e6))
+    part(rows[a0:a1 + 1], "(b) N-best search loop")
+    rest = rows[a1 + 1:b0]
+    print("    host time between the search's last kernel and the next launch: %.2f ms" % ((rest[0][1] - rows[a1][2]) / 1e6))
+    # the training half ends with the optimizer (the last multi-tensor / sgd launch before the next decode's first GEMM)
+    opt = [i for i, r in enumerate(rest) if "multi_tensor" in r[0] or "sgd_kernel" in r[0] or "scale_kernel" in r[0]]
+    cut = (opt[-1] + 1) if opt else len(rest)
+    part(rest[:cut], "(c) n-best read-out, risk terms, TRAINING half, clip + SGD")
+    part(rest[cut:], "(a) next step's decoder encoder pass + joint halves + search set-up")
 
 
 if __name__ == "__main__":

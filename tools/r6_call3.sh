@@ -6,4 +6,4 @@ mkdir -p $O
 (cd /tmp; rm -rf /tmp/prof_mbr; timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_mbr -o mbr -- python $GRAFT_REPO_ROOT/bench.py --workload mbr_step --batch 8 --beam 4 --steps 3 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_mbr.log 2>&1)
 db=$(find /tmp/prof_mbr -name '*_results.db' | head -1)
 python tools/mbr_anatomy.py $db | tee $O/mbr_anatomy.txt
-bash tools/gpu_mbr_prof.sh > $O/mbr_host_head.txt 2>&1; cp gpurun_out/mbr_host.txt $O/ 2>/dev/null; head -60 $O/mbr_host_head.txt
+
