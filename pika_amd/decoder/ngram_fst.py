@@ -63,10 +63,17 @@ class NgramFst(object):
                     n = max(n, s + 1, d + 1)
         return cls.from_arcs(n, arcs, finals)
 
+    isymbols = osymbols = None      # {key: symbol} of the embedded tables of a binary file that carries them
+
     @classmethod
     def read_binary(cls, path):
-        """OpenFST binary `vector` / `standard` FST without embedded symbol tables
-        (what `fst.StdVectorFst.read` loads at decode_transducer.py:83)."""
+        """OpenFST binary `vector` / `standard` FST, with or without embedded symbol tables (what
+        `fst.StdVectorFst.read` loads at decode_transducer.py:83; `fstcompile --isymbols=... --keep_isymbols` or an
+        arpa2fst output written with its tables carries them: header flags bit 0 / bit 1).  A table on disk
+        (OpenFST 1.6 / 1.7 `SymbolTableImpl::Write`): int32 magic 2125658996, string name, int64 available key, int64
+        size, then `size` x (string symbol, int64 key); strings are int32 length + bytes.  The search only ever uses
+        integer labels (sorted_matcher.py:24-111): the tables are parsed, kept as `isymbols` / `osymbols` and otherwise
+        ignored.  Files written with --align (flag bit 2) are refused."""
         with open(path, "rb") as f:
             data = f.read()
         pos = [0]
@@ -88,15 +95,32 @@ class NgramFst(object):
         flags = take("i")
         take("Q")
         start, nstates, _ = take("q"), take("q"), take("q")
-        if fsttype != "vector" or arctype != "standard" or (flags & 3):
-            raise NotImplementedError("need a vector/standard FST without symbol tables")
+        if fsttype != "vector" or arctype != "standard":
+            raise NotImplementedError("need a vector / standard FST, got %s / %s" % (fsttype, arctype))
+        if flags & 4:
+            raise NotImplementedError("aligned OpenFST files (fstconvert --align) are not supported")
+
+        def symbol_table():
+            if take("i") != 2125658996:
+                raise ValueError("corrupt embedded symbol table in %s" % path)
+            string()                    # table name
+            take("q")                   # available key
+            table = {}
+            for _ in range(take("q")):
+                sym = string()
+                table[take("q")] = sym
+            return table
+        isyms = symbol_table() if flags & 1 else None
+        osyms = symbol_table() if flags & 2 else None
         off, il, wt, ns, fin = [0], [], [], [], []
         for _ in range(nstates):
             fin.append(take("f"))
             for _ in range(take("q")):
                 il.append(take("i")); take("i"); wt.append(take("f")); ns.append(take("i"))
             off.append(len(il))
-        return cls(off, il, wt, ns, fin, start)
+        fst = cls(off, il, wt, ns, fin, start)
+        fst.isymbols, fst.osymbols = isyms, osyms
+        return fst
 
 
 class SortedMatcher(object):

@@ -11,9 +11,10 @@ class DoubleMatrix(object):
         self.data = np.zeros((0, 0))
 
     def read_(self, stream, binary):
-        if binary:
-            raise NotImplementedError("binary CMVN statistics: write them in text mode (the recipes do)")
-        self.data = kaldi_io.read_text_matrix(stream.name)
+        """Kaldi's Matrix::Read: the CONTENT decides -- a stream that starts with "\\0B" holds a binary matrix (token DM or
+        FM, what `compute-cmvn-stats --binary=true` writes), anything else the text form ` [ ... ]`; the `binary` argument
+        (what Input detected) is only a hint, as in Kaldi."""
+        self.data = kaldi_io.read_matrix_file(stream.name)
         return self
 
 

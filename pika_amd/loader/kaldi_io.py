@@ -49,27 +49,50 @@ def _read_token(f):
         tok += c
 
 
+def _read_int_vector_body(f):
+    """One int vector at the stream position, behind its key: binary `\\0B <4> <int32 n>` + n x (<4> <int32>), or the rest
+    of a text line (an optional `[ ... ]` is tolerated: copy-int-vector writes none, some tools do)."""
+    pos = f.tell()
+    head = f.read(2)
+    if head == b"\0B":
+        assert f.read(1) == b"\x04"
+        n = struct.unpack("<i", f.read(4))[0]
+        raw = np.frombuffer(f.read(5 * n), dtype=np.uint8).reshape(n, 5)
+        return raw[:, 1:].copy().view("<i4").reshape(n).astype(np.int32)
+    f.seek(pos)
+    parts = [v for v in f.readline().decode("utf-8").split() if v not in ("[", "]")]
+    return np.array([int(v) for v in parts], np.int32)
+
+
 def read_int_vectors(rspec):
-    """Yield (uttid, np.int32 array) from a Kaldi int-vector archive (text or binary)."""
+    """Yield (uttid, np.int32 array) from a Kaldi int-vector table: an archive `ark:file` / `ark,t:file` / a plain path
+    (text or binary, decided per entry by its content), or a script file `scp:file` whose lines are
+    `uttid path[:byte_offset]` -- the offset points BEHIND the key of an archive entry, as `copy-int-vector ark:.. ark,scp:..`
+    writes it; without an offset the file holds one vector."""
     kind, path = _rspec_path(rspec)
     if kind.startswith("scp"):
-        raise NotImplementedError("scp int-vector tables are not used by the recipes")
+        with open(path, "r", encoding="utf-8") as s:
+            for line in s:
+                p = line.split(None, 1)
+                if not p:
+                    continue
+                loc = p[1].strip()
+                fn, off = loc.rsplit(":", 1) if (":" in loc and loc.rsplit(":", 1)[1].isdigit()) else (loc, "0")
+                with open(fn, "rb") as f:
+                    f.seek(int(off))
+                    yield p[0], _read_int_vector_body(f)
+        return
     with open(path, "rb") as f:
         while True:
             pos = f.tell()
             key = _read_token(f)
             if key is None:
                 return
-            head = f.read(2)
-            if head == b"\0B":                       # binary: \0B <4> <int32 n> then n x (<4> <int32>)
-                assert f.read(1) == b"\x04"
-                n = struct.unpack("<i", f.read(4))[0]
-                raw = np.frombuffer(f.read(5 * n), dtype=np.uint8).reshape(n, 5)
-                yield key, raw[:, 1:].copy().view("<i4").reshape(n).astype(np.int32)
-            else:                                    # text line
-                f.seek(pos)
-                parts = f.readline().decode("utf-8").split()
-                yield parts[0], np.array([int(v) for v in parts[1:]], np.int32)
+            f.seek(-1, 1)
+            if f.read(1) == b"\n":                  # `uttid\n`: a text entry with no labels (the token ate its line end)
+                yield key, np.zeros(0, np.int32)
+                continue
+            yield key, _read_int_vector_body(f)
 
 
 def _read_compressed_matrix(f, tok):
@@ -154,6 +177,28 @@ def write_matrix_ark(path, items):
                     struct.pack("<i", m.shape[1]) + m.tobytes())
 
 
+def read_matrix_file(path):
+    """A single Kaldi matrix file, text or binary by its content (Matrix::Read): float64 array.  Binary: `\\0B` + token `DM`
+    (double) or `FM` (float) + <4> rows <4> cols + row-major data; compressed forms as in _read_compressed_matrix."""
+    with open(path, "rb") as f:
+        if f.read(2) != b"\0B":
+            return read_text_matrix(path)
+        tok = _read_token(f)
+        if tok in ("CM", "CM2", "CM3"):
+            return _read_compressed_matrix(f, tok).astype(np.float64)
+        if tok not in ("FM", "DM"):
+            raise NotImplementedError("Kaldi matrix type %r in %s" % (tok, path))
+        assert f.read(1) == b"\x04"
+        rows = struct.unpack("<i", f.read(4))[0]
+        assert f.read(1) == b"\x04"
+        cols = struct.unpack("<i", f.read(4))[0]
+        dt = "<f4" if tok == "FM" else "<f8"
+        data = np.frombuffer(f.read(rows * cols * int(dt[-1])), dtype=dt)
+        if data.size != rows * cols:
+            raise ValueError("truncated Kaldi matrix in %s" % path)
+        return data.reshape(rows, cols).astype(np.float64)
+
+
 def read_text_matrix(path):
     """Kaldi text matrix ` [ a b c\\n d e f ]` -> float64 array (CMVN statistics: 2 x (D+1))."""
     with open(path, "r") as f:
@@ -179,7 +224,8 @@ def write_int_vectors(path, items, binary=False):
     if not binary:
         with open(path, "w", encoding="utf-8") as f:
             for key, vec in items:
-                f.write(" ".join([key] + [str(int(v)) for v in vec]) + "\n")
+                # Kaldi's text holder: key, a space, the elements each FOLLOWED by a space, the line end (`utt1 \n` when empty)
+                f.write(key + " " + "".join("%d " % int(v) for v in vec) + "\n")
         return
     with open(path, "wb") as f:
         for key, vec in items:

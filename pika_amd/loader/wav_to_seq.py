@@ -5,22 +5,63 @@
 Writes `out.mrk.<i>` / `out.seq.<i>`, a new pair every `num_wav_per_seq` utterances: `.seq` is the
 concatenated raw int16 PCM, every `.mrk` line is `uttid byte_offset num_bytes` with offsets restarting at 0 in
 each pair -- the container loader/otf_utt_loader.py reads.  wav.scp lines are `uttid /path/to.wav`
-(RIFF, 16-bit PCM, mono -- the reference asserts one channel as well); Kaldi command pipes (`... |`) are
-not supported here.
+(RIFF, 16-bit PCM, mono -- the reference asserts one channel as well) or Kaldi command pipes
+`uttid sox in.flac -t wav -r 16000 - |` (the command runs through the shell, as Kaldi's Input does, and must write a
+RIFF file to its stdout; a failing command raises with its stderr).
 """
 import argparse
+import io
+import subprocess
 import wave
 
 import numpy as np
 
 
 def read_wav_int16(path):
+    """path: a file name, or a file-like object holding a RIFF file (the output of a wav.scp pipe)."""
+    name = path if isinstance(path, str) else "<pipe>"
     with wave.open(path, "rb") as w:
         if w.getnchannels() != 1:
-            raise ValueError("%s: %d channels, the recipes use mono audio" % (path, w.getnchannels()))
+            raise ValueError("%s: %d channels, the recipes use mono audio" % (name, w.getnchannels()))
         if w.getsampwidth() != 2:
-            raise ValueError("%s: %d-byte samples, expected 16-bit PCM" % (path, w.getsampwidth()))
-        return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+            raise ValueError("%s: %d-byte samples, expected 16-bit PCM" % (name, w.getsampwidth()))
+        data = w.readframes(w.getnframes())
+        return np.frombuffer(data[:len(data) - len(data) % 2], dtype="<i2")
+
+
+def read_wav_pipe(command):
+    """`command` without its trailing `|`: run it, parse its stdout as RIFF.  A streamed header carries no usable data
+    size (0 or 0xFFFFFFFF): the samples are then everything behind the 'data' chunk header."""
+    r = subprocess.run(command, shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        raise RuntimeError("wav.scp pipe failed (exit %d): %s\n%s" % (r.returncode, command,
+                                                                        r.stderr.decode("utf-8", "replace")[-500:]))
+    raw = r.stdout
+    try:
+        pcm = read_wav_int16(io.BytesIO(raw))
+        if len(pcm):
+            return pcm
+    except (wave.Error, EOFError):
+        pass
+    # streamed RIFF: locate "fmt " and "data" by hand
+    if raw[:4] != b"RIFF" or raw[8:12] != b"WAVE":
+        raise ValueError("wav.scp pipe did not write a RIFF/WAVE stream: %s" % command)
+    pos, fmt = 12, None
+    while pos + 8 <= len(raw):
+        tag, size = raw[pos:pos + 4], int.from_bytes(raw[pos + 4:pos + 8], "little")
+        if tag == b"fmt ":
+            fmt = raw[pos + 8:pos + 8 + 16]
+        if tag == b"data":
+            if fmt is None:
+                break
+            chans, width = int.from_bytes(fmt[2:4], "little"), int.from_bytes(fmt[14:16], "little")
+            if int.from_bytes(fmt[0:2], "little") != 1 or chans != 1 or width != 16:
+                raise ValueError("wav.scp pipe: need mono 16-bit PCM, got format %d, %d channels, %d bits: %s" % (
+                    int.from_bytes(fmt[0:2], "little"), chans, width, command))
+            body = raw[pos + 8:] if size in (0, 0xFFFFFFFF) or pos + 8 + size > len(raw) else raw[pos + 8:pos + 8 + size]
+            return np.frombuffer(body[:len(body) - len(body) % 2], dtype="<i2")
+        pos += 8 + size + (size & 1)
+    raise ValueError("wav.scp pipe: no fmt / data chunk in the stream: %s" % command)
 
 
 def iter_wav_scp(rspecifier):
@@ -32,8 +73,9 @@ def iter_wav_scp(rspecifier):
                 continue
             target = p[1].strip()
             if target.endswith("|"):
-                raise NotImplementedError("wav.scp command pipes are not supported: %r" % line.strip())
-            yield p[0], read_wav_int16(target)
+                yield p[0], read_wav_pipe(target[:-1].strip())
+            else:
+                yield p[0], read_wav_int16(target)
 
 
 def convert(rspecifier, out_mrk, out_seq, num_wav_per_seq=2000):

@@ -59,7 +59,27 @@ def test_fst_file_formats(tmp_path):
             for j in range(lo, hi):
                 f.write(struct.pack("<iifi", int(ref.ilabel[j]), int(ref.ilabel[j]), float(ref.weight[j]), int(ref.nextstate[j])))
     c = NgramFst.read_binary(str(b))
-    for g in (a, c):
+    # ... and the same FST with EMBEDDED symbol tables (header flags 1 | 2; `fstcompile --keep_isymbols --keep_osymbols`):
+    # OpenFST 1.6/1.7 SymbolTableImpl::Write -- int32 magic, name, int64 available key, int64 size, size x (symbol, int64 key)
+    syms = ["<eps>"] + ["w%d" % i for i in range(1, 14)]
+
+    def table(name):
+        out = struct.pack("<i", 2125658996) + s_(name) + struct.pack("<qq", len(syms), len(syms))
+        for k, sym in enumerate(syms):
+            out += s_(sym) + struct.pack("<q", k)
+        return out
+    b2 = tmp_path / "g_syms.fst"
+    with open(b2, "wb") as f:
+        f.write(struct.pack("<i", 2125659606) + s_("vector") + s_("standard") + struct.pack("<iiQqqq", 2, 3, 0, 0, n, len(arcs)))
+        f.write(table("words.txt") + table("words.txt"))
+        for st in range(n):
+            lo, hi = ref.offsets[st], ref.offsets[st + 1]
+            f.write(struct.pack("<fq", float(ref.final[st]), hi - lo))
+            for j in range(lo, hi):
+                f.write(struct.pack("<iifi", int(ref.ilabel[j]), int(ref.ilabel[j]), float(ref.weight[j]), int(ref.nextstate[j])))
+    d = NgramFst.read_binary(str(b2))
+    assert d.isymbols[0] == "<eps>" and d.osymbols[13] == "w13" and len(d.isymbols) == len(syms) and c.isymbols is None
+    for g in (a, c, d):
         assert np.array_equal(g.offsets, ref.offsets) and np.array_equal(g.ilabel, ref.ilabel)
         assert np.allclose(g.weight, ref.weight) and np.array_equal(g.nextstate, ref.nextstate)
         assert np.allclose(g.final, ref.final)
