@@ -477,10 +477,13 @@ def decode_workload(args, dev, rank):
         las_bw = las.Net(lopt, 1024, V + 2, PAD).to(dev).eval()
 
     def decoder(beam, nbest, lm=None):
-        return TransducerDecoder(model, batch_size=B, beam_size=beam, n_best=nbest, blk=0,
-                                 global_scorer=GlobalScorer(), sm_scale=0.8, cuda=True,
-                                 lm_scorer=lm, lm_scorer_scale=args.fst_scale,
-                                 beam_prune=True, args=dargs)
+        d = TransducerDecoder(model, batch_size=B, beam_size=beam, n_best=nbest, blk=0,
+                              global_scorer=GlobalScorer(), sm_scale=0.8, cuda=True,
+                              lm_scorer=lm, lm_scorer_scale=args.fst_scale,
+                              beam_prune=True, args=dargs)
+        if getattr(args, "decode_eager", False):
+            d.use_graph = False         # per-kernel counter passes: the same launches, from Python
+        return d
 
     speech = None
     if getattr(args, "decode_model", "speechlike") == "speechlike" and args.pred_net == "transformer":
@@ -535,7 +538,7 @@ def decode_workload(args, dev, rank):
             src = enc_out.transpose(0, 1)                                   # (T', B, H)
             # both rescorers as one call (las.score_nbest_batch_many).  Phase times (a device wait at every phase) only when
             # asked for (step.want_phases: an extra, untimed batch)
-            os.environ["PIKA_LAS_TIMING"] = "1" if step.want_phases else "0"
+            las_fw.want_phase_times = las_bw.want_phase_times = bool(step.want_phases)
             step.calls += 1
             ret["las"] = tuple(las_mod.score_nbest_batch_many(
                 [(las_fw, src, x_len_host, hyps, SOS, EOS, 1.0),
@@ -697,9 +700,10 @@ def self_launch(n, argv):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-HARNESS_NOTE = ("gc.collect() + gc.freeze() after the warm-up steps of a leg: the interpreter's full collections walk the ~1e6 live "
-                "objects of the models and tables (a 45 ms stall every fourth decode batch, profiles/r5_las_pass_overlap.txt); "
-                "frozen, collections still run over the objects made afterwards.  PIKA_BENCH_GC_FREEZE=0: off")
+HARNESS_NOTE = ("gc.collect() + gc.freeze() after the warm-up steps of the TRAINING legs (the interpreter's full collections walk the "
+                "~1e6 live objects of the models and tables); the decode legs get the same from the product itself "
+                "(TransducerDecoder.freeze_gc: once per process after the second batch), as a decode_transducer.py run does.  "
+                "PIKA_BENCH_GC_FREEZE=0: the harness leaves the collector alone")
 
 
 def freeze_gc():
@@ -973,7 +977,7 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
                                     "the joint's projections as two bf16 terms and hi.hi + lo.hi + hi.lo as ONE bf16 product "
                                     "over a 3x longer reduction on the direct-to-LDS kernels (fp32 tensors between products, "
                                     "torch attention chain); the joint's lattice products (fc2 and its gradients) on bf16 "
-                                    "operands as in config 2 (PIKA_X3_JOINT=x3: two terms there too, 122 ms): encoder "
+                                    "operands as in config 2 (pika_amd.gemm.X3_JOINT_BF16 = False: two terms there too, 122 ms): encoder "
                                     "activations 1e-4 and loss 2e-4 of the exact "
                                     "mode, i.e. inside the 1e-3 of north_star (tests/test_model.py, "
                                     "tests/test_train_step_gpu.py, profiles/r2_precision_table.md)"}
@@ -1444,6 +1448,8 @@ def main():
     ap.add_argument("--fst", action="store_true", help="decode: n-gram FST shallow fusion (synthetic bigram)")
     ap.add_argument("--fst-scale", type=float, default=0.3, help="decode --fst: LM weight (egs/eval_transducer.sh uses 0.3)")
     ap.add_argument("--las", action="store_true", help="decode: forward + backward LAS rescoring of the n-best")
+    ap.add_argument("--decode-eager", action="store_true",
+                    help="decode: the search step's launches from Python instead of hipGraph replays (per-kernel counter passes)")
     ap.add_argument("--mbr-search-precision", default=None, choices=["fp32", "fp32-exact", "bf16x3", "bf16"],
                     help="mbr_step: decode arithmetic of the N-best search (default: the decoder's default, fp32-grade)")
     ap.add_argument("--no-mbr", action="store_true", help="default run: skip the MBR-step leg (configs[3])")

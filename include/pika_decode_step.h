@@ -14,10 +14,12 @@
  *                             tanh(.)*sigmoid(.) (+ gathered encoder half) in its epilogue
  *   pika_dstep_attention (x2) self-attention of the new position over the row's cached prefix (keys / values of
  *                             the new position are stored into the caches by the same launch)
- *   pika_dfc2_topk            fc2 (+bias, x sm_scale) with the log-sum-exp partials and the per-row top-K partials
- *                             in its epilogue: the (B*K, V) logits never reach HBM
- *   pika_beam_advance_partials  merges the partials, then the whole of `advance` (as pika_beam_advance,
- *                             pika_decode.h), the all-done test and the step counter
+ *   pika_dfc2_logits          fc2 (+bias, x sm_scale): the scaled logits (B*K, V) and per-row, per-range log-sum-exp
+ *                             statistics (max, sum exp) from its epilogue
+ *   pika_beam_advance_logits  a row's K best by ONE thresholded pass over its logits, then the whole of `advance` (as
+ *                             pika_beam_advance, pika_decode.h), the all-done test and the step counter
+ * (Rounds 2-4 selected K candidates per (row, range) inside the product's epilogue -- pika_dfc2_topk /
+ *  pika_beam_advance_partials -- which cost more than the product; removed in ABI 20.)
  *
  * Weights are constant while decoding: they are packed ONCE (pika_dpack_weight) into MFMA fragment order, as 1, 2
  * or 3 bf16 terms (w = hi [+ mid [+ lo]]: 3 terms reproduce fp32 products exactly, 6 MFMAs per product pair), or --
@@ -176,49 +178,31 @@ int pika_dstep_lstm_cell(const float *gates, long long ldg, float *state, long l
                          const long long *rowmap, const int *m_dev, float *next_a, long long ld_next, int rows, int H,
                          void *stream);
 
-/* ---- fc2 + log-sum-exp partials + per-row top-K partials -------------------------------------------------------
+/* ---- fc2: scaled logits + log-sum-exp statistics per column range ------------------------------------------------
  * h (rows, K) f32, W packed (V, K).  Column range s of `splits` (= pika_dfc2_splits(V)) covers
  * [s*cols, (s+1)*cols), cols = pika_dfc2_cols_per_split().  For every row and range:
  *   pmax[r*splits+s] = max_c x,  psum[...] = sum_c exp(x - pmax),  x = sm_scale * (h.W^T + bias)[r, c]
- *   pcand[(r*splits+s)*topk + j] = {x, c} of the j-th largest x of the range (ties: lowest c), j < topk <= 64;
- *   ranges with fewer than topk columns are filled with {-inf, 0x7fffffff}. */
+ * and the scaled values x themselves go to logits (rows, ldl) f32, ldl >= splits * cols (columns [V, splits*cols) are
+ * written as -inf). */
 #define PIKA_DFC2_COLS 192        /* columns per range (= pika_dfc2_cols_per_split()) */
 int pika_dfc2_splits(int V);
 int pika_dfc2_cols_per_split(void);
-int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K,
-                   int terms, float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream);
-
-/* The same product with the row statistics only: pmax / psum as above, and the scaled values x themselves go to
- * logits (rows, ldl) f32, ldl >= splits * cols (columns [V, splits*cols) are written as -inf).  pika_beam_advance_logits
- * then finds a row's K best with one thresholded pass over the row (below): cheaper than selecting K per range here
- * (27 ranges x 16 candidates per row for 16 winners at V = 5000, and more than half of this launch's time). */
 int pika_dfc2_logits(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K,
                      int terms, float sm_scale, float *pmax, float *psum, float *logits, long long ldl, void *stream);
 
-/* ---- advance from partials ---------------------------------------------------------------------------------
- * As pika_beam_advance (pika_decode.h) with the row log-softmax / top-K taken from the partials above, plus:
+/* ---- advance from the scaled logits ----------------------------------------------------------------------------
+ * As pika_beam_advance (pika_decode.h) with the row log-softmax taken from the statistics above and the row's K best from
+ * its scaled logits: the K-th largest of the row's `splits` range maxima bounds the row's K-th largest value from below;
+ * one pass over the row keeps the values at or above the bound (a few dozen of V), and the K best of those are the row's K
+ * best (ties: lowest column first).  Rows whose survivors outnumber the 256-entry pool (many near-equal values; splits < K)
+ * have the bound raised by bisection with counting passes.  Results identical to pika_beam_advance.  Plus:
  * `first` is read from the device (*step_t == 0); the step counter is incremented by the call;
  * done[b] (u8) = eos_top[b] && fin_n[b] >= n_best; *stop = all utterances done; *max_hyp = max hyp_len.
  * sync (int32[8], zeroed once by the caller): [0..3] scratch for the cross-workgroup arrival counts of even / odd
  * steps; [4] is set once a call was skipped because *stop was already set (the gate of the FST advance that follows);
  * [5], [6] are the compact-row counters of pika_dstep_prep (count = sync + 5): the call zeroes the one the next step
- * will fill.  Needs splits*K <= 1024 and K*L*4 + K*K*8 + 4*splits*K*8 bytes of LDS <= 96 KiB
- * (PIKA_ETOOBIG otherwise). */
-int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
-                               float *scores, const float *lm_scores, float lm_scale, long long *y,
-                               long long *t_idx, const long long *num_frames, const long long *max_len,
-                               long long *hyp, long long *hyp_len, int L, long long *ks_hist,
-                               long long *ys_hist, long long *step_t, unsigned char *eos_top,
-                               float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
-                               int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
-                               int blk, int beam_prune, int n_best, int *stop, long long *max_hyp, int *sync,
-                               void *stream);
-
-/* As pika_beam_advance_partials with the candidates taken from the scaled logits of pika_dfc2_logits: per row, the K-th
- * largest of the row's `splits` range maxima bounds the row's K-th largest value from below; one pass over the row keeps
- * the values at or above the bound (a few dozen of V), and the K best of those are the row's K best (same tie rule: lowest
- * column first).  Rows whose survivors outnumber the 256-entry pool (many near-equal values; splits < K) have the bound
- * raised by bisection with counting passes.  Results identical to pika_beam_advance_partials / pika_beam_advance. */
+ * will fill.  LDS: pika_beam_advance_logits_lds(K, L, splits) bytes (0: the shape is not taken -> PIKA_ETOOBIG). */
+size_t pika_beam_advance_logits_lds(int K, int L, int splits);
 int pika_beam_advance_logits(const float *pmax, const float *psum, const float *logits, long long ldl, int splits,
                              float *scores, const float *lm_scores, float lm_scale, long long *y,
                              long long *t_idx, const long long *num_frames, const long long *max_len,

@@ -31,31 +31,22 @@ int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float
                    float *h_out2, long long ldh2, int N, int H, const int *n_dev, const int *rowlist,
                    const int *rowoff_dev, void *stream);
 
-/* "mlp" attention of N queries over the source positions of their utterances; query n = qidx[i], i < N (qidx NULL:
- * n = i):
+/* "mlp" attention of the queries of a list over the source positions of their utterances; query n = qidx[i]:
  *   align[n, s] = sum_d v[d] tanh(wq[n, d] + proj[owner[n], s, d])          s < lens[owner[n]]  (else excluded)
  *   a[n, :]     = softmax_s align[n, :]
  *   ctx_out[n, :] = sum_s a[n, s] context[owner[n], s, :]
  * wq (., D) f32 pitch ldq = W_q h_t + b_q (the caller's GEMM); proj, context (B, S, D) f32 contiguous = U_a h_s and
- * h_s; owner (.,) int32 utterance of each query; qidx (N,) int32 the queries to process -- consecutive entries
- * should belong to the same utterance: a workgroup takes 4 of them and loads an utterance's rows once for those that
- * share it (the caller's active set is a prefix of its length-sorted hypotheses, the list re-orders it by
- * utterance); lens (B,) int32 valid positions (>= 1); ctx_out (., D) f32 pitch ldo; align_out (., S) f32 or NULL
- * (the attention weights, for tests).  D % 4 == 0, D <= 1024, S <= 2048.
- * n_dev / qoff_dev: NULL, or device ints: the launch processes min(N, *n_dev) list entries starting at qidx + *qoff_dev
- * (one launch captured into a hipGraph serves every token of a pass; N then sizes the grid for the largest step). */
-int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, const float *context, const int *owner,
-                           const int *lens, const int *qidx, const float *v, float *ctx_out, long long ldo,
-                           float *align_out, int N, int B, int S, int D, const int *n_dev, const int *qoff_dev,
-                           void *stream);
-
-/* The same attention for a query list ORDERED BY UTTERANCE, utterance by utterance (two launches): a workgroup takes all
- * the queries of one utterance and a chunk of 32 of its positions -- the utterance's U_a h_s and h_s rows are read once
- * per workgroup instead of once per query (130 -> 73 us at 470 queries of 64 utterances, S = 240, D = 1024) -- and a second launch merges
- * the chunks' partial (max, sum, context sums) into ctx_out.  Same values to rounding (another summation order).
+ * h_s; owner (.,) int32 utterance of each query; lens (B,) int32 valid positions (>= 1); ctx_out (., D) f32 pitch ldo.
+ * D % 4 == 0, D <= 1024, S <= 2048.
+ * The query list is ORDERED BY UTTERANCE and the attention runs utterance by utterance (two launches): a workgroup takes
+ * all the queries of one utterance and a chunk of 32 of its positions -- the utterance's U_a h_s and h_s rows are read
+ * once per workgroup instead of once per query (130 -> 73 us at 470 queries of 64 utterances, S = 240, D = 1024) -- and a
+ * second launch merges the chunks' partial (max, sum, context sums) into ctx_out.
  * uoff int32 (B + 1): the queries of utterance b are entries [uoff[b], uoff[b + 1]) of the list (qidx + *qoff_dev, of
- * min(N, *n_dev) entries); with step_dev the table of the current step, uoff + *step_dev * (B + 1) (step[0] of
- * pika_las_step_advance).  work: f32 scratch of pika_las_attention_work_floats(N, S, D) floats, 16-byte aligned. */
+ * min(N, *n_dev) entries; one launch captured into a hipGraph serves every token of a pass, N then sizes the grid for the
+ * largest step); with step_dev the table of the current step, uoff + *step_dev * (B + 1) (step[0] of
+ * pika_las_step_advance).  work: f32 scratch of pika_las_attention_work_floats(N, S, D) floats, 16-byte aligned.
+ * (Rounds 3-4 launched one query per workgroup -- pika_las_mlp_attention, removed in ABI 20.) */
 size_t pika_las_attention_work_floats(int N, int S, int D);
 int pika_las_mlp_attention_by_utterance(const float *wq, long long ldq, const float *proj, const float *context,
                                         const int *owner, const int *lens, const int *qidx, const int *uoff, const float *v,
@@ -65,7 +56,7 @@ int pika_las_mlp_attention_by_utterance(const float *wq, long long ldq, const fl
 /* The token loop of a rescoring pass as ONE captured launch sequence replayed once per token: every per-token quantity
  * lives on the device.  step int32[4] = {t, n, qoff, -} (the caller starts it at {-1, 0, 0, 0});
  * pika_las_step_advance: t += 1, n = n_active[t], qoff = qoffs[t] (0 beyond L) -- n is what the m_dev / n_dev
- * parameters of pika_dgemm, pika_lstm_cell and pika_las_mlp_attention point at;
+ * parameters of pika_dgemm, pika_lstm_cell and pika_las_mlp_attention_by_utterance point at;
  * pika_las_embed_rows: for e < n, r = rowlist ? rowlist[qoff + e] : e: x0[r, 0:E] = emb[tokens[t, r], :] (the decoder's
  * layer-0 input rows, pitch ldx) and crow[r] = t * N + r (the row of the (L, N, H) result the token's output projection
  * writes through pika_dgemm's crow).  tokens (L, N) int64, E % 4 == 0.  rowlist: the per-step lists of ACTIVE rows

@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -69,7 +69,6 @@ SIGNATURES = {
     "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
     # include/pika_las.h
     "pika_lstm_cell": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
-    "pika_las_mlp_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pika_las_attention_work_floats": (ctypes.c_size_t, [_i, _i, _i]),
     "pika_las_mlp_attention_by_utterance": (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i,
                                                  _vp, _vp, _vp, _vp]),
@@ -114,11 +113,8 @@ SIGNATURES = {
     "pika_dstep_attention": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pika_dfc2_splits": (_i, [_i]),
     "pika_dfc2_cols_per_split": (_i, []),
-    "pika_dfc2_topk": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _vp]),
-    "pika_beam_advance_partials": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i,
-                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
-                                        _vp, _vp, _vp, _vp]),
     "pika_dfc2_logits": (_i, [_vp, _ll, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _vp, _ll, _vp]),
+    "pika_beam_advance_logits_lds": (ctypes.c_size_t, [_i, _i, _i]),
     "pika_beam_advance_logits": (_i, [_vp, _vp, _vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i,
                                       _vp, _vp, _vp, _vp]),

@@ -19,8 +19,7 @@ FLAGS += os.environ.get("PIKA_HIPCC_EXTRA", "").split()      # profiling builds 
 # Per-file code-generation options.  attn.hip: MFMA results in VGPRs instead of AGPRs -- the online softmax reads every
 # score and rescales every context accumulator each key tile, so the AGPR form costs ~80 v_accvgpr_read/write per tile
 # per wave in kernels that are bound by VALU issue (419 -> 343 instructions in the forward loop, same arithmetic).
-# PIKA_ATTN_AGPR=1 builds the AGPR form for A/B runs.
-EXTRA_FLAGS = {"attn.hip": [] if os.environ.get("PIKA_ATTN_AGPR") else ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():

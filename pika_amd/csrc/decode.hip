@@ -382,7 +382,7 @@ __device__ inline void select_row(const Cand *pool, int n, int K, int lane, floa
     }
 }
 
-// ---- kernel B': the same, with the row log-softmax / top-K built from the partials of pika_dfc2_topk ---------
+// ---- kernel B': the same, with the row log-softmax / top-K built from the row statistics + scaled logits of pika_dfc2_logits ----
 // (include/pika_decode_step.h).  Phase 1, one wave per beam row: disabled rows as in kernel A; otherwise
 // log-sum-exp = log sum_s psum_s exp(pmax_s - max), and the K best of the S sorted partial lists by K rounds of
 // "wave arg-max over the S list heads".  Phase 2 = kernel B.  Phase 3: done flags, the all-done stop flag, the
@@ -390,8 +390,7 @@ __device__ inline void select_row(const Cand *pool, int n, int K, int lane, floa
 // Launched with min(16, K) waves per utterance: every beam row gets a wave of its own for phase 1 (the four rows a wave
 // took in turn at 256 threads were four dependent chains of row-sized round trips: 70 us of a 600 us step).
 
-// logits != NULL (pika_beam_advance_logits): the partials are the row statistics only and the candidates come from the
-// scaled logits themselves -- see row_survivors.
+// The partials are the row statistics only; the candidates come from the scaled logits themselves -- see row_survivors.
 constexpr int POOL_CAP = 256;     // candidates a row's wave holds in LDS for the selection (select_row<4>)
 
 // The row's candidates for its K best logits WITHOUT looking at most of them twice: the K-th largest of the row's split
@@ -470,7 +469,7 @@ __device__ inline int row_survivors(const float *__restrict__ row, int V, int K,
 
 __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__restrict__ pmax,
                                                             const float *__restrict__ psum,
-                                                            const Cand *__restrict__ pcand, int S, BeamState a,
+                                                            int S, BeamState a,
                                                             int beam_prune, int n_best, int *__restrict__ stop,
                                                             long long *__restrict__ max_hyp, int *__restrict__ sync,
                                                             long long *__restrict__ step_rw,
@@ -540,36 +539,16 @@ __global__ __launch_bounds__(1024) void beam_partials_kernel(const float *__rest
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float logsum = logf(s);
         const float add_s = a.scores[bk + k], add_l = a.lm_scale * sh.lm_old[k];
-        // all S*K partial candidates of the row into this wave's LDS slab with ONE round of loads, then K rounds of
-        // "lane-local best over its strided share + wave arg-max" (no load sits on the selection's critical path)
-        if (logits) {
-            ADV_STAMP(4);
-            Cand *pool = pool_all + wave * POOL_CAP;
-            const int n = row_survivors(logits + (bk + k) * ldl, V, K, S, mine, lane, pool);
-            __builtin_amdgcn_wave_barrier();
-            ADV_STAMP(5);
-            if (n <= 64) select_row<1>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
-            else if (n <= 128) select_row<2>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
-            else select_row<4>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
-            ADV_STAMP(6);
-            continue;
-        }
-        const int n = S * K;
-        Cand *pool = pool_all + wave * n;
-        const Cand *src = pcand + pi * K;
-        for (int base = lane; base < n; base += 64 * 8) {      // one batch of independent loads, not a chain
-            Cand c[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (base + u * 64 < n) c[u] = src[base + u * 64];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (base + u * 64 < n) pool[base + u * 64] = c[u];
-        }
+        // the row's few dozen candidates for its K best into this wave's LDS pool (row_survivors), then the selection
+        ADV_STAMP(4);
+        Cand *pool = pool_all + wave * POOL_CAP;
+        const int n = row_survivors(logits + (bk + k) * ldl, V, K, S, mine, lane, pool);
         __builtin_amdgcn_wave_barrier();
-        if (n <= 256) select_row<4>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
-        else if (n <= 512) select_row<8>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
-        else select_row<16>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+        ADV_STAMP(5);
+        if (n <= 64) select_row<1>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+        else if (n <= 128) select_row<2>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+        else select_row<4>(pool, n, K, lane, m, logsum, first, add_s, add_l, k * V, out);
+        ADV_STAMP(6);
     }
     lds_barrier();
     ADV_STAMP(7);
@@ -907,56 +886,15 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
     return (int)hipGetLastError();
 }
 
-static int advance_partials_launch(const float *pmax, const float *psum, const void *pcand, const float *logits,
-                                   long long ldl, int splits,
-                                   float *scores, const float *lm_scores, float lm_scale, long long *y,
-                                   long long *t_idx, const long long *num_frames, const long long *max_len,
-                                   long long *hyp, long long *hyp_len, int L, long long *ks_hist,
-                                   long long *ys_hist, long long *step_t, unsigned char *eos_top,
-                                   float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
-                                   int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
-                                   int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
-                                   int *sync, void *stream) {
-    if (!pmax || !psum || (!pcand && !logits) || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
-        !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step || !fin_k || !fin_n ||
-        !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
-        return PIKA_EINVAL;
-    // a wave per beam row (at most 16), fewer when their candidate pools would not fit the LDS budget
+// Also exported: the LDS the launch needs and whether it fits, so that the host-side gate (decoder/fused_step.py::supported)
+// asks the library instead of restating its arithmetic.  Returns the bytes, or 0 when the shape is not taken.
+extern "C" size_t pika_beam_advance_logits_lds(int K, int L, int splits) {
+    if (K <= 0 || L <= 0 || splits < 1 || K > MAXK || splits > 64) return 0;
     int waves = K < 16 ? K : 16;
-    const int pool = logits ? POOL_CAP : splits * K;
-    auto lds_for = [&](int w) { return (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)w * pool * sizeof(Cand); };
+    auto lds_for = [&](int w) { return (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)w * POOL_CAP * sizeof(Cand); };
     while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
     if (waves < 4) waves = 4;
-    const size_t lds_bytes = lds_for(waves);
-    if (K > MAXK || splits > 64 || (!logits && splits * K > 1024) || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_partials_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
-                eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
-    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(64 * waves), lds_bytes, static_cast<hipStream_t>(stream), pmax, psum, static_cast<const Cand *>(pcand), splits, a,
-                       beam_prune, n_best, stop, max_hyp, sync, step_t, logits, ldl);
-    return (int)hipGetLastError();
-}
-
-extern "C" int pika_beam_advance_partials(const float *pmax, const float *psum, const void *pcand, int splits,
-                                          float *scores, const float *lm_scores, float lm_scale, long long *y,
-                                          long long *t_idx, const long long *num_frames, const long long *max_len,
-                                          long long *hyp, long long *hyp_len, int L, long long *ks_hist,
-                                          long long *ys_hist, long long *step_t, unsigned char *eos_top,
-                                          float *fin_score, long long *fin_step, long long *fin_k, long long *fin_n,
-                                          int fin_cap, long long *prev_k_out, long long *y_raw, int B, int K, int V,
-                                          int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
-                                          int *sync, void *stream) {
-    if (!pcand) return PIKA_EINVAL;
-    return advance_partials_launch(pmax, psum, pcand, nullptr, 0, splits, scores, lm_scores, lm_scale, y, t_idx, num_frames,
-                                   max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t, eos_top, fin_score, fin_step, fin_k,
-                                   fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk, beam_prune, n_best, stop, max_hyp, sync,
-                                   stream);
+    return lds_for(waves) > 96 * 1024 ? 0 : lds_for(waves);
 }
 
 extern "C" int pika_beam_advance_logits(const float *pmax, const float *psum, const float *logits, long long ldl,
@@ -970,10 +908,29 @@ extern "C" int pika_beam_advance_logits(const float *pmax, const float *psum, co
                                         int blk, int beam_prune, int n_best, int *stop, long long *max_hyp,
                                         int *sync, void *stream) {
     if (!logits || ldl < V) return PIKA_EINVAL;
-    return advance_partials_launch(pmax, psum, nullptr, logits, ldl, splits, scores, lm_scores, lm_scale, y, t_idx,
-                                   num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t, eos_top, fin_score,
-                                   fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk, beam_prune, n_best,
-                                   stop, max_hyp, sync, stream);
+    if (!pmax || !psum || !scores || !lm_scores || !y || !t_idx || !num_frames || !max_len || !hyp ||
+        !hyp_len || !ks_hist || !ys_hist || !step_t || !eos_top || !fin_score || !fin_step || !fin_k || !fin_n ||
+        !prev_k_out || !stop || !max_hyp || !sync || B <= 0 || K <= 0 || V <= 0 || L <= 0 || fin_cap < 3 || splits < 1)
+        return PIKA_EINVAL;
+    // a wave per beam row (at most 16), fewer when their candidate pools would not fit the LDS budget
+    int waves = K < 16 ? K : 16;
+    auto lds_for = [&](int w) { return (size_t)K * L * 4 + (size_t)K * K * sizeof(Cand) + (size_t)w * POOL_CAP * sizeof(Cand); };
+    while (waves > 4 && lds_for(waves) > 96 * 1024) waves >>= 1;
+    if (waves < 4) waves = 4;
+    const size_t lds_bytes = lds_for(waves);
+    if (K > MAXK || splits > 64 || lds_bytes > 96 * 1024) return PIKA_ETOOBIG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_partials_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
+                eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};
+    hipLaunchKernelGGL(beam_partials_kernel, dim3(B), dim3(64 * waves), lds_bytes, static_cast<hipStream_t>(stream), pmax, psum,
+                       splits, a, beam_prune, n_best, stop, max_hyp, sync, step_t, logits, ldl);
+    return (int)hipGetLastError();
 }
 
 extern "C" int pika_incremental_attention(const float *q, const float *k_cache, const float *v_cache,

@@ -14,6 +14,7 @@
 
 #include "pika_decode_step.h"
 #include "pika_rnnt.h"  // PIKA_EINVAL
+#include "pika_internal.h"
 
 namespace {
 
@@ -1056,12 +1057,12 @@ __host__ __device__ constexpr size_t FC2_LDS_MAIN() {      // operand staging bu
 // K-th largest of the row's split maxima bounds its K-th largest logit from below: a few dozen survivors of 5000) instead
 // of this kernel bisecting every (row, split) pair for its own K best -- 27 x 16 candidates per row for 16 winners, and
 // more than half of this kernel's time.
-template <int NS, int FC2_BM, bool CANDS>
-__global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_topk_kernel(const float *__restrict__ h, long long ldh,
+template <int NS, int FC2_BM>
+__global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_logits_kernel(const float *__restrict__ h, long long ldh,
                                                         const __bf16 *__restrict__ W, const float *__restrict__ bias,
-                                                        int rows, int V, int NT, int KT, float sm_scale, int topk,
+                                                        int rows, int V, int NT, int KT, float sm_scale,
                                                         int splits, float *__restrict__ pmax,
-                                                        float *__restrict__ psum, Cand *__restrict__ pcand, int Kvalid,
+                                                        float *__restrict__ psum, int Kvalid,
                                                         float *__restrict__ logits, long long ldl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
         }
     __syncthreads();
     CORE_STAMP(38, 1);
-    if constexpr (!CANDS) {
+    {
         // Row statistics with FOUR lanes per row -- a lane walks every fourth column of its row (no cross-lane step until
         // the 4-lane merge; the row pitch keeps the 16 rows of a wave in different banks) -- and the slab goes to `logits`
         // in whole 16-byte pieces.  (One row per wave pass: 12 butterfly steps per row, 16 rows per wave.)
@@ -1123,105 +1124,7 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_t
                 *reinterpret_cast<f32x4 *>(logits + (long long)(m0 + r) * ldl + sp * FC2_COLS + 4 * c4) =
                     *reinterpret_cast<const f32x4 *>(slab + r * FC2_PITCH + 4 * c4);
         }
-        return;
     }
-    // FC2_BM / 4 rows per wave: max, sum of exponentials, the topk largest (value desc, column asc).  RG rows at a time:
-    // every stage below is a chain of dependent cross-lane steps (6 + 6 butterfly exchanges; 32 bisection rounds of
-    // compare -> ballot -> scalar popcount -> scalar select -> compare, ~80 cycles each) that leaves the wave idle --
-    // 2.3 us per row one row at a time (tools/core_trace.hip); the RG independent chains fill each other's bubbles.
-    constexpr int PL = FC2_COLS / 64;     // values per lane
-    constexpr int RG = 4;
-    static_assert((FC2_BM / 4) % RG == 0, "row groups");
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int rr = 0; rr < FC2_BM / 4; rr += RG) {
-        const int lr0 = wave * (FC2_BM / 4) + rr;
-        if (m0 + lr0 >= rows) break;
-        float x[RG][PL], m[RG], s[RG];
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-#pragma unroll
-            for (int q = 0; q < PL; ++q) x[g][q] = slab[(lr0 + g) * FC2_PITCH + lane + 64 * q];
-            m[g] = x[g][0];
-#pragma unroll
-            for (int q = 1; q < PL; ++q) m[g] = fmaxf(m[g], x[g][q]);
-        }
-        if (rr == 0) CORE_STAMP(37, 0);
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int g = 0; g < RG; ++g) m[g] = fmaxf(m[g], __shfl_xor(m[g], o));
-        if (rr == 0) CORE_STAMP(37, 1);
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            s[g] = 0.f;
-#pragma unroll
-            for (int q = 0; q < PL; ++q) s[g] += x[g][q] > -INFINITY ? expf(x[g][q] - m[g]) : 0.f;
-        }
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int g = 0; g < RG; ++g) s[g] += __shfl_xor(s[g], o);
-        if (rr == 0) CORE_STAMP(37, 2);
-        // The topk largest WITHOUT cross-lane shuffles (a wave arg-max is 12 dependent LDS-crossbar permutes, and
-        // topk of them per row made this epilogue 4x longer than the product itself): bisect the order-preserving
-        // integer image of the values for the topk-th largest key with ballots + popcounts (scalar unit), then every
-        // lane stores its own survivors at ranks taken from the ballot prefix.  Output order within a range is
-        // arbitrary (the advance re-selects anyway); ties at the threshold go to the lowest columns.
-        unsigned key[RG][PL], T[RG];
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            T[g] = 0;
-#pragma unroll
-            for (int q = 0; q < PL; ++q) key[g][q] = fkey(x[g][q]);
-        }
-        for (int bit = 31; bit >= 0; --bit) {
-            unsigned mid[RG];
-            unsigned long long bal[RG][PL];
-#pragma unroll
-            for (int g = 0; g < RG; ++g) mid[g] = T[g] | (1u << bit);
-#pragma unroll
-            for (int g = 0; g < RG; ++g)
-#pragma unroll
-                for (int q = 0; q < PL; ++q) bal[g][q] = __ballot(key[g][q] >= mid[g]);
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                int cnt = 0;
-#pragma unroll
-                for (int q = 0; q < PL; ++q) cnt += __popcll(bal[g][q]);
-                if (cnt >= topk) T[g] = mid[g];
-            }
-            // the RG * PL compares back to back, then the scalar counting: a compare -> popcount -> add -> select chain per
-            // row, one after the other, is ~145 cycles of dependent-instruction latency per row and round
-            __builtin_amdgcn_sched_group_barrier(0x004, RG, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, RG * PL, 0);
-            __builtin_amdgcn_sched_group_barrier(0x004, RG * (2 * PL + 1), 0);
-        }
-        if (rr == 0) CORE_STAMP(37, 3);
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            const int r = m0 + lr0 + g;
-            if (r >= rows) break;                 // (wave-uniform)
-            const long long pi = (long long)r * splits + sp;
-            if (lane == 0) { pmax[pi] = m[g]; psum[pi] = s[g]; }
-            Cand *out = pcand + pi * topk;
-            int base = 0;
-#pragma unroll
-            for (int q = 0; q < PL; ++q) {
-                const bool gsel = key[g][q] > T[g];
-                const unsigned long long mk = __ballot(gsel);
-                if (gsel) out[base + __popcll(mk & lt)] = Cand{x[g][q], x[g][q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
-                base += __popcll(mk);
-            }
-#pragma unroll
-            for (int q = 0; q < PL; ++q) {
-                const bool e = key[g][q] == T[g];
-                const unsigned long long mk = __ballot(e);
-                const int rk = base + __popcll(mk & lt);
-                if (e && rk < topk) out[rk] = Cand{x[g][q], x[g][q] > -INFINITY ? sp * FC2_COLS + lane + 64 * q : 0x7fffffff};
-                base += __popcll(mk);
-            }
-        }
-        if (rr == 0) CORE_STAMP(37, 4);
-    }
-    CORE_STAMP(38, 2);
 }
 
 int check(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -1234,35 +1137,28 @@ void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
 
 template <int NS, int BM>
 void launch_fc2_bm(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
-                   int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K,
-                   float *logits, long long ldl) {
+                   int V, int NT, int KT, float sm_scale, int splits, float *pmax, float *psum, int K, float *logits,
+                   long long ldl) {
     constexpr size_t lds = FC2_LDS_MAIN<NS, BM>() + FC2_COLS * 4;
-    if (logits)
-        dfc2_topk_kernel<NS, BM, false><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk,
-                                                                            splits, pmax, psum, pc, (K & 3) ? KT * 32 : K,
-                                                                            logits, ldl);
-    else
-        dfc2_topk_kernel<NS, BM, true><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk,
-                                                                           splits, pmax, psum, pc, (K & 3) ? KT * 32 : K,
-                                                                           nullptr, 0);
+    dfc2_logits_kernel<NS, BM><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum,
+                                                                   (K & 3) ? KT * 32 : K, logits, ldl);
 }
 
 int fc2_bm(int rows) {
     // 64-row tiles once the 32-row form would need a second round of workgroups (rows / 32 * 27 splits > 768 resident ones at
     // V = 5000): 74 vs 81 us at 1024 rows, but 50 vs 34 us at 32 rows (tools/dfc2_bench.py)
-    static const int forced = [] { const char *e = getenv("PIKA_DFC2_BM"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char *e = pika_knob("PIKA_DFC2_BM"); return e ? atoi(e) : 0; }();
     if (forced == 32 || forced == 64) return forced;
     return rows > 768 ? 64 : 32;
 }
 
 template <int NS>
 void launch_fc2(hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
-                int V, int NT, int KT, float sm_scale, int topk, int splits, float *pmax, float *psum, Cand *pc, int K,
-                float *logits, long long ldl) {
+                int V, int NT, int KT, float sm_scale, int splits, float *pmax, float *psum, int K, float *logits, long long ldl) {
     const int bm = fc2_bm(rows);
     const unsigned grid = (unsigned)((((rows + bm - 1) / bm + 7) / 8) * 8 * splits);
-    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
-    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
+    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
+    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
 }
 
 }  // namespace
@@ -1302,7 +1198,7 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
     // Few rows (the caller says so for a compact row list whose count lives on the device: PIKA_DG_FEW_ROWS; or M itself
     // is small): the split-reduction kernel, one 16/32-column tile of 32 rows per workgroup.  PIKA_DGEMM_SK=0 / 1 forces the
     // choice (A/B runs).
-    static const int sk_env = [] { const char *e = getenv("PIKA_DGEMM_SK"); return e ? atoi(e) : -1; }();
+    static const int sk_env = [] { const char *e = pika_knob("PIKA_DGEMM_SK"); return e ? atoi(e) : -1; }();
     const bool sk = ln || (sk_env >= 0 ? sk_env != 0 : ((q->flags & PIKA_DG_FEW_ROWS) || q->M <= 256));
     // 4 waves per workgroup take K <= 512 in ONE request round, 8 waves K <= 1024; beyond (K up to 4096) 8 waves in
     // rounds of 4 k-tiles.  Wide products (N >= 1024) take 32-column tiles: all tiles of a ~170-row launch resident at once.
@@ -1327,7 +1223,7 @@ int pika_dgemm(const pika_dgemm_t *q, void *stream) {
         return check(hipGetLastError());
     }
     // wide products (N >= 2048) beyond the few-rows kernel: 64 x 128 tiles (PIKA_DGEMM_WIDE=0: the 64 x 64 tiles, A/B runs)
-    static const bool wide_on = [] { const char *e = getenv("PIKA_DGEMM_WIDE"); return !e || atoi(e) != 0; }();
+    static const bool wide_on = [] { const char *e = pika_knob("PIKA_DGEMM_WIDE"); return !e || atoi(e) != 0; }();
     if (q->N >= 2048 && wide_on && !(q->flags & PIKA_DG_GATE)) {
         const unsigned grid = (unsigned)(8 * ((((p.NT + 7) / 8) + 7) / 8) * ((q->M + 63) / 64));
 #define PIKA_WIDE(NS) dgemm_wide_kernel<NS><<<dim3(grid), dim3(256), Core<64, 2, NS, 2>::LDS_BYTES, st>>>(p)
@@ -1402,35 +1298,20 @@ int pika_dstep_attention(const float *kvq, long long ldkvq, float *k_cache, floa
 int pika_dfc2_splits(int V) { return (V + FC2_COLS - 1) / FC2_COLS; }
 int pika_dfc2_cols_per_split(void) { return FC2_COLS; }
 
-static int dfc2_launch(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
-                       float sm_scale, int topk, float *pmax, float *psum, void *pcand, float *logits, long long ldl,
-                       void *stream) {
-    const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
-    hipStream_t st = (hipStream_t)stream;
-    const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
-    Cand *pc = reinterpret_cast<Cand *>(pcand);
-    if (terms == 1) launch_fc2<1>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
-    else if (terms == 2) launch_fc2<2>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
-    else if (terms == 3) launch_fc2<3>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
-    else launch_fc2<4>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, topk, splits, pmax, psum, pc, K, logits, ldl);
-    return check(hipGetLastError());
-}
-
-int pika_dfc2_topk(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
-                   float sm_scale, int topk, float *pmax, float *psum, void *pcand, void *stream) {
-    if (!h || !W || !pmax || !psum || !pcand || rows <= 0 || V <= 0 || K <= 0 || topk < 1 || topk > 64 || terms < 1 ||
-        terms > 4 || (ldh & 3) || (reinterpret_cast<uintptr_t>(h) & 15))
-        return PIKA_EINVAL;
-    return dfc2_launch(h, ldh, W, bias, rows, V, K, terms, sm_scale, topk, pmax, psum, pcand, nullptr, 0, stream);
-}
-
 int pika_dfc2_logits(const float *h, long long ldh, const void *W, const float *bias, int rows, int V, int K, int terms,
                      float sm_scale, float *pmax, float *psum, float *logits, long long ldl, void *stream) {
     if (!h || !W || !pmax || !psum || !logits || rows <= 0 || V <= 0 || K <= 0 || terms < 1 || terms > 4 || (ldh & 3) ||
         (reinterpret_cast<uintptr_t>(h) & 15) || ldl < (long long)pika_dfc2_splits(V) * FC2_COLS || (ldl & 3) ||
         (reinterpret_cast<uintptr_t>(logits) & 15))
         return PIKA_EINVAL;
-    return dfc2_launch(h, ldh, W, bias, rows, V, K, terms, sm_scale, 1, pmax, psum, nullptr, logits, ldl, stream);
+    const int NT = (V + 15) / 16, KT = (K + 31) / 32, splits = pika_dfc2_splits(V);
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16 *w = reinterpret_cast<const __bf16 *>(W);
+    if (terms == 1) launch_fc2<1>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
+    else if (terms == 2) launch_fc2<2>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
+    else if (terms == 3) launch_fc2<3>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
+    else launch_fc2<4>(st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
+    return check(hipGetLastError());
 }
 
 }  // extern "C"

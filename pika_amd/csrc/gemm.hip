@@ -16,6 +16,7 @@
 
 #include "pika_gemm.h"
 #include "pika_rnnt.h"  // PIKA_EINVAL
+#include "pika_internal.h"
 
 namespace {
 
@@ -397,8 +398,8 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
     const int tiles = ((N + CF::BN - 1) / CF::BN) * ((M + CF::BM - 1) / CF::BM);
     const int nk = (K + CF::BK - 1) / CF::BK;
     int splitk = 1;
-    static const int min_nk = [] { const char *e = getenv("PIKA_GEMM_SPLIT_MIN_NK"); return e ? atoi(e) : 32; }();
-    static const int per_split = [] { const char *e = getenv("PIKA_GEMM_SPLIT_MIN_PER"); return e ? atoi(e) : 8; }();
+    static const int min_nk = [] { const char *e = pika_knob("PIKA_GEMM_SPLIT_MIN_NK"); return e ? atoi(e) : 32; }();
+    static const int per_split = [] { const char *e = pika_knob("PIKA_GEMM_SPLIT_MIN_PER"); return e ? atoi(e) : 8; }();
     // exact-mode products with the reduction contiguous (forward products: the decode path) never split: the split
     // sums through float atomics, whose order -- and with it the last bit of the encoder output, and near-ties of a
     // beam search downstream -- changes from run to run.  Weight gradients (both operands reduction-major) keep it.
@@ -408,7 +409,7 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
         // (K-tiles per workgroup + ~40 of prologue/epilogue) + ~6 per atomic pass over C; the minimum
         // reproduces the measured optimum on every shape of tools/dw_bench.py
         // (profiles/r1_dw_split_sweep.txt).  PIKA_GEMM_SPLIT_TARGET=n forces ceil(n / tiles).
-        static const int target = [] { const char *e = getenv("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
+        static const int target = [] { const char *e = pika_knob("PIKA_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 0; }();
         if (target > 0) {
             splitk = (target + tiles - 1) / tiles;
         } else {
@@ -437,7 +438,7 @@ int launch(const pika_operand_t *A, const pika_operand_t *B, float *C, long long
 // Tile configuration: PIKA_GEMM_CFG=0..3 overrides (hardware A/B only; NT operands).
 //   0: 128x128x32 / 4 waves   1: 128x128x64 / 4 waves   2: 256x128x64 / 8 waves   3: 256x128x32
 int cfg_override() {
-    static const int v = [] { const char *e = getenv("PIKA_GEMM_CFG"); return e ? atoi(e) : -1; }();
+    static const int v = [] { const char *e = pika_knob("PIKA_GEMM_CFG"); return e ? atoi(e) : -1; }();
     return v;
 }
 
@@ -454,7 +455,7 @@ int dispatch(const pika_operand_t *A, const pika_operand_t *B, float *C, long lo
             return PIKA_EINVAL;
     }
     if constexpr (TRA || TRB) {
-        static const int tcfg = [] { const char *e = getenv("PIKA_GEMM_CFG_T"); return e ? atoi(e) : -1; }();
+        static const int tcfg = [] { const char *e = pika_knob("PIKA_GEMM_CFG_T"); return e ? atoi(e) : -1; }();
         if (tcfg == 1) return launch<TA, TB, 1, Cfg<2, 2, 64>, TRA, TRB>(ARGS);
         return launch<TA, TB, 1, Cfg<4, 2, 64>, TRA, TRB>(ARGS);
     } else {
@@ -509,7 +510,7 @@ extern "C" int pika_gemm_nt_ws(const pika_operand_t *A, const pika_operand_t *B,
     if (batch > 65535) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (batch == 1 && !c_z_outer && !c_z_inner) {   // bf16 x bf16: direct-to-LDS ping-pong kernel (gemm_glds.hip)
-        static const bool off = getenv("PIKA_GEMM_NO_PP") != nullptr;
+        static const bool off = pika_knob("PIKA_GEMM_NO_PP") != nullptr;
         const int rc = off ? -100 : pika_internal_gemm_pp(A, B, C, ldc, M, N, K, bias, flags, workspace, workspace_bytes, s);
         if (rc != -100) return rc;
     }

@@ -1018,13 +1018,13 @@ int launch_pp_epi(const PPArgs &P, hipStream_t s) {
     if (nt > 0x7fffffffLL - 65536) return PIKA_ETOOBIG;
     PPArgs Q = P;
     Q.nx = (P.N + 255) / 256; Q.ntiles = (int)nt;
-    static const int gm_env = [] { const char *e = getenv("PIKA_GEMM_PP_GM"); return e ? atoi(e) : 0; }();
+    static const int gm_env = [] { const char *e = pika_knob("PIKA_GEMM_PP_GM"); return e ? atoi(e) : 0; }();
     Q.gm = gm_env > 0 ? gm_env : PP_GM;
     Q.salt = pika_internal_dropout_salt();
     // persistent: one workgroup per CU (128 KB of LDS each) walks its share of the output tiles.
     // PIKA_GEMM_PP_WGS=0 launches one workgroup per tile instead (for A/B timing).
     static const int wgs = [] {
-        const char *e = getenv("PIKA_GEMM_PP_WGS");
+        const char *e = pika_knob("PIKA_GEMM_PP_WGS");
         if (e) return atoi(e);
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1135,7 +1135,7 @@ int launch_pp_tn(const pika_operand_t *A, const pika_operand_t *B, float *C, lon
         const long long cost = (long long)((tiles * sp + 255) / 256) * ((nk + sp - 1) / sp + 40) + per_split * sp;
         if (best < 0 || cost < best) { best = cost; split = sp; }
     }
-    static const int forced = [] { const char *e = getenv("PIKA_GEMM_TN_SPLIT"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char *e = pika_knob("PIKA_GEMM_TN_SPLIT"); return e ? atoi(e) : 0; }();
     if (forced > 0) {
         split = forced < nk ? forced : nk;
         if (have_ws) while (split > 1 && (size_t)split * slice > ws_bytes) --split;

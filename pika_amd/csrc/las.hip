@@ -46,7 +46,6 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const float *__restrict_
     if (h_out2) *reinterpret_cast<f32x4 *>(h_out2 + (long long)n * ldh2 + c) = h;
 }
 
-constexpr int GQ = 4;         // queries per workgroup (1 when the launch has few queries: a group's queries are walked in turn)
 constexpr int KQ = 4;         // float4 slots per lane: D <= 64 * 4 * KQ = 1024
 
 __device__ inline float wave_sum(float v) {
@@ -70,161 +69,8 @@ __device__ inline float block_reduce(float v, bool is_max, float *red) {
     return v;
 }
 
-// Workgroup = 8 waves = G consecutive entries of the query list; wave w walks the source positions w, w+8, ... ONCE
-// (two waves per SIMD: one computes while the other waits for its rows): a lane holds
-// 4*KQ channels of W_q h_t (every query), of v and of the running context sums; per position one load of the
-// utterance's U_a h_s row and one of its h_s row serve every query of the group that belongs to the utterance.  The
-// softmax is online (running maximum m, running sum l, context sums rescaled when m moves), so the scores never leave
-// the registers; the eight waves' partial (m, l, sums) are merged through LDS at the end.
-constexpr int AW = 8;         // waves per workgroup
-#ifndef PIKA_LAS_ATT_G1_MAX
-#define PIKA_LAS_ATT_G1_MAX 1024   // launches sized for up to this many queries take one query per workgroup
-#endif
-template <int G>
-__global__ __launch_bounds__(64 * AW) void las_mlp_attention_kernel(const float *__restrict__ wq, long long ldq,
-                                                                const float *__restrict__ proj,
-                                                                const float *__restrict__ context,
-                                                                const int *__restrict__ owner,
-                                                                const int *__restrict__ lens,
-                                                                const int *__restrict__ qidx,
-                                                                const float *__restrict__ v,
-                                                                float *__restrict__ ctx_out, long long ldo,
-                                                                float *__restrict__ align_out, int N, int S, int D,
-                                                                const int *__restrict__ n_dev,
-                                                                const int *__restrict__ qoff_dev) {
-    __shared__ float wm[AW][G], wl[AW][G];
-    if (n_dev) N = min(N, *n_dev);       // queries in use this step
-    if (qoff_dev && qidx) qidx += *qoff_dev;   // ... and where their list starts
-    if ((int)blockIdx.x * G >= N) return;
-    __shared__ f32x4 wacc[AW][64 * KQ];         // one query's partial sums of the eight waves (32 KB)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, D4 = D >> 2;
-    const int i0 = blockIdx.x * G;
-    int nq[G], b[G], len[G];
-    int smax = 0;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const bool ok = i0 + g < N;
-        nq[g] = ok ? (qidx ? qidx[i0 + g] : i0 + g) : 0;        // the query (row of wq / ctx_out / owner) of entry i0+g
-        b[g] = ok ? owner[nq[g]] : -1;
-        len[g] = ok ? min(lens[b[g]], S) : 0;
-        smax = max(smax, len[g]);
-    }
-    // sum_d v_d tanh(z_d) = sum_d v_d - 2 sum_d v_d / (e^{2 z_d} + 1): per element ONE fma (z scaled for exp2), one
-    // exp2, one add, one reciprocal and one fma -- the kernel is bound by VALU / transcendental issue
-    constexpr float C2 = 2.8853900817779268f;      // 2 * log2(e)
-    f32x4 q[G][KQ], vv[KQ], acc[G][KQ];
-    float m[G], l[G];
-    float vsum = 0.f;
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-        const int j = lane + 64 * k;
-        const f32x4 v4 = j < D4 ? reinterpret_cast<const f32x4 *>(v)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-        vsum += (v4.x + v4.y) + (v4.z + v4.w);
-        vv[k] = v4 * -2.0f;                         // zero past D: those lanes contribute nothing
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            q[g][k] = (j < D4 && b[g] >= 0) ? reinterpret_cast<const f32x4 *>(wq + (long long)nq[g] * ldq)[j] * C2
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    vsum = wave_sum(vsum);
-#pragma unroll
-    for (int g = 0; g < G; ++g) { m[g] = -INFINITY; l[g] = 0.f; }
-    // the common case -- every query of the group belongs to one utterance -- without the per-query reload test
-    // (its register copies were a sixth of the loop)
-    bool uni = true;
-#pragma unroll
-    for (int g = 1; g < G; ++g) uni = uni && (b[g] < 0 || b[g] == b[0]);
-    auto walk = [&](auto uniform_tag) {
-        constexpr bool UNI = decltype(uniform_tag)::value;
-        for (int s = wave; s < smax; s += AW) {
-            f32x4 p[KQ], x[KQ];
-            int loaded = -1;
-            if constexpr (UNI) {
-                const long long off = ((long long)b[0] * S + s) * D;
-                const f32x4 *prow = reinterpret_cast<const f32x4 *>(proj + off);
-                const f32x4 *crow = reinterpret_cast<const f32x4 *>(context + off);
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) {
-                    const int j = lane + 64 * k;
-                    p[k] = j < D4 ? prow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    x[k] = j < D4 ? crow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (s >= len[g]) continue;                           // wave-uniform
-                if constexpr (!UNI) {
-                    if (b[g] != loaded) {
-                        const long long off = ((long long)b[g] * S + s) * D;
-                        const f32x4 *prow = reinterpret_cast<const f32x4 *>(proj + off);
-                        const f32x4 *crow = reinterpret_cast<const f32x4 *>(context + off);
-#pragma unroll
-                        for (int k = 0; k < KQ; ++k) {
-                            const int j = lane + 64 * k;
-                            p[k] = j < D4 ? prow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-                            x[k] = j < D4 ? crow[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                        loaded = b[g];
-                    }
-                }
-                float part = 0.f;
-#pragma unroll
-                for (int k = 0; k < KQ; ++k)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float ex = __builtin_amdgcn_exp2f(__builtin_fmaf(p[k][e], C2, q[g][k][e]));   // e^{2z}
-                        part = __builtin_fmaf(vv[k][e], rcp(ex + 1.0f), part);         // inf -> 0, 0 -> -2 v
-                    }
-                const float sc = vsum + wave_sum(part);
-                if (align_out && lane == 0) align_out[(long long)nq[g] * S + s] = sc;  // raw, normalised below
-                const float mn = fmaxf(m[g], sc);
-                const float alpha = __expf(m[g] - mn), w = __expf(sc - mn);            // exp(-inf) = 0
-                m[g] = mn;
-                l[g] = l[g] * alpha + w;
-#pragma unroll
-                for (int k = 0; k < KQ; ++k) acc[g][k] = acc[g][k] * alpha + w * x[k];
-            }
-        }
-    };
-    if (uni) walk(std::true_type{}); else walk(std::false_type{});
-    // ---- merge the eight waves' partials ----
-    if (lane == 0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) { wm[wave][g] = m[g]; wl[wave][g] = l[g]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (len[g] == 0) continue;                               // block-uniform
-        float M = wm[0][g];                                       // finite: len >= 1
-#pragma unroll
-        for (int w2 = 1; w2 < AW; ++w2) M = fmaxf(M, wm[w2][g]);
-        float L = 0.f;
-#pragma unroll
-        for (int w2 = 0; w2 < AW; ++w2) L += wl[w2][g] * __expf(wm[w2][g] - M);
-        const float mine = __expf(m[g] - M);
-#pragma unroll
-        for (int k = 0; k < KQ; ++k) wacc[wave][lane + 64 * k] = acc[g][k] * mine;
-        __syncthreads();
-        const int j = threadIdx.x;
-        if (j < D4) {
-            f32x4 t = wacc[0][j];
-#pragma unroll
-            for (int w2 = 1; w2 < AW; ++w2) t += wacc[w2][j];
-            reinterpret_cast<f32x4 *>(ctx_out + (long long)nq[g] * ldo)[j] = t * (1.0f / L);
-        }
-        if (align_out) {   // tests: the weights themselves.  The raw scores were written by this workgroup's lanes
-            float *row = align_out + (long long)nq[g] * S;        // before the barriers above
-            for (int s = threadIdx.x; s < S; s += 64 * AW) row[s] = s < len[g] ? __expf(row[s] - M) / L : 0.f;
-        }
-        __syncthreads();                                         // wacc is reused by the next query
-    }
-}
-
-// ---- the same attention, utterance by utterance -----------------------------------------------------------------
-// las_mlp_attention_kernel<1> reads an utterance's U_a h_s and h_s rows once per QUERY: 1.9 MB per workgroup at S = 240,
+// ---- the "mlp" attention, utterance by utterance --------------------------------------------------------------
+// One query per workgroup (rounds 3-4) reads an utterance's U_a h_s and h_s rows once per QUERY: 1.9 MB per workgroup at S = 240,
 // D = 1024, and a CU pulls bytes from beyond its L1 at ~50 GB/s -- 111 us for the ~470 queries of an average step of a
 // rescoring pass, three times what its exp2 / rcp need.  Here a workgroup takes ALL the queries of one utterance (the
 // query list is ordered by utterance) and a chunk of ACS positions: every row is read once per workgroup; a second launch
@@ -260,7 +106,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, D4 = D >> 2;
     float *qs = att_lds;                                       // [AQB][D]: 2 log2(e) (W_q h_t) of the block's queries
     float *sc = att_lds + (size_t)AQB * D;                     // [AQB][ACS] scores, then [ACS][AQB] weights
-    constexpr float C2 = 2.8853900817779268f;                  // 2 log2(e): see las_mlp_attention_kernel
+    constexpr float C2 = 2.8853900817779268f;                  // 2 log2(e): tanh(x) = 1 - 2 / (exp2(C2 x) + 1)
     f32x4 vv[KQ];
     float vsum = 0.f;
 #pragma unroll
@@ -528,30 +374,6 @@ int pika_lstm_cell(const float *gates, long long ldg, const float *c_prev, float
     hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), gates, ldg, c_prev, c_out, h_out, ldh, h_out2, ldh2, N, H, n_dev,
                        rowlist, rowoff_dev);
-    return (int)hipGetLastError();
-}
-
-int pika_las_mlp_attention(const float *wq, long long ldq, const float *proj, const float *context, const int *owner,
-                           const int *lens, const int *qidx, const float *v, float *ctx_out, long long ldo,
-                           float *align_out, int N, int B, int S, int D, const int *n_dev, const int *qoff_dev,
-                           void *stream) {
-    if (!wq || !proj || !context || !owner || !lens || !v || !ctx_out || N <= 0 || B <= 0 || S <= 0 || D <= 0)
-        return PIKA_EINVAL;
-    if ((D & 3) || (ldq & 3) || (ldo & 3) || ldq < D || ldo < D) return PIKA_EINVAL;
-    if (D > 64 * 4 * KQ || S > 2048) return PIKA_ETOOBIG;
-    if ((reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(proj) | reinterpret_cast<uintptr_t>(context) |
-         reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(ctx_out)) & 15)
-        return PIKA_EINVAL;
-    // few queries (a rescoring pass whose n-best entries share their prefixes): one query per workgroup -- a workgroup's
-    // time is (positions / 8 waves) x (queries of the group), and the CUs are not all busy anyway
-    if (N <= PIKA_LAS_ATT_G1_MAX)
-        hipLaunchKernelGGL(las_mlp_attention_kernel<1>, dim3((unsigned)N), dim3(64 * AW), 0,
-                           static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
-                           align_out, N, S, D, n_dev, qoff_dev);
-    else
-        hipLaunchKernelGGL(las_mlp_attention_kernel<GQ>, dim3((unsigned)((N + GQ - 1) / GQ)), dim3(64 * AW), 0,
-                           static_cast<hipStream_t>(stream), wq, ldq, proj, context, owner, lens, qidx, v, ctx_out, ldo,
-                           align_out, N, S, D, n_dev, qoff_dev);
     return (int)hipGetLastError();
 }
 

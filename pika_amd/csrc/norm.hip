@@ -10,6 +10,7 @@
 #include "pika_gemm.h"
 #include "pika_norm.h"
 #include "pika_rnnt.h"
+#include "pika_internal.h"
 
 namespace {
 
@@ -19,7 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // tools/bn_bench.py at 31808 x 1024: statistics 25 / 32 / 48 / 66 us for 512 / 256 / 128 / 64 rows, backward (two input
 // streams, longer chains) 107 / 91 / 101 / 121 us
 inline int bn_rows_per_block(int mode) {
-    static const int v = [] { const char *e = getenv("PIKA_BN_RPB"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 0; }();
+    static const int v = [] { const char *e = pika_knob("PIKA_BN_RPB"); const int x = e ? atoi(e) : 0; return x >= 16 ? x : 0; }();
     return v ? v : (mode ? 256 : 512);
 }
 
@@ -450,7 +451,7 @@ int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long 
     hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
     if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    static const int rpb_env = [] { const char *e = getenv("PIKA_LN_BWD_RPB"); return e ? atoi(e) : 0; }();   // A/B runs
+    static const int rpb_env = [] { const char *e = pika_knob("PIKA_LN_BWD_RPB"); return e ? atoi(e) : 0; }();   // A/B runs
     // rows per workgroup: every workgroup ends with 2*C column-sum atomics onto the same addresses, so few rows per
     // workgroup are bound by that contention and many by the row chain (measured at 31808 x 1024, tools/ln_bwd_bench.py:
     // 8: 483 us, 16: 299, 32: 231, 64: 197, 128: 215, 256: 286 per backward)

@@ -34,6 +34,7 @@
 #include <stdlib.h>
 
 #include "pika_rnnt.h"
+#include "pika_internal.h"
 
 namespace {
 
@@ -898,7 +899,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__
 
 extern "C" {
 
-int pika_amd_abi_version(void) { return 19; }
+int pika_amd_abi_version(void) { return 20; }
 
 size_t pika_rnnt_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024) return 0;
@@ -1012,12 +1013,12 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
     if (colsum) {
         hipError_t e = hipMemsetAsync(colsum, 0, (size_t)V * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
-        static const int rpw_env = [] { const char *e = getenv("PIKA_DLOGITS_RPW"); return e ? atoi(e) : 0; }();   // A/B
+        static const int rpw_env = [] { const char *e = pika_knob("PIKA_DLOGITS_RPW"); return e ? atoi(e) : 0; }();   // A/B
         // tools/dlogits_bench.py at the config-2 lattice: 16 rows per wave 2.43 ms, 32: 2.35, 64: 2.31, 128: 2.31, 256: 2.57;
         // the 4- and 8-column kernels tie (2.35 ms): the pass is the mixed read / write HBM stream at 5.0-5.1 TB/s
         const int rpw = rpw_env > 0 ? rpw_env : (rows >= (1 << 18) ? 64 : 4);
         const long long per_block = 4LL * rpw;
-        static const bool wide_off = getenv("PIKA_DLOGITS_NARROW") != nullptr;     // A/B: the 4-column kernel
+        static const bool wide_off = pika_knob("PIKA_DLOGITS_NARROW") != nullptr;     // A/B: the 4-column kernel
         if (!wide_off && !(V & 7) && !(ld_out & 7) && V > 512 * 9 && ld_out <= 512 * 10 &&
             !(reinterpret_cast<uintptr_t>(out) & 15)) {
             hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<10, float>), dim3((unsigned)((rows + per_block - 1) / per_block)),

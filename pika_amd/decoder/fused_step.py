@@ -70,8 +70,8 @@ def supported(model, beam, K):
     if dec is None or not beam.fused_ok():
         return False
     splits = _lib.lib().pika_dfc2_splits(model.output_dim)
-    lds = K * beam.hyp.shape[2] * 4 + K * K * 8 + 4 * splits * K * 8        # pika_beam_advance_partials
-    if splits > 64 or splits * K > 1024 or lds > 96 * 1024 or K > 64 or model.hid_dim % 4:
+    # the advance's LDS budget, as the library states it (include/pika_decode_step.h; 0 = the shape is not taken)
+    if not _lib.lib().pika_beam_advance_logits_lds(K, int(beam.hyp.shape[2]), splits) or model.hid_dim % 4:
         return False
     if model.decoder_type == "rnn":
         return (isinstance(dec, torch.nn.LSTM) and not dec.bidirectional and dec.batch_first and dec.bias

@@ -23,6 +23,17 @@ class GlobalScorer(object):
         return logprobs
 
 
+_GC_FROZEN = [False]
+
+
+def _freeze_gc_once():
+    if not _GC_FROZEN[0]:
+        import gc
+        _GC_FROZEN[0] = True
+        gc.collect()
+        gc.freeze()
+
+
 class TransducerDecoder(object):
     def __init__(self, model, batch_size, beam_size, n_best=1, blk=0, global_scorer=None,
                  sm_scale=1.0, lm=None, lm_scale=1.0, lm_scorer=None, lm_scorer_scale=1.0,
@@ -45,15 +56,15 @@ class TransducerDecoder(object):
         self.args = args
         self.t_idx = None
         self.dec_states = None
-        # capture the steady-state step in a hipGraph on the GPU (PIKA_DECODE_GRAPH=0: eager launches, for counter passes)
-        self.use_graph = __import__("os").environ.get("PIKA_DECODE_GRAPH", "1") != "0"
+        # capture the steady-state step in a hipGraph on the GPU (use_graph = False: eager launches, for counter passes)
+        self.use_graph = True
         self.fused_step = True   # fused HIP advance kernel on the GPU (include/pika_decode.h)
         self.incremental = True  # transformer prediction net: one new position per step (cached)
         # GPU, transformer prediction net: the whole step as a fixed launch chain (fused_step.py), replayed
         # `replays_per_sync` x 2 steps per host read of the stop flag.  decode_terms: bf16 terms per GEMM operand
         # (3 = fp32-exact products; 2 = hi.hi + hi.lo + lo.hi, an fp32 product to ~2^-17; 1 = plain bf16 operands)
         import os
-        self.fused_search = os.environ.get("PIKA_DECODE_FUSED_SEARCH", "1") != "0"
+        self.fused_search = True        # (False: the stepwise search of the tiny / CPU path on the device)
         # decode_precision "fp32" (default): fp32-grade products everywhere, on two FP16 terms per operand (22 mantissa bits:
         # an fp32 product to ~2^-22 with three MFMA products instead of the six of the exact three-term bf16 split).
         # The step products (prediction network, joint, fc2: 340 steps per batch): include/pika_decode_step.h, terms = 4
@@ -111,6 +122,14 @@ class TransducerDecoder(object):
         last = out.gather(1, ln.view(-1, 1, 1).expand(-1, 1, out.shape[2])).squeeze(1)
         state[0].copy_(torch.where(nonblk.unsqueeze(1), last, state[0]))
 
+    # A decode process holds ~1e6 live Python objects (the models' modules and parameters, FST / trie tables, the n-best
+    # lists of 0-dim tensors the scripts index); every FULL collection of the interpreter's garbage collector walks them
+    # all: a 45 ms stall every fourth batch of decode_transducer.py at B = 64 (profiles/r5_las_pass_overlap.txt).  After the
+    # second batch -- models built, tables and caches warm -- the decoder moves what is alive into the collector's permanent
+    # generation once per process (gc.freeze()); collections keep running over everything made afterwards.
+    # `TransducerDecoder.freeze_gc = False` (class or instance) leaves the collector alone.
+    freeze_gc = True
+
     # ---- the search ---------------------------------------------------------------------------
     @torch.no_grad()
     def decode_batch(self, x, x_len, max_len=None):
@@ -130,6 +149,9 @@ class TransducerDecoder(object):
             G.PRECISION = old
         # what las_rescore / bilas_rescore will be asked about next (batch-ahead scoring, below)
         self._nbest = {"enc_out": enc_out, "hyps": ret["predictions"], "scores": {}}
+        self._batches = getattr(self, "_batches", 0) + 1
+        if self._batches == 2 and x.is_cuda and self.freeze_gc:
+            _freeze_gc_once()
         return ret, enc_out
 
     def _decode_batch(self, x, x_len, max_len=None):
@@ -350,12 +372,12 @@ def _batch_ahead(self, which, rescorer, x, tgt, scale):
             return [[h[::-1] for h in row_] for row_ in lists] if which_ == "bw" else lists
         # The script asks the forward and the backward rescorer about the same batch one after the other
         # (decode_transducer.py:136-156, same SOS / EOS): both passes are run at the first request
-        # (las.score_nbest_batch_many; PIKA_LAS_PAIR=0: each at its own first request)
+        # (las.score_nbest_batch_many; self.las_pair = False: each at its own first request)
         jobs = [(which, rescorer)]
         other = {"fw": "bw", "bw": "fw"}.get(which)
         r2 = {"fw": getattr(self, "las_rescorer", None), "bw": getattr(self, "las_rescorer_bw", None)}.get(other)
         if (r2 is not None and hasattr(r2, "score_nbest_batch") and (other, sos, eos) not in nb["scores"]
-                and os.environ.get("PIKA_LAS_PAIR", "1") != "0"):
+                and getattr(self, "las_pair", True)):
             jobs.append((other, r2))
         lists = [lists_of(w) for w, _ in jobs]
         src = enc.transpose(0, 1)

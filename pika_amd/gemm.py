@@ -36,8 +36,8 @@ PRECISIONS = ("bf16", "bf16x3", "fp32", "mixed", "fp16x2")
 # "bf16x3": the joint's lattice products (fc2 over the (B,T,U) lattice and its two gradient products: half of a training
 # step's FLOPs, on a hidden the gate kernel writes once) stay in the config-2 bf16 arithmetic by default -- the
 # encoder, the prediction network and the joint's projections are what the parity statement (encoder activations,
-# loss) rests on, and the loss moves by ~1e-5 (profiles/r2_precision_table.md).  PIKA_X3_JOINT=x3: two terms there too.
-X3_JOINT_BF16 = os.environ.get("PIKA_X3_JOINT", "bf16") != "x3"
+# loss) rests on, and the loss moves by ~1e-5 (profiles/r2_precision_table.md).  X3_JOINT_BF16 = False: two terms there too.
+X3_JOINT_BF16 = True
 
 
 def joint_in_bf16():
@@ -108,9 +108,9 @@ def _flags(relu, accumulate, precision):
 OUT_BF16 = 8
 F16_OPERANDS = 16
 TERM_PRODUCT = 32
-# "fp32" products of direct-to-LDS size as ONE bf16 product over six term segments (PIKA_FP32_CONCAT=0: always the
+# "fp32" products of direct-to-LDS size as ONE bf16 product over six term segments (FP32_CONCAT = False: always the
 # register-staged exact kernel)
-FP32_CONCAT = os.environ.get("PIKA_FP32_CONCAT", "1") != "0"
+FP32_CONCAT = True
 FP32_CONCAT_MAX_BYTES = 4 << 30     # per operand copy: 6 segments x 2 bytes x rows x reduction
 
 

@@ -20,6 +20,13 @@ from .. import _lib
 from .. import gemm as G
 
 
+# Module switches (tests flip them; no environment variable): the joint's log-sum-exp partials from the fc2 epilogue, the
+# 16-bit logits lattice on top of them, the fused two-term attention of the inference modes.
+JOINT_LSE_EPILOGUE = True
+JOINT_F16_LOGITS = True
+INFER_ATTN = True
+
+
 def _fused():
     """PIKA_NO_FUSED=1 (diagnostics, tools/mode_diff.py) turns the bf16 fast paths off: every product then goes
     through pika_gemm_nt on fp32 tensors (operands rounded inside the kernel) and torch's attention chain."""
@@ -503,7 +510,7 @@ class JointOutFn(torch.autograd.Function):
         # followed by a second, fp32 run of the product for the loss -- ADVICE r4)
         if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and 256 < N <= 5120 and N % 8 == 0
                 and labels.dim() == 2 and labels.shape == (h.shape[0], h.shape[2] - 1)
-                and os.environ.get("PIKA_JOINT_LSE_EPILOGUE", "1") != "0" and os.environ.get("PIKA_JOINT_F16_LOGITS", "1") != "0"):
+                and JOINT_LSE_EPILOGUE and JOINT_F16_LOGITS):
             # 16-bit logits: the (B,T,U1,V) lattice -- the largest tensor of a training step -- is written ONCE as fp16
             # and read once (by the d(logits) pass of the backward); everything the LOSS reads leaves the product's
             # epilogue in fp32: the row log-sum-exp partials and the logits of the blank and of the row's label, so costs
@@ -547,7 +554,7 @@ class JointOutFn(torch.autograd.Function):
             from ..rnnt import LazyLogProbs, LogitsState
             ctx.state = LogitsState(scale)
             M = h2.shape[0]
-            if scale == 1.0 and N > 256 and os.environ.get("PIKA_JOINT_LSE_EPILOGUE", "1") != "0":
+            if scale == 1.0 and N > 256 and JOINT_LSE_EPILOGUE:
                 n_part = (N + 255) // 256 * 4
                 part = torch.empty((2, M, n_part), dtype=torch.float32, device=h.device)
                 wb = weight.detach().to(torch.bfloat16)
@@ -720,13 +727,13 @@ def attention_infer_ok(q, k, v, heads, mask):
     """Inference (no autograd) in one of the two-term arithmetic modes -- the decoder's encoder pass
     (decoder/transducer_decoder.py: "fp16x2" by default, "bf16x3" on request; the exact mode "fp32" keeps the exact torch
     chain): the fused two-term attention takes the fp32 projections, so no decode mode materialises the (B,H,T,T) scores
-    or touches hipBLASLt.  PIKA_INFER_ATTN=0 keeps the torch chain everywhere."""
+    or touches hipBLASLt.  INFER_ATTN = False keeps the torch chain everywhere."""
     D = q.shape[-1] // heads
     if mask is not None and (mask.dim() != 3 or mask.shape[1] != q.shape[1] or mask.shape[2] != k.shape[1]):
         return False
     return (not torch.is_grad_enabled() and G.PRECISION in ("fp16x2", "bf16x3") and _fused() and q.is_cuda
             and q.dtype == torch.float32 and q.dim() == 3 and q.shape == k.shape == v.shape and D in (64, 128)
-            and D * heads == q.shape[-1] and os.environ.get("PIKA_INFER_ATTN", "1") != "0")
+            and D * heads == q.shape[-1] and INFER_ATTN)
 
 
 def attention_infer_two_term(q, k, v, heads, mask=None):

@@ -47,8 +47,8 @@ def _h2d_many(arrays, dev):
 
 
 def _phase_timer(net, dev):
-    """PIKA_LAS_TIMING=1: wall time of the phases of a scoring pass (device-synchronised) into net.phase_times."""
-    if os.environ.get("PIKA_LAS_TIMING") != "1" or dev.type != "cuda":
+    """net.want_phase_times = True: wall time of the phases of a scoring pass (device-synchronised) into net.phase_times."""
+    if not getattr(net, "want_phase_times", False) or dev.type != "cuda":
         return lambda name: None
     import time
     torch.cuda.synchronize(dev)
@@ -564,9 +564,9 @@ class InputFeedRNNDecoder(nn.Module):
             # weights packed once per pass into MFMA fragment order (pika_dpack_weight): 1 bf16 term per operand in the
             # bf16 arithmetic mode; otherwise two fp16 terms (terms = 4: 22 mantissa bits per operand, an fp32 product to
             # ~2^-22 with three MFMAs -- the decoder's activations are bounded, far inside fp16's range);
-            # PIKA_LAS_TERMS=3: three bf16 terms, exact fp32 products, six MFMAs
+            # self.fused_terms = 3: three bf16 terms, exact fp32 products, six MFMAs
             from ..decoder.fused_step import DGemm, PackedWeight
-            terms = 1 if G.PRECISION == "bf16" else int(os.environ.get("PIKA_LAS_TERMS", "4"))
+            terms = 1 if G.PRECISION == "bf16" else int(getattr(self, "fused_terms", 4))
             # (packed once per set of weights: the pack is four kernels over ~90 MB, the weights of a scoring model do not change)
             srcs = [w for c in self.rnn.layers for w in (c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh)] + \
                    [att.linear_query.weight, att.linear_query.bias, att.linear_out.weight, att.linear_out.bias]
@@ -598,10 +598,9 @@ class InputFeedRNNDecoder(nn.Module):
             n_act = hl["n_act"]
             up = uploaded if uploaded is not None else _h2d_many(self.loop_arrays(hl, forks), dev)
             qlist, uoff_d, n_act_d, qoff_d, step = up["qlist"], up["uoff"], up["n_act"], up["qoff"], up["step"]
-            # the attention runs utterance by utterance (pika_las_mlp_attention_by_utterance; PIKA_LAS_ATT=query: per query)
-            by_utt = os.environ.get("PIKA_LAS_ATT", "utterance") != "query" and N > 0
-            if by_utt:
-                att_work = torch.empty(int(lib.pika_las_attention_work_floats(max(int(n_act.max()), 1), S, H)), device=dev)
+            # the attention runs utterance by utterance (pika_las_mlp_attention_by_utterance)
+            att_work = torch.empty(int(lib.pika_las_attention_work_floats(max(int(n_act.max()) if N > 0 else 1, 1), S, H)),
+                                   device=dev)
             n_dev = step[1:2]
             crow = torch.zeros(N, dtype=torch.long, device=dev)
             iden = torch.arange(N, dtype=torch.long, device=dev)
@@ -655,22 +654,16 @@ class InputFeedRNNDecoder(nn.Module):
                                                   nxt.stride(0), n_max, H, n_dev.data_ptr(), qlist.data_ptr(),
                                                   step[2:3].data_ptr(), st), "pika_lstm_cell")
                 dgemm(CQ[:, H:], 2 * H, Wq, bq, wq, H)
-                if by_utt:
-                    _lib.check(lib.pika_las_mlp_attention_by_utterance(
-                        wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(), ln.data_ptr(), qlist.data_ptr(),
-                        uoff_d.data_ptr(), v.data_ptr(), CQ.data_ptr(), 2 * H, att_work.data_ptr(), n_max, B, S, H,
-                        n_dev.data_ptr(), step[2:3].data_ptr(), step[0:1].data_ptr(), st),
-                        "pika_las_mlp_attention_by_utterance")
-                else:
-                    _lib.check(lib.pika_las_mlp_attention(wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(),
-                                                          ln.data_ptr(), qlist.data_ptr(), v.data_ptr(), CQ.data_ptr(),
-                                                          2 * H, None, n_max, B, S, H, n_dev.data_ptr(),
-                                                          step[2:3].data_ptr(), st), "pika_las_mlp_attention")
+                _lib.check(lib.pika_las_mlp_attention_by_utterance(
+                    wq.data_ptr(), H, proj.data_ptr(), ctx.data_ptr(), own.data_ptr(), ln.data_ptr(), qlist.data_ptr(),
+                    uoff_d.data_ptr(), v.data_ptr(), CQ.data_ptr(), 2 * H, att_work.data_ptr(), n_max, B, S, H,
+                    n_dev.data_ptr(), step[2:3].data_ptr(), step[0:1].data_ptr(), st),
+                    "pika_las_mlp_attention_by_utterance")
                 # output projection of [context | h_t]: into row (t, r) of the result AND into the feed block of the
                 # layer-0 input rows (input feeding, las.py:649-668)
                 dgemm(CQ, 2 * H, Wo, bo, outs.view(L * N, H), H, crow_=crow, C2=X[0][:, E:], ldc2=X[0].stride(0))
 
-        return TokenLoop(token_step, L, outs, dev, sig=(str(dev), n_max > 256, terms, H, E, nl, by_utt, fork is not None))
+        return TokenLoop(token_step, L, outs, dev, sig=(str(dev), n_max > 256, terms, H, E, nl, fork is not None))
 
     def _run_fused(self, tokens, context, enc_hidden, owner, lens, spans=None, forks=None, owner_host=None):
         loop = self._prepare_fused(tokens, context, enc_hidden, owner, lens, spans, forks, owner_host)

@@ -35,11 +35,14 @@ What cannot be served raises instead of computing something else: a backward tha
 log-probs that were READ between forward and backward (that normalises the static logits in place; set
 PIKA_TRAIN_GRAPH=0 for such a loop), a gradient that is not this package's loss gradient.
 
-Knobs (environment): PIKA_TRAIN_GRAPH=0 off; PIKA_TRAIN_GRAPH_WARMUP (2); PIKA_TRAIN_GRAPH_MAX (4 shapes kept);
-PIKA_TRAIN_GRAPH_MIN_SEEN (2: a shape is captured the second time it appears after the warm-up -- a corpus whose batch
-lengths never recur stays eager instead of capturing every step); PIKA_TRAIN_GRAPH_U_BUCKET (8: a batch rides
-on graphs whose label axis is up to 7 labels wider than its own, padded with the embedding's padding index);
-PIKA_TRAIN_GRAPH_T_BUCKET (64: ... and whose time axis is up to 63 frames longer; 0: exact frame counts only).
+Switches: PIKA_TRAIN_GRAPH=0 (environment) turns the graphs off; PIKA_TRAIN_GRAPH_DEBUG=1/2/3 prints statistics / every
+call / where a non-finite value first appears.  Everything else is an argument of `enable()` or an entry of DEFAULTS
+(module dictionary; what `pika_amd.launch` leaves untouched): warmup (2 eager calls first), max_graphs (4 shapes kept),
+min_seen (2: a shape is captured the second time it appears after the warm-up -- a corpus whose batch lengths never recur
+stays eager instead of capturing every step), u_bucket (8: a batch rides on graphs whose label axis is up to 7 labels wider
+than its own, padded with the embedding's padding index), t_bucket (64: ... and whose time axis is up to 63 frames longer;
+0: exact frame counts only), freeze_salt (False; tests: keep the dropout salt word as it is), debug_sync (0; bit mask of
+host syncs around the replays: 1 before F, 2 after F, 4 before B, 8 after B -- profiles/r4_hip_graph_packet_capture.txt).
 """
 import collections
 import os
@@ -50,6 +53,7 @@ import torch
 from . import _lib
 
 _SALT = {"word": None, "users": 0}
+DEFAULTS = {"warmup": 2, "max_graphs": 4, "min_seen": 2, "u_bucket": 8, "t_bucket": 64, "freeze_salt": False, "debug_sync": 0}
 
 
 def _salt_word(device):
@@ -88,13 +92,13 @@ class StepGraphs(object):
     """Per-model state of the graphed step (hangs off the module as `_step_graphs`; not pickled)."""
 
     def __init__(self, model, warmup=None, max_graphs=None, min_seen=None, t_bucket=None):
-        env = os.environ.get
-        self.warmup = int(env("PIKA_TRAIN_GRAPH_WARMUP", "2")) if warmup is None else int(warmup)
-        self.max_graphs = max(1, int(env("PIKA_TRAIN_GRAPH_MAX", "4")) if max_graphs is None else int(max_graphs))
-        self.min_seen = max(1, int(env("PIKA_TRAIN_GRAPH_MIN_SEEN", "2")) if min_seen is None else int(min_seen))
-        self.u_bucket = max(1, int(env("PIKA_TRAIN_GRAPH_U_BUCKET", "8")))
+        D = DEFAULTS
+        self.warmup = int(D["warmup"]) if warmup is None else int(warmup)
+        self.max_graphs = max(1, int(D["max_graphs"]) if max_graphs is None else int(max_graphs))
+        self.min_seen = max(1, int(D["min_seen"]) if min_seen is None else int(min_seen))
+        self.u_bucket = max(1, int(D["u_bucket"]))
         # time axis: a batch of T frames rides on graphs captured for up to t_bucket - 1 more frames (0: exact T only)
-        self.t_bucket = max(0, int(env("PIKA_TRAIN_GRAPH_T_BUCKET", "64")) if t_bucket is None else int(t_bucket))
+        self.t_bucket = max(0, int(D["t_bucket"]) if t_bucket is None else int(t_bucket))
         self.entries = collections.OrderedDict()        # key -> _Entry, least recently used first
         self.seen = {}
         self.calls = 0
@@ -103,7 +107,7 @@ class StepGraphs(object):
         self.params = None
         self.broken = None                              # reason the model's forward cannot be captured
         self.last = None                                # (entry, generation) of the latest graphed forward
-        self.freeze_salt = env("PIKA_TRAIN_GRAPH_FREEZE_SALT", "0") == "1"   # tests / debugging: keep the salt word as it is
+        self.freeze_salt = bool(D["freeze_salt"])        # tests / debugging: keep the salt word as it is
         self.stats = {"replays": 0, "captures": 0, "eager": 0, "evictions": 0}
         import weakref
         self.model_ref = weakref.ref(model)
@@ -305,7 +309,7 @@ class _GraphedFn(torch.autograd.Function):
         # a p.grad that IS the static tensor (the caller did not zero its gradients, or backs through a retained graph
         # twice) holds the earlier values the replay is about to overwrite: accumulate as autograd would
         kept = {id(gr): gr.clone() for p, gr in e.grads if p.grad is gr}
-        dbg_sync = int(os.environ.get("PIKA_TRAIN_GRAPH_SYNC", "0"))
+        dbg_sync = int(DEFAULTS["debug_sync"])
         if dbg_sync & 4:
             torch.cuda.synchronize()
         e.gb.replay()
@@ -411,7 +415,7 @@ def forward(model, x, y, x_len, softmax):
         print("train_graph call %d: replay of %s for labels %s" % (st.calls, key[0:3:2], tuple(y.shape)), flush=True)
     e.gen += 1
     st.last = (e, e.gen)
-    dbg_sync = int(os.environ.get("PIKA_TRAIN_GRAPH_SYNC", "0"))      # debugging: 1 before F, 2 after F, 4 before B, 8 after B
+    dbg_sync = int(DEFAULTS["debug_sync"])      # debugging: 1 before F, 2 after F, 4 before B, 8 after B
     if dbg_sync & 1:
         torch.cuda.synchronize()
     e.gf.replay()

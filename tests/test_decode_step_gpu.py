@@ -152,10 +152,10 @@ def _beam_inputs(B, K, V, L, g, dev, first):
 @pytest.mark.parametrize("V,K,Hd,first,ties", [(100, 4, 64, False, 0), (5000, 16, 128, False, 0), (333, 8, 64, True, 0),
                                                 (5000, 16, 64, False, 3), (5000, 16, 64, False, 1), (700, 8, 64, False, 40)])
 @pytest.mark.parametrize("terms", [3, 1, 4])
-def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, first, terms, ties):
-    """fc2 + partial log-sum-exp / top-K + pika_beam_advance_partials == fc2 + row statistics + scaled logits +
-    pika_beam_advance_logits (the thresholded row pass) == materialised logits -> pika_beam_advance: same parents, symbols,
-    finished lists; scores to fp32 rounding of the log-sum-exp.  ties > 0: logits take only that many distinct values
+def test_fc2_logits_advance_equals_the_materialised_logits_advance(hip_device, V, K, Hd, first, terms, ties):
+    """fc2 with row statistics + scaled logits (pika_dfc2_logits) + pika_beam_advance_logits (the thresholded row pass) ==
+    materialised logits -> pika_beam_advance: same parents, symbols, finished lists; scores to fp32 rounding of the
+    log-sum-exp.  ties > 0: logits take only that many distinct values
     (more candidates at the bound than the selection pool holds: the bound is raised / ties go by lowest column)."""
     from pika_amd.decoder.fused_step import PackedWeight
     from pika_amd import _lib
@@ -178,11 +178,6 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
     slog = torch.full((R, ldl), 7.0, device=hip_device)
     _lib.check(lib.pika_dfc2_logits(h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), R, V, Hd, terms, sm,
                                     pmax2.data_ptr(), psum2.data_ptr(), slog.data_ptr(), ldl, _st()), "pika_dfc2_logits")
-    pmax = torch.empty(R * splits, device=hip_device)
-    psum = torch.empty(R * splits, device=hip_device)
-    pcand = torch.empty(R * splits * K * 8, dtype=torch.uint8, device=hip_device)
-    _lib.check(lib.pika_dfc2_topk(h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), R, V, Hd, terms, sm, K,
-                                  pmax.data_ptr(), psum.data_ptr(), pcand.data_ptr(), _st()), "pika_dfc2_topk")
     # the logits the same arithmetic produces (terms-term operands): via a plain dgemm, then the old advance
     from pika_amd.decoder.fused_step import DGemm
     logits = torch.empty(R, V, device=hip_device)
@@ -196,10 +191,9 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
     # partial statistics
     x = (sm * logits).double()
     lse = torch.logsumexp(x, dim=1)
-    pm = pmax.view(R, splits).double()
-    got_lse = (psum.view(R, splits).double() * torch.exp(pm - pm.max(1, keepdim=True).values)).sum(1).log() + pm.max(1).values
+    pm = pmax2.view(R, splits).double()
+    got_lse = (psum2.view(R, splits).double() * torch.exp(pm - pm.max(1, keepdim=True).values)).sum(1).log() + pm.max(1).values
     assert (got_lse - lse).abs().max().item() < 1e-5
-    assert torch.equal(pmax2, pmax) and torch.allclose(psum2, psum, rtol=2e-6, atol=0)      # (another summation order)
     # (the plain product sums its reduction in another order than the vocabulary product)
     assert torch.allclose(slog[:, :V], sm * logits, rtol=0, atol=1e-5 * float(logits.abs().max()) + (2e-2 if terms == 1 else 0))
     assert bool(torch.all(slog[:, V:] == -float("inf")))
@@ -228,24 +222,19 @@ def test_fc2_topk_partials_advance_equals_logits_advance(hip_device, V, K, Hd, f
                                                     B, K, V, blk, 1, K, stop.data_ptr(), max_hyp.data_ptr(),
                                                     sync.data_ptr(), _st()), "pika_beam_advance_logits")
             assert int(step_t) == (1 if first else 4) and int(max_hyp) == int(st["hyp_len"].max())
-        elif use_partials:
-            _lib.check(lib.pika_beam_advance_partials(pmax.data_ptr(), psum.data_ptr(), pcand.data_ptr(), splits, *common,
-                                                      B, K, V, blk, 1, K, stop.data_ptr(), max_hyp.data_ptr(),
-                                                      sync.data_ptr(), _st()), "pika_beam_advance_partials")
-            assert int(step_t) == (1 if first else 4) and int(max_hyp) == int(st["hyp_len"].max())
         else:
             cand = torch.empty(B * K * K * 8, dtype=torch.uint8, device=hip_device)
             _lib.check(lib.pika_beam_advance(logits.data_ptr(), sm, int(first), *common, cand.data_ptr(), B, K, V, blk, 1,
                                              _st()), "pika_beam_advance")
         torch.cuda.synchronize()
         return dict(st, prev_k=prev_k, y_raw=y_raw, fin_n=fin_n, fin_score=fin_score, fin_k=fin_k, fin_step=fin_step)
-    a, b, c = run(True), run(False), run(2)
+    b, c = run(False), run(2)
     for k in ("prev_k", "y_raw", "y", "t_idx", "hyp", "hyp_len", "fin_n", "fin_k", "fin_step", "eos"):
-        assert torch.equal(a[k], b[k]), k
         assert torch.equal(c[k], b[k]), k
-    assert torch.allclose(a["scores"], b["scores"], rtol=0, atol=2e-5)
-    assert torch.allclose(a["fin_score"], b["fin_score"], rtol=0, atol=2e-5)
-    assert torch.allclose(c["scores"], a["scores"], rtol=0, atol=2e-6) and torch.allclose(c["fin_score"], a["fin_score"], rtol=0, atol=2e-6)
+    assert torch.allclose(c["scores"], b["scores"], rtol=0, atol=2e-5)
+    assert torch.allclose(c["fin_score"], b["fin_score"], rtol=0, atol=2e-5)
+    # the library's own statement of the launch's LDS need (what fused_step.supported() asks)
+    assert lib.pika_beam_advance_logits_lds(K, L, splits) > 0 and lib.pika_beam_advance_logits_lds(65, L, splits) == 0
 
 
 @pytest.mark.parametrize("pred_net", ["transformer", "rnn"])

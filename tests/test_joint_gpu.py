@@ -269,6 +269,7 @@ def test_log_sum_exp_from_the_output_gemm_epilogue(hip_device, monkeypatch, V):
     loss merges them (pika_gemm_bf16_nt_lse -> pika_rnnt_fused_forward_partials) instead of re-reading the lattice of
     logits: same costs and parameter gradients as the path that reads the logits for the log-sum-exp."""
     from pika_amd import gemm as G
+    from pika_amd.model import hipops as hipops_mod
     from pika_amd.model.hipops import JointOutFn
     from pika_amd.rnnt import RNNTLoss, LazyLogProbs
     old, G.PRECISION = G.PRECISION, "bf16"
@@ -283,7 +284,7 @@ def test_log_sum_exp_from_the_output_gemm_epilogue(hip_device, monkeypatch, V):
         ul = torch.tensor([U, U - 1, U - 4], dtype=torch.int32, device=hip_device)
 
         def run(epi):
-            monkeypatch.setenv("PIKA_JOINT_LSE_EPILOGUE", "1" if epi else "0")
+            monkeypatch.setattr(hipops_mod, "JOINT_LSE_EPILOGUE", bool(epi))
             hh, ww, bb = (t.clone().requires_grad_(True) for t in (h, w, b))
             lp = JointOutFn.apply(hh, ww, bb, 1.0, True)
             lp._pika_lazy_grad_ok = True

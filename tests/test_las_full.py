@@ -65,7 +65,7 @@ def test_gpu_full_width_las_scores_match_reference_in_the_benchmarked_arithmetic
         # everything the benchmarked pass runs was on this path:
         assert net.encoder._status is not None, "the persistent BLSTM kernel did not take the encoder pass"
         assert net.last_pass["shared"] and net.last_pass["row_steps"] < net.last_pass["pairs"], net.last_pass
-        assert os.environ.get("PIKA_LAS_TERMS", "4") == "4" and os.environ.get("PIKA_LAS_GRAPH", "1") != "0"
+        assert getattr(net.decoder, "fused_terms", 4) == 4 and os.environ.get("PIKA_LAS_GRAPH", "1") != "0"
         out[key] = worst(got, z, key, hyps)
     print("full-width LAS rescoring, default arithmetic: max |log-prob - reference| fw %.2e, bw %.2e "
           "(row steps %d of %d pairs)" % (out["fw"], out["bw"], fw.last_pass["row_steps"], fw.last_pass["pairs"]))

@@ -43,7 +43,7 @@ def test_lstm_cell(hip_device, N, H):
                                         (2, 300, 100, [7, 9]),
                                         (5, 40, 64, [300, 301, 299, 150, 3])])     # > 1024 queries: four per workgroup
 def test_mlp_attention(hip_device, B, S, D, nper):
-    """Queries of several utterances (groups of 4 straddle utterance boundaries), ragged source lengths."""
+    """Queries of several utterances, ragged source lengths, against the formula in float64 (las.py:GlobalAttention "mlp")."""
     from pika_amd import _lib
     g = torch.Generator().manual_seed(B * 100 + S + D)
     owner = torch.tensor([b for b in range(B) for _ in range(nper[b])], dtype=torch.int32)
@@ -58,30 +58,6 @@ def test_mlp_attention(hip_device, B, S, D, nper):
     a_ref = torch.softmax(align.masked_fill(~mask, float("-inf")), -1)
     c_ref = torch.bmm(a_ref.unsqueeze(1), ctx.double()[owner.long()]).squeeze(1)
     dev = [t.to(hip_device) for t in (wq, proj, ctx, owner, lens, v)]
-    out = torch.full((N, 2 * D), -7.0, device=hip_device)
-    a_out = torch.full((N, S), -7.0, device=hip_device)
-    with torch.cuda.device(hip_device):
-        _lib.check(_lib.lib().pika_las_mlp_attention(dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(),
-                                                     dev[3].data_ptr(), dev[4].data_ptr(), None, dev[5].data_ptr(),
-                                                     out.data_ptr(), 2 * D, a_out.data_ptr(), N, B, S, D, None, None,
-                                                     torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention")
-    assert (a_out.double().cpu() - a_ref).abs().max() < 2e-6
-    assert (out[:, :D].double().cpu() - c_ref).abs().max() < 1e-5
-    assert bool((out[:, D:] == -7.0).all())
-    # a query list: a shuffled subset of the queries; only those rows are written
-    pick = torch.randperm(N, generator=g)[:max(1, N - 2)].to(torch.int32)
-    out2 = torch.full((N, D), -7.0, device=hip_device)
-    with torch.cuda.device(hip_device):
-        qd = pick.to(hip_device)
-        _lib.check(_lib.lib().pika_las_mlp_attention(dev[0].data_ptr(), D, dev[1].data_ptr(), dev[2].data_ptr(),
-                                                     dev[3].data_ptr(), dev[4].data_ptr(), qd.data_ptr(), dev[5].data_ptr(),
-                                                     out2.data_ptr(), D, None, pick.numel(), B, S, D, None, None,
-                                                     torch.cuda.current_stream().cuda_stream), "pika_las_mlp_attention")
-    sel = pick.long()
-    assert (out2[sel].double().cpu() - c_ref[sel]).abs().max() < 1e-5
-    rest = torch.ones(N, dtype=torch.bool)
-    rest[sel] = False
-    assert bool((out2[rest] == -7.0).all())
     # utterance by utterance (pika_las_mlp_attention_by_utterance): the list ordered by utterance (a subset: utterance 0
     # loses a query, the last utterance all of them), behind an offset, with the step's table of utterance ranges
     lib = _lib.lib()

@@ -1,4 +1,4 @@
-"""Diagnostic: the full-width beam golden with the decoder's encoder attention on the exact torch chain (PIKA_INFER_ATTN=0)
+"""Diagnostic: the full-width beam golden with the decoder's encoder attention on the exact torch chain (pika_amd.model.hipops.INFER_ATTN = False)
 and on the fused fp16 two-term kernel: encoder output error, score differences, and the neighbourhood of every n-best
 entry that is not at its reference rank."""
 import os
@@ -14,12 +14,13 @@ import test_decode_full as TD  # noqa: E402
 
 z = np.load(TD.GOLD)
 for flag in ("0", "1"):
-    os.environ["PIKA_INFER_ATTN"] = flag
+    from pika_amd.model import hipops
+    hipops.INFER_ATTN = flag != "0"
     got, enc, d = TD.decode("cuda:0", "fp32")
     es = enc[:, ::7, ::37].float().cpu().numpy()
     rel = np.abs(es - z["enc_sample"]).max() / np.abs(z["enc_sample"]).max()
     B, nb = z["lens"].shape
-    print("PIKA_INFER_ATTN=%s: encoder output rel err %.2e, max |score diff| %.2e" % (
+    print("INFER_ATTN=%s: encoder output rel err %.2e, max |score diff| %.2e" % (
         flag, rel, float(np.abs(got["scores"] - z["scores"]).max())))
     for b in range(B):
         for j in range(nb):

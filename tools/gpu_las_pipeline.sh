@@ -1,7 +1,7 @@
 #!/bin/bash
 # configs[4] in full (FST-fused search + fw/bw LAS rescoring) with the rescoring phases
 cd /root/repo; mkdir -p gpurun_out
-PIKA_LAS_TIMING=1 timeout 600 python bench.py --workload decode --batch 64 --fst --las --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+timeout 600 python bench.py --workload decode --batch 64 --fst --las --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

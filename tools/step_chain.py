@@ -5,7 +5,7 @@ latency, and are left out).    python tools/step_chain.py NAME_results.db"""
 import sqlite3
 import sys
 
-STEP = ("dgemm_kernel", "dgemm_sk_kernel", "ln_fwd_kernel", "dstep_", "dfc2_topk", "beam_partials", "fst_advance", "lstm_cell")
+STEP = ("dgemm_kernel", "dgemm_sk_kernel", "ln_fwd_kernel", "dstep_", "dfc2_", "beam_partials", "fst_advance", "lstm_cell")
 con = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
 name = "name" if "name" in cols else [c for c in cols if "name" in c][0]
