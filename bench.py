@@ -1279,7 +1279,7 @@ def cpu_baseline_mbr(args, blank_bias, B=2):
                       "+ oracle C/OpenMP RNN-T loss, %.1f s" % (B, beam, T, el)}
 
 
-def leg_mbr(args, R_, with_cpu, steps=3, warmup=1):
+def leg_mbr(args, R_, with_cpu, steps=4, warmup=3):      # (warm-up: an eager step, the step that captures the graph, a replay)
     """BASELINE configs[3] / SURVEY 8d M4 in the default line: the MBR training step at B = 8 per GPU, beam 4, full config-2
     model, N-best search in the decoder's default (fp32-grade) arithmetic, training part in the package default."""
     from types import SimpleNamespace

@@ -211,6 +211,26 @@ __device__ inline bf16x8 ldsv(const unsigned char *p) { return *reinterpret_cast
 // v_permlane16_swap per dword (odd 16-lane rows of the first operand <-> even rows of the second) leaves every lane with 8
 // consecutive columns: lane group g = lane >> 4 holds columns (g >> 1) * 8.. of block j + (g & 1) -- one 16-byte store
 // per pair instead of two 8-byte ones.  x, y: the lane's packed 4 x 16 bit of blocks j and j + 1.
+// x (op) the values of lanes l ^ 16 / l ^ 32 without the LDS crossbar (__shfl_xor = ds_bpermute: a ~60-cycle round trip):
+// a permlane swap of a register with its own copy leaves {own, partner's} in the two results -- which is which depends on
+// the lane, the (commutative) combination does not.
+__device__ inline float pp_max_x16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float pp_max_x32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float pp_sum_x16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float pp_sum_x32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline u32x4 pp_pair16(u32x2 x, u32x2 y) {
@@ -520,6 +540,7 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
     [[maybe_unused]] const bool wide16 = wide && !(P.ldo16 & 7) && !(reinterpret_cast<uintptr_t>(P.out16) & 15) &&
                                          !(reinterpret_cast<uintptr_t>(P.out16_lo) & 15);
     constexpr int EB = EPI == 3 ? 1 : 2;   // 16-row blocks fetched ahead (sixteen registers either way)
+    [[maybe_unused]] int g_u = 0, g_t = 0, g_b = 0;      // EPI 4: lattice position of the lane's row (see g_lab)
 #pragma unroll
     for (int ip = 0; ip < 8; ip += EB) {
         f32x4 rv[EB][4];
@@ -552,8 +573,14 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
         [[maybe_unused]] int g_lab = -1;
         if constexpr (EPI == 4) {
             if (P.g_out) {
-                const int u = m % P.g_U1;
-                if (u < P.g_U1 - 1) g_lab = P.g_labels[(long long)(m / (P.g_U1 * P.g_T)) * (P.g_U1 - 1) + u];
+                // (b, t, u) of the lane's row: two divisions per TILE, then carried from one 16-row block to the next
+                if (i == 0) {
+                    const int bt = m / P.g_U1;
+                    g_u = m - bt * P.g_U1;
+                    g_b = bt / P.g_T;
+                    g_t = bt - g_b * P.g_T;
+                }
+                if (g_u < P.g_U1 - 1) g_lab = P.g_labels[(long long)g_b * (P.g_U1 - 1) + g_u];
             }
         }
 #pragma unroll
@@ -586,10 +613,6 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             }
             if constexpr (EPI == 4) {
                 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                if (P.g_out) {      // the lane that holds a gathered column hands its fp32 value over
-                    if ((unsigned)(P.g_blank - n) < 4u && P.g_blank < N) P.g_out[2LL * m] = v[P.g_blank - n];
-                    if ((unsigned)(g_lab - n) < 4u && g_lab < N) P.g_out[2LL * m + 1] = v[g_lab - n];
-                }
                 f32x4 c = v;        // fp16 saturates at +-65504: never an infinity in the stored logits
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c[e] = fminf(fmaxf(c[e], -65504.f), 65504.f);
@@ -642,6 +665,29 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
                 }
             }
         }
+        if constexpr (EPI == 4) {
+#ifdef PP_ABL
+            if (P.g_out && !(PP_ABL & 8)) {
+#else
+            if (P.g_out) {
+#endif
+                // the lane that holds a gathered column hands its fp32 value over: column c sits in this lane iff
+                // rel = c - (first column of the lane) is e + 16 j with e < 4, j < 4 -- one test per row block and column
+                // (not one per 16-column block), the value by two levels of selects from lv (= v after the bias)
+                const int c0 = en0 + wc * 64 + (lane >> 4) * 4;
+                auto pick = [&](int rel) {
+                    const int jj = rel >> 4, e = rel & 3;
+                    const f32x4 q = jj == 0 ? lv[0] : (jj == 1 ? lv[1] : (jj == 2 ? lv[2] : lv[3]));
+                    return e == 0 ? q.x : (e == 1 ? q.y : (e == 2 ? q.z : q.w));
+                };
+                const int rb = P.g_blank - c0, rl = g_lab - c0;
+                if (rb >= 0 && !(rb & ~51) && P.g_blank < N) P.g_out[2LL * m] = pick(rb);
+                if (rl >= 0 && !(rl & ~51) && g_lab < N) P.g_out[2LL * m + 1] = pick(rl);
+            }
+            // the next 16-row block of this lane: 16 lattice cells further
+            g_u += 16;
+            while (g_u >= P.g_U1) { g_u -= P.g_U1; if (++g_t == P.g_T) { g_t = 0; ++g_b; } }
+        }
         if constexpr (EPI == 1 || EPI == 2 || EPI == 4) {
             if (wide16) {    // (wave-uniform; every lane of the wave takes part in the swaps: rows m >= M only skip the store)
                 const int g = lane >> 4;
@@ -649,6 +695,9 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const u32x4 q = pp_pair16(pk[j], pk[j + 1]);
+#ifdef PP_ABL
+                    if ((PP_ABL & 16) && q[0] != 0x12345u) continue;      // timing build: no main stores
+#endif
                     *reinterpret_cast<u32x4 *>(orow + j * 16) = q;
                 }
                 if constexpr (EPI == 1) {
@@ -664,13 +713,17 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
             }
         }
         if constexpr (EPI == 0 || EPI == 4) {
+#ifdef PP_ABL
+            if (P.lse_pm && !(PP_ABL & 4)) {
+#else
             if (P.lse_pm) {
+#endif
                 // the 64 columns this wave holds of row m sit in the 4 lanes {l, l+16, l+32, l+48}, 16 values each
                 float mx = -INFINITY;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fmaxf(lv[j].x, lv[j].y), fmaxf(lv[j].z, lv[j].w)));
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = pp_max_x16(mx);
+                mx = pp_max_x32(mx);
                 float sm = 0.f;
                 if (mx > -INFINITY) {
 #pragma unroll
@@ -678,8 +731,8 @@ __global__ __launch_bounds__(512) void gemm_pp(PPArgs P) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) sm += __expf(lv[j][e] - mx);     // masked columns: exp(-inf) = 0
                 }
-                sm += __shfl_xor(sm, 16);
-                sm += __shfl_xor(sm, 32);
+                sm = pp_sum_x16(sm);
+                sm = pp_sum_x32(sm);
                 if ((lane >> 4) == 0) {
                     const long long o = (long long)m * P.lse_np + etn * 4 + wc;
                     P.lse_pm[o] = mx;
