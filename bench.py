@@ -231,16 +231,34 @@ def train_step_workload(args, R_):
     return step, flops_per_utt
 
 
+def committed_traffic(fname, key="hbm_bytes_per_step"):
+    """A number of a committed PMC profile (a constant of that profile, not of this run), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", fname)))[key]
+    except Exception:
+        return None
+
+
+def m1p_traffic():
+    """Bytes beyond L2 per M1' step: the two kernels of the fused logits -> loss path (profiles/r6_m1p_pmc_hbm.json)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r6_m1p_pmc_hbm.json")))
+        ks = [k for k in d["kernels"] if "rnnt_lse_gather" in k["kernel"] or "rnnt_dlogits_fused" in k["kernel"]]
+        return sum(k["write_bytes_per_step"] + k["fetch_bytes_per_step"] for k in ks) if len(ks) == 2 else None
+    except Exception:
+        return None
+
+
 def train_step_traffic():
     """HBM bytes per train step from the committed PMC passes (separate --pmc WRITE_SIZE / FETCH_SIZE runs of this very
     workload, tools/gpu_pmc_train_step.sh; FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- a constant of the
     committed profile, not of this run, and labelled so."""
-    path = os.path.join(ROOT, "profiles", "r4_train_step_pmc_hbm.json")
+    path = os.path.join(ROOT, "profiles", "r6_train_step_pmc_hbm.json")
     try:
         d = json.load(open(path))
         lattice = [k for k in d["kernels"] if "gemm_pp<4" in k["kernel"] or "dlogits_compact" in k["kernel"]]
         return {"traffic": d["hbm_bytes_per_step"], "traffic_unit": "bytes per step (B=32), all kernels",
-                "traffic_source": "profiles/r4_train_step_pmc_hbm.json (separate --pmc WRITE_SIZE / FETCH_SIZE passes, not "
+                "traffic_source": "profiles/r6_train_step_pmc_hbm.json (separate --pmc WRITE_SIZE / FETCH_SIZE passes, not "
                                   "this run; default arithmetic)",
                 "traffic_joint_lattice": {"fc2_logits_fp16_written": lattice and next(
                     (k["write_bytes_per_step"] for k in lattice if "gemm_pp<4" in k["kernel"]), None),
@@ -1173,14 +1191,14 @@ def decode_report(a, step, ret, el, audio_s, world, cal_labels):
 def decode_step_traffic(a):
     """Counter-level traffic of ONE search step: PMC counters need their own rocprofv3 passes, so this is the committed
     measurement of the same kernels at the same shape (tools/gpu_pmc_decode.sh), not this run."""
-    path = os.path.join(ROOT, "profiles", "r5_decode_step_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r6_decode_step_pmc.json")
     try:
         if (a.batch, a.beam, a.vocab, a.pred_net, bool(a.fst)) != (64, 16, 5000, "transformer", False):
             return {"traffic": None}
         d = json.load(open(path))
         return {"traffic": d["hbm_bytes_per_step"], "traffic_unit": "bytes per search step beyond L2 (FETCH_SIZE + WRITE_SIZE; "
                                                                       "Infinity-Cache hits included)",
-                "traffic_source": "profiles/r5_decode_step_pmc.json (separate --pmc passes of the same kernels, eager launches; "
+                "traffic_source": "profiles/r6_decode_step_pmc.json (separate --pmc passes of the same kernels, eager launches; "
                                   "not this run)",
                 "traffic_note": "7.5 x the algorithmic bytes: every XCD pulls the weights through its own L2 (the vocabulary "
                                 "product alone fetches 169 MB = 8 x its 20 MB of two-term weights); the step stays latency-bound"}
@@ -1313,7 +1331,9 @@ def leg_mbr(args, R_, with_cpu, steps=4, warmup=3):      # (warm-up: an eager st
                         "training_part": "one hipGraph replay per step (pika_amd.mbr.GraphedMbrStep: %s)" % (
                             info.get("train_half"),)},
              "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
-                          "traffic": None,
+                          "traffic": committed_traffic("r6_mbr_step_pmc_hbm.json"),
+                          "traffic_source": "profiles/r6_mbr_step_pmc_hbm.json: bytes beyond L2 per MBR step (B = 8, beam 4), every "
+                                            "kernel of the step (search + training half), separate --pmc passes, not this run",
                           "note": "730 GF per utterance (the step's full-lattice RNN-T part, SURVEY 8d M2) over the WHOLE step; "
                                   "%.0f of its %.0f ms are the N-best search, a chain of ~%d dependent launches per step at 32 rows "
                                   "that is bound by launch latency, not by MFMA or HBM (decode.roofline)" % (
@@ -1391,8 +1411,11 @@ def run_m1p(args, R_, steps, warmup):
                    "max_rel_cost_diff_vs_log_softmax_plus_loss": float(((costs - c_ref).abs() / c_ref.abs()).max())},
         "roofline": {"bound": "hbm", "kernel": "rnnt_lse_gather_kernel + rnnt_dlogits_fused_kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": bytes_per_launch,
-                     "forward_ms": fwd_ms, "backward_ms": bwd_ms}}
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": m1p_traffic() if (B, T, U, V) == (32, 1000, 50, 5000) else None,
+                     "traffic_source": "profiles/r6_m1p_pmc_hbm.json (rnnt_lse_gather_kernel + rnnt_dlogits_fused_kernel, separate "
+                                       "--pmc passes, not this run)",
+                     "bytes_per_launch": bytes_per_launch, "forward_ms": fwd_ms, "backward_ms": bwd_ms}}
 
 
 def leg_m1_variants(args, R_):
