@@ -306,6 +306,18 @@ __device__ inline bool xcd_tile(int n_groups, int m_tiles, int &mg, int &ng) {
 // The other way round, for many rows (M = B*beam): an XCD owns a band of row tiles -- their A rows (a few hundred
 // KB) stay in its L2 -- and walks the column groups with the band's row tiles dispatched back to back, so a slab of
 // W is fetched from beyond L2 once per XCD (8x in total) instead of once per row tile.
+// ... and for a product whose WEIGHTS are the large operand (the vocabulary product of a search step: 20 MB of two-term W
+// against 4 MB of rows at B * beam = 1024, 128 KB at 32): an XCD owns the column groups x, x + 8, .. and takes every row tile
+// of them, the row tiles of a group dispatched back to back -- a slab of W is fetched from beyond L2 by ONE XCD (1x in
+// total; the rows 8x), and at one row tile the launch's workgroups spread over all eight XCDs instead of sitting on one.
+// Grid: 8 * ceil(n_groups / 8) * m_tiles.
+__device__ inline bool xcd_tile_cols(int n_groups, int m_tiles, int &mg, int &ng) {
+    const int g = blockIdx.x, xcd = g & 7, i = g >> 3;
+    ng = xcd + 8 * (i / m_tiles);
+    mg = i % m_tiles;
+    return ng < n_groups;
+}
+
 __device__ inline bool xcd_tile_rows(int n_groups, int m_tiles, int &mg, int &ng) {
     const int g = blockIdx.x, xcd = g & 7, i = g >> 3;
     const int band = (m_tiles + 7) >> 3;
@@ -1063,14 +1075,15 @@ __global__ __launch_bounds__(256, (FC2_BM == 32 && NS != 3) ? 3 : 2) void dfc2_l
                                                         int rows, int V, int NT, int KT, float sm_scale,
                                                         int splits, float *__restrict__ pmax,
                                                         float *__restrict__ psum, int Kvalid,
-                                                        float *__restrict__ logits, long long ldl) {
+                                                        float *__restrict__ logits, long long ldl, int by_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef Core<FC2_BM, FC2_WN, NS, FC2_KS> core_t;
     core_t core;
     __bf16 *lds = reinterpret_cast<__bf16 *>(smem);
     float *slab = reinterpret_cast<float *>(smem);                       // [FC2_BM][FC2_PITCH], after the product
     int mb, sp;
-    if (!xcd_tile_rows(splits, (rows + FC2_BM - 1) / FC2_BM, mb, sp)) return;
+    if (by_cols ? !xcd_tile_cols(splits, (rows + FC2_BM - 1) / FC2_BM, mb, sp)
+                : !xcd_tile_rows(splits, (rows + FC2_BM - 1) / FC2_BM, mb, sp)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = mb * FC2_BM, nt0 = (sp * 4 + wave) * FC2_WN;
     if (m0 >= rows) return;
@@ -1138,10 +1151,10 @@ void launch_dgemm(unsigned grid, hipStream_t st, const DG &p) {
 template <int NS, int BM>
 void launch_fc2_bm(unsigned grid, hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
                    int V, int NT, int KT, float sm_scale, int splits, float *pmax, float *psum, int K, float *logits,
-                   long long ldl) {
+                   long long ldl, int by_cols) {
     constexpr size_t lds = FC2_LDS_MAIN<NS, BM>() + FC2_COLS * 4;
     dfc2_logits_kernel<NS, BM><<<dim3(grid), dim3(256), lds, st>>>(h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum,
-                                                                   (K & 3) ? KT * 32 : K, logits, ldl);
+                                                                   (K & 3) ? KT * 32 : K, logits, ldl, by_cols);
 }
 
 int fc2_bm(int rows) {
@@ -1156,9 +1169,14 @@ template <int NS>
 void launch_fc2(hipStream_t st, const float *h, long long ldh, const __bf16 *w, const float *bias, int rows,
                 int V, int NT, int KT, float sm_scale, int splits, float *pmax, float *psum, int K, float *logits, long long ldl) {
     const int bm = fc2_bm(rows);
-    const unsigned grid = (unsigned)((((rows + bm - 1) / bm + 7) / 8) * 8 * splits);
-    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
-    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl);
+    const int m_tiles = (rows + bm - 1) / bm;
+    // up to 512 rows: W slabs pinned to XCDs (xcd_tile_cols: 28.6 vs 33.0 us at 32 rows, 29.0 vs 34.3 at 128, 39.7 vs 42.3 at
+    // 512; 48.7 vs 46.8 at 1024 -- tools/dfc2_bench.py); beyond: row bands per XCD.  PIKA_DFC2_MAP=rows / cols in a tuning build
+    static const int forced_map = [] { const char *e = pika_knob("PIKA_DFC2_MAP"); return !e ? -1 : (e[0] == 'r' ? 0 : 1); }();
+    const int by_cols = forced_map >= 0 ? forced_map : (rows <= 512 ? 1 : 0);
+    const unsigned grid = by_cols ? (unsigned)(8 * ((splits + 7) / 8) * m_tiles) : (unsigned)(((m_tiles + 7) / 8) * 8 * splits);
+    if (bm == 64) launch_fc2_bm<NS, 64>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl, by_cols);
+    else launch_fc2_bm<NS, 32>(grid, st, h, ldh, w, bias, rows, V, NT, KT, sm_scale, splits, pmax, psum, K, logits, ldl, by_cols);
 }
 
 }  // namespace

@@ -1,5 +1,7 @@
-"""pika_dfc2_topk (the search step's vocabulary product + partial log-sum-exp / top-K) alone: time per launch at the
-search's row counts, one subprocess per PIKA_DFC2_BM.    GPU box: python tools/dfc2_bench.py"""
+"""pika_dfc2_logits (the search step's vocabulary product + row statistics) alone: time per launch at the search's row
+counts with a 64 MB copy between launches (as inside a step, W does not survive in L2), one subprocess per knob value of a
+TUNING build (PIKA_HIPCC_EXTRA=-DPIKA_TUNING_KNOBS python -m pika_amd.build --force).
+    GPU box: python tools/dfc2_bench.py [PIKA_DFC2_MAP rows cols | PIKA_DFC2_BM 32 64]"""
 import os
 import subprocess
 import sys
@@ -26,28 +28,34 @@ def worker():
             splits = lib.pika_dfc2_splits(V)
             pmax = torch.empty(R * splits, device=dev)
             psum = torch.empty(R * splits, device=dev)
-            pcand = torch.empty(R * splits * K * 8, dtype=torch.uint8, device=dev)
+            ldl = splits * lib.pika_dfc2_cols_per_split()
+            logits = torch.empty(R, ldl, device=dev)
+            evict_a, evict_b = torch.empty(8 << 20, device=dev), torch.empty(8 << 20, device=dev)
 
             def fn():
-                _lib.check(lib.pika_dfc2_topk(h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), R, V, Hd, terms, sm, K,
-                                              pmax.data_ptr(), psum.data_ptr(), pcand.data_ptr(), st), "pika_dfc2_topk")
+                _lib.check(lib.pika_dfc2_logits(h.data_ptr(), Hd, pw.buf.data_ptr(), bias.data_ptr(), R, V, Hd, terms, sm,
+                                                pmax.data_ptr(), psum.data_ptr(), logits.data_ptr(), ldl, st), "pika_dfc2_logits")
             for _ in range(5):
                 fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(50):
+            tot = 0.0
+            for _ in range(30):
+                evict_b.copy_(evict_a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 fn()
-            e1.record()
-            torch.cuda.synchronize()
-            print("BM %-4s terms %d rows %4d: %7.1f us   (checksum %.6e)" % (
-                os.environ.get("PIKA_DFC2_BM", "auto"), terms, R, e0.elapsed_time(e1) / 50 * 1e3,
-                float(pmax.double().sum() + psum.double().sum())), flush=True)
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            us = tot / 30 * 1e3
+            print("%s terms %d rows %4d: %7.1f us (one launch between two events, incl. ~4 us of event overhead)   (checksum %.6e)" % (
+                os.environ.get("DFC2_TAG", ""), terms, R, us, float(pmax.double().sum() + psum.double().sum())), flush=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "worker":
         worker()
     else:
-        for bm in ("32", "64"):
-            subprocess.run([sys.executable, os.path.abspath(__file__), "worker"], env=dict(os.environ, PIKA_DFC2_BM=bm),
-                           check=False, timeout=200)
+        var = sys.argv[1] if len(sys.argv) > 1 else "PIKA_DFC2_MAP"
+        for val in (sys.argv[2:] or ["rows", "cols"]):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "worker"],
+                           env=dict(os.environ, **{var: val, "DFC2_TAG": "%s=%s" % (var, val)}), check=False, timeout=300)
