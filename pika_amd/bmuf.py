@@ -135,7 +135,7 @@ class BmufTrainer(object):
         if ev is not None:
             ev[1].record()
             self.collective_events.append(ev)
-        inv_world = 1.0 / float(self.world_size)
+        world = float(self.world_size)
         bm, blr = self.block_momentum, self.block_lr
         if self.is_hip:
             # the NaN guard of bmuf.py:89-90 is decided ON THE DEVICE: the flag kernel runs, and the update kernel leaves
@@ -148,7 +148,7 @@ class BmufTrainer(object):
                            "pika_bmuf_nan_flag")
                 _lib.check(lib.pika_bmuf_update(self.delta.data_ptr(), self.delta_prev.data_ptr(),
                                                 self.param.data_ptr(), self.local.data_ptr(), n,
-                                                inv_world, bm, blr, self._flag.data_ptr(), _stream()), "pika_bmuf_update")
+                                                world, bm, blr, self._flag.data_ptr(), _stream()), "pika_bmuf_update")
                 self._flag_host.copy_(self._flag, non_blocking=True)
                 self._flag_event.record()
             if self.sync_stop:
@@ -164,7 +164,7 @@ class BmufTrainer(object):
         # CPU (gloo plumbing tests); float32 scalars rounded exactly as the kernel rounds them
         f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
         c = f32(f32(blr) * f32(1.0 - f32(bm)))
-        self.delta.mul_(f32(inv_world))
+        self.delta.div_(world)                      # (bmuf.py:93: a division)
         self.delta_prev.mul_(f32(bm)).add_(self.delta * c)
         self.param.sub_(self.delta_prev * f32(1.0 + f32(bm)))
         self.local.copy_(self.param)
@@ -293,10 +293,10 @@ class BmufAdamTrainer(object):
                 _lib.check(lib.pika_bmuf_nan_flag(self.xch.data_ptr(), self.xch.numel(), self._flag.data_ptr(), _stream()),
                            "pika_bmuf_nan_flag")
                 _lib.check(lib.pika_bmuf_update(delta.data_ptr(), self.delta_prev.data_ptr(), self.param.data_ptr(),
-                                                self.local.data_ptr(), n, 1.0 / W, bm, self.block_lr,
+                                                self.local.data_ptr(), n, W, bm, self.block_lr,
                                                 self._flag.data_ptr(), _stream()), "pika_bmuf_update")
                 _lib.check(lib.pika_bmuf_adam_moments(m_sum.data_ptr(), self.exp_avg.data_ptr(), v_sum.data_ptr(),
-                                                      self.exp_avg_sq.data_ptr(), dim, 1.0 / W, *c_avg, *c_sq,
+                                                      self.exp_avg_sq.data_ptr(), dim, W, *c_avg, *c_sq,
                                                       self._flag.data_ptr(), _stream()), "pika_bmuf_adam_moments")
             if int(self._flag.item()):
                 return STOP

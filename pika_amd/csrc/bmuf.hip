@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void bmuf_nan_kernel(const float *__restrict__
 // Same operation order and roundings as bmuf.py:93-96 run as separate PyTorch ops: FMA
 // contraction is switched off so every product is rounded before it is added.
 template <typename V>
-__device__ inline void upd(V d, V &dp, V &g, V &l, float inv_world, float bm, float blr) {
+__device__ inline void upd(V d, V &dp, V &g, V &l, float world, float bm, float blr) {
 #pragma clang fp contract(off)
-    const V avg = d * inv_world;
+    const V avg = d / world;      // bmuf.py:93 `delta / float(world_size)`: a division, exact for every world size
     const V t1 = dp * bm;
     const V t2 = avg * (blr * (1.0f - bm));
     dp = t1 + t2;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bmuf_update_kernel(const float *__restric
                                                           float *__restrict__ dprev,
                                                           float *__restrict__ g,
                                                           float *__restrict__ l, size_t n,
-                                                          float inv_world, float bm, float blr,
+                                                          float world, float bm, float blr,
                                                           const int *__restrict__ skip_flag) {
     if (skip_flag && *skip_flag) return;     // a NaN in the summed delta: leave every vector as it is (bmuf.py:89-90)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -69,15 +69,15 @@ __global__ __launch_bounds__(256) void bmuf_update_kernel(const float *__restric
         for (size_t k = i; k < n4; k += stride) {
             const v4f d = reinterpret_cast<const v4f *>(delta)[k];
             v4f p = reinterpret_cast<v4f *>(dprev)[k], gg = reinterpret_cast<v4f *>(g)[k], ll;
-            upd(d, p, gg, ll, inv_world, bm, blr);
+            upd(d, p, gg, ll, world, bm, blr);
             reinterpret_cast<v4f *>(dprev)[k] = p;
             reinterpret_cast<v4f *>(g)[k] = gg;
             reinterpret_cast<v4f *>(l)[k] = ll;
         }
         for (size_t k = (n4 << 2) + i; k < n; k += stride)
-            upd(delta[k], dprev[k], g[k], l[k], inv_world, bm, blr);
+            upd(delta[k], dprev[k], g[k], l[k], world, bm, blr);
     } else {
-        for (size_t k = i; k < n; k += stride) upd(delta[k], dprev[k], g[k], l[k], inv_world, bm, blr);
+        for (size_t k = i; k < n; k += stride) upd(delta[k], dprev[k], g[k], l[k], world, bm, blr);
     }
 }
 
@@ -88,13 +88,13 @@ __global__ __launch_bounds__(256) void bmuf_update_kernel(const float *__restric
 // every product rounded before it is added (the reference's sequence of separate torch ops).
 __global__ __launch_bounds__(256) void bmuf_adam_moments_kernel(float *__restrict__ x1, float *__restrict__ b1,
                                                                 float *__restrict__ x2, float *__restrict__ b2, size_t n,
-                                                                float inv_world, float c1a, float c2a, float c3a, float c1b,
+                                                                float world, float c1a, float c2a, float c3a, float c1b,
                                                                 float c2b, float c3b, const int *__restrict__ skip_flag) {
 #pragma clang fp contract(off)
     if (skip_flag && *skip_flag) return;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float m = x1[i] * inv_world, v = x2[i] * inv_world;
+        const float m = x1[i] / world, v = x2[i] / world;      // bmuf.py:276
         float a = c1a * b1[i];
         a = a + c2a * m;
         a = a / c3a;
@@ -135,26 +135,26 @@ int pika_bmuf_nan_flag(const float *delta, size_t n, int *flag, void *stream) {
 }
 
 int pika_bmuf_update(const float *delta, float *delta_prev, float *global, float *local, size_t n,
-                     float inv_world, float block_momentum, float block_lr, const int *skip_flag, void *stream) {
+                     float world, float block_momentum, float block_lr, const int *skip_flag, void *stream) {
     if (!delta || !delta_prev || !global || !local) return PIKA_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (aligned16(delta) && aligned16(delta_prev) && aligned16(global) && aligned16(local))
         hipLaunchKernelGGL(bmuf_update_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, delta,
-                           delta_prev, global, local, n, inv_world, block_momentum, block_lr, skip_flag);
+                           delta_prev, global, local, n, world, block_momentum, block_lr, skip_flag);
     else
         hipLaunchKernelGGL(bmuf_update_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, delta,
-                           delta_prev, global, local, n, inv_world, block_momentum, block_lr, skip_flag);
+                           delta_prev, global, local, n, world, block_momentum, block_lr, skip_flag);
     return (int)hipGetLastError();
 }
 
-int pika_bmuf_adam_moments(float *sum_avg, float *blk_avg, float *sum_sq, float *blk_sq, size_t n, float inv_world,
+int pika_bmuf_adam_moments(float *sum_avg, float *blk_avg, float *sum_sq, float *blk_sq, size_t n, float world,
                            float c1_avg, float c2_avg, float c3_avg, float c1_sq, float c2_sq, float c3_sq,
                            const int *skip_flag, void *stream) {
     if (!sum_avg || !blk_avg || !sum_sq || !blk_sq || c3_avg == 0.f || c3_sq == 0.f) return PIKA_EINVAL;
     if (n == 0) return 0;
     hipLaunchKernelGGL(bmuf_adam_moments_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), sum_avg,
-                       blk_avg, sum_sq, blk_sq, n, inv_world, c1_avg, c2_avg, c3_avg, c1_sq, c2_sq, c3_sq, skip_flag);
+                       blk_avg, sum_sq, blk_sq, n, world, c1_avg, c2_avg, c3_avg, c1_sq, c2_sq, c3_sq, skip_flag);
     return (int)hipGetLastError();
 }
 

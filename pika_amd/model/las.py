@@ -484,6 +484,21 @@ class InputFeedRNNDecoder(nn.Module):
         state.pop("_packed", None)          # the packed copies of the weights (a scoring pass' cache) are not part of a checkpoint
         return state
 
+    # The packed-weight cache of the fused token loop is keyed on (data_ptr, _version) of every weight -- which writes
+    # through `p.data` or raw pointers (BMUF's flat vector, `p.data.copy_()`) do not move.  Whatever can change
+    # the weights therefore drops the cache: entering training mode, loading a state dict, or an explicit call.
+    def invalidate_packed_weights(self):
+        self.__dict__.pop("_packed", None)
+
+    def train(self, mode=True):
+        if mode:
+            self.invalidate_packed_weights()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed_weights()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _fix_enc_hidden(self, h):
         if self.bidirectional_encoder:
             h = torch.cat([h[0:h.size(0):2], h[1:h.size(0):2]], 2)

@@ -224,6 +224,13 @@ def _native_step_vs_script_golden(device, search_precision=None, _raw=False, gra
         # are asserted, the rest is reported
         assert np.array_equal(got_h[:, 0], want["hyps"][:, 0])
         same = int((got_h == want["hyps"]).all(axis=2).sum())
+        # bounded, not free: most entries at the reference rank (measured 7 of 9), and whatever moved is the SAME
+        # set of hypotheses per utterance in another order, with scores within the one-term noise
+        n_all = got_h.shape[0] * got_h.shape[1]
+        assert same >= (6 * n_all + 8) // 9, (same, n_all)
+        for b in range(got_h.shape[0]):
+            assert sorted(map(tuple, got_h[b].tolist())) == sorted(map(tuple, want["hyps"][b].tolist())), b
+        assert score_err < 0.1, score_err
         print("bf16 N-best search: top-1 identical, %d of %d entries at the reference rank, max |score diff| %.2e"
               % (same, got_h.shape[0] * got_h.shape[1], score_err))
         if _raw is False:
