@@ -44,5 +44,24 @@ def inputs():
     return x, x_len
 
 
+# The BENCHMARKED row layout (BASELINE.json configs[4]: B = 64 utterances x beam 16 = 1024 beam rows -- the 64-row tiles of
+# the vocabulary product, 64 workgroups of the advance, 1024-row compaction of the prediction-net launches) on short
+# utterances (1.4-1.9 s: the reference decoder's Python loops are per utterance and step): VERDICT r5 weak #3.
+WIDE_B = 64
+WIDE_LENS = [142 + (37 * i) % 50 for i in range(WIDE_B)]
+
+
+def inputs_wide():
+    g = torch.Generator().manual_seed(SEED + 9)
+    x = torch.randn(WIDE_B, max(WIDE_LENS), D_IN, generator=g)
+    lens = torch.tensor(WIDE_LENS)
+    x_len = (lens - 42) // 4 + ((lens - 42) % 4 != 0).long()
+    return x, x_len
+
+
+def max_len_wide(x_len):
+    return [int(v) + 40 for v in x_len]
+
+
 def max_len(x_len):
     return [int(v) + 100 for v in x_len]                          # decode_transducer.py:132-133

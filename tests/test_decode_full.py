@@ -29,21 +29,21 @@ def fst_matcher():
     return SortedMatcher(NgramFst.from_arcs(n, arcs, finals), **params)
 
 
-def decode(device, precision=None, fst=False):
+def decode(device, precision=None, fst=False, wide=False):
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
     from decoder.transducer_decoder import TransducerDecoder
     from decoder.beam_transducer import GlobalScorer
     from pika_amd.model import transducer
     net = F.build(transducer, seeded_state_dict).to(device)
-    x, x_len = F.inputs()
+    x, x_len = F.inputs_wide() if wide else F.inputs()
     args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None,
                            nonblk_reward=F.FST_REWARD if fst else 0.0)
-    d = TransducerDecoder(net, batch_size=F.B, beam_size=F.BEAM, n_best=F.BEAM, blk=0, global_scorer=GlobalScorer(),
-                          sm_scale=F.SM_SCALE, cuda=(device != "cpu"), beam_prune=True, args=args,
+    d = TransducerDecoder(net, batch_size=F.WIDE_B if wide else F.B, beam_size=F.BEAM, n_best=F.BEAM, blk=0,
+                          global_scorer=GlobalScorer(), sm_scale=F.SM_SCALE, cuda=(device != "cpu"), beam_prune=True, args=args,
                           **(dict(lm_scorer=fst_matcher(), lm_scorer_scale=F.FST_SCALE) if fst else {}))
     if precision is not None:
         d.decode_precision = precision
-    ret, enc = d.decode_batch(x.to(device), x_len.to(device), F.max_len(x_len))
+    ret, enc = d.decode_batch(x.to(device), x_len.to(device), (F.max_len_wide if wide else F.max_len)(x_len))
     return D.pack(ret["predictions"], ret["scores"]), enc, d
 
 
@@ -53,7 +53,7 @@ def same_entry(got, z, b, j, k=None):
     return int(got["lens"][b, k]) == L and np.array_equal(got["hyps"][b, k, :L], z["hyps"][b, j, :L])
 
 
-def check(got, enc, z, enc_tol, exact, ranks=True):
+def check(got, enc, z, enc_tol, exact, ranks=True, last_rank_strict=True):
     """exact: every list identical (CPU: same fp32 library arithmetic as the reference run).  Otherwise (GPU): scores
     are sums of ~150 log-probs of |logit| ~ 30 taken from K = 1024 fp32 accumulations in a different order than the
     CPU GEMM -- 1e-4-level noise per score -- so entries whose reference score is closer than `gap` to a neighbour
@@ -84,6 +84,11 @@ def check(got, enc, z, enc_tol, exact, ranks=True):
         sc = z["scores"][b]
         for j in range(nb):
             sep = (j == 0 or sc[j - 1] - sc[j] > gap) and (j == nb - 1 or sc[j] - sc[j + 1] > gap)
+            if j == nb - 1 and not last_rank_strict:
+                # the LAST entry of a list has no lower neighbour IN the list: how far the best hypothesis that did not make
+                # the list lies below it is not recorded, so it cannot be called separated (at 64 utterances one of the 64
+                # last entries has a rival inside the score noise; at B = 4 none happened to)
+                sep = False
             same = same_entry(got, z, b, j)
             n_same += int(same)
             n_sep += int(sep)
@@ -230,6 +235,11 @@ def check_fst(got, z, gap=1.5e-3):
         sc = z["scores"][b]
         for j in range(nb):
             sep = (j == 0 or sc[j - 1] - sc[j] > gap) and (j == nb - 1 or sc[j] - sc[j + 1] > gap)
+            if j == nb - 1 and not last_rank_strict:
+                # the LAST entry of a list has no lower neighbour IN the list: how far the best hypothesis that did not make
+                # the list lies below it is not recorded, so it cannot be called separated (at 64 utterances one of the 64
+                # last entries has a rival inside the score noise; at B = 4 none happened to)
+                sep = False
             same = same_entry(got, z, b, j)
             n_same += int(same)
             assert same or not sep, "utterance %d rank %d: separated by > %g from its neighbours but differs" % (b, j, gap)
@@ -351,3 +361,24 @@ def test_decode_encoder_on_two_fp16_terms_matches_the_exact_products(hip_device)
     # encoder on the golden (3.9e-6)
     rel = ((out["fp16x2"] - out["fp32"]).abs().max() / out["fp32"].abs().max()).item()
     assert rel < 1.5e-5, rel
+
+
+GOLD_WIDE = os.path.join(HERE, "golden", "decode_full_wide.npz")   # tests/golden/make_decode_full_wide_golden.py
+
+
+@pytest.mark.gpu
+def test_gpu_benchmarked_row_layout_matches_the_reference_decoder(hip_device):
+    """configs[4]'s ROW LAYOUT against the reference: B = 64 utterances x beam 16 = 1024 beam rows --
+    64-row tiles of the vocabulary product, 64 workgroups of the advance, the 1024-row compaction of the prediction-net
+    launches, the fp16x2 encoder products above the fill gate WITHOUT lowering it -- on the golden the reference decoder
+    (decoder/transducer_decoder.py:123-183, beam_transducer.py:82-187) produced for the same 64 utterances on CPU fp32.
+    Criterion of the B = 4 golden: every top-1 hypothesis identical, every n-best entry separated from its neighbours by more
+    than the score noise at its reference rank, >= 85 % of all entries at their rank, scores within 2e-3."""
+    z = np.load(GOLD_WIDE)
+    assert z["lens"].shape == (F.WIDE_B, F.BEAM)
+    got, enc, d = decode(hip_device, "fp32", wide=True)
+    assert "launches_per_step" in d.timing and d.timing["graphs"] == 1        # the fused, graphed launch chain ran
+    rel, frac = check(got, enc, z, 1e-4, exact=False, last_rank_strict=False)
+    print("B = 64 x beam 16 (1024 rows), fp32-grade search: encoder output max rel err %.2e; top-1 identical for all %d "
+          "utterances; %.1f %% of the %d n-best entries at the reference rank; max |score diff| on entries at their rank %.2e"
+          % (rel, F.WIDE_B, 100 * frac, F.WIDE_B * F.BEAM, float(np.abs(got["scores"] - z["scores"]).max())))
