@@ -815,6 +815,9 @@ __device__ inline void joint_carry(const pika_dstep_joint_t &j, int src, long lo
     }
 }
 
+// (Round 6: what bounds this launch is BYTES, not its chain of dependent loads -- 17.7 MB read + 16.2 MB written per step at
+// 1024 rows (profiles/r6_decode_step_pmc.json): the prediction half of the joint alone is 8 KB in and 8 KB out per row.  A
+// variant with every load of a row requested up front, in three rounds instead of seven, ran 14.0 us against 14.4.)
 __global__ __launch_bounds__(256) void dstep_prep_kernel(PrepDev a) {
     const pika_dstep_prep_t &p = a.p;
     if (p.stop && *p.stop) return;

@@ -235,11 +235,6 @@ def check_fst(got, z, gap=1.5e-3):
         sc = z["scores"][b]
         for j in range(nb):
             sep = (j == 0 or sc[j - 1] - sc[j] > gap) and (j == nb - 1 or sc[j] - sc[j + 1] > gap)
-            if j == nb - 1 and not last_rank_strict:
-                # the LAST entry of a list has no lower neighbour IN the list: how far the best hypothesis that did not make
-                # the list lies below it is not recorded, so it cannot be called separated (at 64 utterances one of the 64
-                # last entries has a rival inside the score noise; at B = 4 none happened to)
-                sep = False
             same = same_entry(got, z, b, j)
             n_same += int(same)
             assert same or not sep, "utterance %d rank %d: separated by > %g from its neighbours but differs" % (b, j, gap)
