@@ -27,28 +27,30 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 # The REFERENCE's own Python modules timed on CPU ("the reference's own Python modules ... on PyTorch-CPU fp32").
-# /root/reference does not exist on the GPU box, so these are constants measured by tools/time_reference_cpu.py in the
-# build container (8 cores, fp32, warm) and carried beside the port each leg times live on the GPU box's host cores.
+# /root/reference does not exist on the GPU box and a Python reference may not travel there in any form, so these are
+# constants measured by tools/time_reference_cpu.py in the build container (8 cores, fp32, warm; re-measured in round 6) and
+# carried, labelled as such, beside the PORT each leg times live on the GPU box's host cores (`cpu_baseline`).
 CPU_REFERENCE = {
-    "source": "tools/time_reference_cpu.py, build container, 8 cores, round 4",
-    "train_step": {"value": 0.1505, "unit": "utterances/s", "cores": 8, "kind": "reference",
+    "source": "tools/time_reference_cpu.py, build container, 8 cores, round 6",
+    "train_step": {"value": 0.1220, "unit": "utterances/s", "cores": 8, "kind": "reference",
                    "sample": "reference transducer.Net fwd (as written: (B,T,U,2H) concat, dense log-softmax) + oracle C RNN-T "
-                             "loss + bwd + clip + SGD, B=2, T_in=1000, U=50, V=5000, warm, 2 steps of 13.3 s"},
-    "decode": {"value": 2.84, "unit": "RTF", "cores": 8, "kind": "reference",
+                             "loss + bwd + clip + SGD, B=2, T_in=1000, U=50, V=5000, warm, 2 steps of 16.4 s"},
+    "decode": {"value": 2.716, "unit": "RTF", "cores": 8, "kind": "reference",
                "sample": "reference TransducerDecoder.decode_batch, B=4, beam 16, n-best 16, 10.0 s of audio, full-width model "
-                         "(tests/decode_full_common.py), 28.3 s of wall time"},
-    "mbr_step": {"value": 1.094, "unit": "utterances/s", "cores": 8, "kind": "reference",
+                         "(tests/decode_full_common.py), 27.1 s of wall time"},
+    "mbr_step": {"value": 1.126, "unit": "utterances/s", "cores": 8, "kind": "reference",
                  "sample": "UNCHANGED train_transducer_mbr_bmuf_otfaug.py on the reference's own modules, full-width model, "
                            "B=2 utterances of 1.5 s (not 10 s), beam 4: decode -> optimizer step 1.8 s (second batch)"},
 }
 
 
 def cpu_reference(leg, live):
-    """The `cpu_baseline_reference` entry of a leg.  live (rank 0 of a 1-GPU run with CPU baselines on): the REFERENCE's own
-    modules are timed here and now, on this host's cores, by tools/time_reference_cpu.py in a child process (its shims
-    replace torch.Tensor.cuda: never in this process) -- from /root/reference, or on the GPU box from the copy that
-    tools/stage_reference.py staged under the git-ignored _ref_scratch/ ("timed on the same box's host
-    cores").  Otherwise, or if that fails: the round-4 figures of the 8-core build container, labelled as such."""
+    """The `cpu_baseline_reference` entry of a leg.  Where /root/reference EXISTS (the build container) and live is asked for
+    (rank 0 of a 1-GPU run with CPU baselines on), the REFERENCE's own modules are timed here and now by
+    tools/time_reference_cpu.py in a child process (its shims replace torch.Tensor.cuda: never in this process).  On the GPU
+    box the reference does not exist: the build container's figures, labelled as constants.  (Round 5 shipped a staged copy
+    of the reference's modules to the box -- tools/stage_reference.py, git-ignored _ref_scratch/ -- to time them there; the
+    final tree does not stage: a Python reference does not travel.  The tool remains for a host that holds the reference.)"""
     import subprocess
     const = dict(CPU_REFERENCE[leg], measured="constants: " + CPU_REFERENCE["source"])
     name = {"train_step": "train", "decode": "decode", "mbr_step": "mbr"}[leg]
