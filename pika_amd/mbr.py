@@ -207,7 +207,9 @@ class GraphedMbrStep(object):
         from .rnnt import RNNTLoss
         self.model, self.rnnt_scale, self.sm_scale, self.blk = model, float(rnnt_scale), float(sm_scale), int(blk)
         self.max_graphs, self.min_seen = max(1, int(max_graphs)), max(1, int(min_seen))
-        self.s_bucket, self.u_bucket, self.warmup = max(1, int(s_bucket)), max(1, int(u_bucket)), int(warmup)
+        # (at least ONE eager call first: libraries that initialise lazily -- hipBLASLt behind a stock torch op of a narrow layer,
+        #  kernel attributes, the allocator -- must not meet their first call inside a stream capture: hipBLASLt aborts the process)
+        self.s_bucket, self.u_bucket, self.warmup = max(1, int(s_bucket)), max(1, int(u_bucket)), max(1, int(warmup))
         self.loss = RNNTLoss(blank=self.blk).apply
         import collections
         self.entries = collections.OrderedDict()
