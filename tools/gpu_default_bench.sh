@@ -1,15 +1,13 @@
 #!/bin/bash
-# the default bench line only (what the driver runs), with the decode pipeline leg's LAS phases
-cd /root/repo; mkdir -p gpurun_out
-timeout 1200 python bench.py > gpurun_out/default_bench.json 2> gpurun_out/default_bench.err; tail -2 gpurun_out/default_bench.err | cut -c1-200
+# the default `python bench.py` line of the tree -> gpurun_out/bench_default.json (copy to profiles/rN_bench_default_run.json)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 python - <<'PY'
 import json
-for l in open('gpurun_out/default_bench.json'):
-    l=l.strip()
-    if l.startswith('{'):
-        d=json.loads(l)
-        print(d['metric'], d['value'], d['ms_per_step'], d['roofline']['frac'])
-        ts=d.get('train_step',{}); print('train', {k:ts.get(k) for k in ('value','ms_per_step')}, ts.get('roofline',{}).get('frac'))
-        dc=d.get('decode',{}); print('decode', dc.get('value'), dc.get('ms_per_step'), dc.get('exact_step_products'))
-        w=dc.get('with_fst_and_las',{}); print('pipeline', {k:w.get(k) for k in ('value','ms_per_step','search_s','las_rescoring_s','las_phases_ms')})
+d = json.loads(open("gpurun_out/bench_default.json").read().strip().splitlines()[-1])
+print("M1", d["value"], d["ms_per_step"], d["roofline"]["frac"])
+print("M1p", d["rnnt_loss_M1p"]["ms_per_step"], d["rnnt_loss_M1p"]["roofline"]["frac"])
+ts = d["train_step"]; print("train", ts["ms_per_step"], ts["roofline"]["frac"], "lstm", ts["lstm_prediction_net"]["ms_per_step"])
+dc = d["decode"]; print("decode", dc["ms_per_step"], dc["config"]["timing"]["search_s"], "full", dc["with_fst_and_las"]["ms_per_step"], dc["with_fst_and_las"]["las_rescoring_s"])
+m = d["mbr_step"]; print("mbr", m["ms_per_step"], m["value"])
 PY
