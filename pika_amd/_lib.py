@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -80,6 +80,13 @@ SIGNATURES = {
     "pika_blstm_pack": (_i, [_vp, _i, _i, _vp, _vp]),
     "pika_blstm_layer": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
     "pika_blstm_status": (_i, [_vp, _vp, _vp]),
+    "pika_lstm_train_packed_bytes": (_ll, [_i]),
+    "pika_lstm_train_fwd_work_bytes": (_ll, [_i, _i, _i]),
+    "pika_lstm_train_bwd_work_bytes": (_ll, [_i, _i, _i]),
+    "pika_lstm_train_pack": (_i, [_vp, _i, _vp, _vp]),
+    "pika_lstm_train_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "pika_lstm_train_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
+    "pika_lstm_train_status": (_i, [_vp, _vp, _vp]),
     # include/pika_joint.h
     "pika_joint_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pika_joint_gate_bwd": (_i, [_vp, _i] + [_vp] * 8 + [_i, _i, _i, _i, _vp]),

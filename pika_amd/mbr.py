@@ -250,6 +250,7 @@ class GraphedMbrStep(object):
         return rnnt.detach()
 
     def _capture(self, key, feats, labels, x_len, ali, y, sym, slen, seq_grad):
+        from . import train_graph
         model = self.model
         dev = feats.device
         e = _MbrEntry()
@@ -285,6 +286,7 @@ class GraphedMbrStep(object):
                     grads = torch.autograd.grad((rnnt + surrogate,), [aliases[n] for n, _ in named], allow_unused=True)
                     grads = [g if g is None or (g.dtype == p.dtype and g.is_contiguous() and g.shape == p.shape)
                              else g.to(p.dtype).expand_as(p).contiguous() for g, (_, p) in zip(grads, named)]
+                    grads = train_graph.distinct_buffers(grads)
                     e.rnnt = rnnt.detach()
                 except Exception as ex:     # leaving the context with an exception in flight ends the capture twice
                     err = ex

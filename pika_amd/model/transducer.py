@@ -15,7 +15,13 @@ def _lstm_forward(rnn, x):
     dropout INSIDE the library's multi-layer call keeps the mask it drew when a hipGraph was captured: every replay of
     the graphed training step (pika_amd/train_graph.py) would drop the same units for the rest of the run
     (tests/test_train_step_gpu.py::test_graphed_lstm_prediction_net_draws_new_dropout_masks_per_replay).  torch's dropout
-    takes its Philox offset from the graph-registered generator state and draws a new mask per replay."""
+    takes its Philox offset from the graph-registered generator state and draws a new mask per replay.
+
+    First choice on a HIP device: the recurrence of every layer as one persistent launch per direction of time
+    (pika_amd/model/lstm.py, include/pika_lstm.h) -- the library's step-by-step chain is 4.3 ms of a 47 ms training step."""
+    from . import lstm
+    if lstm.applies(rnn, x):
+        return lstm.forward(rnn, x)[0]
     if not (rnn.training and rnn.dropout > 0.0 and rnn.num_layers > 1 and x.is_cuda and rnn.batch_first
             and not rnn.bidirectional and getattr(rnn, "proj_size", 0) == 0 and rnn.bias):
         return rnn(x)[0]

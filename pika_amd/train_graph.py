@@ -249,6 +249,7 @@ def _capture(model, st, key, x, y, x_len, t_valid=None):
             # expanded gradient would send clip / SGD to the stock multi-tensor path); the copies are part of graph B
             grads = [g if g is None or (g.dtype == p.dtype and g.is_contiguous() and g.shape == p.shape)
                      else g.to(p.dtype).expand_as(p).contiguous() for g, (_, p) in zip(grads, named)]
+            grads = distinct_buffers(grads)
         except Exception as ex:         # reported below; leaving the context with an exception in flight ends the capture twice
             err = ex
             if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG"):
@@ -263,6 +264,20 @@ def _capture(model, st, key, x, y, x_len, t_valid=None):
               flush=True)
     e.grads = [(p, g) for p, g in zip(params, grads) if g is not None]
     return e, None
+
+
+def distinct_buffers(grads):
+    """autograd.grad returns ONE tensor for two parameters whose sum entered the model (`b_ih + b_hh`: the addition's backward
+    hands its incoming gradient to both); AccumulateGrad would give every parameter a buffer of its own -- the clip and
+    the optimizer scale gradients in place, a shared buffer would be scaled twice."""
+    seen, out = set(), []
+    for g in grads:
+        if g is not None:
+            if g.data_ptr() in seen:
+                g = g.clone()
+            seen.add(g.data_ptr())
+        out.append(g)
+    return out
 
 
 class _GraphedFn(torch.autograd.Function):
