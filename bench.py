@@ -971,10 +971,11 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
                 rn = run_train_step(a2, R_, max(5, steps // 2), 3)
                 ts["lstm_prediction_net"] = {
                     "ms_per_step": rn["ms_per_step"], "value": rn["value"], "unit": rn["unit"], "loss": rn["config"]["loss"],
-                    "note": "dec_type=rnn as in the recipes: nn.LSTM (MIOpen recurrence, fp32) inside the captured step, layer by "
-                            "layer with torch's dropout between the layers (the library's own inter-layer dropout keeps the mask of "
-                            "the capture); parity at full width: tests/test_model_full.py::test_gpu_lstm_prediction_net_against_"
-                            "reference_full_golden[mixed]"}
+                    "note": "dec_type=rnn as in the recipes: the recurrence of each nn.LSTM layer as one persistent launch per "
+                            "direction of time (include/pika_lstm.h; two bf16 terms per operand) inside the captured step, torch's "
+                            "dropout between the layers; the library's step-by-step recurrence (MIOpen) was 4.3 ms of this step; "
+                            "parity at full width: tests/test_model_full.py::test_gpu_lstm_prediction_net_against_"
+                            "reference_full_golden[mixed], against torch's nn.LSTM: tests/test_lstm_train_gpu.py"}
             except Exception as e:
                 ts["lstm_prediction_net"] = {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
