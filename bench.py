@@ -542,8 +542,10 @@ def decode_workload(args, dev, rank):
     dec = decoder(args.beam, args.beam, lm_scorer)
     x_len_host = [int(v) for v in x_len]     # (the decode script holds the lengths on the host: decode_transducer.py:100-110)
 
+    max_len_host = [v + 100 for v in x_len_host]
+
     def step():
-        ret, enc_out = dec.decode_batch(feats, x_len, [int(v) + 100 for v in x_len])
+        ret, enc_out = dec.decode_batch(feats, x_len, max_len_host)
         t0 = time.perf_counter()
         if las_fw is not None:      # decode_transducer.py:136-156: every n-best entry, forward and reversed
             # (the script's `[e.item() for e in hyp if e != blk]`, decode_transducer.py:139, with blk = 0, through the

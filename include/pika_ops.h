@@ -54,7 +54,8 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
  *       runs over the rows (Cp must equal C).
  *   PIKA_SPLIT_PAIR (n_terms = 2, role ignored): dst (2, n_batch, t_in, Cp) bf16, plane 0 = t0 ("hi"), plane 1 = t1
  *       ("lo"), pad columns zero: the two-term A operand of pika_gemm_bf16_ex (pika_operand_t.seg = Cp,
- *       lo_off = n_batch * t_in * Cp). */
+ *       lo_off = n_batch * t_in * Cp).  With n_terms = 4: fp16 planes hi = fp16(x), lo' = fp16((x - hi) 2^11) -- the
+ *       operands of pika_attention_infer_f16x2 (pika_attn.h) straight from a packed fp32 [q | k | v] projection. */
 #define PIKA_SPLIT_CONCAT 0
 #define PIKA_SPLIT_STACK 1
 #define PIKA_SPLIT_PAIR 2

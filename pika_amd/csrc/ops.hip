@@ -186,6 +186,11 @@ __global__ __launch_bounds__(256) void split_terms_kernel(const float *__restric
                 const _Float16 h = (_Float16)x_;
                 const float lo = x_ - (float)h;        // exact in fp32
                 t0[i] = h;
+                if (f16_role == 3) {        // the pair of pika_attention_infer_f16x2: x = hi + 2^-11 lo'
+                    t1[i] = (_Float16)(lo * 2048.f);
+                    t2[i] = (_Float16)0.f;
+                    continue;
+                }
                 t1[i] = f16_role == 1 ? (_Float16)(lo * 32.f) : (_Float16)((float)h * (1.f / 32.f));
                 t2[i] = f16_role == 1 ? (_Float16)((float)h * (1.f / 64.f)) : (_Float16)(lo * 64.f);
             }
@@ -271,9 +276,9 @@ int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long lon
                           int role, int n_terms, int layout, int Cp, void *dst, void *stream) {
     if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
     if (n_terms != 2 && n_terms != 3 && n_terms != 4) return PIKA_EINVAL;
-    if (n_terms == 4 && layout != PIKA_SPLIT_CONCAT) return PIKA_EINVAL;
+    if (n_terms == 4 && layout == PIKA_SPLIT_STACK) return PIKA_EINVAL;
     if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK && layout != PIKA_SPLIT_PAIR) return PIKA_EINVAL;
-    if (layout == PIKA_SPLIT_PAIR && n_terms != 2) return PIKA_EINVAL;
+    if (layout == PIKA_SPLIT_PAIR && n_terms != 2 && n_terms != 4) return PIKA_EINVAL;
     if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
         return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) return PIKA_EINVAL;
@@ -281,7 +286,7 @@ int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long lon
     const long long n_gran = rows * (Cp >> 3);
     if ((n_gran + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
     const int nseg = layout == PIKA_SPLIT_PAIR ? 2 : (n_terms == 3 ? 6 : 3);
-    const int f16_role = n_terms == 4 ? 1 + role : 0;
+    const int f16_role = n_terms == 4 ? (layout == PIKA_SPLIT_PAIR ? 3 : 1 + role) : 0;
     long long seg_stride, dst_batch, dst_ld;
     if (layout == PIKA_SPLIT_PAIR) { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
     else if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }

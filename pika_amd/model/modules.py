@@ -48,12 +48,30 @@ class MultiHeadedAttention(nn.Module):
         if max_relative_positions > 0:
             raise NotImplementedError("relative positions are off the RNN-T hot path (SURVEY 8a row 7)")
 
+    def _stacked_qkv(self):
+        """[W_q; W_k; W_v] and the stacked biases, rebuilt when a parameter changed (inference: once per model)."""
+        import torch
+        ps = [m.weight for m in (self.linear_query, self.linear_keys, self.linear_values)] + \
+             [m.bias for m in (self.linear_query, self.linear_keys, self.linear_values)]
+        tag = tuple((p.data_ptr(), p._version) for p in ps)
+        got = self.__dict__.get("_qkv_stack")
+        if got is None or got[0] != tag:
+            with torch.no_grad():
+                got = (tag, torch.cat(ps[:3], 0).contiguous(), torch.cat(ps[3:], 0).contiguous())
+            self.__dict__["_qkv_stack"] = got
+        return got[1], got[2]
+
     def forward(self, key, value, query, mask=None, layer_cache=None, type=None, residual=None,
                 residual_dropout=0.0):
         """residual (not in the reference signature): when given, returns dropout(out) + residual, which the
         packed self-attention path folds into the output projection."""
         if layer_cache is not None:
             raise NotImplementedError("layer_cache is off the RNN-T hot path (SURVEY 8a row 7)")
+        if key is value and value is query and residual is None and ops.self_attention_infer_ok(query, self.head_count, mask):
+            # the decoder's encoder pass: q, k, v as ONE product over the stacked weights, their 16-bit planes from one launch
+            w, b = self._stacked_qkv()
+            ctx = ops.self_attention_infer(query, w, b, self.head_count, mask)
+            return ops.linear(ctx, self.final_linear.weight, self.final_linear.bias), None
         if key is value and value is query and ops.self_attention_packed_ok(query, self.head_count, mask):
             ctx = ops.self_attention_packed(query, self.linear_query.weight, self.linear_query.bias,
                                             self.linear_keys.weight, self.linear_keys.bias,

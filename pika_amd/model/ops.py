@@ -294,6 +294,19 @@ def attention(q, k, v, heads, mask, p_drop, training):
     return ctx.transpose(1, 2).contiguous().view(B, Tq, HD)
 
 
+def self_attention_infer_ok(x, heads, mask):
+    """Inference self-attention of a two-term decode mode on ONE packed projection (hipops.attention_infer_packed)."""
+    if not _hip(x) or x.shape[-1] % 8:
+        return False
+    from .hipops import attention_infer_ok
+    return attention_infer_ok(x, x, x, heads, mask)
+
+
+def self_attention_infer(x, w_qkv, b_qkv, heads, mask=None):
+    from .hipops import attention_infer_packed
+    return attention_infer_packed(linear(x, w_qkv, b_qkv), heads, mask)
+
+
 def feed_forward_applies(x, w_1, w_2):
     if not _hip(x):
         return False

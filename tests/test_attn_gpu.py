@@ -143,6 +143,10 @@ def test_inference_attention_on_two_fp16_terms(hip_device, B, T, H, D, masked):
                                                  None if mask is None else mask.to(hip_device))
                 got = hipops.attention_infer_two_term(q.to(hip_device), k.to(hip_device), v.to(hip_device), H,
                                                       None if mask is None else mask.to(hip_device))
+                # the same on the packed [q | k | v] projection, planes from one split launch: the very same bits
+                packed = hipops.attention_infer_packed(torch.cat((q, k, v), -1).to(hip_device), H,
+                                                       None if mask is None else mask.to(hip_device))
+                assert torch.equal(got, packed), mode
             out[mode] = float((got.double().cpu() - want).abs().max() / want.abs().max())
     finally:
         G.PRECISION = old

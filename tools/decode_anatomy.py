@@ -43,6 +43,11 @@ for g, at, a, b in sorted(gaps, reverse=True)[:8]:
     print("    gap %6.2f ms at %6.2f ms: %s -> %s" % (g / 1e6, at, a, b))
 for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:24]:
     print("    %7.3f ms  %5d x  %s" % (t / 1e6, c, k))
+if "--seq" in sys.argv:     # the launches between the two searches in order: start (us), duration, gap, kernel
+    end = seg[0][1]
+    for n, s_, e in seg:
+        print("  %9.1f %8.1f %7.1f  %s" % ((s_ - t0) / 1e3, (e - s_) / 1e3, max(0, s_ - end) / 1e3, short(n)))
+        end = max(end, e)
 last = rows[runs[-1][0]:]
 print("search loop of the last batch: %.2f ms from its first dstep_prep to the last kernel of the trace region" % (
     (last[-1][2] - last[0][1]) / 1e6))

@@ -8,3 +8,4 @@ cd $R
 tail -1 gpurun_out/prof_dec.log | cut -c1-600
 DB=$(find /tmp/prof_dec -name "*_results.db" | head -1)
 python tools/decode_anatomy.py $DB | tee gpurun_out/r6_decode_anatomy.txt
+python tools/decode_anatomy.py $DB --seq > gpurun_out/r6_decode_anatomy_seq.txt
