@@ -81,17 +81,24 @@ class BeamState(object):
             return
         dev, n = self.device, self.B * self.K
         sm = _lib.lib().pika_fst_states_per_slot()
-        d = {"off": torch.as_tensor(f.offsets, dtype=torch.int64, device=dev),
-             "il": torch.as_tensor(f.ilabel, dtype=torch.int32, device=dev),
-             "wt": torch.as_tensor(f.weight, dtype=torch.float32, device=dev),
-             "ns": torch.as_tensor(f.nextstate, dtype=torch.int32, device=dev),
-             "fin": torch.as_tensor(f.final, dtype=torch.float32, device=dev),
+        # the FST's CSR tables are uploaded once per matcher and device (they were converted and copied for every batch:
+        # 22 ms of host time at the bigram of bench.py's configs[4] leg), the per-slot state sets are this search's own
+        tables = m.__dict__.setdefault("_pika_device_tables", {})
+        t = tables.get(str(dev))
+        if t is None or t[0] is not f:
+            t = tables[str(dev)] = (f, {"off": torch.as_tensor(f.offsets, dtype=torch.int64, device=dev),
+                                        "il": torch.as_tensor(f.ilabel, dtype=torch.int32, device=dev),
+                                        "wt": torch.as_tensor(f.weight, dtype=torch.float32, device=dev),
+                                        "ns": torch.as_tensor(f.nextstate, dtype=torch.int32, device=dev),
+                                        "fin": torch.as_tensor(f.final, dtype=torch.float32, device=dev)})
+        d = dict(t[1])
+        d.update({
              "dis": (ctypes.c_int * max(len(m.disambig_ids), 1))(*m.disambig_ids), "ndis": len(m.disambig_ids),
              "set_n": torch.ones(n, dtype=torch.int32, device=dev),               # every slot starts as {0: 0.0}
              "set_st": torch.zeros(n, sm, dtype=torch.int32, device=dev),
              "set_cs": torch.zeros(n, sm, dtype=torch.float64, device=dev),
              "err": torch.zeros(1, dtype=torch.int32, device=dev),
-             "y_raw": torch.zeros(self.B, self.K, dtype=torch.long, device=dev)}
+             "y_raw": torch.zeros(self.B, self.K, dtype=torch.long, device=dev)})
         self.fst_dev = d
 
     def _fst_advance_device(self, prev_k, lm_scale, skip=None):

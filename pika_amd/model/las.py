@@ -10,6 +10,7 @@ decoder pass over ONE encoder pass (the reference re-runs the BLSTM encoder and 
 loop per hypothesis, decoder/transducer_decoder.py:219-236)."""
 import ctypes
 import os
+import time
 
 import torch
 import torch.nn as nn
@@ -64,7 +65,21 @@ def _phase_timer(net, dev):
 
 
 def scoring_plan(flat, own_h, sos, eos, pad, share):
-    """Host-side plan of one scoring pass over the hypotheses `flat` (lists of labels; hypothesis i belongs to utterance
+    """scoring_plan_slices run to its end."""
+    it = scoring_plan_slices(flat, own_h, sos, eos, pad, share)
+    while True:
+        try:
+            next(it)
+        except StopIteration as done:
+            return done.value
+
+
+def scoring_plan_slices(flat, own_h, sos, eos, pad, share):
+    """(A generator: it yields between slices of ~30-300 us of host work -- one trie level, then the remaining array steps --
+    so that a caller can spread the plan of the NEXT pass over the launches of this pass' token loop; the plan is the
+    generator's return value.)
+
+    Host-side plan of one scoring pass over the hypotheses `flat` (lists of labels; hypothesis i belongs to utterance
     own_h[i]) -- everything `Net._score_flat` hands to the token loop, as whole-array numpy (the per-hypothesis Python loops
     and dict tries this replaces were 5 of the 7 ms of host work per pass at 64 x 16 hypotheses):
 
@@ -105,6 +120,7 @@ def scoring_plan(flat, own_h, sos, eos, pad, share):
             _, first_idx, inv = np.unique(key, return_index=True, return_inverse=True)
             cls = first_idx[inv.reshape(-1)]
             rep[:, t + 1] = cls
+            yield
         own = (rep == ar[:, None]) & (steps <= lens[:, None])
         act = np.where(own.any(1), own.argmax(1), L + 1).astype(np.int64)
     perm = np.argsort(-ntok, kind="stable")
@@ -117,6 +133,7 @@ def scoring_plan(flat, own_h, sos, eos, pad, share):
     if L > 1:
         body = labels[perm, :L - 1].T                       # step t + 1 feeds label t ...
         tok[1:, :] = np.where(np.arange(1, L)[:, None] < end[None, :], body, pad)        # ... while the row has steps left
+    yield
     forks = None
     if share:
         f_i = np.nonzero((act > 0) & (act <= L))[0]
@@ -124,6 +141,7 @@ def scoring_plan(flat, own_h, sos, eos, pad, share):
         order = np.argsort(f_t, kind="stable")
         fork_off = np.searchsorted(f_t[order], np.arange(L + 1)).astype(np.int32)
         forks = (fork_off, col_of[f_i].astype(np.int32)[order], col_of[rep[f_i, f_t - 1]].astype(np.int32)[order])
+    yield
     ii, tt = np.nonzero(steps < ntok[:, None])              # hypothesis-major, steps ascending
     rr = col_of[rep[ii, tt]] if share else col_of[ii]
     target = labels.copy()
@@ -135,21 +153,31 @@ def scoring_plan(flat, own_h, sos, eos, pad, share):
 
 def _run_stages(gens):
     """Scoring passes (Net._score_stages generators), one after the other, each in its stages: (A) host plan; (B) encoder,
-    uploads, loop preparation, then the token loop; (C) the tail queued; (D) the wait and the lists -- the next pass' plan
-    (pure host work, ~3 ms) runs under this pass' token loop.
+    uploads, loop preparation, then the token loop; (C) the tail queued; (D) the wait and the lists.  What overlaps
+    (tools/las_stage_clock.py: the host clock of a call):
+      * a token loop is bound by its kernels: the launching thread waits inside every graph launch for room in the queue
+        (with the interpreter lock held -- a planner THREAD made no progress until the last launch).  The next pass' plan
+        (pure numpy, ~3.6 ms) is cut into slices of 30-300 us and one slice runs between two launches; it used to run
+        after the last launch, with the device idle;
+      * the next pass' (B) -- its encoder, uploads, loop preparation -- is queued right behind this pass' tail, BEFORE this
+        pass' (D): the wait for the scores and the list building happen under the next encoder's kernels.
     Tried on this runtime (ROCm 7.2, graph packet capture off) and measured worse -- profiles/r5_las_pass_overlap.txt:
-    the second pass' host work under the first pass' kernels (its replays, launched into a busy stream, cost 0.4-1.3 ms of
+    the second pass' device work under the first pass' kernels (its replays, launched into a busy stream, cost 0.4-1.3 ms of
     host time each); both passes' token loops as one replayed graph (a pass' weights and projected encoder outputs,
     ~215 MB at B = 64, stay in the Infinity Cache from token to token; two passes' do not: 1.3 x the kernel time); the
     loops launched from Python without a graph (twice the device time)."""
     out = []
-    if gens:
-        next(gens[0])                               # (A) of the first pass
+    if not gens:
+        return out
+    next(gens[0])                                   # (A) of the first pass
+    loop = next(gens[0])                            # (B) of the first pass
     for k, g in enumerate(gens):
-        drive_token_loops([next(g)])                # (B), then its token loop queued
-        if k + 1 < len(gens):
-            next(gens[k + 1])                       # (A) of the next pass under this pass' token loop
+        nxt = gens[k + 1] if k + 1 < len(gens) else None
+        advance = next(nxt) if nxt is not None else None        # (A) of the next pass, as slices
+        drive_token_loops([loop], between=advance)  # this pass' token loop queued
         next(g)                                     # (C)
+        if nxt is not None:
+            loop = next(nxt)                        # rest of the plan, then (B) of the next pass behind this pass' tail
         out.append(next(g))                         # (D)
     return out
 
@@ -194,8 +222,8 @@ class TokenLoop(object):
 _warmed = set()     # launch configurations (TokenLoop.sig) whose kernels have run once in this process
 
 
-def drive_token_loops(loops):
-    """Run prepared token loops: ONE captured launch sequence -- a token of every loop -- replayed max(L) times
+def drive_token_loops(loops, between=None):
+    """Run prepared token loops (between: host work in slices, one call after every launch of the replayed sequence): ONE captured launch sequence -- a token of every loop -- replayed max(L) times
     (PIKA_LAS_GRAPH=0: the same launches from Python).  The first time a launch configuration is seen its token 0 runs
     eagerly, outside the capture (kernel attributes are set at a kernel's first launch), and the graph takes the rest."""
     loops = [lp for lp in loops if lp is not None]
@@ -225,6 +253,8 @@ def drive_token_loops(loops):
             cur.wait_stream(side)
             for _ in range(n_more):
                 graph.replay()
+                if between is not None:
+                    between()
         else:
             for _ in range(n_more):
                 for lp in loops:
@@ -848,21 +878,50 @@ class Net(nn.Module):
             owner_host = owner.cpu().numpy() if owner is not None else np.zeros(n, np.int64)
         n_utt = int(lens.numel()) if (owner is not None and torch.is_tensor(lens)) else None
 
-        def make_plan(share):
-            plan = scoring_plan(flat, owner_host, sos, eos, pad, share)
+        def plan_slices(share):
+            plan = yield from scoring_plan_slices(flat, owner_host, sos, eos, pad, share)
+            yield
             # the (step, hypothesis) pairs that exist, the (step, row) each one reads, the token each one predicts; the
             # distinct (step, row) pairs are what the tail projects onto the vocabulary
             plan["key"], plan["inv"] = np.unique(plan["pair_step"] * n + plan["pair_row"], return_inverse=True)
+            yield
             if n_utt is not None:                           # the token loop's row lists (the fused loop takes them)
                 plan["lists"] = InputFeedRNNDecoder.step_lists(owner_host[plan["perm"]], (plan["first"], plan["end"]),
                                                                plan["L"], n, n_utt)
             return plan
+
+        def make_plan(share):
+            it = plan_slices(share)
+            while True:
+                try:
+                    next(it)
+                except StopIteration as done:
+                    return done.value
         # (whether the fused token loop takes the pass is known for sure once the encoder has run: fused_hint says what to plan for)
         share = os.environ.get("PIKA_LAS_SHARE_PREFIXES", "1") != "0" and owner is not None and bool(fused_hint)
         if encode_first:                                    # (the first pass of a call: its plan runs under its encoder's kernels)
             enc_hidden, enc_out = encode()
-        plan = make_plan(share)
-        yield None                                          # ---- (A) done
+            plan = make_plan(share)
+            yield None                                      # ---- (A) done
+        else:
+            # a later pass: the plan in slices, handed to the caller, who runs one between two launches of the previous
+            # pass' token loop (that loop is bound by its kernels: the launching thread has ~250 us to spare per token) and
+            # the rest when the loop is queued
+            it, box = plan_slices(share), {}
+
+            def advance(finish=False, budget=120e-6):
+                # (between two launches: slices until ~120 us are spent -- a token of the loop keeps the device busy for ~250)
+                t_end = time.perf_counter() + budget
+                while "plan" not in box:
+                    try:
+                        next(it)
+                    except StopIteration as done:
+                        box["plan"] = done.value
+                    if not finish and time.perf_counter() >= t_end:
+                        break
+            yield advance                                   # ---- (A) handed over
+            advance(finish=True)
+            plan = box["plan"]
         if not encode_first:
             if make_tick is not None:                       # (a later pass' plan ran under the previous pass' token loop: its
                 _tick = make_tick()                         #  phase clock starts with its encoder)
