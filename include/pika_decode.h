@@ -55,6 +55,14 @@ int pika_fst_advance(const long long *fst_offsets, const int *fst_ilabel, const 
  * include/pika_decode_step.h). */
 int pika_fst_states_per_slot(void);
 
+/* get_hyp (/root/reference/decoder/beam_transducer.py:234-243) for all n = B * per_utt n-best entries at once, after the
+ * search: entry e (of utterance e / per_utt) finished at step sel_step[e] in beam slot sel_k[e]; its symbols
+ *   out[e, j] = ys_hist[j + 1, b, k_j],   k_{sel_step - 1} = sel_k[e],   k_{j-1} = ks_hist[j, b, k_j]     (j < sel_step[e])
+ * and blk for j >= sel_step[e].  ys_hist (S+1, B, K), ks_hist (S, B, K) int64 as pika_beam_advance keeps them;
+ * out (n, smax) int32, smax >= every sel_step.  Replaces a host loop over the steps on 5 MB of copied histories. */
+int pika_beam_backtrack(const long long *ys_hist, const long long *ks_hist, const int *sel_step, const int *sel_k,
+                        int n, int per_utt, int B, int K, int smax, int blk, int *out, void *stream);
+
 /* Self-attention of ONE new position per beam row over that row's cached prefix, for the incremental
  * conv-transformer prediction network (pika_amd/decoder/prednet_cache.py; reference arithmetic
  * trainer/model/multi_headed_attn.py:199-231 at a single query position with the causal mask, i.e. keys at

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pika_fst_advance": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, ctypes.c_double,
                               ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pika_fst_states_per_slot": (_i, []),
+    "pika_beam_backtrack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     # include/pika_decode_step.h
     "pika_dpack_bytes": (_sz, [_i, _i, _i]),
     "pika_dpack_weight": (_i, [_vp, _ll, _i, _i, _i, _i, _vp, _vp]),

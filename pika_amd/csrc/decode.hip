@@ -984,3 +984,40 @@ extern "C" int pika_fst_advance(const long long *fst_offsets, const int *fst_ila
 }
 
 extern "C" int pika_fst_states_per_slot(void) { return FST_SM; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// get_hyp for every n-best entry at once (include/pika_decode.h: pika_beam_backtrack): one thread walks one entry's
+// back-pointers from its finishing step down to step 0 -- two dependent loads per step from histories that sit in L2.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void beam_backtrack_kernel(const long long *__restrict__ ys_hist,
+                                                            const long long *__restrict__ ks_hist,
+                                                            const int *__restrict__ sel_step, const int *__restrict__ sel_k,
+                                                            int n, int per_utt, int B, int K, int smax, int blk,
+                                                            int *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const long long plane = (long long)B * K;
+    const long long base = (long long)(e / per_utt) * K;
+    int steps = sel_step[e];
+    steps = steps < 0 ? 0 : (steps > smax ? smax : steps);
+    int *o = out + (long long)e * smax;
+    for (int j = smax - 1; j >= steps; --j) o[j] = blk;
+    long long idx = sel_k[e];
+    for (int j = steps - 1; j >= 0; --j) {
+        idx = idx < 0 ? 0 : (idx >= K ? K - 1 : idx);
+        o[j] = (int)ys_hist[(long long)(j + 1) * plane + base + idx];
+        idx = ks_hist[(long long)j * plane + base + idx];
+    }
+}
+}  // namespace
+
+extern "C" int pika_beam_backtrack(const long long *ys_hist, const long long *ks_hist, const int *sel_step, const int *sel_k,
+                                   int n, int per_utt, int B, int K, int smax, int blk, int *out, void *stream) {
+    if (!ys_hist || !ks_hist || !sel_step || !sel_k || !out || n <= 0 || per_utt <= 0 || B <= 0 || K <= 0 || smax <= 0 ||
+        (long long)B * per_utt < n)
+        return PIKA_EINVAL;
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       ys_hist, ks_hist, sel_step, sel_k, n, per_utt, B, K, smax, blk, out);
+    return (int)hipGetLastError();
+}

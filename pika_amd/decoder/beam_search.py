@@ -290,15 +290,17 @@ class BeamState(object):
         lists were 13 of the 17 ms this took at B = 64, beam 16)."""
         import numpy as np
         S = self.steps
-        ys = self.ys_hist[:S + 1].cpu().numpy()
-        ks = self.ks_hist[:S].cpu().numpy()
+        on_device = self.ys_hist.is_cuda and self.B > 0      # the back-pointer walk as one launch (pika_beam_backtrack)
+        if not on_device:
+            ys = self.ys_hist[:S + 1].cpu().numpy()
+            ks = self.ks_hist[:S].cpu().numpy()
         fin_n = self.fin_n.cpu().clamp(max=self.fin_cap - 1).numpy()
         nmax = int(fin_n.max()) if self.B else 0
         fin_score, fin_step, fin_k = (t[:, :nmax].cpu().numpy() for t in
                                       (self.fin_score, self.fin_step, self.fin_k))
         scores = self.scores.cpu().numpy()
         B, nb = self.B, self.n_best
-        K = ys.shape[2] if ys.ndim == 3 else 1
+        K = self.ys_hist.shape[2]
         # sort_finished: the finished list of an utterance, filled up to n_best with (scores[b, 0], S, 0) (:202-210, i stays 0),
         # stably sorted by descending score (:212).  Columns [0, nmax): the finished slots (valid below fin_n[b]); columns
         # [nmax, nmax + nb): the fill-ups (valid below nb - fin_n[b]); invalid columns sort behind every valid one.
@@ -316,6 +318,17 @@ class BeamState(object):
         # step down to 0.  Entries ordered by finishing step, so that the ones still walking at step j are a prefix.
         smax = int(sel_step.max()) if B else 0
         n = B * nb
+        if on_device:
+            from .. import _lib
+            dev = self.ys_hist.device
+            sel = torch.from_numpy(np.stack((sel_step.reshape(n), sel_k.reshape(n))).astype(np.int32)).to(dev)
+            out_d = torch.empty((n, max(smax, 1)), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().pika_beam_backtrack(
+                    self.ys_hist.data_ptr(), self.ks_hist.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), n, nb, B, K,
+                    max(smax, 1), self.blk, out_d.data_ptr(), torch.cuda.current_stream().cuda_stream), "pika_beam_backtrack")
+            out = out_d.cpu().numpy()
+            return BeamState._lists(out, sel_step.reshape(n), sel_score, B, nb)
         by_len = np.argsort(-sel_step.reshape(n), kind="stable")
         steps_sorted = sel_step.reshape(n)[by_len]
         base = (np.repeat(np.arange(B), nb) * K)[by_len]                          # row b of the (B*K)-wide history rows
@@ -330,7 +343,14 @@ class BeamState(object):
             idx[:m] = base[:m] + ks2[j].take(cur)
         out = np.empty((n, max(smax, 1)), np.int64)
         out[by_len] = out_t.T
-        keep = np.maximum(sel_step.reshape(n) - 1, 0)
+        return BeamState._lists(out, sel_step.reshape(n), sel_score, B, nb)
+
+    @staticmethod
+    def _lists(out, steps, sel_score, B, nb):
+        """The (B, n_best) lists of symbols / scores of `results` from the (entries, steps) symbol table."""
+        import numpy as np
+        n = B * nb
+        keep = np.maximum(steps - 1, 0)
         # hyp[:-1]: strip the trailing eos (:214); elements expose .item() like the reference's 0-dim tensors
         # (decode_transducer.py:139): numpy scalars / 0-dim views of one score tensor
         score_elems = torch.from_numpy(np.ascontiguousarray(sel_score, dtype=np.float32).reshape(n)).unbind(0)

@@ -272,3 +272,36 @@ def test_fused_search_equals_stepwise_search(hip_device, dec_terms, pred_net):
                 assert np.allclose(o["scores"], outs[0]["scores"], atol=1e-4)
         else:       # bf16 operands: graph and eager runs of the SAME chain agree exactly; the op-by-op search rounds
             assert np.array_equal(outs[0]["hyps"], outs[1]["hyps"])          # elsewhere and may differ on near-ties
+
+
+def test_backtrack_launch_gives_the_lists_of_the_host_walk(hip_device):
+    """BeamState.results on the device (pika_beam_backtrack: one thread per n-best entry walks its back-pointers) against
+    the host walk over copied histories, on random histories with ragged finishing steps and fill-up entries."""
+    from pika_amd.decoder.beam_search import BeamState
+    B, K, S, nb, V = 7, 16, 61, 16, 500
+    g = torch.Generator().manual_seed(11)
+    states = []
+    for dev in (torch.device("cpu"), hip_device):
+        bs = BeamState(B, K, 0, nb, [S + 5] * B, V, dev)
+        states.append(bs)
+    ks = torch.randint(0, K, (S, B, K), generator=g)
+    ys = torch.randint(1, V, (S + 1, B, K), generator=g)
+    ys[torch.rand(S + 1, B, K, generator=g) < 0.8] = 0
+    fin_n = torch.randint(0, 30, (B,), generator=g)          # fewer than n_best: fill-ups; more: the best n_best
+    fin_score = torch.randn(B, 40, generator=g)
+    fin_step = torch.randint(1, S + 1, (B, 40), generator=g)
+    fin_k = torch.randint(0, K, (B, 40), generator=g)
+    scores = torch.randn(B, K, generator=g)
+    for bs in states:
+        bs.steps = S
+        bs.ks_hist[:S] = ks.to(bs.device)
+        bs.ys_hist[:S + 1] = ys.to(bs.device)
+        bs.fin_n[:] = fin_n.to(bs.device)
+        bs.fin_score[:, :40] = fin_score.to(bs.device)
+        bs.fin_step[:, :40] = fin_step.to(bs.device)
+        bs.fin_k[:, :40] = fin_k.to(bs.device)
+        bs.scores[:] = scores.to(bs.device)
+    (p0, s0), (p1, s1) = states[0].results(), states[1].results()
+    assert [[[int(e) for e in h] for h in row] for row in p0] == [[[int(e) for e in h] for h in row] for row in p1]
+    assert [[float(v) for v in row] for row in s0] == [[float(v) for v in row] for row in s1]
+    assert all(hasattr(e, "item") for e in p1[0][0])
