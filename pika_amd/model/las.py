@@ -97,7 +97,7 @@ def scoring_plan_slices(flat, own_h, sos, eos, pad, share):
                   hypothesis, and the token it predicts there (h_t, then eos)"""
     import numpy as np
     n = len(flat)
-    lens = np.fromiter((len(h) for h in flat), np.int64, n)
+    lens = np.fromiter(map(len, flat), np.int64, n)
     ntok = lens + 1
     L = int(ntok.max())
     labels = np.full((n, L), pad, np.int64)                 # labels[i, t] = h_t; column L - 1 only ever holds padding / eos
@@ -108,19 +108,27 @@ def scoring_plan_slices(flat, own_h, sos, eos, pad, share):
     rep = act = None
     if share:
         own_h = np.asarray(own_h, np.int64)
+        # rep[i, t] for ALL levels at once (the level-by-level np.unique this replaces was 1.9 of the plan's 3.6 ms): rows
+        # [owner, label 0 .. label L-2] sorted as byte strings -- any lexicographic order puts the rows that share a prefix
+        # next to each other; a hypothesis that has ended holds `pad` where a longer one holds a label, so the two never
+        # share a level beyond its end -- then, per level t, a sorted row starts a new class where it shares fewer than
+        # t + 1 leading columns with its predecessor, and a class is represented by its smallest hypothesis index
+        M = np.empty((n, L), np.int64)
+        M[:, 0] = own_h
+        M[:, 1:] = labels[:, :L - 1]
+        o = np.argsort(M.view(np.dtype((np.void, 8 * L))).ravel(), kind="stable")
+        Ms = M[o]
+        neq = Ms[1:] != Ms[:-1]
+        lcp = np.where(neq.any(1), neq.argmax(1), L)                    # leading columns shared with the predecessor
+        start = np.ones((L, n), bool)
+        start[:, 1:] = lcp[None, :] < (np.arange(L)[:, None] + 1)       # [level][sorted position]
+        yield
+        gid = np.cumsum(start, axis=1) - 1
+        mins = np.minimum.reduceat(np.tile(o, L), np.flatnonzero(start.ravel()))
+        first_group = np.concatenate(([0], np.cumsum(start.sum(1))[:-1]))
         rep = np.empty((n, L), np.int64)
-        _, first_idx, inv = np.unique(own_h, return_index=True, return_inverse=True)
-        cls = first_idx[inv.reshape(-1)]                    # class of a prefix = index of its first member
-        rep[:, 0] = cls
-        width = int(max(int(labels.max()), 0)) + 2
-        for t in range(L - 1):
-            key = cls * width + (labels[:, t] + 1)
-            done = lens <= t                                # ended before label t: a class of its own, never looked at
-            key[done] = -1 - ar[done]
-            _, first_idx, inv = np.unique(key, return_index=True, return_inverse=True)
-            cls = first_idx[inv.reshape(-1)]
-            rep[:, t + 1] = cls
-            yield
+        rep[o, :] = mins[first_group[:, None] + gid].T
+        yield
         own = (rep == ar[:, None]) & (steps <= lens[:, None])
         act = np.where(own.any(1), own.argmax(1), L + 1).astype(np.int64)
     perm = np.argsort(-ntok, kind="stable")
