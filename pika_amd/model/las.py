@@ -167,8 +167,8 @@ def _run_stages(gens):
         (with the interpreter lock held -- a planner THREAD made no progress until the last launch).  The next pass' plan
         (pure numpy, ~3.6 ms) is cut into slices of 30-300 us and one slice runs between two launches; it used to run
         after the last launch, with the device idle;
-      * the next pass' (B) -- its encoder, uploads, loop preparation -- is queued right behind this pass' tail, BEFORE this
-        pass' (D): the wait for the scores and the list building happen under the next encoder's kernels.
+      * the next pass' (B) -- its uploads, encoder, loop preparation -- is queued right behind this pass' tail, and its token
+        loop too, BEFORE this pass' (D): the wait for the scores and the list building happen under the next loop's kernels.
     Tried on this runtime (ROCm 7.2, graph packet capture off) and measured worse -- profiles/r5_las_pass_overlap.txt:
     the second pass' device work under the first pass' kernels (its replays, launched into a busy stream, cost 0.4-1.3 ms of
     host time each); both passes' token loops as one replayed graph (a pass' weights and projected encoder outputs,
@@ -179,14 +179,18 @@ def _run_stages(gens):
         return out
     next(gens[0])                                   # (A) of the first pass
     loop = next(gens[0])                            # (B) of the first pass
+    waiting = None                                  # the pass whose (D) is still to come
     for k, g in enumerate(gens):
         nxt = gens[k + 1] if k + 1 < len(gens) else None
         advance = next(nxt) if nxt is not None else None        # (A) of the next pass, as slices
         drive_token_loops([loop], between=advance)  # this pass' token loop queued
+        if waiting is not None:
+            out.append(next(waiting))               # (D) of the previous pass, under this pass' token loop
         next(g)                                     # (C)
         if nxt is not None:
             loop = next(nxt)                        # rest of the plan, then (B) of the next pass behind this pass' tail
-        out.append(next(g))                         # (D)
+        waiting = g
+    out.append(next(waiting))                       # (D) of the last pass
     return out
 
 
@@ -930,24 +934,34 @@ class Net(nn.Module):
             yield advance                                   # ---- (A) handed over
             advance(finish=True)
             plan = box["plan"]
+        def upload(plan, with_lists):
+            # ONE upload: the tokens, the permutation, the tail's index arrays (once the token loop is queued a copy waits for
+            # all of it) and the token loop's row lists
+            key = plan["key"]
+            arrays = {"tok": plan["tok"], "perm": plan["perm"], "key_t": key // n, "key_r": key % n, "inv": plan["inv"],
+                      "tgt": plan["pair_target"]}
+            if with_lists:
+                arrays.update(InputFeedRNNDecoder.loop_arrays(plan["lists"], plan["forks"]))
+            return _h2d_many(arrays, dev)
+        up = None
         if not encode_first:
             if make_tick is not None:                       # (a later pass' plan ran under the previous pass' token loop: its
                 _tick = make_tick()                         #  phase clock starts with its encoder)
+            # the upload BEFORE the encoder is queued: the copy waits for what the stream holds -- the previous pass' tail --
+            # instead of this pass' encoder, and the loop preparation that follows runs under the encoder's kernels
+            if share and "lists" in plan:
+                up = upload(plan, True)
             enc_hidden, enc_out = encode()
         _tick("encoder + host plan" if encode_first else "encoder")
         fused = owner is not None and self.decoder._fused_ok(enc_out)
         if share and not fused:
-            plan, share = make_plan(False), False
+            plan, share, up = make_plan(False), False, None
         L, ntok, perm, tok, first, end, forks, row_steps = (plan[k] for k in
                                                             ("L", "ntok", "perm", "tok", "first", "end", "forks", "row_steps"))
-        key, inv, tgt = plan["key"], plan["inv"], plan["pair_target"]
-        # ONE upload: the tokens, the permutation, the tail's index arrays (once the token loop is queued a copy waits for all
-        # of it) and the token loop's row lists
-        arrays = {"tok": tok, "perm": perm, "key_t": key // n, "key_r": key % n, "inv": inv, "tgt": tgt}
+        key = plan["key"]
         lists = plan.get("lists") if (fused and enc_out.shape[1] == n_utt) else None
-        if lists is not None:
-            arrays.update(InputFeedRNNDecoder.loop_arrays(lists, forks))
-        up = _h2d_many(arrays, dev)
+        if up is None or lists is None:
+            up = upload(plan, lists is not None)
         tok_d, key_t, key_r, inv_d, tgt_d = up["tok"], up["key_t"], up["key_r"], up["inv"], up["tgt"]
         own = owner[up["perm"].to(owner.device)]
         _tick("host prep + uploads")
