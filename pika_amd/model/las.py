@@ -895,7 +895,14 @@ class Net(nn.Module):
             yield
             # the (step, hypothesis) pairs that exist, the (step, row) each one reads, the token each one predicts; the
             # distinct (step, row) pairs are what the tail projects onto the vocabulary
-            plan["key"], plan["inv"] = np.unique(plan["pair_step"] * n + plan["pair_row"], return_inverse=True)
+            # (np.unique over the ~48 k pairs without its sort: the distinct (step, row) pairs are the cells first[r] <= t <
+            #  end[r] of the (step, row) table -- every cell is read by the hypothesis that owns the row -- and a pair finds its
+            #  cell's rank by a running count)
+            t_col = np.arange(plan["L"])[:, None]
+            cells = (t_col >= plan["first"][None, :]) & (t_col < plan["end"][None, :])
+            plan["key"] = np.flatnonzero(cells.ravel())
+            rank = np.cumsum(cells.ravel()) - 1
+            plan["inv"] = rank[plan["pair_step"] * n + plan["pair_row"]]
             yield
             if n_utt is not None:                           # the token loop's row lists (the fused loop takes them)
                 plan["lists"] = InputFeedRNNDecoder.step_lists(owner_host[plan["perm"]], (plan["first"], plan["end"]),

@@ -107,3 +107,19 @@ def test_scoring_plan_equals_the_per_hypothesis_form(share, B, nb, U, V):
                 assert g.dtype == w.dtype and np.array_equal(w, g)
         else:
             assert got["forks"] is None
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_distinct_step_row_cells_are_what_np_unique_finds(share):
+    """Net._score_stages takes the distinct (step, row) pairs of a plan -- what the tail projects onto the vocabulary -- from
+    the rows' spans instead of sorting the pairs: same keys in the same order, same inverse."""
+    from pika_amd.model.las import scoring_plan
+    for seed in range(6):
+        flat, own = _nbest_lists(seed, 5, 7, 9, 20)
+        n = len(flat)
+        p = scoring_plan(flat, own, 21, 22, 23, share)
+        key, inv = np.unique(p["pair_step"] * n + p["pair_row"], return_inverse=True)
+        t_col = np.arange(p["L"])[:, None]
+        cells = (t_col >= p["first"][None, :]) & (t_col < p["end"][None, :])
+        assert np.array_equal(key, np.flatnonzero(cells.ravel()))
+        assert np.array_equal(inv.reshape(-1), (np.cumsum(cells.ravel()) - 1)[p["pair_step"] * n + p["pair_row"]])
