@@ -565,12 +565,19 @@ class InputFeedRNNDecoder(nn.Module):
         first = np.zeros(N, np.int64) if spans is None else np.asarray(spans[0], np.int64)
         end = np.full(N, L, np.int64) if spans is None else np.asarray(spans[1], np.int64)
         f_o, e_o = first[by_owner], end[by_owner]
-        lists = [by_owner[(f_o <= t) & (t < e_o)] for t in range(L)]
-        n_act = np.asarray([len(x) for x in lists], np.int32)
+        if not (N and L):
+            return {"n_act": np.zeros(L, np.int32), "qoff": np.zeros(L + 1, np.int32), "qlist": np.zeros(0, np.int32),
+                    "uoff": np.zeros((L, B + 1), np.int32)}
+        # all steps at once (a Python loop over the steps -- a mask, a gather and a searchsorted each -- was 1 ms of a plan):
+        # cells[t, j] = row by_owner[j] is active at step t; a step's list = its active rows in utterance order; an
+        # utterance's offset in it = the active rows of the utterances before it (a running count up to its first row)
+        t_col = np.arange(L)[:, None]
+        cells = (f_o[None, :] <= t_col) & (t_col < e_o[None, :])
+        n_act = cells.sum(1).astype(np.int32)
         qoff = np.concatenate([[0], np.cumsum(n_act)]).astype(np.int32)
-        qlist = np.concatenate(lists).astype(np.int32) if N and L else np.zeros(0, np.int32)
-        uoff = (np.stack([np.searchsorted(own_h[x], np.arange(B + 1)) for x in lists]).astype(np.int32) if L
-                else np.zeros((0, B + 1), np.int32))
+        qlist = np.broadcast_to(by_owner, (L, N))[cells].astype(np.int32)
+        run = np.concatenate([np.zeros((L, 1), np.int64), np.cumsum(cells, axis=1)], axis=1)      # (L, N + 1)
+        uoff = run[:, np.searchsorted(np.asarray(own_h)[by_owner], np.arange(B + 1))].astype(np.int32)
         return {"n_act": n_act, "qoff": qoff, "qlist": qlist, "uoff": uoff}
 
     @staticmethod
