@@ -16,6 +16,7 @@ from . import ops
 # False: the library's recurrence (MIOpen), layer by layer (pika_amd/model/transducer.py::_lstm_forward)
 PERSISTENT = True
 _WORK = {}
+_RETIRED = []      # outgrown scratch buffers (kept: _work)
 _CUS = {}
 
 
@@ -52,6 +53,11 @@ def _work(device, nbytes, backward):
     key = (device.index, backward)
     w = _WORK.get(key)
     if w is None or w.numel() < nbytes:
+        if w is not None:
+            # a captured training step (pika_amd/train_graph.py) may hold this buffer's address: it stays alive, and the
+            # next one is sized so that this does not happen often
+            _RETIRED.append(w)
+            nbytes = max(nbytes, w.numel() + w.numel() // 2)
         w = _WORK[key] = torch.full((nbytes,), 255, dtype=torch.uint8, device=device)
     return w
 
