@@ -135,3 +135,29 @@ def test_backward_scratch_is_left_as_a_memset_leaves_it():
         w = lstm._WORK[(0, True)]
         assert lstm.status() == 0
         assert bool((w[256:] == 255).all()), (B, S, H)
+
+
+def test_no_grad_forward_and_growing_shapes_keep_earlier_scratch_alive():
+    """Evaluation (no autograd) takes the same launch; a larger shape later gets a larger scratch while the outgrown one
+    stays allocated (a captured training step may hold its address)."""
+    from pika_amd import gemm as G
+    from pika_amd.model import lstm, transducer
+    ref = _nets(100, 512, 2, seed=9).eval()
+    old = G.PRECISION
+    G.PRECISION = "mixed"
+    try:
+        with torch.no_grad():
+            x = torch.randn(4, 6, 100, device="cuda")
+            assert lstm.applies(ref, x)
+            got = transducer._lstm_forward(ref, x)
+            assert _rel(got, ref(x)[0]) < 2e-4
+            first = lstm._WORK[(0, True)]
+            big = torch.randn(33, 40, 100, device="cuda")
+            got = transducer._lstm_forward(ref, big)
+            assert _rel(got, ref(big)[0]) < 2e-4
+        now = lstm._WORK[(0, True)]
+        if now is not first:
+            assert any(w is first for w in lstm._RETIRED) and now.numel() >= first.numel() + first.numel() // 2
+        assert lstm.status() == 0
+    finally:
+        G.PRECISION = old
