@@ -97,7 +97,7 @@ int pika_rnnt_export_lattice(const void *workspace, const int *frames_lengths,
  * layer that produced the logits, without another pass over `out`.
  * lse (rows floats) non-NULL: `log_probs` holds the RAW logits and lse their per-row log-sum-exp (as written by
  * pika_rnnt_fused_forward) -- the log-probabilities never have to exist (scale must then be 1).
- * V % 4 == 0, V <= 5120, ld_out % 4 == 0. */
+ * V % 4 == 0, V <= 8192, ld_out % 4 == 0 (a wave covers a row in 64 x 4 x 20 columns up to 5120, x 32 beyond). */
 int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, const void *workspace, int B, int T,
                                    int U1, int V, int blank, void *out, long long ld_out, float scale,
                                    float *colsum, void *stream);
@@ -132,7 +132,7 @@ int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, 
 
 /* Fused boundary logits -> (costs, d loss / d logits)  (SURVEY.md 8d M1'): replaces
  * F.log_softmax (trainer/model/transducer.py:111) + the loss + the log-softmax backward for a caller that owns
- * the joint output.  `logits` (B,T,U1,V) f32 are the RAW fc2 outputs, V % 4 == 0, V <= 5120; lse (B*T*U1) f32
+ * the joint output.  `logits` (B,T,U1,V) f32 are the RAW fc2 outputs, V % 4 == 0, V <= 8192; lse (B*T*U1) f32
  * receives the per-row log-sum-exp and must be handed to the backward together with the same logits and
  * workspace.  grad_logits: f32 (out_dtype 0, ld_out >= V) or bf16 (out_dtype 1; columns [V, ld_out) zeroed).
  * Traffic 3 x B*T*U1*V*4 bytes (one read for lse + gather, one read + one write for the gradient) against

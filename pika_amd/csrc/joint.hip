@@ -222,7 +222,9 @@ __global__ __launch_bounds__(ROW_THREADS) void log_softmax_bwd_kernel(const floa
 
 // ---- wave-per-row variants: no workgroup barriers, 4 rows in flight per workgroup; row held in
 // registers (cols <= 64 lanes * 4 * WQ floats) -------------------------------------------------
-constexpr int WQ = 20;  // float4 per lane -> up to 5120 columns
+// WQ float4 per lane: 20 -> up to 5120 columns (the benchmarked V = 5000), 32 -> up to 8192 (the shipped recipes' V = 6268)
+constexpr int WQ_MAX = 32;
+#define PIKA_WQ(extent, CALL) do { if ((extent) <= 64 * 4 * 20) { constexpr int WQ = 20; CALL; } else { constexpr int WQ = 32; CALL; } } while (0)
 
 __device__ inline float wave_red(float v, bool is_max) {
 #pragma unroll
@@ -233,6 +235,7 @@ __device__ inline float wave_red(float v, bool is_max) {
     return v;
 }
 
+template <int WQ>
 __global__ __launch_bounds__(256) void log_softmax_wave_kernel(float *__restrict__ x, long long rows,
                                                                int cols, long long ld, float scale) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(256) void log_softmax_wave_kernel(float *__restrict
         if (lane + q * 64 < c4) row[lane + q * 64] = v[q] - lse;
 }
 
+template <int WQ>
 __global__ __launch_bounds__(256) void log_softmax_bwd_wave_kernel(const float *__restrict__ lp,
                                                                    float *__restrict__ g, long long rows,
                                                                    int cols, long long ld, float scale) {
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_wave_kernel(const float *
         }
 }
 
+template <int WQ>
 __global__ __launch_bounds__(256) void log_softmax_bwd_bf16_kernel(const float *__restrict__ lp,
                                                                    const float *__restrict__ g,
                                                                    __bf16 *__restrict__ out, long long rows,
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_bf16_kernel(const float *
 }
 
 inline bool wave_row_ok(const void *a, const void *b, int cols, long long ld) {
-    return (cols & 3) == 0 && (ld & 3) == 0 && cols <= 64 * 4 * WQ &&
+    return (cols & 3) == 0 && (ld & 3) == 0 && cols <= 64 * 4 * WQ_MAX &&
            ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 
@@ -399,8 +404,8 @@ int pika_log_softmax_rows(float *x, long long rows, int cols, long long ld, floa
     if (!x || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
     if (wave_row_ok(x, x, cols, ld))
-        hipLaunchKernelGGL(log_softmax_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), x, rows, cols, ld, scale);
+        PIKA_WQ(cols, hipLaunchKernelGGL(log_softmax_wave_kernel<WQ>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), x, rows, cols, ld, scale));
     else
         hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
                            static_cast<hipStream_t>(stream), x, cols, ld, scale);
@@ -412,8 +417,8 @@ int pika_log_softmax_bwd_rows(const float *lp, float *g, long long rows, int col
     if (!lp || !g || rows <= 0 || cols <= 0 || ld < cols) return PIKA_EINVAL;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
     if (wave_row_ok(lp, g, cols, ld))
-        hipLaunchKernelGGL(log_softmax_bwd_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), lp, g, rows, cols, ld, scale);
+        PIKA_WQ(cols, hipLaunchKernelGGL(log_softmax_bwd_wave_kernel<WQ>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), lp, g, rows, cols, ld, scale));
     else
         hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0,
                            static_cast<hipStream_t>(stream), lp, g, cols, ld, scale);
@@ -433,13 +438,13 @@ int pika_log_softmax_bwd_rows_bf16(const float *lp, const float *g, void *out, l
                                    int cols, long long ld, long long ld_out, float scale,
                                    void *stream) {
     if (!lp || !g || !out || rows <= 0 || cols <= 0 || ld < cols || ld_out < cols) return PIKA_EINVAL;
-    if (!wave_row_ok(lp, g, cols, ld) || (ld_out & 3) || ld_out > 64 * 4 * WQ ||
+    if (!wave_row_ok(lp, g, cols, ld) || (ld_out & 3) || ld_out > 64 * 4 * WQ_MAX ||
         (reinterpret_cast<uintptr_t>(out) & 7))
         return PIKA_EINVAL;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
-    hipLaunchKernelGGL(log_softmax_bwd_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), lp, g, static_cast<__bf16 *>(out), rows, cols,
-                       ld, ld_out, scale);
+    PIKA_WQ(ld_out, hipLaunchKernelGGL(log_softmax_bwd_bf16_kernel<WQ>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                       static_cast<hipStream_t>(stream), lp, g, static_cast<__bf16 *>(out), rows, cols,
+                                       ld, ld_out, scale));
     return (int)hipGetLastError();
 }
 

@@ -490,8 +490,11 @@ void launch_ab(const Lattice &L, const int *Tn, const int *Un, float *costs, int
 // d(logits) of log_softmax(scale * logits) under the RNN-T gradient WITHOUT reading the dense gradient:
 // row r of it has at most two non-zeros, kept in meta[r] by the backward call; with s = gb + ge
 //   out[r, v] = scale * ((v == blank) * gb + (v == ye) * ge - exp(lp[r, v]) * s)      (bf16, zero-padded)
-// One wavefront per row (V <= 64*4*CQ, V % 4 == 0), 16-byte loads, 8-byte stores.
-constexpr int CQ = 20;
+// One wavefront per row (V <= 64*4*CQ, V % 4 == 0), 16-byte loads, 8-byte stores.  CQ = 20 (V <= 5120: the 80 row
+// registers the benchmarked V = 5000 needs) or 32 (V <= 8192: the shipped recipes' own vocabulary is 6268,
+// egs/train_transducer_bmuf_otfaug.sh:37).
+constexpr int CQ_MAX = 32, V_MAX = 64 * 4 * CQ_MAX;
+#define PIKA_CQ(extent, CALL) do { if ((extent) <= 64 * 4 * 20) { constexpr int CQ = 20; CALL; } else { constexpr int CQ = 32; CALL; } } while (0)
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -505,7 +508,7 @@ typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
 __device__ inline f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ inline f32x4 ld4(const _Float16 *p) { return __builtin_convertvector(*reinterpret_cast<const ch16x4 *>(p), f32x4); }
 
-template <bool COLSUM, typename TI = float>
+template <bool COLSUM, typename TI, int CQ>
 __global__ __launch_bounds__(256) void rnnt_dlogits_compact_kernel(const TI *__restrict__ lp,
                                                                    const RowMeta *__restrict__ meta,
                                                                    __bf16 *__restrict__ out, long long rows,
@@ -655,6 +658,10 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const TI *__
                 }
             }
             if (c < V) {
+                if (c + 8 > V) {            // V % 8 == 4: the last granule holds four columns and four of the pitch's padding
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = c + e < V ? o[e] : 0.f;
+                }
                 cbf16x8 w;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) w[e] = (__bf16)o[e];
@@ -708,7 +715,8 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_compact8_kernel(const TI *__
         if (any && wave == 0 && c < V) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                atomicAdd(colsum + c + e, (red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e]));
+                if (c + e < V)
+                    atomicAdd(colsum + c + e, (red[0][lane][e] + red[1][lane][e]) + (red[2][lane][e] + red[3][lane][e]));
         }
     }
     if (cs_blank != 0.f) atomicAdd(colsum + blank, cs_blank);
@@ -748,6 +756,7 @@ __device__ inline float fwave_sum(float v) {
     return v;
 }
 
+template <int CQ>
 __global__ __launch_bounds__(256) void rnnt_lse_gather_kernel(
     const float *__restrict__ logits, const int *__restrict__ labels, const int *__restrict__ Tn_,
     const int *__restrict__ Un_, long long rows, int T, int U1, int V, int blank, float *__restrict__ lse,
@@ -859,7 +868,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_merge_gather_kernel(
     lpe[o] = ve;
 }
 
-template <typename TO>
+template <typename TO, int CQ>
 __global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__restrict__ logits,
                                                                  const float *__restrict__ lse,
                                                                  const RowMeta *__restrict__ meta,
@@ -1005,7 +1014,7 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
     if (!log_probs || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
         blank >= V)
         return PIKA_EINVAL;
-    if ((V & 3) || V > 64 * 4 * CQ || ld_out < V || (ld_out & 3) || ld_out > 64 * 4 * CQ ||
+    if ((V & 3) || V > V_MAX || ld_out < V || (ld_out & 3) || ld_out > V_MAX ||
         (reinterpret_cast<uintptr_t>(log_probs) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
         return PIKA_EINVAL;
     const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
@@ -1021,20 +1030,21 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
         const int rpw = rpw_env > 0 ? rpw_env : (rows >= (1 << 18) ? 64 : 4);
         const long long per_block = 4LL * rpw;
         static const bool wide_off = pika_knob("PIKA_DLOGITS_NARROW") != nullptr;     // A/B: the 4-column kernel
-        if (!wide_off && !(V & 7) && !(ld_out & 7) && V > 512 * 9 && ld_out <= 512 * 10 &&
-            !(reinterpret_cast<uintptr_t>(out) & 15)) {
-            hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<10, float>), dim3((unsigned)((rows + per_block - 1) / per_block)),
-                               dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
-                               scale, rpw, colsum, lse, 0LL);
+        if (!wide_off && !(V & 7) && !(ld_out & 7) && V > 512 * 9 && !(reinterpret_cast<uintptr_t>(out) & 15)) {
+#define PIKA_C8(NIT) hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<NIT, float>), dim3((unsigned)((rows + per_block - 1) / per_block)), \
+                                        dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale,  \
+                                        rpw, colsum, lse, 0LL)
+            if (ld_out <= 512 * 10) PIKA_C8(10); else if (ld_out <= 512 * 13) PIKA_C8(13); else PIKA_C8(16);
+#undef PIKA_C8
             return (int)hipGetLastError();
         }
-        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, float>), dim3((unsigned)((rows + per_block - 1) / per_block)),
-                           dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
-                           scale, rpw, colsum, lse, 0LL);
+        PIKA_CQ(ld_out, hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, float, CQ>),
+                                           dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, s, log_probs, L.meta,
+                                           static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw, colsum, lse, 0LL));
     } else {
-        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, float>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
-                           log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
-                           static_cast<float *>(nullptr), lse, 0LL);
+        PIKA_CQ(ld_out, hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, float, CQ>), dim3((unsigned)((rows + 3) / 4)),
+                                           dim3(256), 0, s, log_probs, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank,
+                                           scale, 1, static_cast<float *>(nullptr), lse, 0LL));
     }
     return (int)hipGetLastError();
 }
@@ -1045,13 +1055,13 @@ int pika_rnnt_fused_forward(const float *logits, const int *labels, const int *f
     if (int rc = check_dims(B, T, U1, V, blank)) return rc;
     if (!logits || !frames_lengths || !labels_lengths || !costs || !lse || !workspace) return PIKA_EINVAL;
     if (U1 > 1 && !labels) return PIKA_EINVAL;
-    if ((V & 3) || V > 64 * 4 * CQ || (reinterpret_cast<uintptr_t>(logits) & 15)) return PIKA_EINVAL;
+    if ((V & 3) || V > V_MAX || (reinterpret_cast<uintptr_t>(logits) & 15)) return PIKA_EINVAL;
     const long long rows = (long long)B * T * U1;
     if (rows > 0x7fffffffLL) return PIKA_ETOOBIG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Lattice L = carve(workspace, B, T, U1);
-    hipLaunchKernelGGL(rnnt_lse_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, labels,
-                       frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe, L.Wp, L.D);
+    PIKA_CQ(V, hipLaunchKernelGGL(rnnt_lse_gather_kernel<CQ>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, labels,
+                                  frames_lengths, labels_lengths, rows, T, U1, V, blank, lse, L.lpb, L.lpe, L.Wp, L.D));
     return run_alpha_beta(L, frames_lengths, labels_lengths, costs, B, T, U1, s);
 }
 
@@ -1102,7 +1112,7 @@ int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, 
     if (!logits16 || !lse || !workspace || !out || B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024 || V <= 0 || blank < 0 ||
         blank >= V)
         return PIKA_EINVAL;
-    if ((V & 3) || V > 64 * 4 * CQ || ld_out < V || (ld_out & 3) || ld_out > 64 * 4 * CQ || ld_in < V || (ld_in & 3) ||
+    if ((V & 3) || V > V_MAX || ld_out < V || (ld_out & 3) || ld_out > V_MAX || ld_in < V || (ld_in & 3) ||
         (reinterpret_cast<uintptr_t>(logits16) & 7) || (reinterpret_cast<uintptr_t>(out) & 7))
         return PIKA_EINVAL;
     const Lattice L = carve(const_cast<void *>(workspace), B, T, U1);
@@ -1115,20 +1125,24 @@ int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, 
         if (e != hipSuccess) return (int)e;
         const int rpw = rows >= (1 << 18) ? 64 : 4;
         const long long per_block = 4LL * rpw;
-        if (!(V & 7) && !(ld_out & 7) && !(ld_in & 7) && V > 512 * 9 && ld_out <= 512 * 10 &&
-            !(reinterpret_cast<uintptr_t>(out) & 15) && !(reinterpret_cast<uintptr_t>(logits16) & 15)) {
-            hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<10, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)),
-                               dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw,
-                               colsum, lse, ld_in, gathered, g_labels, g_blank, T, U1);
+        // (V % 8 == 4 -- the shipped recipes' 6268 -- rides on a 16-bit pitch of whole granules: the last one is masked)
+        if (!(ld_out & 7) && !(ld_in & 7) && ld_in >= ((V + 7) & ~7) && V > 512 * 9 && !(reinterpret_cast<uintptr_t>(out) & 15) &&
+            !(reinterpret_cast<uintptr_t>(logits16) & 15)) {
+#define PIKA_C8(NIT) hipLaunchKernelGGL((rnnt_dlogits_compact8_kernel<NIT, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)), \
+                                        dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw, colsum,  \
+                                        lse, ld_in, gathered, g_labels, g_blank, T, U1)
+            if (ld_out <= 512 * 10) PIKA_C8(10); else if (ld_out <= 512 * 13) PIKA_C8(13); else PIKA_C8(16);
+#undef PIKA_C8
             return (int)hipGetLastError();
         }
-        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, _Float16>), dim3((unsigned)((rows + per_block - 1) / per_block)),
-                           dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw, colsum,
-                           lse, ld_in, gathered, g_labels, g_blank, T, U1);
+        PIKA_CQ(ld_out, hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<true, _Float16, CQ>),
+                                           dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(256), 0, s, x, L.meta,
+                                           static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, rpw, colsum, lse, ld_in,
+                                           gathered, g_labels, g_blank, T, U1));
     } else {
-        hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, _Float16>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
-                           x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
-                           static_cast<float *>(nullptr), lse, ld_in, gathered, g_labels, g_blank, T, U1);
+        PIKA_CQ(ld_out, hipLaunchKernelGGL((rnnt_dlogits_compact_kernel<false, _Float16, CQ>), dim3((unsigned)((rows + 3) / 4)),
+                                           dim3(256), 0, s, x, L.meta, static_cast<__bf16 *>(out), rows, V, ld_out, blank, scale, 1,
+                                           static_cast<float *>(nullptr), lse, ld_in, gathered, g_labels, g_blank, T, U1));
     }
     return (int)hipGetLastError();
 }
@@ -1140,7 +1154,7 @@ int pika_rnnt_fused_backward(const float *logits, const float *lse, const int *l
     if (int rc = check_dims(B, T, U1, V, blank)) return rc;
     if (!logits || !lse || !frames_lengths || !labels_lengths || !workspace || !grad_logits) return PIKA_EINVAL;
     if (U1 > 1 && !labels) return PIKA_EINVAL;
-    if ((V & 3) || V > 64 * 4 * CQ || ld_out < V || (ld_out & 3) || ld_out > 64 * 4 * CQ ||
+    if ((V & 3) || V > V_MAX || ld_out < V || (ld_out & 3) || ld_out > V_MAX ||
         (reinterpret_cast<uintptr_t>(logits) & 15))
         return PIKA_EINVAL;
     if (out_dtype != 0 && out_dtype != 1) return PIKA_EINVAL;   // PIKA_F32 / PIKA_BF16 (pika_gemm.h)
@@ -1154,11 +1168,11 @@ int pika_rnnt_fused_backward(const float *logits, const float *lse, const int *l
                        L.alpha, L.beta, L.off_a, L.off_b, L.ll, L.Wp, L.D, L.meta);
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (out_dtype == 0)
-        hipLaunchKernelGGL(rnnt_dlogits_fused_kernel<float>, grid, dim3(256), 0, s, logits, lse, L.meta,
-                           static_cast<float *>(grad_logits), rows, V, ld_out, blank);
+        PIKA_CQ(ld_out, hipLaunchKernelGGL((rnnt_dlogits_fused_kernel<float, CQ>), grid, dim3(256), 0, s, logits, lse, L.meta,
+                                           static_cast<float *>(grad_logits), rows, V, ld_out, blank));
     else
-        hipLaunchKernelGGL(rnnt_dlogits_fused_kernel<__bf16>, grid, dim3(256), 0, s, logits, lse, L.meta,
-                           static_cast<__bf16 *>(grad_logits), rows, V, ld_out, blank);
+        PIKA_CQ(ld_out, hipLaunchKernelGGL((rnnt_dlogits_fused_kernel<__bf16, CQ>), grid, dim3(256), 0, s, logits, lse, L.meta,
+                                           static_cast<__bf16 *>(grad_logits), rows, V, ld_out, blank));
     return (int)hipGetLastError();
 }
 

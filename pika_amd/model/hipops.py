@@ -18,6 +18,7 @@ import torch
 
 from .. import _lib
 from .. import gemm as G
+from ..rnnt import MAX_FUSED_V
 
 
 # Module switches (tests flip them; no environment variable): the joint's log-sum-exp partials from the fc2 epilogue, the
@@ -479,11 +480,12 @@ class LogSoftmaxFn(torch.autograd.Function):
 
 def joint_out_ok(h, weight):
     """JointOutFn preconditions: bf16 hidden, reduction a multiple of 64, vocabulary a multiple of
-    8 (16-byte bf16 granules of the d(logits) copy) that one wave covers (log-softmax row kernels)."""
+    4 (8-byte bf16 groups of the d(logits) copy; the 16-bit logits of a vocabulary that is not a multiple of 8 -- the
+    shipped recipes' 6268 -- get a pitch of whole 16-byte granules) that one wave covers (log-softmax row kernels)."""
     N, K = weight.shape
-    # N <= 5120: what the d(logits) kernels of the backward take (one wave holds a 64-padded row: 64 x 4 x 20 columns)
-    return (G.joint_in_bf16() and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 8 == 0
-            and N <= 5120)
+    # N <= 8192: what the d(logits) kernels of the backward take (one wave holds a 64-padded row: 64 x 4 x 32 columns)
+    return (G.joint_in_bf16() and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0
+            and N <= MAX_FUSED_V)
 
 
 class JointOutFn(torch.autograd.Function):
@@ -506,9 +508,9 @@ class JointOutFn(torch.autograd.Function):
         ctx.scale = float(scale)
         ctx.has_bias = bias is not None
         ctx.state = None
-        # (N <= 5120: what the loss' fused path and the compact d(logits) kernels take; beyond, the fp16 copy would only be
+        # (N <= 8192: what the loss' fused path and the compact d(logits) kernels take; beyond, the fp16 copy would only be
         # followed by a second, fp32 run of the product for the loss -- ADVICE r4)
-        if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and 256 < N <= 5120 and N % 8 == 0
+        if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and 256 < N <= MAX_FUSED_V and N % 4 == 0
                 and labels.dim() == 2 and labels.shape == (h.shape[0], h.shape[2] - 1)
                 and JOINT_LSE_EPILOGUE and JOINT_F16_LOGITS):
             # 16-bit logits: the (B,T,U1,V) lattice -- the largest tensor of a training step -- is written ONCE as fp16
@@ -520,7 +522,10 @@ class JointOutFn(torch.autograd.Function):
             from ..rnnt import LazyLogProbs, LogitsState
             B_, T_, U1_ = h.shape[0], h.shape[1], h.shape[2]
             M = h2.shape[0]
-            out16 = torch.empty(h.shape[:-1] + (N,), dtype=torch.float16, device=h.device)
+            Nld = (N + 7) & ~7          # rows of whole 16-byte granules
+            out16 = torch.empty(h.shape[:-1] + (Nld,), dtype=torch.float16, device=h.device)
+            if Nld != N:
+                out16 = out16[..., :N]
             n_part = (N + 255) // 256 * 4
             part = torch.empty((2, M, n_part), dtype=torch.float32, device=h.device)
             gath = torch.empty((M, 2), dtype=torch.float32, device=h.device)
@@ -528,7 +533,7 @@ class JointOutFn(torch.autograd.Function):
             wb = weight.detach().to(torch.bfloat16)
             with torch.cuda.device(h.device):
                 _lib.check(_lib.lib().pika_gemm_bf16_nt_lse_f16(
-                    h2.data_ptr(), h2.stride(0), wb.data_ptr(), wb.stride(0), out16.data_ptr(), N, M, N, K,
+                    h2.data_ptr(), h2.stride(0), wb.data_ptr(), wb.stride(0), out16.data_ptr(), Nld, M, N, K,
                     None if bias is None else bias.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), n_part,
                     lab32.data_ptr(), T_, U1_, 0, gath.data_ptr(), _stream()), "pika_gemm_bf16_nt_lse_f16")
             st = ctx.state = LogitsState(scale)
@@ -587,7 +592,7 @@ class JointOutFn(torch.autograd.Function):
         if isinstance(g, LazyDenseGrad):
             # the loss' own gradient, never written: its non-zeros are in the loss workspace.  (Once something has
             # made it dense, or when it does not fit the compact kernel, it is an ordinary tensor from here on.)
-            if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= 5120:
+            if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= MAX_FUSED_V:
                 compact = g.compact
                 if ctx.state is not None and ctx.state.raw:
                     lse = g.lse     # the loss read the raw logits `lp` still holds: log-prob = logit - lse
@@ -606,7 +611,7 @@ class JointOutFn(torch.autograd.Function):
             if not g.is_contiguous():
                 g = g.contiguous()
             c = getattr(g, "_pika_compact", None)
-            if c is not None and c.matches(g) and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= 5120:
+            if c is not None and c.matches(g) and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= MAX_FUSED_V:
                 compact = c
         dh = dw = db = None
         with torch.cuda.device(lp.device):
@@ -646,7 +651,10 @@ class JointOutFn(torch.autograd.Function):
                 dh = torch.empty(lp.shape[:-1] + (K,), dtype=torch.bfloat16, device=dl.device)
                 _gemm_epilogue(dl, wt, dh.view(-1, K), None, EPI_DROPOUT_BF16)
             if ctx.needs_input_grad[1]:
-                dw = _grad_weight(dl[:, :N], G.matrix(h2)[0], 8, M, K, N)
+                # (N % 8 != 0: over the padded columns of d(logits) -- zeros -- and the rows cut off: the in-place `trans`
+                # operands want whole 16-byte granules)
+                dw = _grad_weight(dl[:, :N], G.matrix(h2)[0], 8, M, K, N) if N % 8 == 0 else \
+                    _grad_weight(dl, G.matrix(h2)[0], 8, M, K, Np)[:N]
             if db_fused is not None:
                 db = db_fused           # column sums came out of the d(logits) kernel itself
             elif ctx.has_bias and ctx.needs_input_grad[2]:

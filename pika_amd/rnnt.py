@@ -26,6 +26,10 @@ from . import _lib
 # recorded on the launch stream (torch's current stream) so kernel time is measured live.
 KERNEL_EVENTS = None
 
+# widest vocabulary the fused lattice kernels take (include/pika_rnnt.h: one wave covers a row in 64 x 4 x 32 columns; the
+# benchmarked V = 5000 runs the 20-register instantiation, the recipes' 6268 the 32-register one)
+MAX_FUSED_V = 8192
+
 
 class _timed(object):
     def __init__(self, key):
@@ -237,7 +241,7 @@ class _RNNTLossFn(torch.autograd.Function):
         B, T, U1, V = log_probs.shape
         lse = None
         state = log_probs.state if isinstance(log_probs, LazyLogProbs) else None
-        if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= 5120
+        if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= MAX_FUSED_V
                                       and (state.gathered is None or state.partials is not None)):
             state = None
         if state is not None:
@@ -354,7 +358,7 @@ class _FusedLogitsLossFn(torch.autograd.Function):
 
 def rnnt_loss_from_logits(logits, labels, frames_lengths, labels_lengths, blank=0):
     """Per-utterance costs of log_softmax(logits) under the RNN-T loss, differentiable w.r.t. the logits,
-    without materialising the log-probabilities (V % 4 == 0, V <= 5120)."""
+    without materialising the log-probabilities (V % 4 == 0, V <= 8192)."""
     return _FusedLogitsLossFn.apply(logits, labels, frames_lengths, labels_lengths, blank)
 
 

@@ -87,9 +87,10 @@ def test_joint_output_fn(hip_device, M, V, H, scale):
         G.PRECISION = old
 
 
-@pytest.mark.parametrize("V", [40, 5000, 4616])
+@pytest.mark.parametrize("V", [40, 5000, 4616, 6268, 8192])
 def test_joint_backward_uses_compact_rnnt_gradient(hip_device, V):
-    """(V = 5000 / 4616 take the 8-column d(logits) kernel, 40 the 4-column one.)
+    """(V = 5000 / 4616 take the 8-column d(logits) kernel, 40 the 4-column one; 6268 -- the shipped recipes' vocabulary,
+    not a multiple of 8: the last granule is masked -- and 8192 take its 13- and 16-block instantiations.)
     log_probs from JointOutFn straight into the RNN-T loss: the joint backward recognises the loss' own
     dense gradient tensor and rebuilds d(logits) from the two non-zeros per row kept in the loss workspace
     (pika_rnnt_dlogits_compact_bf16) -- same parameter gradients as the dense path; any tensor that is
@@ -214,8 +215,8 @@ def test_lazy_log_probs_and_lazy_rnnt_gradient(hip_device, monkeypatch):
 
 
 def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
-    """ADVICE r1 (rnnt.py:232): vocabularies the lazy joint output cannot serve (V = 5128 > 5120: the d(logits)
-    kernels hold one 64-padded row per wave) must take the plain chain -- linear, log-softmax, loss -- end to end,
+    """ADVICE r1 (rnnt.py:232): vocabularies the lazy joint output cannot serve (V = 8200 > 8192: the d(logits)
+    kernels hold one 64-padded row per wave; round 6 widened them from 5120 for the recipes' V = 6268) must take the plain chain -- linear, log-softmax, loss -- end to end,
     and a LazyLogProbs that reaches the loss already normalised (read first) must be handed over as log-probs."""
     import torch.nn as nn
     from pika_amd import gemm as G
@@ -226,7 +227,7 @@ def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
     try:
         g = torch.Generator().manual_seed(11)
         B, T, U, H = 2, 5, 3, 64
-        for V, lazy_expected in ((5128, False), (5120, True)):
+        for V, lazy_expected in ((8200, False), (8192, True), (6268, True)):
             fc1, fcg, fc2 = nn.Linear(2 * H, H), nn.Linear(2 * H, H), nn.Linear(H, V)
             for m in (fc1, fcg, fc2):
                 m.to(hip_device)
@@ -263,7 +264,7 @@ def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
         G.PRECISION = old
 
 
-@pytest.mark.parametrize("V", [1000, 5000, 264])
+@pytest.mark.parametrize("V", [1000, 5000, 264, 6268])
 def test_log_sum_exp_from_the_output_gemm_epilogue(hip_device, monkeypatch, V):
     """The joint's output GEMM emits per-row partial (max, sum exp) pairs per 64-column block in its epilogue and the
     loss merges them (pika_gemm_bf16_nt_lse -> pika_rnnt_fused_forward_partials) instead of re-reading the lattice of
@@ -302,7 +303,7 @@ def test_log_sum_exp_from_the_output_gemm_epilogue(hip_device, monkeypatch, V):
         G.PRECISION = old
 
 
-@pytest.mark.parametrize("V", [5000, 1000, 264])
+@pytest.mark.parametrize("V", [5000, 1000, 264, 6268, 4612])
 def test_sixteen_bit_logits_keep_the_loss_in_fp32(hip_device, V):
     """JointOutFn with the lattice's labels (pika_gemm_bf16_nt_lse_f16): the (B,T,U1,V) logits exist only as fp16, yet
     * costs equal those of the fp32-logits path to fp32 rounding: log-sum-exp partials and the two logits per row the loss

@@ -207,7 +207,7 @@ def test_full_size_lattice_properties_and_sampled_parity(hip_device):
 
 
 @pytest.mark.parametrize("B,T,U,V,ragged", [(2, 9, 4, 40, True), (3, 50, 12, 5000, True), (1, 1, 0, 8, False),
-                                            (4, 120, 30, 1024, False)])
+                                            (4, 120, 30, 1024, False), (2, 30, 9, 6268, True), (1, 12, 5, 8192, False)])
 def test_fused_logits_loss_matches_log_softmax_plus_loss(hip_device, B, T, U, V, ragged):
     """pika_rnnt_fused_forward/backward (SURVEY 8d M1\': logits -> costs, d/dlogits, no log-prob tensor) vs
     the composition it replaces: torch.log_softmax -> RNNTLoss -> autograd."""
