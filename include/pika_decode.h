@@ -13,7 +13,7 @@
  * All state is int64 / f32 device memory laid out as pika_amd/decoder/beam_search.py keeps it.
  * Two launches: one wavefront per beam row (row top-K), then one workgroup per utterance (merge +
  * bookkeeping).  `cand_ws`: B*K*K*8 bytes of device scratch.
- * Requirements: K <= 64, V <= 5120, K*L*4 bytes <= 64 KiB; otherwise PIKA_ETOOBIG.
+ * Requirements: K <= 64, V <= 8192, K*L*4 bytes <= 64 KiB; otherwise PIKA_ETOOBIG.
  * `first` != 0 selects the reference's first-step branch (only row 0 competes, no score added).
  */
 #ifndef PIKA_DECODE_H

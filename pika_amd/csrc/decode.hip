@@ -17,7 +17,7 @@ namespace {
 
 constexpr float DEAD = -1e20f;
 constexpr long long EOS = -1;
-constexpr int MAXV = 5120, MAXK = 64, WAVES = 4;
+constexpr int MAXV = 8192, MAXK = 64, WAVES = 4;      // (the shipped recipes' vocabulary is 6268)
 
 struct Cand { float v; int idx; };
 
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WAVES * 64) void beam_row_topk_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rowid = blockIdx.x * WAVES + wave;
     if (rowid >= B * K) return;
-    float *x = reinterpret_cast<float *>(smem) + wave * MAXV;
+    float *x = reinterpret_cast<float *>(smem) + wave * ((V + 3) & ~3);      // (a row of logits per wave)
     const int b = rowid / K, k = rowid - b * K;
     const long long bk = (long long)b * K;
     Cand *out = cand + (long long)rowid * K;
@@ -877,7 +877,7 @@ extern "C" int pika_beam_advance(const float *logits, float sm_scale, int first,
     }
     Cand *cand = static_cast<Cand *>(cand_ws);
     hipLaunchKernelGGL(beam_row_topk_kernel, dim3((B * K + WAVES - 1) / WAVES), dim3(WAVES * 64),
-                       (size_t)WAVES * MAXV * 4, st, logits, sm_scale, first, scores, lm_scores, lm_scale,
+                       (size_t)WAVES * ((V + 3) & ~3) * 4, st, logits, sm_scale, first, scores, lm_scores, lm_scale,
                        y, hyp, hyp_len, L, B, K, V, beam_prune, cand);
     BeamState a{scores, lm_scores, lm_scale, y, t_idx, num_frames, max_len, hyp, hyp_len, L, ks_hist, ys_hist, step_t,
                 eos_top, fin_score, fin_step, fin_k, fin_n, fin_cap, prev_k_out, y_raw, B, K, V, blk};

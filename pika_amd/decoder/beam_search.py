@@ -248,9 +248,12 @@ class BeamState(object):
                     out[b, i] = -min(best.values())
         return out.to(self.device)
 
-    def fused_ok(self):
+    def fused_ok(self, chain=False):
+        """The one-launch advance of this class (pika_beam_advance: a row of logits per wave in LDS, V <= 8192); chain: the
+        launch chain of fused_step.FusedSearch, whose advance reads the logits thresholded and has no bound on V of its own
+        (pika_beam_advance_logits_lds says what it takes)."""
         return (self.device.type == "cuda" and (self.lm_scorer is None or self.fst_dev is not None) and self.K <= 64 and
-                self.K <= self.V <= 5120 and self.K * self.hyp.shape[2] * 4 <= 64 * 1024)
+                self.K <= self.V and (chain or self.V <= 8192) and self.K * self.hyp.shape[2] * 4 <= 64 * 1024)
 
     def advance_fused(self, logits, t_idx, num_frames, sm_scale, lm_scale, first):
         """The whole of `_advance` + the frame-index re-ordering in ONE HIP launch

@@ -67,7 +67,7 @@ def _stream():
 def supported(model, beam, K):
     """Conv-transformer or LSTM prediction net on a HIP device, shapes the kernels take."""
     dec = getattr(model, "decoder", None)
-    if dec is None or not beam.fused_ok():
+    if dec is None or not beam.fused_ok(chain=True):
         return False
     splits = _lib.lib().pika_dfc2_splits(model.output_dim)
     # the advance's LDS budget, as the library states it (include/pika_decode_step.h; 0 = the shape is not taken)

@@ -230,3 +230,45 @@ def test_results_extraction_equals_the_per_utterance_form():
                 assert isinstance(gh, list) and [int(e) for e in wh] == [e.item() for e in gh]
         for wr, gr in zip(want_s, got_s):
             assert [float(e) for e in wr] == [e.item() for e in gr]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dec", ["transformer", "rnn"])
+def test_gpu_launch_chain_at_the_recipes_vocabulary(hip_device, dec):
+    """V = 6268 (egs/train_transducer_bmuf_otfaug.sh:37; beyond the 5120 the one-launch advance used to stop at): the launch
+    chain of fused_step takes the search -- and returns the n-best lists of the tensor-op path."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from decoder.transducer_decoder import TransducerDecoder
+    from decoder.beam_transducer import GlobalScorer
+    from pika_amd import gemm as G
+    from pika_amd.model import transducer, encoder
+    V = 6268
+    torch.manual_seed(0)
+    opt = C.make_opt(dec)
+    opt.padding_idx = V
+    o2 = SimpleNamespace(**vars(opt))
+    o2.encoder_type, o2.enc_layers = "rnn", 1
+    net = transducer.Net(o2, C.D_IN, V)
+    net.encoder = encoder.Net(C.D_IN, 0, C.H, tdnn_nhid=C.NHID, tdnn_layers=C.LAYERS)
+    net.pack_seq = False
+    net.load_state_dict(seeded_state_dict(net, C.SEED))
+    D.tweak(net)
+    net = net.eval().to(hip_device)
+    old, G.PRECISION = G.PRECISION, "fp32"
+    try:
+        x, x_len = D.inputs()
+        x, xl = x.to(hip_device), x_len.to(hip_device)
+        for beam, nb in ((4, 4), (16, 16)):
+            outs = []
+            for chain in (True, False):
+                args = SimpleNamespace(las_rescorer=None, las_rescorer_bw=None, bilas_rescorer=None, nonblk_reward=0.0)
+                d = TransducerDecoder(net, 4, beam, n_best=nb, blk=0, global_scorer=GlobalScorer(), sm_scale=0.85, cuda=True,
+                                      beam_prune=True, args=args)
+                d.fused_step = chain
+                ret, _ = d.decode_batch(x, xl, [int(v) + 100 for v in x_len])
+                assert bool(d.timing.get("launches_per_step")) == chain, d.timing
+                outs.append(D.pack(ret["predictions"], ret["scores"]))
+            assert np.array_equal(outs[0]["hyps"], outs[1]["hyps"]), (dec, beam)
+            assert np.allclose(outs[0]["scores"], outs[1]["scores"], atol=2e-4), (dec, beam)
+    finally:
+        G.PRECISION = old
