@@ -41,7 +41,9 @@ call / where a non-finite value first appears.  Everything else is an argument o
 min_seen (2: a shape is captured the second time it appears after the warm-up -- a corpus whose batch lengths never recur
 stays eager instead of capturing every step), u_bucket (8: a batch rides on graphs whose label axis is up to 7 labels wider
 than its own, padded with the embedding's padding index), t_bucket (64: ... and whose time axis is up to 63 frames longer;
-0: exact frame counts only), freeze_salt (False; tests: keep the dropout salt word as it is), debug_sync (0; bit mask of
+0: exact frame counts only), bucket_capture (True: a bucket of t_bucket frames x u_bucket labels that has shown two different shapes
+gets a pair of graphs at its upper boundary -- corpora whose exact shapes never recur), freeze_salt (False; tests: keep the dropout
+salt word as it is), debug_sync (0; bit mask of
 host syncs around the replays: 1 before F, 2 after F, 4 before B, 8 after B -- profiles/r4_hip_graph_packet_capture.txt).
 """
 import collections
@@ -53,7 +55,8 @@ import torch
 from . import _lib
 
 _SALT = {"word": None, "users": 0}
-DEFAULTS = {"warmup": 2, "max_graphs": 4, "min_seen": 2, "u_bucket": 8, "t_bucket": 64, "freeze_salt": False, "debug_sync": 0}
+DEFAULTS = {"warmup": 2, "max_graphs": 4, "min_seen": 2, "u_bucket": 8, "t_bucket": 64, "freeze_salt": False, "debug_sync": 0,
+            "bucket_capture": True}
 
 
 def _salt_word(device):
@@ -101,6 +104,8 @@ class StepGraphs(object):
         self.t_bucket = max(0, int(D["t_bucket"]) if t_bucket is None else int(t_bucket))
         self.entries = collections.OrderedDict()        # key -> _Entry, least recently used first
         self.seen = {}
+        self.bucket_shapes = {}                         # bucket key -> the distinct (frames, labels) shapes it has shown
+        self.used_at = {}                               # entry key -> st.calls of its last replay
         self.calls = 0
         self.pool = None
         self.param_ptrs = None
@@ -116,6 +121,7 @@ class StepGraphs(object):
 
     def clear(self):
         self.entries.clear()
+        self.used_at.clear()
         self.last = None
 
     def close(self):
@@ -393,14 +399,35 @@ def forward(model, x, y, x_len, softmax):
         n = st.seen[key] = st.seen.get(key, 0) + 1
         if os.environ.get("PIKA_TRAIN_GRAPH_DEBUG") == "2":
             print("train_graph call %d: %s seen %d" % (st.calls, key[0:3:2], n), flush=True)
+        cx, cy = x, y
         if n < st.min_seen:
-            st.stats["eager"] += 1
-            return model._forward_eager(x, y, x_len, softmax)
+            # A corpus whose lengths vary from batch to batch shows an exact shape once: its batches fall into BUCKETS of
+            # t_bucket frames x u_bucket labels instead.  A bucket that has shown two different shapes (and min_seen
+            # batches) gets a pair of graphs at its upper boundary, which every later batch of the bucket rides padded --
+            # unless that would push out a pair that is still in use (more live buckets than max_graphs: the step then
+            # stays the eager launch sequence instead of re-capturing in circles).
+            bT = -(-T // st.t_bucket) * st.t_bucket if timed else T
+            bU = -(-U // st.u_bucket) * st.u_bucket if (pad is not None and y.dim() == 2) else U
+            shapes = st.bucket_shapes.setdefault(key_for(bT, bU), set())
+            shapes.add((T, U))
+            room = len(st.entries) < st.max_graphs or \
+                st.calls - st.used_at.get(next(iter(st.entries)), 0) > 8 * st.max_graphs
+            if not (DEFAULTS["bucket_capture"] and (bT, bU) != (T, U) and len(shapes) >= max(2, st.min_seen) and room):
+                st.stats["eager"] += 1
+                return model._forward_eager(x, y, x_len, softmax)
+            key, Tb, Ub = key_for(bT, bU), bT, bU
+            cx = x.new_zeros((x.shape[0], bT) + tuple(x.shape[2:]))
+            cx[:, :T] = x
+            cy = y.new_full((y.shape[0], bU), int(pad)) if bU != U else y
+            if bU != U:
+                cy[:, :U] = y
+            st.stats["bucket_captures"] = st.stats.get("bucket_captures", 0) + 1
         while len(st.entries) >= st.max_graphs:
-            st.entries.popitem(last=False)               # least recently used: its static outputs go back to the pool
+            old_key, _ = st.entries.popitem(last=False)  # least recently used: its static outputs go back to the pool
+            st.used_at.pop(old_key, None)
             st.stats["evictions"] += 1
         try:
-            e, why = _capture(model, st, key, x, y, x_len, t_valid=T if timed else None)
+            e, why = _capture(model, st, key, cx, cy, x_len, t_valid=T if timed else None)
         except Exception as err:                         # a launch the stream capture refuses, out of memory, ...
             e, why = None, "%s: %s" % (type(err).__name__, str(err).split("\n")[0])
         if e is None:
@@ -430,6 +457,7 @@ def forward(model, x, y, x_len, softmax):
         print("train_graph call %d: replay of %s for labels %s" % (st.calls, key[0:3:2], tuple(y.shape)), flush=True)
     e.gen += 1
     st.last = (e, e.gen)
+    st.used_at[key] = st.calls
     dbg_sync = int(DEFAULTS["debug_sync"])      # debugging: 1 before F, 2 after F, 4 before B, 8 after B
     if dbg_sync & 1:
         torch.cuda.synchronize()

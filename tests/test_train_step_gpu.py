@@ -549,6 +549,43 @@ def test_script_loop_with_varying_lengths_rides_on_padded_graphs(hip_device):
     assert torch.allclose(torch.tensor(got), torch.tensor(want), rtol=5e-4), (got, want)
 
 
+def test_script_loop_whose_exact_shapes_never_recur_gets_bucket_graphs(hip_device):
+    """A corpus whose lengths vary from batch to batch: no (frames, labels) shape appears twice, so no pair of graphs is
+    ever captured at a batch's own shape -- the bucket of 64 frames x 8 labels that has shown two shapes gets a pair at its
+    upper boundary (320 frames, 16 labels) and the later batches of the bucket ride it; another bucket gets its own pair;
+    the loss sequence equals the eager loop's."""
+    import copy
+    from pika_amd import gemm as G
+    from pika_amd import train_graph
+    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0, V=512)
+    ref = copy.deepcopy(model)
+    g = torch.Generator().manual_seed(47)
+    shapes = ((300, 10), (297, 9), (311, 12), (289, 11), (305, 13), (390, 20), (384, 19), (318, 10), (371, 22), (262, 14))
+    batches = [_batch(hip_device, g, 4, T, U, 512, pad_from=min(6, U - 1)) for T, U in shapes]
+    old, old_auto = G.PRECISION, train_graph.AUTO
+    G.PRECISION = "mixed"
+    fused_optim.install()
+    try:
+        train_graph.AUTO = False
+        want = _script_loop(ref, batches)
+        train_graph.AUTO = True
+        got = _script_loop(model, batches)
+        st = model._step_graphs
+        assert st.broken is None, st.broken
+        keys = sorted((k[0][1], k[2][1]) for k in st.entries)
+        # warm-up: batches 0, 1 (eager); bucket (320, 16): shapes 2, 3 -> captured at batch 3 (its second shape after the
+        # warm-up), ridden by 4, 7, 9; batch 5 (390 frames) is alone in bucket (448, 24); bucket (384, 24): 6, 8 -> captured at 8
+        assert keys == [(320, 16), (384, 24)], (keys, st.stats)
+        assert st.stats.get("bucket_captures") == 2 and st.stats["captures"] == 2, st.stats
+        assert st.stats["replays"] == 5 and st.stats["eager"] == 5 and st.stats.get("padded") == 3, st.stats
+        train_graph.disable(model)
+    finally:
+        train_graph.AUTO = old_auto
+        fused_optim.uninstall()
+        G.PRECISION = old
+    assert torch.allclose(torch.tensor(got), torch.tensor(want), rtol=5e-4), (got, want)
+
+
 def test_lazy_log_probs_switched_off_gives_the_same_training_steps(hip_device, monkeypatch):
     """PIKA_LAZY_LOGPROBS=0: the joint returns a plain (B,T,U+1,V) log-prob tensor (log-softmax pass, dense RNN-T gradient
     consumed by the log-softmax backward) instead of the lazy raw logits.  Both forms serve the script's loop -- the lazy
