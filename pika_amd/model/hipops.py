@@ -478,11 +478,13 @@ class LogSoftmaxFn(torch.autograd.Function):
         return g, None
 
 
-def joint_out_ok(h, weight):
-    """JointOutFn preconditions: bf16 hidden, reduction a multiple of 64, vocabulary a multiple of
+def joint_out_ok(h, weight, units=None):
+    """(units: the size of the output layer when it is not weight.shape[0] -- a layer about to be padded.)
+    JointOutFn preconditions: bf16 hidden, reduction a multiple of 64, vocabulary a multiple of
     4 (8-byte bf16 groups of the d(logits) copy; the 16-bit logits of a vocabulary that is not a multiple of 8 -- the
     shipped recipes' 6268 -- get a pitch of whole 16-byte granules) that one wave covers (log-softmax row kernels)."""
     N, K = weight.shape
+    N = N if units is None else int(units)
     # N <= 8192: what the d(logits) kernels of the backward take (one wave holds a 64-padded row: 64 x 4 x 32 columns)
     return (G.joint_in_bf16() and _fused() and h.dtype == torch.bfloat16 and K % 64 == 0 and N % 4 == 0
             and N <= MAX_FUSED_V)
@@ -502,12 +504,16 @@ class JointOutFn(torch.autograd.Function):
     compact_hits = 0   # times the backward used the loss' compact gradient (tests / diagnostics)
 
     @staticmethod
-    def forward(ctx, h, weight, bias, scale, lazy=False, labels=None):
+    def forward(ctx, h, weight, bias, scale, lazy=False, labels=None, width=None):
+        # width (lazy output only): the caller's vocabulary when `weight` / `bias` are its output layer padded to a
+        # multiple of four units (pika_amd.model.ops.joint): the lazy tensor returned stands for `width` columns
         N, K = weight.shape
         h2 = h.reshape(-1, K)
         ctx.scale = float(scale)
         ctx.has_bias = bias is not None
         ctx.state = None
+        ctx.width = None if width is None or int(width) == N else int(width)
+        assert ctx.width is None or (lazy and h.dim() == 4), "a padded output layer needs the lazy output"
         # (N <= 8192: what the loss' fused path and the compact d(logits) kernels take; beyond, the fp16 copy would only be
         # followed by a second, fp32 run of the product for the loss -- ADVICE r4)
         if (lazy and h.dim() == 4 and labels is not None and scale == 1.0 and 256 < N <= MAX_FUSED_V and N % 4 == 0
@@ -549,7 +555,7 @@ class JointOutFn(torch.autograd.Function):
                 return full
             st.recompute = recompute
             ctx.save_for_backward(h2, weight, out16)
-            return LazyLogProbs(st, out16)
+            return LazyLogProbs(st, out16, ctx.width)
         out = torch.empty(h.shape[:-1] + (N,), dtype=torch.float32, device=h.device)
         if lazy and out.dim() == 4:
             # the log-softmax pass is deferred until something needs the values (pika_amd.rnnt.LazyLogProbs);
@@ -572,7 +578,7 @@ class JointOutFn(torch.autograd.Function):
             else:
                 G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
             ctx.save_for_backward(h2, weight, out)
-            return LazyLogProbs(ctx.state, out)
+            return LazyLogProbs(ctx.state, out, ctx.width)
         G.gemm_bf16_nt(h2, weight.detach().to(torch.bfloat16), bias=bias, out=out.view(-1, N))
         ctx.save_for_backward(h2, weight, out)
         with torch.cuda.device(h.device):
@@ -592,12 +598,16 @@ class JointOutFn(torch.autograd.Function):
         if isinstance(g, LazyDenseGrad):
             # the loss' own gradient, never written: its non-zeros are in the loss workspace.  (Once something has
             # made it dense, or when it does not fit the compact kernel, it is an ordinary tensor from here on.)
-            if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.shape) and N <= MAX_FUSED_V:
+            # (the workspace is laid out for the columns the KERNELS saw: `lp`'s, also when the caller sees fewer -- ctx.width)
+            if g._dense is None and lp.dim() == 4 and tuple(lp.shape) == tuple(g.compact.dims[:4]) and N <= MAX_FUSED_V:
                 compact = g.compact
                 if ctx.state is not None and ctx.state.raw:
                     lse = g.lse     # the loss read the raw logits `lp` still holds: log-prob = logit - lse
             else:
                 g = g.dense()
+        if ctx.width is not None and compact is None:
+            # a dense gradient over the caller's columns: zeros for the padding units of the output layer
+            g = torch.nn.functional.pad(g.dense() if isinstance(g, LazyDenseGrad) else g, (0, N - ctx.width))
         lp16 = None
         if lp.dtype == torch.float16:      # 16-bit logits: only the compact gradient on the raw logits reads them ...
             if compact is not None and lse is not None:
@@ -661,7 +671,7 @@ class JointOutFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=dl.device)
                 _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
                            "pika_colsum_bf16")
-        return dh, dw, db, None, None, None
+        return dh, dw, db, None, None, None, None
 
 
 def attention_ok(q, k, v, heads, mask):

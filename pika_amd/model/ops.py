@@ -384,6 +384,22 @@ def joint(enc, pred, fc1, fc_gate, fc2, log_softmax=True, scale=1.0, labels=None
         eg = linear(enc, wge.contiguous(), fc_gate.bias)
         pg = linear(pred, wgp.contiguous())
         h = GateFn.apply(e1, p1, eg, pg)
+        lazy_on = None
+        if log_softmax and h.dim() == 4 and fc2.bias is not None and fc2.weight.shape[0] % 4 and \
+                joint_out_ok(h, fc2.weight, units=(fc2.weight.shape[0] + 3) & ~3):
+            # An output layer whose size is not a multiple of four: padded to the next one HERE, with a bias of -6e4 on the
+            # padding units (probability zero: log-sum-exp, costs and gradients are those of the layer itself), so that it
+            # takes the same kernels as any other; the lazy output stands for the layer's own columns.  (Without the lazy
+            # output -- PIKA_LAZY_LOGPROBS=0 -- such a layer runs the plain chain below.)
+            from ..rnnt import _lazy_enabled
+            lazy_on = _lazy_enabled() and os.environ.get("PIKA_LAZY_LOGPROBS", "1") != "0"
+            N = fc2.weight.shape[0]
+            if lazy_on:
+                w4 = F.pad(fc2.weight, (0, 0, 0, (-N) % 4))
+                b4 = F.pad(fc2.bias, (0, (-N) % 4), value=-6.0e4)
+                lp = JointOutFn.apply(h, w4, b4, scale, True, labels, N)
+                lp._pika_lazy_grad_ok = True
+                return lp
         if log_softmax and joint_out_ok(h, fc2.weight):
             from ..rnnt import _lazy_enabled
             # the log-softmax pass runs only if something other than this package's RNN-T loss needs the values

@@ -113,10 +113,12 @@ class LazyDenseGrad(torch.Tensor):
     streaming pass the eager path runs) and then runs the op on it: values are identical in every case."""
 
     @staticmethod
-    def __new__(cls, compact, labels, frames_lengths, labels_lengths):
+    def __new__(cls, compact, labels, frames_lengths, labels_lengths, width=None):
+        # width: the vocabulary the CALLER sees when the kernels run on a wider one (an output layer padded to a multiple of
+        # four units inside the joint, pika_amd.model.ops.joint): the tensor this object stands for has `width` columns
         B, T, U1, V, _ = compact.dims
-        r = torch.Tensor._make_wrapper_subclass(cls, (B, T, U1, V), dtype=torch.float32, device=compact.ws.device,
-                                                requires_grad=False)
+        r = torch.Tensor._make_wrapper_subclass(cls, (B, T, U1, V if width is None else int(width)), dtype=torch.float32,
+                                                device=compact.ws.device, requires_grad=False)
         r.compact = compact
         r._keep = (labels, frames_lengths, labels_lengths)   # the metadata kernel has run; kept for symmetry of lifetimes
         r._dense = None
@@ -132,7 +134,7 @@ class LazyDenseGrad(torch.Tensor):
                 with _timed("bwd"):
                     _lib.check(_lib.lib().pika_rnnt_loss_dense_grads(_ptr(ws), B, T, U1, V, blank, _ptr(g), _stream()),
                                "pika_rnnt_loss_dense_grads")
-            self._dense = g
+            self._dense = g if V == self.shape[-1] else g[..., :self.shape[-1]].contiguous()
         return self._dense
 
     def __repr__(self):
@@ -197,15 +199,18 @@ class LazyLogProbs(torch.Tensor):
     place (the same kernel the eager path runs in the forward) and then runs the op on the real log-probabilities."""
 
     @staticmethod
-    def __new__(cls, state, buf):
-        # (buf: the fp32 logits, or the fp16 matrix of a 16-bit joint; the tensor this object stands for is fp32 either way)
-        r = torch.Tensor._make_wrapper_subclass(cls, tuple(buf.shape), dtype=torch.float32, device=buf.device,
-                                                requires_grad=False)
+    def __new__(cls, state, buf, width=None):
+        # (buf: the fp32 logits, or the fp16 matrix of a 16-bit joint; the tensor this object stands for is fp32 either way.
+        #  width: the caller's vocabulary when the joint padded its output layer to a multiple of four units -- the extra
+        #  columns hold logits of -6e4, probability zero: the tensor this object stands for has `width` columns)
+        shape = tuple(buf.shape) if width is None else tuple(buf.shape[:-1]) + (int(width),)
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=torch.float32, device=buf.device, requires_grad=False)
         r.state, r.buf = state, buf
         return r
 
     def dense(self):
-        return self.state.to_log_probs(self.buf)
+        full = self.state.to_log_probs(self.buf)
+        return full if full.shape[-1] == self.shape[-1] else full[..., :self.shape[-1]]
 
     def __repr__(self):
         return "LazyLogProbs(shape=%s, normalised=%s)" % (tuple(self.shape), not self.state.raw)
@@ -241,9 +246,15 @@ class _RNNTLossFn(torch.autograd.Function):
         B, T, U1, V = log_probs.shape
         lse = None
         state = log_probs.state if isinstance(log_probs, LazyLogProbs) else None
+        ctx.width = None
+        if state is not None:
+            # (a joint that padded its output layer: the kernels see the buffer's columns, the caller `V` of them)
+            Vk = log_probs.buf.shape[-1]
+            ctx.width, V = (V, Vk) if Vk != V else (None, V)
         if state is not None and not (state.raw and ctx.lazy and state.scale == 1.0 and V % 4 == 0 and V <= MAX_FUSED_V
                                       and (state.gathered is None or state.partials is not None)):
-            state = None
+            state, V = None, log_probs.shape[-1]
+            ctx.width = None
         if state is not None:
             # raw logits of this package's joint: log-sum-exp + gather in one read, no log-prob tensor
             x = log_probs.buf
@@ -277,7 +288,7 @@ class _RNNTLossFn(torch.autograd.Function):
         else:
             # a LazyLogProbs the fused path cannot take (already read, scaled, V out of the fused kernel's range) is
             # normalised HERE: `.contiguous()` on the wrapper subclass short-circuits and would hand back the wrapper
-            lp = log_probs.dense() if isinstance(log_probs, LazyLogProbs) else log_probs.contiguous()
+            lp = log_probs.dense().contiguous() if isinstance(log_probs, LazyLogProbs) else log_probs.contiguous()
             with torch.cuda.device(lp.device):
                 costs = torch.empty(B, dtype=torch.float32, device=lp.device)
                 ws = torch.empty(lib.pika_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8,
@@ -305,7 +316,7 @@ class _RNNTLossFn(torch.autograd.Function):
                     _ptr(gc), _ptr(ws), None, _stream()), "pika_rnnt_loss_backward")
             compact = CompactGrad.__new__(CompactGrad)
             compact.ws, compact.dims, compact.ptr, compact.version = ws, (B, T, U1, V, blank), 0, 0
-            lazy = LazyDenseGrad(compact, labels, frames_lengths, labels_lengths)
+            lazy = LazyDenseGrad(compact, labels, frames_lengths, labels_lengths, width=ctx.width)
             lazy.lse = lse
             return lazy, None, None, None, None
         with torch.cuda.device(ws.device):

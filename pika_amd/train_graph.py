@@ -225,7 +225,7 @@ def _capture(model, st, key, x, y, x_len, t_valid=None):
     if compact_ok:
         # the fast form: raw logits out, the loss' compact gradient in (neither log-probs nor a dense gradient exist)
         e.kind = "compact"
-        B, T, U1, V = out.shape
+        B, T, U1, V = out.buf.shape          # (the kernels' columns: more than the caller's when the joint padded its layer)
         e.logits, e.partials, e.scale = out.buf, out.state.partials, out.state.scale
         e.gathered, e.recompute = out.state.gathered, out.state.recompute      # 16-bit logits (JointOutFn.forward)
         e.dims = (B, T, U1, V, 0)
@@ -234,7 +234,7 @@ def _capture(model, st, key, x, y, x_len, t_valid=None):
             e.lse = torch.empty(B * T * U1, dtype=torch.float32, device=dev)
         compact = CompactGrad.__new__(CompactGrad)
         compact.ws, compact.dims, compact.ptr, compact.version = e.ws, e.dims, 0, 0
-        gout = LazyDenseGrad(compact, None, None, None)
+        gout = LazyDenseGrad(compact, None, None, None, width=None if out.shape[-1] == V else out.shape[-1])
         gout.lse = e.lse
     elif type(out) is torch.Tensor and out.requires_grad:
         # the general form (vocabularies the lazy joint does not take, PIKA_LAZY_LOGPROBS=0, ...): a plain output tensor

@@ -227,7 +227,9 @@ def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
     try:
         g = torch.Generator().manual_seed(11)
         B, T, U, H = 2, 5, 3, 64
-        for V, lazy_expected in ((8200, False), (8192, True), (6268, True)):
+        # (5001 / 6269: not multiples of four -- the joint pads the output layer to the next one and the lazy output stands for
+        #  the layer's own columns; 8190: its padding would reach 8192)
+        for V, lazy_expected in ((8200, False), (8192, True), (6268, True), (5001, True), (6269, True), (8190, True)):
             fc1, fcg, fc2 = nn.Linear(2 * H, H), nn.Linear(2 * H, H), nn.Linear(H, V)
             for m in (fc1, fcg, fc2):
                 m.to(hip_device)
@@ -236,12 +238,16 @@ def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
             labels = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(hip_device)
             tl = torch.tensor([T, T - 1], dtype=torch.int32, device=hip_device)
             ul = torch.tensor([U, U - 2], dtype=torch.int32, device=hip_device)
-            assert joint_out_ok(torch.empty(1, H, dtype=torch.bfloat16, device=hip_device), fc2.weight) == lazy_expected
-            for read_first in (False, True):
+            assert joint_out_ok(torch.empty(1, H, dtype=torch.bfloat16, device=hip_device), fc2.weight,
+                                units=(V + 3) & ~3) == lazy_expected
+            # (with_labels: the 16-bit lattice of JointOutFn's labelled form, as Net.forward calls the joint)
+            for read_first, with_labels in ((False, False), (True, False)) + (((False, True),) if V % 4 else ()):
                 for m in (fc1, fcg, fc2):
                     m.zero_grad()
-                lp = ops.joint(enc, pred, fc1, fcg, fc2, log_softmax=True)
-                assert isinstance(lp, LazyLogProbs) == lazy_expected
+                lp = ops.joint(enc, pred, fc1, fcg, fc2, log_softmax=True, labels=labels.long() if with_labels else None)
+                assert isinstance(lp, LazyLogProbs) == lazy_expected and lp.shape[-1] == V
+                if with_labels:
+                    assert lp.buf.dtype == torch.float16 and lp.buf.shape[-1] == (V + 3) & ~3
                 if read_first:
                     assert torch.allclose(lp.detach().exp().sum(-1), torch.ones(B, T, U + 1, device=hip_device), atol=1e-4)
                 costs = RNNTLoss().apply(lp, labels, tl, ul)
@@ -259,7 +265,7 @@ def test_joint_beyond_the_lazy_range(hip_device, monkeypatch):
                 lp64.backward(torch.from_numpy(g64).to(hip_device))
                 assert np.allclose(got[0].numpy(), c64, rtol=3e-2)              # bf16 operands in every product
                 for a, r in ((got[1], w[2].grad.cpu()), (got[2], w[0].grad.cpu())):
-                    assert (a - r).norm() <= 6e-2 * r.norm(), (V, read_first, float((a - r).norm() / r.norm()))
+                    assert (a - r).norm() <= 6e-2 * r.norm(), (V, read_first, with_labels, float((a - r).norm() / r.norm()))
     finally:
         G.PRECISION = old
 
