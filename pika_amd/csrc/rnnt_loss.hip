@@ -495,6 +495,13 @@ void launch_ab(const Lattice &L, const int *Tn, const int *Un, float *costs, int
 // egs/train_transducer_bmuf_otfaug.sh:37).
 constexpr int CQ_MAX = 32, V_MAX = 64 * 4 * CQ_MAX;
 #define PIKA_CQ(extent, CALL) do { if ((extent) <= 64 * 4 * 20) { constexpr int CQ = 20; CALL; } else { constexpr int CQ = 32; CALL; } } while (0)
+// Rows a wave of the column-summing d(logits) kernels walks before its column sums go out (one atomicAdd per column and
+// workgroup): as many as still leave two workgroups per CU.  (It was 64 from 2^18 rows on and 4 below: the recipes' own
+// lattice -- 8 utterances, 97 920 rows -- issued 38 M atomics per pass and ran at 1.5 TB/s, 1.62 ms; now 0.5.)
+inline int rows_per_wave(long long rows) {
+    const long long r = rows / (4 * 2 * 256);
+    return (int)(r < 4 ? 4 : (r > 64 ? 64 : r));
+}
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1027,7 +1034,7 @@ int pika_rnnt_dlogits_compact_bf16(const float *log_probs, const float *lse, con
         static const int rpw_env = [] { const char *e = pika_knob("PIKA_DLOGITS_RPW"); return e ? atoi(e) : 0; }();   // A/B
         // tools/dlogits_bench.py at the config-2 lattice: 16 rows per wave 2.43 ms, 32: 2.35, 64: 2.31, 128: 2.31, 256: 2.57;
         // the 4- and 8-column kernels tie (2.35 ms): the pass is the mixed read / write HBM stream at 5.0-5.1 TB/s
-        const int rpw = rpw_env > 0 ? rpw_env : (rows >= (1 << 18) ? 64 : 4);
+        const int rpw = rpw_env > 0 ? rpw_env : rows_per_wave(rows);
         const long long per_block = 4LL * rpw;
         static const bool wide_off = pika_knob("PIKA_DLOGITS_NARROW") != nullptr;     // A/B: the 4-column kernel
         if (!wide_off && !(V & 7) && !(ld_out & 7) && V > 512 * 9 && !(reinterpret_cast<uintptr_t>(out) & 15)) {
@@ -1123,7 +1130,7 @@ int pika_rnnt_dlogits_compact_bf16_f16in(const void *logits16, long long ld_in, 
     if (colsum) {
         hipError_t e = hipMemsetAsync(colsum, 0, (size_t)V * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
-        const int rpw = rows >= (1 << 18) ? 64 : 4;
+        const int rpw = rows_per_wave(rows);
         const long long per_block = 4LL * rpw;
         // (V % 8 == 4 -- the shipped recipes' 6268 -- rides on a 16-bit pitch of whole granules: the last one is masked)
         if (!(ld_out & 7) && !(ld_in & 7) && ld_in >= ((V + 7) & ~7) && V > 512 * 9 && !(reinterpret_cast<uintptr_t>(out) & 15) &&
