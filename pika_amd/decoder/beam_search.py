@@ -358,15 +358,11 @@ class BeamState(object):
         # (decode_transducer.py:139): numpy scalars / 0-dim views of one score tensor
         score_elems = torch.from_numpy(np.ascontiguousarray(sel_score, dtype=np.float32).reshape(n)).unbind(0)
         # (the ~300 k list elements are references into ONE table of numpy scalars -- they are immutable -- picked by an
-        # object-array gather: creating a scalar per element was 7 of this function's 13 ms;
-        # ... the kept symbols of ALL entries in one gather and one tolist(), the entries cut out of the flat list)
+        # object-array gather: creating a scalar per element was 7 of this function's 13 ms)
         lo = min(int(out.min()), 0) if out.size else 0
-        table = _scalar_table(int(out.max()) - lo + 1 if out.size else 1, lo)
-        kept = out[np.arange(out.shape[1])[None, :] < keep[:, None]] if out.size else out.reshape(-1)
-        flat = table[kept - lo if lo else kept].tolist()
-        off = np.concatenate(([0], np.cumsum(keep))).tolist()
+        elems = _scalar_table(int(out.max()) - lo + 1 if out.size else 1, lo)[out - lo if lo else out]
         preds, out_scores = [], []
         for b in range(B):
-            preds.append([flat[off[b * nb + j]:off[b * nb + j + 1]] for j in range(nb)])
+            preds.append([elems[b * nb + j, :keep[b * nb + j]].tolist() for j in range(nb)])
             out_scores.append(list(score_elems[b * nb:(b + 1) * nb]))
         return preds, out_scores
