@@ -177,7 +177,7 @@ def mbr_backward(model, enc, hyps, seq_grad, nonblk, blk, sm_scale):
 
 
 class _MbrEntry(object):
-    __slots__ = ("graph", "x", "labels", "labels32", "x_len", "ali", "y", "sym", "slen", "seq_grad", "rnnt", "grads", "key")
+    __slots__ = ("graph", "x", "labels", "labels32", "x_len", "ali", "y", "sym", "slen", "seq_grad", "rnnt", "grads", "key", "t_valid")
 
 
 class GraphedMbrStep(object):
@@ -199,10 +199,14 @@ class GraphedMbrStep(object):
     padded to a multiple of `u_bucket` with the embedding's padding index (masked as keys by the prediction network).  A key
     is captured the `min_seen`-th time it appears (LRU bound `max_graphs`, ONE memory pool); until then, and whenever a
     capture fails, the step runs as the eager launch sequence (`eager_step`: the two backward passes of the script).
+    A batch also rides a graph whose time axis is up to `t_bucket` - 1 frames and whose label axis is up to `l_bucket` - 1
+    labels longer than its own (padding frames masked through the encoder's `valid_frames`, labels padded with the padding
+    index, as pika_amd.train_graph does for the plain step), and a bucket of t_bucket x l_bucket that has shown two different
+    shapes is captured at its upper boundary: a corpus whose batch shapes never recur still gets graphs.
     Dropout: the device-side salt word of pika_amd.train_graph, re-drawn before every replay."""
 
     def __init__(self, model, rnnt_scale=1.0, sm_scale=1.0, blk=0, max_graphs=4, min_seen=2, s_bucket=32, u_bucket=8,
-                 warmup=1):
+                 warmup=1, t_bucket=64, l_bucket=8):
         from . import train_graph
         from .rnnt import RNNTLoss
         self.model, self.rnnt_scale, self.sm_scale, self.blk = model, float(rnnt_scale), float(sm_scale), int(blk)
@@ -214,6 +218,8 @@ class GraphedMbrStep(object):
         import collections
         self.entries = collections.OrderedDict()
         self.seen, self.calls, self.pool, self.broken = {}, 0, None, None
+        self.t_bucket, self.l_bucket = max(0, int(t_bucket)), max(1, int(l_bucket))
+        self.bucket_shapes, self.used_at = {}, {}
         self.param_ptrs = None
         self.stats = {"replays": 0, "captures": 0, "eager": 0, "evictions": 0}
         self.salt = train_graph._salt_acquire(next(model.parameters()).device)
@@ -249,13 +255,15 @@ class GraphedMbrStep(object):
         mbr_backward(model, enc, hyps, seq_grad, nonblk, self.blk, self.sm_scale)                # :197-235
         return rnnt.detach()
 
-    def _capture(self, key, feats, labels, x_len, ali, y, sym, slen, seq_grad):
+    def _capture(self, key, feats, labels, x_len, ali, y, sym, slen, seq_grad, t_valid=None):
         from . import train_graph
         model = self.model
         dev = feats.device
         e = _MbrEntry()
         e.key = key
         e.x, e.labels, e.x_len, e.ali = feats.clone(), labels.long().clone(), x_len.int().clone(), ali.int().clone()
+        # (frames of data on a time axis that may be padded: a device word the encoder's BatchNorm / attention launches read)
+        e.t_valid = None if t_valid is None else torch.tensor([int(t_valid)], dtype=torch.int32, device=dev)
         e.labels32 = e.labels.int()
         e.y, e.sym, e.slen, e.seq_grad = y.clone(), sym.clone(), slen.clone(), seq_grad.float().clone()
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
@@ -277,7 +285,7 @@ class GraphedMbrStep(object):
             with torch.cuda.graph(e.graph, pool=self.pool, capture_error_mode="thread_local"):
                 try:
                     B = e.x.shape[0]
-                    enc = model.encode(e.x, None)
+                    enc = model.encode(e.x, None) if e.t_valid is None else model.encode(e.x, None, valid_frames=e.t_valid)
                     sos = torch.zeros(B, 1, dtype=torch.long, device=dev)
                     pred = model.predict(torch.cat((sos, e.labels), dim=1))
                     lp = ops.joint(enc, pred, model.fc1, model.fc_gate, model.fc2, log_softmax=True, labels=e.labels)
@@ -331,20 +339,46 @@ class GraphedMbrStep(object):
         Ub = -(-max(u_need, 1) // self.u_bucket) * self.u_bucket
         pad = model.embed.padding_idx
         y_h, sym_h, slen_h = hyp_arrays(hyps, nonblk, pad, self.blk, S=Sb, Umax=Ub)
-        key = (tuple(feats.shape), feats.dtype, tuple(labels.shape), beam, Sb, Ub)
-        e = self.entries.get(key)
+        T, U = feats.shape[1], labels.shape[1]
+        timed = self.t_bucket > 0 and feats.dim() == 3 and hasattr(model.encoder, "hidden_conv") and pad is not None
+
+        def key_for(frames, width):
+            return ((feats.shape[0], frames) + tuple(feats.shape[2:]), feats.dtype, (labels.shape[0], width), beam, Sb, Ub)
+        e, Tb, Lb = None, T, U
+        for k_, cand in self.entries.items():           # (at most max_graphs entries)
+            if k_ == key_for(k_[0][1], k_[2][1]) and U <= k_[2][1] < U + (self.l_bucket if timed else 1) \
+                    and T <= k_[0][1] < T + (self.t_bucket if timed else 1) and (e is None or (k_[0][1], k_[2][1]) < (Tb, Lb)):
+                e, Tb, Lb = cand, k_[0][1], k_[2][1]
+        key = key_for(Tb, Lb)
         if e is None:
             n = self.seen[key] = self.seen.get(key, 0) + 1
+            cf, cl = feats, labels
             if n < self.min_seen:
-                self.stats["eager"] += 1
-                return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)
+                # (the bucket logic of pika_amd.train_graph.forward: two different shapes in a bucket -> a graph at its upper
+                #  boundary, unless that pushes out one that is still in use)
+                bT = -(-T // self.t_bucket) * self.t_bucket if timed else T
+                bL = -(-U // self.l_bucket) * self.l_bucket if timed else U
+                shapes = self.bucket_shapes.setdefault(key_for(bT, bL), set())
+                shapes.add((T, U))
+                room = len(self.entries) < self.max_graphs or \
+                    self.calls - self.used_at.get(next(iter(self.entries)), 0) > 8 * self.max_graphs
+                if not ((bT, bL) != (T, U) and len(shapes) >= max(2, self.min_seen) and room):
+                    self.stats["eager"] += 1
+                    return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)
+                key, Tb, Lb = key_for(bT, bL), bT, bL
+                cf = feats.new_zeros((feats.shape[0], bT) + tuple(feats.shape[2:]))
+                cf[:, :T] = feats
+                cl = labels.new_full((labels.shape[0], bL), int(pad))
+                cl[:, :U] = labels
+                self.stats["bucket_captures"] = self.stats.get("bucket_captures", 0) + 1
             while len(self.entries) >= self.max_graphs:
-                self.entries.popitem(last=False)
+                old_key, _ = self.entries.popitem(last=False)
+                self.used_at.pop(old_key, None)
                 self.stats["evictions"] += 1
             y, sym, slen = (torch.from_numpy(a).to(dev) for a in (y_h, sym_h, slen_h))
             self.salt.random_()
             try:
-                e, why = self._capture(key, feats, labels, x_len, ali, y, sym, slen, seq_grad)
+                e, why = self._capture(key, cf, cl, x_len, ali, y, sym, slen, seq_grad, t_valid=T if timed else None)
             except Exception as err:
                 e, why = None, "%s: %s" % (type(err).__name__, str(err).split("\n")[0])
             if e is None:
@@ -356,15 +390,26 @@ class GraphedMbrStep(object):
             self.stats["captures"] += 1
         else:
             self.entries.move_to_end(key)
-            e.x.copy_(feats, non_blocking=True)
-            e.labels.copy_(labels, non_blocking=True)
-            e.labels32.copy_(labels, non_blocking=True)
+            if Tb != T:
+                e.x[:, :T].copy_(feats, non_blocking=True)       # frames beyond T keep what they held: finite, and masked
+                self.stats["padded"] = self.stats.get("padded", 0) + 1
+            else:
+                e.x.copy_(feats, non_blocking=True)
+            if e.t_valid is not None:
+                e.t_valid.fill_(T)
+            if Lb != U:
+                e.labels.fill_(int(pad))
+                e.labels[:, :U].copy_(labels, non_blocking=True)
+            else:
+                e.labels.copy_(labels, non_blocking=True)
+            e.labels32.copy_(e.labels, non_blocking=True)
             e.x_len.copy_(x_len, non_blocking=True)
             e.ali.copy_(ali, non_blocking=True)
             for dst, a in ((e.y, y_h), (e.sym, sym_h), (e.slen, slen_h)):
                 dst.copy_(torch.from_numpy(a), non_blocking=False)      # (pageable source: the copy returns when staged)
             e.seq_grad.copy_(seq_grad, non_blocking=True)
         self.salt.random_()                              # device-side draw: new dropout masks per replay
+        self.used_at[key] = self.calls
         kept = {id(g): g.clone() for p, g in e.grads if p.grad is g}
         e.graph.replay()
         self.stats["replays"] += 1

@@ -453,4 +453,84 @@ def test_gpu_graphed_mbr_step_replays_on_other_nbest_lists_and_buckets(hip_devic
     finally:
         G.PRECISION = old
         step.close()
+
+
+def test_gpu_graphed_mbr_step_on_batches_whose_shapes_never_recur(hip_device):
+    """A corpus whose frame and label counts differ from batch to batch: no exact shape repeats, so a bucket of 64 frames x 8
+    labels that has shown two shapes gets a graph at its upper boundary (192 frames, 8 labels) which the later batches of
+    the bucket ride -- padding frames masked, labels padded -- and every call leaves the gradients of the eager step
+    (`eager_step`) on the same weights.  Exact arithmetic; dropout off."""
+    import copy
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "pika_amd", "dropin"))
+    from types import SimpleNamespace as NS
+    from oracle.pika_ref import seeded_state_dict
+    from model.transducer import Net
+    from pika_amd import gemm as G
+    from pika_amd import mbr
+    V, B, beam, T_in, U = 120, 3, 3, 150, 6
+    opt = NS(rnn_size=64, local_rank=0, decoder_type="transformer", brnn=False, encoder_type="tdnn", dropout=0.0,
+             enc_layers=2, dec_layers=1, embd_dim=32, padding_idx=V)
+    net = Net(opt, 240, V)
+    net.encoder = type(net.encoder)(240, 0, 64, tdnn_nhid=64, tdnn_layers=6)
+    net.pack_seq = False
+    net.load_state_dict(seeded_state_dict(net, 77))
+    net = net.to(hip_device).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    g = torch.Generator().manual_seed(5)
+    old, G.PRECISION = G.PRECISION, "fp32"
+    step = mbr.GraphedMbrStep(net, rnnt_scale=0.1, sm_scale=0.9, blk=0, min_seen=2, warmup=1, s_bucket=64, u_bucket=16)
+    ref_step = mbr.GraphedMbrStep(copy.deepcopy(net), rnnt_scale=0.1, sm_scale=0.9, blk=0)
+
+    def batch(n_lab, seed, T_in, U):
+        Tp = (T_in - 24 + 3) // 4
+        gg = torch.Generator().manual_seed(seed)
+        feats = torch.randn(B, T_in, 240, generator=gg).to(hip_device)
+        labels = torch.randint(1, V, (B, U), generator=gg)
+        ali = torch.tensor([U, U - 1, max(U - 2, 1)], dtype=torch.int32)
+        for b in range(B):
+            labels[b, int(ali[b]):] = V
+        x_len = torch.full((B,), Tp, dtype=torch.int32)
+        hyps, scores = [], []
+        for b in range(B):
+            row, sc = [], []
+            for j in range(beam):
+                nl = max(1, n_lab - j - b)                      # labels of this hypothesis
+                nb = Tp - int(torch.randint(0, 3, (1,), generator=gg))
+                sym = [0] * nb + [int(v) for v in torch.randint(1, V, (nl,), generator=gg)]
+                perm = torch.randperm(len(sym), generator=gg).tolist()
+                row.append([torch.tensor(sym[i]) for i in perm])
+                sc.append(torch.tensor(-1.0 - 0.3 * j - 0.01 * float(torch.rand(1, generator=gg))))
+            hyps.append(row)
+            scores.append(sc)
+        return feats, labels.to(hip_device), x_len.to(hip_device), ali.to(hip_device), hyps, scores
+
+    def grads_of(fn, args):
+        fn.model.zero_grad(set_to_none=True)
+        out = fn(*args) if fn is step else fn.eager_step(*args)
+        torch.cuda.synchronize()
+        return float(out), [None if p.grad is None else p.grad.detach().clone() for p in fn.model.parameters()]
+    try:
+        # frames / labels per batch; S <= 64 and hypothesis labels <= 16 throughout: one (S, U) bucket
+        shapes = ((150, 6), (141, 5), (163, 7), (172, 6), (134, 4), (190, 8))
+        for k, (T_in_k, U_k) in enumerate(shapes):
+            args = batch(5 + k % 3, 10 + k, T_in_k, U_k)
+            got_loss, got = grads_of(step, args)
+            want_loss, want = grads_of(ref_step, args)
+            assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss) + 1e-5, (k, got_loss, want_loss)
+            for (name, _), a, b in zip(net.named_parameters(), got, want):
+                if b is None:
+                    assert a is None or float(a.abs().max()) == 0.0, name
+                    continue
+                scale = float(b.abs().max()) + 1e-12
+                assert a is not None and float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (k, name, float((a - b).abs().max()), scale)
+        assert step.broken is None, step.broken
+        # call 1 warm-up, 2 eager (first shape of bucket (192, 8) after the warm-up), 3 captures the bucket at (192, 8), 4-6 ride it
+        assert step.stats.get("bucket_captures") == 1 and step.stats["captures"] == 1, step.stats
+        assert step.stats["replays"] == 4 and step.stats["eager"] == 2 and step.stats.get("padded") == 3, step.stats
+        assert [(k_[0][1], k_[2][1]) for k_ in step.entries] == [(192, 8)]
+    finally:
+        G.PRECISION = old
+        step.close()
         ref_step.close()
