@@ -279,6 +279,10 @@ class GraphedMbrStep(object):
                     mod._parameters[k] = by_id[id(p)]
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
+        if isinstance(getattr(model, "decoder", None), torch.nn.LSTM):
+            from .model import lstm
+            # (the recurrence runs over SOS + labels for the RNN-T part and over the N-best rows for the risk part)
+            lstm.reserve(model.decoder, max(e.labels.shape[0], e.y.shape[0]), max(e.labels.shape[1], e.y.shape[1]) + 1, dev)
         e.graph = torch.cuda.CUDAGraph()
         err = None
         try:

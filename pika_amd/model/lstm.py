@@ -69,6 +69,21 @@ def _work_ready(device, S, B, H):
             and bw.numel() >= lib.pika_lstm_train_bwd_work_bytes(S, B, H))
 
 
+def reserve(rnn, B, S, device):
+    """Make the scratch of both directions large enough for a (B, S) batch NOW -- called in front of a stream capture
+    (pika_amd/train_graph.py, pika_amd/mbr.py: a graph captured at a bucket's boundary runs more steps than any batch so far),
+    since inside one the scratch can neither be allocated nor filled."""
+    H = getattr(rnn, "hidden_size", 0)
+    if not (PERSISTENT and isinstance(rnn, torch.nn.LSTM) and device.type == "cuda" and H % 256 == 0 and 0 < H <= 1024):
+        return
+    lib = _lib.lib()
+    nf, nb = lib.pika_lstm_train_fwd_work_bytes(int(S), int(B), H), lib.pika_lstm_train_bwd_work_bytes(int(S), int(B), H)
+    if nf > 0 and nb > 0:
+        with torch.cuda.device(device):
+            _work(device, nf, False)
+            _work(device, nb, True)
+
+
 class LstmRecurrenceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh):

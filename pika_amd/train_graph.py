@@ -204,6 +204,9 @@ def _capture(model, st, key, x, y, x_len, t_valid=None):
         st.pool = torch.cuda.graph_pool_handle()
     lib = _lib.lib()
     e.gf, e.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    if isinstance(getattr(model, "decoder", None), torch.nn.LSTM) and y.dim() == 2:
+        from .model import lstm
+        lstm.reserve(model.decoder, y.shape[0], y.shape[1] + 1, dev)        # (SOS + labels: the recurrence's steps)
     # thread_local: the loader thread keeps issuing its own uploads / kernels on its side stream during the capture
     # (not torch.func.functional_call: with a module registered under two names -- the embedding the prediction network
     # shares with the transducer -- it leaves the alias in place of the Parameter when it restores the module)

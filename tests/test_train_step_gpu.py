@@ -549,7 +549,8 @@ def test_script_loop_with_varying_lengths_rides_on_padded_graphs(hip_device):
     assert torch.allclose(torch.tensor(got), torch.tensor(want), rtol=5e-4), (got, want)
 
 
-def test_script_loop_whose_exact_shapes_never_recur_gets_bucket_graphs(hip_device):
+@pytest.mark.parametrize("pred_net", ["transformer", "rnn"])
+def test_script_loop_whose_exact_shapes_never_recur_gets_bucket_graphs(hip_device, pred_net, monkeypatch):
     """A corpus whose lengths vary from batch to batch: no (frames, labels) shape appears twice, so no pair of graphs is
     ever captured at a batch's own shape -- the bucket of 64 frames x 8 labels that has shown two shapes gets a pair at its
     upper boundary (320 frames, 16 labels) and the later batches of the bucket ride it; another bucket gets its own pair;
@@ -557,8 +558,20 @@ def test_script_loop_whose_exact_shapes_never_recur_gets_bucket_graphs(hip_devic
     import copy
     from pika_amd import gemm as G
     from pika_amd import train_graph
-    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0, V=512)
+    model, _, _, fused_optim = _small_step_harness(hip_device, 0.0, V=512, decoder_type=pred_net)
     ref = copy.deepcopy(model)
+    # (the LSTM prediction network: the graphs at a bucket's boundary run more recurrence steps than any batch before them --
+    #  the persistent recurrence must still be what is captured: its scratch is reserved in front of the capture)
+    from pika_amd.model import lstm as lstm_mod
+    taken = {"captured": 0, "library": 0}
+    real_applies = lstm_mod.applies
+
+    def applies(rnn, x):
+        ok = real_applies(rnn, x)
+        if torch.cuda.is_current_stream_capturing():
+            taken["captured" if ok else "library"] += 1
+        return ok
+    monkeypatch.setattr(lstm_mod, "applies", applies)
     g = torch.Generator().manual_seed(47)
     shapes = ((300, 10), (297, 9), (311, 12), (289, 11), (305, 13), (390, 20), (384, 19), (318, 10), (371, 22), (262, 14))
     batches = [_batch(hip_device, g, 4, T, U, 512, pad_from=min(6, U - 1)) for T, U in shapes]
@@ -578,6 +591,8 @@ def test_script_loop_whose_exact_shapes_never_recur_gets_bucket_graphs(hip_devic
         assert keys == [(320, 16), (384, 24)], (keys, st.stats)
         assert st.stats.get("bucket_captures") == 2 and st.stats["captures"] == 2, st.stats
         assert st.stats["replays"] == 5 and st.stats["eager"] == 5 and st.stats.get("padded") == 3, st.stats
+        if pred_net == "rnn":
+            assert taken["captured"] == 2 and taken["library"] == 0, taken
         train_graph.disable(model)
     finally:
         train_graph.AUTO = old_auto
