@@ -205,7 +205,7 @@ class GraphedMbrStep(object):
     shapes is captured at its upper boundary: a corpus whose batch shapes never recur still gets graphs.
     Dropout: the device-side salt word of pika_amd.train_graph, re-drawn before every replay."""
 
-    def __init__(self, model, rnnt_scale=1.0, sm_scale=1.0, blk=0, max_graphs=4, min_seen=2, s_bucket=32, u_bucket=8,
+    def __init__(self, model, rnnt_scale=1.0, sm_scale=1.0, blk=0, max_graphs=16, min_seen=2, s_bucket=32, u_bucket=8,
                  warmup=1, t_bucket=64, l_bucket=8):
         from . import train_graph
         from .rnnt import RNNTLoss
@@ -316,6 +316,7 @@ class GraphedMbrStep(object):
         in place) and returns rnnt_scale * sum of the RNN-T costs (device tensor)."""
         import os
         import warnings
+        from . import train_graph
         model = self.model
         dev = feats.device
         self.calls += 1
@@ -359,13 +360,12 @@ class GraphedMbrStep(object):
             cf, cl = feats, labels
             if n < self.min_seen:
                 # (the bucket logic of pika_amd.train_graph.forward: two different shapes in a bucket -> a graph at its upper
-                #  boundary, unless that pushes out one that is still in use)
+                #  boundary while there is room: a bucket never pushes another graph out)
                 bT = -(-T // self.t_bucket) * self.t_bucket if timed else T
                 bL = -(-U // self.l_bucket) * self.l_bucket if timed else U
                 shapes = self.bucket_shapes.setdefault(key_for(bT, bL), set())
                 shapes.add((T, U))
-                room = len(self.entries) < self.max_graphs or \
-                    self.calls - self.used_at.get(next(iter(self.entries)), 0) > 8 * self.max_graphs
+                room = len(self.entries) < self.max_graphs and train_graph._memory_to_spare(dev)
                 if not ((bT, bL) != (T, U) and len(shapes) >= max(2, self.min_seen) and room):
                     self.stats["eager"] += 1
                     return self.eager_step(feats, labels, x_len, ali, hyps, scores, terms)

@@ -37,7 +37,7 @@ PIKA_TRAIN_GRAPH=0 for such a loop), a gradient that is not this package's loss 
 
 Switches: PIKA_TRAIN_GRAPH=0 (environment) turns the graphs off; PIKA_TRAIN_GRAPH_DEBUG=1/2/3 prints statistics / every
 call / where a non-finite value first appears.  Everything else is an argument of `enable()` or an entry of DEFAULTS
-(module dictionary; what `pika_amd.launch` leaves untouched): warmup (2 eager calls first), max_graphs (4 shapes kept),
+(module dictionary; what `pika_amd.launch` leaves untouched): warmup (2 eager calls first), max_graphs (16 shapes kept),
 min_seen (2: a shape is captured the second time it appears after the warm-up -- a corpus whose batch lengths never recur
 stays eager instead of capturing every step), u_bucket (8: a batch rides on graphs whose label axis is up to 7 labels wider
 than its own, padded with the embedding's padding index), t_bucket (64: ... and whose time axis is up to 63 frames longer;
@@ -55,7 +55,7 @@ import torch
 from . import _lib
 
 _SALT = {"word": None, "users": 0}
-DEFAULTS = {"warmup": 2, "max_graphs": 4, "min_seen": 2, "u_bucket": 8, "t_bucket": 64, "freeze_salt": False, "debug_sync": 0,
+DEFAULTS = {"warmup": 2, "max_graphs": 16, "min_seen": 2, "u_bucket": 8, "t_bucket": 64, "freeze_salt": False, "debug_sync": 0,
             "bucket_capture": True}
 
 
@@ -275,6 +275,14 @@ def _capture(model, st, key, x, y, x_len, t_valid=None):
     return e, None
 
 
+def _memory_to_spare(device):
+    try:
+        free, total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return True
+    return free > 0.25 * total
+
+
 def distinct_buffers(grads):
     """autograd.grad returns ONE tensor for two parameters whose sum entered the model (`b_ih + b_hh`: the addition's backward
     hands its incoming gradient to both); AccumulateGrad would give every parameter a buffer of its own -- the clip and
@@ -407,14 +415,15 @@ def forward(model, x, y, x_len, softmax):
             # A corpus whose lengths vary from batch to batch shows an exact shape once: its batches fall into BUCKETS of
             # t_bucket frames x u_bucket labels instead.  A bucket that has shown two different shapes (and min_seen
             # batches) gets a pair of graphs at its upper boundary, which every later batch of the bucket rides padded --
-            # unless that would push out a pair that is still in use (more live buckets than max_graphs: the step then
-            # stays the eager launch sequence instead of re-capturing in circles).
+            # while there is room (more live buckets than max_graphs: the rest stay the eager launch sequence).
             bT = -(-T // st.t_bucket) * st.t_bucket if timed else T
             bU = -(-U // st.u_bucket) * st.u_bucket if (pad is not None and y.dim() == 2) else U
             shapes = st.bucket_shapes.setdefault(key_for(bT, bU), set())
             shapes.add((T, U))
-            room = len(st.entries) < st.max_graphs or \
-                st.calls - st.used_at.get(next(iter(st.entries)), 0) > 8 * st.max_graphs
+            # (a bucket never pushes out another pair: with more live buckets than max_graphs the table would turn over for
+            #  ever -- tools/real_corpus_sim.py: a capture every ~12 steps at 4 pairs and ~20 buckets -- and never while less
+            #  than a quarter of the device memory is free: a pair holds its static logits and gradients)
+            room = len(st.entries) < st.max_graphs and _memory_to_spare(x.device)
             if not (DEFAULTS["bucket_capture"] and (bT, bU) != (T, U) and len(shapes) >= max(2, st.min_seen) and room):
                 st.stats["eager"] += 1
                 return model._forward_eager(x, y, x_len, softmax)
