@@ -67,7 +67,7 @@ struct BL {
     const int *lens;        // (B,)
     float *out;             // (S, B, D*H)
     float *h_n, *c_n;       // (D, B, H)
-    unsigned *xbuf;         // [D*nq][S][RB][H] words (bf16 hi << 16 | bf16 lo), all EMPTY before the launch
+    unsigned *xbuf;         // [D*nq][S][H / 8][RB][8] words (bf16 hi << 16 | bf16 lo), all EMPTY before the launch
     int *err;
     int S, B, D, H, nq, ng;
 };
@@ -87,6 +87,23 @@ __device__ inline unsigned pack_terms(float h) {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte loads at agent scope (`sc1`: what __hip_atomic_load compiles to, which exists for 4 and 8 bytes only).  The compiler
+// does not count these loads: wait_loads names the registers they fill (csrc/lstm_train.hip: the same pair).
+__device__ inline void load16_agent(u32x4 &d, const unsigned *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(d) : "v"(p) : "memory");
+}
+template <int N>
+__device__ inline void wait_loads(u32x4 (&v)[N]) {
+    static_assert(N == 2 || N == 4 || N == 6 || N == 8, "registers named one by one");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+    if constexpr (N == 6)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5])::"memory");
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+}
 
 template <int KTW>
 __global__ __launch_bounds__(256) void blstm_layer_kernel(BL p) {
@@ -135,22 +152,25 @@ __global__ __launch_bounds__(256) void blstm_layer_kernel(BL p) {
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) acc[gate] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            // the 16 x (KTW*32) words of step s-1 this wave reduces over: lane -> row lane & 15, 8 consecutive words
-            // per k-tile; agent-scope loads (the writers sit on other XCDs), repeated until no word is EMPTY
-            const unsigned long long *xs = reinterpret_cast<const unsigned long long *>(
-                xb + ((long long)(s - 1) * RB + (lane & 15)) * H + wave * KTW * 32 + (lane >> 4) * 8);
+            // the 16 x (KTW*32) words of step s-1 this wave reduces over, in FRAGMENT order ([group of 8 units][row][8]: a lane
+            // finds the 8 words of a k-tile in 32 contiguous bytes, the wave reads 2 KB in one piece per k-tile -- round 6:
+            // as [row][H] words read 8 bytes at a time a wave instruction touched 64 sectors for 8 bytes each);
+            // agent-scope loads (the writers sit on other XCDs), repeated until no word is EMPTY
+            const unsigned *xs = xb + (long long)(s - 1) * RB * H + (((wave * KTW) * 4 + (lane >> 4)) * RB + (lane & 15)) * 8;
+            u32x4 wq[KTW * 2];
             u32x2 wd[KTW][4];
             unsigned long long t0 = 0;
             for (unsigned spin = 0;; ++spin) {
+#pragma unroll
+                for (int kt = 0; kt < KTW; ++kt) {
+                    load16_agent(wq[2 * kt], xs + kt * 4 * RB * 8);
+                    load16_agent(wq[2 * kt + 1], xs + kt * 4 * RB * 8 + 4);
+                }
+                wait_loads(wq);
                 bool empty = false;
 #pragma unroll
-                for (int kt = 0; kt < KTW; ++kt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const unsigned long long v = __hip_atomic_load(xs + kt * 16 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        wd[kt][j] = u32x2{(unsigned)v, (unsigned)(v >> 32)};
-                        empty |= wd[kt][j].x == EMPTY || wd[kt][j].y == EMPTY;
-                    }
+                for (int i = 0; i < KTW * 2; ++i)
+                    empty |= wq[i][0] == EMPTY || wq[i][1] == EMPTY || wq[i][2] == EMPTY || wq[i][3] == EMPTY;
                 if (!__any(empty)) break;
                 if ((spin & 63) == 63) {
                     if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -163,6 +183,10 @@ __global__ __launch_bounds__(256) void blstm_layer_kernel(BL p) {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wd[kt][j] = u32x2{wq[2 * kt + (j >> 1)][2 * (j & 1)], wq[2 * kt + (j >> 1)][2 * (j & 1) + 1]};
 #pragma unroll
             for (int kt = 0; kt < KTW; ++kt) {
                 u32x4 hb, lb;       // bf16 pairs: element 2i in the low half
@@ -197,7 +221,8 @@ __global__ __launch_bounds__(256) void blstm_layer_kernel(BL p) {
             h = sigmoid_fast(z[3]) * tanh_fast(c);
         }
         if (s + 1 < nsteps)     // rows past their end publish their frozen state: the peers only test for EMPTY
-            __hip_atomic_store(xb + ((long long)s * RB + r) * H + unit, pack_terms(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(xb + (long long)s * RB * H + ((unit >> 3) * RB + r) * 8 + (unit & 7), pack_terms(h), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         if (valid) {
             p.out[((long long)t * B + row) * ldo + (long long)d * H + unit] = h;
             if (s == len - 1) {
