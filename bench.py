@@ -228,7 +228,7 @@ def train_step_workload(args, R_):
         except Exception:
             pass
         th.join(timeout=2.0)
-    step.close, step.frontend, step.bmuf = close, fe, bmuf
+    step.close, step.frontend, step.bmuf, step.graphed = close, fe, bmuf, graphed
     flops_per_utt = 730e9  # ~243 GF fwd, x3 fwd+bwd (split fc1/fc_gate)
     return step, flops_per_utt
 
@@ -285,8 +285,15 @@ def run_train_step(args, R_, steps, warmup):
             step.bmuf.collective_events = []
         fe = step.frontend
         fe.host_seconds, fe.batches = 0.0, 0
-        el, loss = R_.timed(step, steps, 0)
+        calls = []
+
+        def clocked():
+            calls.append(time.perf_counter())
+            return step()
+        el, loss = R_.timed(clocked, steps, 0)
         loss = float(loss.item())
+        intervals = [round((b - a) * 1e3, 1) for a, b in zip(calls, calls[1:])]     # host cadence: the queue's back-pressure
+        graph_stats = dict(step.graphed.state.stats, broken=step.graphed.state.broken) if step.graphed is not None else None
     finally:
         step.close()
     tf = flops_per_utt * B / (el / steps) / 1e12
@@ -308,7 +315,8 @@ def run_train_step(args, R_, steps, warmup):
                                 "loss.backward() the model's forward and backward are two hipGraph replays, loss + clip + SGD ~10 "
                                 "eager launches (pika_amd/train_graph.py: what the unchanged training script gets through "
                                 "pika_amd.launch)"
-                                if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0" else "eager (~650 launches per step)"},
+                                if os.environ.get("PIKA_TRAIN_GRAPH", "1") != "0" else "eager (~650 launches per step)",
+                      "graphs": graph_stats, "ms_between_step_calls": intervals},
            "roofline": dict({"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
                              "frac": tf / 2500.0}, **train_step_traffic()),
            "loader": {"host_ms_per_batch": fe.host_seconds / max(fe.batches, 1) * 1e3, "batches": fe.batches,
@@ -965,9 +973,10 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
             a2.pred_net = "rnn"
             old, G.PRECISION = G.PRECISION, "mixed"
             try:
-                rn = run_train_step(a2, R_, max(5, steps // 2), 3)
+                rn = run_train_step(a2, R_, steps, 3)
                 ts["lstm_prediction_net"] = {
                     "ms_per_step": rn["ms_per_step"], "value": rn["value"], "unit": rn["unit"], "loss": rn["config"]["loss"],
+                    "graphs": rn["config"]["graphs"], "ms_between_step_calls": rn["config"]["ms_between_step_calls"],
                     "note": "dec_type=rnn as in the recipes: the recurrence of each nn.LSTM layer as one persistent launch per "
                             "direction of time (include/pika_lstm.h; two bf16 terms per operand) inside the captured step, torch's "
                             "dropout between the layers; the library's step-by-step recurrence (MIOpen) was 4.3 ms of this step; "
@@ -980,10 +989,12 @@ def leg_train_step(args, R_, steps, warmup, with_cpu):
         if extras and args.precision is None:
             old, G.PRECISION = G.PRECISION, "bf16"
             try:
-                b16 = run_train_step(args, R_, max(5, steps // 2), 2)
+                b16 = run_train_step(args, R_, steps, 3)
             finally:
                 G.PRECISION = old
             ts["bf16_no_parity"] = {"ms_per_step": b16["ms_per_step"], "value": b16["value"], "dtype": b16["dtype"],
+                                    "graphs": b16["config"]["graphs"],
+                                    "ms_between_step_calls": b16["config"]["ms_between_step_calls"],
                                     "roofline_frac": b16["roofline"]["frac"],
                                     "note": "same step with ONE bf16 term per operand in every product: encoder activations "
                                             "3e-2 off the reference (no parity claim; tests/test_model_full.py[bf16])"}
