@@ -52,9 +52,16 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *const *__restr
              [&](int i) { const float v = g[i]; m = fmaxf(m, fabsf(v)); nan |= v != v; });
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     nan = __any(nan);
-    if ((threadIdx.x & 63) == 0) {
-        // non-negative floats order like their bit patterns; NaN (0x7fc00000) is above every finite value and +inf
-        atomicMax(reinterpret_cast<unsigned *>(out), nan ? 0x7fc00000u : __float_as_uint(m));
+    // non-negative floats order like their bit patterns; NaN (0x7fc00000) is above every finite value and +inf.
+    // ONE atomic per workgroup, and only when it would raise the word: every wave of ~3700 workgroups hitting the one
+    // address was a queue of ~15 000 device-scope atomics at ~12 ns each -- 0.19 of this kernel's 0.27 ms over 240 MB
+    __shared__ unsigned wave_key[4];
+    if ((threadIdx.x & 63) == 0) wave_key[threadIdx.x >> 6] = nan ? 0x7fc00000u : __float_as_uint(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned key = max(max(wave_key[0], wave_key[1]), max(wave_key[2], wave_key[3]));
+        if (key > __hip_atomic_load(reinterpret_cast<unsigned *>(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned *>(out), key);
     }
 }
 
