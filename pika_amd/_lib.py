@@ -7,7 +7,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libpika_amd.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _vp, _i, _sz, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_longlong
 
@@ -97,7 +97,8 @@ SIGNATURES = {
     "pika_edit_distances": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     # include/pika_norm.h
     "pika_layer_norm_fwd": (_i, [_vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
-    "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pika_layer_norm_bwd_partial_floats": (_ll, [_ll, _i]),
     "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     "pika_bn_apply": (_i, [_vp, _ll, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp,
                            _vp, _i, _vp, _vp, _vp]),

@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dgamma += dy * xhat, dbeta += dy
 // (per-lane column partials over the block's rows, one atomicAdd per column per block).
-template <typename TD, int LNQ>
+// PART: the block's column sums go to partials[block][gamma | beta][C] instead (ln_param_grad_kernel adds them up in block
+// order): 497 workgroups x 1024 atomics onto the same 1024 words were half of this kernel's time at 31808 x 512.
+template <typename TD, int LNQ, bool PART>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ gamma, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
@@ -320,9 +322,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
         const int i = lane + q * 64;
         if (any && wave < 2 && i < c4) {
             const ln_f4 t = red[wave][0][lane] + red[wave][1][lane] + red[wave][2][lane] + red[wave][3][lane];
-            float *dst = (wave == 0 ? dgamma : dbeta) + 4 * i;
-            atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
+            if constexpr (PART) {       // (dgamma = the partials here)
+                reinterpret_cast<ln_f4 *>(dgamma + ((long long)blockIdx.x * 2 + wave) * C)[i] = t;
+            } else {
+                float *dst = (wave == 0 ? dgamma : dbeta) + 4 * i;
+                atomicAdd(dst + 0, t.x); atomicAdd(dst + 1, t.y); atomicAdd(dst + 2, t.z); atomicAdd(dst + 3, t.w);
+            }
         }
+    }
+}
+
+// dgamma / dbeta from the per-block partials of ln_bwd_kernel<PART>: 16 groups of 64 lanes take the blocks round-robin, the
+// groups' sums meet in LDS in group order -- the same value whatever the timing.  grid (ceil(C/4/64), 2), 1024 threads.
+__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float *__restrict__ partials, int nb, int C,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ ln_f4 red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, which = blockIdx.y, i = blockIdx.x * 64 + lane, c4 = C >> 2;
+    ln_f4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = ln_f4{0.f, 0.f, 0.f, 0.f};
+    if (i < c4) {
+        int b = rg;
+        for (; b + 48 < nb; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                a[u] += reinterpret_cast<const ln_f4 *>(partials + ((long long)(b + 16 * u) * 2 + which) * C)[i];
+        }
+        for (; b < nb; b += 16) a[0] += reinterpret_cast<const ln_f4 *>(partials + ((long long)b * 2 + which) * C)[i];
+    }
+    red[rg][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (rg == 0 && i < c4) {
+        ln_f4 t = red[0][lane];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][lane];
+        reinterpret_cast<ln_f4 *>(which == 0 ? dgamma : dbeta)[i] = t;
     }
 }
 
@@ -439,25 +473,38 @@ int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamm
     return (int)hipGetLastError();
 }
 
+static int ln_bwd_rows_per_block(long long rows) {
+    static const int rpb_env = [] { const char *e = pika_knob("PIKA_LN_BWD_RPB"); return e ? atoi(e) : 0; }();   // A/B runs
+    return rpb_env > 0 ? rpb_env : (rows >= 16384 ? 64 : rows >= 4096 ? 32 : 8);
+}
+
+long long pika_layer_norm_bwd_partial_floats(long long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    const int rpb = ln_bwd_rows_per_block(rows);
+    return (rows + rpb - 1) / rpb * 2 * C;
+}
+
 int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
                         const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
-                        void *stream) {
+                        float *partials, void *stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return PIKA_EINVAL;
     if ((C & 3) || C > 64 * 4 * LNQ_MAX) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx) |
-         reinterpret_cast<uintptr_t>(dgamma) | reinterpret_cast<uintptr_t>(dbeta)) & 15)
+         reinterpret_cast<uintptr_t>(dgamma) | reinterpret_cast<uintptr_t>(dbeta) | reinterpret_cast<uintptr_t>(partials)) & 15)
         return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    static const int rpb_env = [] { const char *e = pika_knob("PIKA_LN_BWD_RPB"); return e ? atoi(e) : 0; }();   // A/B runs
-    // rows per workgroup: every workgroup ends with 2*C column-sum atomics onto the same addresses, so few rows per
+    if (!partials) {
+        hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)C * sizeof(float), s);
+        if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    // rows per workgroup (the form without `partials`): every workgroup ends with 2*C column-sum atomics onto the same addresses, so few rows per
     // workgroup are bound by that contention and many by the row chain (measured at 31808 x 1024, tools/ln_bwd_bench.py:
     // 8: 483 us, 16: 299, 32: 231, 64: 197, 128: 215, 256: 286 per backward)
-    const int rpb = rpb_env > 0 ? rpb_env : (rows >= 16384 ? 64 : rows >= 4096 ? 32 : 8);
+    const int rpb = ln_bwd_rows_per_block(rows);
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-#define PIKA_LN_BWD(TD, Q) hipLaunchKernelGGL((ln_bwd_kernel<TD, Q>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb)
+#define PIKA_LN_BWD(TD, Q) do { if (partials) hipLaunchKernelGGL((ln_bwd_kernel<TD, Q, true>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, partials, nullptr, rows, C, rpb); \
+                                else hipLaunchKernelGGL((ln_bwd_kernel<TD, Q, false>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb); } while (0)
 #define PIKA_LN_BWD_Q(TD) do { if (C <= 512) PIKA_LN_BWD(TD, 2); else if (C <= 1024) PIKA_LN_BWD(TD, 4); else PIKA_LN_BWD(TD, 8); } while (0)
     if (dy_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(dy) & 15))
         PIKA_LN_BWD_Q(float);
@@ -467,6 +514,9 @@ int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long 
         return PIKA_EINVAL;
 #undef PIKA_LN_BWD_Q
 #undef PIKA_LN_BWD
+    if (partials)
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((C / 4 + 63) / 64), 2), dim3(1024), 0, s, partials, (int)grid.x, C,
+                           dgamma, dbeta);
     return (int)hipGetLastError();
 }
 

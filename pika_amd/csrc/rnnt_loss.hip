@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void rnnt_dlogits_fused_kernel(const float *__
 
 extern "C" {
 
-int pika_amd_abi_version(void) { return 21; }
+int pika_amd_abi_version(void) { return 22; }
 
 size_t pika_rnnt_workspace_bytes(int B, int T, int U1) {
     if (B <= 0 || T <= 0 || U1 <= 0 || U1 > 1024) return 0;

@@ -326,11 +326,13 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
         dg = torch.empty(C, dtype=torch.float32, device=dy.device)
         db = torch.empty(C, dtype=torch.float32, device=dy.device)
+        # the workgroups' column sums side by side, added up by a second launch in a fixed order (no atomics, no memsets)
+        part = torch.empty(int(_lib.lib().pika_layer_norm_bwd_partial_floats(rows, C)), dtype=torch.float32, device=dy.device)
         with torch.cuda.device(dy.device):
             _lib.check(_lib.lib().pika_layer_norm_bwd(
                 dy.data_ptr(), G.PIKA_F32 if dy.dtype == torch.float32 else G.PIKA_BF16, x2.data_ptr(), rows, C,
                 weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                _stream()), "pika_layer_norm_bwd")
+                part.data_ptr(), _stream()), "pika_layer_norm_bwd")
         return dx, dg, db, None, None, None
 
 

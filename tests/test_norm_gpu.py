@@ -64,6 +64,43 @@ def test_layer_norm_forward_backward(hip_device, rows, C, bf16):
         assert (a.grad.double().cpu() - r.grad).abs().max() < 2e-5 * max(s, 1.0) * (rows ** 0.5 if a.dim() == 1 else 1.0)
 
 
+def test_layer_norm_backward_parameter_gradients_with_and_without_the_scratch(hip_device):
+    """pika_layer_norm_bwd at the benchmark's shape (31808 rows x 512): with `partials` the workgroups' column sums are added up
+    in a fixed order by a second launch -- two calls give the SAME bits -- and equal the float-atomics form (partials NULL)
+    and the float64 sums to rounding."""
+    from pika_amd import _lib
+    from pika_amd import gemm as G
+    rows, C = 31808, 512
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(hip_device)
+    w = torch.randn(C, generator=g).to(hip_device)
+    dy = torch.randn(rows, C, generator=g).bfloat16().to(hip_device)
+    mean = x.mean(1).contiguous()
+    rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt().contiguous()
+    lib = _lib.lib()
+    n = int(lib.pika_layer_norm_bwd_partial_floats(rows, C))
+    assert n >= 2 * C and n % (2 * C) == 0
+
+    def run(with_scratch):
+        dx, dg, db = torch.empty_like(x), torch.full((C,), 7.0, device=hip_device), torch.full((C,), 7.0, device=hip_device)
+        part = torch.empty(n, device=hip_device) if with_scratch else None
+        with torch.cuda.device(hip_device):
+            _lib.check(lib.pika_layer_norm_bwd(dy.data_ptr(), G.PIKA_BF16, x.data_ptr(), rows, C, w.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                               None if part is None else part.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream), "pika_layer_norm_bwd")
+        torch.cuda.synchronize()
+        return dx, dg, db
+    a, b, c = run(True), run(True), run(False)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert torch.equal(a[0], c[0])
+    xh = ((x - mean[:, None]) * rstd[:, None]).double()
+    dg64, db64 = (dy.double() * xh).sum(0), dy.double().sum(0)
+    for got in (a, c):
+        assert (got[1].double() - dg64).abs().max() < 1e-5 * rows ** 0.5 * 4
+        assert (got[2].double() - db64).abs().max() < 1e-5 * rows ** 0.5 * 4
+
+
 @pytest.mark.parametrize("B,Tp,C,V,sub,div", [(3, 40, 64, 31, 0, 1), (2, 25, 128, 140, 39, 4), (4, 16, 8, 16, 0, 1)])
 def test_batch_norm_over_the_data_rows_of_a_padded_time_axis(hip_device, B, Tp, C, V, sub, div):
     """pika_bn_valid_t: the matrix is B blocks of Tp rows of which the first (V - sub) // div hold data (V read on the
