@@ -63,8 +63,9 @@ SIGNATURES = {
     "pika_attention_mask_bits": (_i, [_vp, _i, _i, _vp, _vp]),
     # include/pika_ops.h
     "pika_transpose_cast": (_i, [_vp, _i, _i, _vp, _ll, _i, _vp]),
-    "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
-    "pika_colsum_bf16": (_i, [_vp, _ll, _i, _i, _vp, _vp]),
+    "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp]),
+    "pika_colsum_bf16": (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp]),
+    "pika_colsum_partial_floats": (_ll, [_i, _i]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
     # include/pika_las.h

@@ -109,10 +109,109 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ x
     }
 }
 
+// The same walk with EIGHT row-steps in flight and many more, shorter row chunks (64 rows: the launch of a 31808 x 512 bf16
+// matrix was 124 workgroups with 16 KB in flight each -- 34 us for 32 MB), the chunk's sums written side by side
+// (partials[chunk][cols]) for colsum_fold_kernel instead of added onto `out` with float atomics.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T *__restrict__ x, long long ld, int rows, int cols,
+                                                          int rows_per_block, float *__restrict__ partials) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float part[4][64 * VEC];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * VEC;
+    const int rbeg = blockIdx.y * rows_per_block, rend = min(rows, rbeg + rows_per_block);
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (c < cols) {
+        const T *col = x + c;
+        int r = rbeg + g;
+        for (; r + 28 < rend; r += 32) {
+            vec_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const vec_t *>(col + (long long)(r + 4 * q) * ld);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += (float)v[q][i];
+        }
+        for (; r < rend; r += 4) {
+            const vec_t v = *reinterpret_cast<const vec_t *>(col + (long long)r * ld);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += (float)v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) part[g][i * 64 + lane] = acc[i];
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        float *dst = partials + (long long)blockIdx.y * cols + c;
+#pragma unroll
+        for (int i = 0; i < VEC; i += 4) {
+            f4 t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                t[e] = (part[0][(i + e) * 64 + lane] + part[1][(i + e) * 64 + lane]) +
+                       (part[2][(i + e) * 64 + lane] + part[3][(i + e) * 64 + lane]);
+            *reinterpret_cast<f4 *>(dst + i) = t;
+        }
+    }
+}
+
+// out[c] = sum over the nb chunks of partials[chunk][c], 4 columns per lane: 16 groups of 64 lanes take the chunks round-robin
+// (4 loads in flight each), their sums meet in LDS in group order -- the same bits whatever the timing.  cols % 4 == 0.
+__global__ __launch_bounds__(1024) void colsum_fold_kernel(const float *__restrict__ partials, int nb, int cols,
+                                                           float *__restrict__ out) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ f4 red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, i = blockIdx.x * 64 + lane, c4 = cols >> 2;
+    f4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = f4{0.f, 0.f, 0.f, 0.f};
+    if (i < c4) {
+        int b = rg;
+        for (; b + 48 < nb; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += reinterpret_cast<const f4 *>(partials + (long long)(b + 16 * u) * cols)[i];
+        }
+        for (; b < nb; b += 16) a[0] += reinterpret_cast<const f4 *>(partials + (long long)b * cols)[i];
+    }
+    red[rg][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (rg == 0 && i < c4) {
+        f4 t = red[0][lane];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][lane];
+        reinterpret_cast<f4 *>(out)[i] = t;
+    }
+}
+
+inline int colsum_part_rows(int rows) {         // rows per chunk of the partials form: 64, more beyond 1024 chunks
+    int rpb = 64;
+    if ((rows + rpb - 1) / rpb > 1024) rpb = (((rows + 1023) / 1024) + 3) & ~3;
+    return rpb;
+}
+
 template <typename T>
-int colsum_impl(const T *x, long long ld, int rows, int cols, float *out, void *stream) {
+bool colsum_part_ok(const T *x, long long ld, int cols, const float *out, const float *partials) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    return partials && ld % VEC == 0 && cols % VEC == 0 &&
+           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(partials)) & 15) == 0;
+}
+
+template <typename T>
+int colsum_impl(const T *x, long long ld, int rows, int cols, float *out, float *partials, void *stream) {
     if (!x || !out || rows <= 0 || cols <= 0) return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (colsum_part_ok(x, ld, cols, out, partials)) {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        const int rpb = colsum_part_rows(rows), chunks = (rows + rpb - 1) / rpb;
+        hipLaunchKernelGGL((colsum_part_kernel<T, VEC>), dim3((cols + 64 * VEC - 1) / (64 * VEC), chunks), dim3(256), 0, s, x, ld,
+                           rows, cols, rpb, partials);
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols / 4 + 63) / 64), dim3(1024), 0, s, partials, chunks, cols, out);
+        return (int)hipGetLastError();
+    }
     hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -253,12 +352,18 @@ int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, lon
     return (int)hipGetLastError();
 }
 
-int pika_colsum(const float *x, long long ld, int rows, int cols, float *out, void *stream) {
-    return colsum_impl<float>(x, ld, rows, cols, out, stream);
+int pika_colsum(const float *x, long long ld, int rows, int cols, float *out, float *partials, void *stream) {
+    return colsum_impl<float>(x, ld, rows, cols, out, partials, stream);
 }
 
-int pika_colsum_bf16(const void *x, long long ld, int rows, int cols, float *out, void *stream) {
-    return colsum_impl<__bf16>(static_cast<const __bf16 *>(x), ld, rows, cols, out, stream);
+int pika_colsum_bf16(const void *x, long long ld, int rows, int cols, float *out, float *partials, void *stream) {
+    return colsum_impl<__bf16>(static_cast<const __bf16 *>(x), ld, rows, cols, out, partials, stream);
+}
+
+long long pika_colsum_partial_floats(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int rpb = colsum_part_rows(rows);
+    return (long long)((rows + rpb - 1) / rpb) * cols;
 }
 
 int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C, int taps,

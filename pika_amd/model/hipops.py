@@ -122,11 +122,19 @@ def transpose_cast(op, rows, K, device):
     return out
 
 
+def _colsum_into(out, ptr, ld, rows, cols, device, bf16):
+    """Column sums of a (rows, cols) matrix at `ptr` with pitch `ld` into `out`: chunk sums side by side in a scratch tensor,
+    folded by a second launch (include/pika_ops.h: no atomics, the same bits every time)."""
+    lib = _lib.lib()
+    part = torch.empty(int(lib.pika_colsum_partial_floats(rows, cols)), dtype=torch.float32, device=device)
+    fn = lib.pika_colsum_bf16 if bf16 else lib.pika_colsum
+    _lib.check(fn(ptr, ld, rows, cols, out.data_ptr(), part.data_ptr(), _stream()), "pika_colsum_bf16" if bf16 else "pika_colsum")
+    return out
+
+
 def colsum(x2d):
     out = torch.empty(x2d.shape[1], dtype=torch.float32, device=x2d.device)
-    _lib.check(_lib.lib().pika_colsum(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1],
-                                      out.data_ptr(), _stream()), "pika_colsum")
-    return out
+    return _colsum_into(out, x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1], x2d.device, False)
 
 
 def _bf16_operand(t, min_elems=1 << 21):
@@ -200,9 +208,7 @@ def colsum_any(x2d):
     if x2d.dtype == torch.float32:
         return colsum(x2d)
     out = torch.empty(x2d.shape[1], dtype=torch.float32, device=x2d.device)
-    _lib.check(_lib.lib().pika_colsum_bf16(x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1],
-                                           out.data_ptr(), _stream()), "pika_colsum_bf16")
-    return out
+    return _colsum_into(out, x2d.data_ptr(), x2d.stride(0), x2d.shape[0], x2d.shape[1], x2d.device, True)
 
 
 class LinearFn(torch.autograd.Function):
@@ -671,8 +677,7 @@ class JointOutFn(torch.autograd.Function):
                 db = db_fused           # column sums came out of the d(logits) kernel itself
             elif ctx.has_bias and ctx.needs_input_grad[2]:
                 db = torch.empty(N, dtype=torch.float32, device=dl.device)
-                _lib.check(_lib.lib().pika_colsum_bf16(dl.data_ptr(), Np, M, N, db.data_ptr(), _stream()),
-                           "pika_colsum_bf16")
+                _colsum_into(db, dl.data_ptr(), Np, M, N, dl.device, True)
         return dh, dw, db, None, None, None, None
 
 
@@ -1055,8 +1060,7 @@ class FeedForwardFn(torch.autograd.Function):
                 dw1 = _grad_weight(dh, G.matrix(xb)[0], 8, M, d, F)
             if ctx.needs_input_grad[2]:
                 db1 = torch.empty(F, dtype=torch.float32, device=dy.device)
-                _lib.check(_lib.lib().pika_colsum_bf16(dh.data_ptr(), F, M, F, db1.data_ptr(), _stream()),
-                           "pika_colsum_bf16")
+                _colsum_into(db1, dh.data_ptr(), F, M, F, dy.device, True)
             if ctx.needs_input_grad[0]:
                 w1t = w1.detach().t().contiguous().to(torch.bfloat16)
                 if ctx.x_bf16:

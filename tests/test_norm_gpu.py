@@ -146,3 +146,34 @@ def test_batch_norm_over_the_data_rows_of_a_padded_time_axis(hip_device, B, Tp, 
     with torch.no_grad():
         ref3.weight.copy_(ref.weight); ref3.bias.copy_(ref.bias)
     assert (y2[:, :vl2].reshape(-1, C) - ref3(x[:, :vl2].reshape(-1, C)).detach()).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("rows,cols,bf16", [(31808, 512, True), (31808, 2048, True), (7680, 1536, False), (3, 8, True),
+                                            (70001, 264, False), (257, 5001, True), (1000, 12, False)])
+def test_column_sums_with_and_without_the_scratch(hip_device, rows, cols, bf16):
+    """pika_colsum / pika_colsum_bf16 (bias gradients): chunk sums side by side + a fixed-order fold (the same bits on every
+    call) against the float-atomics form (partials NULL; also what odd widths fall back to) and float64."""
+    from pika_amd import _lib
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g)
+    x = (x.bfloat16() if bf16 else x).to(hip_device)
+    lib = _lib.lib()
+    fn = lib.pika_colsum_bf16 if bf16 else lib.pika_colsum
+    n = int(lib.pika_colsum_partial_floats(rows, cols))
+    assert n >= cols and n % cols == 0 and n // cols <= 1024
+
+    def run(with_scratch):
+        out = torch.full((cols,), 3.0, device=hip_device)
+        part = torch.empty(n, device=hip_device) if with_scratch else None
+        with torch.cuda.device(hip_device):
+            _lib.check(fn(x.data_ptr(), cols, rows, cols, out.data_ptr(), None if part is None else part.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream), "pika_colsum")
+        torch.cuda.synchronize()
+        return out
+    a, b, c = run(True), run(True), run(False)
+    ref = x.double().sum(0)
+    tol = 2e-6 * rows ** 0.5 * max(1.0, float(x.float().abs().max()))
+    assert (a.double() - ref).abs().max() < tol and (c.double() - ref).abs().max() < tol
+    if cols % (8 if bf16 else 4) == 0:
+        assert torch.equal(a, b)
+
