@@ -58,8 +58,10 @@ int pika_layer_norm_fwd(const float *x, long long rows, int C, const float *gamm
                         float eps, void *y, int y_dtype, void *y_lo, float *mean, float *rstd, void *stream);
 int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
                         const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
-                        float *partials, void *stream);
-/* partials: device scratch of pika_layer_norm_bwd_partial_floats(rows, C) floats (16-byte aligned), or NULL.  With it the
+                        float *partials, const float *dx_add, void *stream);
+/* dx_add: NULL, or (rows, C) f32 added to dx on the way out -- the gradient of the skip connection around the LN
+ * (transformer.py:95-99: out = drop(attn(LN(x))) + x), which autograd would otherwise add in a launch of its own.
+ * partials: device scratch of pika_layer_norm_bwd_partial_floats(rows, C) floats (16-byte aligned), or NULL.  With it the
  * workgroups of the backward write their column sums side by side and a second launch adds them up in a fixed order:
  * dgamma / dbeta do not depend on timing and cost no atomics (31808 x 512: 95 -> ~60 us); NULL = float atomics onto
  * dgamma / dbeta (which this call zeroes first). */

@@ -19,6 +19,11 @@ extern "C" {
 int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, long long ld_out,
                         int out_dtype, void *stream);
 
+/* out (C, taps * N) bf16, out[c][(taps - 1 - t) * N + n] = W[n][t * C + c] for W (N, taps * C) f32 contiguous: the weight
+ * operand of a layer's d(input) product -- the time-delay layers' transposed convolution (taps reversed;
+ * /root/reference/trainer/model/encoder/tdnn.py via nn.Conv1d's backward) and, at taps = 1, plain W^T -- in one launch. */
+int pika_weight_taps_transposed_bf16(const float *W, int N, int taps, int C, void *out, void *stream);
+
 /* out[c] = sum_r x[r][c]  (bias gradients).  x (rows, cols) f32 with pitch ld.
  * partials: device scratch of pika_colsum_partial_floats(rows, cols) floats (16-byte aligned) or NULL.  With it (and 16-byte
  * aligned x / out, ld and cols multiples of 4 f32 / 8 bf16) chunks of 64 rows are summed side by side and folded by a

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pika_colsum": (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp]),
     "pika_colsum_bf16": (_i, [_vp, _ll, _i, _i, _vp, _vp, _vp]),
     "pika_colsum_partial_floats": (_ll, [_i, _i]),
+    "pika_weight_taps_transposed_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
     # include/pika_las.h
@@ -98,7 +99,7 @@ SIGNATURES = {
     "pika_edit_distances": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     # include/pika_norm.h
     "pika_layer_norm_fwd": (_i, [_vp, _ll, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
-    "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pika_layer_norm_bwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pika_layer_norm_bwd_partial_floats": (_ll, [_ll, _i]),
     "pika_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp]),
     "pika_bn_apply": (_i, [_vp, _ll, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp,

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
                                                      const float *__restrict__ gamma, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
                                                      float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                     long long rows, int C, int rows_per_block) {
+                                                     long long rows, int C, int rows_per_block,
+                                                     const float *__restrict__ add) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c4 = C >> 2;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
@@ -306,7 +307,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TD *__restrict__ dy, 
 #pragma unroll
         for (int q = 0; q < LNQ; ++q) {
             const int i = lane + q * 64;
-            if (i < c4) reinterpret_cast<ln_f4 *>(dx + r * C)[i] = (g[q] - m1 - xh[q] * m2) * rs;
+            if (i < c4) {
+                ln_f4 v = (g[q] - m1 - xh[q] * m2) * rs;
+                if (add) v += reinterpret_cast<const ln_f4 *>(add + r * C)[i];      // the gradient of the skip connection around the LN
+                reinterpret_cast<ln_f4 *>(dx + r * C)[i] = v;
+            }
         }
     }
     __shared__ ln_f4 red[2][4][64];
@@ -486,11 +491,12 @@ long long pika_layer_norm_bwd_partial_floats(long long rows, int C) {
 
 int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long rows, int C, const float *gamma,
                         const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta,
-                        float *partials, void *stream) {
+                        float *partials, const float *dx_add, void *stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0) return PIKA_EINVAL;
     if ((C & 3) || C > 64 * 4 * LNQ_MAX) return PIKA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dx) |
-         reinterpret_cast<uintptr_t>(dgamma) | reinterpret_cast<uintptr_t>(dbeta) | reinterpret_cast<uintptr_t>(partials)) & 15)
+         reinterpret_cast<uintptr_t>(dgamma) | reinterpret_cast<uintptr_t>(dbeta) | reinterpret_cast<uintptr_t>(partials) |
+         reinterpret_cast<uintptr_t>(dx_add)) & 15)
         return PIKA_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!partials) {
@@ -503,8 +509,8 @@ int pika_layer_norm_bwd(const void *dy, int dy_dtype, const float *x, long long 
     // 8: 483 us, 16: 299, 32: 231, 64: 197, 128: 215, 256: 286 per backward)
     const int rpb = ln_bwd_rows_per_block(rows);
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-#define PIKA_LN_BWD(TD, Q) do { if (partials) hipLaunchKernelGGL((ln_bwd_kernel<TD, Q, true>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, partials, nullptr, rows, C, rpb); \
-                                else hipLaunchKernelGGL((ln_bwd_kernel<TD, Q, false>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb); } while (0)
+#define PIKA_LN_BWD(TD, Q) do { if (partials) hipLaunchKernelGGL((ln_bwd_kernel<TD, Q, true>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, partials, nullptr, rows, C, rpb, dx_add); \
+                                else hipLaunchKernelGGL((ln_bwd_kernel<TD, Q, false>), grid, dim3(256), 0, s, static_cast<const TD *>(dy), x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, rpb, dx_add); } while (0)
 #define PIKA_LN_BWD_Q(TD) do { if (C <= 512) PIKA_LN_BWD(TD, 2); else if (C <= 1024) PIKA_LN_BWD(TD, 4); else PIKA_LN_BWD(TD, 8); } while (0)
     if (dy_dtype == PIKA_F32 && !(reinterpret_cast<uintptr_t>(dy) & 15))
         PIKA_LN_BWD_Q(float);

@@ -109,6 +109,25 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T *__restrict__ x
     }
 }
 
+// out[c][(taps - 1 - t) * N + n] = bf16(W[n][t * C + c]): the weight operand of the transposed convolution / of a plain
+// d(input) product (taps = 1: W^T) in ONE launch -- torch's flip + permuted copy + cast were three (35 us per TDNN layer).
+// 32 x 32 tiles through LDS: reads coalesced along c, writes along n.  grid (ceil(C/32), ceil(N/32), taps), 256 threads.
+__global__ __launch_bounds__(256) void weight_taps_transposed_kernel(const float *__restrict__ W, int N, int taps, int C,
+                                                                     __bf16 *__restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, t = blockIdx.z;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const long long ldw = (long long)taps * C, ldo = (long long)taps * N;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8)
+        tile[j][tx] = (n0 + j < N && c0 + tx < C) ? W[(long long)(n0 + j) * ldw + (long long)t * C + c0 + tx] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && n0 + tx < N)
+            out[(long long)(c0 + j) * ldo + (long long)(taps - 1 - t) * N + n0 + tx] = (__bf16)tile[tx][j];
+}
+
 // The same walk with EIGHT row-steps in flight and many more, shorter row chunks (64 rows: the launch of a 31808 x 512 bf16
 // matrix was 124 workgroups with 16 KB in flight each -- 34 us for 32 MB), the chunk's sums written side by side
 // (partials[chunk][cols]) for colsum_fold_kernel instead of added onto `out` with float atomics.
@@ -349,6 +368,13 @@ int pika_transpose_cast(const pika_operand_t *X, int rows, int K, void *out, lon
                            static_cast<__bf16 *>(out), ld_out);
     else
         return PIKA_EINVAL;
+    return (int)hipGetLastError();
+}
+
+int pika_weight_taps_transposed_bf16(const float *W, int N, int taps, int C, void *out, void *stream) {
+    if (!W || !out || N <= 0 || taps <= 0 || C <= 0 || taps > 65535) return PIKA_EINVAL;
+    hipLaunchKernelGGL(weight_taps_transposed_kernel, dim3((C + 31) / 32, (N + 31) / 32, taps), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), W, N, taps, C, static_cast<__bf16 *>(out));
     return (int)hipGetLastError();
 }
 

@@ -122,6 +122,21 @@ def transpose_cast(op, rows, K, device):
     return out
 
 
+def weight_taps_transposed(w2d, taps=1):
+    """(C, taps * N) bf16 operand of a layer's d(input) product from its (N, taps * C) f32 weight: taps reversed and W^T per tap
+    (taps = 1: W^T), one launch (include/pika_ops.h) -- what `w.view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, -1)
+    .to(bfloat16)` computes in three."""
+    w = w2d.detach()
+    if not (w.is_contiguous() and w.dtype == torch.float32):
+        w = w.contiguous().float()
+    N, K = w.shape
+    C = K // taps
+    out = torch.empty((C, taps * N), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().pika_weight_taps_transposed_bf16(w.data_ptr(), N, taps, C, out.data_ptr(), _stream()),
+               "pika_weight_taps_transposed_bf16")
+    return out
+
+
 def _colsum_into(out, ptr, ld, rows, cols, device, bf16):
     """Column sums of a (rows, cols) matrix at `ptr` with pitch `ld` into `out`: chunk sums side by side in a scratch tensor,
     folded by a second launch (include/pika_ops.h: no atomics, the same bits every time)."""
@@ -300,7 +315,11 @@ class LayerNormFn(torch.autograd.Function):
     products, so it is produced (and its gradient accepted) in bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, out_bf16, out_pair=False):
+    def forward(ctx, x, weight, bias, eps, out_bf16, out_pair=False, with_skip=False):
+        """with_skip: x itself is returned as the LAST output (autograd makes it an alias whose gradient arrives in this
+        node's backward): the caller's skip connection around the LN then costs no gradient-accumulation launch -- the
+        backward kernel adds the skip's gradient to dx on the way out."""
+        ctx.with_skip = bool(with_skip)
         C = x.shape[-1]
         x2 = x.reshape(-1, C).contiguous()
         rows = x2.shape[0]
@@ -319,13 +338,20 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2, weight, mean, rstd)
         if out_pair:
             ctx.mark_non_differentiable(pair.lo)
-            return pair.hi, pair.lo
-        return y
+            return (pair.hi, pair.lo, x) if with_skip else (pair.hi, pair.lo)
+        return (y, x) if with_skip else y
 
     @staticmethod
-    def backward(ctx, dy, *_):
+    def backward(ctx, dy, *rest):
         x2, weight, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
+        dskip = rest[-1] if (ctx.with_skip and rest) else None
+        if dy is None:                  # only the skip connection reached the loss
+            return dskip, None, None, None, None, None, None
+        if dskip is not None:
+            dskip = dskip.reshape(rows, C)
+            if dskip.dtype != torch.float32 or not dskip.is_contiguous():
+                dskip = dskip.float().contiguous()
         if dy.dtype not in (torch.float32, torch.bfloat16):
             dy = dy.float()
         dy = dy.contiguous()
@@ -338,8 +364,8 @@ class LayerNormFn(torch.autograd.Function):
             _lib.check(_lib.lib().pika_layer_norm_bwd(
                 dy.data_ptr(), G.PIKA_F32 if dy.dtype == torch.float32 else G.PIKA_BF16, x2.data_ptr(), rows, C,
                 weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                part.data_ptr(), _stream()), "pika_layer_norm_bwd")
-        return dx, dg, db, None, None, None
+                part.data_ptr(), None if dskip is None else dskip.data_ptr(), _stream()), "pika_layer_norm_bwd")
+        return dx, dg, db, None, None, None, None
 
 
 class TimeDelayFn(torch.autograd.Function):
@@ -396,8 +422,7 @@ class TimeDelayFn(torch.autograd.Function):
                 # dx[b,ti,c] = sum_{tap',n} dY[b, ti + tap'*dil - pad', n] * W[n, (taps-1-tap')*C + c],
                 # pad' = (taps-1)*dil - pad; rows outside [0,t_out) read as zeros.  No (M, taps*C) column
                 # gradient, no col2im pass.
-                wrev = (w2d.detach().view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, taps * N)
-                        .to(torch.bfloat16))
+                wrev = weight_taps_transposed(w2d, taps)
                 a_op = G.Operand(dyb.data_ptr(), G.PIKA_BF16, T, t_out, t_out * N, N, N, 1, dil,
                                  (taps - 1) * dil - pad, 0, 0)
                 dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -1048,7 +1073,7 @@ class FeedForwardFn(torch.autograd.Function):
         dyb = _mask_cast(dy2, p2, seed2) if has_res else dy2.to(torch.bfloat16)
         thr = round(p_drop * 65536)
         dh = torch.empty((M, F), dtype=torch.bfloat16, device=dy.device)
-        _gemm_epilogue(dyb, w2.detach().t().contiguous().to(torch.bfloat16), dh, None, EPI_MASK_BF16, aux=h,
+        _gemm_epilogue(dyb, weight_taps_transposed(w2), dh, None, EPI_MASK_BF16, aux=h,
                        scale=65536.0 / (65536 - thr))
         dx = dw1 = db1 = dw2 = db2 = None
         with torch.cuda.device(dy.device):
@@ -1062,7 +1087,7 @@ class FeedForwardFn(torch.autograd.Function):
                 db1 = torch.empty(F, dtype=torch.float32, device=dy.device)
                 _colsum_into(db1, dh.data_ptr(), F, M, F, dy.device, True)
             if ctx.needs_input_grad[0]:
-                w1t = w1.detach().t().contiguous().to(torch.bfloat16)
+                w1t = weight_taps_transposed(w1)
                 if ctx.x_bf16:
                     dx = torch.empty(xshape, dtype=torch.bfloat16, device=dy.device)
                     _gemm_epilogue(dh, w1t, dx.view(-1, d), None, EPI_DROPOUT_BF16)
@@ -1234,8 +1259,7 @@ class TdnnBnFn(torch.autograd.Function):
                           and ((Bn * T + 255) // 256) * ((C + 255) // 256) >= 160)
                 dx = torch.empty(xb.shape, dtype=torch.bfloat16 if direct else torch.float32, device=dout.device)
                 if stride == 1 and N % 64 == 0:
-                    wrev = (w2d.detach().view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, taps * N)
-                            .to(torch.bfloat16))
+                    wrev = weight_taps_transposed(w2d, taps)
                     a_op = G.Operand(dyb.data_ptr(), G.PIKA_BF16, T, t_out, t_out * N, N, N, 1, dil,
                                      (taps - 1) * dil - pad, 0, 0)
                     G.launch(a_op, G.matrix(wrev)[0], dx.view(-1, C), C, Bn * T, C, taps * N)

@@ -19,8 +19,8 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         if ops.feed_forward_applies(x, self.w_1, self.w_2):
-            return ops.feed_forward(ops.layer_norm(x, self.layer_norm, mfma_only=True), self.w_1, self.w_2,
-                                    self.dropout_1.p if self.training else 0.0, residual=x,
+            n, skip = ops.layer_norm(x, self.layer_norm, mfma_only=True, with_skip=True)
+            return ops.feed_forward(n, self.w_1, self.w_2, self.dropout_1.p if self.training else 0.0, residual=skip,
                                     p_residual=self.dropout_2.p if self.training else 0.0)
         h = ops.linear(ops.layer_norm(x, self.layer_norm), self.w_1.weight, self.w_1.bias, relu=1)
         h = ops.dropout(h, self.dropout_1.p, self.training)
@@ -101,10 +101,10 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, inputs, mask):
         packed = ops.self_attention_packed_ok(inputs, self.self_attn.head_count, mask)
-        n = ops.layer_norm(inputs, self.layer_norm, mfma_only=packed)
+        n, skip = ops.layer_norm(inputs, self.layer_norm, mfma_only=packed, with_skip=True)
         if packed:   # residual dropout + add folded into the output projection
-            out, _ = self.self_attn(n, n, n, mask=mask, type="self", residual=inputs,
+            out, _ = self.self_attn(n, n, n, mask=mask, type="self", residual=skip,
                                     residual_dropout=self.dropout.p if self.training else 0.0)
             return self.feed_forward(out)
         ctx, _ = self.self_attn(n, n, n, mask=mask, type="self")
-        return self.feed_forward(ops.dropout(ctx, self.dropout.p, self.training) + inputs)
+        return self.feed_forward(ops.dropout(ctx, self.dropout.p, self.training) + skip)

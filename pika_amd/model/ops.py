@@ -215,16 +215,23 @@ def _bn_momentum(bn):
     return 0.0 if bn.momentum is None else bn.momentum
 
 
-def layer_norm(x, ln, mfma_only=False):
+def layer_norm(x, ln, mfma_only=False, with_skip=False):
     """nn.LayerNorm over the last dim.  mfma_only: every consumer of the result is an MFMA product
-    (projection / feed-forward GEMMs), so in the bf16 arithmetic mode it is produced in bf16."""
+    (projection / feed-forward GEMMs), so in the bf16 arithmetic mode it is produced in bf16.
+    with_skip: returns (LN(x), x') where x' is x for the caller's skip connection around the LN -- on the HIP path an alias
+    whose gradient is added to the LN's input gradient inside the backward kernel (hipops.LayerNormFn)."""
     C = x.shape[-1]
     if (_hip(x) and x.dtype == torch.float32 and len(ln.normalized_shape) == 1 and ln.weight is not None
             and ln.bias is not None and C % 4 == 0 and C <= 2048):
         from .hipops import LayerNormFn
         narrow = bool(mfma_only and _bf16_mode() and C % 64 == 0)
-        return _pair(LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, narrow, narrow and _mixed()))
-    return F.layer_norm(x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+        if with_skip and x.requires_grad and torch.is_grad_enabled():
+            ret = LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, narrow, narrow and _mixed(), True)
+            return _pair(ret[:-1] if len(ret) > 2 else ret[0]), ret[-1]
+        y = _pair(LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps, narrow, narrow and _mixed()))
+        return (y, x) if with_skip else y
+    y = F.layer_norm(x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+    return (y, x) if with_skip else y
 
 
 def dropout(x, p, training):

@@ -87,7 +87,7 @@ def test_layer_norm_backward_parameter_gradients_with_and_without_the_scratch(hi
         with torch.cuda.device(hip_device):
             _lib.check(lib.pika_layer_norm_bwd(dy.data_ptr(), G.PIKA_BF16, x.data_ptr(), rows, C, w.data_ptr(), mean.data_ptr(),
                                                rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                               None if part is None else part.data_ptr(),
+                                               None if part is None else part.data_ptr(), None,
                                                torch.cuda.current_stream().cuda_stream), "pika_layer_norm_bwd")
         torch.cuda.synchronize()
         return dx, dg, db
@@ -176,4 +176,58 @@ def test_column_sums_with_and_without_the_scratch(hip_device, rows, cols, bf16):
     assert (a.double() - ref).abs().max() < tol and (c.double() - ref).abs().max() < tol
     if cols % (8 if bf16 else 4) == 0:
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,taps,C", [(512, 3, 1024), (1536, 1, 512), (64, 5, 100), (33, 2, 7), (2048, 1, 1024)])
+def test_weight_operand_of_the_input_gradient_product_in_one_launch(hip_device, N, taps, C):
+    """pika_weight_taps_transposed_bf16 == flip(taps) + per-tap transpose + bf16 cast as torch computes them."""
+    from pika_amd.model.hipops import weight_taps_transposed
+    w = torch.randn(N, taps * C, generator=torch.Generator().manual_seed(N + C)).to(hip_device)
+    want = w.view(N, taps, C).flip(1).permute(2, 1, 0).reshape(C, taps * N).to(torch.bfloat16)
+    with torch.cuda.device(hip_device):
+        got = weight_taps_transposed(w, taps)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_layer_norm_with_the_skip_connection_gradient_added_in_the_backward_kernel(hip_device, bf16):
+    """ops.layer_norm(..., with_skip=True): (LN(x), x') with x' an alias of x whose gradient reaches the LN node -- the sum
+    d(LN)/dx + d(skip) is formed inside pika_layer_norm_bwd (dx_add), not by an accumulation launch.  Against autograd over
+    the plain formulation in float64, and with only one of the two outputs used."""
+    from pika_amd.model import ops
+    rows, C = 300, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, rows // 2, C, generator=g)
+    ln = torch.nn.LayerNorm(C, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g)); ln.bias.copy_(torch.randn(C, generator=g))
+    gy, gs = torch.randn(2, rows // 2, C, generator=g), torch.randn(2, rows // 2, C, generator=g)
+    if bf16:
+        gy = gy.bfloat16().float()
+    ref_ln = torch.nn.LayerNorm(C, eps=1e-6).double()
+    ref_ln.load_state_dict(ln.state_dict())
+    for use_y, use_s in ((True, True), (True, False), (False, True)):
+        xr = x.double().requires_grad_(True)
+        loss = 0
+        if use_y:
+            loss = loss + (ref_ln(xr) * gy.double()).sum()
+        if use_s:
+            loss = loss + (xr * gs.double()).sum()
+        ref_ln.zero_grad()
+        loss.backward()
+        dev_ln = torch.nn.LayerNorm(C, eps=1e-6).to(hip_device)
+        dev_ln.load_state_dict(ln.state_dict())
+        xd = x.to(hip_device).requires_grad_(True)
+        y, skip = ops.layer_norm(xd, dev_ln, with_skip=True)
+        assert skip.data_ptr() == xd.data_ptr() and skip.grad_fn is not None
+        loss = 0
+        if use_y:
+            yy = y.bfloat16() if bf16 else y
+            loss = loss + (yy * gy.to(hip_device).to(yy.dtype)).sum()
+        if use_s:
+            loss = loss + (skip * gs.to(hip_device)).sum()
+        loss.backward()
+        assert (xd.grad.double().cpu() - xr.grad).abs().max() < (3e-2 if bf16 else 2e-5) * max(1.0, float(xr.grad.abs().max()))
+        if use_y:
+            assert (dev_ln.weight.grad.double().cpu() - ref_ln.weight.grad).abs().max() < 2e-4 * rows ** 0.5
 

@@ -23,7 +23,7 @@ for rows, C in ((31808, 512), (31808, 1024), (7680, 512), (1632, 512)):
 
     def call(p):
         _lib.check(lib.pika_layer_norm_bwd(dy.data_ptr(), G.PIKA_BF16, x.data_ptr(), rows, C, w.data_ptr(), mean.data_ptr(),
-                                           rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), p, st), "ln_bwd")
+                                           rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), p, None, st), "ln_bwd")
     out = []
     for p in (None, part.data_ptr()):
         for _ in range(5):
