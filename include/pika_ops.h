@@ -72,6 +72,17 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
 int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
                           int role, int n_terms, int layout, int Cp, void *dst, void *stream);
 
+/* The splits of BOTH operands of one product in a single launch (same n_terms and layout; the fields are the arguments of
+ * pika_split_bf16_terms): a weight's split is otherwise a launch of ~5 us of its own, 56 of them in a train step. */
+typedef struct {
+    const float *x;
+    int n_batch, t_in, C;
+    long long batch_stride, ld;
+    int role, n_terms, layout, Cp;
+    void *dst;
+} pika_split_job_t;
+int pika_split_bf16_terms2(const pika_split_job_t *a, const pika_split_job_t *b, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pika_weight_taps_transposed_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pika_col2im": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pika_split_bf16_terms": (_i, [_vp, _i, _i, _i, _ll, _ll, _i, _i, _i, _i, _vp, _vp]),
+    "pika_split_bf16_terms2": (_i, [_vp, _vp, _vp]),
     # include/pika_las.h
     "pika_lstm_cell": (_i, [_vp, _ll, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp]),
     "pika_las_attention_work_floats": (ctypes.c_size_t, [_i, _i, _i]),

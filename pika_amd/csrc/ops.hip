@@ -272,15 +272,19 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ d
 // t2 = bf16(x - t0 - t1) (exact: 8 + 8 + 8 mantissa bits) and writes the NSEG 16-byte segments of its granule, segment s
 // holding term (pattern >> 2s) & 3.  seg_stride = elements between consecutive segments of one source element; pad
 // columns [C, Cp) of the concat layout are zero-filled by the threads that own them.
+struct SplitJob {
+    const float *x; int t_in, C, Cp; long long batch_stride, ld; unsigned pattern;
+    long long seg_stride, dst_batch, dst_ld, n_gran; __bf16 *dst; int f16_role;
+};
+
 template <int NSEG>
-__global__ __launch_bounds__(256) void split_terms_kernel(const float *__restrict__ x, int t_in, int C, int Cp,
-                                                          long long batch_stride, long long ld, unsigned pattern,
-                                                          long long seg_stride, long long dst_batch,
-                                                          long long dst_ld, long long n_gran,
-                                                          __bf16 *__restrict__ dst, int f16_role) {
+__device__ inline void split_terms_body(const float *__restrict__ x, int t_in, int C, int Cp,
+                                        long long batch_stride, long long ld, unsigned pattern,
+                                        long long seg_stride, long long dst_batch,
+                                        long long dst_ld, long long n_gran,
+                                        __bf16 *__restrict__ dst, int f16_role, long long g) {
     typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_gran) return;
     const int gpr = Cp >> 3;                       // granules per destination row
     const long long row = g / gpr;
@@ -338,6 +342,60 @@ __global__ __launch_bounds__(256) void split_terms_kernel(const float *__restric
         const unsigned k = (pattern >> (2 * s2)) & 3u;
         *reinterpret_cast<bf8 *>(o + s2 * seg_stride) = k == 0 ? term[0] : (k == 1 ? term[1] : term[2]);
     }
+}
+
+template <int NSEG>
+__global__ __launch_bounds__(256) void split_terms_kernel(const float *__restrict__ x, int t_in, int C, int Cp,
+                                                          long long batch_stride, long long ld, unsigned pattern,
+                                                          long long seg_stride, long long dst_batch,
+                                                          long long dst_ld, long long n_gran,
+                                                          __bf16 *__restrict__ dst, int f16_role) {
+    split_terms_body<NSEG>(x, t_in, C, Cp, batch_stride, ld, pattern, seg_stride, dst_batch, dst_ld, n_gran, dst, f16_role,
+                           (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// BOTH operands of a K-concatenated product in one launch (a weight's split is a 5-us launch of its own otherwise, 56 of
+// them in a train step): the first blocks_a workgroups take job a, the rest job b.
+template <int NSEG>
+__global__ __launch_bounds__(256) void split_terms2_kernel(SplitJob a, SplitJob b, unsigned blocks_a) {
+    if (blockIdx.x < blocks_a)
+        split_terms_body<NSEG>(a.x, a.t_in, a.C, a.Cp, a.batch_stride, a.ld, a.pattern, a.seg_stride, a.dst_batch, a.dst_ld,
+                               a.n_gran, a.dst, a.f16_role, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+    else
+        split_terms_body<NSEG>(b.x, b.t_in, b.C, b.Cp, b.batch_stride, b.ld, b.pattern, b.seg_stride, b.dst_batch, b.dst_ld,
+                               b.n_gran, b.dst, b.f16_role, (long long)(blockIdx.x - blocks_a) * blockDim.x + threadIdx.x);
+}
+
+// argument checks + derived quantities of one split (pika_split_bf16_terms); nseg out
+int make_split_job(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld, int role, int n_terms,
+                   int layout, int Cp, void *dst, SplitJob &j, int &nseg) {
+    if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
+    if (n_terms != 2 && n_terms != 3 && n_terms != 4) return PIKA_EINVAL;
+    if (n_terms == 4 && layout == PIKA_SPLIT_STACK) return PIKA_EINVAL;
+    if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK && layout != PIKA_SPLIT_PAIR) return PIKA_EINVAL;
+    if (layout == PIKA_SPLIT_PAIR && n_terms != 2 && n_terms != 4) return PIKA_EINVAL;
+    if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
+        return PIKA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) return PIKA_EINVAL;
+    const long long rows = (long long)n_batch * t_in;
+    const long long n_gran = rows * (Cp >> 3);
+    if ((n_gran + 255) / 256 > 0x3fffffffLL) return PIKA_ETOOBIG;
+    nseg = layout == PIKA_SPLIT_PAIR ? 2 : (n_terms == 3 ? 6 : 3);
+    const int f16_role = n_terms == 4 ? (layout == PIKA_SPLIT_PAIR ? 3 : 1 + role) : 0;
+    long long seg_stride, dst_batch, dst_ld;
+    if (layout == PIKA_SPLIT_PAIR) { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
+    else if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
+    else { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
+    // term index per segment, two bits each (segment 0 in the low bits); the pairs (A side, B side) of one segment
+    // are the products kept: two terms  h.h + l.h + h.l;  three terms  h.h + h.m + m.h + h.l + l.h + m.m
+    static const unsigned pat[2][2] = {{0u | 1u << 2 | 0u << 4, 0u | 0u << 2 | 1u << 4},
+                                       {0u | 0u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 1u << 10,
+                                        0u | 1u << 2 | 0u << 4 | 2u << 6 | 0u << 8 | 1u << 10}};
+    const unsigned pattern = layout == PIKA_SPLIT_PAIR ? (0u | 1u << 2)
+                             : (n_terms == 4 ? (0u | 1u << 2 | 2u << 4) : pat[n_terms - 2][role]);
+    j = SplitJob{x, t_in, C, Cp, batch_stride, ld, pattern, seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst),
+                 f16_role};
+    return 0;
 }
 
 }  // namespace
@@ -405,41 +463,39 @@ int pika_col2im(const float *dcol, float *dx, int B, int t_out, int t_in, int C,
 
 int pika_split_bf16_terms(const float *x, int n_batch, int t_in, int C, long long batch_stride, long long ld,
                           int role, int n_terms, int layout, int Cp, void *dst, void *stream) {
-    if (!x || !dst || n_batch <= 0 || t_in <= 0 || C <= 0 || (role != 0 && role != 1)) return PIKA_EINVAL;
-    if (n_terms != 2 && n_terms != 3 && n_terms != 4) return PIKA_EINVAL;
-    if (n_terms == 4 && layout == PIKA_SPLIT_STACK) return PIKA_EINVAL;
-    if (layout != PIKA_SPLIT_CONCAT && layout != PIKA_SPLIT_STACK && layout != PIKA_SPLIT_PAIR) return PIKA_EINVAL;
-    if (layout == PIKA_SPLIT_PAIR && n_terms != 2 && n_terms != 4) return PIKA_EINVAL;
-    if ((C & 7) || (ld & 3) || (batch_stride & 3) || Cp < C || (Cp & 7) || (layout == PIKA_SPLIT_STACK && Cp != C))
-        return PIKA_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dst)) & 15) return PIKA_EINVAL;
-    const long long rows = (long long)n_batch * t_in;
-    const long long n_gran = rows * (Cp >> 3);
-    if ((n_gran + 255) / 256 > 0x7fffffffLL) return PIKA_ETOOBIG;
-    const int nseg = layout == PIKA_SPLIT_PAIR ? 2 : (n_terms == 3 ? 6 : 3);
-    const int f16_role = n_terms == 4 ? (layout == PIKA_SPLIT_PAIR ? 3 : 1 + role) : 0;
-    long long seg_stride, dst_batch, dst_ld;
-    if (layout == PIKA_SPLIT_PAIR) { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
-    else if (layout == PIKA_SPLIT_CONCAT) { dst_ld = (long long)nseg * Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = Cp; }
-    else { dst_ld = Cp; dst_batch = (long long)t_in * dst_ld; seg_stride = rows * dst_ld; }
-    // term index per segment, two bits each (segment 0 in the low bits); the pairs (A side, B side) of one segment
-    // are the products kept: two terms  h.h + l.h + h.l;  three terms  h.h + h.m + m.h + h.l + l.h + m.m
-    static const unsigned pat[2][2] = {{0u | 1u << 2 | 0u << 4, 0u | 0u << 2 | 1u << 4},
-                                       {0u | 0u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 1u << 10,
-                                        0u | 1u << 2 | 0u << 4 | 2u << 6 | 0u << 8 | 1u << 10}};
-    const unsigned pattern = layout == PIKA_SPLIT_PAIR ? (0u | 1u << 2)
-                             : (n_terms == 4 ? (0u | 1u << 2 | 2u << 4) : pat[n_terms - 2][role]);
-    const dim3 grid((unsigned)((n_gran + 255) / 256));
+    SplitJob j;
+    int nseg = 0;
+    const int rc = make_split_job(x, n_batch, t_in, C, batch_stride, ld, role, n_terms, layout, Cp, dst, j, nseg);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((j.n_gran + 255) / 256));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (nseg == 2)
-        hipLaunchKernelGGL(split_terms_kernel<2>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
-                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst), f16_role);
+        hipLaunchKernelGGL(split_terms_kernel<2>, grid, dim3(256), 0, s, j.x, j.t_in, j.C, j.Cp, j.batch_stride, j.ld, j.pattern,
+                           j.seg_stride, j.dst_batch, j.dst_ld, j.n_gran, j.dst, j.f16_role);
     else if (nseg == 3)
-        hipLaunchKernelGGL(split_terms_kernel<3>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
-                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst), f16_role);
+        hipLaunchKernelGGL(split_terms_kernel<3>, grid, dim3(256), 0, s, j.x, j.t_in, j.C, j.Cp, j.batch_stride, j.ld, j.pattern,
+                           j.seg_stride, j.dst_batch, j.dst_ld, j.n_gran, j.dst, j.f16_role);
     else
-        hipLaunchKernelGGL(split_terms_kernel<6>, grid, dim3(256), 0, s, x, t_in, C, Cp, batch_stride, ld, pattern,
-                           seg_stride, dst_batch, dst_ld, n_gran, static_cast<__bf16 *>(dst), f16_role);
+        hipLaunchKernelGGL(split_terms_kernel<6>, grid, dim3(256), 0, s, j.x, j.t_in, j.C, j.Cp, j.batch_stride, j.ld, j.pattern,
+                           j.seg_stride, j.dst_batch, j.dst_ld, j.n_gran, j.dst, j.f16_role);
+    return (int)hipGetLastError();
+}
+
+int pika_split_bf16_terms2(const pika_split_job_t *a, const pika_split_job_t *b, void *stream) {
+    if (!a || !b || a->n_terms != b->n_terms || a->layout != b->layout) return PIKA_EINVAL;
+    SplitJob ja, jb;
+    int na = 0, nb = 0;
+    int rc = make_split_job(a->x, a->n_batch, a->t_in, a->C, a->batch_stride, a->ld, a->role, a->n_terms, a->layout, a->Cp,
+                            a->dst, ja, na);
+    if (!rc) rc = make_split_job(b->x, b->n_batch, b->t_in, b->C, b->batch_stride, b->ld, b->role, b->n_terms, b->layout, b->Cp,
+                                 b->dst, jb, nb);
+    if (rc) return rc;
+    if (na != nb) return PIKA_EINVAL;
+    const unsigned ga = (unsigned)((ja.n_gran + 255) / 256), gb = (unsigned)((jb.n_gran + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (na == 2) hipLaunchKernelGGL(split_terms2_kernel<2>, dim3(ga + gb), dim3(256), 0, s, ja, jb, ga);
+    else if (na == 3) hipLaunchKernelGGL(split_terms2_kernel<3>, dim3(ga + gb), dim3(256), 0, s, ja, jb, ga);
+    else hipLaunchKernelGGL(split_terms2_kernel<6>, dim3(ga + gb), dim3(256), 0, s, ja, jb, ga);
     return (int)hipGetLastError();
 }
 

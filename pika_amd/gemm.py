@@ -130,16 +130,39 @@ def _pad64(n):
     return (n + 63) & ~63
 
 
-def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_terms=2):
+class SplitJob(ctypes.Structure):
+    """pika_split_job_t (include/pika_ops.h)"""
+    _fields_ = [("x", ctypes.c_void_p), ("n_batch", ctypes.c_int), ("t_in", ctypes.c_int), ("C", ctypes.c_int),
+                ("batch_stride", ctypes.c_longlong), ("ld", ctypes.c_longlong), ("role", ctypes.c_int),
+                ("n_terms", ctypes.c_int), ("layout", ctypes.c_int), ("Cp", ctypes.c_int), ("dst", ctypes.c_void_p)]
+
+
+def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_terms=2, pending=None):
     """bf16 term-segment copy of an f32 source (pika_split_bf16_terms: 3 segments for two terms, 6 for three);
-    returns the tensor (flat)."""
+    returns the tensor (flat).  pending (a list): the launch is left to `_split_flush`, which sends the two operands of a
+    product as ONE launch."""
     rows = n_batch * t_in
     nseg = 6 if n_terms == 3 else 3
     dst = torch.empty(nseg * rows * Cp, dtype=torch.bfloat16, device=device)
+    if pending is not None:
+        pending.append(SplitJob(op.ptr, n_batch, t_in, C, batch_stride, ld, role, n_terms, layout, Cp, dst.data_ptr()))
+        return dst
     rc = _lib.lib().pika_split_bf16_terms(op.ptr, n_batch, t_in, C, batch_stride, ld, role, n_terms, layout, Cp,
                                           dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "pika_split_bf16_terms")
     return dst
+
+
+def _split_flush(pending):
+    st = torch.cuda.current_stream().cuda_stream
+    lib = _lib.lib()
+    if len(pending) == 2:
+        _lib.check(lib.pika_split_bf16_terms2(ctypes.byref(pending[0]), ctypes.byref(pending[1]), st), "pika_split_bf16_terms2")
+    else:
+        for j in pending:
+            _lib.check(lib.pika_split_bf16_terms(j.x, j.n_batch, j.t_in, j.C, j.batch_stride, j.ld, j.role, j.n_terms, j.layout,
+                                                 j.Cp, j.dst, st), "pika_split_bf16_terms")
+    del pending[:]
 
 
 def _plain(op, K):
@@ -188,11 +211,11 @@ def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):
         if seg & 7 or K % seg:
             return None
         taps, Cp = K // seg, _pad64(seg)
-        ops, keep = [], []
+        ops, keep, pending = [], [], []
         for op, extent, role in ((a_op, M, 0), (b_op, N, 1)):
             if op.C < K or taps == 1:       # the time-delay view itself, or a plain matrix with one segment per row
                 nb = (extent + op.rows_per_batch - 1) // op.rows_per_batch
-                t = _split(op, nb, op.t_in, seg, op.batch_stride, op.ld, role, 0, Cp, device, n_terms)
+                t = _split(op, nb, op.t_in, seg, op.batch_stride, op.ld, role, 0, Cp, device, n_terms, pending)
                 # one block: batch stride 0 like every plain matrix (the direct-to-LDS kernel bounds its 32-bit row
                 # offsets by rows_per_tile * pitch + batch stride)
                 new = Operand(t.data_ptr(), PIKA_BF16, op.rows_per_batch, op.t_in, op.t_in * S * Cp if nb > 1 else 0,
@@ -201,22 +224,21 @@ def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):
                     new.C = S * Cp * taps
             else:                           # plain (rows, taps*seg) matrix against a time-delay view: per-tap segments
                 if op.ld != K or not _plain(op, K):
-                    return None
-                t = _split(op, 1, extent * taps, seg, 0, seg, role, 0, Cp, device, n_terms)
+                    return None                     # (a first operand's pending split is dropped with it)
+                t = _split(op, 1, extent * taps, seg, 0, seg, role, 0, Cp, device, n_terms, pending)
                 rows = max(extent, 1)
                 new = Operand(t.data_ptr(), PIKA_BF16, rows, rows, 0, taps * S * Cp, taps * S * Cp, 1, 0, 0, 0, 0)
             ops.append(new)
             keep.append(t)
+        _split_flush(pending)
         return ops[0], ops[1], taps * S * Cp, keep
     # `trans` operands (dW = dY^T X): the reduction runs over the rows -> the three segments are stacked row blocks
-    ops, keep = [], []
+    ops, keep, pending = [], [], []
     for op, extent, role in ((a_op, M, 0), (b_op, N, 1)):
-        if op.C & 7 or extent & 7 or op.pad:
-            return None
         nb = (K + op.rows_per_batch - 1) // op.rows_per_batch
-        if nb * op.rows_per_batch != K:
+        if op.C & 7 or extent & 7 or op.pad or nb * op.rows_per_batch != K:
             return None
-        t = _split(op, nb, op.t_in, op.C, op.batch_stride, op.ld, role, 1, op.C, device, n_terms)
+        t = _split(op, nb, op.t_in, op.C, op.batch_stride, op.ld, role, 1, op.C, device, n_terms, pending)
         if nb == 1 and op.t_in == op.rows_per_batch:    # one block: the stack is one plain (S*R, C) matrix
             new = Operand(t.data_ptr(), PIKA_BF16, S * K, S * K, 0, op.C, op.C, op.stride, op.dil, 0, 0, 0)
         else:
@@ -225,6 +247,7 @@ def _bf16x3_operands(a_op, b_op, M, N, K, device, n_terms=2):
         new.trans = 1
         ops.append(new)
         keep.append(t)
+    _split_flush(pending)
     return ops[0], ops[1], S * K, keep
 
 

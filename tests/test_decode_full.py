@@ -77,7 +77,8 @@ def check(got, enc, z, enc_tol, exact, ranks=True, last_rank_strict=True):
     # MI355X (tools/diag_decode_attn.py): max |score - reference| 1.3e-3 .. 1.5e-3 in the fp32-grade modes, whatever the
     # encoder's attention runs on (exact torch chain: 1.46e-3, encoder output 3.9e-6 off; fused two-fp16-term kernel:
     # 1.29e-3, 4.4e-6 off): two entries 1.05e-3 apart in the reference list can and do trade places.
-    gap, n_same, n_sep = (1e-4 if exact else 1.5e-3), 0, 0
+    # (a foreign host's CPU run gets the same separation: its noise was 1e-5 on one GPU box's host and > 1e-4 on another's)
+    gap, n_same, n_sep = 1.5e-3, 0, 0
     B, nb = z["lens"].shape
     for b in range(B):
         assert same_entry(got, z, b, 0), "top-1 hypothesis of utterance %d differs" % b
@@ -168,7 +169,14 @@ def _host_matches_golden():
 
 
 def test_cpu_full_width_decode_matches_reference():
-    got, enc, _ = decode("cpu")
+    # (at most the 8 threads of the machine the golden was recorded on: with 256 threads torch's CPU products block their
+    #  reductions differently and near-ties of the search can swap)
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(n, 8))
+    try:
+        got, enc, _ = decode("cpu")
+    finally:
+        torch.set_num_threads(n)
     check(got, enc, np.load(GOLD), 1e-4, exact=True)
 
 
