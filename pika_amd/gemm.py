@@ -154,6 +154,8 @@ def _split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_t
 
 
 def _split_flush(pending):
+    if not pending:
+        return
     st = torch.cuda.current_stream().cuda_stream
     lib = _lib.lib()
     if len(pending) == 2:

@@ -56,7 +56,7 @@ PATTERNS = {2: ((0, 1, 0), (0, 0, 1)), 3: ((0, 0, 1, 0, 2, 1), (0, 1, 0, 2, 0, 1
 
 
 def fake_split(mem):
-    def split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_terms=2):
+    def split(op, n_batch, t_in, C, batch_stride, ld, role, layout, Cp, device, n_terms=2, pending=None):
         src = mem.bufs[op.ptr]
         x = np.zeros((n_batch, t_in, C))
         for b in range(n_batch):
