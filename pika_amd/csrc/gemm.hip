@@ -223,6 +223,14 @@ struct Loader {
     }
 };
 
+#ifdef PIKA_NT_TRACE      // profiling builds only (tools/nt_trace.py): time stamps (100 MHz) of workgroup 0's first lane, last launch
+__device__ unsigned long long g_nt_trace[64];
+#define NT_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (k) < 64) \
+    g_nt_trace[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NT_STAMP(k) do { } while (0)
+#endif
+
 template <typename TA, typename TB, int NS, typename CF, bool TRA, bool TRB>
 __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
     Op A, Op B, long long a_zo, long long a_zi, long long b_zo, long long b_zi,
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / CF::WN, wn = wave % CF::WN;
 
+    NT_STAMP(0);
     LA la;
     LB lb;
     const int nk_all = (K + BK - 1) / BK;
@@ -273,12 +282,15 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    NT_STAMP(1);
     f32x4 ra[LA::NP], rb[LB::NP];
     la.load(ra);
     lb.load(rb);
     la.template stage<NS>(lds, TA_ELEMS, ra);
     lb.template stage<NS>(lds + BOFF, TB_ELEMS, rb);
+    NT_STAMP(2);
     __syncthreads();
+    NT_STAMP(3);
 
     for (int kb = 0; kb < nk; ++kb) {
         const __bf16 *cur = lds + (kb & 1) * PER_BUF;
@@ -290,6 +302,7 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
             la.load(ra);
             lb.load(rb);
         }
+        NT_STAMP(4 + 4 * kb);
         // split products kept: (0,0) [NS=1]; + (0,1),(1,0),(1,1),(0,2),(2,0) [NS=3]: every term
         // above 2^-24 of the leading one
         constexpr int NPAIR = NS == 1 ? 1 : 6;
@@ -311,12 +324,16 @@ __global__ __launch_bounds__(CF::THREADS) void gemm_nt_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             }
         }
+        NT_STAMP(5 + 4 * kb);
         if (more) {
             la.template stage<NS>(nxt, TA_ELEMS, ra);
             lb.template stage<NS>(nxt + BOFF, TB_ELEMS, rb);
         }
+        NT_STAMP(6 + 4 * kb);
         __syncthreads();
+        NT_STAMP(7 + 4 * kb);
     }
+    NT_STAMP(62);
 
     // epilogue: lane holds C[m][n..n+3], m = tile row (lane&15), n = (lane>>4)*4
     float *Cz = Cp + zo * c_zo + zi * c_zi;
@@ -492,6 +509,12 @@ int dispatch_trans(const pika_operand_t *A, const pika_operand_t *B, float *C, l
 int pika_internal_gemm_pp(const pika_operand_t *A, const pika_operand_t *B, float *C, long long ldc,
                           int M, int N, int K, const float *bias, int flags, void *ws, size_t ws_bytes,
                           hipStream_t s);
+
+#ifdef PIKA_NT_TRACE
+extern "C" int pika_debug_nt_trace(unsigned long long *out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_nt_trace), sizeof(g_nt_trace));
+}
+#endif
 
 extern "C" int pika_gemm_nt(const pika_operand_t *A, const pika_operand_t *B, float *C,
                             long long ldc, long long c_z_outer, long long c_z_inner, int M, int N,
