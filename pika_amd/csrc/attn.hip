@@ -45,14 +45,18 @@ __device__ inline bool keep(uint32_t rowh, uint32_t key, uint32_t thr) {
 }
 // keep bits of keys kb*64 .. kb*64+63 of one (b,h,query) row
 __device__ inline uint64_t keep_word(uint32_t rowh, uint32_t kb, uint32_t thr) {
-    uint64_t w = 0;
+    // (the word's two halves in 32-bit registers: assembling 64 bits with 64-bit shifts and ors was more work than the hashes)
+    uint32_t half[2] = {0u, 0u};
+#pragma unroll
+    for (uint32_t hw = 0; hw < 2; ++hw) {
 #pragma unroll 8
-    for (uint32_t j = 0; j < 32; ++j) {
-        const uint32_t h = mix32(rowh ^ ((kb * 32 + j) * 0x85ebca6bu));
-        w |= (uint64_t)((h & 0xffffu) >= thr) << (2 * j);
-        w |= (uint64_t)((h >> 16) >= thr) << (2 * j + 1);
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t h = mix32(rowh ^ ((kb * 32 + hw * 16 + j) * 0x85ebca6bu));
+            half[hw] |= (uint32_t)((h & 0xffffu) >= thr) << (2 * j);
+            half[hw] |= (uint32_t)((h >> 16) >= thr) << (2 * j + 1);
+        }
     }
-    return w;
+    return (uint64_t)half[0] | ((uint64_t)half[1] << 32);
 }
 
 __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
